@@ -1,0 +1,101 @@
+"""Deterministic synthetic inputs at the reference's real shapes.
+
+No weights or datasets exist for the reference here, so every workload is synthetic: descriptors
+are `3*(base + 0.3*eps)` so the diagonal logit (after the reference's `0.1/sqrt(D)` factor,
+/root/reference/models/first_layer.py:110-114) beats the dustbin marginal, target areas follow the
+reference's scale head `exp(sigmoid(x)*ln256 - ln256/2)` (/root/reference/models/first_layer.py:106).
+All draws come from numpy's PCG64 `default_rng(seed)` in float32, in a fixed order, so goldens,
+tests and bench.py regenerate identical tensors (fixtures additionally store an input checksum).
+Seed 18027 is the reference configs' seed (/root/reference/configs/test_megadepth.yaml `seed`).
+"""
+import math
+
+import numpy as np
+
+SEED = 18027
+LN256 = math.log(256.0)
+
+
+def _scale_head(rng, shape, spread=0.3):
+    x = spread * rng.standard_normal(shape, dtype=np.float32)
+    sig = 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    return np.exp(sig * LN256 - LN256 / 2).astype(np.float32)
+
+
+def _desc_pair(rng, shape, amp=3.0, noise=0.3, drop=0.0):
+    base = rng.standard_normal(shape, dtype=np.float32)
+    e0 = rng.standard_normal(shape, dtype=np.float32)
+    e1 = rng.standard_normal(shape, dtype=np.float32)
+    d0 = (amp * (base + noise * e0)).astype(np.float32)
+    d1 = (amp * (base + noise * e1)).astype(np.float32)
+    if drop > 0.0:
+        # "dropped" source patches have no counterpart: their descriptor is fresh noise, so the
+        # transport sends them to the dustbin (exercises the no-match paths downstream)
+        fresh = rng.standard_normal(shape, dtype=np.float32)
+        gone = rng.random((shape[0], 1, shape[2])) < drop
+        d0 = np.where(gone, (amp * 1.04 * fresh).astype(np.float32), d0)
+    return d0, d1
+
+
+def coarse_inputs(seed=SEED, h=15, w=20, D=448, b=1):
+    """L1 (a1,a4): mdesc0/mdesc1 [b,D,N], ns [b,1,N] target areas, alpha = |bin_score| (0-d)."""
+    rng = np.random.default_rng(seed)
+    n = h * w
+    d0, d1 = _desc_pair(rng, (b, D, n))
+    ns = _scale_head(rng, (b, 1, n))
+    alpha = np.float32(0.0)
+    return {"d0": d0, "d1": d1, "ns": ns, "alpha": alpha, "h": h, "w": w}
+
+
+def fine_inputs(seed=SEED + 1, B=6, D=264, n=145):
+    """L2 (a2,a5): mdesc [B,D,145] (last column = dustbin feature), scale_x, scale_y [B,1,144]."""
+    rng = np.random.default_rng(seed)
+    d0, d1 = _desc_pair(rng, (B, D, n), drop=0.12)
+    # keep the dustbin feature column moderate so both matches and non-matches occur
+    d0[:, :, -1] *= 0.5
+    d1[:, :, -1] *= 0.5
+    sx = _scale_head(rng, (B, 1, n - 1))
+    sy = _scale_head(rng, (B, 1, n - 1))
+    return {"d0": d0, "d1": d1, "scale_x": sx, "scale_y": sy}
+
+
+def third_inputs(seed=SEED + 2, P=32, D=128, W=8):
+    """L3 (a3,a5,a17): feat [P,128,65], scale [P,1,64], coarse points p_s,p_t [P,2] (multiples of 4)."""
+    rng = np.random.default_rng(seed)
+    n = W * W + 1
+    d0, d1 = _desc_pair(rng, (P, D, n), drop=0.12)
+    d0[:, :, -1] *= 0.5
+    d1[:, :, -1] *= 0.5
+    scale = _scale_head(rng, (P, 1, n - 1))
+    p_s = (rng.integers(1, 23, size=(P, 2)) * 4).astype(np.int64)
+    p_t = (rng.integers(0, 25, size=(P, 2)) * 4).astype(np.int64)
+    return {"d0": d0, "d1": d1, "scale": scale, "p_s": p_s, "p_t": p_t}
+
+
+def image_pair(seed=SEED + 3, H=480, W=640):
+    """Two uint8-valued HWC images as float32 [1,H,W,3] (what evaluate.py hands to the model)."""
+    rng = np.random.default_rng(seed)
+    left = rng.integers(0, 256, size=(1, H, W, 3)).astype(np.float32)
+    right = rng.integers(0, 256, size=(1, H, W, 3)).astype(np.float32)
+    # smooth a little along x so bilinear taps are not pure noise
+    right = (0.5 * right + 0.5 * np.roll(right, 1, axis=2)).astype(np.float32)
+    return left, right
+
+
+def roofline_inputs(seed=SEED + 4, N=4096, D=448):
+    """Config 5: d0,d1 ~ N(0,1) [1,D,N], ns ~ U(0.5,2) [1,1,N]."""
+    rng = np.random.default_rng(seed)
+    d0 = rng.standard_normal((1, D, N), dtype=np.float32)
+    d1 = rng.standard_normal((1, D, N), dtype=np.float32)
+    ns = rng.uniform(0.5, 2.0, size=(1, 1, N)).astype(np.float32)
+    return {"d0": d0, "d1": d1, "ns": ns, "alpha": np.float32(1.0)}
+
+
+def checksum(*arrays):
+    """Order-sensitive float64 checksum used to prove regenerated inputs equal the fixture's."""
+    acc = 0.0
+    for k, a in enumerate(arrays):
+        a = np.ascontiguousarray(a).astype(np.float64).ravel()
+        idx = np.arange(1, a.size + 1, dtype=np.float64)
+        acc += (k + 1) * float(np.dot(a, np.cos(idx * 0.37)))
+    return acc

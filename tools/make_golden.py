@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (this container only).
+
+TEST INFRASTRUCTURE.  Imports /root/reference through tools/ref_import.py (torch CPU), feeds it
+the deterministic inputs of pats_amd/synth.py and stores inputs' checksums + the reference's
+outputs as small fixtures.  The fixtures are data; no reference source is copied.
+Re-run:  python tools/make_golden.py   (needs /root/reference and oracle/_ref built).
+
+What each fixture pins (reference file:line):
+  ot_kat.npz       log_optimal_transport / log_optimal_transport2 known answers
+                   (models/modules.py:145-182; values quoted in SURVEY.md section 8c)
+  sinkhorn_raw.npz log_sinkhorn_iterations on a ragged 2x21x23 problem (models/modules.py:137-143)
+  ot_ties.npz      exact column duplicates -> argmax first-index tie-break (first_layer.py:162)
+  coarse_301.npz   L1: cost einsum, OT, column mass, est_position, Iterative_expand_matrix,
+                   split_patches, Compute_imgs/tensor_resize (first_layer.py:110-146,159-178;
+                   utils/utils.py:152-181,1179-1393; setup/library.cpp:47-66)
+  coarse_portrait.npz  same expansion on a 20x15 grid (the height/width swap quirk, utils.py:1181)
+  coarse_769.npz   YFCC-sized L1 (24x32 grid): argmax, marginals, sampled Z
+  fine_145.npz     L2: cost, log_optimal_transport2, dustbin bias ln2, est_position(8 iters)
+                   (second_layer.py:100-116,240-259)
+  fine_145_indoor.npz  L2 with ln3 bias
+  third_65.npz     L3: cost, OT2, Compute_result, outdoor label (third_layer.py:156-170,184-217)
+  third_65_indoor.npz  indoor label rule
+  resize_small.npz tensor_resize edge cases (1-pixel crops, borders) (setup/library.cpp:47-66)
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from pats_amd import synth  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+T = torch.from_numpy
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print("%-24s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def sample_idx(rng, shape, k=1024):
+    flat = rng.choice(int(np.prod(shape)), size=min(k, int(np.prod(shape))), replace=False)
+    return np.sort(flat).astype(np.int64)
+
+
+def cost(d0, d1, D):
+    """The forward-body expression of first_layer.py:110-111,114 / second_layer.py:100-101,104 /
+    third_layer.py:156-158, re-executed verbatim on synthetic tensors."""
+    scores = torch.einsum('bdn,bdm->bnm', d0, d1)
+    scores = scores / D ** .5
+    return 0.1 * scores
+
+
+def gen_kat(R):
+    s1 = torch.tensor([[[1., 0., -1.], [0., 2., .5]]])
+    a1 = torch.tensor(.5)
+    n1 = torch.tensor([[[1., 2., .5]]])
+    z1 = R.M.log_optimal_transport(s1, a1, n1, 100)
+    s2 = torch.tensor([[[1., 0., .2], [0., 2., .1], [.3, .3, 0.]]])
+    n2 = torch.tensor([[[2., .5]]])
+    z2 = R.M.log_optimal_transport2(s2, torch.tensor(1.0), n2, 100)
+    save("ot_kat.npz", s1=s1, a1=a1, n1=n1, z1=z1, s2=s2, n2=n2, z2=z2)
+
+
+def gen_sinkhorn_raw(R):
+    rng = np.random.default_rng(synth.SEED + 10)
+    Z = (2.0 * rng.standard_normal((2, 21, 23), dtype=np.float32))
+    mu = rng.uniform(0.5, 2.0, (2, 21)).astype(np.float32)
+    nu = rng.uniform(0.5, 2.0, (2, 23)).astype(np.float32)
+    nu *= (mu.sum(1, keepdims=True) / nu.sum(1, keepdims=True))
+    log_mu, log_nu = np.log(mu), np.log(nu)
+    outs = {}
+    for it in (1, 3, 100):
+        outs["out%d" % it] = R.M.log_sinkhorn_iterations(T(Z), T(log_mu), T(log_nu), it)
+    save("sinkhorn_raw.npz", Z=Z, log_mu=log_mu, log_nu=log_nu, **outs)
+
+
+def gen_ties(R):
+    rng = np.random.default_rng(synth.SEED + 11)
+    s = rng.standard_normal((1, 12, 12), dtype=np.float32)
+    s[0, :, 7] = s[0, :, 3]          # duplicate columns -> exactly tied Z columns
+    s[0, 9, :] = s[0, 2, :]          # duplicate rows    -> exactly tied Z rows
+    s[0, 5, 3] = s[0, 5, 7] = 6.0    # make the tie the row maximum
+    s[0, 2, 4] = s[0, 9, 4] = 6.0    # make the tie the column maximum
+    ns = np.ones((1, 1, 12), np.float32)
+    ns[0, 0, 7] = ns[0, 0, 3] = 1.5
+    z = R.M.log_optimal_transport(T(s), torch.tensor(0.25), T(ns), 100)
+    save("ot_ties.npz", s=s, ns=ns, alpha=np.float32(0.25), z=z,
+         max0=z.max(2).indices, max1=z.max(1).indices)
+
+
+def run_coarse(R, inp, H, W, name, full=True, with_imgs=True):
+    h, w = inp["h"], inp["w"]
+    d0, d1, ns = T(inp["d0"]), T(inp["d1"]), T(inp["ns"])
+    D = d0.shape[1]
+    S = cost(d0, d1, D)
+    Z = R.M.log_optimal_transport(S, torch.tensor(float(inp["alpha"])), ns, 100)
+    scales = torch.sqrt(Z[:, :-1, :-1].exp().sum(1) + 1e-8)          # first_layer.py:117-118
+    trust, pts, xs, ys, ifn1, ifn2 = R.L1.FirstLayer.est_position(None, Z, scales, (H, W), 32)
+    # the same call est_position makes (first_layer.py:173-175), to also pin core_cost and bound
+    positions, ranges = R.U.Compute_positions_and_ranges(H // 32, W // 32, 'cpu')
+    lim = torch.tensor([0, H // 32, 0, W // 32])
+    sc = scales.reshape(scales.shape[0], -1, 1)
+    whole, core, avg, xs2, ys2, bound = R.U.Iterative_expand_matrix(
+        Z.exp(), sc, sc, lim, ranges, positions, height=H // 32, width=W // 32,
+        iter_num=15, lower_bound=1e-5)
+    assert torch.equal(whole, trust) and torch.equal(avg, pts)
+    rng = np.random.default_rng(1)
+    sidx = sample_idx(rng, S.shape)
+    out = dict(in_checksum=synth.checksum(inp["d0"], inp["d1"], inp["ns"]),
+               H=H, W=W, S_idx=sidx, S_val=S.reshape(-1)[T(sidx)],
+               scales=scales, max0=Z.max(2).indices[:, :-1], max1=Z.max(1).indices[:, :-1],
+               ifn1=ifn1, ifn2=ifn2, whole_cost=whole, core_cost=core, average_point=avg,
+               x_scale=xs, y_scale=ys, bound=bound,
+               row_mass=Z.exp().sum(2), col_mass=Z.exp().sum(1))
+    if full:
+        out["Z"] = Z
+    else:
+        zi = sample_idx(rng, Z.shape, 4096)
+        out["Z_idx"], out["Z_val"] = zi, Z.reshape(-1)[T(zi)]
+    # split_patches (utils.py:152-181) on the cumsum the caller builds (first_layer.py:130)
+    sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1)
+    for cap in (w * 2, 512, 100):
+        cyc, second, third = R.U.split_patches(sum_cycle[0], h, w, cap)
+        out["split%d_cycle" % cap] = np.int64(cyc)
+        out["split%d_second" % cap] = np.array([[int(a), int(b)] for a, b in second], np.int64)
+        out["split%d_third" % cap] = np.array([[int(a), int(b)] for a, b in third], np.int64)
+    if with_imgs:
+        left, right = synth.image_pair(H=H, W=W)
+        out["img_checksum"] = synth.checksum(left, right)
+        nl, nr, xsn, ysn, avgn = R.U.Compute_imgs(xs, ys, pts, ifn1, T(left), T(right),
+                                                  width=w, height=h)
+        K = nr.shape[0]
+        pick = np.unique(np.linspace(0, K - 1, 8).astype(np.int64))
+        out.update(K=np.int64(K), x_scale_new=xsn, y_scale_new=ysn, average_new=avgn,
+                   crop_pick=pick, right_pick=nr[T(pick)], left_pick=nl[T(pick)][:, ::4, ::4],
+                   right_sum=nr.double().sum((1, 2, 3)), left_sum=nl.double().sum((1, 2, 3)),
+                   right_wsum=(nr.double() * torch.arange(96 * 96 * 3).reshape(96, 96, 3)).sum((1, 2, 3)))
+        # the exact bound tensor handed to the native module (utils.py:1380-1381), recomputed by
+        # the same expressions so the gather kernel can be pinned in isolation
+        captured = {}
+        orig = R.U.tensor_resize.tensor_resize
+
+        def spy(src, bnd):
+            captured["bound"] = bnd.clone()
+            captured["src_shape"] = np.array(src.shape, np.int64)
+            return orig(src, bnd)
+        R.U.tensor_resize = types.SimpleNamespace(tensor_resize=spy)
+        try:
+            R.U.Compute_imgs(xs, ys, pts, ifn1, T(left), T(right), width=w, height=h)
+        finally:
+            R.U.tensor_resize = types.SimpleNamespace(tensor_resize=orig)
+        out["resize_bound"] = captured["bound"]
+        out["resize_src_shape"] = captured["src_shape"]
+    save(name, **out)
+    return Z
+
+
+def gen_fine(R, name, B, outdoor, seed):
+    inp = synth.fine_inputs(seed=seed, B=B)
+    d0, d1 = T(inp["d0"]), T(inp["d1"])
+    sx, sy = T(inp["scale_x"]), T(inp["scale_y"])
+    S = cost(d0, d1, 264)
+    one = torch.tensor(1.0)
+    Z0 = R.M.log_optimal_transport2(S, one, sx * sy, 100)
+    Z = Z0.clone()
+    bias = torch.log(one * 2) if outdoor else torch.log(one * 3)   # second_layer.py:107-112
+    Z[:, :, -1] += bias
+    Z[:, -1, :] += bias
+    trust, pts, xs, ys, ifn1, ifn2 = R.L2.SecondLayer.est_position(None, Z, sx, sy, [96, 96], 8)
+    positions, ranges = R.U.Compute_positions_and_ranges(12, 12, 'cpu')
+    whole, core, avg, xs2, ys2, bound = R.U.Iterative_expand_matrix(
+        Z.exp(), sx.reshape(B, -1, 1), sy.reshape(B, -1, 1), torch.tensor([0, 12, 0, 12]),
+        ranges, positions, height=12, width=12, iter_num=8, lower_bound=1e-3)
+    assert torch.equal(whole, trust)
+    rng = np.random.default_rng(2)
+    sidx = sample_idx(rng, S.shape)
+    save(name, in_checksum=synth.checksum(inp["d0"], inp["d1"], inp["scale_x"], inp["scale_y"]),
+         B=np.int64(B), outdoor=np.int64(outdoor), seed=np.int64(seed),
+         S_idx=sidx, S_val=S.reshape(-1)[T(sidx)], Z=Z,
+         max0=Z.max(2).indices[:, :-1], max1=Z.max(1).indices[:, :-1], ifn1=ifn1, ifn2=ifn2,
+         whole_cost=whole, core_cost=core, average_point=avg, x_scale=xs, y_scale=ys, bound=bound,
+         row_mass=Z0.exp().sum(2), col_mass=Z0.exp().sum(1))
+
+
+def gen_third(R, name, P, outdoor, seed):
+    inp = synth.third_inputs(seed=seed, P=P)
+    d0, d1, scale = T(inp["d0"]), T(inp["d1"]), T(inp["scale"])
+    p_s, p_t = T(inp["p_s"]), T(inp["p_t"])
+    S = cost(d0, d1, 128)
+    one = torch.tensor(1.0)
+    Zo = R.M.log_optimal_transport2(S, one, scale, 100)           # third_layer.py:158
+    scores = torch.exp(Zo)
+    scale_x = (scale + 1e-8).sqrt()                               # third_layer.py:153-154
+    scale_y = (scale + 1e-8).sqrt()
+    ns = types.SimpleNamespace(pad=torch.nn.ZeroPad2d(2), pad_1=torch.nn.ConstantPad2d(2, 1e-2))
+    m0, m1, wl = R.L3.ThirdLayer.Compute_result(ns, scores, 8, 5, scale_x, scale_y, p_s, p_t, 'cpu')
+    # label rule, third_layer.py:161-170, re-executed verbatim
+    Wd = 8
+    label = ((torch.zeros_like(p_t[:, None, :].expand(-1, 16, -1).float())) + 1e8).reshape(-1, 2)
+    if not outdoor:
+        ar = torch.arange(label.shape[0])
+        select1 = torch.logical_or(ar % 16 == 5, ar % 16 == 15)
+        select2 = torch.logical_or(ar % 16 == 7, ar % 16 == 13)
+        select = torch.logical_or(select1, select2)
+        label[:, 0] = torch.where(select, label[:, 0], torch.tensor(-10.0))
+    scores_used = scores[:, :-1, :].reshape(scores.shape[0], Wd, Wd, -1)[:, 2:6, 2:6, :] \
+        .reshape(scores.shape[0], 16, -1) + 1e-8
+    if_matching1 = (scores_used.max(2)[1] != Wd ** 2)
+    if outdoor:
+        label[:, 0] = torch.where(if_matching1.reshape(-1), label[:, 0], torch.tensor(-10.0))
+    rng = np.random.default_rng(3)
+    sidx = sample_idx(rng, S.shape)
+    save(name, in_checksum=synth.checksum(inp["d0"], inp["d1"], inp["scale"]),
+         P=np.int64(P), outdoor=np.int64(outdoor), seed=np.int64(seed),
+         S_idx=sidx, S_val=S.reshape(-1)[T(sidx)], Z=Zo,
+         mkpts0_f=m0, mkpts1_f=m1, whole_loss=wl, label=label, if_matching1=if_matching1,
+         max0=scores[:, :-1, :-1].max(2)[1])
+
+
+def gen_resize_small(R):
+    rng = np.random.default_rng(synth.SEED + 12)
+    src = rng.uniform(0, 255, (2, 3, 40, 50)).astype(np.float32)
+    bound = np.array([
+        [0, 40, 0, 49, 0],          # whole image 0   (rows [0,40), cols [0,49])
+        [5, 6, 7, 7, 3],            # 1x1 crop
+        [10, 11, 0, 49, 10007],     # 1 pixel high, image 1
+        [0, 40, 20, 20, 10001],     # 1 pixel wide
+        [3, 30, 4, 44, 20],         # generic downscale... 27 rows x 41 cols -> upsample
+        [38, 40, 47, 49, 19999],    # bottom-right corner, image 1
+        [12, 19, 13, 21, 5],        # small crop (7x9), strong upsample
+    ], np.int64)
+    out = R.tensor_resize.tensor_resize(T(src), T(bound))
+    save("resize_small.npz", src=src, bound=bound, out=out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = ref_import.load()
+    gen_kat(R)
+    gen_sinkhorn_raw(R)
+    gen_ties(R)
+    run_coarse(R, synth.coarse_inputs(), 480, 640, "coarse_301.npz")
+    run_coarse(R, synth.coarse_inputs(seed=synth.SEED + 20, h=20, w=15), 640, 480,
+               "coarse_portrait.npz", full=True, with_imgs=False)
+    run_coarse(R, synth.coarse_inputs(seed=synth.SEED + 21, h=24, w=32), 768, 1024,
+               "coarse_769.npz", full=False, with_imgs=False)
+    gen_fine(R, "fine_145.npz", 6, True, synth.SEED + 1)
+    gen_fine(R, "fine_145_indoor.npz", 2, False, synth.SEED + 31)
+    gen_third(R, "third_65.npz", 32, True, synth.SEED + 2)
+    gen_third(R, "third_65_indoor.npz", 8, False, synth.SEED + 32)
+    gen_resize_small(R)
+
+
+if __name__ == "__main__":
+    main()
