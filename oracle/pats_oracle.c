@@ -1,0 +1,671 @@
+/*
+ * pats_oracle.c - CPU restatement of the PATS patch-area optimal-transport hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may call this; the product path (pats_amd/, libpats_amd.so) never does.
+ *
+ * Every function restates one piece of the reference algorithm in scalar fp32 C and cites the
+ * reference file:line it follows (paths relative to /root/reference).  It is pinned against
+ * tests/golden/ (.npz fixtures produced by running the reference's own Python / C++ in the build
+ * container, tools/make_golden.py) by tests/test_oracle_golden.py.
+ *
+ * Numerics: values are fp32 like the reference (torch CPU fp32).  Reductions whose order ATen
+ * leaves unspecified (logsumexp's sum, einsum/bmm dot products, .sum()) are accumulated in double
+ * and rounded once to fp32 - the closest representable answer to what any fp32 summation order
+ * approximates.  Index results (argmax, bounds, chunk plans) are exact integer arithmetic with
+ * ATen-CPU's first-index tie-break.
+ *
+ * OpenMP is used only across independent problems (batch dimension) so the same code serves as
+ * the bench's CPU baseline ("port") on the GPU box's host cores.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ZERO_F 1e-14f /* `zero = scores.new_tensor(1e-14)`, utils/utils.py:1201 */
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a1-a3  cost build.  scores = einsum('bdn,bdm->bnm', d0, d1) / D**.5 ; then 0.1 * scores
+ * models/first_layer.py:110-111,114  second_layer.py:100-101,104  third_layer.py:156-158
+ * d0 [b,D,n], d1 [b,D,m] channel-major -> out [b,n,m]
+ * ---------------------------------------------------------------------------------------- */
+void oracle_cost(const float* d0, const float* d1, int64_t b, int D, int n, int m, float* out) {
+    const float sq = (float)sqrt((double)D); /* `D ** .5` is a Python double, cast to fp32 by ATen */
+#pragma omp parallel for schedule(static)
+    for (int64_t bi = 0; bi < b; ++bi) {
+        const float* a = d0 + bi * (int64_t)D * n;
+        const float* c = d1 + bi * (int64_t)D * m;
+        float* o = out + bi * (int64_t)n * m;
+        double* acc = (double*)malloc(sizeof(double) * (size_t)m);
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < m; ++j) acc[j] = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double av = a[(int64_t)d * n + i];
+                const float* crow = c + (int64_t)d * m;
+                for (int j = 0; j < m; ++j) acc[j] += av * (double)crow[j];
+            }
+            for (int j = 0; j < m; ++j) {
+                float s = (float)acc[j];
+                s = s / sq;
+                o[(int64_t)i * m + j] = 0.1f * s;
+            }
+        }
+        free(acc);
+    }
+}
+
+/* torch.logsumexp over a strided vector of x[k] + add[k]  (ATen: amax, masked_fill(inf->0),
+ * log(sum(exp(x - max))) + max) */
+static inline float lse_strided(const float* x, int64_t xs, const float* add, int len) {
+    float mx = -INFINITY;
+    for (int k = 0; k < len; ++k) {
+        float t = x[k * xs] + add[k];
+        if (t > mx) mx = t;
+    }
+    float msub = isinf(mx) ? 0.0f : mx;
+    double s = 0.0;
+    for (int k = 0; k < len; ++k) {
+        float t = x[k * xs] + add[k];
+        s += (double)expf(t - msub);
+    }
+    return logf((float)s) + msub;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a6  log_sinkhorn_iterations, models/modules.py:137-143
+ *   u = v = 0;  iters x { u = log_mu - lse_j(Z + v);  v = log_nu - lse_i(Z + u) };  Z + u + v
+ * Z [b,M,N], log_mu [b,M], log_nu [b,N] -> out [b,M,N].  If sub_norm != NULL, out -= norm[b]
+ * (the `Z - norm` of modules.py:161,181).
+ * ---------------------------------------------------------------------------------------- */
+static void sinkhorn_one(const float* Z, int M, int N, const float* log_mu, const float* log_nu,
+                         int iters, float* out, const float* sub_norm) {
+    float* u = (float*)calloc((size_t)M, sizeof(float));
+    float* v = (float*)calloc((size_t)N, sizeof(float));
+    for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < M; ++i) u[i] = log_mu[i] - lse_strided(Z + (int64_t)i * N, 1, v, N);
+        for (int j = 0; j < N; ++j) v[j] = log_nu[j] - lse_strided(Z + j, N, u, M);
+    }
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            float z = (Z[(int64_t)i * N + j] + u[i]) + v[j];
+            if (sub_norm) z = z - *sub_norm;
+            out[(int64_t)i * N + j] = z;
+        }
+    free(u);
+    free(v);
+}
+
+void oracle_sinkhorn(const float* Z, int64_t b, int M, int N, const float* log_mu,
+                     const float* log_nu, int iters, float* out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t bi = 0; bi < b; ++bi)
+        sinkhorn_one(Z + bi * (int64_t)M * N, M, N, log_mu + bi * M, log_nu + bi * N, iters,
+                     out + bi * (int64_t)M * N, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4  log_optimal_transport, models/modules.py:145-162
+ * scores [b,m,n], alpha scalar, ns [b,1,n] -> Z [b,m+1,n+1]
+ * ---------------------------------------------------------------------------------------- */
+void oracle_log_optimal_transport(const float* scores, int64_t b, int m, int n, float alpha,
+                                  const float* ns, int iters, float* out) {
+    const int M = m + 1, N = n + 1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t bi = 0; bi < b; ++bi) {
+        const float* S = scores + bi * (int64_t)m * n;
+        const float* nsb = ns + bi * (int64_t)n;
+        float* C = (float*)malloc(sizeof(float) * (size_t)M * N);
+        float* log_mu = (float*)malloc(sizeof(float) * (size_t)M);
+        float* log_nu = (float*)malloc(sizeof(float) * (size_t)N);
+        /* couplings = [[scores, alpha],[alpha, alpha]]  (modules.py:152-156) */
+        for (int i = 0; i < m; ++i) {
+            memcpy(C + (int64_t)i * N, S + (int64_t)i * n, sizeof(float) * (size_t)n);
+            C[(int64_t)i * N + n] = alpha;
+        }
+        for (int j = 0; j < N; ++j) C[(int64_t)m * N + j] = alpha;
+        /* norm = -log(ms + sum(ns))  (modules.py:157) */
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += (double)nsb[j];
+        const float ns_sum = (float)acc;
+        const float ms = (float)m;
+        const float norm = -logf(ms + ns_sum);
+        for (int j = 0; j < n; ++j) log_nu[j] = logf(nsb[j]) + norm; /* modules.py:158 */
+        log_nu[n] = logf(ms) + norm;
+        for (int i = 0; i < m; ++i) log_mu[i] = norm;                /* modules.py:159 */
+        log_mu[m] = logf(ns_sum) + norm;
+        sinkhorn_one(C, M, N, log_mu, log_nu, iters, out + bi * (int64_t)M * N, &norm);
+        free(C);
+        free(log_mu);
+        free(log_nu);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a5  log_optimal_transport2, models/modules.py:165-182
+ * scores [b,m,n] (last row/col = dustbin already), one = 1.0, ns [b,1,n-1] -> Z [b,m,n]
+ * ---------------------------------------------------------------------------------------- */
+void oracle_log_optimal_transport2(const float* scores, int64_t b, int m, int n, float one,
+                                   const float* ns, int iters, float* out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t bi = 0; bi < b; ++bi) {
+        const float* S = scores + bi * (int64_t)m * n;
+        const float* nsb = ns + bi * (int64_t)(n - 1);
+        float* log_mu = (float*)malloc(sizeof(float) * (size_t)m);
+        float* log_nu = (float*)malloc(sizeof(float) * (size_t)n);
+        const float ms = (float)(m - 1) * one;                       /* modules.py:169 */
+        double acc = 0.0;
+        for (int j = 0; j < n - 1; ++j) acc += (double)nsb[j];
+        const float ns_sum = (float)acc;
+        const float norm = -logf(ms + ns_sum);                       /* modules.py:176 */
+        for (int j = 0; j < n - 1; ++j) log_nu[j] = logf(nsb[j]) + norm;
+        log_nu[n - 1] = logf(ms) + norm;                             /* modules.py:178 */
+        for (int i = 0; i < m - 1; ++i) log_mu[i] = norm;            /* modules.py:179 */
+        log_mu[m - 1] = logf(ns_sum) + norm;
+        sinkhorn_one(S, m, n, log_mu, log_nu, iters, out + bi * (int64_t)m * n, &norm);
+        free(log_mu);
+        free(log_nu);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a7  post-OT reductions.
+ *   colmass: scales = sqrt(exp(Z[:, :-1, :-1]).sum(1) + 1e-8)   first_layer.py:117-118
+ *   bias:    Z[:, :, -1] += log(k); Z[:, -1, :] += log(k)       second_layer.py:107-112
+ *            (the corner gets it twice, as in the reference)
+ * ---------------------------------------------------------------------------------------- */
+void oracle_colmass_sqrt(const float* Z, int64_t b, int M, int N, float* out /*[b,N-1]*/) {
+#pragma omp parallel for schedule(static)
+    for (int64_t bi = 0; bi < b; ++bi) {
+        const float* z = Z + bi * (int64_t)M * N;
+        for (int j = 0; j < N - 1; ++j) {
+            double s = 0.0;
+            for (int i = 0; i < M - 1; ++i) s += (double)expf(z[(int64_t)i * N + j]);
+            out[bi * (N - 1) + j] = sqrtf((float)s + 1e-8f);
+        }
+    }
+}
+
+void oracle_dustbin_bias(float* Z, int64_t b, int M, int N, float k) {
+    const float lb = logf(1.0f * k); /* torch.log(self.one * 2) */
+    for (int64_t bi = 0; bi < b; ++bi) {
+        float* z = Z + bi * (int64_t)M * N;
+        for (int i = 0; i < M; ++i) z[(int64_t)i * N + (N - 1)] += lb;
+        for (int j = 0; j < N; ++j) z[(int64_t)(M - 1) * N + j] += lb;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a8  argmax with first-index tie-break: scores.max(2).indices / scores.max(1).indices
+ * first_layer.py:162  second_layer.py:243.  Full [b,M] / [b,N] index vectors (the callers slice
+ * [:, :-1]).
+ * ---------------------------------------------------------------------------------------- */
+void oracle_argmax(const float* Z, int64_t b, int M, int N, int64_t* row_arg /*[b,M]*/,
+                   int64_t* col_arg /*[b,N]*/) {
+#pragma omp parallel for schedule(static)
+    for (int64_t bi = 0; bi < b; ++bi) {
+        const float* z = Z + bi * (int64_t)M * N;
+        if (row_arg)
+            for (int i = 0; i < M; ++i) {
+                int best = 0;
+                float bv = z[(int64_t)i * N];
+                for (int j = 1; j < N; ++j)
+                    if (z[(int64_t)i * N + j] > bv) { bv = z[(int64_t)i * N + j]; best = j; }
+                row_arg[bi * M + i] = best;
+            }
+        if (col_arg)
+            for (int j = 0; j < N; ++j) {
+                int best = 0;
+                float bv = z[j];
+                for (int i = 1; i < M; ++i)
+                    if (z[(int64_t)i * N + j] > bv) { bv = z[(int64_t)i * N + j]; best = i; }
+                col_arg[bi * N + j] = best;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a9  Compute_positions_and_ranges, utils/utils.py:1527-1537
+ * positions[k] = (k / w, k % w) for the TRUE grid (h, w);  ranges is implicit:
+ * ranges[d][k] = k <= d ? k : 1e7, row length max(h, w).
+ * ---------------------------------------------------------------------------------------- */
+void oracle_positions(int h, int w, float* positions /*[h*w,2]*/) {
+    for (int k = 0; k < h * w; ++k) {
+        positions[2 * k + 0] = (float)(k / w);
+        positions[2 * k + 1] = (float)(k % w);
+    }
+}
+
+static inline float range_val(int d, int k) { return k <= d ? (float)k : 1e7f; }
+
+/* ------------------------------------------------------------------------------------------
+ * a10 + a11  Iterative_expand_matrix (utils/utils.py:1179-1297) + Compute_scaling (:1321-1340)
+ *
+ * P       [b,M,N]   = exp(Z) incl. dustbin row (M-1) and dustbin column (N-1)
+ * scalex, scaley [b,n] with n = N-1 (the reference passes [b,n,1])
+ * lim3    = limitation[3] (true grid width, W // patch_scale), used for point0 only (:1189-1190)
+ * h, w    = true grid; the function itself derives width = ranges.shape[0] = max(h,w) and
+ *           height = positions.shape[0] // width (:1181) - the portrait swap quirk is kept.
+ * outputs: whole_cost, core_cost [b,m]; average_point [b,m,2]; x_scale, y_scale [b,m];
+ *          bound [b,m,4] int64 (up, down, left, right)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* prow; /* this source patch's row of exp(Z), N entries */
+    const float* scale; /* scalex*scaley, n entries */
+    const float* opp;   /* dustbin row of exp(Z), n entries */
+    int N, n, S;        /* S = sentinel index width*height+1 */
+} expand_ctx;
+
+/* expand_scores = cat([scores, 1e-14]) : N+1 entries (utils.py:1205) */
+static inline float ES(const expand_ctx* c, int64_t idx) { return idx < c->N ? c->prow[idx] : ZERO_F; }
+/* expand_scale = cat([scale, 1e-14, 1e-14]) : n+2 entries (utils.py:1206-1207) */
+static inline float ESC(const expand_ctx* c, int64_t idx) { return idx < c->n ? c->scale[idx] : ZERO_F; }
+/* opposite_nomatching_scores padded the same way (utils.py:1208) */
+static inline float EOPP(const expand_ctx* c, int64_t idx) { return idx < c->n ? c->opp[idx] : ZERO_F; }
+
+static inline int64_t clamp_seq(float f, int wh, int S) {
+    int64_t s = (int64_t)f; /* float -> long assignment truncates (utils.py:1216-1219) */
+    if (!(s >= 0)) s = S;   /* utils.py:1220 */
+    if (!(s <= wh - 1)) s = S; /* utils.py:1221 */
+    return s;
+}
+
+void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const float* scalex,
+                             const float* scaley, int lim3, int h, int w, float lower_bound,
+                             int iter_num, float* whole_cost, float* core_cost,
+                             float* average_point, float* x_scale, float* y_scale,
+                             int64_t* bound_out) {
+    const int m = M - 1, n = N - 1;
+    const int width = h > w ? h : w;            /* ranges.shape[0]          (utils.py:1181) */
+    const int height = (h * w) / width;         /* positions.shape[0] // width              */
+    const int wh = width * height;
+    const int S = wh + 1;
+    float* positions = (float*)malloc(sizeof(float) * 2 * (size_t)(h * w));
+    oracle_positions(h, w, positions);
+#pragma omp parallel for schedule(static)
+    for (int64_t bi = 0; bi < b; ++bi) {
+        const float* Pb = P + bi * (int64_t)M * N;
+        const float* sx = scalex + bi * (int64_t)n;
+        const float* sy = scaley + bi * (int64_t)n;
+        float* scale = (float*)malloc(sizeof(float) * (size_t)n);
+        float* ox = (float*)malloc(sizeof(float) * (size_t)n);
+        float* oy = (float*)malloc(sizeof(float) * (size_t)n);
+        for (int j = 0; j < n; ++j) scale[j] = sx[j] * sy[j]; /* utils.py:1192 */
+        const float* opp = Pb + (int64_t)(M - 1) * N;       /* scores_in[:, -1, :-1] :1183 */
+        for (int r = 0; r < m; ++r) {
+            expand_ctx c = {Pb + (int64_t)r * N, scale, opp, N, n, S};
+            /* max0 over real columns (:1182); argmax over all columns (:1191) */
+            int max0 = 0, maxall = 0;
+            for (int j = 1; j < n; ++j) if (c.prow[j] > c.prow[max0]) max0 = j;
+            for (int j = 1; j < N; ++j) if (c.prow[j] > c.prow[maxall]) maxall = j;
+            const int if_nomatching = (maxall == m); /* `== scores.shape[1]` (:1191) */
+            float last_nomatching = opp[max0];       /* :1184 */
+            int64_t up = max0 / lim3, down = up, left = max0 % lim3, right = left; /* :1189-1197 */
+            int bd0 = 0, bd1 = 0, sb0 = 0, sb1 = 0;  /* bound_difference; sb* = the copy the LAST
+                                                        iteration's sequence_base was built from */
+            float last_sum = ES(&c, max0);           /* :1209 */
+            float last_scale = ESC(&c, max0);        /* :1210 */
+            for (int it = 0; it < iter_num; ++it) {
+                sb0 = bd0; sb1 = bd1;                /* sequence_base = ranges[bound_difference] :1215 */
+                double e_sum[4] = {0, 0, 0, 0}, nm_sum[4] = {0, 0, 0, 0}, sc_sum[4] = {0, 0, 0, 0};
+                const float off[4] = {
+                    (float)(left + up * width - width),   /* strip above   :1217 */
+                    (float)(left + down * width + width), /* strip below   :1218 */
+                    (float)(left + up * width - 1),       /* strip left    :1219 */
+                    (float)(right + up * width + 1)};     /* strip right   :1220 */
+                for (int d = 0; d < 4; ++d)
+                    for (int k = 0; k < width; ++k) {
+                        float f = d < 2 ? range_val(sb1, k) + off[d]
+                                        : range_val(sb0, k) * (float)width + off[d];
+                        int64_t s = clamp_seq(f, wh, S);
+                        float v = ES(&c, s);
+                        e_sum[d] += (double)v;
+                        nm_sum[d] += (double)(v > lower_bound ? EOPP(&c, s) : ZERO_F); /* :1225 */
+                        sc_sum[d] += (double)ESC(&c, s);                               /* :1231 */
+                    }
+                float es[4];
+                for (int d = 0; d < 4; ++d) es[d] = (float)e_sum[d];
+                if (up == 0) es[0] = ZERO_F;              /* :1227-1230 */
+                if (down == height - 1) es[1] = ZERO_F;
+                if (left == 0) es[2] = ZERO_F;
+                if (right == width - 1) es[3] = ZERO_F;
+                int arg = 0;
+                for (int d = 1; d < 4; ++d) if (es[d] > es[arg]) arg = d; /* :1232 */
+                const float max_sum = es[arg];
+                float add_sum = ZERO_F, add_scale = ZERO_F, add_nm = ZERO_F;
+                if (max_sum > lower_bound) {              /* :1235-1238 */
+                    if (arg == 0) up -= 1; else if (arg == 1) down += 1;
+                    else if (arg == 2) left -= 1; else right += 1;
+                    add_sum = max_sum;
+                    add_scale = (float)sc_sum[arg];
+                    add_nm = (float)nm_sum[arg];
+                }
+                bd0 = (int)(down - up);                   /* :1239-1240 */
+                bd1 = (int)(right - left);
+                last_sum = last_sum + add_sum;            /* :1241-1243 */
+                last_scale = last_scale + add_scale;
+                last_nomatching = last_nomatching + add_nm;
+            }
+            (void)last_scale;
+            const int if_core_exist = (bd0 > 1) && (bd1 > 1); /* :1244 */
+            /* border strips of the final rectangle, with the STALE sequence_base (:1245-1253) */
+            double edge_sum[4] = {0, 0, 0, 0}, edge_scale[4] = {0, 0, 0, 0};
+            const float eoff[4] = {(float)(left + up * width), (float)(left + down * width),
+                                   (float)(left + up * width), (float)(right + up * width)};
+            for (int d = 0; d < 4; ++d)
+                for (int k = 0; k < width; ++k) {
+                    float f = d < 2 ? range_val(sb1, k) + eoff[d]
+                                    : range_val(sb0, k) * (float)width + eoff[d];
+                    int64_t s = clamp_seq(f, wh, S);
+                    edge_sum[d] += (double)ES(&c, s);
+                    edge_scale[d] += (double)ESC(&c, s);
+                }
+            /* in-rectangle weights (:1254-1260) and weighted centroid (:1264-1273) */
+            double wx = 0, wy = 0, sumx = 0, sumy = 0, ws = 0, so = 0;
+            for (int p = 0; p < n; ++p) {
+                const float py = positions[2 * p], px = positions[2 * p + 1];
+                const int crit = (py >= (float)up) && (py <= (float)down) && (px >= (float)left) &&
+                                 (px <= (float)right);
+                const float root = sqrtf(c.prow[p] + 1e-7f);
+                ox[p] = crit ? root / sx[p] : ZERO_F;
+                oy[p] = crit ? root / sy[p] : ZERO_F;
+                wx += (double)ox[p] * (double)px;
+                wy += (double)oy[p] * (double)py;
+                sumx += (double)ox[p];
+                sumy += (double)oy[p];
+                const float o = ox[p] * oy[p];            /* Compute_scaling :1323 */
+                ws += (double)o * (double)scale[p];
+                so += (double)o;
+            }
+            const int64_t o2 = (bi * m + r);
+            average_point[o2 * 2 + 1] = (float)wx / (float)sumx + 0.5f;
+            average_point[o2 * 2 + 0] = (float)wy / (float)sumy + 0.5f;
+            /* corners (:1279-1287) */
+            const int64_t corner[4] = {up * width + left, up * width + right, down * width + left,
+                                       down * width + right};
+            double cps = 0, css = 0;
+            for (int q = 0; q < 4; ++q) {
+                int64_t s = corner[q];
+                if (!(s >= 0)) s = S;
+                if (!(s <= wh - 1)) s = S;
+                cps += (double)ES(&c, s);
+                css += (double)ESC(&c, s);
+            }
+            double ts = 0;
+            for (int j = 0; j < N; ++j) ts += (double)c.prow[j];
+            const float the_scale = (float)ts;            /* :1288 */
+            const float e4 = (float)((double)(float)edge_sum[0] + (double)(float)edge_sum[1] +
+                                     (double)(float)edge_sum[2] + (double)(float)edge_sum[3]);
+            const float s4 = (float)((double)(float)edge_scale[0] + (double)(float)edge_scale[1] +
+                                     (double)(float)edge_scale[2] + (double)(float)edge_scale[3]);
+            const float core_scale_sum = the_scale - s4 + (float)css;  /* :1289 */
+            const float core_sum = last_sum - e4 + (float)cps;         /* :1290 */
+            core_cost[o2] = (if_core_exist && !if_nomatching)
+                                ? fabsf((core_sum - core_scale_sum) / the_scale) : ZERO_F; /* :1291 */
+            whole_cost[o2] = if_nomatching ? ZERO_F
+                : (fabsf(the_scale - last_sum) + last_nomatching / 4.0f) / the_scale;      /* :1296 */
+            const float average_scale = sqrtf((float)ws / (float)so);  /* :1326 */
+            x_scale[o2] = 1.0f / (average_scale / 1.0f);               /* :1335-1340, ratio = 1.0 */
+            y_scale[o2] = 1.0f / (average_scale * 1.0f);
+            bound_out[o2 * 4 + 0] = up;
+            bound_out[o2 * 4 + 1] = down;
+            bound_out[o2 * 4 + 2] = left;
+            bound_out[o2 * 4 + 3] = right;
+        }
+        free(scale);
+        free(ox);
+        free(oy);
+    }
+    free(positions);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a12  split_patches, utils/utils.py:152-181.  sum_cycle [h*w] int32 cumsum of matched flags.
+ * Python's negative index `sum_cycle[i*width - 1]` at i == 0 reads the LAST element; kept.
+ * second/third: caller-provided [h+1][2] int64.  Returns cycle_num.
+ * ---------------------------------------------------------------------------------------- */
+int oracle_split_patches(const int32_t* sum_cycle, int h, int w, int max_once_used,
+                         int64_t* second, int64_t* third) {
+    const int L = h * w;
+#define SC(i) ((int64_t)sum_cycle[((i) % L + L) % L])
+    int cycle = 0, last_second = 0, last_third = 0;
+    for (int i = 0; i < h; ++i) {
+        const int64_t num = SC((i + 1) * w - 1);
+        if (num > (int64_t)max_once_used * (cycle + 1)) {
+            const int64_t origin = last_second == 0 ? 0 : SC(last_second * w - 1);
+            second[2 * cycle] = origin;
+            second[2 * cycle + 1] = SC((i + 1) * w - 1);
+            third[2 * cycle] = SC(last_third * w) - origin;
+            third[2 * cycle + 1] = SC((i + 1) * w - 1) - SC(i * w - 1);
+            cycle += 1;
+            last_second = i;
+            last_third = i + 1;
+        }
+    }
+    const int64_t origin = last_second == 0 ? 0 : SC(last_second * w - 1);
+    second[2 * cycle] = origin;
+    second[2 * cycle + 1] = (int64_t)h * w;
+    const int64_t end_num = (last_third == h) ? origin : SC(last_third * w);
+    third[2 * cycle] = end_num - origin;
+    third[2 * cycle + 1] = 0;
+    cycle += 1;
+#undef SC
+    return cycle;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a13  Compute_imgs bounds, utils/utils.py:1350-1382 (margin = 128, patch_scale = 32).
+ * In : x_scale, y_scale [N]; average_point [N,2]; if_nomatching [N] (uint8); grid (height,width)
+ * Out: bound5 [K,5] int64 (y0,y1,x0,x1,seq) for matched patches in order;
+ *      x_scale_new, y_scale_new [N,2]; average_new [N,2].   Returns K.   (batch element img)
+ * ---------------------------------------------------------------------------------------- */
+int64_t oracle_compute_imgs_bounds(const float* x_scale, const float* y_scale,
+                                   const float* average_point, const uint8_t* if_nomatching,
+                                   int Np, int height, int width, int img, int64_t* bound5,
+                                   float* x_scale_new, float* y_scale_new, float* average_new) {
+    const float ps = 32.0f, margin = 128.0f;
+    const float board1 = (float)(32 * height - 1), board3 = (float)(32 * width); /* :1351 */
+    int64_t K = 0;
+    for (int k = 0; k < Np; ++k) {
+        const float ay = average_point[2 * k], ax = average_point[2 * k + 1];
+        float b0 = (ay - y_scale[k] * 3.0f / 2.0f) * ps + margin; /* :1360-1363 */
+        float b1 = (ay + y_scale[k] * 3.0f / 2.0f) * ps + margin;
+        float b2 = (ax - x_scale[k] * 3.0f / 2.0f) * ps + margin;
+        float b3 = (ax + x_scale[k] * 3.0f / 2.0f) * ps + margin;
+        b0 = b0 >= 0 ? b0 : 0.0f;                                  /* :1364 */
+        b1 = b1 >= 0 ? b1 : 0.0f;
+        b2 = b2 >= 0 ? b2 : 0.0f;
+        b3 = b3 >= 0 ? b3 : 0.0f;
+        b1 = (b1 < (float)(32 * height + 256)) ? b1 : board1;       /* :1365 */
+        b3 = (b3 < (float)(32 * width + 256)) ? b3 : board3;        /* :1366 */
+        x_scale_new[2 * k] = (b1 - b0 + 1.0f) / 96.0f;              /* :1367 (row extent!) */
+        x_scale_new[2 * k + 1] = 1.0f;                              /* :1378-1381 */
+        y_scale_new[2 * k] = (b3 - b2 + 1.0f) / 96.0f;              /* :1368 */
+        y_scale_new[2 * k + 1] = 1.0f;
+        const int64_t l0 = (int64_t)b0, l1 = (int64_t)b1, l2 = (int64_t)b2, l3 = (int64_t)b3; /* :1369 */
+        average_new[2 * k + 1] = (float)(l1 + l0) / 2.0f - 128.0f + 0.5f; /* :1371 */
+        average_new[2 * k + 0] = (float)(l2 + l3) / 2.0f - 128.0f + 0.5f; /* :1372 */
+        if (!if_nomatching[k]) {
+            bound5[K * 5 + 0] = l0;
+            bound5[K * 5 + 1] = l1;
+            bound5[K * 5 + 2] = l2;
+            bound5[K * 5 + 3] = l3;
+            bound5[K * 5 + 4] = (int64_t)img * 10000 + k;           /* :1374-1377 */
+            K += 1;
+        }
+    }
+    return K;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a13  left crops: origin_extract on the 32-px zero-padded left image, utils/utils.py:1300-1318,
+ * caller :1383-1384.  left [H,W,3] HWC -> out [K,96,96,3] for matched patches (grid h x w).
+ * ---------------------------------------------------------------------------------------- */
+int64_t oracle_left_crops(const float* left, int H, int W, const uint8_t* if_nomatching, int h,
+                          int w, float* out) {
+    int64_t K = 0;
+    for (int k = 0; k < h * w; ++k) {
+        if (if_nomatching[k]) continue;
+        const int r = k / w, c = k % w;
+        float* o = out + K * 96 * 96 * 3;
+        for (int y = 0; y < 96; ++y)
+            for (int x = 0; x < 96; ++x) {
+                const int iy = r * 32 + y - 32, ix = c * 32 + x - 32;
+                for (int ch = 0; ch < 3; ++ch) {
+                    float v = 0.0f;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = left[((int64_t)iy * W + ix) * 3 + ch];
+                    o[((int64_t)y * 96 + x) * 3 + ch] = v;
+                }
+            }
+        K += 1;
+    }
+    return K;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a14  tensor_resize, setup/library.cpp:47-66.
+ * input [n_img,C,Hp,Wp]; bound [K,5] int64 (y0,y1,x0,x1,seq); out [K,C,96,96].
+ * crop rows [y0,y1), cols [x0,x1]  (height y1-y0, width x1-x0+1, library.cpp:56-59);
+ * upsample_bilinear2d(align_corners=true) (library.cpp:60) = ATen's
+ * area_pixel_compute_scale / source index: scale = (in-1)/(out-1), src = scale*dst.
+ * Returns 0, or -1 if a crop is empty / out of range (torch raises there).
+ * ---------------------------------------------------------------------------------------- */
+int oracle_tensor_resize(const float* input, int n_img, int C, int Hp, int Wp, const int64_t* bound,
+                         int64_t K, float* out) {
+    int err = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < K; ++i) {
+        const int64_t y0 = bound[i * 5], y1 = bound[i * 5 + 1], x0 = bound[i * 5 + 2],
+                      x1 = bound[i * 5 + 3], img = bound[i * 5 + 4] / 10000; /* library.cpp:55-56 */
+        const int64_t ih = y1 - y0, iw = x1 - x0 + 1;
+        if (ih <= 0 || iw <= 0 || y0 < 0 || x0 < 0 || y0 + ih > Hp || x0 + iw > Wp || img < 0 ||
+            img >= n_img) {
+#pragma omp atomic write
+            err = -1;
+            continue;
+        }
+        const float sh = (float)(ih - 1) / 95.0f, sw = (float)(iw - 1) / 95.0f;
+        for (int c = 0; c < C; ++c) {
+            const float* src = input + (((int64_t)img * C + c) * Hp + y0) * Wp + x0;
+            float* o = out + ((i * C + c) * 96) * 96;
+            for (int oy = 0; oy < 96; ++oy) {
+                const float fy = sh * (float)oy;
+                const int64_t h1 = (int64_t)fy;
+                const int64_t h1p = (h1 < ih - 1) ? 1 : 0;
+                const float l1 = fy - (float)h1, l0 = 1.0f - l1;
+                for (int ox = 0; ox < 96; ++ox) {
+                    const float fx = sw * (float)ox;
+                    const int64_t w1 = (int64_t)fx;
+                    const int64_t w1p = (w1 < iw - 1) ? 1 : 0;
+                    const float m1 = fx - (float)w1, m0 = 1.0f - m1;
+                    const float* p = src + h1 * Wp + w1;
+                    o[oy * 96 + ox] = l0 * (m0 * p[0] + m1 * p[w1p]) +
+                                      l1 * (m0 * p[h1p * Wp] + m1 * p[h1p * Wp + w1p]);
+                }
+            }
+        }
+    }
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a17 + a18  ThirdLayer.Compute_result (third_layer.py:184-217) and the match label
+ * (third_layer.py:161-170).  W = 8, T = 5.
+ * scores [P,65,65] = exp(Z);  scale_x, scale_y [P,64];  p_s, p_t [P,2] int64
+ * -> mkpts0_f, mkpts1_f [P,16,2];  whole_loss [P,16];  label [P*16,2];  if_matching1 [P,16]
+ * ---------------------------------------------------------------------------------------- */
+void oracle_compute_result(const float* scores, int64_t P, const float* scale_x,
+                           const float* scale_y, const int64_t* p_s, const int64_t* p_t,
+                           int outdoor, float* mkpts0_f, float* mkpts1_f, float* whole_loss,
+                           float* label, uint8_t* if_matching1) {
+    const int W = 8, T = 5, NN = 65;
+    int64_t count = 0;
+#pragma omp parallel for schedule(static) reduction(+ : count)
+    for (int64_t p = 0; p < P; ++p) {
+        const float* Sp = scores + p * (int64_t)NN * NN;
+        const float* sx = scale_x + p * 64;
+        const float* sy = scale_y + p * 64;
+        for (int q = 0; q < 16; ++q) {
+            const int qy = q / 4 + 2, qx = q % 4 + 2; /* [:, 2:6, 2:6] (:186,188) */
+            const float* row = Sp + (int64_t)(qy * W + qx) * NN;
+            int max0 = 0;
+            for (int j = 1; j < 64; ++j) if (row[j] > row[max0]) max0 = j; /* :188 */
+            const int mx = max0 % W, my = max0 / W;
+            double wpx = 0, wpy = 0, sumx = 0, sumy = 0, unfold = 0;
+            for (int t = 0; t < T * T; ++t) {
+                const int tx = t % T, ty = t / T;
+                /* index3 = y3*(W+4) + x3 into the pad-2 map (:189-191) */
+                const int ux = mx + tx - 2, uy = my + ty - 2; /* unpadded coordinates */
+                const int inside = (ux >= 0 && ux < W && uy >= 0 && uy < W);
+                const float sb = inside ? row[uy * W + ux] : 0.0f;        /* ZeroPad2d(2)  :185 */
+                const float scx = inside ? sx[uy * W + ux] : 1e-2f;       /* pad_1 = 1e-2  :195 */
+                const float scy = inside ? sy[uy * W + ux] : 1e-2f;
+                const float root = sqrtf(sb + 1e-7f);
+                const float fx = root / scx, fy = root / scy;              /* :197-198 */
+                const float posx = (float)tx * 2.0f - (float)(T - 1);      /* :199 */
+                const float posy = (float)ty * 2.0f - (float)(T - 1);
+                wpx += (double)fx * (double)posx;
+                wpy += (double)fy * (double)posy;
+                sumx += (double)fx;
+                sumy += (double)fy;
+                unfold += (double)sb;
+            }
+            const int64_t o = (p * 16 + q) * 2;
+            float m1x = (float)wpx / (float)sumx + ((float)mx + 0.5f - (float)W / 2) * 2.0f; /* :206 */
+            float m1y = (float)wpy / (float)sumy + ((float)my + 0.5f - (float)W / 2) * 2.0f; /* :207 */
+            mkpts1_f[o + 0] = m1x + (float)p_t[p * 2 + 0];                                   /* :208 */
+            mkpts1_f[o + 1] = m1y + (float)p_t[p * 2 + 1];
+            mkpts0_f[o + 0] = (float)p_s[p * 2 + 0] + (float)(q % 4) * 2.0f - 3.0f;           /* :209-210 */
+            mkpts0_f[o + 1] = (float)p_s[p * 2 + 1] + (float)(q / 4) * 2.0f - 3.0f;
+            double rs = 0;
+            for (int j = 0; j < NN; ++j) rs += (double)row[j];
+            const float wl = (float)rs - (float)unfold;                                       /* :213 */
+            whole_loss[p * 16 + q] = wl;
+            if (wl >= 1e-2f) count += 1;
+            /* label (:161-170) */
+            int amax = 0;
+            float bv = row[0] + 1e-8f;
+            for (int j = 1; j < NN; ++j) {
+                const float v = row[j] + 1e-8f;
+                if (v > bv) { bv = v; amax = j; }
+            }
+            const int matching = (amax != W * W);
+            if_matching1[p * 16 + q] = (uint8_t)matching;
+            float l0 = 1e8f;
+            if (!outdoor) {
+                const int64_t a = (p * 16 + q) % 16;
+                const int select = (a == 5 || a == 15 || a == 7 || a == 13);
+                l0 = select ? l0 : -10.0f;
+            } else {
+                l0 = matching ? l0 : -10.0f;
+            }
+            label[o + 0] = l0;
+            label[o + 1] = 1e8f;
+        }
+    }
+    /* whole_loss = where(wl >= 1e-2, wl, 0) / (count + 10) / 10   (:215) */
+    const float denom = (float)count + 10.0f;
+    for (int64_t k = 0; k < P * 16; ++k) {
+        const float wl = whole_loss[k];
+        whole_loss[k] = (wl >= 1e-2f ? wl : 0.0f) / denom / 10.0f;
+    }
+}

@@ -1,0 +1,209 @@
+"""ctypes binding of oracle/libpats_oracle.so (numpy in, numpy out).
+
+TEST INFRASTRUCTURE, NOT PRODUCT: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  pats_amd/ never imports it.  Function names mirror the reference's
+(/root/reference/models/modules.py, utils/utils.py, models/third_layer.py, setup/library.cpp).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpats_oracle.so")
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i64 = ctypes.POINTER(ctypes.c_int64)
+c_i32 = ctypes.POINTER(ctypes.c_int32)
+c_u8 = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pats_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libpats_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_split_patches.restype = ctypes.c_int
+        _lib.oracle_compute_imgs_bounds.restype = ctypes.c_int64
+        _lib.oracle_left_crops.restype = ctypes.c_int64
+        _lib.oracle_tensor_resize.restype = ctypes.c_int
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(c_f)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
+def cost(d0, d1):
+    d0, p0 = _f(d0)
+    d1, p1 = _f(d1)
+    b, D, n = d0.shape
+    m = d1.shape[2]
+    out = np.empty((b, n, m), np.float32)
+    lib().oracle_cost(p0, p1, ctypes.c_int64(b), D, n, m, _p(out, c_f))
+    return out
+
+
+def log_sinkhorn_iterations(Z, log_mu, log_nu, iters):
+    Z, pz = _f(Z)
+    log_mu, pm = _f(log_mu)
+    log_nu, pn = _f(log_nu)
+    b, M, N = Z.shape
+    out = np.empty_like(Z)
+    lib().oracle_sinkhorn(pz, ctypes.c_int64(b), M, N, pm, pn, int(iters), _p(out, c_f))
+    return out
+
+
+def log_optimal_transport(scores, alpha, ns, iters):
+    scores, ps = _f(scores)
+    ns, pn = _f(ns)
+    b, m, n = scores.shape
+    out = np.empty((b, m + 1, n + 1), np.float32)
+    lib().oracle_log_optimal_transport(ps, ctypes.c_int64(b), m, n, ctypes.c_float(float(alpha)),
+                                       pn, int(iters), _p(out, c_f))
+    return out
+
+
+def log_optimal_transport2(scores, one, ns, iters):
+    scores, ps = _f(scores)
+    ns, pn = _f(ns)
+    b, m, n = scores.shape
+    out = np.empty((b, m, n), np.float32)
+    lib().oracle_log_optimal_transport2(ps, ctypes.c_int64(b), m, n, ctypes.c_float(float(one)),
+                                        pn, int(iters), _p(out, c_f))
+    return out
+
+
+def colmass_sqrt(Z):
+    Z, pz = _f(Z)
+    b, M, N = Z.shape
+    out = np.empty((b, N - 1), np.float32)
+    lib().oracle_colmass_sqrt(pz, ctypes.c_int64(b), M, N, _p(out, c_f))
+    return out
+
+
+def dustbin_bias(Z, k):
+    Z = np.array(Z, dtype=np.float32, order="C", copy=True)
+    b, M, N = Z.shape
+    lib().oracle_dustbin_bias(_p(Z, c_f), ctypes.c_int64(b), M, N, ctypes.c_float(float(k)))
+    return Z
+
+
+def argmax(Z):
+    Z, pz = _f(Z)
+    b, M, N = Z.shape
+    r = np.empty((b, M), np.int64)
+    c = np.empty((b, N), np.int64)
+    lib().oracle_argmax(pz, ctypes.c_int64(b), M, N, _p(r, c_i64), _p(c, c_i64))
+    return r, c
+
+
+def iterative_expand(P, scalex, scaley, lim3, h, w, lower_bound, iter_num):
+    P, pp = _f(P)
+    b, M, N = P.shape
+    scalex, px = _f(np.asarray(scalex).reshape(b, N - 1))
+    scaley, py = _f(np.asarray(scaley).reshape(b, N - 1))
+    m = M - 1
+    whole = np.empty((b, m), np.float32)
+    core = np.empty((b, m), np.float32)
+    avg = np.empty((b, m, 2), np.float32)
+    xs = np.empty((b, m), np.float32)
+    ys = np.empty((b, m), np.float32)
+    bound = np.empty((b, m, 4), np.int64)
+    lib().oracle_iterative_expand(pp, ctypes.c_int64(b), M, N, px, py, int(lim3), int(h), int(w),
+                                  ctypes.c_float(lower_bound), int(iter_num), _p(whole, c_f),
+                                  _p(core, c_f), _p(avg, c_f), _p(xs, c_f), _p(ys, c_f),
+                                  _p(bound, c_i64))
+    return whole, core, avg, xs, ys, bound
+
+
+def split_patches(sum_cycle, h, w, cap):
+    sc = np.ascontiguousarray(sum_cycle, dtype=np.int32)
+    second = np.zeros((h + 1, 2), np.int64)
+    third = np.zeros((h + 1, 2), np.int64)
+    n = lib().oracle_split_patches(_p(sc, c_i32), int(h), int(w), int(cap), _p(second, c_i64),
+                                   _p(third, c_i64))
+    return n, second[:n].copy(), third[:n].copy()
+
+
+def compute_imgs_bounds(x_scale, y_scale, average_point, if_nomatching, height, width, img=0):
+    xs, px = _f(np.asarray(x_scale).reshape(-1))
+    ys, py = _f(np.asarray(y_scale).reshape(-1))
+    ap, pa = _f(np.asarray(average_point).reshape(-1, 2))
+    ifn = np.ascontiguousarray(np.asarray(if_nomatching).reshape(-1), dtype=np.uint8)
+    Np = xs.shape[0]
+    bound5 = np.zeros((Np, 5), np.int64)
+    xsn = np.empty((Np, 2), np.float32)
+    ysn = np.empty((Np, 2), np.float32)
+    avn = np.empty((Np, 2), np.float32)
+    K = lib().oracle_compute_imgs_bounds(px, py, pa, _p(ifn, c_u8), Np, int(height), int(width),
+                                         int(img), _p(bound5, c_i64), _p(xsn, c_f), _p(ysn, c_f),
+                                         _p(avn, c_f))
+    return bound5[:K].copy(), xsn, ysn, avn
+
+
+def left_crops(left_hwc, if_nomatching, h, w):
+    left, pl = _f(left_hwc)
+    H, W = left.shape[0], left.shape[1]
+    ifn = np.ascontiguousarray(np.asarray(if_nomatching).reshape(-1), dtype=np.uint8)
+    K = int((ifn == 0).sum())
+    out = np.empty((K, 96, 96, 3), np.float32)
+    lib().oracle_left_crops(pl, H, W, _p(ifn, c_u8), int(h), int(w), _p(out, c_f))
+    return out
+
+
+def tensor_resize(inp, bound):
+    inp, pi = _f(inp)
+    bound = np.ascontiguousarray(bound, dtype=np.int64).reshape(-1, 5)
+    n_img, C, Hp, Wp = inp.shape
+    K = bound.shape[0]
+    out = np.zeros((K, C, 96, 96), np.float32)
+    if K:
+        rc = lib().oracle_tensor_resize(pi, n_img, C, Hp, Wp, _p(bound, c_i64), ctypes.c_int64(K),
+                                        _p(out, c_f))
+        if rc != 0:
+            raise RuntimeError("tensor_resize: empty or out-of-range crop")
+    return out
+
+
+def compute_result(scores, scale_x, scale_y, p_s, p_t, outdoor):
+    scores, ps = _f(scores)
+    P = scores.shape[0]
+    sx, px = _f(np.asarray(scale_x).reshape(P, 64))
+    sy, py = _f(np.asarray(scale_y).reshape(P, 64))
+    p_s = np.ascontiguousarray(p_s, dtype=np.int64).reshape(P, 2)
+    p_t = np.ascontiguousarray(p_t, dtype=np.int64).reshape(P, 2)
+    m0 = np.empty((P, 16, 2), np.float32)
+    m1 = np.empty((P, 16, 2), np.float32)
+    wl = np.empty((P, 16), np.float32)
+    label = np.empty((P * 16, 2), np.float32)
+    ifm = np.empty((P, 16), np.uint8)
+    lib().oracle_compute_result(ps, ctypes.c_int64(P), px, py, _p(p_s, c_i64), _p(p_t, c_i64),
+                                int(bool(outdoor)), _p(m0, c_f), _p(m1, c_f), _p(wl, c_f),
+                                _p(label, c_f), _p(ifm, c_u8))
+    return m0, m1, wl, label, ifm.astype(bool)

@@ -1,0 +1,207 @@
+"""Pins the CPU oracle (oracle/pats_oracle.c) against fixtures produced by the REFERENCE's own
+code (tools/make_golden.py).  CPU only.  Gates: indices exact, transport
+mass |d exp(Z)| <= 1e-4 element-wise and on marginals, crops <= 1e-4 abs on 0-255 data."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from pats_amd import synth
+
+MASS_TOL = 1e-4
+
+
+def assert_mass(Zo, Zr):
+    eo, er = np.exp(Zo.astype(np.float64)), np.exp(Zr.astype(np.float64))
+    assert np.abs(eo - er).max() <= MASS_TOL
+    # marginals: 1e-4 absolute, plus fp32 resolution on the dustbin marginals (mass ~ sum(ns) >> 1)
+    np.testing.assert_allclose(eo.sum(-1), er.sum(-1), atol=MASS_TOL, rtol=1e-6)
+    np.testing.assert_allclose(eo.sum(-2), er.sum(-2), atol=MASS_TOL, rtol=1e-6)
+    # log-plan itself agrees tightly where mass is non-negligible
+    big = er > 1e-6
+    assert np.abs(Zo[big] - Zr[big]).max() <= 2e-4
+
+
+def test_kat(oracle):
+    g = golden("ot_kat.npz")
+    z1 = oracle.log_optimal_transport(g["s1"], g["a1"], g["n1"], 100)
+    assert_mass(z1, g["z1"])
+    # the SURVEY 8c known-answer values
+    np.testing.assert_allclose(np.exp(z1[0, 0]), [.3251170, .2107056, .0291975, .4349800], atol=2e-6)
+    np.testing.assert_allclose(np.exp(z1).sum(2)[0], [1, 1, 3.5], atol=1e-5)
+    np.testing.assert_allclose(np.exp(z1).sum(1)[0], [1, 2, .5, 2], atol=1e-5)
+    z2 = oracle.log_optimal_transport2(g["s2"], 1.0, g["n2"], 100)
+    assert_mass(z2, g["z2"])
+    np.testing.assert_allclose(np.exp(z2[0, 2]), [1.1363239, .1686142, 1.1950618], atol=2e-6)
+
+
+@pytest.mark.parametrize("iters", [1, 3, 100])
+def test_sinkhorn_raw_ragged(oracle, iters):
+    g = golden("sinkhorn_raw.npz")
+    out = oracle.log_sinkhorn_iterations(g["Z"], g["log_mu"], g["log_nu"], iters)
+    np.testing.assert_allclose(out, g["out%d" % iters], atol=2e-5, rtol=0)
+
+
+def test_exact_ties_first_index(oracle):
+    g = golden("ot_ties.npz")
+    z = oracle.log_optimal_transport(g["s"], g["alpha"], g["ns"], 100)
+    assert_mass(z, g["z"])
+    r, c = oracle.argmax(z)
+    assert np.array_equal(r, g["max0"]) and np.array_equal(c, g["max1"])
+    # the duplicated columns/rows really are exact ties in the oracle too
+    assert np.array_equal(z[0, :, 3], z[0, :, 7]) and np.array_equal(z[0, 2, :], z[0, 9, :])
+    assert r[0, 5] == 3 and c[0, 4] == 2
+
+
+def _coarse(oracle, name, seed, h, w):
+    g = golden(name)
+    inp = synth.coarse_inputs(seed=seed, h=h, w=w)
+    assert synth.checksum(inp["d0"], inp["d1"], inp["ns"]) == pytest.approx(float(g["in_checksum"]), rel=1e-12)
+    S = oracle.cost(inp["d0"], inp["d1"])
+    np.testing.assert_allclose(S.reshape(-1)[g["S_idx"]], g["S_val"], atol=2e-5, rtol=1e-5)
+    Z = oracle.log_optimal_transport(S, inp["alpha"], inp["ns"], 100)
+    return g, inp, S, Z
+
+
+@pytest.mark.parametrize("name,seed,h,w", [("coarse_301.npz", synth.SEED, 15, 20),
+                                           ("coarse_portrait.npz", synth.SEED + 20, 20, 15)])
+def test_coarse_ot_and_expand(oracle, name, seed, h, w):
+    g, inp, S, Z = _coarse(oracle, name, seed, h, w)
+    assert_mass(Z, g["Z"])
+    np.testing.assert_allclose(np.exp(Z).sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-6)
+    np.testing.assert_allclose(np.exp(Z).sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-6)
+    r, c = oracle.argmax(Z)
+    assert np.array_equal(r[:, :-1], g["max0"]) and np.array_equal(c[:, :-1], g["max1"])
+    n = h * w
+    assert np.array_equal(r[:, :-1] == n, g["ifn1"]) and np.array_equal(c[:, :-1] == n, g["ifn2"])
+    scales = oracle.colmass_sqrt(Z)
+    np.testing.assert_allclose(scales, g["scales"], atol=2e-5)
+    # expansion on the reference's own Z (so decisions see identical inputs)
+    P = np.exp(g["Z"])
+    whole, core, avg, xs, ys, bound = oracle.iterative_expand(P, g["scales"], g["scales"], w, h, w, 1e-5, 15)
+    assert np.array_equal(bound, g["bound"])
+    np.testing.assert_allclose(whole, g["whole_cost"], atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(core, g["core_cost"], atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(avg, g["average_point"], atol=1e-4)
+    np.testing.assert_allclose(xs, g["x_scale"], rtol=2e-5)
+    np.testing.assert_allclose(ys, g["y_scale"], rtol=2e-5)
+    # ... and end to end on the oracle's own Z: integer outputs still identical
+    _, _, _, _, _, bound2 = oracle.iterative_expand(np.exp(Z), scales, scales, w, h, w, 1e-5, 15)
+    assert np.array_equal(bound2, g["bound"])
+
+
+def test_coarse_769_sampled(oracle):
+    g, inp, S, Z = _coarse(oracle, "coarse_769.npz", synth.SEED + 21, 24, 32)
+    zs = Z.reshape(-1)[g["Z_idx"]]
+    e0, e1 = np.exp(zs.astype(np.float64)), np.exp(g["Z_val"].astype(np.float64))
+    assert np.abs(e0 - e1).max() <= MASS_TOL
+    r, c = oracle.argmax(Z)
+    assert np.array_equal(r[:, :-1], g["max0"]) and np.array_equal(c[:, :-1], g["max1"])
+    np.testing.assert_allclose(np.exp(Z).sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-5)
+    np.testing.assert_allclose(np.exp(Z).sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-5)
+    whole, core, avg, xs, ys, bound = oracle.iterative_expand(np.exp(Z), oracle.colmass_sqrt(Z),
+                                                              oracle.colmass_sqrt(Z), 32, 24, 32, 1e-5, 15)
+    assert np.array_equal(bound, g["bound"])
+    np.testing.assert_allclose(avg, g["average_point"], atol=1e-4)
+
+
+@pytest.mark.parametrize("cap", [40, 100, 512])
+def test_split_patches(oracle, cap):
+    g = golden("coarse_301.npz")
+    sum_cycle = np.cumsum(~g["ifn1"][0]).astype(np.int32)
+    n, second, third = oracle.split_patches(sum_cycle, 15, 20, cap)
+    assert n == int(g["split%d_cycle" % cap])
+    assert np.array_equal(second, g["split%d_second" % cap])
+    assert np.array_equal(third, g["split%d_third" % cap])
+
+
+def test_split_patches_first_row_overflow(oracle):
+    # i == 0 branch: Python's sum_cycle[-1] wrap (utils.py:165) is reproduced
+    sc = np.cumsum(np.ones(12, np.int32)).astype(np.int32)
+    n, second, third = oracle.split_patches(sc, 3, 4, 3)
+    assert n == 4
+    assert second.tolist() == [[0, 4], [0, 8], [4, 12], [8, 12]]
+    assert third.tolist() == [[1, 4 - 12], [5, 4], [5, 4], [0, 0]]
+
+
+def test_compute_imgs_and_resize(oracle):
+    g = golden("coarse_301.npz")
+    left, right = synth.image_pair()
+    assert synth.checksum(left, right) == pytest.approx(float(g["img_checksum"]), rel=1e-12)
+    bound5, xsn, ysn, avn = oracle.compute_imgs_bounds(g["x_scale"], g["y_scale"], g["average_point"],
+                                                       g["ifn1"], 15, 20)
+    assert np.array_equal(bound5, g["resize_bound"])
+    np.testing.assert_allclose(xsn[None], g["x_scale_new"], rtol=1e-6)
+    np.testing.assert_allclose(ysn[None], g["y_scale_new"], rtol=1e-6)
+    np.testing.assert_allclose(avn[None], g["average_new"], atol=1e-5)
+    # right crops through the subdivision gather
+    src = np.zeros((1, 3, 480 + 256, 640 + 256), np.float32)
+    src[0, :, 128:-128, 128:-128] = right[0].transpose(2, 0, 1)
+    assert list(src.shape) == g["resize_src_shape"].tolist()
+    crops = oracle.tensor_resize(src, bound5).transpose(0, 2, 3, 1)
+    assert crops.shape[0] == int(g["K"])
+    np.testing.assert_allclose(crops[g["crop_pick"]], g["right_pick"], atol=1e-4)
+    np.testing.assert_allclose(crops.astype(np.float64).sum((1, 2, 3)), g["right_sum"], rtol=1e-6)
+    wts = np.arange(96 * 96 * 3, dtype=np.float64).reshape(96, 96, 3)
+    np.testing.assert_allclose((crops.astype(np.float64) * wts).sum((1, 2, 3)), g["right_wsum"], rtol=1e-6)
+    # left crops (origin_extract)
+    lc = oracle.left_crops(left[0], g["ifn1"][0], 15, 20)
+    np.testing.assert_array_equal(lc[g["crop_pick"]][:, ::4, ::4], g["left_pick"])
+    np.testing.assert_allclose(lc.astype(np.float64).sum((1, 2, 3)), g["left_sum"], rtol=1e-9)
+
+
+def test_resize_small_edges(oracle):
+    g = golden("resize_small.npz")
+    out = oracle.tensor_resize(g["src"], g["bound"])
+    np.testing.assert_allclose(out, g["out"], atol=1e-4)
+    with pytest.raises(RuntimeError):
+        oracle.tensor_resize(g["src"], np.array([[5, 5, 0, 3, 0]]))   # empty crop: torch raises too
+    assert oracle.tensor_resize(g["src"], np.zeros((0, 5), np.int64)).shape == (0, 3, 96, 96)
+
+
+@pytest.mark.parametrize("name,k", [("fine_145.npz", 2.0), ("fine_145_indoor.npz", 3.0)])
+def test_fine_layer(oracle, name, k):
+    g = golden(name)
+    B = int(g["B"])
+    inp = synth.fine_inputs(seed=int(g["seed"]), B=B)
+    assert synth.checksum(inp["d0"], inp["d1"], inp["scale_x"], inp["scale_y"]) == \
+        pytest.approx(float(g["in_checksum"]), rel=1e-12)
+    S = oracle.cost(inp["d0"], inp["d1"])
+    np.testing.assert_allclose(S.reshape(-1)[g["S_idx"]], g["S_val"], atol=2e-5, rtol=1e-5)
+    Z0 = oracle.log_optimal_transport2(S, 1.0, inp["scale_x"] * inp["scale_y"], 100)
+    np.testing.assert_allclose(np.exp(Z0).sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-5)
+    np.testing.assert_allclose(np.exp(Z0).sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-5)
+    Z = oracle.dustbin_bias(Z0, k)
+    assert_mass(Z, g["Z"])
+    r, c = oracle.argmax(Z)
+    assert np.array_equal(r[:, :-1], g["max0"]) and np.array_equal(c[:, :-1], g["max1"])
+    assert np.array_equal(r[:, :-1] == 144, g["ifn1"])
+    out = oracle.iterative_expand(np.exp(g["Z"]), inp["scale_x"], inp["scale_y"], 12, 12, 12, 1e-3, 8)
+    whole, core, avg, xs, ys, bound = out
+    assert np.array_equal(bound, g["bound"])
+    np.testing.assert_allclose(whole, g["whole_cost"], atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(core, g["core_cost"], atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(avg, g["average_point"], atol=1e-4)
+    np.testing.assert_allclose(xs, g["x_scale"], rtol=2e-5)
+    np.testing.assert_allclose(ys, g["y_scale"], rtol=2e-5)
+    bound2 = oracle.iterative_expand(np.exp(Z), inp["scale_x"], inp["scale_y"], 12, 12, 12, 1e-3, 8)[5]
+    assert np.array_equal(bound2, g["bound"])
+
+
+@pytest.mark.parametrize("name", ["third_65.npz", "third_65_indoor.npz"])
+def test_third_layer(oracle, name):
+    g = golden(name)
+    P, outdoor = int(g["P"]), bool(g["outdoor"])
+    inp = synth.third_inputs(seed=int(g["seed"]), P=P)
+    assert synth.checksum(inp["d0"], inp["d1"], inp["scale"]) == pytest.approx(float(g["in_checksum"]), rel=1e-12)
+    S = oracle.cost(inp["d0"], inp["d1"])
+    np.testing.assert_allclose(S.reshape(-1)[g["S_idx"]], g["S_val"], atol=2e-5, rtol=1e-5)
+    Z = oracle.log_optimal_transport2(S, 1.0, inp["scale"], 100)
+    assert_mass(Z, g["Z"])
+    sxy = np.sqrt(inp["scale"] + np.float32(1e-8)).astype(np.float32)
+    for Zin in (g["Z"], Z):
+        m0, m1, wl, label, ifm = oracle.compute_result(np.exp(Zin), sxy, sxy, inp["p_s"], inp["p_t"], outdoor)
+        np.testing.assert_array_equal(m0, g["mkpts0_f"])
+        np.testing.assert_allclose(m1, g["mkpts1_f"], atol=2e-4)
+        np.testing.assert_allclose(wl, g["whole_loss"], atol=1e-6)
+        assert np.array_equal(ifm, g["if_matching1"])
+        np.testing.assert_array_equal(label, g["label"])
