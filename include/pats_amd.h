@@ -1,0 +1,171 @@
+/*
+ * pats_amd.h - C ABI of libpats_amd.so: the MI355X (gfx950) implementation of the PATS
+ * patch-area optimal-transport hot path.
+ *
+ * Every entry point takes plain DEVICE pointers (fp32 / int64 / uint8, contiguous, row-major,
+ * layouts exactly as the reference's tensors) plus sizes and a HIP stream; no torch types.  All
+ * launches are asynchronous on `stream` (NULL = the default stream); nothing synchronises the
+ * device unless stated.  Return value: PATS_OK or a PATS_ERR_* code, message in pats_last_error().
+ * Inputs are never modified unless the name says `_inplace`.  Thread-safe (stateless).
+ *
+ * Citations are paths relative to the reference repository (zju3dv/pats).
+ */
+#ifndef PATS_AMD_H
+#define PATS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pats_stream_t; /* hipStream_t */
+
+enum {
+    PATS_OK = 0,
+    PATS_ERR_INVALID = 1,     /* bad shape / null pointer / workspace too small  (reference: TORCH_CHECK -> RuntimeError) */
+    PATS_ERR_UNSUPPORTED = 2, /* shape outside what the kernels cover */
+    PATS_ERR_LAUNCH = 3,      /* hip launch / runtime failure */
+    PATS_ERR_NO_DEVICE = 4
+};
+
+/* Sinkhorn arithmetic.  LOG = max-subtracted log-sum-exp sweeps exactly as
+ * models/modules.py:137-143.  KERNEL = the same fixed-point iteration carried in the linear
+ * domain on K = exp(Z + u1 + v1) after one LOG warm-up sweep (row/col normalisation by
+ * matrix-vector products, duals folded back into log space at the end), with an in-kernel guard
+ * that re-runs a problem in LOG when its scaling vectors leave the safe fp32 range.  AUTO = KERNEL
+ * where implemented, LOG otherwise. */
+enum { PATS_SINKHORN_AUTO = 0, PATS_SINKHORN_LOG = 1, PATS_SINKHORN_KERNEL = 2 };
+
+const char* pats_version(void);
+const char* pats_last_error(void);
+/* number of HIP devices visible (0 on a CPU-only box; never fails) */
+int pats_device_count(void);
+/* process-wide default for PATS_SINKHORN_AUTO (returns the previous value) */
+int pats_set_sinkhorn_mode(int mode);
+
+/* ---- a1-a3: cost build -------------------------------------------------------------------
+ * out[b,i,j] = 0.1f * ( (sum_d d0[b,d,i] * d1[b,d,j]) / sqrtf(D) )
+ * replaces  scores = einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5 ; 0.1 * scores
+ *           models/first_layer.py:110-111,114  second_layer.py:100-101,104  third_layer.py:156-158
+ * d0 [batch,D,n], d1 [batch,D,m] (channel-major), out [batch,n,m].  fp32 MFMA, fp32 accumulate. */
+int pats_cost_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m, float* out,
+                  pats_stream_t stream);
+
+/* ---- a6: log_sinkhorn_iterations(Z, log_mu, log_nu, iters)  models/modules.py:137-143 ------
+ * Z [batch,M,N], log_mu [batch,M], log_nu [batch,N] -> out [batch,M,N] = Z + u + v.
+ * workspace: pats_sinkhorn_workspace_bytes(batch, M, N) bytes of device memory (may be NULL if
+ * that returns 0). */
+size_t pats_sinkhorn_workspace_bytes(int64_t batch, int M, int N);
+int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, const float* log_mu,
+                      const float* log_nu, int iters, float* out, void* workspace,
+                      size_t workspace_bytes, pats_stream_t stream);
+
+/* ---- a4: log_optimal_transport(scores, alpha, ns, iters)  models/modules.py:145-162 --------
+ * scores [batch,m,n]; alpha: DEVICE pointer to one float (the reference's 0-d `bin_score.abs()`);
+ * ns [batch,n] target areas (the reference's [b,1,n]) -> Z [batch,m+1,n+1] log-plan with dustbin
+ * row/col, already `- norm`.  workspace: pats_ot_workspace_bytes(batch, m+1, n+1). */
+size_t pats_ot_workspace_bytes(int64_t batch, int M, int N);
+int pats_log_optimal_transport_f32(const float* scores, int64_t batch, int m, int n,
+                                   const float* alpha, const float* ns, int iters, float* Z,
+                                   void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
+/* ---- a5: log_optimal_transport2(scores, one, ns, iters)  models/modules.py:165-182 ---------
+ * scores [batch,m,n] whose last row/col are already the dustbin; one: DEVICE pointer to one float
+ * or NULL (= 1.0f); ns [batch,n-1] -> Z [batch,m,n].  bias_k > 0 additionally applies the
+ * caller's  Z[:,:,-1] += log(k); Z[:,-1,:] += log(k)  (second_layer.py:107-112); 0 = none. */
+int pats_log_optimal_transport2_f32(const float* scores, int64_t batch, int m, int n,
+                                    const float* one, const float* ns, int iters, float bias_k,
+                                    float* Z, void* workspace, size_t workspace_bytes,
+                                    pats_stream_t stream);
+
+/* ---- a1-a3 + a4/a5 fused: descriptors -> log-plan, no score matrix round trip ---------------
+ * variant 1 = log_optimal_transport (Z [batch,n+1,m+1], ns [batch,m]);
+ * variant 2 = log_optimal_transport2 (Z [batch,n,m], ns [batch,m-1]).
+ * scalar = alpha (variant 1) or one (variant 2), device pointer (NULL = 0 / 1). */
+int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
+                     int variant, const float* scalar, const float* ns, int iters, float bias_k,
+                     float* Z, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int variant);
+
+/* ---- a7: post-OT reductions ----------------------------------------------------------------
+ * colmass: out[b,j] = sqrtf(sum_{i<M-1} expf(Z[b,i,j]) + 1e-8f), j < N-1   first_layer.py:117-118
+ * bias   : Z[:,:,-1] += logf(k); Z[:,-1,:] += logf(k) in place              second_layer.py:107-112
+ * exp    : out = expf(Z)                                                    third_layer.py:159 */
+int pats_colmass_sqrt_f32(const float* Z, int64_t batch, int M, int N, float* out,
+                          pats_stream_t stream);
+int pats_dustbin_bias_inplace_f32(float* Z, int64_t batch, int M, int N, float k,
+                                  pats_stream_t stream);
+int pats_exp_f32(const float* Z, int64_t count, float* out, pats_stream_t stream);
+
+/* ---- a8: scores.max(2).indices / scores.max(1).indices, first index wins ties ---------------
+ * first_layer.py:162  second_layer.py:243.  row_arg [batch,M], col_arg [batch,N]; either NULL. */
+int pats_argmax_f32(const float* Z, int64_t batch, int M, int N, int64_t* row_arg,
+                    int64_t* col_arg, pats_stream_t stream);
+
+/* ---- a9-a11: Iterative_expand_matrix + Compute_scaling  utils/utils.py:1179-1297,1321-1340 --
+ * P [batch,M,N] = exp(Z) incl. dustbin row/col (or Z itself when input_is_log != 0: the kernel
+ * exponentiates on load, saving the exp(Z) round trip of first_layer.py:174 / second_layer.py:255);
+ * scalex, scaley [batch,N-1]; lim3 = limitation[3]; (h, w) = the TRUE grid the caller built
+ * positions/ranges for (Compute_positions_and_ranges, utils.py:1527-1537).
+ * outputs: whole_cost, core_cost, x_scale, y_scale [batch,M-1]; average_point [batch,M-1,2];
+ * bound [batch,M-1,4] int64 (up,down,left,right). */
+int pats_iterative_expand_f32(const float* P, int input_is_log, int64_t batch, int M, int N,
+                              const float* scalex, const float* scaley, int lim3, int h, int w,
+                              float lower_bound, int iter_num, float* whole_cost, float* core_cost,
+                              float* average_point, float* x_scale, float* y_scale, int64_t* bound,
+                              pats_stream_t stream);
+
+/* ---- a12: split_patches(sum_cycle, height, width, max_once_used)  utils/utils.py:152-181 ----
+ * HOST function on a host copy of the int32 cumsum (the reference syncs per comparison; here the
+ * caller pays one D->H copy).  second/third: [height+1][2] int64.  Returns cycle_num (>= 1), or
+ * a negative PATS_ERR code. */
+int pats_split_patches(const int32_t* sum_cycle_host, int height, int width, int max_once_used,
+                       int64_t* second_layer_set, int64_t* third_layer_set);
+
+/* ---- a13: Compute_imgs bounds  utils/utils.py:1350-1382 ------------------------------------
+ * x_scale, y_scale [Np]; average_point [Np,2]; if_nomatching [Np] uint8; grid (height,width).
+ * -> bound5 [Np,5] int64, only the first *K rows valid (y0,y1,x0,x1,img*10000+patch) in patch
+ *    order; K_out: DEVICE int64 count; x_scale_new, y_scale_new, average_new [Np,2]. */
+int pats_compute_imgs_bounds_f32(const float* x_scale, const float* y_scale,
+                                 const float* average_point, const uint8_t* if_nomatching, int Np,
+                                 int height, int width, int img, int64_t* bound5, int64_t* K_out,
+                                 float* x_scale_new, float* y_scale_new, float* average_new,
+                                 pats_stream_t stream);
+
+/* ---- a13: left crops = origin_extract on the 32-px padded left image  utils.py:1300-1318,1383
+ * left [H,W,3] HWC fp32; bound5/K as produced above (row k's patch index = bound5[k,4] % 10000)
+ * -> out [K,96,96,3]. K is read on the host side by the caller (max rows = K_cap). */
+int pats_left_crops_f32(const float* left, int H, int W, const int64_t* bound5, int64_t K,
+                        int height, int width, float* out, pats_stream_t stream);
+
+/* ---- a14: tensor_resize(input, bound)  setup/library.cpp:47-66 (module def :92-93) ----------
+ * input [n_img,C,Hp,Wp] fp32; bound [K,5] int64 (y0,y1,x0,x1,seq), image = seq / 10000;
+ * crop rows [y0,y1) x cols [x0,x1] -> bilinear align_corners=True -> out [K,C,96,96].
+ * One launch, no host sync (the reference does 5 .item() syncs per crop).  status: optional DEVICE
+ * int32 that is set non-zero if any crop is empty / out of range (torch raises there); the kernel
+ * itself clamps reads so it is always memory-safe.  K == 0 is a no-op. */
+int pats_tensor_resize_f32(const float* input, int n_img, int C, int Hp, int Wp,
+                           const int64_t* bound, int64_t K, float* out, int32_t* status,
+                           pats_stream_t stream);
+/* same, fused with the zero padding of utils.py:1352 and the HWC->CHW permute: reads the
+ * UNPADDED right image [n_img,H,W,3] (margin = 128) and writes [K,96,96,3] (the layout the caller
+ * permutes to at utils.py:1385). */
+int pats_tensor_resize_hwc_f32(const float* right, int n_img, int H, int W, int margin,
+                               const int64_t* bound, int64_t K, float* out, int32_t* status,
+                               pats_stream_t stream);
+
+/* ---- a17 + a18: ThirdLayer.Compute_result + match label  models/third_layer.py:161-170,184-217
+ * scores [P,65,65] = exp(Z) (or Z when input_is_log); scale_x, scale_y [P,64]; p_s, p_t [P,2]
+ * int64 -> mkpts0_f, mkpts1_f [P,16,2]; whole_loss [P,16]; label [P*16,2]; if_matching1 [P,16]
+ * uint8.  W = 8, T = 5 as in the reference. */
+int pats_compute_result_f32(const float* scores, int input_is_log, int64_t P, const float* scale_x,
+                            const float* scale_y, const int64_t* p_s, const int64_t* p_t,
+                            int outdoor, float* mkpts0_f, float* mkpts1_f, float* whole_loss,
+                            float* label, uint8_t* if_matching1, pats_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATS_AMD_H */

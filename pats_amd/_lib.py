@@ -1,0 +1,78 @@
+"""Loads libpats_amd.so (the C-ABI of include/pats_amd.h) with ctypes.
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises.  Nothing under
+oracle/ is ever imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpats_amd.so")
+
+c_void_p, c_int, c_i64, c_f, c_size = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                       ctypes.c_size_t)
+
+# name -> (restype, argtypes); must list every symbol include/pats_amd.h declares
+SIGNATURES = {
+    "pats_version": (ctypes.c_char_p, []),
+    "pats_last_error": (ctypes.c_char_p, []),
+    "pats_device_count": (c_int, []),
+    "pats_set_sinkhorn_mode": (c_int, [c_int]),
+    "pats_cost_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pats_sinkhorn_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "pats_sinkhorn_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_size, c_void_p]),
+    "pats_ot_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "pats_log_optimal_transport_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_log_optimal_transport2_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
+                                                c_f, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_cost_ot_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_void_p, c_int, c_f, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_cost_ot_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int]),
+    "pats_colmass_sqrt_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p]),
+    "pats_dustbin_bias_inplace_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_f, c_void_p]),
+    "pats_exp_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
+    "pats_argmax_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pats_iterative_expand_f32": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
+                                          c_int, c_int, c_f, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pats_split_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pats_compute_imgs_bounds_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                             c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
+    "pats_left_crops_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_int, c_void_p,
+                                    c_void_p]),
+    "pats_tensor_resize_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p,
+                                       c_void_p, c_void_p]),
+    "pats_tensor_resize_hwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64,
+                                           c_void_p, c_void_p, c_void_p]),
+    "pats_compute_result_f32": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "pats_amd: %s is missing - the HIP extension was not built (run "
+                "`python -m pats_amd.build` / __graft_entry__.build()). There is no CPU fallback."
+                % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)     # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pats_last_error().decode()
+        raise RuntimeError("pats_amd.%s failed (code %d): %s" % (what, rc, msg))

@@ -1,0 +1,63 @@
+"""Builds pats_amd/libpats_amd.so (hipcc, gfx950 only) in-tree.  Called by __graft_entry__.build()."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpats_amd.so")
+SOURCES = ["host.cpp", "sinkhorn.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip",
+           "fused.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found - libpats_amd.so cannot be built")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pats_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        spath = os.path.join(CSRC, src)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
+                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, "common.hpp"))
+                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(HERE, "..", "include", "pats_amd.h"))):
+            continue
+        cmd = [hipcc()] + FLAGS + ["-c", spath, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on %s" % src)
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

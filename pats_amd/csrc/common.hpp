@@ -1,0 +1,100 @@
+// Shared host/device helpers for libpats_amd.so (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/pats_amd.h"
+
+namespace pats {
+
+constexpr int WAVE = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float ZERO_F = 1e-14f;  // the reference's `zero` (utils/utils.py:1201)
+
+// ---- error plumbing ----------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PATS_REQUIRE(cond, ...)               \
+    do {                                      \
+        if (!(cond)) {                        \
+            pats::set_error(__VA_ARGS__);     \
+            return PATS_ERR_INVALID;          \
+        }                                     \
+    } while (0)
+
+// ---- wave-level reductions: 4 DPP steps inside each 16-lane row, then two half-swaps -------
+// Every lane ends up with the full 64-lane result (all-reduce).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+struct OpSum {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+struct OpMax {
+    __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
+};
+
+template <class Op>
+__device__ __forceinline__ float wave_allreduce(float v, Op op) {
+    v = op(v, dpp_f<DPP_QUAD_XOR1>(v));
+    v = op(v, dpp_f<DPP_QUAD_XOR2>(v));
+    v = op(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+    v = op(v, dpp_f<DPP_ROW_MIRROR>(v));
+    // rows of 16 now hold their totals; exchange rows 0<->1, 2<->3 then halves 0<->1
+    {
+        unsigned x = __builtin_bit_cast(unsigned, v);
+        auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    }
+    {
+        unsigned x = __builtin_bit_cast(unsigned, v);
+        auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce(v, OpSum()); }
+__device__ __forceinline__ float wave_max(float v) { return wave_allreduce(v, OpMax()); }
+
+// argmax all-reduce with first-index tie-break (ATen CPU semantics relied on at
+// first_layer.py:162, utils.py:1182,1232, third_layer.py:188)
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float ov = __shfl_xor(v, off);
+        int oi = __shfl_xor(i, off);
+        argmax_combine(v, i, ov, oi);
+    }
+}
+
+// raw transcendental units (v_exp_f32 = 2^x, v_log_f32 = log2 x): no denormal range fix-up code.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+inline hipStream_t as_stream(pats_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace pats

@@ -1,0 +1,41 @@
+// Descriptor -> log-plan in one call (cost build feeding the OT solve).
+//   variant 1: first_layer.py:110-115   (einsum, /sqrt(D), 0.1*, log_optimal_transport)
+//   variant 2: second_layer.py:100-105 / third_layer.py:156-158 (log_optimal_transport2)
+// The score matrix lives only in the caller's workspace (L2 / Infinity-Cache resident between the
+// MFMA kernel and the Sinkhorn kernel on the same stream); nothing is returned to the host side.
+#include "common.hpp"
+
+using namespace pats;
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int variant) {
+    (void)D;
+    const size_t scores = align256((size_t)batch * n * m * sizeof(float));
+    const int M = variant == 1 ? n + 1 : n, N = variant == 1 ? m + 1 : m;
+    return scores + pats_ot_workspace_bytes(batch, M, N);
+}
+
+extern "C" int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
+                                int variant, const float* scalar, const float* ns, int iters,
+                                float bias_k, float* Z, void* workspace, size_t workspace_bytes,
+                                pats_stream_t stream) {
+    PATS_REQUIRE(variant == 1 || variant == 2, "cost_ot: variant must be 1 or 2");
+    PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost_ot: bad shape");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_cost_ot_workspace_bytes(batch, D, n, m, variant),
+                 "cost_ot: workspace too small");
+    float* scores = (float*)workspace;
+    const size_t off = align256((size_t)batch * n * m * sizeof(float));
+    void* ws2 = (char*)workspace + off;
+    int rc = pats_cost_f32(d0, d1, batch, D, n, m, scores, stream);
+    if (rc) return rc;
+    if (variant == 1) {
+        PATS_REQUIRE(scalar, "cost_ot: alpha pointer required for variant 1");
+        PATS_REQUIRE(bias_k == 0.f, "cost_ot: bias only applies to variant 2");
+        return pats_log_optimal_transport_f32(scores, batch, n, m, scalar, ns, iters, Z, ws2,
+                                              workspace_bytes - off, stream);
+    }
+    return pats_log_optimal_transport2_f32(scores, batch, n, m, scalar, ns, iters, bias_k, Z, ws2,
+                                           workspace_bytes - off, stream);
+}

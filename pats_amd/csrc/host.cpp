@@ -1,0 +1,89 @@
+// Host-side pieces of libpats_amd.so: error plumbing, version, and the chunk planner.
+#include "common.hpp"
+
+#include <string>
+
+namespace pats {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return e == hipErrorNoDevice ? PATS_ERR_NO_DEVICE : PATS_ERR_LAUNCH;
+    }
+    return PATS_OK;
+}
+
+static int g_mode = PATS_SINKHORN_AUTO;
+int sinkhorn_mode() { return g_mode; }
+
+}  // namespace pats
+
+using namespace pats;
+
+extern "C" const char* pats_version(void) { return "pats_amd 0.1.0 (gfx950)"; }
+
+extern "C" const char* pats_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int pats_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int pats_set_sinkhorn_mode(int mode) {
+    const int prev = g_mode;
+    if (mode == PATS_SINKHORN_AUTO || mode == PATS_SINKHORN_LOG || mode == PATS_SINKHORN_KERNEL)
+        g_mode = mode;
+    return prev;
+}
+
+// split_patches, utils/utils.py:152-181.  Greedy row-aligned chunking of the matched coarse
+// patches: a chunk closes at the first grid row whose cumulative match count exceeds
+// max_once_used * (chunks so far + 1); chunks overlap by one grid row (the third_layer_set pair
+// says how many leading / trailing patches of a chunk belong to the neighbouring chunk).
+// Python's negative index sum_cycle[i*width - 1] at i == 0 (last element) is reproduced.
+extern "C" int pats_split_patches(const int32_t* sc, int height, int width, int max_once_used,
+                                  int64_t* second, int64_t* third) {
+    if (!sc || !second || !third || height <= 0 || width <= 0 || max_once_used <= 0) {
+        set_error("split_patches: bad argument");
+        return -PATS_ERR_INVALID;
+    }
+    const int64_t L = (int64_t)height * width;
+    auto at = [&](int64_t i) -> int64_t { return sc[((i % L) + L) % L]; };
+    int cycle = 0, last_second = 0, last_third = 0;
+    for (int i = 0; i < height; ++i) {
+        const int64_t num = at((int64_t)(i + 1) * width - 1);
+        if (num > (int64_t)max_once_used * (cycle + 1)) {
+            const int64_t origin = last_second == 0 ? 0 : at((int64_t)last_second * width - 1);
+            second[2 * cycle] = origin;
+            second[2 * cycle + 1] = num;
+            third[2 * cycle] = at((int64_t)last_third * width) - origin;
+            third[2 * cycle + 1] = num - at((int64_t)i * width - 1);
+            ++cycle;
+            last_second = i;
+            last_third = i + 1;
+        }
+    }
+    const int64_t origin = last_second == 0 ? 0 : at((int64_t)last_second * width - 1);
+    second[2 * cycle] = origin;
+    second[2 * cycle + 1] = L;
+    const int64_t end_num = (last_third == height) ? origin : at((int64_t)last_third * width);
+    third[2 * cycle] = end_num - origin;
+    third[2 * cycle + 1] = 0;
+    return cycle + 1;
+}

@@ -1,0 +1,141 @@
+// Post-OT reductions and argmax for PATS on gfx950.
+//   colmass : scales = sqrt(exp(Z[:, :-1, :-1]).sum(1) + 1e-8)          models/first_layer.py:117-118
+//   bias    : Z[:, :, -1] += log(k); Z[:, -1, :] += log(k)              models/second_layer.py:107-112
+//   exp     : torch.exp(scores_origin)                                  models/third_layer.py:159
+//   argmax  : scores.max(2).indices, scores.max(1).indices (first index on ties)
+//                                                   first_layer.py:162  second_layer.py:243
+// All HBM-bound single-pass kernels; column-direction work maps lanes to consecutive columns so
+// every wave load is one contiguous segment.
+#include "common.hpp"
+
+namespace pats {
+
+__global__ void __launch_bounds__(256)
+colmass_kernel(const float* __restrict__ Z, int M, int N, float* __restrict__ out) {
+    const int64_t b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N - 1) return;
+    const float* z = Z + b * (int64_t)M * N + j;
+    float s0 = 0.f, s1 = 0.f;
+    int i = 0;
+    for (; i + 1 < M - 1; i += 2) {
+        s0 += expf(z[(int64_t)i * N]);
+        s1 += expf(z[(int64_t)(i + 1) * N]);
+    }
+    if (i < M - 1) s0 += expf(z[(int64_t)i * N]);
+    out[b * (N - 1) + j] = sqrtf((s0 + s1) + 1e-8f);
+}
+
+__global__ void __launch_bounds__(256)
+bias_kernel(float* __restrict__ Z, int M, int N, float lb) {
+    const int64_t b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float* z = Z + b * (int64_t)M * N;
+    // in-place adds of second_layer.py:108-109: column first, then row; the corner gets both
+    if (t < M - 1) z[(int64_t)t * N + (N - 1)] += lb;
+    if (t < N - 1) z[(int64_t)(M - 1) * N + t] += lb;
+    if (t == 0) {
+        float c = z[(int64_t)(M - 1) * N + (N - 1)];
+        c += lb;
+        c += lb;
+        z[(int64_t)(M - 1) * N + (N - 1)] = c;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+exp_kernel(const float* __restrict__ in, int64_t count, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < count; i += stride) out[i] = expf(in[i]);
+}
+
+// one wave per row
+__global__ void __launch_bounds__(256)
+argmax_rows_kernel(const float* __restrict__ Z, int64_t rows, int N, int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* z = Z + row * (int64_t)N;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < N; j += 64) {
+        const float x = z[j];
+        if (x > bv || bi == 0x7fffffff) { bv = x; bi = j; }
+    }
+    wave_argmax(bv, bi);
+    if (lane == 0) out[row] = bi;
+}
+
+// one thread per column
+__global__ void __launch_bounds__(256)
+argmax_cols_kernel(const float* __restrict__ Z, int M, int N, int64_t* __restrict__ out) {
+    const int64_t b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float* z = Z + b * (int64_t)M * N + j;
+    float bv = z[0];
+    int bi = 0;
+    for (int i = 1; i < M; ++i) {
+        const float x = z[(int64_t)i * N];
+        if (x > bv) { bv = x; bi = i; }
+    }
+    out[b * N + j] = bi;
+}
+
+}  // namespace pats
+
+using namespace pats;
+
+extern "C" int pats_colmass_sqrt_f32(const float* Z, int64_t batch, int M, int N, float* out,
+                                     pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && M > 1 && N > 1, "colmass: bad shape");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(Z && out, "colmass: null pointer");
+    PATS_REQUIRE(batch <= 65535, "colmass: batch too large");
+    hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)batch),
+                       dim3(256), 0, as_stream(stream), Z, M, N, out);
+    return check_launch("colmass_kernel");
+}
+
+extern "C" int pats_dustbin_bias_inplace_f32(float* Z, int64_t batch, int M, int N, float k,
+                                             pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && M > 0 && N > 0 && k > 0.f, "dustbin_bias: bad argument");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(Z, "dustbin_bias: null pointer");
+    PATS_REQUIRE(batch <= 65535, "dustbin_bias: batch too large");
+    const int len = M > N ? M : N;
+    hipLaunchKernelGGL(bias_kernel, dim3((unsigned)ceil_div(len, 256), (unsigned)batch), dim3(256),
+                       0, as_stream(stream), Z, M, N, logf(1.0f * k));
+    return check_launch("bias_kernel");
+}
+
+extern "C" int pats_exp_f32(const float* Z, int64_t count, float* out, pats_stream_t stream) {
+    PATS_REQUIRE(count >= 0, "exp: bad count");
+    if (count == 0) return PATS_OK;
+    PATS_REQUIRE(Z && out, "exp: null pointer");
+    const int64_t blocks = ceil_div(count, 256);
+    hipLaunchKernelGGL(exp_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       as_stream(stream), Z, count, out);
+    return check_launch("exp_kernel");
+}
+
+extern "C" int pats_argmax_f32(const float* Z, int64_t batch, int M, int N, int64_t* row_arg,
+                               int64_t* col_arg, pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && M > 0 && N > 0, "argmax: bad shape");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(Z, "argmax: null pointer");
+    PATS_REQUIRE(batch <= 65535, "argmax: batch too large");
+    if (row_arg) {
+        const int64_t rows = batch * M;
+        hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0,
+                           as_stream(stream), Z, rows, N, row_arg);
+        int rc = check_launch("argmax_rows_kernel");
+        if (rc) return rc;
+    }
+    if (col_arg) {
+        hipLaunchKernelGGL(argmax_cols_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)batch),
+                           dim3(256), 0, as_stream(stream), Z, M, N, col_arg);
+        return check_launch("argmax_cols_kernel");
+    }
+    return PATS_OK;
+}

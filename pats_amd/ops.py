@@ -1,0 +1,384 @@
+"""Host-side mirror of the reference's operator surface for the OT hot path.
+
+Same names, positional arguments, dtypes and return shapes as the reference's Python functions, so
+the parity tests read like the reference's own call sites; each function is a thin shim that
+hands raw device pointers to the C-ABI of include/pats_amd.h (libpats_amd.so, hand-written HIP for
+gfx950).  PyTorch is used for device memory and streams only.  Tensors must live on a HIP device
+("cuda" in torch-ROCm); there is no CPU path and no fallback.
+
+Reference call sites (paths relative to zju3dv/pats):
+  log_sinkhorn_iterations / log_optimal_transport / log_optimal_transport2   models/modules.py:137-182
+  cost (einsum + scale)            models/first_layer.py:110-114 second_layer.py:100-104 third_layer.py:156-158
+  Compute_positions_and_ranges     utils/utils.py:1527-1537
+  Iterative_expand_matrix          utils/utils.py:1179-1297
+  est_position (first / second)    models/first_layer.py:159-178  models/second_layer.py:240-259
+  split_patches                    utils/utils.py:152-181
+  Compute_imgs / tensor_resize     utils/utils.py:1343-1393  setup/library.cpp:47-66
+  Compute_result / third label     models/third_layer.py:161-170,184-217
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_L = _lib.lib
+_check = _lib.check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("pats_amd: %s is on %s; the HIP path needs a GPU tensor (no CPU fallback)"
+                           % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("pats_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+def _scalar_dev(x, device):
+    """0-d tensor / python float -> device float32[1] without a device sync."""
+    if isinstance(x, torch.Tensor):
+        return x.detach().reshape(1).to(device=device, dtype=torch.float32)
+    return torch.full((1,), float(x), dtype=torch.float32, device=device)
+
+
+def set_sinkhorn_mode(mode):
+    """'auto' | 'log' | 'kernel' (include/pats_amd.h PATS_SINKHORN_*). Returns the previous mode."""
+    names = {"auto": 0, "log": 1, "kernel": 2}
+    prev = _L().pats_set_sinkhorn_mode(names[mode])
+    return {v: k for k, v in names.items()}[prev]
+
+
+# ------------------------------------------------------------------------------------------------
+# cost build
+# ------------------------------------------------------------------------------------------------
+def cost(mdesc0, mdesc1):
+    """0.1 * (einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5)   (first_layer.py:110-114)."""
+    d0, d1 = _dev(mdesc0, "mdesc0"), _dev(mdesc1, "mdesc1")
+    b, D, n = d0.shape
+    if d1.shape[0] != b or d1.shape[1] != D:
+        raise RuntimeError("cost: descriptor shapes %s / %s do not match" % (tuple(d0.shape), tuple(d1.shape)))
+    m = d1.shape[2]
+    out = torch.empty((b, n, m), dtype=torch.float32, device=d0.device)
+    _check(_L().pats_cost_f32(_ptr(d0), _ptr(d1), b, D, n, m, _ptr(out), _stream()), "cost")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Sinkhorn / OT
+# ------------------------------------------------------------------------------------------------
+def log_sinkhorn_iterations(Z, log_mu, log_nu, iters: int):
+    Z, log_mu, log_nu = _dev(Z, "Z"), _dev(log_mu, "log_mu"), _dev(log_nu, "log_nu")
+    b, M, N = Z.shape
+    if tuple(log_mu.shape) != (b, M) or tuple(log_nu.shape) != (b, N):
+        raise RuntimeError("log_sinkhorn_iterations: marginal shapes do not match Z")
+    out = torch.empty_like(Z)
+    nb = _L().pats_sinkhorn_workspace_bytes(b, M, N)
+    ws = _workspace(nb, Z.device)
+    _check(_L().pats_sinkhorn_f32(_ptr(Z), b, M, N, _ptr(log_mu), _ptr(log_nu), int(iters), _ptr(out),
+                                  _ptr(ws), nb, _stream()), "log_sinkhorn_iterations")
+    return out
+
+
+def log_optimal_transport(scores, alpha, ns, iters: int):
+    scores = _dev(scores, "scores")
+    b, m, n = scores.shape
+    ns = _dev(ns, "ns").reshape(b, -1)
+    if ns.shape[1] != n:
+        raise RuntimeError("log_optimal_transport: ns must have %d entries per batch" % n)
+    a = _scalar_dev(alpha, scores.device)
+    Z = torch.empty((b, m + 1, n + 1), dtype=torch.float32, device=scores.device)
+    nb = _L().pats_ot_workspace_bytes(b, m + 1, n + 1)
+    ws = _workspace(nb, scores.device)
+    _check(_L().pats_log_optimal_transport_f32(_ptr(scores), b, m, n, _ptr(a), _ptr(ns), int(iters),
+                                               _ptr(Z), _ptr(ws), nb, _stream()), "log_optimal_transport")
+    return Z
+
+
+def log_optimal_transport2(scores, one, ns, iters: int, bias_k: float = 0.0):
+    """bias_k = 2 (outdoor) / 3 (indoor) folds the caller's dustbin `+= log(k)` of
+    second_layer.py:107-112 into the epilogue; 0 returns exactly modules.py:165-182."""
+    scores = _dev(scores, "scores")
+    b, m, n = scores.shape
+    ns = _dev(ns, "ns").reshape(b, -1)
+    if ns.shape[1] != n - 1:
+        raise RuntimeError("log_optimal_transport2: ns must have %d entries per batch" % (n - 1))
+    o = _scalar_dev(one, scores.device)
+    Z = torch.empty((b, m, n), dtype=torch.float32, device=scores.device)
+    nb = _L().pats_ot_workspace_bytes(b, m, n)
+    ws = _workspace(nb, scores.device)
+    _check(_L().pats_log_optimal_transport2_f32(_ptr(scores), b, m, n, _ptr(o), _ptr(ns), int(iters),
+                                                float(bias_k), _ptr(Z), _ptr(ws), nb, _stream()),
+           "log_optimal_transport2")
+    return Z
+
+
+def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0):
+    """descriptors -> log-plan (cost build + OT on one stream, score matrix never returned)."""
+    d0, d1 = _dev(mdesc0, "mdesc0"), _dev(mdesc1, "mdesc1")
+    b, D, n = d0.shape
+    m = d1.shape[2]
+    ns = _dev(ns, "ns").reshape(b, -1)
+    s = _scalar_dev(scalar, d0.device)
+    shape = (b, n + 1, m + 1) if variant == 1 else (b, n, m)
+    Z = torch.empty(shape, dtype=torch.float32, device=d0.device)
+    nb = _L().pats_cost_ot_workspace_bytes(b, D, n, m, variant)
+    ws = _workspace(nb, d0.device)
+    _check(_L().pats_cost_ot_f32(_ptr(d0), _ptr(d1), b, D, n, m, int(variant), _ptr(s), _ptr(ns),
+                                 int(iters), float(bias_k), _ptr(Z), _ptr(ws), nb, _stream()), "cost_ot")
+    return Z
+
+
+# ------------------------------------------------------------------------------------------------
+# post-OT
+# ------------------------------------------------------------------------------------------------
+def colmass_sqrt(Z):
+    """sqrt(exp(Z[:, :-1, :-1]).sum(1) + 1e-8)   (first_layer.py:117-118)."""
+    Z = _dev(Z, "Z")
+    b, M, N = Z.shape
+    out = torch.empty((b, N - 1), dtype=torch.float32, device=Z.device)
+    _check(_L().pats_colmass_sqrt_f32(_ptr(Z), b, M, N, _ptr(out), _stream()), "colmass_sqrt")
+    return out
+
+
+def dustbin_bias_(Z, k):
+    """In place: Z[:, :, -1] += log(k); Z[:, -1, :] += log(k)   (second_layer.py:107-112)."""
+    if not Z.is_contiguous():
+        raise RuntimeError("dustbin_bias_: Z must be contiguous (in-place op)")
+    _dev(Z, "Z")
+    b, M, N = Z.shape
+    _check(_L().pats_dustbin_bias_inplace_f32(_ptr(Z), b, M, N, float(k), _stream()), "dustbin_bias_")
+    return Z
+
+
+def exp(Z):
+    Z = _dev(Z, "Z")
+    out = torch.empty_like(Z)
+    _check(_L().pats_exp_f32(_ptr(Z), Z.numel(), _ptr(out), _stream()), "exp")
+    return out
+
+
+def argmax(Z):
+    """(scores.max(2).indices, scores.max(1).indices), first index on ties (first_layer.py:162)."""
+    Z = _dev(Z, "Z")
+    b, M, N = Z.shape
+    r = torch.empty((b, M), dtype=torch.int64, device=Z.device)
+    c = torch.empty((b, N), dtype=torch.int64, device=Z.device)
+    _check(_L().pats_argmax_f32(_ptr(Z), b, M, N, _ptr(r), _ptr(c), _stream()), "argmax")
+    return r, c
+
+
+# ------------------------------------------------------------------------------------------------
+# patch-area expansion
+# ------------------------------------------------------------------------------------------------
+def Compute_positions_and_ranges(height, width, device):
+    """utils/utils.py:1527-1537.  The returned tensors carry the grid as `_pats_grid` so
+    Iterative_expand_matrix does not have to read them back from the device."""
+    k = torch.arange(height * width)
+    positions = torch.stack([(k // width).float(), (k % width).float()], dim=1)
+    max_shape = max(height, width)
+    kk = torch.arange(max_shape).float()
+    ranges = torch.where(kk[None, :] <= kk[:, None], kk[None, :].expand(max_shape, -1),
+                         torch.full((max_shape, max_shape), 1e7))
+    positions, ranges = positions.to(device), ranges.to(device)
+    positions._pats_grid = (int(height), int(width))
+    ranges._pats_grid = (int(height), int(width))
+    return positions, ranges
+
+
+def _grid_of(positions, ranges):
+    g = getattr(positions, "_pats_grid", None) or getattr(ranges, "_pats_grid", None)
+    if g is not None:
+        return g
+    # foreign tensors: recover (h, w) from the values (one device read)
+    w = int((positions[:, 0] == 0).sum().item())
+    return positions.shape[0] // w, w
+
+
+def Iterative_expand_matrix(scores_in, scalex, scaley, limitation, ranges, positions,
+                            lower_bound=1e-3, upper_bound=1e7, iter_num=15, width=20, height=15,
+                            type="distance", input_is_log=False):
+    """utils/utils.py:1179-1297.  Returns (whole_cost, core_cost, average_point, x_scale, y_scale,
+    bound) with the reference's shapes/dtypes.  `width`/`height`/`upper_bound`/`type` are accepted
+    and ignored exactly as the reference ignores them (it re-derives width/height at :1181)."""
+    P = _dev(scores_in, "scores_in")
+    b, M, N = P.shape
+    sx = _dev(scalex, "scalex").reshape(b, -1)
+    sy = _dev(scaley, "scaley").reshape(b, -1)
+    if sx.shape[1] != N - 1 or sy.shape[1] != N - 1:
+        raise RuntimeError("Iterative_expand_matrix: scale tensors must have %d entries" % (N - 1))
+    h, w = _grid_of(positions, ranges)
+    if isinstance(limitation, torch.Tensor):
+        lim3 = getattr(limitation, "_pats_lim3", None)
+        if lim3 is None:
+            lim3 = int(limitation[3].item())
+    else:
+        lim3 = int(limitation[3])
+    m = M - 1
+    dev = P.device
+    whole = torch.empty((b, m), dtype=torch.float32, device=dev)
+    core = torch.empty((b, m), dtype=torch.float32, device=dev)
+    avg = torch.empty((b, m, 2), dtype=torch.float32, device=dev)
+    xs = torch.empty((b, m), dtype=torch.float32, device=dev)
+    ys = torch.empty((b, m), dtype=torch.float32, device=dev)
+    bound = torch.empty((b, m, 4), dtype=torch.int64, device=dev)
+    _check(_L().pats_iterative_expand_f32(_ptr(P), int(bool(input_is_log)), b, M, N, _ptr(sx), _ptr(sy),
+                                          lim3, h, w, float(lower_bound), int(iter_num), _ptr(whole),
+                                          _ptr(core), _ptr(avg), _ptr(xs), _ptr(ys), _ptr(bound),
+                                          _stream()), "Iterative_expand_matrix")
+    return whole, core, avg, xs, ys, bound
+
+
+def _est_position(scores, scale_x, scale_y, H, W, patch_scale, iter_num, lower_bound):
+    b = scores.shape[0]
+    h, w = H // patch_scale, W // patch_scale
+    max0, max1 = argmax(scores)
+    max0, max1 = max0[:, :-1], max1[:, :-1]
+    if_nomatching1 = max0 == h * w
+    if_nomatching2 = max1 == h * w
+    positions1, ranges1 = Compute_positions_and_ranges(h, w, scores.device)
+    limitation1 = [0, h, 0, w]
+    trust_score, _, average_point1, x_scale, y_scale, _ = Iterative_expand_matrix(
+        scores, scale_x.reshape(b, -1, 1), scale_y.reshape(b, -1, 1), limitation1, ranges1, positions1,
+        height=h, width=w, iter_num=iter_num, lower_bound=lower_bound, input_is_log=True)
+    return trust_score, average_point1, x_scale, y_scale, if_nomatching1, if_nomatching2
+
+
+def est_position_first(scores, scale_src, image_shape, patch_scale):
+    """FirstLayer.est_position (first_layer.py:159-178): scores is the LOG plan; exp() is fused
+    into the expansion kernel's load."""
+    H, W = image_shape
+    return _est_position(scores, scale_src, scale_src, H, W, patch_scale, 15, 1e-5)
+
+
+def est_position_second(scores, scale_x, scale_y, image_shape, patch_scale):
+    """SecondLayer.est_position (second_layer.py:240-259)."""
+    H, W = image_shape
+    return _est_position(scores, scale_x, scale_y, H, W, patch_scale, 8, 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# chunk planner (host)
+# ------------------------------------------------------------------------------------------------
+def split_patches(sum_cycle, height, width, max_once_used=350):
+    """utils/utils.py:152-181.  One D->H copy of the cumsum, then host C++."""
+    sc = sum_cycle.detach().to("cpu", torch.int32).contiguous().numpy()
+    if sc.shape[0] != height * width:
+        raise RuntimeError("split_patches: sum_cycle must have height*width entries")
+    second = np.zeros((height + 1, 2), np.int64)
+    third = np.zeros((height + 1, 2), np.int64)
+    n = _L().pats_split_patches(sc.ctypes.data_as(ctypes.c_void_p), int(height), int(width),
+                                int(max_once_used), second.ctypes.data_as(ctypes.c_void_p),
+                                third.ctypes.data_as(ctypes.c_void_p))
+    if n < 1:
+        _check(-n, "split_patches")
+    return n, second[:n].tolist(), third[:n].tolist()
+
+
+# ------------------------------------------------------------------------------------------------
+# subdivision gather
+# ------------------------------------------------------------------------------------------------
+def tensor_resize(input_tensor, bound):
+    """tensor_resize.tensor_resize(input, bound)  (setup/library.cpp:47-66,92-93).
+    input [n,C,Hp,Wp] float32, bound [K,5] int64 -> new [K,C,96,96] float32 on input.device."""
+    inp = _dev(input_tensor, "input_tensor")
+    bnd = _dev(bound, "bound", torch.int64)
+    if inp.dim() != 4 or bnd.dim() != 2 or bnd.shape[1] != 5:
+        raise RuntimeError("tensor_resize: expected input [n,C,H,W] and bound [K,5]")
+    n_img, C, Hp, Wp = inp.shape
+    K = bnd.shape[0]
+    out = torch.empty((K, C, 96, 96), dtype=torch.float32, device=inp.device)
+    _check(_L().pats_tensor_resize_f32(_ptr(inp), n_img, C, Hp, Wp, _ptr(bnd), K, _ptr(out),
+                                       ctypes.c_void_p(0), _stream()), "tensor_resize")
+    return out
+
+
+def Compute_imgs(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num=0,
+                 output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32):
+    """utils/utils.py:1343-1393 - same 5-tuple as the reference."""
+    return Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num,
+                           output_path, if_view, margin, width, height, patch_scale)[:5]
+
+
+def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num=0,
+                    output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32):
+    """Compute_imgs plus the [K,5] bound tensor the reference hands to tensor_resize (utils.py:1382).
+    utils/utils.py:1343-1393 for batch 1 (the reference's only mode, first_layer.py:135).
+    Returns (new_left [K,96,96,3], new_right [K,96,96,3], x_scale_new [1,N,2], y_scale_new
+    [1,N,2], average_new [1,N,2]).  One host read (K) sizes the outputs, as the reference's
+    boolean-mask indexing does."""
+    if margin != 128 or patch_scale != 32:
+        raise RuntimeError("Compute_imgs: margin=128 / patch_scale=32 are what the path uses")
+    if left.shape[0] != 1:
+        raise RuntimeError("Compute_imgs: batch 1 only (as PATS.forward, first_layer.py:135)")
+    dev = x_scale.device
+    Np = width * height
+    xs = _dev(x_scale.float(), "x_scale").reshape(-1)
+    ys = _dev(y_scale.float(), "y_scale").reshape(-1)
+    ap = _dev(average_point.float(), "average_point").reshape(-1, 2)
+    ifn = _dev(if_nomatching.to(torch.uint8), "if_nomatching", torch.uint8).reshape(-1)
+    leftf = _dev(left.float(), "left")
+    rightf = _dev(right.float(), "right")
+    H, W = leftf.shape[1], leftf.shape[2]
+    bound5 = torch.empty((Np, 5), dtype=torch.int64, device=dev)
+    Kd = torch.empty((1,), dtype=torch.int64, device=dev)
+    xsn = torch.empty((1, Np, 2), dtype=torch.float32, device=dev)
+    ysn = torch.empty((1, Np, 2), dtype=torch.float32, device=dev)
+    avn = torch.empty((1, Np, 2), dtype=torch.float32, device=dev)
+    _check(_L().pats_compute_imgs_bounds_f32(_ptr(xs), _ptr(ys), _ptr(ap), _ptr(ifn), Np, height, width,
+                                             0, _ptr(bound5), _ptr(Kd), _ptr(xsn), _ptr(ysn), _ptr(avn),
+                                             _stream()), "Compute_imgs(bounds)")
+    K = int(Kd.item())
+    new_left = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
+    new_right = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
+    _check(_L().pats_left_crops_f32(_ptr(leftf), H, W, _ptr(bound5), K, height, width, _ptr(new_left),
+                                    _stream()), "Compute_imgs(left)")
+    _check(_L().pats_tensor_resize_hwc_f32(_ptr(rightf), 1, H, W, margin, _ptr(bound5), K,
+                                           _ptr(new_right), ctypes.c_void_p(0), _stream()),
+           "Compute_imgs(right)")
+    new_left = new_left.to(left.dtype) if left.dtype != torch.float32 else new_left
+    return new_left, new_right, xsn, ysn, avn, bound5[:K]
+
+
+# ------------------------------------------------------------------------------------------------
+# third level
+# ------------------------------------------------------------------------------------------------
+def Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device=None, outdoor=True,
+                   input_is_log=False):
+    """ThirdLayer.Compute_result (third_layer.py:184-217) + the label rule (:161-170).
+    Returns (mkpts0_f, mkpts1_f, whole_loss, label, if_matching1)."""
+    if W != 8 or T != 5:
+        raise RuntimeError("Compute_result: the path uses W=8, T=5 (third_layer.py:108-111)")
+    S = _dev(scores, "scores")
+    P = S.shape[0]
+    if tuple(S.shape[1:]) != (65, 65):
+        raise RuntimeError("Compute_result: scores must be [P,65,65]")
+    sx = _dev(scale_x, "scale_x").reshape(P, 64)
+    sy = _dev(scale_y, "scale_y").reshape(P, 64)
+    ps = _dev(p_s.to(torch.int64), "p_s", torch.int64).reshape(P, 2)
+    pt = _dev(p_t.to(torch.int64), "p_t", torch.int64).reshape(P, 2)
+    dev = S.device
+    m0 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
+    m1 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
+    wl = torch.empty((P, 16), dtype=torch.float32, device=dev)
+    label = torch.empty((P * 16, 2), dtype=torch.float32, device=dev)
+    ifm = torch.empty((P, 16), dtype=torch.uint8, device=dev)
+    _check(_L().pats_compute_result_f32(_ptr(S), int(bool(input_is_log)), P, _ptr(sx), _ptr(sy), _ptr(ps),
+                                        _ptr(pt), int(bool(outdoor)), _ptr(m0), _ptr(m1), _ptr(wl),
+                                        _ptr(label), _ptr(ifm), _stream()), "Compute_result")
+    return m0, m1, wl, label, ifm.bool()

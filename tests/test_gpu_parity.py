@@ -1,0 +1,313 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C-ABI, via pats_amd.ops) against
+ (a) the golden fixtures the REFERENCE produced (tests/golden, tools/make_golden.py) and
+ (b) the CPU oracle on the same seeded inputs,
+plus size-independent properties at the reference's full sizes.
+Gates: indices identical; |exp(Z)_hip - exp(Z)_ref| <= 1e-4 element-wise and on
+marginals; crops <= 1e-4 abs on 0-255 data.  Nothing here reads /root/reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, golden
+from pats_amd import synth
+
+pytestmark = pytest.mark.gpu
+MASS_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from pats_amd import ops as o
+    return o
+
+
+def cu(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def assert_mass(Zh, Zr):
+    Zh = Zh.detach().cpu().numpy() if isinstance(Zh, torch.Tensor) else Zh
+    eo, er = np.exp(Zh.astype(np.float64)), np.exp(np.asarray(Zr).astype(np.float64))
+    assert np.abs(eo - er).max() <= MASS_TOL
+    np.testing.assert_allclose(eo.sum(-1), er.sum(-1), atol=MASS_TOL, rtol=1e-6)
+    np.testing.assert_allclose(eo.sum(-2), er.sum(-2), atol=MASS_TOL, rtol=1e-6)
+    big = er > 1e-6
+    assert np.abs(Zh[big] - np.asarray(Zr)[big]).max() <= 2e-4
+
+
+def test_native_library_loaded(ops):
+    from pats_amd import _lib
+    maps = open("/proc/self/maps").read()
+    assert "libpats_amd.so" in maps and _lib.lib().pats_device_count() >= 1
+
+
+# ---- OT known answers and edge shapes ----------------------------------------------------------
+def test_kat(ops):
+    g = golden("ot_kat.npz")
+    z1 = ops.log_optimal_transport(cu(g["s1"]), float(g["a1"]), cu(g["n1"]), 100)
+    assert z1.shape == (1, 3, 4)
+    assert_mass(z1, g["z1"])
+    z1b = ops.log_optimal_transport(cu(g["s1"]), cu(g["a1"]), cu(g["n1"]), 100)   # 0-d tensor alpha
+    assert torch.equal(z1, z1b)
+    z2 = ops.log_optimal_transport2(cu(g["s2"]), cu(np.float32(1.0)), cu(g["n2"]), 100)
+    assert_mass(z2, g["z2"])
+
+
+@pytest.mark.parametrize("iters", [1, 3, 100])
+def test_sinkhorn_raw_ragged(ops, iters):
+    g = golden("sinkhorn_raw.npz")
+    out = ops.log_sinkhorn_iterations(cu(g["Z"]), cu(g["log_mu"]), cu(g["log_nu"]), iters)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out%d" % iters], atol=3e-5, rtol=0)
+
+
+def test_exact_ties_first_index(ops):
+    g = golden("ot_ties.npz")
+    z = ops.log_optimal_transport(cu(g["s"]), float(g["alpha"]), cu(g["ns"]), 100)
+    assert_mass(z, g["z"])
+    r, c = ops.argmax(z)
+    assert np.array_equal(r.cpu().numpy(), g["max0"]) and np.array_equal(c.cpu().numpy(), g["max1"])
+    zc = z.cpu().numpy()
+    assert np.array_equal(zc[0, :, 3], zc[0, :, 7]) and np.array_equal(zc[0, 2, :], zc[0, 9, :])
+
+
+def test_empty_batch_and_zero_iters(ops):
+    z = ops.log_optimal_transport2(torch.zeros(0, 65, 65).cuda(), 1.0, torch.zeros(0, 1, 64).cuda(), 100)
+    assert z.shape == (0, 65, 65)
+    s = cu(np.random.default_rng(0).standard_normal((2, 5, 7)).astype(np.float32))
+    out = ops.log_sinkhorn_iterations(s, torch.zeros(2, 5).cuda(), torch.zeros(2, 7).cuda(), 0)
+    assert torch.equal(out, s)        # u = v = 0 -> Z + 0 + 0
+
+
+# ---- coarse level ------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,seed,h,w", [("coarse_301.npz", synth.SEED, 15, 20),
+                                           ("coarse_portrait.npz", synth.SEED + 20, 20, 15)])
+def test_coarse_level(ops, oracle, name, seed, h, w):
+    g = golden(name)
+    H, W = int(g["H"]), int(g["W"])
+    inp = synth.coarse_inputs(seed=seed, h=h, w=w)
+    d0, d1, ns = cu(inp["d0"]), cu(inp["d1"]), cu(inp["ns"])
+    S = ops.cost(d0, d1)
+    np.testing.assert_allclose(S.cpu().numpy().reshape(-1)[g["S_idx"]], g["S_val"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(S.cpu().numpy(), oracle.cost(inp["d0"], inp["d1"]), atol=2e-5, rtol=1e-5)
+    Z = ops.log_optimal_transport(S, float(inp["alpha"]), ns, 100)
+    assert_mass(Z, g["Z"])
+    Zf = ops.cost_ot(d0, d1, 1, float(inp["alpha"]), ns, 100)
+    assert torch.equal(Z, Zf)
+    scales = ops.colmass_sqrt(Z)
+    np.testing.assert_allclose(scales.cpu().numpy(), g["scales"], atol=2e-5)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (H, W), 32)
+    r, c = ops.argmax(Z)
+    assert np.array_equal(r[:, :-1].cpu().numpy(), g["max0"]) and np.array_equal(c[:, :-1].cpu().numpy(), g["max1"])
+    assert np.array_equal(ifn1.cpu().numpy(), g["ifn1"]) and np.array_equal(ifn2.cpu().numpy(), g["ifn2"])
+    np.testing.assert_allclose(trust.cpu().numpy(), g["whole_cost"], atol=3e-6, rtol=5e-5)
+    np.testing.assert_allclose(pts.cpu().numpy(), g["average_point"], atol=1e-4)
+    np.testing.assert_allclose(xs.cpu().numpy(), g["x_scale"], rtol=5e-5)
+    np.testing.assert_allclose(ys.cpu().numpy(), g["y_scale"], rtol=5e-5)
+    # the reference-signature entry point on the reference's own exp(Z): bounds bit-exact
+    positions, ranges = ops.Compute_positions_and_ranges(H // 32, W // 32, "cuda")
+    sc = cu(g["scales"]).reshape(1, -1, 1)
+    whole, core, avg, xs2, ys2, bound = ops.Iterative_expand_matrix(
+        cu(np.exp(g["Z"])), sc, sc, torch.tensor([0, H // 32, 0, W // 32]).cuda(), ranges, positions,
+        height=H // 32, width=W // 32, iter_num=15, lower_bound=1e-5)
+    assert bound.dtype == torch.int64 and np.array_equal(bound.cpu().numpy(), g["bound"])
+    np.testing.assert_allclose(core.cpu().numpy(), g["core_cost"], atol=3e-6, rtol=5e-4)
+    np.testing.assert_allclose(whole.cpu().numpy(), g["whole_cost"], atol=3e-6, rtol=5e-5)
+    # foreign (un-annotated) positions/ranges tensors work too
+    pf, rf = positions.clone(), ranges.clone()
+    b2 = ops.Iterative_expand_matrix(cu(np.exp(g["Z"])), sc, sc, [0, H // 32, 0, W // 32], rf, pf,
+                                     iter_num=15, lower_bound=1e-5)[5]
+    assert torch.equal(b2, bound)
+
+
+def test_coarse_769(ops):
+    g = golden("coarse_769.npz")
+    inp = synth.coarse_inputs(seed=synth.SEED + 21, h=24, w=32)
+    Z = ops.cost_ot(cu(inp["d0"]), cu(inp["d1"]), 1, float(inp["alpha"]), cu(inp["ns"]), 100)
+    zs = Z.cpu().numpy().reshape(-1)[g["Z_idx"]]
+    assert np.abs(np.exp(zs.astype(np.float64)) - np.exp(g["Z_val"].astype(np.float64))).max() <= MASS_TOL
+    r, c = ops.argmax(Z)
+    assert np.array_equal(r[:, :-1].cpu().numpy(), g["max0"]) and np.array_equal(c[:, :-1].cpu().numpy(), g["max1"])
+    e = np.exp(Z.cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(e.sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-5)
+    np.testing.assert_allclose(e.sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-5)
+    scales = ops.colmass_sqrt(Z)
+    out = ops.est_position_first(Z, scales, (768, 1024), 32)
+    np.testing.assert_allclose(out[1].cpu().numpy(), g["average_point"], atol=1e-4)
+
+
+def test_split_and_compute_imgs(ops, oracle):
+    g = golden("coarse_301.npz")
+    ifn1 = cu(g["ifn1"])
+    sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1)
+    n, second, third = ops.split_patches(sum_cycle[0], 15, 20, 40)
+    assert n == int(g["split40_cycle"]) and second == g["split40_second"].tolist() \
+        and third == g["split40_third"].tolist()
+    left, right = synth.image_pair()
+    nl, nr, xsn, ysn, avn, bound5 = ops.Compute_imgs_ex(cu(g["x_scale"]), cu(g["y_scale"]),
+                                                        cu(g["average_point"]), ifn1, cu(left), cu(right),
+                                                        width=20, height=15)
+    assert np.array_equal(bound5.cpu().numpy(), g["resize_bound"])
+    assert nr.shape == (int(g["K"]), 96, 96, 3) and nl.shape == nr.shape
+    np.testing.assert_allclose(xsn.cpu().numpy(), g["x_scale_new"], rtol=1e-6)
+    np.testing.assert_allclose(ysn.cpu().numpy(), g["y_scale_new"], rtol=1e-6)
+    np.testing.assert_allclose(avn.cpu().numpy(), g["average_new"], atol=1e-5)
+    nrc, nlc = nr.cpu().numpy(), nl.cpu().numpy()
+    np.testing.assert_allclose(nrc[g["crop_pick"]], g["right_pick"], atol=1e-4)
+    np.testing.assert_allclose(nrc.astype(np.float64).sum((1, 2, 3)), g["right_sum"], rtol=1e-6)
+    wts = np.arange(96 * 96 * 3, dtype=np.float64).reshape(96, 96, 3)
+    np.testing.assert_allclose((nrc.astype(np.float64) * wts).sum((1, 2, 3)), g["right_wsum"], rtol=1e-6)
+    np.testing.assert_array_equal(nlc[g["crop_pick"]][:, ::4, ::4], g["left_pick"])
+    np.testing.assert_allclose(nlc.astype(np.float64).sum((1, 2, 3)), g["left_sum"], rtol=1e-9)
+    # the drop-in native boundary: module `tensor_resize`, padded CHW source, same crops
+    import tensor_resize
+    src = torch.nn.functional.pad(cu(right), (0, 0, 128, 128, 128, 128)).permute(0, 3, 1, 2).contiguous()
+    crops = tensor_resize.tensor_resize(src, bound5)
+    assert crops.shape == (int(g["K"]), 3, 96, 96) and crops.device == src.device
+    assert torch.allclose(crops.permute(0, 2, 3, 1), nr, atol=1e-5)
+    np.testing.assert_allclose(crops.cpu().numpy(), oracle.tensor_resize(src.cpu().numpy(), g["resize_bound"]),
+                               atol=1e-4)
+
+
+def test_tensor_resize_edges_and_empty(ops):
+    import tensor_resize
+    g = golden("resize_small.npz")
+    out = tensor_resize.tensor_resize(cu(g["src"]), cu(g["bound"]))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=1e-4)
+    empty = tensor_resize.tensor_resize(cu(g["src"]), torch.zeros(0, 5, dtype=torch.int64).cuda())
+    assert empty.shape == (0, 3, 96, 96)
+    src_before = cu(g["src"])
+    keep = src_before.clone()
+    tensor_resize.tensor_resize(src_before, cu(g["bound"]))
+    assert torch.equal(src_before, keep)                      # inputs are borrowed, never written
+    with pytest.raises(RuntimeError):
+        tensor_resize.tensor_resize(cu(g["src"]).double(), cu(g["bound"]))
+
+
+def test_tensor_resize_against_compiled_reference(ops):
+    """When the reference's own library.cpp build travelled (oracle/_ref), compare against it
+    directly on CPU tensors - the strongest pin of the native boundary."""
+    ref_dir = os.path.join(REPO, "oracle", "_ref")
+    so = [f for f in os.listdir(ref_dir)] if os.path.isdir(ref_dir) else []
+    if not any(f.startswith("tensor_resize") for f in so):
+        pytest.skip("oracle/_ref not built")
+    import importlib.util
+    path = os.path.join(ref_dir, [f for f in so if f.startswith("tensor_resize")][0])
+    spec = importlib.util.spec_from_file_location("tensor_resize", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(7)
+    src = torch.from_numpy(rng.uniform(0, 255, (2, 3, 200, 240)).astype(np.float32))
+    y0 = rng.integers(0, 150, 64); x0 = rng.integers(0, 180, 64)
+    bound = np.stack([y0, y0 + rng.integers(1, 50, 64), x0, x0 + rng.integers(0, 59, 64),
+                      rng.integers(0, 2, 64) * 10000 + np.arange(64)], 1).astype(np.int64)
+    want = ref.tensor_resize(src, torch.from_numpy(bound))
+    import tensor_resize
+    got = tensor_resize.tensor_resize(src.cuda(), torch.from_numpy(bound).cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+
+
+# ---- fine level --------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,k", [("fine_145.npz", 2.0), ("fine_145_indoor.npz", 3.0)])
+def test_fine_level(ops, name, k):
+    g = golden(name)
+    B = int(g["B"])
+    inp = synth.fine_inputs(seed=int(g["seed"]), B=B)
+    d0, d1 = cu(inp["d0"]), cu(inp["d1"])
+    sx, sy = cu(inp["scale_x"]), cu(inp["scale_y"])
+    S = ops.cost(d0, d1)
+    np.testing.assert_allclose(S.cpu().numpy().reshape(-1)[g["S_idx"]], g["S_val"], atol=2e-5, rtol=1e-5)
+    Z0 = ops.log_optimal_transport2(S, 1.0, sx * sy, 100)
+    e = np.exp(Z0.cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(e.sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-5)
+    np.testing.assert_allclose(e.sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-5)
+    Z = ops.dustbin_bias_(Z0.clone(), k)
+    assert_mass(Z, g["Z"])
+    Zf = ops.cost_ot(d0, d1, 2, 1.0, sx * sy, 100, bias_k=k)     # bias folded into the epilogue
+    assert torch.equal(Z, Zf)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_second(Z, sx, sy, [96, 96], 8)
+    assert np.array_equal(ifn1.cpu().numpy(), g["ifn1"]) and np.array_equal(ifn2.cpu().numpy(), g["ifn2"])
+    np.testing.assert_allclose(trust.cpu().numpy(), g["whole_cost"], atol=3e-6, rtol=5e-5)
+    np.testing.assert_allclose(pts.cpu().numpy(), g["average_point"], atol=1e-4)
+    np.testing.assert_allclose(xs.cpu().numpy(), g["x_scale"], rtol=5e-5)
+    positions, ranges = ops.Compute_positions_and_ranges(12, 12, "cuda")
+    out = ops.Iterative_expand_matrix(cu(np.exp(g["Z"])), sx.reshape(B, -1, 1), sy.reshape(B, -1, 1),
+                                      [0, 12, 0, 12], ranges, positions, iter_num=8, lower_bound=1e-3)
+    assert np.array_equal(out[5].cpu().numpy(), g["bound"])
+    np.testing.assert_allclose(out[1].cpu().numpy(), g["core_cost"], atol=3e-6, rtol=5e-4)
+
+
+# ---- third level -------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["third_65.npz", "third_65_indoor.npz"])
+def test_third_level(ops, oracle, name):
+    g = golden(name)
+    P, outdoor = int(g["P"]), bool(g["outdoor"])
+    inp = synth.third_inputs(seed=int(g["seed"]), P=P)
+    d0, d1, scale = cu(inp["d0"]), cu(inp["d1"]), cu(inp["scale"])
+    Z = ops.cost_ot(d0, d1, 2, 1.0, scale, 100)
+    assert_mass(Z, g["Z"])
+    sxy = torch.sqrt(scale + 1e-8)
+    ps, pt = cu(inp["p_s"]), cu(inp["p_t"])
+    for src, is_log in ((ops.exp(Z), False), (Z, True), (cu(np.exp(g["Z"])), False)):
+        m0, m1, wl, label, ifm = ops.Compute_result(src, 8, 5, sxy, sxy, ps, pt, "cuda", outdoor=outdoor,
+                                                    input_is_log=is_log)
+        np.testing.assert_array_equal(m0.cpu().numpy(), g["mkpts0_f"])
+        np.testing.assert_allclose(m1.cpu().numpy(), g["mkpts1_f"], atol=3e-4)
+        np.testing.assert_allclose(wl.cpu().numpy(), g["whole_loss"], atol=1e-6)
+        assert np.array_equal(ifm.cpu().numpy(), g["if_matching1"])
+        np.testing.assert_array_equal(label.cpu().numpy(), g["label"])
+    # a6 on the 65x65 register-resident kernel with explicit marginals, against the oracle
+    rng = np.random.default_rng(11)
+    Zr = (2 * rng.standard_normal((5, 65, 65))).astype(np.float32)
+    mu = rng.uniform(.5, 2, (5, 65)).astype(np.float32)
+    nu = rng.uniform(.5, 2, (5, 65)).astype(np.float32)
+    nu *= mu.sum(1, keepdims=True) / nu.sum(1, keepdims=True)
+    out = ops.log_sinkhorn_iterations(cu(Zr), cu(np.log(mu)), cu(np.log(nu)), 100)
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.log_sinkhorn_iterations(Zr, np.log(mu), np.log(nu), 100),
+                               atol=3e-5)
+
+
+# ---- properties at the reference's full sizes (oracle would take minutes) ------------------------
+def _check_marginals(Z, ns, ms):
+    e = torch.exp(Z.double())
+    rows, cols = e.sum(2), e.sum(1)
+    ns = ns.reshape(ns.shape[0], -1).double()
+    assert (rows[:, :-1] - 1).abs().max().item() <= 2e-4          # every source patch ships mass 1
+    assert ((cols[:, :-1] - ns).abs() / ns).max().item() <= 2e-4  # target j receives its area ns_j
+    assert ((rows[:, -1] - ns.sum(1)).abs() / ns.sum(1)).max().item() <= 2e-4
+    assert ((cols[:, -1] - ms).abs() / ms).max().item() <= 2e-4
+
+
+def test_full_size_third_level_properties(ops):
+    P = 20000                                   # P ~ 60 * B per 640x480 pair
+    inp = synth.third_inputs(seed=123, P=P)
+    Z = ops.cost_ot(cu(inp["d0"]), cu(inp["d1"]), 2, 1.0, cu(inp["scale"]), 100)
+    assert Z.shape == (P, 65, 65) and torch.isfinite(Z).all()
+    _check_marginals(Z, cu(inp["scale"]), 64.0)
+    # idempotence of the fixed point: more sweeps on the converged plan change nothing
+    e = torch.exp(Z[:64])
+    lm, ln = torch.log(e.sum(2)), torch.log(e.sum(1))
+    Z2 = ops.log_sinkhorn_iterations(Z[:64].contiguous(), lm, ln, 5)
+    assert (Z2 - Z[:64]).abs().max().item() <= 5e-4
+
+
+def test_full_size_fine_level_properties(ops):
+    B = 512                                     # the if_local=False cap (first_layer.py:134)
+    inp = synth.fine_inputs(seed=124, B=B)
+    ns = cu(inp["scale_x"] * inp["scale_y"])
+    Z = ops.cost_ot(cu(inp["d0"]), cu(inp["d1"]), 2, 1.0, ns, 100)
+    assert torch.isfinite(Z).all()
+    _check_marginals(Z, ns, 144.0)
+
+
+def test_roofline_config_4096_properties(ops):
+    inp = synth.roofline_inputs()
+    Z = ops.cost_ot(cu(inp["d0"]), cu(inp["d1"]), 1, float(inp["alpha"]), cu(inp["ns"]), 200)
+    assert Z.shape == (1, 4097, 4097) and torch.isfinite(Z).all()
+    _check_marginals(Z, cu(inp["ns"]), 4096.0)

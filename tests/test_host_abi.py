@@ -1,0 +1,105 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/pats_amd.h declares, validates
+arguments without touching a GPU, and its host-side chunk planner matches the reference fixtures.
+No compute kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, golden
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pats_amd import build, _lib
+    build.build()
+    return _lib.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    from pats_amd import _lib
+    header = open(os.path.join(REPO, "include", "pats_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pats_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.pats_version()
+
+
+def test_library_is_in_tree_and_links_no_torch():
+    from pats_amd import _lib
+    assert os.path.dirname(_lib.LIB_PATH) == os.path.join(REPO, "pats_amd")
+    import subprocess
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in out and "libamdhip64" in out
+
+
+def test_argument_validation_without_gpu(lib):
+    # bad shapes / null pointers are rejected before any launch (reference: TORCH_CHECK -> RuntimeError)
+    from pats_amd import _lib
+    rc = lib.pats_cost_f32(None, None, 1, 0, 4, 4, None, None)
+    assert rc == 1 and b"cost" in lib.pats_last_error()
+    rc = lib.pats_tensor_resize_f32(None, 1, 3, 10, 10, None, 5, None, None, None)
+    assert rc == 1
+    # K == 0 is a successful no-op (nothing matched, utils.py:1385 with an empty bound)
+    assert lib.pats_tensor_resize_f32(None, 1, 3, 10, 10, None, 0, None, None, None) == 0
+    assert lib.pats_log_optimal_transport_f32(None, 0, 3, 3, None, None, 100, None, None, 0, None) == 0
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.pats_iterative_expand_f32(None, 0, 1, 5, 5, None, None, 2, 3, 3, 1e-3, 8, None, None,
+                                                 None, None, None, None, None), "expand")
+    assert lib.pats_ot_workspace_bytes(2, 301, 301) >= 2 * 2 * 301 * 301 * 4
+    assert lib.pats_sinkhorn_workspace_bytes(1000, 65, 65) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from pats_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.log_optimal_transport(torch.zeros(1, 3, 3), 0.5, torch.ones(1, 1, 3), 10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        import tensor_resize
+        tensor_resize.tensor_resize(torch.zeros(1, 3, 8, 8), torch.zeros(1, 5, dtype=torch.int64))
+
+
+def _split(lib, sc, h, w, cap):
+    sc = np.ascontiguousarray(sc, np.int32)
+    second = np.zeros((h + 1, 2), np.int64)
+    third = np.zeros((h + 1, 2), np.int64)
+    n = lib.pats_split_patches(sc.ctypes.data_as(ctypes.c_void_p), h, w, cap,
+                               second.ctypes.data_as(ctypes.c_void_p), third.ctypes.data_as(ctypes.c_void_p))
+    return n, second[:n], third[:n]
+
+
+@pytest.mark.parametrize("cap", [40, 100, 512])
+def test_split_patches_matches_reference(lib, cap):
+    g = golden("coarse_301.npz")
+    sc = np.cumsum(~g["ifn1"][0]).astype(np.int32)
+    n, second, third = _split(lib, sc, 15, 20, cap)
+    assert n == int(g["split%d_cycle" % cap])
+    assert np.array_equal(second, g["split%d_second" % cap])
+    assert np.array_equal(third, g["split%d_third" % cap])
+
+
+def test_split_patches_agrees_with_oracle_on_random_plans(lib, oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        h, w = int(rng.integers(1, 30)), int(rng.integers(1, 40))
+        flags = rng.random(h * w) < rng.random()
+        sc = np.cumsum(flags).astype(np.int32)
+        cap = int(rng.integers(1, 3 * w + 2))
+        n, second, third = _split(lib, sc, h, w, cap)
+        on, osec, oth = oracle.split_patches(sc, h, w, cap)
+        assert n == on and np.array_equal(second, osec) and np.array_equal(third, oth)
+
+
+def test_split_patches_through_ops_cpu_tensor(lib):
+    import torch
+    from pats_amd import ops
+    g = golden("coarse_301.npz")
+    sc = torch.from_numpy(np.cumsum(~g["ifn1"][0]).astype(np.int32))
+    n, second, third = ops.split_patches(sc, 15, 20, 40)
+    assert n == 8 and second == g["split40_second"].tolist() and third == g["split40_third"].tolist()
