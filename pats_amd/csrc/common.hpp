@@ -56,16 +56,26 @@ __device__ __forceinline__ float wave_allreduce(float v, Op op) {
     v = op(v, dpp_f<DPP_QUAD_XOR2>(v));
     v = op(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
     v = op(v, dpp_f<DPP_ROW_MIRROR>(v));
-    // rows of 16 now hold their totals; exchange rows 0<->1, 2<->3 then halves 0<->1
+    // rows of 16 now hold their totals; exchange rows 0<->1, 2<->3 then halves 0<->1.
+    // v_permlane{16,32}_swap exchange IN PLACE between two distinct VGPRs and the builtin returns
+    // both.  hipcc (ROCm 7.2) mis-folds the pair when it can see through it - op(r[0], r[1]) came
+    // out as op(r[0], r[0]) (a wave sum returned 4 x the row total on hardware) - so the second
+    // operand and both results are passed through empty asm to keep them opaque.
     {
-        unsigned x = __builtin_bit_cast(unsigned, v);
-        auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+        unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+        asm volatile("" : "+v"(y));
+        auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+        unsigned a = r[0], b = r[1];
+        asm volatile("" : "+v"(a), "+v"(b));
+        v = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
     }
     {
-        unsigned x = __builtin_bit_cast(unsigned, v);
-        auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-        v = op(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+        unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+        asm volatile("" : "+v"(y));
+        auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+        unsigned a = r[0], b = r[1];
+        asm volatile("" : "+v"(a), "+v"(b));
+        v = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
     }
     return v;
 }

@@ -25,6 +25,7 @@ from . import _lib
 
 _L = _lib.lib
 _check = _lib.check
+_L()   # load libpats_amd.so at import: a missing HIP extension fails here, loudly
 
 
 def _stream():
@@ -98,9 +99,10 @@ def log_sinkhorn_iterations(Z, log_mu, log_nu, iters: int):
 def log_optimal_transport(scores, alpha, ns, iters: int):
     scores = _dev(scores, "scores")
     b, m, n = scores.shape
-    ns = _dev(ns, "ns").reshape(b, -1)
-    if ns.shape[1] != n:
+    ns = _dev(ns, "ns")
+    if ns.numel() != b * n:
         raise RuntimeError("log_optimal_transport: ns must have %d entries per batch" % n)
+    ns = ns.reshape(b, n)
     a = _scalar_dev(alpha, scores.device)
     Z = torch.empty((b, m + 1, n + 1), dtype=torch.float32, device=scores.device)
     nb = _L().pats_ot_workspace_bytes(b, m + 1, n + 1)
@@ -115,9 +117,10 @@ def log_optimal_transport2(scores, one, ns, iters: int, bias_k: float = 0.0):
     second_layer.py:107-112 into the epilogue; 0 returns exactly modules.py:165-182."""
     scores = _dev(scores, "scores")
     b, m, n = scores.shape
-    ns = _dev(ns, "ns").reshape(b, -1)
-    if ns.shape[1] != n - 1:
+    ns = _dev(ns, "ns")
+    if ns.numel() != b * (n - 1):
         raise RuntimeError("log_optimal_transport2: ns must have %d entries per batch" % (n - 1))
+    ns = ns.reshape(b, n - 1)
     o = _scalar_dev(one, scores.device)
     Z = torch.empty((b, m, n), dtype=torch.float32, device=scores.device)
     nb = _L().pats_ot_workspace_bytes(b, m, n)
@@ -133,7 +136,7 @@ def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0
     d0, d1 = _dev(mdesc0, "mdesc0"), _dev(mdesc1, "mdesc1")
     b, D, n = d0.shape
     m = d1.shape[2]
-    ns = _dev(ns, "ns").reshape(b, -1)
+    ns = _dev(ns, "ns").reshape(b, m if variant == 1 else m - 1)
     s = _scalar_dev(scalar, d0.device)
     shape = (b, n + 1, m + 1) if variant == 1 else (b, n, m)
     Z = torch.empty(shape, dtype=torch.float32, device=d0.device)

@@ -35,7 +35,9 @@ def cu(x, dtype=None):
 def assert_mass(Zh, Zr):
     Zh = Zh.detach().cpu().numpy() if isinstance(Zh, torch.Tensor) else Zh
     eo, er = np.exp(Zh.astype(np.float64)), np.exp(np.asarray(Zr).astype(np.float64))
-    assert np.abs(eo - er).max() <= MASS_TOL
+    # 1e-4 absolute on transport mass; the dustbin entries carry mass >> 1 (corner ~ 3e2..3e3), where
+    # two fp32 evaluations of Z + u + v differ by a few ulp of Z (|Z| ~ 8 -> 1e-6 relative in exp)
+    np.testing.assert_allclose(eo, er, atol=MASS_TOL, rtol=2e-6)
     np.testing.assert_allclose(eo.sum(-1), er.sum(-1), atol=MASS_TOL, rtol=1e-6)
     np.testing.assert_allclose(eo.sum(-2), er.sum(-2), atol=MASS_TOL, rtol=1e-6)
     big = er > 1e-6
@@ -44,8 +46,9 @@ def assert_mass(Zh, Zr):
 
 def test_native_library_loaded(ops):
     from pats_amd import _lib
+    assert _lib.lib().pats_device_count() >= 1
     maps = open("/proc/self/maps").read()
-    assert "libpats_amd.so" in maps and _lib.lib().pats_device_count() >= 1
+    assert "libpats_amd.so" in maps
 
 
 # ---- OT known answers and edge shapes ----------------------------------------------------------
@@ -275,13 +278,18 @@ def test_third_level(ops, oracle, name):
 
 # ---- properties at the reference's full sizes (oracle would take minutes) ------------------------
 def _check_marginals(Z, ns, ms):
+    """Each sweep ends with the column update (modules.py:142), so after any number of sweeps the
+    COLUMN marginals are exact: target j receives its area ns_j, the dustbin column receives ms.
+    Row marginals (mass 1 per source patch) only hold at convergence - checked loosely."""
     e = torch.exp(Z.double())
     rows, cols = e.sum(2), e.sum(1)
     ns = ns.reshape(ns.shape[0], -1).double()
-    assert (rows[:, :-1] - 1).abs().max().item() <= 2e-4          # every source patch ships mass 1
-    assert ((cols[:, :-1] - ns).abs() / ns).max().item() <= 2e-4  # target j receives its area ns_j
-    assert ((rows[:, -1] - ns.sum(1)).abs() / ns.sum(1)).max().item() <= 2e-4
-    assert ((cols[:, -1] - ms).abs() / ms).max().item() <= 2e-4
+    assert ((cols[:, :-1] - ns).abs() / ns).max().item() <= 2e-5
+    assert ((cols[:, -1] - ms).abs() / ms).max().item() <= 2e-5
+    total = ms + ns.sum(1)
+    assert ((e.sum((1, 2)) - total).abs() / total).max().item() <= 2e-5    # mass conservation
+    assert (rows[:, :-1] - 1).abs().max().item() <= 0.15
+    assert (rows[:, :-1] - 1).abs().mean().item() <= 2e-3
 
 
 def test_full_size_third_level_properties(ops):
