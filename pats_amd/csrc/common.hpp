@@ -17,6 +17,7 @@ constexpr float ZERO_F = 1e-14f;  // the reference's `zero` (utils/utils.py:1201
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int sinkhorn_mode();   // PATS_SINKHORN_* (host.cpp)
 
 #define PATS_REQUIRE(cond, ...)               \
     do {                                      \

@@ -50,20 +50,81 @@ ot_prep_kernel(const float* __restrict__ ns, int ns_len, int M, int N, float ms_
 }
 
 // ------------------------------------------------------------------------------------------
+// Linear-domain ("kernel matrix") form of the same iteration
+// ------------------------------------------------------------------------------------------
+// With row stabilisers r_i = max_j Z_ij and column stabilisers c_j = max_i (Z_ij - r_i):
+//     K_ij = exp(Z_ij - r_i - c_j)  in (0, 1], every row and every column contains a 1,
+//     a_i = exp(u_i + r_i),  b_j = exp(v_j + c_j)
+// the reference's sweep  u = log_mu - lse_j(Z + v);  v = log_nu - lse_i(Z + u)  is EXACTLY
+//     a_i = mu_i / sum_j K_ij b_j ;   b_j = nu_j / sum_i K_ij a_i          (b starts at exp(c_j))
+// i.e. the same fixed-point sequence (same iterate after every sweep), but one FMA per element per
+// half-sweep instead of add/max/sub/exp/add.  The duals return to log space once at the end:
+// u_i = log a_i - r_i, v_j = log b_j - c_j, Z_out = ((Z + u) + v) - norm from the ORIGINAL Z.
+// Guard: entries of K below 2^-126 flush to zero; their true mass is < 2^-126 * a_i * b_j, so the
+// result is unaffected as long as the scalings stay below 2^30.  Each problem checks
+// max(a, b) <= 2^30 and finiteness at the end and otherwise re-runs itself with the max-subtracted
+// log-sum-exp sweeps (the code below each linear block), which have no range restriction.
+constexpr float SCALE_GUARD = 1073741824.0f;   // 2^30
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ bool scaling_ok(float x) { return x <= SCALE_GUARD && x > 0.f; }
+
+__device__ __forceinline__ float lse_finish(float s, float mI) {
+    return (fast_log2(s) + mI) * LN2;
+}
+
+// ------------------------------------------------------------------------------------------
 // 65 x 65, one wave per problem
 // ------------------------------------------------------------------------------------------
 constexpr int NB = 64;          // real rows / columns
 constexpr int NT = NB + 1;      // + dustbin
 constexpr int TILE = NT * NT;   // 4225
 
-struct Wave65Lds {
-    float tile[TILE + 3];       // staging for the load-time transpose
-    float us[NT + 3];           // broadcast buffers for the duals
-    float vs[NT + 3];
+struct __attribute__((aligned(16))) Wave65Lds {
+    float bc0[NT + 3];          // broadcast buffers (duals / scalings / stabilisers), 16-B aligned
+    float bc1[NT + 3];
+    float tile[TILE + 3];       // the problem's Z, kept for the epilogue
 };
 
-__device__ __forceinline__ float lse_finish(float s, float mI) {
-    return (fast_log2(s) + mI) * LN2;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// dot of a lane's register-resident K entries with a vector broadcast from LDS.  All LDS reads of a
+// batch are issued before the first FMA (a lone wave otherwise pays the ~64-cycle LDS latency per
+// read), and the products pair up as (k[4q],k[4q+1])*(b.x,b.y), (k[4q+2],k[4q+3])*(b.z,b.w) so the
+// compiler emits v_pk_fma_f32 without register shuffles.
+template <int LEN, int BATCH>
+__device__ __forceinline__ float dot_bcast(const float* k, const float* bc) {
+    static_assert(LEN % 4 == 0, "dot_bcast: LEN must be a multiple of 4");
+    const f4* b4 = reinterpret_cast<const f4*>(bc);
+    f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+    for (int q0 = 0; q0 < LEN / 4; q0 += BATCH) {
+        f4 bb[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q)
+            if (q0 + q < LEN / 4) bb[q] = b4[q0 + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q)
+            if (q0 + q < LEN / 4) {
+                const int e = 4 * (q0 + q);
+                const f2 k0 = {k[e + 0], k[e + 1]}, k1 = {k[e + 2], k[e + 3]};
+                acc0 = __builtin_elementwise_fma(k0, bb[q].xy, acc0);
+                acc1 = __builtin_elementwise_fma(k1, bb[q].zw, acc1);
+            }
+        // without this the scheduler hoists the NEXT batch's reads above these FMAs and every
+        // batch is live at once (LEN extra VGPRs -> spills in the 145-wide kernel)
+        // (sched_barrier alone does not do it - instruction selection has already clustered the
+        // loads; a compiler memory barrier keeps the next batch's ds_reads behind this point)
+        // and the accumulators pass through it so this batch's FMAs cannot sink below it
+        if (q0 + BATCH < LEN / 4) asm volatile("" : "+v"(acc0), "+v"(acc1) : : "memory");
+    }
+    const f2 sacc = acc0 + acc1;
+    return sacc.x + sacc.y;
+}
+__device__ __forceinline__ float dot64(const float (&k)[64], const float* bc) {
+    return dot_bcast<64, 16>(k, bc);
 }
 
 // mode 0: log_mu/log_nu given (a6)      mode 2: ns given, log_optimal_transport2 marginals (a5)
@@ -71,7 +132,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64)
 sinkhorn65_kernel(const float* __restrict__ Zin, int64_t P, const float* __restrict__ log_mu_in,
                   const float* __restrict__ log_nu_in, const float* __restrict__ ns,
-                  const float* __restrict__ one, int iters, float bias_k,
+                  const float* __restrict__ one, int iters, float bias_k, int linear,
                   float* __restrict__ out) {
     __shared__ Wave65Lds lds;
     const int lane = threadIdx.x;
@@ -79,19 +140,10 @@ sinkhorn65_kernel(const float* __restrict__ Zin, int64_t P, const float* __restr
     if (p >= P) return;
     const float* Zp = Zin + p * TILE;
 
-    // ---- coalesced load -> LDS -> row-per-lane and column-per-lane register images ----------
+    // ---- coalesced load of the 4225 floats into LDS --------------------------------------------
 #pragma unroll 11
     for (int k = 0; k < 66; ++k) lds.tile[k * 64 + lane] = Zp[k * 64 + lane];
     if (lane == 0) lds.tile[TILE - 1] = Zp[TILE - 1];
-    __syncthreads();
-    float zr[NB], zc[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) zr[j] = lds.tile[lane * NT + j];   // stride 65: conflict-free
-#pragma unroll
-    for (int i = 0; i < NB; ++i) zc[i] = lds.tile[i * NT + lane];
-    const float zr64 = lds.tile[lane * NT + NB];    // Z[lane][64]   (dustbin column)
-    const float zc64 = lds.tile[NB * NT + lane];    // Z[64][lane]   (dustbin row)
-    const float corner = lds.tile[TILE - 1];        // Z[64][64]
 
     // ---- marginals -----------------------------------------------------------------------
     float lmu, lmu64, lnu, lnu64, norm = 0.f;
@@ -110,72 +162,304 @@ sinkhorn65_kernel(const float* __restrict__ Zin, int64_t P, const float* __restr
         lmu = norm;
         lmu64 = logf(ns_sum) + norm;
     }
+    __syncthreads();
+    const float* T = lds.tile;
+    const float corner_z = T[TILE - 1];
 
     float u = 0.f, u64 = 0.f, v = 0.f, v64 = 0.f;
-    for (int it = 0; it < iters; ++it) {
-        // ---- u = log_mu - lse_j(Z + v) ------------------------------------------------------
-        __syncthreads();
-        lds.vs[lane] = v;
-        if (lane == 0) lds.vs[NB] = v64;
-        __syncthreads();
-        {
-            float m = zr64 + v64;
+    bool solved = (iters == 0);
+
+    if (linear && !solved) {
+        // ---- stabilisers: r_i = max_j Z_ij ; c_j = max_i (Z_ij - r_i) ---------------------------
+        float r = T[lane * NT + NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) m = fmaxf(m, zr[j] + lds.vs[j]);
-            const float mI = ceilf(m * LOG2E);
-            float s = fast_exp2(fmaf(zr64 + v64, LOG2E, -mI));
+        for (int j = 0; j < NB; ++j) r = fmaxf(r, T[lane * NT + j]);      // stride 65: conflict-free
+        const float r64 = fmaxf(wave_max(T[NB * NT + lane]), corner_z);
+        lds.bc0[lane] = r;
+        __syncthreads();
+        float c = T[NB * NT + lane] - r64;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) s += fast_exp2(fmaf(zr[j] + lds.vs[j], LOG2E, -mI));
-            u = lmu - lse_finish(s, mI);
-            // dustbin row: elements live one per lane
-            const float t = zc64 + v, tc = corner + v64;
-            const float mI2 = ceilf(fmaxf(wave_max(t), tc) * LOG2E);
-            const float s2 = wave_sum(fast_exp2(fmaf(t, LOG2E, -mI2))) + fast_exp2(fmaf(tc, LOG2E, -mI2));
-            u64 = lmu64 - lse_finish(s2, mI2);
+        for (int i = 0; i < NB; ++i) c = fmaxf(c, T[i * NT + lane] - lds.bc0[i]);
+        const float c64 = fmaxf(wave_max(T[lane * NT + NB] - r), corner_z - r64);
+        lds.bc1[lane] = c;
+        __syncthreads();
+        // ---- K in both orientations (identical op order => kr/kc hold bitwise-equal entries) ----
+        float kr[NB], kc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) kr[j] = fast_exp2(((T[lane * NT + j] - r) - lds.bc1[j]) * LOG2E);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) kc[i] = fast_exp2(((T[i * NT + lane] - lds.bc0[i]) - c) * LOG2E);
+        const float kr64 = fast_exp2(((T[lane * NT + NB] - r) - c64) * LOG2E);     // K[lane][64]
+        const float kc64 = fast_exp2(((T[NB * NT + lane] - r64) - c) * LOG2E);     // K[64][lane]
+        const float kcorner = fast_exp2(((corner_z - r64) - c64) * LOG2E);
+        const float mu = expf(lmu), mu64 = expf(lmu64), nu = expf(lnu), nu64 = expf(lnu64);
+        float a = 0.f, a64 = 0.f, b = expf(c), b64 = expf(c64);
+        for (int it = 0; it < iters; ++it) {
+            __syncthreads();
+            lds.bc1[lane] = b;
+            __syncthreads();
+            a = mu * fast_rcp(fmaf(kr64, b64, dot64(kr, lds.bc1)));
+            a64 = mu64 * fast_rcp(fmaf(kcorner, b64, wave_sum(kc64 * b)));
+            __syncthreads();
+            lds.bc0[lane] = a;
+            __syncthreads();
+            b = nu * fast_rcp(fmaf(kc64, a64, dot64(kc, lds.bc0)));
+            b64 = nu64 * fast_rcp(fmaf(kcorner, a64, wave_sum(kr64 * a)));
         }
-        // ---- v = log_nu - lse_i(Z + u) ------------------------------------------------------
-        __syncthreads();
-        lds.us[lane] = u;
-        if (lane == 0) lds.us[NB] = u64;
-        __syncthreads();
-        {
-            float m = zc64 + u64;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) m = fmaxf(m, zc[i] + lds.us[i]);
-            const float mI = ceilf(m * LOG2E);
-            float s = fast_exp2(fmaf(zc64 + u64, LOG2E, -mI));
-#pragma unroll
-            for (int i = 0; i < NB; ++i) s += fast_exp2(fmaf(zc[i] + lds.us[i], LOG2E, -mI));
-            v = lnu - lse_finish(s, mI);
-            const float t = zr64 + u, tc = corner + u64;
-            const float mI2 = ceilf(fmaxf(wave_max(t), tc) * LOG2E);
-            const float s2 = wave_sum(fast_exp2(fmaf(t, LOG2E, -mI2))) + fast_exp2(fmaf(tc, LOG2E, -mI2));
-            v64 = lnu64 - lse_finish(s2, mI2);
+        // guard: every scaling finite, positive and <= 2^30 (comparisons are false for NaN)
+        const bool ok_lane = scaling_ok(a) && scaling_ok(b);
+        if (__all(ok_lane) && scaling_ok(a64) && scaling_ok(b64)) {
+            u = logf(a) - r;
+            u64 = logf(a64) - r64;
+            v = logf(b) - c;
+            v64 = logf(b64) - c64;
+            solved = true;
         }
     }
 
-    // ---- Z + u + v - norm (+ the caller's dustbin bias), rows written coalesced ---------------
+    if (!solved) {
+        // ---- max-subtracted log-sum-exp sweeps, Z rows and columns in registers -------------------
+        float zr[NB], zc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) zr[j] = T[lane * NT + j];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) zc[i] = T[i * NT + lane];
+        const float zr64 = T[lane * NT + NB];    // Z[lane][64]   (dustbin column)
+        const float zc64 = T[NB * NT + lane];    // Z[64][lane]   (dustbin row)
+        u = u64 = v = v64 = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            // u = log_mu - lse_j(Z + v)
+            __syncthreads();
+            lds.bc1[lane] = v;
+            __syncthreads();
+            {
+                float m = zr64 + v64;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) m = fmaxf(m, zr[j] + lds.bc1[j]);
+                const float mI = ceilf(m * LOG2E);
+                float s = fast_exp2(fmaf(zr64 + v64, LOG2E, -mI));
+#pragma unroll
+                for (int j = 0; j < NB; ++j) s += fast_exp2(fmaf(zr[j] + lds.bc1[j], LOG2E, -mI));
+                u = lmu - lse_finish(s, mI);
+                const float t = zc64 + v, tc = corner_z + v64;     // dustbin row, one element per lane
+                const float mI2 = ceilf(fmaxf(wave_max(t), tc) * LOG2E);
+                const float s2 = wave_sum(fast_exp2(fmaf(t, LOG2E, -mI2))) + fast_exp2(fmaf(tc, LOG2E, -mI2));
+                u64 = lmu64 - lse_finish(s2, mI2);
+            }
+            // v = log_nu - lse_i(Z + u)
+            __syncthreads();
+            lds.bc0[lane] = u;
+            __syncthreads();
+            {
+                float m = zc64 + u64;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) m = fmaxf(m, zc[i] + lds.bc0[i]);
+                const float mI = ceilf(m * LOG2E);
+                float s = fast_exp2(fmaf(zc64 + u64, LOG2E, -mI));
+#pragma unroll
+                for (int i = 0; i < NB; ++i) s += fast_exp2(fmaf(zc[i] + lds.bc0[i], LOG2E, -mI));
+                v = lnu - lse_finish(s, mI);
+                const float t = zr64 + u, tc = corner_z + u64;
+                const float mI2 = ceilf(fmaxf(wave_max(t), tc) * LOG2E);
+                const float s2 = wave_sum(fast_exp2(fmaf(t, LOG2E, -mI2))) + fast_exp2(fmaf(tc, LOG2E, -mI2));
+                v64 = lnu64 - lse_finish(s2, mI2);
+            }
+        }
+    }
+
+    // ---- Z + u + v - norm (+ the caller's dustbin bias) from the original Z, coalesced rows ------
     __syncthreads();
-    lds.us[lane] = u;
-    if (lane == 0) lds.us[NB] = u64;
+    lds.bc0[lane] = u;
     __syncthreads();
     const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
     float* Op = out + p * TILE;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {   // full unroll: zc[] must stay in registers (static indices)
-        Op[i * NT + lane] = ((zc[i] + lds.us[i]) + v) - norm;
-    }
+#pragma unroll 8
+    for (int i = 0; i < NB; ++i) Op[i * NT + lane] = ((T[i * NT + lane] + lds.bc0[i]) + v) - norm;
     {   // dustbin column entries (i, 64) and dustbin row entries (64, j)
-        float c = ((zr64 + u) + v64) - norm;
-        float r = ((zc64 + u64) + v) - norm;
-        if (bias_k > 0.f) { c += lb; r += lb; }
-        Op[lane * NT + NB] = c;
-        Op[NB * NT + lane] = r;
+        float cc = ((T[lane * NT + NB] + u) + v64) - norm;
+        float rr = ((T[NB * NT + lane] + u64) + v) - norm;
+        if (bias_k > 0.f) { cc += lb; rr += lb; }
+        Op[lane * NT + NB] = cc;
+        Op[NB * NT + lane] = rr;
         if (lane == 0) {
-            float q = ((corner + u64) + v64) - norm;
+            float q = ((corner_z + u64) + v64) - norm;
             if (bias_k > 0.f) { q += lb; q += lb; }     // corner receives both in-place adds
             Op[TILE - 1] = q;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// N x N with N <= 192 (the fine level: 145 x 145), one 384-thread workgroup per problem
+// ------------------------------------------------------------------------------------------
+// Waves 0-2 are ROW waves (lane i keeps row i of K in N VGPRs), waves 3-5 are COLUMN waves (lane j
+// keeps column j).  Each half-sweep is a lane-local dot product of those registers with the other
+// side's scaling vector, broadcast from LDS in batches that are fully in flight before the FMAs
+// start; one barrier hands a (or b) to the other wave group, so two barriers per sweep (the
+// Gauss-Seidel order leaves no work for the idle group anyway).  Splitting the orientations keeps
+// each thread at N + prefetch registers (< 256, two waves per SIMD) instead of 2N.  The problem's
+// Z stays in LDS (N*N*4 B = 84 KB at N = 145) for the stabilisers and the epilogue: HBM sees Z
+// once in and once out.
+template <int N_>
+struct __attribute__((aligned(16))) WgLds {
+    float bc0[(N_ + 7) & ~3];       // r, then a (and u for the epilogue)
+    float bc1[(N_ + 7) & ~3];       // c, then b (and v)
+    float red[8];
+    float tile[N_ * N_];
+};
+
+template <int N_>
+__device__ __forceinline__ float dotN(const float (&k)[(N_ + 3) & ~3], const float* bc) {
+    return dot_bcast<(N_ + 3) & ~3, 19>(k, bc);      // k and bc are zero-padded to a multiple of 4
+}
+
+template <int N_, int MODE>
+__global__ void __launch_bounds__(384)
+sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __restrict__ log_mu_in,
+                   const float* __restrict__ log_nu_in, const float* __restrict__ ns,
+                   const float* __restrict__ one, int iters, float bias_k, int linear,
+                   float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) WgLds<N_> lds;     // 85 KB at N = 145 (static: no opt-in)
+    constexpr int TH = 384, NN = N_ * N_, NP = (N_ + 3) & ~3;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool colw = __builtin_amdgcn_readfirstlane(wave) >= 3;   // wave-uniform orientation
+    const int tl = t - (colw ? 192 : 0);                           // row (or column) index of this lane
+    const bool act = tl < N_;
+    const int tt = act ? tl : 0;
+    const int64_t p = blockIdx.x;
+    const float* Zp = Zin + p * NN;
+    for (int k = t; k < NN; k += TH) lds.tile[k] = Zp[k];
+    if (t < 2 * ((N_ + 7) & ~3)) lds.bc0[t] = 0.f;                 // bc0 and bc1 are adjacent: zero the pads
+
+    // ---- marginals: row waves need log_mu of their row, column waves log_nu of their column ----
+    float lmarg, norm = 0.f;
+    if (MODE == 0) {
+        lmarg = colw ? log_nu_in[p * N_ + tt] : log_mu_in[p * N_ + tt];
+    } else {
+        const float nsj = (!colw && t < N_ - 1) ? ns[p * (N_ - 1) + t] : 0.f;
+        const float part = wave_sum(nsj);
+        if (lane == 0) lds.red[wave] = part;
+        __syncthreads();
+        const float ns_sum = (lds.red[0] + lds.red[1]) + lds.red[2];
+        const float ms = (float)(N_ - 1) * (one ? *one : 1.0f);
+        norm = -logf(ms + ns_sum);
+        if (colw) lmarg = (tl < N_ - 1 ? logf(ns[p * (N_ - 1) + tt]) : logf(ms)) + norm;
+        else lmarg = (tl < N_ - 1 ? 0.f : logf(ns_sum)) + norm;
+    }
+    __syncthreads();
+    const float* T = lds.tile;
+    float dual = 0.f;                   // u_i in row waves, v_j in column waves
+    bool solved = (iters == 0);
+
+    if (linear && !solved) {
+        // stabilisers r_i = max_j Z_ij (row waves), then c_j = max_i (Z_ij - r_i) (column waves)
+        float stab = -INFINITY;
+        if (!colw) {
+#pragma unroll 5
+            for (int j = 0; j < N_; ++j) stab = fmaxf(stab, T[tt * N_ + j]);     // stride N_ (odd): conflict-free
+            if (act) lds.bc0[tl] = stab;
+        }
+        __syncthreads();
+        if (colw) {
+#pragma unroll 5
+            for (int i = 0; i < N_; ++i) stab = fmaxf(stab, T[i * N_ + tt] - lds.bc0[i]);
+            if (act) lds.bc1[tl] = stab;
+        }
+        __syncthreads();
+        float kk[NP];
+        // built in chunks of 8 with a compiler barrier between them: a free-running full unroll
+        // keeps hundreds of LDS reads in flight and the allocator answers by spilling K entries
+        // for the whole kernel
+        if (!colw) {
+#pragma unroll
+            for (int j0 = 0; j0 < N_; j0 += 8) {
+#pragma unroll
+                for (int j = j0; j < j0 + 8 && j < N_; ++j)
+                    kk[j] = fast_exp2(((T[tt * N_ + j] - stab) - lds.bc1[j]) * LOG2E);
+                asm volatile("" ::: "memory");
+            }
+        } else {
+#pragma unroll
+            for (int i0 = 0; i0 < N_; i0 += 8) {
+#pragma unroll
+                for (int i = i0; i < i0 + 8 && i < N_; ++i)
+                    kk[i] = fast_exp2(((T[i * N_ + tt] - lds.bc0[i]) - stab) * LOG2E);
+                asm volatile("" ::: "memory");
+            }
+        }
+#pragma unroll
+        for (int q = N_; q < NP; ++q) kk[q] = 0.f;
+        const float marg = expf(lmarg);
+        float sc = colw ? expf(stab) : 1.f;        // b starts at exp(c_j); a is computed first
+        __syncthreads();                           // everyone is done reading the stabilisers
+        if (colw && act) lds.bc1[tl] = sc;
+        for (int it = 0; it < iters; ++it) {
+            __syncthreads();                       // b visible
+            if (!colw) {
+                sc = marg * fast_rcp(dotN<N_>(kk, lds.bc1));
+                if (act) lds.bc0[tl] = sc;
+            }
+            __syncthreads();                       // a visible
+            if (colw) {
+                sc = marg * fast_rcp(dotN<N_>(kk, lds.bc0));
+                if (act) lds.bc1[tl] = sc;
+            }
+        }
+        const bool ok_wave = __all(!act || scaling_ok(sc));
+        __syncthreads();
+        if (lane == 0) lds.red[wave] = ok_wave ? 1.f : 0.f;
+        __syncthreads();
+        const float okp = (lds.red[0] * lds.red[1] * lds.red[2]) * (lds.red[3] * lds.red[4] * lds.red[5]);
+        if (okp > 0.5f) {
+            dual = logf(sc) - stab;
+            solved = true;
+        }
+        __syncthreads();
+    }
+
+    if (!solved) {      // workgroup-uniform: max-subtracted log-sum-exp sweeps on Z itself.
+        // Rare path (guard tripped, or PATS_SINKHORN_LOG): Z is read from the LDS tile each time
+        // rather than held in registers, so it does not raise the kernel's VGPR budget.
+        const int zstride = colw ? N_ : 1;
+        const float* zbase = colw ? T + tt : T + tt * N_;
+        dual = 0.f;
+        if (act) { lds.bc0[tl] = 0.f; lds.bc1[tl] = 0.f; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {          // h = 0: u from v (row waves); h = 1: v from u
+                __syncthreads();
+                if ((h == 1) == colw) {
+                    const float* other = h == 0 ? lds.bc1 : lds.bc0;
+                    float m = -INFINITY;
+#pragma unroll 8
+                    for (int q = 0; q < N_; ++q) m = fmaxf(m, zbase[q * zstride] + other[q]);
+                    if (m == -INFINITY || m == INFINITY) m = 0.f;
+                    const float mI = ceilf(m * LOG2E);
+                    float sacc = 0.f;
+#pragma unroll 8
+                    for (int q = 0; q < N_; ++q)
+                        sacc += fast_exp2(fmaf(zbase[q * zstride] + other[q], LOG2E, -mI));
+                    dual = lmarg - lse_finish(sacc, mI);
+                    if (act) (h == 0 ? lds.bc0 : lds.bc1)[tl] = dual;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: ((Z + u) + v) - norm (+ bias) from the LDS copy of Z, coalesced ---------------
+    __syncthreads();
+    if (act) (colw ? lds.bc1 : lds.bc0)[tl] = dual;
+    __syncthreads();
+    const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
+    float* Op = out + p * NN;
+    for (int k = t; k < NN; k += TH) {
+        const int i = k / N_, j = k - i * N_;
+        float z = ((T[k] + lds.bc0[i]) + lds.bc1[j]) - norm;
+        if (bias_k > 0.f) {
+            if (j == N_ - 1) z += lb;
+            if (i == N_ - 1) z += lb;
+        }
+        Op[k] = z;
     }
 }
 
@@ -214,8 +498,9 @@ __global__ void sinkhorn_wg_kernel(SrcView src, int M, int N, const float* __res
                                    const float* __restrict__ log_nu,
                                    const float* __restrict__ norm_in, int iters, float bias_k,
                                    float* __restrict__ out, float* __restrict__ wsZ,
-                                   float* __restrict__ wsT) {
+                                   float* __restrict__ wsT, const int* __restrict__ only_if) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    if (only_if && only_if[blockIdx.x] == 0) return;     // re-solve pass: only flagged problems
     float* u = sm;          // [M]
     float* v = sm + M;      // [N]
     const int b = blockIdx.x;
@@ -269,12 +554,248 @@ __global__ void sinkhorn_wg_kernel(SrcView src, int M, int N, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// up to 304 x 320 (the coarse level: 301 x 301), one 1024-thread workgroup = one CU per problem
+// ------------------------------------------------------------------------------------------
+// The whole kernel matrix lives in the register files of one CU: wave w owns rows w, w+16, ...
+// (RPW = 19 of them), lane l owns columns l, l+64, ... (CPL = 5), so a lane holds a 19 x 5 block
+// (95 VGPRs, 4 waves per SIMD).  Column scalings b_j are lane-local registers; row scalings a_i
+// are wave-uniform (SGPR) values.  Row pass: 95 FMAs per lane, then ONE transposed all-reduce of
+// the 19 partial sums (v_permlane32_swap pairs rows across half-waves, v_permlane16_swap across
+// 16-lane rows, then 4 DPP steps: ~50 instructions instead of 19 separate 6-step reductions).
+// Column pass: 95 FMAs per lane into 5 partial column sums, combined across the 16 waves through a
+// double-buffered 20 KB LDS array (one barrier per sweep).  Z is re-read from L2 for the epilogue.
+// A problem whose scalings leave the guard sets fail[b]; sinkhorn_wg_kernel re-solves only those.
+template <int RPW, class Op>
+struct RowReduce {
+    static constexpr int N1 = (RPW + 1) / 2, N2 = (N1 + 1) / 2;
+    // slot s (row wave + 16 s) lives in red[slot_reg(s)], 16-lane group slot_grp(s)
+    __host__ __device__ static constexpr int slot_reg(int s) { return (s < N1 ? s : s - N1) % N2; }
+    __host__ __device__ static constexpr int slot_grp(int s) {
+        return (s < N1 ? 0 : 2) + (((s < N1 ? s : s - N1) >= N2) ? 1 : 0);
+    }
+    // slot held by register i in 16-lane group g (may be >= RPW: padding)
+    __device__ static int slot_of(int i, int g) { return i + N2 * (g & 1) + N1 * (g >> 1); }
+
+    // pf(s) yields this lane's partial for slot s; it is evaluated right before the swap that
+    // consumes it so the RPW partials are never all live at once
+    template <class PF>
+    __device__ static void run(PF pf, float (&red)[N2], Op op, float identity) {
+        float a1[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) {
+            unsigned x = __builtin_bit_cast(unsigned, pf(i));
+            unsigned y = __builtin_bit_cast(unsigned, (i + N1 < RPW) ? pf(i + N1 < RPW ? i + N1 : 0) : identity);
+            asm volatile("" : "+v"(y));
+            auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+            unsigned a = r[0], b = r[1];
+            asm volatile("" : "+v"(a), "+v"(b));
+            a1[i] = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+        }
+#pragma unroll
+        for (int i = 0; i < N2; ++i) {
+            unsigned x = __builtin_bit_cast(unsigned, a1[i]);
+            unsigned y = __builtin_bit_cast(unsigned, (i + N2 < N1) ? a1[i + N2] : identity);
+            asm volatile("" : "+v"(y));
+            auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+            unsigned a = r[0], b = r[1];
+            asm volatile("" : "+v"(a), "+v"(b));
+            float v = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+            v = op(v, dpp_f<DPP_QUAD_XOR1>(v));
+            v = op(v, dpp_f<DPP_QUAD_XOR2>(v));
+            v = op(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+            v = op(v, dpp_f<DPP_ROW_MIRROR>(v));
+            red[i] = v;
+        }
+    }
+};
+
+template <int RPW, int CPL, int LSLOTS>
+__global__ void __launch_bounds__(1024)
+sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
+                   const float* __restrict__ log_nu, const float* __restrict__ norm_in, int iters,
+                   float* __restrict__ out, int* __restrict__ fail) {
+    constexpr int NW = 16, CW = CPL * 64, RREG = RPW - LSLOTS;
+    using RSum = RowReduce<RPW, OpSum>;
+    using RMax = RowReduce<RPW, OpMax>;
+    constexpr int N1 = RSum::N1, N2 = RSum::N2;
+    __shared__ float part[2][NW][CW];       // cross-wave column partials (double-buffered)
+    __shared__ float kl[LSLOTS][NW][CW];    // the last LSLOTS row-slots of K (register budget: 128)
+    __shared__ float rsave[NW][RPW + 1];    // row stabilisers r_i per (wave, slot)
+    __shared__ float csave[CW];             // column stabilisers
+    __shared__ int ok_s[NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4;
+    const int b = blockIdx.x;
+    const float* sb = src.base + (int64_t)b * src.stride;
+    const float* lmu = log_mu + (int64_t)b * M;
+    const float* lnu = log_nu + (int64_t)b * N;
+
+    float K[RREG][CPL];
+#define KREF(s_, c) (*((s_) < RREG ? &K[(s_) < RREG ? (s_) : 0][c] : &kl[(s_) >= RREG ? (s_) - RREG : 0][wave][lane + 64 * (c)]))
+    bool cval[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) cval[c] = lane + 64 * c < N;
+
+    // ---- load Z block (rows wave + 16 s, columns lane + 64 c); -inf outside the matrix ----------
+#pragma unroll
+    for (int s_ = 0; s_ < RPW; ++s_) {
+        const int i = wave + NW * s_;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            KREF(s_, c) = (i < M && cval[c]) ? src_at(src, sb, i, lane + 64 * c) : -INFINITY;
+    }
+    // ---- r_i = max_j Z_ij (transposed wave reduction) ------------------------------------------
+    {
+        float rred[N2];
+        RMax::run([&](int s_) {
+            float m = KREF(s_, 0);
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) m = fmaxf(m, KREF(s_, c));
+            return m; }, rred, OpMax(), -INFINITY);
+        // keep one scalar per row slot: slot s sits in register slot_reg(s), 16-lane group slot_grp(s)
+#pragma unroll
+        for (int i = 0; i < N2; ++i)
+            if ((lane & 15) == 0 && RSum::slot_of(i, grp) < RPW) rsave[wave][RSum::slot_of(i, grp)] = rred[i];
+    }
+    // ---- c_j = max_i (Z_ij - r_i): per-wave partial, then across waves through LDS ---------------
+    // (same wave wrote rsave: LDS operations of one wave complete in order)
+#define RS(s_) (rsave[wave][s_])
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int s_ = 0; s_ < RPW; ++s_)
+            if (s_ * NW < M) m = fmaxf(m, (wave + NW * s_ < M) ? KREF(s_, c) - RS(s_) : -INFINITY);
+        part[0][wave][lane + 64 * c] = m;
+    }
+    __syncthreads();
+    float bsc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        float m = part[0][0][lane + 64 * c];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, part[0][w][lane + 64 * c]);
+        m = cval[c] ? m : 0.f;
+        if (wave == 0) csave[lane + 64 * c] = m;
+        bsc[c] = m;                                     // temporarily the stabiliser c_j
+    }
+    // ---- K = exp(Z - r - c), zero outside the matrix -------------------------------------------
+#pragma unroll
+    for (int s_ = 0; s_ < RPW; ++s_) {
+        const float r_s = RS(s_);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool v = (wave + NW * s_ < M) && cval[c];
+            KREF(s_, c) = v ? fast_exp2(((KREF(s_, c) - r_s) - bsc[c]) * LOG2E) : 0.f;
+        }
+    }
+    // marginals: nu per owned column; mu in the reduced layout (register i, group g <-> slot)
+    float nu[CPL], mured[N2], ared[N2];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        nu[c] = cval[c] ? expf(lnu[lane + 64 * c]) : 0.f;
+        bsc[c] = cval[c] ? expf(bsc[c]) : 0.f;          // b starts at exp(c_j)
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const int row = wave + NW * RSum::slot_of(i, grp);
+        mured[i] = (RSum::slot_of(i, grp) < RPW && row < M) ? expf(lmu[row]) : 0.f;
+        ared[i] = 0.f;
+    }
+    __syncthreads();        // part[0] is free again
+
+    for (int it = 0; it < iters; ++it) {
+        // ---- a_i = mu_i / sum_j K_ij b_j ----------------------------------------------------------
+        float sred[N2];
+        RSum::run([&](int s_) {
+            float acc = KREF(s_, 0) * bsc[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) acc = fmaf(KREF(s_, c), bsc[c], acc);
+            return acc; }, sred, OpSum(), 0.f);
+#pragma unroll
+        for (int i = 0; i < N2; ++i) ared[i] = mured[i] * fast_rcp(sred[i]);   // padding slots: never read
+        // ---- b_j = nu_j / sum_i K_ij a_i ----------------------------------------------------------
+        float t[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t[c] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < RPW; ++s_) {
+            const float a_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                __builtin_bit_cast(int, ared[RSum::slot_reg(s_)]), 16 * RSum::slot_grp(s_)));
+            const float a_u = (wave + NW * s_ < M) ? a_s : 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) t[c] = fmaf(KREF(s_, c), a_u, t[c]);
+        }
+        float (*pb)[CW] = part[it & 1];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) pb[wave][lane + 64 * c] = t[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += pb[w][lane + 64 * c];
+            bsc[c] = cval[c] ? nu[c] * fast_rcp(tot) : 0.f;
+        }
+    }
+
+    // ---- guard -------------------------------------------------------------------------------
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) ok = ok && (!cval[c] || scaling_ok(bsc[c]));
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const int sl = RSum::slot_of(i, grp);
+        ok = ok && (!(sl < RPW && wave + NW * sl < M) || scaling_ok(ared[i]));
+    }
+    const bool okw = __all(ok);
+    __syncthreads();
+    if (lane == 0) ok_s[wave] = okw ? 1 : 0;
+    __syncthreads();
+    bool all_ok = iters > 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) all_ok = all_ok && ok_s[w] != 0;
+    if (threadIdx.x == 0) fail[b] = all_ok ? 0 : 1;
+    if (!all_ok) return;            // sinkhorn_wg_kernel will solve this problem
+
+    // ---- duals and epilogue: ((Z + u) + v) - norm ----------------------------------------------
+    float ured[N2], vs[CPL];
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const int sl = RSum::slot_of(i, grp);
+        ured[i] = logf(ared[i]) - rsave[wave][sl < RPW ? sl : RPW];
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) vs[c] = logf(bsc[c]) - csave[lane + 64 * c];
+    const float norm = norm_in ? norm_in[b] : 0.f;
+    float* ob = out + (int64_t)b * M * N;
+#pragma unroll
+    for (int s_ = 0; s_ < RPW; ++s_) {
+        const int i = wave + NW * s_;
+        const float u_s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+            __builtin_bit_cast(int, ured[RSum::slot_reg(s_)]), 16 * RSum::slot_grp(s_)));
+        if (i < M) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (cval[c]) {
+                    const int j = lane + 64 * c;
+                    float z = (src_at(src, sb, i, j) + u_s) + vs[c];
+                    if (norm_in) z = z - norm;
+                    ob[(int64_t)i * N + j] = z;
+                }
+        }
+    }
+#undef KREF
+#undef RS
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct OtWorkspace {
     float *log_mu, *log_nu, *norm, *Zw, *Zt;
+    int* fail;
     size_t bytes;
 };
 static OtWorkspace carve(void* ws, int64_t batch, int M, int N, bool marginals, bool zw) {
@@ -287,6 +808,7 @@ static OtWorkspace carve(void* ws, int64_t batch, int M, int N, bool marginals, 
         w.log_nu = take((size_t)batch * N);
         w.norm = take((size_t)batch);
     }
+    w.fail = (int*)take((size_t)batch);
     if (zw) w.Zw = take((size_t)batch * M * N);
     w.Zt = take((size_t)batch * M * N);
     w.bytes = off;
@@ -295,21 +817,39 @@ static OtWorkspace carve(void* ws, int64_t batch, int M, int N, bool marginals, 
 
 static int launch_wg(const SrcView& src, int64_t batch, int M, int N, const float* log_mu,
                      const float* log_nu, const float* norm, int iters, float bias_k, float* out,
-                     float* Zw, float* Zt, hipStream_t st) {
+                     float* Zw, float* Zt, hipStream_t st, const int* only_if = nullptr) {
     const int threads = ((int64_t)M * N >= 128 * 128) ? 1024 : 256;
     const size_t lds = (size_t)(M + N) * sizeof(float);
     PATS_REQUIRE(lds <= 64 * 1024, "sinkhorn: M+N=%d too large for the one-workgroup kernel", M + N);
     hipLaunchKernelGGL(sinkhorn_wg_kernel, dim3((unsigned)batch), dim3(threads), lds, st, src, M, N,
-                       log_mu, log_nu, norm, iters, bias_k, out, Zw, Zt);
+                       log_mu, log_nu, norm, iters, bias_k, out, Zw, Zt, only_if);
     return check_launch("sinkhorn_wg_kernel");
+}
+
+constexpr int CU_RPW = 19, CU_CPL = 5, CU_LSLOTS = 5;            // 16 * 19 = 304 rows, 64 * 5 = 320 columns
+static inline bool cu_shape(int M, int N) { return M <= 16 * CU_RPW && N <= 64 * CU_CPL && M * N >= 96 * 96; }
+
+// one-CU linear-domain kernel, then the log-domain kernel on the problems it flagged
+static int launch_cu_then_fallback(const SrcView& src, int64_t batch, int M, int N, const float* log_mu,
+                                   const float* log_nu, const float* norm, int iters, float* out,
+                                   const OtWorkspace& w, hipStream_t st) {
+    hipLaunchKernelGGL((sinkhorn_cu_kernel<CU_RPW, CU_CPL, CU_LSLOTS>), dim3((unsigned)batch), dim3(1024), 0, st, src, M,
+                       N, log_mu, log_nu, norm, iters, out, w.fail);
+    int rc = check_launch("sinkhorn_cu_kernel");
+    if (rc) return rc;
+    return launch_wg(src, batch, M, N, log_mu, log_nu, norm, iters, 0.f, out, w.Zw, w.Zt, st, w.fail);
 }
 
 }  // namespace pats
 
 using namespace pats;
 
+constexpr int NF = 145;   // fine level (12 x 12 + dustbin)
+static inline bool resident_shape(int M, int N) { return (M == NT && N == NT) || (M == NF && N == NF); }
+static inline int use_linear() { return sinkhorn_mode() != PATS_SINKHORN_LOG; }
+
 extern "C" size_t pats_sinkhorn_workspace_bytes(int64_t batch, int M, int N) {
-    if (M == NT && N == NT) return 0;
+    if (resident_shape(M, N)) return 0;
     return carve(nullptr, batch, M, N, false, false).bytes;
 }
 
@@ -327,13 +867,20 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
     hipStream_t st = as_stream(stream);
     if (M == NT && N == NT) {
         hipLaunchKernelGGL(sinkhorn65_kernel<0>, dim3((unsigned)batch), dim3(64), 0, st, Z, batch,
-                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, out);
+                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, use_linear(), out);
         return check_launch("sinkhorn65_kernel<0>");
+    }
+    if (M == NF && N == NF) {
+        hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch,
+                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, use_linear(), out);
+        return check_launch("sinkhorn_rc_kernel<145,0>");
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_sinkhorn_workspace_bytes(batch, M, N),
                  "sinkhorn: workspace too small");
     OtWorkspace w = carve(workspace, batch, M, N, false, false);
     SrcView src{Z, (int64_t)M * N, N, M, N, nullptr};
+    if (use_linear() && cu_shape(M, N))
+        return launch_cu_then_fallback(src, batch, M, N, log_mu, log_nu, nullptr, iters, out, w, st);
     return launch_wg(src, batch, M, N, log_mu, log_nu, nullptr, iters, 0.f, out, nullptr, w.Zt, st);
 }
 
@@ -354,6 +901,8 @@ extern "C" int pats_log_optimal_transport_f32(const float* scores, int64_t batch
     int rc = check_launch("ot_prep_kernel");
     if (rc) return rc;
     SrcView src{scores, (int64_t)m * n, n, m, n, alpha};
+    if (use_linear() && cu_shape(M, N))
+        return launch_cu_then_fallback(src, batch, M, N, w.log_mu, w.log_nu, w.norm, iters, Z, w, st);
     return launch_wg(src, batch, M, N, w.log_mu, w.log_nu, w.norm, iters, 0.f, Z, w.Zw, w.Zt, st);
 }
 
@@ -367,11 +916,16 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     hipStream_t st = as_stream(stream);
     if (m == NT && n == NT) {
         hipLaunchKernelGGL(sinkhorn65_kernel<2>, dim3((unsigned)batch), dim3(64), 0, st, scores,
-                           batch, nullptr, nullptr, ns, one, iters, bias_k, Z);
+                           batch, nullptr, nullptr, ns, one, iters, bias_k, use_linear(), Z);
         return check_launch("sinkhorn65_kernel<2>");
     }
+    if (m == NF && n == NF) {
+        hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, scores,
+                           batch, nullptr, nullptr, ns, one, iters, bias_k, use_linear(), Z);
+        return check_launch("sinkhorn_rc_kernel<145,2>");
+    }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_ot_workspace_bytes(batch, m, n),
-                 "log_optimal_transport2: workspace too small");
+                 "log_optimal_transport2: workspace too small");   // shapes without a resident kernel
     OtWorkspace w = carve(workspace, batch, m, n, true, true);
     hipLaunchKernelGGL(ot_prep_kernel, dim3((unsigned)batch), dim3(256), 0, st, ns, n - 1, m, n,
                        (float)(m - 1), one, w.log_mu, w.log_nu, w.norm);

@@ -14,8 +14,8 @@ def assert_mass(Zo, Zr):
     eo, er = np.exp(Zo.astype(np.float64)), np.exp(Zr.astype(np.float64))
     np.testing.assert_allclose(eo, er, atol=MASS_TOL, rtol=2e-6)
     # marginals: 1e-4 absolute, plus fp32 resolution on the dustbin marginals (mass ~ sum(ns) >> 1)
-    np.testing.assert_allclose(eo.sum(-1), er.sum(-1), atol=MASS_TOL, rtol=1e-6)
-    np.testing.assert_allclose(eo.sum(-2), er.sum(-2), atol=MASS_TOL, rtol=1e-6)
+    np.testing.assert_allclose(eo.sum(-1), er.sum(-1), atol=MASS_TOL, rtol=3e-6)
+    np.testing.assert_allclose(eo.sum(-2), er.sum(-2), atol=MASS_TOL, rtol=3e-6)
     # log-plan itself agrees tightly where mass is non-negligible
     big = er > 1e-6
     assert np.abs(Zo[big] - Zr[big]).max() <= 2e-4
