@@ -165,6 +165,18 @@ int pats_compute_result_f32(const float* scores, int input_is_log, int64_t P, co
                             int outdoor, float* mkpts0_f, float* mkpts1_f, float* whole_loss,
                             float* label, uint8_t* if_matching1, pats_stream_t stream);
 
+/* ---- the whole third-level step in ONE launch: a3 + a5 + a7(exp) + a17 + a18 ------------------
+ * feat0, feat1 [P,D,65] (D a multiple of 16; 128 in the reference) -> cost build (third_layer.py:156-157),
+ * log_optimal_transport2(0.1*scores, 1, scale, iters) (:158), exp (:159), Compute_result (:160,
+ * :184-217) and the label (:161-170).  One wave per problem; the 65x65 plan never leaves the CU
+ * unless Z_out != NULL ([P,65,65] log-plan).  scale [P,64] = target areas (the OT's `ns`);
+ * scale_x, scale_y [P,64] = sqrt(scale + 1e-8) as the caller computes them (:153-154).
+ * whole_loss is not produced (unused at inference; use pats_compute_result_f32 for it). */
+int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int D, const float* scale,
+                         const float* scale_x, const float* scale_y, const int64_t* p_s,
+                         const int64_t* p_t, int iters, int outdoor, float* mkpts0_f, float* mkpts1_f,
+                         float* label, uint8_t* if_matching1, float* Z_out, pats_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,21 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
     if (i0 >= n || j0 >= m) return;
     const float* A = d0 + b * (int64_t)D * n;
     const float* B = d1 + b * (int64_t)D * m;
+    float* O = out + b * (int64_t)n * m;
+    // One-wide edge tiles (the dustbin row / column of 65 = 64 + 1 and 145 = 144 + 1 shapes): a
+    // 32x32 MFMA tile would spend the whole K loop on one valid row, so these are plain fp32 dot
+    // products instead - one output per lane, fmaf chain in k order (same numerics as the MFMA).
+    if (n - i0 == 1 || m - j0 == 1) {
+        const bool row_edge = (n - i0 == 1);
+        const int cnt = row_edge ? min(32, m - j0) : min(32, n - i0);
+        for (int e = lane; e < cnt; e += 64) {
+            const int i = row_edge ? i0 : i0 + e, j = row_edge ? j0 + e : j0;
+            float acc = 0.f;
+            for (int k = 0; k < D; ++k) acc = fmaf(A[(int64_t)k * n + i], B[(int64_t)k * m + j], acc);
+            O[(int64_t)i * m + j] = 0.1f * (acc / sqrtD);
+        }
+        return;
+    }
     const int li = lane & 31, lk = lane >> 5;
     const int ia = i0 + li, jb = j0 + li;
     const bool va = ia < n, vb = jb < m;
@@ -55,7 +70,6 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
     }
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float* O = out + b * (int64_t)n * m;
     const int col = j0 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -69,6 +83,7 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
 
 }  // namespace pats
 
+namespace pats { int launch_cost65(const float*, const float*, int, int64_t, float*, hipStream_t); }
 using namespace pats;
 
 extern "C" int pats_cost_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
@@ -76,6 +91,8 @@ extern "C" int pats_cost_f32(const float* d0, const float* d1, int64_t batch, in
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(d0 && d1 && out, "cost: null pointer");
+    if (n == 65 && m == 65 && (D % 16) == 0)      // third level: one wave per problem, see sinkhorn.hip
+        return launch_cost65(d0, d1, D, batch, out, as_stream(stream));
     const int64_t tiles = (int64_t)((n + 63) / 64) * ((m + 63) / 64);
     PATS_REQUIRE(tiles * batch < (1ll << 31), "cost: grid too large (split the call)");
     hipLaunchKernelGGL(cost_mfma_kernel, dim3((unsigned)(tiles * batch)), dim3(256), 0,

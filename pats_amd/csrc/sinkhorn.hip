@@ -19,6 +19,7 @@
 // stabiliser mI = ceil(max_j t_j * log2e): max-subtracted like ATen's logsumexp, exact stabiliser
 // arithmetic, one v_exp_f32 per element.
 #include "common.hpp"
+#include "third_device.hpp"
 
 namespace pats {
 
@@ -127,23 +128,142 @@ __device__ __forceinline__ float dot64(const float (&k)[64], const float* bc) {
     return dot_bcast<64, 16>(k, bc);
 }
 
-// mode 0: log_mu/log_nu given (a6)      mode 2: ns given, log_optimal_transport2 marginals (a5)
-template <int MODE>
-__global__ void __launch_bounds__(64)
-sinkhorn65_kernel(const float* __restrict__ Zin, int64_t P, const float* __restrict__ log_mu_in,
-                  const float* __restrict__ log_nu_in, const float* __restrict__ ns,
-                  const float* __restrict__ one, int iters, float bias_k, int linear,
-                  float* __restrict__ out) {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Cost build of ONE 65x65 problem by one wave, straight into its LDS tile (third_layer.py:156-158):
+// the 64x64 core as 2x2 tiles of v_mfma_f32_32x32x2_f32 over D (operands global -> VGPR, each
+// half-wave reads 256 contiguous bytes of a descriptor row; every element is loaded exactly once),
+// the dustbin row / column / corner (index 64) as fp32 FMA chains riding along in the VALU slots
+// between the MFMAs (even-k and odd-k half-wave chains, summed at the end).  D % 16 == 0.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ void cost65_to_tile(const float* __restrict__ A, const float* __restrict__ B,
+                                               int D, float* tile, int lane) {
+    // MFMA row index li of tile t stands for matrix row 2*li + t (tile 0 = even rows, tile 1 = odd
+    // rows; same for columns): one 8-byte load per lane then feeds BOTH tiles, and every 32-lane
+    // half reads one contiguous 256-byte stretch of a descriptor row.
+    const int li = lane & 31, lk = lane >> 5;
+    f32x16 c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+    float er0 = 0.f, er1 = 0.f, ec0 = 0.f, ec1 = 0.f, cn = 0.f;
+    const float* pa = A + lk * NT + 2 * li;
+    const float* pb = B + lk * NT + 2 * li;
+    // explicit software pipeline over blocks of KB = 4 k-steps (8 descriptor rows): the next block's
+    // 8 vector + 16 scalar loads are in flight while this block's 16 MFMAs (1024 cycles) run
+    constexpr int KB = 4;
+    struct Blk { f2u a[KB], b[KB]; float ea[KB], eb[KB]; };
+    auto load_blk = [&](int k0, Blk& q) {
+#pragma unroll
+        for (int s_ = 0; s_ < KB; ++s_) {
+            const int k = k0 + 2 * s_;                    // D % 16 == 0: whole blocks only
+            q.a[s_] = *reinterpret_cast<const f2u*>(pa + k * NT);
+            q.b[s_] = *reinterpret_cast<const f2u*>(pb + k * NT);
+            // dustbin entries: wave-uniform addresses -> scalar loads, then pick this half's k
+            const float ea_e = A[k * NT + NB], ea_o = A[(k + 1) * NT + NB];
+            const float eb_e = B[k * NT + NB], eb_o = B[(k + 1) * NT + NB];
+            q.ea[s_] = lk ? ea_o : ea_e;
+            q.eb[s_] = lk ? eb_o : eb_e;
+        }
+    };
+    auto compute_blk = [&](const Blk& q) {
+#pragma unroll
+        for (int s_ = 0; s_ < KB; ++s_) {
+            const f2u av = q.a[s_], bv = q.b[s_];
+            const float ea = q.ea[s_], eb = q.eb[s_];
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c11, 0, 0, 0);
+            er0 = fmaf(ea, bv.x, er0);
+            er1 = fmaf(ea, bv.y, er1);
+            ec0 = fmaf(av.x, eb, ec0);
+            ec1 = fmaf(av.y, eb, ec1);
+            cn = fmaf(ea, eb, cn);
+        }
+    };
+    // ping-pong buffers, two blocks per trip (D % 16 == 0): no register copies, so the only wait in
+    // front of a block's MFMAs is for that block's own loads
+    Blk bufA, bufB;
+    load_blk(0, bufA);
+    for (int k0 = 0; k0 < D; k0 += 4 * KB) {
+        load_blk(k0 + 2 * KB, bufB);
+        compute_blk(bufA);
+        load_blk(k0 + 4 * KB < D ? k0 + 4 * KB : 0, bufA);    // (a harmless reload of block 0 at the end)
+        compute_blk(bufB);
+    }
+    er0 += __shfl_xor(er0, 32); er1 += __shfl_xor(er1, 32);
+    ec0 += __shfl_xor(ec0, 32); ec1 += __shfl_xor(ec1, 32);
+    cn += __shfl_xor(cn, 32);
+    const float sq = sqrtf((float)D);
+    auto scl = [sq](float x) { return 0.1f * (x / sq); };      // `/ D**.5` then `0.1 *`, two roundings
+    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rc = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        tile[(2 * rc) * NT + 2 * li] = scl(c00[r]);
+        tile[(2 * rc) * NT + 2 * li + 1] = scl(c01[r]);
+        tile[(2 * rc + 1) * NT + 2 * li] = scl(c10[r]);
+        tile[(2 * rc + 1) * NT + 2 * li + 1] = scl(c11[r]);
+    }
+    if (lk == 0) {
+        tile[NB * NT + 2 * li] = scl(er0);
+        tile[NB * NT + 2 * li + 1] = scl(er1);
+        tile[(2 * li) * NT + NB] = scl(ec0);
+        tile[(2 * li + 1) * NT + NB] = scl(ec1);
+    }
+    if (lane == 0) tile[TILE - 1] = scl(cn);
+}
+
+struct Ot65Args {
+    const float* Zin;        // SRC 0: [P,65,65] couplings
+    const float* d0;         // SRC 1: [P,D,65] descriptors
+    const float* d1;
+    int D;
+    int64_t P;
+    const float* log_mu;     // MODE 0
+    const float* log_nu;
+    const float* ns;         // MODE 2: [P,64]
+    const float* one;
+    int iters;
+    float bias_k;
+    int linear;
+    float* out;              // [P,65,65] log-plan, may be null when EPI == 1
+    // EPI 1: Compute_result fused (third_layer.py:159-170,184-217)
+    const float* scale_x;
+    const float* scale_y;
+    const int64_t* p_s;
+    const int64_t* p_t;
+    int outdoor;
+    ComputeResultOut cr;
+};
+
+// MODE 0: log_mu/log_nu given (a6)      MODE 2: ns given, log_optimal_transport2 marginals (a5)
+// SRC  0: couplings from HBM            SRC  1: cost build from descriptors (a3 fused)
+// EPI  0: write the log-plan            EPI  1: Compute_result + label from the LDS-resident plan
+template <int MODE, int SRC, int EPI>
+__global__ void __launch_bounds__(64, 2)     // 2 waves/SIMD: VGPR + AGPR (MFMA accumulators) <= 256
+sinkhorn65_kernel(Ot65Args g) {
     __shared__ Wave65Lds lds;
     const int lane = threadIdx.x;
     const int64_t p = blockIdx.x;
-    if (p >= P) return;
-    const float* Zp = Zin + p * TILE;
+    if (p >= g.P) return;
+    const float* __restrict__ log_mu_in = g.log_mu;
+    const float* __restrict__ log_nu_in = g.log_nu;
+    const float* __restrict__ ns = g.ns;
+    const float* __restrict__ one = g.one;
+    const int iters = g.iters, linear = g.linear;
+    const float bias_k = g.bias_k;
 
-    // ---- coalesced load of the 4225 floats into LDS --------------------------------------------
+    if (SRC == 0) {
+        // ---- coalesced load of the 4225 floats into LDS ----------------------------------------
+        const float* Zp = g.Zin + p * TILE;
 #pragma unroll 11
-    for (int k = 0; k < 66; ++k) lds.tile[k * 64 + lane] = Zp[k * 64 + lane];
-    if (lane == 0) lds.tile[TILE - 1] = Zp[TILE - 1];
+        for (int k = 0; k < 66; ++k) lds.tile[k * 64 + lane] = Zp[k * 64 + lane];
+        if (lane == 0) lds.tile[TILE - 1] = Zp[TILE - 1];
+    } else {
+        cost65_to_tile(g.d0 + p * (int64_t)g.D * NT, g.d1 + p * (int64_t)g.D * NT, g.D, lds.tile, lane);
+    }
 
     // ---- marginals -----------------------------------------------------------------------
     float lmu, lmu64, lnu, lnu64, norm = 0.f;
@@ -267,15 +387,17 @@ sinkhorn65_kernel(const float* __restrict__ Zin, int64_t P, const float* __restr
         }
     }
 
-    // ---- Z + u + v - norm (+ the caller's dustbin bias) from the original Z, coalesced rows ------
+    // ---- Z + u + v - norm (+ the caller's dustbin bias) from the original Z -----------------------
     __syncthreads();
     lds.bc0[lane] = u;
     __syncthreads();
     const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
-    float* Op = out + p * TILE;
+    float* Tw = lds.tile;
+    if (EPI == 0) {
+        float* Op = g.out + p * TILE;
 #pragma unroll 8
-    for (int i = 0; i < NB; ++i) Op[i * NT + lane] = ((T[i * NT + lane] + lds.bc0[i]) + v) - norm;
-    {   // dustbin column entries (i, 64) and dustbin row entries (64, j)
+        for (int i = 0; i < NB; ++i) Op[i * NT + lane] = ((T[i * NT + lane] + lds.bc0[i]) + v) - norm;
+        // dustbin column entries (i, 64) and dustbin row entries (64, j)
         float cc = ((T[lane * NT + NB] + u) + v64) - norm;
         float rr = ((T[NB * NT + lane] + u64) + v) - norm;
         if (bias_k > 0.f) { cc += lb; rr += lb; }
@@ -286,7 +408,51 @@ sinkhorn65_kernel(const float* __restrict__ Zin, int64_t P, const float* __restr
             if (bias_k > 0.f) { q += lb; q += lb; }     // corner receives both in-place adds
             Op[TILE - 1] = q;
         }
+    } else {
+        // the log-plan replaces Z in the LDS tile; Compute_result reads it there
+#pragma unroll 8
+        for (int i = 0; i < NB; ++i) Tw[i * NT + lane] = ((T[i * NT + lane] + lds.bc0[i]) + v) - norm;
+        float cc = ((T[lane * NT + NB] + u) + v64) - norm;
+        float rr = ((T[NB * NT + lane] + u64) + v) - norm;
+        if (bias_k > 0.f) { cc += lb; rr += lb; }
+        float q = ((corner_z + u64) + v64) - norm;
+        if (bias_k > 0.f) { q += lb; q += lb; }
+        __syncthreads();
+        Tw[lane * NT + NB] = cc;
+        Tw[NB * NT + lane] = rr;
+        if (lane == 0) Tw[TILE - 1] = q;
+        __syncthreads();
+        if (g.out) {
+            float* Op = g.out + p * TILE;
+#pragma unroll 11
+            for (int k = 0; k < 66; ++k) Op[k * 64 + lane] = Tw[k * 64 + lane];
+            if (lane == 0) Op[TILE - 1] = Tw[TILE - 1];
+        }
+        compute_result_problem(Tw, 1, p, g.scale_x + p * 64, g.scale_y + p * 64,
+                               (float)g.p_s[p * 2], (float)g.p_s[p * 2 + 1], (float)g.p_t[p * 2],
+                               (float)g.p_t[p * 2 + 1], g.outdoor, g.cr, lane);
     }
+}
+
+// standalone cost build for 65-wide problems (pats_cost_f32 fast path): one wave per problem
+__global__ void __launch_bounds__(64)
+cost65_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D, int64_t P,
+              float* __restrict__ out) {
+    __shared__ float tile[TILE + 3];
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    if (p >= P) return;
+    cost65_to_tile(d0 + p * (int64_t)D * NT, d1 + p * (int64_t)D * NT, D, tile, lane);
+    __syncthreads();
+    float* Op = out + p * TILE;
+#pragma unroll 11
+    for (int k = 0; k < 66; ++k) Op[k * 64 + lane] = tile[k * 64 + lane];
+    if (lane == 0) Op[TILE - 1] = tile[TILE - 1];
+}
+
+int launch_cost65(const float* d0, const float* d1, int D, int64_t P, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(cost65_kernel, dim3((unsigned)P), dim3(64), 0, st, d0, d1, D, P, out);
+    return check_launch("cost65_kernel");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -866,9 +1032,11 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
     PATS_REQUIRE(Z && log_mu && log_nu && out, "sinkhorn: null pointer");
     hipStream_t st = as_stream(stream);
     if (M == NT && N == NT) {
-        hipLaunchKernelGGL(sinkhorn65_kernel<0>, dim3((unsigned)batch), dim3(64), 0, st, Z, batch,
-                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, use_linear(), out);
-        return check_launch("sinkhorn65_kernel<0>");
+        Ot65Args g{};
+        g.Zin = Z; g.P = batch; g.log_mu = log_mu; g.log_nu = log_nu; g.iters = iters;
+        g.linear = use_linear(); g.out = out;
+        hipLaunchKernelGGL((sinkhorn65_kernel<0, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
+        return check_launch("sinkhorn65_kernel<0,0,0>");
     }
     if (M == NF && N == NF) {
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch,
@@ -915,9 +1083,11 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     PATS_REQUIRE(scores && ns && Z, "log_optimal_transport2: null pointer");
     hipStream_t st = as_stream(stream);
     if (m == NT && n == NT) {
-        hipLaunchKernelGGL(sinkhorn65_kernel<2>, dim3((unsigned)batch), dim3(64), 0, st, scores,
-                           batch, nullptr, nullptr, ns, one, iters, bias_k, use_linear(), Z);
-        return check_launch("sinkhorn65_kernel<2>");
+        Ot65Args g{};
+        g.Zin = scores; g.P = batch; g.ns = ns; g.one = one; g.iters = iters; g.bias_k = bias_k;
+        g.linear = use_linear(); g.out = Z;
+        hipLaunchKernelGGL((sinkhorn65_kernel<2, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
+        return check_launch("sinkhorn65_kernel<2,0,0>");
     }
     if (m == NF && n == NF) {
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, scores,
@@ -933,4 +1103,34 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     if (rc) return rc;
     SrcView src{scores, (int64_t)m * n, n, m, n, nullptr};
     return launch_wg(src, batch, m, n, w.log_mu, w.log_nu, w.norm, iters, bias_k, Z, nullptr, w.Zt, st);
+}
+
+// descriptors -> log-plan for 65x65 problems in one launch (cost build + OT2), used by pats_cost_ot_f32
+namespace pats {
+int launch_cost_ot65(const float* d0, const float* d1, int64_t batch, int D, const float* one,
+                     const float* ns, int iters, float bias_k, float* Z, pats_stream_t stream) {
+    Ot65Args g{};
+    g.d0 = d0; g.d1 = d1; g.D = D; g.P = batch; g.ns = ns; g.one = one; g.iters = iters;
+    g.bias_k = bias_k; g.linear = use_linear(); g.out = Z;
+    hipLaunchKernelGGL((sinkhorn65_kernel<2, 1, 0>), dim3((unsigned)batch), dim3(64), 0, as_stream(stream), g);
+    return check_launch("sinkhorn65_kernel<2,1,0>");
+}
+}  // namespace pats
+
+extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int D,
+                                    const float* scale, const float* scale_x, const float* scale_y,
+                                    const int64_t* p_s, const int64_t* p_t, int iters, int outdoor,
+                                    float* mkpts0_f, float* mkpts1_f, float* label,
+                                    uint8_t* if_matching1, float* Z_out, pats_stream_t stream) {
+    PATS_REQUIRE(P >= 0 && D > 0 && (D % 16) == 0 && iters >= 0, "third_level: bad shape (D must be a multiple of 16)");
+    if (P == 0) return PATS_OK;
+    PATS_REQUIRE(feat0 && feat1 && scale && scale_x && scale_y && p_s && p_t && mkpts0_f && mkpts1_f &&
+                     label && if_matching1, "third_level: null pointer");
+    Ot65Args g{};
+    g.d0 = feat0; g.d1 = feat1; g.D = D; g.P = P; g.ns = scale; g.iters = iters;
+    g.linear = use_linear(); g.out = Z_out;
+    g.scale_x = scale_x; g.scale_y = scale_y; g.p_s = p_s; g.p_t = p_t; g.outdoor = outdoor;
+    g.cr = ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr};
+    hipLaunchKernelGGL((sinkhorn65_kernel<2, 1, 1>), dim3((unsigned)P), dim3(64), 0, as_stream(stream), g);
+    return check_launch("sinkhorn65_kernel<2,1,1>");
 }

@@ -385,3 +385,31 @@ def Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device=None, outdoo
                                         _ptr(pt), int(bool(outdoor)), _ptr(m0), _ptr(m1), _ptr(wl),
                                         _ptr(label), _ptr(ifm), _stream()), "Compute_result")
     return m0, m1, wl, label, ifm.bool()
+
+
+def third_level(feat_f0_unfold, feat_f1_unfold, scale, mkpts0_c, mkpts1_c, outdoor=True, iters=100,
+                return_plan=False):
+    """The third layer's whole OT step in one launch (third_layer.py:153-170):
+        scale_x = scale_y = sqrt(scale + 1e-8)
+        scores  = exp(log_optimal_transport2(0.1 * einsum(f0, f1) / 128**.5, 1, scale, 100))
+        mkpts0_f, mkpts1_f, _ = Compute_result(scores, 8, 5, scale_x, scale_y, mkpts0_c, mkpts1_c)
+        label / if_matching1 as :161-170
+    Returns (mkpts0_f, mkpts1_f, label, if_matching1[, Z]).  The 65x65 plans stay on chip."""
+    f0, f1 = _dev(feat_f0_unfold, "feat_f0_unfold"), _dev(feat_f1_unfold, "feat_f1_unfold")
+    P, D, n = f0.shape
+    if n != 65 or tuple(f1.shape) != (P, D, 65):
+        raise RuntimeError("third_level: descriptors must be [P,D,65]")
+    sc = _dev(scale, "scale").reshape(P, 64)
+    sxy = torch.sqrt(sc + 1e-8)
+    ps = _dev(mkpts0_c.to(torch.int64), "mkpts0_c", torch.int64).reshape(P, 2)
+    pt = _dev(mkpts1_c.to(torch.int64), "mkpts1_c", torch.int64).reshape(P, 2)
+    dev = f0.device
+    m0 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
+    m1 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
+    label = torch.empty((P * 16, 2), dtype=torch.float32, device=dev)
+    ifm = torch.empty((P, 16), dtype=torch.uint8, device=dev)
+    Z = torch.empty((P, 65, 65), dtype=torch.float32, device=dev) if return_plan else None
+    _check(_L().pats_third_level_f32(_ptr(f0), _ptr(f1), P, D, _ptr(sc), _ptr(sxy), _ptr(sxy), _ptr(ps),
+                                     _ptr(pt), int(iters), int(bool(outdoor)), _ptr(m0), _ptr(m1),
+                                     _ptr(label), _ptr(ifm), _ptr(Z), _stream()), "third_level")
+    return (m0, m1, label, ifm.bool(), Z) if return_plan else (m0, m1, label, ifm.bool())

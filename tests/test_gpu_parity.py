@@ -274,6 +274,18 @@ def test_third_level(ops, oracle, name):
         np.testing.assert_allclose(wl.cpu().numpy(), g["whole_loss"], atol=1e-6)
         assert np.array_equal(ifm.cpu().numpy(), g["if_matching1"])
         np.testing.assert_array_equal(label.cpu().numpy(), g["label"])
+    # the whole step fused in one launch: descriptors in, matches out
+    m0, m1, label, ifm, Zf = ops.third_level(d0, d1, scale, ps, pt, outdoor=outdoor, return_plan=True)
+    assert torch.equal(Zf, Z)
+    np.testing.assert_array_equal(m0.cpu().numpy(), g["mkpts0_f"])
+    np.testing.assert_allclose(m1.cpu().numpy(), g["mkpts1_f"], atol=3e-4)
+    assert np.array_equal(ifm.cpu().numpy(), g["if_matching1"])
+    np.testing.assert_array_equal(label.cpu().numpy(), g["label"])
+    m0b, m1b, labelb, ifmb = ops.third_level(d0, d1, scale, ps, pt, outdoor=outdoor)
+    assert torch.equal(m1b, m1) and torch.equal(labelb, label)
+    # the 65-wide cost fast path against the oracle
+    np.testing.assert_allclose(ops.cost(d0, d1).cpu().numpy(), oracle.cost(inp["d0"], inp["d1"]),
+                               atol=2e-5, rtol=1e-5)
     # a6 on the 65x65 register-resident kernel with explicit marginals, against the oracle
     rng = np.random.default_rng(11)
     Zr = (2 * rng.standard_normal((5, 65, 65))).astype(np.float32)
