@@ -2,10 +2,14 @@
 //
 // Replaces Iterative_expand_matrix (utils/utils.py:1179-1297) + Compute_scaling (:1321-1340) +
 // Compute_positions_and_ranges (:1527-1537).  The reference runs ~40 small ATen ops per growth
-// iteration over index tensors [b, m, 4*width] and materialises a [hw, b, m, 2] ruler; here one
-// wave owns one source patch: its row of exp(Z) is staged once in LDS, each growth step gathers
-// the four adjacent strips from LDS and reduces them with wave shuffles, and the final centroid /
-// scale is one strided pass over the row.  Every quirk of the reference is kept literally:
+// iteration over index tensors [b, m, 4*width] and materialises a [hw, b, m, 2] ruler.
+//
+// Here one 16-lane DPP row owns one source patch (four patches per wave, sixteen per workgroup):
+// the patch's row of exp(Z) is staged once in LDS (exp fused into the load when handed the log
+// plan), lane t of the group gathers cell t (t+16, ...) of each of the four adjacent strips, and
+// every sum / argmax is a 4-step row-level DPP reduction whose result lands in all 16 lanes - no
+// cross-row traffic, no LDS shuffles; the growth decision is then taken redundantly per lane.
+// Every quirk of the reference is kept literally (each has a fixture):
 //   * sentinel index width*height+1 reading the appended 1e-14 (:1205-1208,1220-1221)
 //   * `ranges` rows padded with 1e7 so out-of-span strip cells overflow to the sentinel (:1536)
 //   * the left/right strips wrapping into the neighbouring grid row (only the SUM is zeroed at
@@ -14,6 +18,7 @@
 //   * width = max(h, w), height = h*w / width as the function derives them (:1181)
 //   * if_nomatching compared against the ROW count (:1191)
 #include "common.hpp"
+#include "third_device.hpp"     // row16_sum / row16_argmax
 
 namespace pats {
 
@@ -40,51 +45,53 @@ __device__ __forceinline__ int clamp_seq(float f, int wh, int S) {
     return (int)s;
 }
 
+
 __global__ void __launch_bounds__(256)
 expand_kernel(ExpandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = threadIdx.x & 15, slot = threadIdx.x >> 4;      // lane in group, group in workgroup
+    const int ROWS_PER_WG = blockDim.x >> 4;                      // 16 (256 threads) or 4 for wide rows
     const int M = a.M, N = a.N, m = M - 1, n = N - 1;
-    const int64_t gr = (int64_t)blockIdx.x * 4 + wave;
-    const bool active = gr < a.rows_total;
-    const int64_t b = active ? gr / m : 0;
-    const int r = active ? (int)(gr - b * m) : 0;
-    float* prow = sm + (size_t)wave * (N + 3);
+    const int64_t gr_raw = (int64_t)blockIdx.x * ROWS_PER_WG + slot;
+    const bool active = gr_raw < a.rows_total;
+    const int64_t gr = active ? gr_raw : a.rows_total - 1;       // idle groups shadow the last row
+    const int64_t b = gr / m;
+    const int r = (int)(gr - b * m);
+    const int ld = N + 3;
+    float* prow = sm + (size_t)slot * ld;
+    float* popp = sm + (size_t)ROWS_PER_WG * ld + (size_t)slot * ld;   // this batch's dustbin row
     const float* Pb = a.P + b * (int64_t)M * N;
     const float* src = Pb + (int64_t)r * N;
-    const float* oppsrc = Pb + (int64_t)(M - 1) * N;   // scores_in[:, -1, :-1]   (:1183)
+    const float* oppsrc = Pb + (int64_t)(M - 1) * N;              // scores_in[:, -1, :-1]   (:1183)
     const float* sx = a.scalex + b * (int64_t)n;
     const float* sy = a.scaley + b * (int64_t)n;
-    if (active) {
-        for (int j = lane; j < N; j += 64) prow[j] = a.input_is_log ? expf(src[j]) : src[j];
+    for (int j = t; j < N; j += 16) {
+        const float x = src[j], o = oppsrc[j];
+        prow[j] = a.input_is_log ? expf(x) : x;
+        popp[j] = a.input_is_log ? expf(o) : o;
     }
-    __syncthreads();
-    if (!active) return;
+    __syncthreads();     // every thread gets here (idle groups shadow the last row)
 
     const int width = a.h > a.w ? a.h : a.w;
     const int height = (a.h * a.w) / width;
     const int wh = width * height, S = wh + 1;
-    auto ES = [&](int idx) { return idx < N ? prow[idx] : ZERO_F; };
-    auto ESC = [&](int idx) { return idx < n ? sx[idx] * sy[idx] : ZERO_F; };
-    auto EOPP = [&](int idx) {
-        if (idx >= n) return ZERO_F;
-        const float o = oppsrc[idx];
-        return a.input_is_log ? expf(o) : o;
-    };
+    auto ES = [&](int idx) { return idx < N ? prow[idx] : ZERO_F; };                 // :1205
+    auto ESC = [&](int idx) { return idx < n ? sx[idx] * sy[idx] : ZERO_F; };        // :1206-1207
+    auto EOPP = [&](int idx) { return idx < n ? popp[idx] : ZERO_F; };               // :1208
 
     // argmax over the real columns (:1182) and over all columns (:1191), first index on ties
     float bv = -INFINITY, bva = -INFINITY;
     int bi = 0x7fffffff, bia = 0x7fffffff;
     float rowsum = 0.f;
-    for (int j = lane; j < N; j += 64) {
+    for (int j = t; j < N; j += 16) {
         const float x = prow[j];
         rowsum += x;
         if (j < n && (x > bv || bi == 0x7fffffff)) { bv = x; bi = j; }
         if (x > bva || bia == 0x7fffffff) { bva = x; bia = j; }
     }
-    wave_argmax(bv, bi);
-    wave_argmax(bva, bia);
-    const float the_scale = wave_sum(rowsum);                       // scores.sum(2)  (:1288)
+    row16_argmax(bv, bi);
+    row16_argmax(bva, bia);
+    const float the_scale = row16_sum(rowsum);                      // scores.sum(2)  (:1288)
     const int max0 = bi;
     const bool if_nomatching = (bia == m);
     float last_nomatching = EOPP(max0);                             // :1184
@@ -94,44 +101,45 @@ expand_kernel(ExpandArgs a) {
 
     for (int it = 0; it < a.iter_num; ++it) {
         sb0 = bd0; sb1 = bd1;                                       // :1215
-        const float off0 = (float)(left + up * width - width);      // :1217
-        const float off1 = (float)(left + down * width + width);    // :1218
-        const float off2 = (float)(left + up * width - 1);          // :1219
-        const float off3 = (float)(right + up * width + 1);         // :1220
+        const float off[4] = {(float)(left + up * width - width),   // :1217
+                              (float)(left + down * width + width), // :1218
+                              (float)(left + up * width - 1),       // :1219
+                              (float)(right + up * width + 1)};     // :1220
         float es[4], nm[4], sc[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float e = 0.f, q = 0.f, c = 0.f;
-            const float off = d == 0 ? off0 : d == 1 ? off1 : d == 2 ? off2 : off3;
-            for (int k = lane; k < width; k += 64) {
-                const float f = d < 2 ? range_val(sb1, k) + off : range_val(sb0, k) * (float)width + off;
+            for (int k = t; k < width; k += 16) {
+                const float f = d < 2 ? range_val(sb1, k) + off[d] : range_val(sb0, k) * (float)width + off[d];
                 const int s = clamp_seq(f, wh, S);
                 const float v = ES(s);
                 e += v;
                 q += (v > a.lower_bound) ? EOPP(s) : ZERO_F;        // :1225
                 c += ESC(s);                                        // :1231
             }
-            es[d] = wave_sum(e);
-            nm[d] = wave_sum(q);
-            sc[d] = wave_sum(c);
+            es[d] = row16_sum(e);
+            nm[d] = row16_sum(q);
+            sc[d] = row16_sum(c);
         }
         if (up == 0) es[0] = ZERO_F;                                // :1227-1230
         if (down == height - 1) es[1] = ZERO_F;
         if (left == 0) es[2] = ZERO_F;
         if (right == width - 1) es[3] = ZERO_F;
         int arg = 0;
-        float mx = es[0], msc = sc[0], mnm = nm[0];
+        float mx = es[0], mnm = nm[0];
 #pragma unroll
         for (int d = 1; d < 4; ++d)
-            if (es[d] > mx) { mx = es[d]; msc = sc[d]; mnm = nm[d]; arg = d; }   // :1232-1234
+            if (es[d] > mx) { mx = es[d]; mnm = nm[d]; arg = d; }   // :1232-1234
+        (void)sc;       // last_scale is accumulated by the reference (:1242) but never consumed
         float add_sum = ZERO_F, add_nm = ZERO_F;
         if (mx > a.lower_bound) {                                   // :1235-1238
-            if (arg == 0) up -= 1; else if (arg == 1) down += 1;
-            else if (arg == 2) left -= 1; else right += 1;
+            up -= (arg == 0);
+            down += (arg == 1);
+            left -= (arg == 2);
+            right += (arg == 3);
             add_sum = mx;
             add_nm = mnm;
         }
-        (void)msc;   // last_scale is accumulated by the reference (:1242) but never consumed
         bd0 = down - up;                                            // :1239-1240
         bd1 = right - left;
         last_sum = last_sum + add_sum;                              // :1241
@@ -140,7 +148,7 @@ expand_kernel(ExpandArgs a) {
     const bool if_core_exist = (bd0 > 1) && (bd1 > 1);              // :1244
 
     // border strips of the final rectangle with the stale sequence_base (:1245-1253)
-    float e4 = 0.f, s4 = 0.f;
+    float e4, s4;
     {
         const float eoff[4] = {(float)(left + up * width), (float)(left + down * width),
                                (float)(left + up * width), (float)(right + up * width)};
@@ -148,15 +156,15 @@ expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float e = 0.f, c = 0.f;
-            for (int k = lane; k < width; k += 64) {
+            for (int k = t; k < width; k += 16) {
                 const float f = d < 2 ? range_val(sb1, k) + eoff[d]
                                       : range_val(sb0, k) * (float)width + eoff[d];
                 const int s = clamp_seq(f, wh, S);
                 e += ES(s);
                 c += ESC(s);
             }
-            ed[d] = wave_sum(e);
-            sd[d] = wave_sum(c);
+            ed[d] = row16_sum(e);
+            sd[d] = row16_sum(c);
         }
         e4 = (ed[0] + ed[1]) + (ed[2] + ed[3]);
         s4 = (sd[0] + sd[1]) + (sd[2] + sd[3]);
@@ -164,7 +172,7 @@ expand_kernel(ExpandArgs a) {
 
     // in-rectangle weights, centroid and scale (:1254-1273, Compute_scaling :1321-1340)
     float wx = 0.f, wy = 0.f, sumx = 0.f, sumy = 0.f, ws = 0.f, so = 0.f;
-    for (int p = lane; p < n; p += 64) {
+    for (int p = t; p < n; p += 16) {
         const int pyi = p / a.w, pxi = p - pyi * a.w;               // positions (:1528-1532)
         const bool crit = pyi >= up && pyi <= down && pxi >= left && pxi <= right;
         const float root = sqrtf(prow[p] + 1e-7f);
@@ -179,10 +187,10 @@ expand_kernel(ExpandArgs a) {
         ws += o * (fx * fy);
         so += o;
     }
-    wx = wave_sum(wx); wy = wave_sum(wy); sumx = wave_sum(sumx); sumy = wave_sum(sumy);
-    ws = wave_sum(ws); so = wave_sum(so);
+    wx = row16_sum(wx); wy = row16_sum(wy); sumx = row16_sum(sumx); sumy = row16_sum(sumy);
+    ws = row16_sum(ws); so = row16_sum(so);
 
-    if (lane == 0) {
+    if (t == 0 && active) {
         // corners (:1279-1287)
         const int corner[4] = {up * width + left, up * width + right, down * width + left,
                                down * width + right};
@@ -232,9 +240,14 @@ extern "C" int pats_iterative_expand_f32(const float* P, int input_is_log, int64
                      y_scale && bound, "iterative_expand: null pointer");
     ExpandArgs a{P, input_is_log, batch * (int64_t)(M - 1), M, N, scalex, scaley, lim3, h, w,
                  lower_bound, iter_num, whole_cost, core_cost, average_point, x_scale, y_scale, bound};
-    const size_t lds = 4 * (size_t)(N + 3) * sizeof(float);
+    int rows_per_wg = 16;
+    size_t lds = 2 * (size_t)rows_per_wg * (size_t)(N + 3) * sizeof(float);
+    if (lds > 48 * 1024) {
+        rows_per_wg = 4;
+        lds = 2 * (size_t)rows_per_wg * (size_t)(N + 3) * sizeof(float);
+    }
     PATS_REQUIRE(lds <= 64 * 1024, "iterative_expand: N=%d too large", N);
-    const int64_t blocks = ceil_div(a.rows_total, 4);
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), a);
+    const int64_t blocks = ceil_div(a.rows_total, rows_per_wg);
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(16 * rows_per_wg), lds, as_stream(stream), a);
     return check_launch("expand_kernel");
 }
