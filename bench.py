@@ -237,6 +237,16 @@ def main():
     exp_rate = float((2.0 * ITERS * 65 * 65 * probs / (ms * 1e-3)).mean())
     sweeps_per_pair = ITERS * (1 + B + P)        # one sweep = row + column normalisation of one problem
 
+    # HBM traffic of the dominant kernel from rocprofv3 PMC passes (collected separately, see the file)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_third.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        traffic = float(pmc["hbm_bytes_per_problem"]) * float(probs.mean())
+        traffic_src = "profiles/r01_pmc_third.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), " \
+                      "FETCH calibrated x%.2f on cost65_kernel's known byte count; per problem x problems per launch" \
+                      % pmc["fetch_calibration"]["factor"]
+
     out = {
         "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -252,7 +262,9 @@ def main():
         "ot_iters_per_sec": value * sweeps_per_pair,
         "roofline": {"bound": "hbm", "kernel": "sinkhorn65_kernel<2,1,1> (fused third level, %d problems per launch)" % wl.chunks[0]["P"],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
                      "avg_launch_ms": float(ms.mean()), "launches": int(len(ms)),
                      "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
                      "sweep_elements_per_s": exp_rate,
