@@ -166,7 +166,7 @@ int pats_compute_result_f32(const float* scores, int input_is_log, int64_t P, co
                             float* label, uint8_t* if_matching1, pats_stream_t stream);
 
 /* ---- the whole third-level step in ONE launch: a3 + a5 + a7(exp) + a17 + a18 ------------------
- * feat0, feat1 [P,D,65] (D a multiple of 16; 128 in the reference) -> cost build (third_layer.py:156-157),
+ * feat0, feat1 [P,D,65] (D a multiple of 32, at most 512; 128 in the reference) -> cost build (third_layer.py:156-157),
  * log_optimal_transport2(0.1*scores, 1, scale, iters) (:158), exp (:159), Compute_result (:160,
  * :184-217) and the label (:161-170).  One wave per problem; the 65x65 plan never leaves the CU
  * unless Z_out != NULL ([P,65,65] log-plan).  scale [P,64] = target areas (the OT's `ns`);

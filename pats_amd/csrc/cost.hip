@@ -91,7 +91,7 @@ extern "C" int pats_cost_f32(const float* d0, const float* d1, int64_t batch, in
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(d0 && d1 && out, "cost: null pointer");
-    if (n == 65 && m == 65 && (D % 16) == 0)      // third level: one wave per problem, see sinkhorn.hip
+    if (n == 65 && m == 65 && (D % 32) == 0 && D <= 512)      // third level: one wave per problem, see sinkhorn.hip
         return launch_cost65(d0, d1, D, batch, out, as_stream(stream));
     const int64_t tiles = (int64_t)((n + 63) / 64) * ((m + 63) / 64);
     PATS_REQUIRE(tiles * batch < (1ll << 31), "cost: grid too large (split the call)");

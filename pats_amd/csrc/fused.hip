@@ -16,7 +16,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int variant) {
     (void)D;
-    if (variant == 2 && n == 65 && m == 65 && (D % 16) == 0) return 0;
+    if (variant == 2 && n == 65 && m == 65 && (D % 32) == 0 && D <= 512) return 0;
     const size_t scores = align256((size_t)batch * n * m * sizeof(float));
     const int M = variant == 1 ? n + 1 : n, N = variant == 1 ? m + 1 : m;
     return scores + pats_ot_workspace_bytes(batch, M, N);
@@ -29,7 +29,7 @@ extern "C" int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch,
     PATS_REQUIRE(variant == 1 || variant == 2, "cost_ot: variant must be 1 or 2");
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost_ot: bad shape");
     if (batch == 0) return PATS_OK;
-    if (variant == 2 && n == 65 && m == 65 && (D % 16) == 0) {
+    if (variant == 2 && n == 65 && m == 65 && (D % 32) == 0 && D <= 512) {
         PATS_REQUIRE(d0 && d1 && ns && Z, "cost_ot: null pointer");
         return launch_cost_ot65(d0, d1, batch, D, scalar, ns, iters, bias_k, Z, stream);
     }

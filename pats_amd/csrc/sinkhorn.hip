@@ -20,6 +20,7 @@
 // arithmetic, one v_exp_f32 per element.
 #include "common.hpp"
 #include "third_device.hpp"
+#include <stdlib.h>
 
 namespace pats {
 
@@ -147,30 +148,34 @@ __device__ __forceinline__ void cost65_to_tile(const float* __restrict__ A, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
     float er0 = 0.f, er1 = 0.f, ec0 = 0.f, ec1 = 0.f, cn = 0.f;
+    // the dustbin columns d0[:,64], d1[:,64] (D values each) are parked in the still-unused LDS
+    // tile, so the register ring below carries only the MFMA operand pairs
+    float* eA = tile;
+    float* eB = tile + 512;
+    for (int k = lane; k < D; k += 64) {
+        eA[k] = A[k * NT + NB];
+        eB[k] = B[k * NT + NB];
+    }
     const float* pa = A + lk * NT + 2 * li;
     const float* pb = B + lk * NT + 2 * li;
-    // explicit software pipeline over blocks of KB = 4 k-steps (8 descriptor rows): the next block's
-    // 8 vector + 16 scalar loads are in flight while this block's 16 MFMAs (1024 cycles) run
+    // explicit software pipeline over blocks of KB = 4 k-steps (8 descriptor rows): a ring of four
+    // named register buffers keeps three blocks of loads in flight ahead of the MFMAs (deeper rings
+    // were measured slower: the phase is HBM-bandwidth-bound, and the extra registers spill)
     constexpr int KB = 4;
-    struct Blk { f2u a[KB], b[KB]; float ea[KB], eb[KB]; };
+    struct Blk { f2u a[KB], b[KB]; };
     auto load_blk = [&](int k0, Blk& q) {
 #pragma unroll
         for (int s_ = 0; s_ < KB; ++s_) {
-            const int k = k0 + 2 * s_;                    // D % 16 == 0: whole blocks only
+            const int k = k0 + 2 * s_;                    // D % 32 == 0: whole rings only
             q.a[s_] = *reinterpret_cast<const f2u*>(pa + k * NT);
             q.b[s_] = *reinterpret_cast<const f2u*>(pb + k * NT);
-            // dustbin entries: wave-uniform addresses -> scalar loads, then pick this half's k
-            const float ea_e = A[k * NT + NB], ea_o = A[(k + 1) * NT + NB];
-            const float eb_e = B[k * NT + NB], eb_o = B[(k + 1) * NT + NB];
-            q.ea[s_] = lk ? ea_o : ea_e;
-            q.eb[s_] = lk ? eb_o : eb_e;
         }
     };
-    auto compute_blk = [&](const Blk& q) {
+    auto compute_blk = [&](int k0, const Blk& q) {
 #pragma unroll
         for (int s_ = 0; s_ < KB; ++s_) {
             const f2u av = q.a[s_], bv = q.b[s_];
-            const float ea = q.ea[s_], eb = q.eb[s_];
+            const float ea = eA[k0 + 2 * s_ + lk], eb = eB[k0 + 2 * s_ + lk];
             c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c00, 0, 0, 0);
             c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, c01, 0, 0, 0);
             c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, c10, 0, 0, 0);
@@ -182,16 +187,18 @@ __device__ __forceinline__ void cost65_to_tile(const float* __restrict__ A, cons
             cn = fmaf(ea, eb, cn);
         }
     };
-    // ping-pong buffers, two blocks per trip (D % 16 == 0): no register copies, so the only wait in
-    // front of a block's MFMAs is for that block's own loads
-    Blk bufA, bufB;
-    load_blk(0, bufA);
-    for (int k0 = 0; k0 < D; k0 += 4 * KB) {
-        load_blk(k0 + 2 * KB, bufB);
-        compute_blk(bufA);
-        load_blk(k0 + 4 * KB < D ? k0 + 4 * KB : 0, bufA);    // (a harmless reload of block 0 at the end)
-        compute_blk(bufB);
+    const int nblk = D / (2 * KB);
+    auto k0_of = [&](int blk) { return (blk < nblk ? blk : 0) * 2 * KB; };   // wrap: harmless reloads at the end
+    Blk r0, r1, r2, r3;
+    load_blk(k0_of(0), r0); load_blk(k0_of(1), r1); load_blk(k0_of(2), r2);
+    __syncthreads();                                     // eA / eB visible
+    for (int blk = 0; blk < nblk; blk += 4) {
+        load_blk(k0_of(blk + 3), r3); compute_blk(k0_of(blk + 0), r0);
+        load_blk(k0_of(blk + 4), r0); compute_blk(k0_of(blk + 1), r1);
+        load_blk(k0_of(blk + 5), r1); compute_blk(k0_of(blk + 2), r2);
+        load_blk(k0_of(blk + 6), r2); compute_blk(k0_of(blk + 3), r3);
     }
+    __syncthreads();                                     // done with eA / eB before the tile is written
     er0 += __shfl_xor(er0, 32); er1 += __shfl_xor(er1, 32);
     ec0 += __shfl_xor(ec0, 32); ec1 += __shfl_xor(ec1, 32);
     cn += __shfl_xor(cn, 32);
@@ -236,6 +243,7 @@ struct Ot65Args {
     const int64_t* p_t;
     int outdoor;
     ComputeResultOut cr;
+    int stagger;             // first-wave-front start delay unit, in s_sleep(127) periods (0 = off)
 };
 
 // MODE 0: log_mu/log_nu given (a6)      MODE 2: ns given, log_optimal_transport2 marginals (a5)
@@ -255,6 +263,15 @@ sinkhorn65_kernel(Ot65Args g) {
     const int iters = g.iters, linear = g.linear;
     const float bias_k = g.bias_k;
 
+    // Every problem takes the same time, so without this all resident waves stay phase-locked: the
+    // chip alternates between "everyone streams descriptors" (HBM-bound, VALU idle) and "everyone
+    // sweeps" (VALU/LDS-bound, HBM idle) and the phase times ADD.  A hashed one-off start delay for
+    // the first wave-front spreads the phases; later blocks inherit the spread from the slot they
+    // take over.  Purely a scheduling aid - no effect on results.
+    if (g.stagger > 0 && blockIdx.x < 4096u) {
+        const unsigned slots = (blockIdx.x * 2654435761u) >> 29;         // 0..7
+        for (unsigned q = 0; q < slots * (unsigned)g.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+    }
     if (SRC == 0) {
         // ---- coalesced load of the 4225 floats into LDS ----------------------------------------
         const float* Zp = g.Zin + p * TILE;
@@ -1131,6 +1148,11 @@ extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int6
     g.linear = use_linear(); g.out = Z_out;
     g.scale_x = scale_x; g.scale_y = scale_y; g.p_s = p_s; g.p_t = p_t; g.outdoor = outdoor;
     g.cr = ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr};
+    // one problem ~ (30 + 0.6 * iters) us per wave slot; spread 8 start phases over that period
+    // when the launch is at least ~4 full rounds of the 2048 wave slots (s_sleep(127) ~ 3.4 us)
+    // (measured on MI355X: unit 1-3 all give ~-11 %, larger units lose it again)
+    if (P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)iters) / 16.0f / 3.4f);
+    if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
     hipLaunchKernelGGL((sinkhorn65_kernel<2, 1, 1>), dim3((unsigned)P), dim3(64), 0, as_stream(stream), g);
     return check_launch("sinkhorn65_kernel<2,1,1>");
 }
