@@ -975,10 +975,13 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
 // host side
 // ------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t stream_workspace_bytes(int64_t batch, int M, int N);
+static inline size_t al256_fwd(int64_t batch, int M, int N) { return align256(stream_workspace_bytes(batch, M, N)); }
 
 struct OtWorkspace {
     float *log_mu, *log_nu, *norm, *Zw, *Zt;
     int* fail;
+    void* stream;
     size_t bytes;
 };
 static OtWorkspace carve(void* ws, int64_t batch, int M, int N, bool marginals, bool zw) {
@@ -994,6 +997,10 @@ static OtWorkspace carve(void* ws, int64_t batch, int M, int N, bool marginals, 
     w.fail = (int*)take((size_t)batch);
     if (zw) w.Zw = take((size_t)batch * M * N);
     w.Zt = take((size_t)batch * M * N);
+    if ((int64_t)M * N > 304 * 320 && N <= 512 * 9) {       // streaming solver's K / partials / vectors
+        w.stream = base + off;
+        off += al256_fwd(batch, M, N);
+    }
     w.bytes = off;
     return w;
 }
@@ -1008,6 +1015,12 @@ static int launch_wg(const SrcView& src, int64_t batch, int M, int N, const floa
                        log_mu, log_nu, norm, iters, bias_k, out, Zw, Zt, only_if);
     return check_launch("sinkhorn_wg_kernel");
 }
+
+size_t stream_workspace_bytes(int64_t batch, int M, int N);
+int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols, const float* alpha,
+                  int64_t batch, int M, int N, const float* log_mu, const float* log_nu, const float* norm,
+                  int iters, float* out, void* ws, int* fail, hipStream_t st);
+static inline bool stream_shape(int M, int N) { return (int64_t)M * N > 304 * 320 && N <= 512 * 9; }
 
 constexpr int CU_RPW = 19, CU_CPL = 5, CU_LSLOTS = 5;            // 16 * 19 = 304 rows, 64 * 5 = 320 columns
 static inline bool cu_shape(int M, int N) { return M <= 16 * CU_RPW && N <= 64 * CU_CPL && M * N >= 96 * 96; }
@@ -1063,9 +1076,15 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
     PATS_REQUIRE(workspace && workspace_bytes >= pats_sinkhorn_workspace_bytes(batch, M, N),
                  "sinkhorn: workspace too small");
     OtWorkspace w = carve(workspace, batch, M, N, false, false);
-    SrcView src{Z, (int64_t)M * N, N, M, N, nullptr};
+    SrcView src{Z, (int64_t)M * N, N, M, N, nullptr};   // (w.fail / w.stream are carved for every shape)
     if (use_linear() && cu_shape(M, N))
         return launch_cu_then_fallback(src, batch, M, N, log_mu, log_nu, nullptr, iters, out, w, st);
+    if (use_linear() && stream_shape(M, N) && batch <= 65535) {
+        int rc = launch_stream(Z, (int64_t)M * N, N, M, N, nullptr, batch, M, N, log_mu, log_nu, nullptr, iters,
+                               out, w.stream, w.fail, st);
+        if (rc) return rc;
+        return launch_wg(src, batch, M, N, log_mu, log_nu, nullptr, iters, 0.f, out, nullptr, w.Zt, st, w.fail);
+    }
     return launch_wg(src, batch, M, N, log_mu, log_nu, nullptr, iters, 0.f, out, nullptr, w.Zt, st);
 }
 
@@ -1088,6 +1107,12 @@ extern "C" int pats_log_optimal_transport_f32(const float* scores, int64_t batch
     SrcView src{scores, (int64_t)m * n, n, m, n, alpha};
     if (use_linear() && cu_shape(M, N))
         return launch_cu_then_fallback(src, batch, M, N, w.log_mu, w.log_nu, w.norm, iters, Z, w, st);
+    if (use_linear() && stream_shape(M, N) && batch <= 65535) {
+        rc = launch_stream(scores, (int64_t)m * n, n, m, n, alpha, batch, M, N, w.log_mu, w.log_nu, w.norm, iters,
+                           Z, w.stream, w.fail, st);
+        if (rc) return rc;
+        return launch_wg(src, batch, M, N, w.log_mu, w.log_nu, w.norm, iters, 0.f, Z, w.Zw, w.Zt, st, w.fail);
+    }
     return launch_wg(src, batch, M, N, w.log_mu, w.log_nu, w.norm, iters, 0.f, Z, w.Zw, w.Zt, st);
 }
 

@@ -1,0 +1,295 @@
+// Streaming Sinkhorn for problems too large for one CU (coarse level on big images: 769^2 at
+// 1024x768, 1901^2 at 1600 px; BASELINE config 5: 4097^2, 200 sweeps).
+//
+// Same linear-domain iteration as sinkhorn.hip (a = mu / K b ; b = nu / K^T a on
+// K = exp(Z - r - c), models/modules.py:137-143 in kernel-matrix form), but K lives in HBM
+// (67 MB at 4097^2: resident in the 256 MB Infinity Cache) and every sweep is TWO launches:
+//
+//   stream_sweep_kernel   one 512-thread workgroup per block of RB rows.  Thread t owns columns
+//                         t, t+512, ... (CPT of them): it loads its RB x CPT piece of K ONCE
+//                         (fully coalesced 2 KB row segments), forms the RB partial row dots with
+//                         the lane-local b, reduces them (transposed wave all-reduce + 8-wave LDS
+//                         combine) to a_i = mu_i / sum, and - K still in registers - accumulates
+//                         the column partials sum_i K_ij a_i of its block, stored as one
+//                         coalesced row of `partial[block][N]`.  K is read once per sweep, not
+//                         twice: HBM/L3 traffic per sweep = 4 M N (+ partials), half the
+//                         "two passes" model (8 M N).
+//   stream_colreduce_kernel  b_j = nu_j / sum_blocks partial[block][j]   (16 waves split the blocks)
+//
+// Set-up (row max, column max of Z - r, K build) and the epilogue (duals back to log space,
+// Z_out = ((Z + u) + v) - norm, guard) are plain streaming kernels.  Deterministic: no atomics.
+#include "common.hpp"
+
+namespace pats {
+
+struct SrcViewS {           // same virtual source as sinkhorn.hip: plain [M,N] or scores+alpha border
+    const float* base;
+    int64_t stride;
+    int ld, rows, cols;
+    const float* alpha;
+};
+__device__ __forceinline__ float srcs_at(const SrcViewS& s, const float* b, int i, int j) {
+    if (s.alpha && (i >= s.rows || j >= s.cols)) return *s.alpha;
+    return b[(int64_t)i * s.ld + j];
+}
+
+constexpr int ST = 512;      // threads per workgroup
+constexpr int SW = ST / 64;  // waves
+
+// block-wide sum / max of one value per thread, result to all threads (LDS scratch: SW floats)
+template <class Op>
+__device__ __forceinline__ float block_allreduce(float v, Op op, float* scratch) {
+    v = wave_allreduce(v, op);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < SW; ++w) r = op(r, scratch[w]);
+    return r;
+}
+
+// ---- set-up 1: r_i = max_j Z_ij ; one workgroup per row -------------------------------------------
+__global__ void __launch_bounds__(ST)
+stream_rowmax_kernel(SrcViewS src, int M, int N, float* __restrict__ r) {
+    __shared__ float scratch[SW];
+    const int i = blockIdx.x, b = blockIdx.y;
+    const float* sb = src.base + (int64_t)b * src.stride;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < N; j += ST) m = fmaxf(m, srcs_at(src, sb, i, j));
+    m = block_allreduce(m, OpMax(), scratch);
+    if (threadIdx.x == 0) r[(int64_t)b * M + i] = m;
+}
+
+// ---- set-up 2: partial column max of (Z - r) over a block of RB rows -------------------------------
+template <int RB>
+__global__ void __launch_bounds__(ST)
+stream_colmax_partial_kernel(SrcViewS src, int M, int N, const float* __restrict__ r,
+                             float* __restrict__ partial, int nblk) {
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const float* sb = src.base + (int64_t)b * src.stride;
+    const float* rb = r + (int64_t)b * M;
+    float* pb = partial + ((int64_t)b * nblk + blk) * N;
+    for (int j = threadIdx.x; j < N; j += ST) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int i = blk * RB + k;
+            if (i < M) m = fmaxf(m, srcs_at(src, sb, i, j) - rb[i]);
+        }
+        pb[j] = m;
+    }
+}
+
+// ---- column reduce: MODE 0: c_j = max over blocks ; MODE 1: b_j = nu_j / sum over blocks -----------
+// MODE 0 also writes b_j = exp(c_j) (the scaling b starts there) to `aux`.
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+stream_colreduce_kernel(const float* __restrict__ partial, int nblk, int N,
+                        const float* __restrict__ log_nu, float* __restrict__ outv,
+                        float* __restrict__ aux) {
+    __shared__ float sm[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int j = blockIdx.x * 64 + lane;
+    const float* pb = partial + (int64_t)b * nblk * N;
+    float acc = MODE == 0 ? -INFINITY : 0.f;
+    if (j < N)
+        for (int k = wave; k < nblk; k += 16) {
+            const float v = pb[(int64_t)k * N + j];
+            acc = MODE == 0 ? fmaxf(acc, v) : acc + v;
+        }
+    sm[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && j < N) {
+        float t = sm[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t = MODE == 0 ? fmaxf(t, sm[w][lane]) : t + sm[w][lane];
+        if (MODE == 0) {
+            outv[(int64_t)b * N + j] = t;
+            aux[(int64_t)b * N + j] = expf(t);
+        } else {
+            outv[(int64_t)b * N + j] = expf(log_nu[(int64_t)b * N + j]) * __builtin_amdgcn_rcpf(t);
+        }
+    }
+}
+
+// ---- set-up 3: K = exp((Z - r_i) - c_j) ------------------------------------------------------------
+__global__ void __launch_bounds__(ST)
+stream_kbuild_kernel(SrcViewS src, int M, int N, const float* __restrict__ r,
+                     const float* __restrict__ c, float* __restrict__ K) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    const float* sb = src.base + (int64_t)b * src.stride;
+    const float ri = r[(int64_t)b * M + i];
+    const float* cb = c + (int64_t)b * N;
+    float* Kr = K + ((int64_t)b * M + i) * N;
+    for (int j = threadIdx.x; j < N; j += ST)
+        Kr[j] = fast_exp2(((srcs_at(src, sb, i, j) - ri) - cb[j]) * LOG2E);
+}
+
+// ---- the sweep ------------------------------------------------------------------------------------
+template <int RB, int CPT>
+__global__ void __launch_bounds__(ST)
+stream_sweep_kernel(const float* __restrict__ K, int M, int N, const float* __restrict__ bvec,
+                    const float* __restrict__ log_mu, float* __restrict__ avec,
+                    float* __restrict__ partial, int nblk) {
+    __shared__ float red[SW][RB];
+    __shared__ float a_s[RB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const float* Kb = K + (int64_t)b * M * N;
+    const float* bb = bvec + (int64_t)b * N;
+    float kv[RB][CPT], bq[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int j = t + ST * q;
+        bq[q] = j < N ? bb[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        const int i = blk * RB + k;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = t + ST * q;
+            kv[k][q] = (i < M && j < N) ? Kb[(int64_t)i * N + j] : 0.f;
+        }
+    }
+    // row dots: per-thread partials, wave all-reduce, then across the 8 waves through LDS
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        float p = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) p = fmaf(kv[k][q], bq[q], p);
+        p = wave_sum(p);
+        if (lane == 0) red[wave][k] = p;
+    }
+    __syncthreads();
+    if (t < RB) {
+        const int i = blk * RB + t;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < SW; ++w) s += red[w][t];
+        const float a = i < M ? expf(log_mu[(int64_t)b * M + i]) * __builtin_amdgcn_rcpf(s) : 0.f;
+        a_s[t] = a;
+        if (i < M) avec[(int64_t)b * M + i] = a;
+    }
+    __syncthreads();
+    // column partials of this row block, K still in registers
+    float* pb = partial + ((int64_t)b * nblk + blk) * N;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < RB; ++k) acc = fmaf(kv[k][q], a_s[k], acc);
+        const int j = t + ST * q;
+        if (j < N) pb[j] = acc;
+    }
+}
+
+// ---- epilogue: guard + Z_out = ((Z + u) + v) - norm -------------------------------------------------
+__global__ void __launch_bounds__(ST)
+stream_guard_kernel(const float* __restrict__ a, int M, const float* __restrict__ bvec, int N,
+                    int* __restrict__ fail) {
+    __shared__ float scratch[SW];
+    const int b = blockIdx.x;
+    float bad = 0.f;
+    for (int i = threadIdx.x; i < M; i += ST) {
+        const float x = a[(int64_t)b * M + i];
+        if (!(x <= 1073741824.0f && x > 0.f)) bad = 1.f;
+    }
+    for (int j = threadIdx.x; j < N; j += ST) {
+        const float x = bvec[(int64_t)b * N + j];
+        if (!(x <= 1073741824.0f && x > 0.f)) bad = 1.f;
+    }
+    bad = block_allreduce(bad, OpMax(), scratch);
+    if (threadIdx.x == 0) fail[b] = bad > 0.f ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(ST)
+stream_finish_kernel(SrcViewS src, int M, int N, const float* __restrict__ a,
+                     const float* __restrict__ r, const float* __restrict__ bvec,
+                     const float* __restrict__ c, const float* __restrict__ norm_in,
+                     const int* __restrict__ fail, float* __restrict__ out) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    if (fail[b]) return;                    // the log-domain kernel re-solves this problem
+    const float* sb = src.base + (int64_t)b * src.stride;
+    const float u = logf(a[(int64_t)b * M + i]) - r[(int64_t)b * M + i];
+    const float norm = norm_in ? norm_in[b] : 0.f;
+    float* ob = out + ((int64_t)b * M + i) * N;
+    for (int j = threadIdx.x; j < N; j += ST) {
+        const float v = logf(bvec[(int64_t)b * N + j]) - c[(int64_t)b * N + j];
+        float z = (srcs_at(src, sb, i, j) + u) + v;
+        if (norm_in) z = z - norm;
+        ob[j] = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t stream_workspace_bytes(int64_t batch, int M, int N) {
+    const int RB = 16;
+    const int nblk = (M + RB - 1) / RB;
+    size_t f = 0;
+    f += al256((size_t)batch * M * N * 4);          // K
+    f += al256((size_t)batch * nblk * N * 4);       // partial
+    f += 2 * al256((size_t)batch * M * 4);          // r, a
+    f += 2 * al256((size_t)batch * N * 4);          // c, b
+    return f;
+}
+
+template <int RB, int CPT>
+static void launch_sweep(const float* K, int M, int N, const float* bvec, const float* log_mu, float* a,
+                         float* partial, int nblk, int64_t batch, hipStream_t st) {
+    hipLaunchKernelGGL((stream_sweep_kernel<RB, CPT>), dim3(nblk, (unsigned)batch), dim3(ST), 0, st, K, M, N,
+                       bvec, log_mu, a, partial, nblk);
+}
+
+// Solves `batch` problems; fail[b] != 0 marks problems the caller must re-solve in the log domain.
+int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols, const float* alpha,
+                  int64_t batch, int M, int N, const float* log_mu, const float* log_nu, const float* norm,
+                  int iters, float* out, void* ws, int* fail, hipStream_t st) {
+    constexpr int RB = 16;
+    PATS_REQUIRE(N <= ST * 9, "streaming sinkhorn: N=%d exceeds %d columns", N, ST * 9);
+    PATS_REQUIRE(batch <= 65535, "streaming sinkhorn: batch too large");
+    SrcViewS src{base, stride, ld, rows, cols, alpha};
+    const int nblk = (M + RB - 1) / RB;
+    char* p = (char*)ws;
+    float* K = (float*)p;        p += al256((size_t)batch * M * N * 4);
+    float* partial = (float*)p;  p += al256((size_t)batch * nblk * N * 4);
+    float* r = (float*)p;        p += al256((size_t)batch * M * 4);
+    float* a = (float*)p;        p += al256((size_t)batch * M * 4);
+    float* c = (float*)p;        p += al256((size_t)batch * N * 4);
+    float* bv = (float*)p;
+    const dim3 rows_grid(M, (unsigned)batch), blk_grid(nblk, (unsigned)batch), col_grid((N + 63) / 64, (unsigned)batch);
+    hipLaunchKernelGGL(stream_rowmax_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r);
+    hipLaunchKernelGGL((stream_colmax_partial_kernel<RB>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
+    hipLaunchKernelGGL((stream_colreduce_kernel<0>), col_grid, dim3(1024), 0, st, partial, nblk, N, log_nu, c, bv);
+    hipLaunchKernelGGL(stream_kbuild_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r, c, K);
+    const int cpt = (N + ST - 1) / ST;
+    for (int it = 0; it < iters; ++it) {
+        switch (cpt) {
+            case 1: launch_sweep<RB, 1>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 2: launch_sweep<RB, 2>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 3: launch_sweep<RB, 3>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 4: launch_sweep<RB, 4>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 5: launch_sweep<RB, 5>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 6: launch_sweep<RB, 6>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 7: launch_sweep<RB, 7>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            case 8: launch_sweep<RB, 8>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            default: launch_sweep<RB, 9>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+        }
+        hipLaunchKernelGGL((stream_colreduce_kernel<1>), col_grid, dim3(1024), 0, st, partial, nblk, N, log_nu,
+                           bv, (float*)nullptr);
+    }
+    if (iters == 0) {       // u = v = 0: a = exp(r), b = exp(c)  ->  Z + 0 + 0; simplest: mark for the log kernel
+        hipMemsetAsync(fail, 0xff, sizeof(int) * (size_t)batch, st);
+        return check_launch("streaming sinkhorn (iters == 0)");
+    }
+    hipLaunchKernelGGL(stream_guard_kernel, dim3((unsigned)batch), dim3(ST), 0, st, a, M, bv, N, fail);
+    hipLaunchKernelGGL(stream_finish_kernel, rows_grid, dim3(ST), 0, st, src, M, N, a, r, bv, c, norm, fail, out);
+    return check_launch("streaming sinkhorn");
+}
+
+}  // namespace pats
