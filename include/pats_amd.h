@@ -165,6 +165,26 @@ int pats_compute_result_f32(const float* scores, int input_is_log, int64_t P, co
                             int outdoor, float* mkpts0_f, float* mkpts1_f, float* whole_loss,
                             float* label, uint8_t* if_matching1, pats_stream_t stream);
 
+/* ---- a15: fine-level descriptor sampling  models/second_layer.py:71-86 -----------------------
+ * feat0 [2B,64,48,48], feat1 [2B,64,24,24], feat2 [2B,128,12,12] (ResNet2.forward2 of the stacked
+ * left|right crops), title [B,8] (= compress_1(desc_l)), rubbish [B,264] (= compress_2(desc_l))
+ * -> desc [2,B,264,145]: 8 title channels, AvgPool2d(2,1,1)+grid samples at strides 4/2/1
+ * (64+64+128 channels), dustbin feature column last.  desc[0] / desc[1] are mdesc inputs of the GNN. */
+int pats_fine_descriptors_f32(const float* feat0, const float* feat1, const float* feat2,
+                              const float* title, const float* rubbish, int64_t B, float* desc,
+                              pats_stream_t stream);
+
+/* ---- a16: third-level 8x8 window gather  models/third_layer.py:121-146 -----------------------
+ * feat_f0, feat_f1 [B,128,52,52]; mkpts0_c, mkpts1_c [P,2] float (x, y) coarse points in crop
+ * pixels; b_ids [P] int64; kenc [128,64] (= self.kenc(kpts)[0]); rubbish [B,128,144]
+ * -> out0, out1 [P,128,65] (window cell t = wy*8 + wx, dustbin feature at column 64), and the
+ * rounded points the caller keeps using (p_s_out, p_t_out [P,2] int64; may be NULL).
+ * Out-of-map indices (torch.gather would raise) are clamped. */
+int pats_third_descriptors_f32(const float* feat_f0, const float* feat_f1, const float* mkpts0_c,
+                               const float* mkpts1_c, const int64_t* b_ids, const float* kenc,
+                               const float* rubbish, int64_t P, int64_t B, float* out0, float* out1,
+                               int64_t* p_s_out, int64_t* p_t_out, pats_stream_t stream);
+
 /* ---- the whole third-level step in ONE launch: a3 + a5 + a7(exp) + a17 + a18 ------------------
  * feat0, feat1 [P,D,65] (D a multiple of 32, at most 512; 128 in the reference) -> cost build (third_layer.py:156-157),
  * log_optimal_transport2(0.1*scores, 1, scale, iters) (:158), exp (:159), Compute_result (:160,

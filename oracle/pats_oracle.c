@@ -669,3 +669,83 @@ void oracle_compute_result(const float* scores, int64_t P, const float* scale_x,
         whole_loss[k] = (wl >= 1e-2f ? wl : 0.0f) / denom / 10.0f;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * a15  fine-level descriptor sampling, models/second_layer.py:71-86
+ * f0 [2B,64,48,48], f1 [2B,64,24,24], f2 [2B,128,12,12], title [B,8], rubbish [B,264]
+ * -> desc [2,B,264,145]
+ * ---------------------------------------------------------------------------------------- */
+void oracle_fine_descriptors(const float* f0, const float* f1, const float* f2, const float* title,
+                             const float* rubbish, int64_t B, float* desc) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < 2 * B; ++n) {
+        const int64_t b = n % B;
+        float* o = desc + n * 264 * 145;
+        for (int ch = 0; ch < 264; ++ch)
+            for (int p = 0; p < 145; ++p) {
+                float v;
+                if (p == 144) v = rubbish[b * 264 + ch];                   /* :83,85 */
+                else if (ch < 8) v = title[b * 8 + ch];                    /* :82,84 */
+                else {
+                    const int r = p / 12, c = p % 12;                      /* positions (k//12, k%12) :45-49 */
+                    if (ch < 72) {        /* AvgPool2d(2,1,1) of the 48x48 map at (4r+2, 4c+2)  :73-79 */
+                        const float* m = f0 + (n * 64 + (ch - 8)) * 48 * 48;
+                        const int y = 4 * r + 1, x = 4 * c + 1;
+                        v = (((m[y * 48 + x] + m[y * 48 + x + 1]) + m[(y + 1) * 48 + x]) + m[(y + 1) * 48 + x + 1]) / 4.0f;
+                    } else if (ch < 136) {   /* 24x24 map pooled, at (2r+1, 2c+1) */
+                        const float* m = f1 + (n * 64 + (ch - 72)) * 24 * 24;
+                        const int y = 2 * r, x = 2 * c;
+                        v = (((m[y * 24 + x] + m[y * 24 + x + 1]) + m[(y + 1) * 24 + x]) + m[(y + 1) * 24 + x + 1]) / 4.0f;
+                    } else {
+                        v = f2[(n * 128 + (ch - 136)) * 144 + p];
+                    }
+                }
+                o[ch * 145 + p] = v;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a16  third-level window gather, models/third_layer.py:121-146
+ * ff0, ff1 [B,128,52,52]; mk0, mk1 [P,2] (x,y); b_ids [P]; kenc [128,64]; rubbish [B,128,144]
+ * -> out0, out1 [P,128,65]; ps, pt [P,2] int64 (points rounded to the 4-px lattice)
+ * Returns -1 if an index leaves the map (torch.gather raises there), else 0.
+ * ---------------------------------------------------------------------------------------- */
+static long long floordiv2(long long v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
+
+int oracle_third_descriptors(const float* ff0, const float* ff1, const float* mk0, const float* mk1,
+                             const int64_t* b_ids, const float* kenc, const float* rubbish, int64_t P,
+                             int64_t B, float* out0, float* out1, int64_t* ps, int64_t* pt) {
+    const int W = 8, M = 52, C = 128;
+    int err = 0;
+    for (int64_t p = 0; p < P; ++p) {
+        const int64_t b = b_ids[p];
+        const long long s0 = (long long)rintf(mk0[p * 2] / 4.0f) * 4, s1 = (long long)rintf(mk0[p * 2 + 1] / 4.0f) * 4; /* :124 */
+        float t0 = mk1[p * 2], t1 = mk1[p * 2 + 1];
+        t0 = t0 >= 96.f ? 96.f : t0; t1 = t1 >= 96.f ? 96.f : t1;            /* :128 */
+        t0 = t0 <= 0.f ? 0.f : t0;   t1 = t1 <= 0.f ? 0.f : t1;              /* :129 */
+        const long long q0 = (long long)rintf(t0 / 4.0f) * 4, q1 = (long long)rintf(t1 / 4.0f) * 4;                   /* :130 */
+        ps[p * 2] = s0; ps[p * 2 + 1] = s1; pt[p * 2] = q0; pt[p * 2 + 1] = q1;
+        const long long x2 = (long long)rintf((float)s0 / 8.0f), y2 = (long long)rintf((float)s1 / 8.0f);              /* :141-142 */
+        const long long i2 = y2 * 12 + x2;
+        if (i2 < 0 || i2 > 143 || b < 0 || b >= B) { err = -1; continue; }
+        for (int t = 0; t < 64; ++t) {
+            const int wx = t % W, wy = t / W;
+            const long long x0 = floordiv2(s0) + wx - W / 2 + 2, y0 = floordiv2(s1) + wy - W / 2 + 2;   /* :125-126 */
+            const long long x1 = floordiv2(q0) + wx - W / 2 + 2, y1 = floordiv2(q1) + wy - W / 2 + 2;   /* :131-132 */
+            const long long i0 = b * M * M + y0 * M + x0, i1 = b * M * M + y1 * M + x1;                   /* :127,133 */
+            if (i0 < 0 || i0 >= B * M * M || i1 < 0 || i1 >= B * M * M) { err = -1; continue; }
+            const long long bb0 = i0 / (M * M), r0 = i0 % (M * M), bb1 = i1 / (M * M), r1 = i1 % (M * M);
+            for (int ch = 0; ch < C; ++ch) {
+                out0[(p * C + ch) * 65 + t] = ff0[(bb0 * C + ch) * (M * M) + r0] + kenc[ch * 64 + t];    /* :139 */
+                out1[(p * C + ch) * 65 + t] = ff1[(bb1 * C + ch) * (M * M) + r1] + kenc[ch * 64 + t];    /* :140 */
+            }
+        }
+        for (int ch = 0; ch < C; ++ch) {
+            const float rb = rubbish[(b * C + ch) * 144 + i2];                                              /* :143-146 */
+            out0[(p * C + ch) * 65 + 64] = rb;
+            out1[(p * C + ch) * 65 + 64] = rb;
+        }
+    }
+    return err;
+}

@@ -39,6 +39,7 @@ def lib():
         _lib.oracle_left_crops.restype = ctypes.c_int64
         _lib.oracle_tensor_resize.restype = ctypes.c_int
         _lib.oracle_num_threads.restype = ctypes.c_int
+        _lib.oracle_third_descriptors.restype = ctypes.c_int
     return _lib
 
 
@@ -207,3 +208,36 @@ def compute_result(scores, scale_x, scale_y, p_s, p_t, outdoor):
                                 int(bool(outdoor)), _p(m0, c_f), _p(m1, c_f), _p(wl, c_f),
                                 _p(label, c_f), _p(ifm, c_u8))
     return m0, m1, wl, label, ifm.astype(bool)
+
+
+def fine_descriptors(f0, f1, f2, title, rubbish):
+    f0, p0 = _f(f0)
+    f1, p1 = _f(f1)
+    f2, p2 = _f(f2)
+    B = f0.shape[0] // 2
+    ti, pt_ = _f(np.asarray(title).reshape(B, 8))
+    ru, pr = _f(np.asarray(rubbish).reshape(B, 264))
+    desc = np.empty((2, B, 264, 145), np.float32)
+    lib().oracle_fine_descriptors(p0, p1, p2, pt_, pr, ctypes.c_int64(B), _p(desc, c_f))
+    return desc
+
+
+def third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rubbish):
+    ff0, p0 = _f(ff0)
+    ff1, p1 = _f(ff1)
+    B = ff0.shape[0]
+    mk0, pm0 = _f(np.asarray(mk0).reshape(-1, 2))
+    mk1, pm1 = _f(np.asarray(mk1).reshape(-1, 2))
+    P = mk0.shape[0]
+    bi = np.ascontiguousarray(b_ids, dtype=np.int64).reshape(P)
+    ke, pk = _f(np.asarray(kenc).reshape(128, 64))
+    ru, pr = _f(np.asarray(rubbish).reshape(B, 128, 144))
+    o0 = np.zeros((P, 128, 65), np.float32)
+    o1 = np.zeros((P, 128, 65), np.float32)
+    ps = np.zeros((P, 2), np.int64)
+    pt = np.zeros((P, 2), np.int64)
+    rc = lib().oracle_third_descriptors(p0, p1, pm0, pm1, _p(bi, c_i64), pk, pr, ctypes.c_int64(P),
+                                        ctypes.c_int64(B), _p(o0, c_f), _p(o1, c_f), _p(ps, c_i64), _p(pt, c_i64))
+    if rc != 0:
+        raise IndexError("third_descriptors: gather index out of range")
+    return o0, o1, ps, pt

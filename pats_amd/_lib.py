@@ -50,6 +50,9 @@ SIGNATURES = {
     "pats_compute_result_f32": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
+    "pats_fine_descriptors_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pats_third_descriptors_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pats_third_level_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),

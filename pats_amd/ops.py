@@ -413,3 +413,44 @@ def third_level(feat_f0_unfold, feat_f1_unfold, scale, mkpts0_c, mkpts1_c, outdo
                                      _ptr(pt), int(iters), int(bool(outdoor)), _ptr(m0), _ptr(m1),
                                      _ptr(label), _ptr(ifm), _ptr(Z), _stream()), "third_level")
     return (m0, m1, label, ifm.bool(), Z) if return_plan else (m0, m1, label, ifm.bool())
+
+
+def fine_descriptors(desc0_, title, rubbish):
+    """second_layer.py:71-86: desc0_ = the three maps of ResNet2.forward2 on the stacked crops
+    ([2B,64,48,48], [2B,64,24,24], [2B,128,12,12]); title [B,8] = compress_1(desc_l); rubbish [B,264]
+    = compress_2(desc_l).  Returns desc [2,B,264,145] (desc[0], desc[1] feed the GNN)."""
+    f0, f1, f2 = (_dev(t, "desc0_[%d]" % i) for i, t in enumerate(desc0_))
+    B = f0.shape[0] // 2
+    if tuple(f0.shape[1:]) != (64, 48, 48) or tuple(f1.shape) != (2 * B, 64, 24, 24) or \
+            tuple(f2.shape) != (2 * B, 128, 12, 12):
+        raise RuntimeError("fine_descriptors: unexpected feature-map shapes")
+    ti = _dev(title, "title").reshape(B, 8)
+    ru = _dev(rubbish, "rubbish").reshape(B, 264)
+    desc = torch.empty((2, B, 264, 145), dtype=torch.float32, device=f0.device)
+    _check(_L().pats_fine_descriptors_f32(_ptr(f0), _ptr(f1), _ptr(f2), _ptr(ti), _ptr(ru), B, _ptr(desc),
+                                          _stream()), "fine_descriptors")
+    return desc
+
+
+def third_descriptors(feat_f0, feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish):
+    """third_layer.py:121-146.  Returns (feat_f0_unfold, feat_f1_unfold [P,128,65], mkpts0_c,
+    mkpts1_c [P,2] int64 rounded to the 4-px lattice as the reference reassigns them)."""
+    f0, f1 = _dev(feat_f0, "feat_f0"), _dev(feat_f1, "feat_f1")
+    B = f0.shape[0]
+    if tuple(f0.shape[1:]) != (128, 52, 52) or f1.shape != f0.shape:
+        raise RuntimeError("third_descriptors: feature maps must be [B,128,52,52]")
+    m0 = _dev(mkpts0_c.float(), "mkpts0_c").reshape(-1, 2)
+    m1 = _dev(mkpts1_c.float(), "mkpts1_c").reshape(-1, 2)
+    P = m0.shape[0]
+    bi = _dev(b_ids.to(torch.int64), "b_ids", torch.int64).reshape(P)
+    ke = _dev(kenc, "kenc").reshape(128, 64)
+    ru = _dev(rubbish, "rubbish").reshape(B, 128, 144)
+    dev = f0.device
+    o0 = torch.empty((P, 128, 65), dtype=torch.float32, device=dev)
+    o1 = torch.empty((P, 128, 65), dtype=torch.float32, device=dev)
+    ps = torch.empty((P, 2), dtype=torch.int64, device=dev)
+    pt = torch.empty((P, 2), dtype=torch.int64, device=dev)
+    _check(_L().pats_third_descriptors_f32(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), _ptr(bi), _ptr(ke), _ptr(ru),
+                                           P, B, _ptr(o0), _ptr(o1), _ptr(ps), _ptr(pt), _stream()),
+           "third_descriptors")
+    return o0, o1, ps, pt

@@ -99,3 +99,32 @@ def checksum(*arrays):
         idx = np.arange(1, a.size + 1, dtype=np.float64)
         acc += (k + 1) * float(np.dot(a, np.cos(idx * 0.37)))
     return acc
+
+
+def fine_maps(seed=SEED + 5, B=3):
+    """a15 inputs: the three ResNet2.forward2 maps of the stacked left|right crops, the 8-channel
+    title (compress_1 output) and the dustbin feature (compress_2 output)."""
+    rng = np.random.default_rng(seed)
+    f0 = rng.standard_normal((2 * B, 64, 48, 48), dtype=np.float32)
+    f1 = rng.standard_normal((2 * B, 64, 24, 24), dtype=np.float32)
+    f2 = rng.standard_normal((2 * B, 128, 12, 12), dtype=np.float32)
+    title = rng.standard_normal((B, 8, 1), dtype=np.float32)
+    rubbish = rng.standard_normal((B, 264, 1), dtype=np.float32)
+    return {"f0": f0, "f1": f1, "f2": f2, "title": title, "rubbish": rubbish}
+
+
+def third_maps(seed=SEED + 6, B=3, P=40):
+    """a16 inputs: FPN maps [B,128,52,52], coarse points in crop pixels (source on the 8c+4 lattice as
+    pats.py:57-61 builds them, targets arbitrary halves/quarters to exercise round-half-even), kenc, rubbish."""
+    rng = np.random.default_rng(seed)
+    ff0 = rng.standard_normal((B, 128, 52, 52), dtype=np.float32)
+    ff1 = rng.standard_normal((B, 128, 52, 52), dtype=np.float32)
+    # source cells 1..10 only: PATS masks the border ring (second_layer.py:140-149), and the reference's
+    # own dustbin index round(mk/8) leaves the 12x12 map for cell 11
+    mk0 = (rng.integers(1, 11, size=(P, 2)) * 8 + 4).astype(np.float32)
+    mk1 = (rng.integers(8, 185, size=(P, 2)) * 0.5).astype(np.float32)        # 4.0 .. 92.0 in steps of 0.5
+    mk1[:6] = np.array([[10, 6], [14, 18], [22, 26], [6, 90], [90.5, 4.0], [50, 2 * 23 + 0.0]], np.float32)
+    b_ids = rng.integers(0, B, size=(P,)).astype(np.int64)
+    kenc = rng.standard_normal((1, 128, 64), dtype=np.float32)
+    rubbish = rng.standard_normal((B, 128, 144), dtype=np.float32)
+    return {"ff0": ff0, "ff1": ff1, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "kenc": kenc, "rubbish": rubbish}

@@ -322,6 +322,37 @@ def test_wide_dynamic_range_trips_guard_and_falls_back(ops, oracle):
         np.testing.assert_allclose(got[fin], want[fin], atol=3e-5)
 
 
+# ---- descriptor gathers (a15, a16) --------------------------------------------------------------
+def test_fine_descriptors(ops, oracle):
+    g = golden("fine_desc.npz")
+    inp = synth.fine_maps()
+    desc = ops.fine_descriptors([cu(inp["f0"]), cu(inp["f1"]), cu(inp["f2"])], cu(inp["title"]), cu(inp["rubbish"]))
+    d = desc.cpu().numpy()
+    np.testing.assert_array_equal(d.reshape(-1)[g["idx"]], g["val"])
+    np.testing.assert_array_equal(d, oracle.fine_descriptors(inp["f0"], inp["f1"], inp["f2"], inp["title"], inp["rubbish"]))
+    # the descriptor block it produces is exactly what the cost build consumes
+    S = ops.cost(desc[0], desc[1])
+    assert S.shape == (3, 145, 145) and torch.isfinite(S).all()
+
+
+def test_third_descriptors(ops, oracle):
+    g = golden("third_desc.npz")
+    inp = synth.third_maps()
+    o0, o1, ps, pt = ops.third_descriptors(cu(inp["ff0"]), cu(inp["ff1"]), cu(inp["mk0"]), cu(inp["mk1"]),
+                                           cu(inp["b_ids"]), cu(inp["kenc"]), cu(inp["rubbish"]))
+    assert np.array_equal(ps.cpu().numpy(), g["p_s"]) and np.array_equal(pt.cpu().numpy(), g["p_t"])
+    np.testing.assert_array_equal(o0.cpu().numpy()[:, ::4, :], g["out0"])
+    np.testing.assert_array_equal(o1.cpu().numpy()[:, ::4, :], g["out1"])
+    r0, r1, rps, rpt = oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], inp["b_ids"],
+                                                inp["kenc"], inp["rubbish"])
+    np.testing.assert_array_equal(o0.cpu().numpy(), r0)
+    np.testing.assert_array_equal(o1.cpu().numpy(), r1)
+    # ... and feeds the fused third-level step directly
+    scale = torch.ones(o0.shape[0], 1, 64, device="cuda")
+    m0, m1, label, ifm = ops.third_level(o0, o1, scale, ps, pt)
+    assert m0.shape == (o0.shape[0], 16, 2) and torch.isfinite(m1).all()
+
+
 # ---- properties at the reference's full sizes (oracle would take minutes) ------------------------
 def _check_marginals(Z, ns, ms):
     """Each sweep ends with the column update (modules.py:142), so after any number of sweeps the

@@ -205,3 +205,31 @@ def test_third_layer(oracle, name):
         np.testing.assert_allclose(wl, g["whole_loss"], atol=1e-6)
         assert np.array_equal(ifm, g["if_matching1"])
         np.testing.assert_array_equal(label, g["label"])
+
+
+def test_fine_descriptors(oracle):
+    g = golden("fine_desc.npz")
+    inp = synth.fine_maps()
+    assert synth.checksum(inp["f0"], inp["f1"], inp["f2"], inp["title"], inp["rubbish"]) == \
+        pytest.approx(float(g["in_checksum"]), rel=1e-12)
+    desc = oracle.fine_descriptors(inp["f0"], inp["f1"], inp["f2"], inp["title"], inp["rubbish"])
+    assert desc.shape == (2, 3, 264, 145)
+    np.testing.assert_array_equal(desc.reshape(-1)[g["idx"]], g["val"])          # pure gathers + exact /4
+    np.testing.assert_allclose(desc.astype(np.float64).sum((2, 3)), g["sum_per_block"], rtol=1e-12)
+    np.testing.assert_array_equal(desc[:, 0][:, ::7, ::5], g["first"])
+
+
+def test_third_descriptors(oracle):
+    g = golden("third_desc.npz")
+    inp = synth.third_maps()
+    o0, o1, ps, pt = oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], inp["b_ids"],
+                                              inp["kenc"], inp["rubbish"])
+    assert np.array_equal(ps, g["p_s"]) and np.array_equal(pt, g["p_t"])
+    np.testing.assert_array_equal(o0[:, ::4, :], g["out0"])
+    np.testing.assert_array_equal(o1[:, ::4, :], g["out1"])
+    np.testing.assert_allclose(o0.astype(np.float64).sum((1, 2)), g["sum0"], rtol=1e-12)
+    np.testing.assert_allclose(o1.astype(np.float64).sum((1, 2)), g["sum1"], rtol=1e-12)
+    bad, bid = inp["mk1"].copy(), inp["b_ids"].copy()
+    bad[0], bid[0] = [0.0, 0.0], 0                # flattened index goes negative: torch.gather raises
+    with pytest.raises(IndexError):
+        oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], bad, bid, inp["kenc"], inp["rubbish"])

@@ -235,6 +235,74 @@ def gen_third(R, name, P, outdoor, seed):
          max0=scores[:, :-1, :-1].max(2)[1])
 
 
+def gen_fine_desc(R):
+    """second_layer.py:71-86 re-executed verbatim (self.* replaced by the constructor's values, :23,45-53)."""
+    inp = synth.fine_maps()
+    B = inp["f0"].shape[0] // 2
+    desc0_ = [T(inp["f0"]), T(inp["f1"]), T(inp["f2"])]
+    left = torch.zeros(B, 3, 96, 96)                       # only left.shape[0] / .device are used
+    row_num, point_num, descriptor_dim = 12, 144, 264
+    cols = torch.arange(0, row_num).reshape(row_num, 1).repeat(1, row_num).reshape(point_num)
+    rows = torch.arange(0, row_num).reshape(1, row_num).repeat(row_num, 1).reshape(point_num)
+    positions = torch.zeros((point_num, 2))
+    positions[:, 0] = cols
+    positions[:, 1] = rows
+    avgpool = torch.nn.AvgPool2d(2, stride=1, padding=1)
+    compress_1_out = T(inp["title"])                       # stands for self.compress_1(desc_l.unsqueeze(2))
+    compress_2_out = T(inp["rubbish"])                     # stands for self.compress_2(desc_l.unsqueeze(2))
+    desc = []
+    for i, feat in enumerate(desc0_):
+        stride = int(8.0 / torch.pow(torch.tensor(2.0, device=left.device), i + 1))
+        if i <= 1:
+            feat = avgpool(feat)
+        index = ((positions.reshape(row_num, row_num, 2) + 0.5) * stride).long()
+        index = (index[:, :, 0] * feat.shape[3] + index[:, :, 1]).reshape(1, 1, -1).\
+            repeat(feat.shape[0], feat.shape[1], 1)
+        desc.append(torch.gather(feat.reshape(feat.shape[0], feat.shape[1], -1), 2, index))
+    desc = torch.cat(desc, dim=1).reshape(2, left.shape[0], 256, -1)
+    title = compress_1_out.repeat(2, 1, point_num).reshape(2, left.shape[0], 8, -1)
+    rubbish = compress_2_out.repeat(2, 1, 1).reshape(2, left.shape[0], descriptor_dim, 1)
+    desc = torch.cat([title, desc], dim=2)
+    desc = torch.cat([desc, rubbish], dim=3)
+    rng = np.random.default_rng(4)
+    idx = sample_idx(rng, desc.shape, 8192)
+    save("fine_desc.npz", in_checksum=synth.checksum(inp["f0"], inp["f1"], inp["f2"], inp["title"], inp["rubbish"]),
+         idx=idx, val=desc.reshape(-1)[T(idx)], sum_per_block=desc.double().sum((2, 3)),
+         first=desc[:, 0, :, :].clone()[:, ::7, ::5])
+
+
+def gen_third_desc(R):
+    """third_layer.py:121-146 re-executed verbatim (self.W = 8, self.M = 52, :108-110)."""
+    inp = synth.third_maps()
+    feat_f0, feat_f1 = T(inp["ff0"]), T(inp["ff1"])
+    mkpts0_c, mkpts1_c, b_ids = T(inp["mk0"]), T(inp["mk1"]), T(inp["b_ids"])
+    kenc_out = T(inp["kenc"])                               # stands for self.kenc(kpts)
+    rubbish = T(inp["rubbish"])
+    W_, M_ = 8, 52
+    b = b_ids.reshape(-1, 1).repeat(1, W_ * W_)
+    mkpts0_c = torch.round(mkpts0_c / 4.0).long() * 4
+    x0 = (mkpts0_c[:, 0] // 2).reshape(-1, 1).expand(-1, W_ * W_) + torch.arange(W_).reshape(1, 1, W_).repeat(b_ids.shape[0], W_, 1).reshape(-1, W_ * W_) - W_ / 2 + 2
+    y0 = (mkpts0_c[:, 1] // 2).reshape(-1, 1).expand(-1, W_ * W_) + torch.arange(W_).reshape(1, W_, 1).repeat(b_ids.shape[0], 1, W_).reshape(-1, W_ * W_) - W_ / 2 + 2
+    index0 = (b * M_ * M_ + y0 * M_ + x0).long().reshape(-1, 1).expand(-1, 128)
+    mkpts1_c = torch.where(mkpts1_c >= 96, torch.tensor(96).float(), mkpts1_c)
+    mkpts1_c = torch.where(mkpts1_c <= 0, torch.tensor(0).float(), mkpts1_c)
+    mkpts1_c = torch.round(mkpts1_c / 4.0).long() * 4
+    x1 = (mkpts1_c[:, 0] // 2).reshape(-1, 1).expand(-1, W_ * W_) + torch.arange(W_).reshape(1, 1, W_).repeat(b_ids.shape[0], W_, 1).reshape(-1, W_ * W_) - W_ / 2 + 2
+    y1 = (mkpts1_c[:, 1] // 2).reshape(-1, 1).expand(-1, W_ * W_) + torch.arange(W_).reshape(1, W_, 1).repeat(b_ids.shape[0], 1, W_).reshape(-1, W_ * W_) - W_ / 2 + 2
+    index1 = (b * M_ * M_ + y1 * M_ + x1).long().reshape(-1, 1).expand(-1, 128)
+    feat_f0_unfold = torch.gather(feat_f0.permute(0, 2, 3, 1).reshape(-1, feat_f0.shape[1]), 0, index0).reshape(-1, W_ * W_, 128).permute(0, 2, 1) + kenc_out
+    feat_f1_unfold = torch.gather(feat_f1.permute(0, 2, 3, 1).reshape(-1, feat_f1.shape[1]), 0, index1).reshape(-1, W_ * W_, 128).permute(0, 2, 1) + kenc_out
+    x2 = torch.round(mkpts0_c[:, 0] / 8.0).long()
+    y2 = torch.round(mkpts0_c[:, 1] / 8.0).long()
+    index2 = (b_ids * 12 * 12 + y2 * 12 + x2).long().reshape(-1, 1).expand(-1, 128)
+    rubbish_unfold = torch.gather(rubbish.permute(0, 2, 1).reshape(-1, 128), 0, index2).reshape(-1, 128, 1)
+    feat_f0_unfold = torch.cat([feat_f0_unfold, rubbish_unfold], dim=2)
+    feat_f1_unfold = torch.cat([feat_f1_unfold, rubbish_unfold], dim=2)
+    save("third_desc.npz", in_checksum=synth.checksum(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], inp["kenc"], inp["rubbish"]),
+         p_s=mkpts0_c, p_t=mkpts1_c, out0=feat_f0_unfold[:, ::4, :], out1=feat_f1_unfold[:, ::4, :],
+         sum0=feat_f0_unfold.double().sum((1, 2)), sum1=feat_f1_unfold.double().sum((1, 2)))
+
+
 def gen_resize_small(R):
     rng = np.random.default_rng(synth.SEED + 12)
     src = rng.uniform(0, 255, (2, 3, 40, 50)).astype(np.float32)
@@ -269,6 +337,8 @@ def main():
     gen_third(R, "third_65.npz", 32, True, synth.SEED + 2)
     gen_third(R, "third_65_indoor.npz", 8, False, synth.SEED + 32)
     gen_resize_small(R)
+    gen_fine_desc(R)
+    gen_third_desc(R)
 
 
 if __name__ == "__main__":
