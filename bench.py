@@ -70,6 +70,7 @@ class Workload:
     def __init__(self, ops, dev, gen, pairs, fill, per_chunk=False):
         c = synth.coarse_inputs()
         self.pairs, self.h, self.w = pairs, c["h"], c["w"]
+        self.per_chunk_imgs = per_chunk
         rep = lambda a: torch.from_numpy(a).to(dev).repeat(pairs, *([1] * (a.ndim - 1))).contiguous()  # noqa: E731
         self.d0, self.d1, self.ns = rep(c["d0"]), rep(c["d1"]), rep(c["ns"])
         self.alpha = torch.tensor(float(c["alpha"]), device=dev)
@@ -108,13 +109,24 @@ def coarse_stage(ops, wl):
     plans = []
     for i in range(wl.pairs):
         n, second, third = ops.split_patches(sum_cycle[i], wl.h, wl.w, 2 * wl.w)
-        plan = []
-        for lo, hi in second:
-            mask = torch.logical_or(ifn1[i:i + 1], torch.logical_or(sum_cycle[i:i + 1] <= lo,
-                                                                    sum_cycle[i:i + 1] > hi))
-            nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left,
+        if wl.per_chunk_imgs:
+            # the reference's loop (first_layer.py:136-146): one Compute_imgs per chunk mask
+            plan = []
+            for lo, hi in second:
+                mask = torch.logical_or(ifn1[i:i + 1], torch.logical_or(sum_cycle[i:i + 1] <= lo,
+                                                                        sum_cycle[i:i + 1] > hi))
+                nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left,
+                                                         wl.right, width=wl.w, height=wl.h)
+                plan.append(int(nr.shape[0]))
+        else:
+            # chunk c's patches are rows [lo, min(hi, K)) of the all-matched crop tensors (the cumsum is
+            # monotone, so a chunk mask selects a contiguous run of matched patches): one gather per
+            # pair, chunks are views of it (tests/test_gpu_parity.py::test_chunk_crops_are_slices)
+            nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], ifn1[i:i + 1], wl.left,
                                                      wl.right, width=wl.w, height=wl.h)
-            plan.append(int(nr.shape[0]))
+            K = int(nr.shape[0])
+            views = [(nl[lo:min(hi, K)], nr[lo:min(hi, K)]) for lo, hi in second]
+            plan = [v[1].shape[0] for v in views]
         plans.append(plan)
     return plans
 
@@ -260,7 +272,7 @@ def main():
                    "L3": "%d x [128,65]^2 -> 65x65 (fill %d)" % (P, args.fill), "sinkhorn_iters": ITERS,
                    "parallelism": "pairs sharded over %d rank(s), no data-path collective" % world},
         "ot_iters_per_sec": value * sweeps_per_pair,
-        "roofline": {"bound": "hbm", "kernel": "sinkhorn65_kernel<2,1,1> (fused third level, %d problems per launch)" % wl.chunks[0]["P"],
+        "roofline": {"bound": "hbm", "kernel": "third_fused_kernel (fused third level, %d problems per launch)" % wl.chunks[0]["P"],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

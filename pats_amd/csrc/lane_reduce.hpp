@@ -1,0 +1,82 @@
+// Transposed reductions for an 8x8 lane grid (lane = 8*I + J) on a 64-lane wave.
+//
+// Each lane brings 8 partial values p[0..7]; value k must be reduced over the 8 lanes that share
+// I (consecutive lanes 8I..8I+7) or over the 8 lanes that share J (lanes J, J+8, ..., J+56), and
+// the 8 results are to end up one per lane.  A butterfly that halves the number of live values at
+// every level does this in 4+2+1 = 7 exchange-and-combine steps instead of 8 separate 3-level
+// reductions:
+//   reduce8_consecutive: result for index J lands in lane (I, J)      (row_half_mirror, quad xor 2, xor 1)
+//   reduce8_strided    : result for index I lands in lane (I, J)      (permlane32_swap, permlane16_swap, row_ror:8)
+#pragma once
+#include "common.hpp"
+
+namespace pats {
+
+constexpr int DPP_ROW_ROR8 = 0x128;      // row_ror:8  == lane ^ 8 inside a 16-lane row
+
+template <class Op>
+__device__ __forceinline__ float reduce8_consecutive(const float (&p)[8], Op op, int lane) {
+    // Each level forms BOTH candidate sums with the DPP operand taken from a register that was
+    // written a level earlier, then selects - so no DPP instruction reads a just-written VGPR (each
+    // such read costs two wait states) and the independent ops of a level interleave freely.
+    const bool hi = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float lo4[4], hi4[4], r[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lo4[t] = op(p[t], dpp_f<DPP_ROW_HALF_MIRROR>(p[t]));          // partner = lane 7 - J
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hi4[t] = op(p[4 + t], dpp_f<DPP_ROW_HALF_MIRROR>(p[4 + t]));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r[t] = hi ? hi4[t] : lo4[t];
+    float lo2[2], hi2[2], q[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) lo2[s] = op(r[s], dpp_f<DPP_QUAD_XOR2>(r[s]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) hi2[s] = op(r[2 + s], dpp_f<DPP_QUAD_XOR2>(r[2 + s]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) q[s] = b1 ? hi2[s] : lo2[s];
+    const float x = op(q[0], dpp_f<DPP_QUAD_XOR1>(q[0])), y = op(q[1], dpp_f<DPP_QUAD_XOR1>(q[1]));
+    return b0 ? y : x;
+}
+
+// in-place exchange of two registers between wave halves / 16-lane rows, with the operands and
+// results kept opaque (see common.hpp: hipcc mis-folds the paired result otherwise)
+__device__ __forceinline__ void swap32(float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
+    asm volatile("" : "+v"(b));
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    unsigned c = r[0], d = r[1];
+    asm volatile("" : "+v"(c), "+v"(d));
+    x = __builtin_bit_cast(float, c);
+    y = __builtin_bit_cast(float, d);
+}
+__device__ __forceinline__ void swap16(float& x, float& y) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
+    asm volatile("" : "+v"(b));
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    unsigned c = r[0], d = r[1];
+    asm volatile("" : "+v"(c), "+v"(d));
+    x = __builtin_bit_cast(float, c);
+    y = __builtin_bit_cast(float, d);
+}
+
+template <class Op>
+__device__ __forceinline__ float reduce8_strided(const float (&p)[8], Op op, int lane) {
+    float r[4], q[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {           // lanes < 32 end with index t, lanes >= 32 with index 4 + t
+        float x = p[t], y = p[4 + t];
+        swap32(x, y);
+        r[t] = op(x, y);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {           // even 16-rows: index s, odd 16-rows: index 2 + s
+        float x = r[s], y = r[2 + s];
+        swap16(x, y);
+        q[s] = op(x, y);
+    }
+    const bool b3 = lane & 8;
+    const float keep = b3 ? q[1] : q[0], send = b3 ? q[0] : q[1];
+    return op(keep, dpp_f<DPP_ROW_ROR8>(send));
+}
+
+}  // namespace pats

@@ -20,6 +20,7 @@
 // arithmetic, one v_exp_f32 per element.
 #include "common.hpp"
 #include "third_device.hpp"
+#include "cost65_device.hpp"
 #include <stdlib.h>
 
 namespace pats {
@@ -127,99 +128,6 @@ __device__ __forceinline__ float dot_bcast(const float* k, const float* bc) {
 }
 __device__ __forceinline__ float dot64(const float (&k)[64], const float* bc) {
     return dot_bcast<64, 16>(k, bc);
-}
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// Cost build of ONE 65x65 problem by one wave, straight into its LDS tile (third_layer.py:156-158):
-// the 64x64 core as 2x2 tiles of v_mfma_f32_32x32x2_f32 over D (operands global -> VGPR, each
-// half-wave reads 256 contiguous bytes of a descriptor row; every element is loaded exactly once),
-// the dustbin row / column / corner (index 64) as fp32 FMA chains riding along in the VALU slots
-// between the MFMAs (even-k and odd-k half-wave chains, summed at the end).  D % 16 == 0.
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-
-__device__ __forceinline__ void cost65_to_tile(const float* __restrict__ A, const float* __restrict__ B,
-                                               int D, float* tile, int lane) {
-    // MFMA row index li of tile t stands for matrix row 2*li + t (tile 0 = even rows, tile 1 = odd
-    // rows; same for columns): one 8-byte load per lane then feeds BOTH tiles, and every 32-lane
-    // half reads one contiguous 256-byte stretch of a descriptor row.
-    const int li = lane & 31, lk = lane >> 5;
-    f32x16 c00, c01, c10, c11;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
-    float er0 = 0.f, er1 = 0.f, ec0 = 0.f, ec1 = 0.f, cn = 0.f;
-    // the dustbin columns d0[:,64], d1[:,64] (D values each) are parked in the still-unused LDS
-    // tile, so the register ring below carries only the MFMA operand pairs
-    float* eA = tile;
-    float* eB = tile + 512;
-    for (int k = lane; k < D; k += 64) {
-        eA[k] = A[k * NT + NB];
-        eB[k] = B[k * NT + NB];
-    }
-    const float* pa = A + lk * NT + 2 * li;
-    const float* pb = B + lk * NT + 2 * li;
-    // explicit software pipeline over blocks of KB = 4 k-steps (8 descriptor rows): a ring of four
-    // named register buffers keeps three blocks of loads in flight ahead of the MFMAs (deeper rings
-    // were measured slower: the phase is HBM-bandwidth-bound, and the extra registers spill)
-    constexpr int KB = 4;
-    struct Blk { f2u a[KB], b[KB]; };
-    auto load_blk = [&](int k0, Blk& q) {
-#pragma unroll
-        for (int s_ = 0; s_ < KB; ++s_) {
-            const int k = k0 + 2 * s_;                    // D % 32 == 0: whole rings only
-            q.a[s_] = *reinterpret_cast<const f2u*>(pa + k * NT);
-            q.b[s_] = *reinterpret_cast<const f2u*>(pb + k * NT);
-        }
-    };
-    auto compute_blk = [&](int k0, const Blk& q) {
-#pragma unroll
-        for (int s_ = 0; s_ < KB; ++s_) {
-            const f2u av = q.a[s_], bv = q.b[s_];
-            const float ea = eA[k0 + 2 * s_ + lk], eb = eB[k0 + 2 * s_ + lk];
-            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c11, 0, 0, 0);
-            er0 = fmaf(ea, bv.x, er0);
-            er1 = fmaf(ea, bv.y, er1);
-            ec0 = fmaf(av.x, eb, ec0);
-            ec1 = fmaf(av.y, eb, ec1);
-            cn = fmaf(ea, eb, cn);
-        }
-    };
-    const int nblk = D / (2 * KB);
-    auto k0_of = [&](int blk) { return (blk < nblk ? blk : 0) * 2 * KB; };   // wrap: harmless reloads at the end
-    Blk r0, r1, r2, r3;
-    load_blk(k0_of(0), r0); load_blk(k0_of(1), r1); load_blk(k0_of(2), r2);
-    __syncthreads();                                     // eA / eB visible
-    for (int blk = 0; blk < nblk; blk += 4) {
-        load_blk(k0_of(blk + 3), r3); compute_blk(k0_of(blk + 0), r0);
-        load_blk(k0_of(blk + 4), r0); compute_blk(k0_of(blk + 1), r1);
-        load_blk(k0_of(blk + 5), r1); compute_blk(k0_of(blk + 2), r2);
-        load_blk(k0_of(blk + 6), r2); compute_blk(k0_of(blk + 3), r3);
-    }
-    __syncthreads();                                     // done with eA / eB before the tile is written
-    er0 += __shfl_xor(er0, 32); er1 += __shfl_xor(er1, 32);
-    ec0 += __shfl_xor(ec0, 32); ec1 += __shfl_xor(ec1, 32);
-    cn += __shfl_xor(cn, 32);
-    const float sq = sqrtf((float)D);
-    auto scl = [sq](float x) { return 0.1f * (x / sq); };      // `/ D**.5` then `0.1 *`, two roundings
-    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rc = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        tile[(2 * rc) * NT + 2 * li] = scl(c00[r]);
-        tile[(2 * rc) * NT + 2 * li + 1] = scl(c01[r]);
-        tile[(2 * rc + 1) * NT + 2 * li] = scl(c10[r]);
-        tile[(2 * rc + 1) * NT + 2 * li + 1] = scl(c11[r]);
-    }
-    if (lk == 0) {
-        tile[NB * NT + 2 * li] = scl(er0);
-        tile[NB * NT + 2 * li + 1] = scl(er1);
-        tile[(2 * li) * NT + NB] = scl(ec0);
-        tile[(2 * li + 1) * NT + NB] = scl(ec1);
-    }
-    if (lane == 0) tile[TILE - 1] = scl(cn);
 }
 
 struct Ot65Args {
@@ -1159,6 +1067,15 @@ int launch_cost_ot65(const float* d0, const float* d1, int64_t batch, int D, con
 }
 }  // namespace pats
 
+namespace pats {
+struct Fused65Args {
+    const float* d0; const float* d1; int D; int64_t P; const float* ns; const float* one; int iters, linear;
+    const float* scale_x; const float* scale_y; const int64_t* p_s; const int64_t* p_t; int outdoor;
+    ComputeResultOut cr; int stagger;
+};
+int launch_third_fused(const Fused65Args& g, hipStream_t st);
+}
+
 extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int D,
                                     const float* scale, const float* scale_x, const float* scale_y,
                                     const int64_t* p_s, const int64_t* p_t, int iters, int outdoor,
@@ -1168,6 +1085,12 @@ extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int6
     if (P == 0) return PATS_OK;
     PATS_REQUIRE(feat0 && feat1 && scale && scale_x && scale_y && p_s && p_t && mkpts0_f && mkpts1_f &&
                      label && if_matching1, "third_level: null pointer");
+    static const bool v1_only = getenv("PATS_THIRD_V1") != nullptr;     // A/B switch for benchmarking
+    if (!Z_out && !v1_only) {      // no plan requested: the 8x8 register-block kernel (third_fused.hip)
+        Fused65Args f{feat0, feat1, D, P, scale, nullptr, iters, 1, scale_x, scale_y, p_s, p_t, outdoor,
+                      ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr}, 0};
+        return launch_third_fused(f, as_stream(stream));
+    }
     Ot65Args g{};
     g.d0 = feat0; g.d1 = feat1; g.D = D; g.P = P; g.ns = scale; g.iters = iters;
     g.linear = use_linear(); g.out = Z_out;

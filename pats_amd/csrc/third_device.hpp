@@ -41,10 +41,13 @@ __device__ __forceinline__ void row16_argmax(float& v, int& i) {
 // of the wave owns one centre row (lane t of the group holds targets t, t+16, t+32, t+48), so the
 // argmax / sums are 4-step row-level DPP reductions and the 5x5 taps are two per lane, gathered
 // from the plan by address.  sx / sy are indexable [64] scale vectors (global or LDS).
+// `compact_stride` == 0: Sp is the full 65 x 65 matrix (row stride 65); otherwise Sp holds only the 16
+// centre rows, row q at Sp + q * compact_stride.
 __device__ __forceinline__ void compute_result_problem(const float* Sp, int input_is_log, int64_t p,
                                                        const float* sx, const float* sy, float ps0,
                                                        float ps1, float pt0, float pt1, int outdoor,
-                                                       const ComputeResultOut& o, int lane) {
+                                                       const ComputeResultOut& o, int lane,
+                                                       int compact_stride = 0) {
     constexpr int W = 8, T = 5, NN = 65;
     const int grp = lane >> 4, t = lane & 15;
     int local_count = 0;
@@ -52,7 +55,7 @@ __device__ __forceinline__ void compute_result_problem(const float* Sp, int inpu
     for (int pass = 0; pass < 4; ++pass) {
         const int q = pass * 4 + grp;
         const int qy = q / 4 + 2, qx = q % 4 + 2;                    // [:, 2:6, 2:6]  (:186,188)
-        const float* row = Sp + (qy * W + qx) * NN;
+        const float* row = compact_stride ? Sp + q * compact_stride : Sp + (qy * W + qx) * NN;
         float x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
