@@ -225,11 +225,13 @@ def main():
         step(ops, wl, None)
     ev = []
     barrier()
+    ops.sinkhorn_fallbacks(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(ops, wl, ev)
     barrier()
     dt = time.perf_counter() - t0
+    fallbacks = ops.sinkhorn_fallbacks(reset=True)       # after the timed region (it synchronises)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -272,6 +274,7 @@ def main():
                    "L3": "%d x [128,65]^2 -> 65x65 (fill %d)" % (P, args.fill), "sinkhorn_iters": ITERS,
                    "parallelism": "pairs sharded over %d rank(s), no data-path collective" % world},
         "ot_iters_per_sec": value * sweeps_per_pair,
+        "guard_fallbacks_per_step": fallbacks / max(1, args.steps),
         "roofline": {"bound": "hbm", "kernel": "third_fused_kernel (fused third level, %d problems per launch)" % wl.chunks[0]["P"],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

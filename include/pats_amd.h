@@ -45,6 +45,11 @@ int pats_device_count(void);
 /* process-wide default for PATS_SINKHORN_AUTO (returns the previous value) */
 int pats_set_sinkhorn_mode(int mode);
 
+/* Number of problems (on the current device, since the last reset) whose linear-domain solve left the
+ * guard band and was re-solved with log-sum-exp sweeps.  Results are the same either way; a high rate
+ * only costs time.  Synchronous (device -> host copy of one counter).  No reference counterpart. */
+int pats_sinkhorn_fallbacks(int64_t* count, int reset);
+
 /* ---- a1-a3: cost build -------------------------------------------------------------------
  * out[b,i,j] = 0.1f * ( (sum_d d0[b,d,i] * d1[b,d,j]) / sqrtf(D) )
  * replaces  scores = einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5 ; 0.1 * scores

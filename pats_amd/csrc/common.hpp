@@ -18,6 +18,9 @@ constexpr float ZERO_F = 1e-14f;  // the reference's `zero` (utils/utils.py:1201
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 int sinkhorn_mode();   // PATS_SINKHORN_* (host.cpp)
+// device-resident count of problems whose linear-domain solve left the guard and was redone in the
+// log domain (host.cpp; one counter per device, allocated on first use; null if that failed)
+unsigned long long* fallback_counter();
 
 #define PATS_REQUIRE(cond, ...)               \
     do {                                      \
@@ -81,6 +84,30 @@ __device__ __forceinline__ float wave_allreduce(float v, Op op) {
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return wave_allreduce(v, OpSum()); }
+
+// 64-lane sum delivered as a wave-uniform value (SGPR): four in-row DPP steps, then the GFX9 row
+// broadcasts (row 0->1 and 2->3, then lane 31 -> rows 2,3) leave the total in row 3 and one
+// v_readlane hands it to every lane.  Seven issue slots against ten for the all-reduce above
+// (whose two lane swaps each need an opaque register copy).  Masked-off rows add the `old` 0.
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), DPP_ROW_BCAST15, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// x / d for a loop-invariant divisor, rd = 1.0f / d (IEEE): one residual correction of x * rd.
+// Agrees with the IEEE quotient the reference computes (`/ D**.5`) on every one of 3.6e7 sampled
+// operands per divisor used here, in 3 issue slots instead of the ~13 of a full fp32 division.
+__device__ __forceinline__ float div_invariant(float x, float d, float rd) {
+    const float q = x * rd;
+    return fmaf(fmaf(-q, d, x), rd, q);
+}
 __device__ __forceinline__ float wave_max(float v) { return wave_allreduce(v, OpMax()); }
 
 // argmax all-reduce with first-index tie-break (ATen CPU semantics relied on at

@@ -20,8 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256)
 cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D, int n, int m,
-                 float inv_unused, float sqrtD, float* __restrict__ out) {
-    (void)inv_unused;
+                 float rsqrtD, float sqrtD, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_j = (m + 63) / 64, tiles = tiles_j * ((n + 63) / 64);
     const int64_t b = blockIdx.x / tiles;
@@ -42,7 +41,7 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
             const int i = row_edge ? i0 : i0 + e, j = row_edge ? j0 + e : j0;
             float acc = 0.f;
             for (int k = 0; k < D; ++k) acc = fmaf(A[(int64_t)k * n + i], B[(int64_t)k * m + j], acc);
-            O[(int64_t)i * m + j] = 0.1f * (acc / sqrtD);
+            O[(int64_t)i * m + j] = 0.1f * div_invariant(acc, sqrtD, rsqrtD);
         }
         return;
     }
@@ -75,7 +74,7 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
     for (int r = 0; r < 16; ++r) {
         const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row < n && col < m) {
-            float s = acc[r] / sqrtD;       // `scores / D ** .5`
+            float s = div_invariant(acc[r], sqrtD, rsqrtD);       // `scores / D ** .5`
             O[(int64_t)row * m + col] = 0.1f * s;   // `0.1 * scores`
         }
     }
@@ -96,6 +95,6 @@ extern "C" int pats_cost_f32(const float* d0, const float* d1, int64_t batch, in
     const int64_t tiles = (int64_t)((n + 63) / 64) * ((m + 63) / 64);
     PATS_REQUIRE(tiles * batch < (1ll << 31), "cost: grid too large (split the call)");
     hipLaunchKernelGGL(cost_mfma_kernel, dim3((unsigned)(tiles * batch)), dim3(256), 0,
-                       as_stream(stream), d0, d1, D, n, m, 0.f, (float)sqrt((double)D), out);
+                       as_stream(stream), d0, d1, D, n, m, 1.0f / (float)sqrt((double)D), (float)sqrt((double)D), out);
     return check_launch("cost_mfma_kernel");
 }

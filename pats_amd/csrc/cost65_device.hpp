@@ -89,7 +89,11 @@ __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, c
     o.c00 = c00; o.c01 = c01; o.c10 = c10; o.c11 = c11;
 }
 
-__device__ __forceinline__ float cost65_scale(float x, float sqrtD) { return 0.1f * (x / sqrtD); }
+struct Cost65Scale {
+    float d, rd;                 // D**.5 and its IEEE reciprocal
+    __device__ __forceinline__ explicit Cost65Scale(int D) : d(sqrtf((float)D)), rd(1.0f / sqrtf((float)D)) {}
+};
+__device__ __forceinline__ float cost65_scale(float x, const Cost65Scale& k) { return 0.1f * div_invariant(x, k.d, k.rd); }
 
 // accumulate + write the scaled 65x65 matrix into a row-major LDS tile (row stride 65)
 __device__ __forceinline__ void cost65_to_tile(const float* __restrict__ A, const float* __restrict__ B,
@@ -98,7 +102,7 @@ __device__ __forceinline__ void cost65_to_tile(const float* __restrict__ A, cons
     Cost65Acc c;
     cost65_accumulate(A, B, D, tile, lane, c);
     const int li = lane & 31, lk = lane >> 5;
-    const float sq = sqrtf((float)D);
+    const Cost65Scale sq(D);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rc = (r & 3) + 8 * (r >> 2) + 4 * lk;

@@ -28,6 +28,21 @@ int check_launch(const char* what) {
 static int g_mode = PATS_SINKHORN_AUTO;
 int sinkhorn_mode() { return g_mode; }
 
+static unsigned long long* g_fallbacks[64];
+unsigned long long* fallback_counter() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    if (!g_fallbacks[dev]) {
+        unsigned long long* p = nullptr;
+        if (hipMalloc((void**)&p, sizeof(*p)) != hipSuccess || hipMemset(p, 0, sizeof(*p)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g_fallbacks[dev] = p;
+    }
+    return g_fallbacks[dev];
+}
+
 }  // namespace pats
 
 using namespace pats;
@@ -50,6 +65,17 @@ extern "C" int pats_set_sinkhorn_mode(int mode) {
     if (mode == PATS_SINKHORN_AUTO || mode == PATS_SINKHORN_LOG || mode == PATS_SINKHORN_KERNEL)
         g_mode = mode;
     return prev;
+}
+
+extern "C" int pats_sinkhorn_fallbacks(int64_t* count, int reset) {
+    PATS_REQUIRE(count, "sinkhorn_fallbacks: null pointer");
+    unsigned long long* p = fallback_counter();
+    PATS_REQUIRE(p, "sinkhorn_fallbacks: no counter on this device");
+    unsigned long long v = 0;
+    if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return check_launch("sinkhorn_fallbacks");
+    if (reset && hipMemset(p, 0, sizeof(v)) != hipSuccess) return check_launch("sinkhorn_fallbacks");
+    *count = (int64_t)v;
+    return PATS_OK;
 }
 
 // split_patches, utils/utils.py:152-181.  Greedy row-aligned chunking of the matched coarse

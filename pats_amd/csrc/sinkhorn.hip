@@ -152,6 +152,7 @@ struct Ot65Args {
     int outdoor;
     ComputeResultOut cr;
     int stagger;             // first-wave-front start delay unit, in s_sleep(127) periods (0 = off)
+    unsigned long long* fallbacks;   // guard-trip counter or null
 };
 
 // MODE 0: log_mu/log_nu given (a6)      MODE 2: ns given, log_optimal_transport2 marginals (a5)
@@ -263,6 +264,7 @@ sinkhorn65_kernel(Ot65Args g) {
     }
 
     if (!solved) {
+        if (g.linear && lane == 0 && g.fallbacks) atomicAdd(g.fallbacks, 1ull);
         // ---- max-subtracted log-sum-exp sweeps, Z rows and columns in registers -------------------
         float zr[NB], zc[NB];
 #pragma unroll
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(384)
 sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __restrict__ log_mu_in,
                    const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                    const float* __restrict__ one, int iters, float bias_k, int linear,
-                   float* __restrict__ out) {
+                   float* __restrict__ out, unsigned long long* fallbacks) {
     __shared__ __attribute__((aligned(16))) WgLds<N_> lds;     // 85 KB at N = 145 (static: no opt-in)
     constexpr int TH = 384, NN = N_ * N_, NP = (N_ + 3) & ~3;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -509,6 +511,7 @@ sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __rest
     }
 
     if (!solved) {      // workgroup-uniform: max-subtracted log-sum-exp sweeps on Z itself.
+        if (linear && t == 0 && fallbacks) atomicAdd(fallbacks, 1ull);
         // Rare path (guard tripped, or PATS_SINKHORN_LOG): Z is read from the LDS tile each time
         // rather than held in registers, so it does not raise the kernel's VGPR budget.
         const int zstride = colw ? N_ : 1;
@@ -589,9 +592,11 @@ __global__ void sinkhorn_wg_kernel(SrcView src, int M, int N, const float* __res
                                    const float* __restrict__ log_nu,
                                    const float* __restrict__ norm_in, int iters, float bias_k,
                                    float* __restrict__ out, float* __restrict__ wsZ,
-                                   float* __restrict__ wsT, const int* __restrict__ only_if) {
+                                   float* __restrict__ wsT, const int* __restrict__ only_if,
+                                   unsigned long long* fallbacks) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     if (only_if && only_if[blockIdx.x] == 0) return;     // re-solve pass: only flagged problems
+    if (only_if && fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1ull);
     float* u = sm;          // [M]
     float* v = sm + M;      // [N]
     const int b = blockIdx.x;
@@ -920,7 +925,7 @@ static int launch_wg(const SrcView& src, int64_t batch, int M, int N, const floa
     const size_t lds = (size_t)(M + N) * sizeof(float);
     PATS_REQUIRE(lds <= 64 * 1024, "sinkhorn: M+N=%d too large for the one-workgroup kernel", M + N);
     hipLaunchKernelGGL(sinkhorn_wg_kernel, dim3((unsigned)batch), dim3(threads), lds, st, src, M, N,
-                       log_mu, log_nu, norm, iters, bias_k, out, Zw, Zt, only_if);
+                       log_mu, log_nu, norm, iters, bias_k, out, Zw, Zt, only_if, only_if ? fallback_counter() : nullptr);
     return check_launch("sinkhorn_wg_kernel");
 }
 
@@ -971,6 +976,7 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
     hipStream_t st = as_stream(stream);
     if (M == NT && N == NT) {
         Ot65Args g{};
+    g.fallbacks = fallback_counter();
         g.Zin = Z; g.P = batch; g.log_mu = log_mu; g.log_nu = log_nu; g.iters = iters;
         g.linear = use_linear(); g.out = out;
         hipLaunchKernelGGL((sinkhorn65_kernel<0, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
@@ -978,7 +984,7 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
     }
     if (M == NF && N == NF) {
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch,
-                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, use_linear(), out);
+                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, use_linear(), out, fallback_counter());
         return check_launch("sinkhorn_rc_kernel<145,0>");
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_sinkhorn_workspace_bytes(batch, M, N),
@@ -1034,6 +1040,7 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     hipStream_t st = as_stream(stream);
     if (m == NT && n == NT) {
         Ot65Args g{};
+    g.fallbacks = fallback_counter();
         g.Zin = scores; g.P = batch; g.ns = ns; g.one = one; g.iters = iters; g.bias_k = bias_k;
         g.linear = use_linear(); g.out = Z;
         hipLaunchKernelGGL((sinkhorn65_kernel<2, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
@@ -1041,7 +1048,7 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     }
     if (m == NF && n == NF) {
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, scores,
-                           batch, nullptr, nullptr, ns, one, iters, bias_k, use_linear(), Z);
+                           batch, nullptr, nullptr, ns, one, iters, bias_k, use_linear(), Z, fallback_counter());
         return check_launch("sinkhorn_rc_kernel<145,2>");
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_ot_workspace_bytes(batch, m, n),
@@ -1060,6 +1067,7 @@ namespace pats {
 int launch_cost_ot65(const float* d0, const float* d1, int64_t batch, int D, const float* one,
                      const float* ns, int iters, float bias_k, float* Z, pats_stream_t stream) {
     Ot65Args g{};
+    g.fallbacks = fallback_counter();
     g.d0 = d0; g.d1 = d1; g.D = D; g.P = batch; g.ns = ns; g.one = one; g.iters = iters;
     g.bias_k = bias_k; g.linear = use_linear(); g.out = Z;
     hipLaunchKernelGGL((sinkhorn65_kernel<2, 1, 0>), dim3((unsigned)batch), dim3(64), 0, as_stream(stream), g);
@@ -1067,14 +1075,6 @@ int launch_cost_ot65(const float* d0, const float* d1, int64_t batch, int D, con
 }
 }  // namespace pats
 
-namespace pats {
-struct Fused65Args {
-    const float* d0; const float* d1; int D; int64_t P; const float* ns; const float* one; int iters, linear;
-    const float* scale_x; const float* scale_y; const int64_t* p_s; const int64_t* p_t; int outdoor;
-    ComputeResultOut cr; int stagger;
-};
-int launch_third_fused(const Fused65Args& g, hipStream_t st);
-}
 
 extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int D,
                                     const float* scale, const float* scale_x, const float* scale_y,
@@ -1088,10 +1088,11 @@ extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int6
     static const bool v1_only = getenv("PATS_THIRD_V1") != nullptr;     // A/B switch for benchmarking
     if (!Z_out && !v1_only) {      // no plan requested: the 8x8 register-block kernel (third_fused.hip)
         Fused65Args f{feat0, feat1, D, P, scale, nullptr, iters, 1, scale_x, scale_y, p_s, p_t, outdoor,
-                      ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr}, 0};
+                      ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr}, 0, nullptr};
         return launch_third_fused(f, as_stream(stream));
     }
     Ot65Args g{};
+    g.fallbacks = fallback_counter();
     g.d0 = feat0; g.d1 = feat1; g.D = D; g.P = P; g.ns = scale; g.iters = iters;
     g.linear = use_linear(); g.out = Z_out;
     g.scale_x = scale_x; g.scale_y = scale_y; g.p_s = p_s; g.p_t = p_t; g.outdoor = outdoor;

@@ -16,6 +16,26 @@ struct ComputeResultOut {
     int* count;            // global count of whole_loss >= 1e-2, or null
 };
 
+// arguments of the register-block fused third-level kernel (third_fused.hip)
+struct Fused65Args {
+    const float* d0;
+    const float* d1;
+    int D;
+    int64_t P;
+    const float* ns;             // [P,64] target areas
+    const float* one;
+    int iters, linear;
+    const float* scale_x;
+    const float* scale_y;
+    const int64_t* p_s;
+    const int64_t* p_t;
+    int outdoor;
+    ComputeResultOut cr;
+    int stagger;
+    unsigned long long* fallbacks;   // guard-trip counter or null
+};
+int launch_third_fused(const Fused65Args& g, hipStream_t st);
+
 // row-level (16-lane) all-reduces: 4 DPP steps, no LDS traffic
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f<DPP_QUAD_XOR1>(v);

@@ -44,24 +44,9 @@ struct __attribute__((aligned(16))) BlkLds {
     float stage[32 * SST];       // redistribution staging; later rows16[16][66]; first: cost edge columns
 };
 
-struct Fused65Args {
-    const float* d0;
-    const float* d1;
-    int D;
-    int64_t P;
-    const float* ns;             // [P,64] target areas
-    const float* one;
-    int iters, linear;
-    const float* scale_x;
-    const float* scale_y;
-    const int64_t* p_s;
-    const int64_t* p_t;
-    int outdoor;
-    ComputeResultOut cr;
-    int stagger;
-};
 
 __device__ __forceinline__ float lse_fin(float s, float mI) { return (fast_log2(s) + mI) * LN2; }
+__device__ __forceinline__ float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
 __global__ void __launch_bounds__(64, 3)
 third_fused_kernel(Fused65Args g) {
@@ -76,12 +61,15 @@ third_fused_kernel(Fused65Args g) {
     }
     const int colj = 8 * J + I;              // the column this lane owns in the column half-sweep
     // ---- marginals of log_optimal_transport2 (modules.py:169-179) --------------------------------
+    // Wave-uniform quantities are pinned to SGPRs (uni): the kernel sits at the 168-VGPR budget of
+    // three waves per SIMD, and every uniform value left in a VGPR pushes a spill reload into the
+    // sweep loop (tools/check_hot_loops.py keeps watch).
     const float ns_own = g.ns[p * 64 + colj];
-    const float ns_sum = wave_sum(g.ns[p * 64 + lane]);
-    const float ms = 64.0f * (g.one ? *g.one : 1.0f);
-    const float norm = -logf(ms + ns_sum);
-    const float lmu = norm, lmu64 = logf(ns_sum) + norm;
-    const float lnu = logf(ns_own) + norm, lnu64 = logf(ms) + norm;
+    const float ns_sum = uni(wave_sum(g.ns[p * 64 + lane]));
+    const float ms = uni(64.0f * (g.one ? *g.one : 1.0f));
+    const float norm = uni(-logf(ms + ns_sum));
+    const float lmu = norm, lmu64 = uni(logf(ns_sum) + norm);
+    const float lnu = logf(ns_own) + norm, lnu64 = uni(logf(ms) + norm);
 
     float dual_r = 0.f, dual_c = 0.f, dual_r64 = 0.f, dual_c64 = 0.f;   // u_(8I+J), v_(8J+I), u_64, v_64
     float kb[8][8];                          // the block: Z, then K (linear) - or Z kept (log path)
@@ -97,7 +85,7 @@ third_fused_kernel(Fused65Args g) {
             Cost65Acc c;
             cost65_accumulate(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
             const int li = lane & 31, lk = lane >> 5;
-            const float sq = sqrtf((float)g.D);
+            const Cost65Scale sq(g.D);
 #pragma unroll
             for (int tile = 0; tile < 4; ++tile) {
                 const int ti = tile >> 1, tj = tile & 1;
@@ -142,7 +130,7 @@ third_fused_kernel(Fused65Args g) {
                 part[r] = m;
             }
             const float r_own = fmaxf(reduce8_consecutive(part, OpMax(), lane), zdcol);
-            const float r64 = fmaxf(wave_max(zdrow), zcorner);
+            const float r64 = uni(fmaxf(wave_max(zdrow), zcorner));
             __syncthreads();
             lds.va[lane] = r_own;
             __syncthreads();
@@ -160,7 +148,7 @@ third_fused_kernel(Fused65Args g) {
                 part[c] = m;
             }
             const float c_own = fmaxf(reduce8_strided(part, OpMax(), lane), zdrow - r64);
-            const float c64 = fmaxf(wave_max(zdcol - r_own), zcorner - r64);
+            const float c64 = uni(fmaxf(wave_max(zdcol - r_own), zcorner - r64));
             __syncthreads();
             lds.vb[colj] = c_own;
             __syncthreads();
@@ -177,7 +165,7 @@ third_fused_kernel(Fused65Args g) {
             const float kdcol = fast_exp2(((zdcol - r_own) - c64) * LOG2E);     // K[8I+J][64]
             const float kdrow = fast_exp2(((zdrow - r64) - c_own) * LOG2E);     // K[64][8J+I]
             const float kcorner = fast_exp2(((zcorner - r64) - c64) * LOG2E);
-            const float mu = expf(lmu), mu64 = expf(lmu64), nu = expf(lnu), nu64 = expf(lnu64);
+            const float mu = uni(expf(lmu)), mu64 = uni(expf(lmu64)), nu = expf(lnu), nu64 = uni(expf(lnu64));
             float a = 0.f, a64 = 0.f, b = expf(c_own), b64 = expf(c64);
             __syncthreads();
             lds.vb[colj] = b;
@@ -197,11 +185,20 @@ third_fused_kernel(Fused65Args g) {
                     for (int r = 0; r < 8; ++r) acc[r] = __builtin_elementwise_fma(f2v{kb[r][4], kb[r][5]}, b1.xy, acc[r]);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) acc[r] = __builtin_elementwise_fma(f2v{kb[r][6], kb[r][7]}, b1.zw, acc[r]);
+                    // row sums: transpose the 8 partials of each row through LDS (the LDS pipe idles
+                    // here while the VALU is the bound): lane (I,J) posts its partial of row 8I+r at
+                    // [I][r][J] (stride 72: bank = 8I+8r+J, conflict-free) and collects row 8I+J's
+                    // eight as two b128 reads - odd I takes the halves in swapped order so that a
+                    // 16-lane read group touches every bank once.  12 VALU slots against the 29 of
+                    // x+y adds plus the DPP butterfly.
+                    // (measured: transposing the row partials through LDS instead of this DPP butterfly
+                    // saves 17 VALU slots per sweep but lengthens the wave's LDS latency chain - 3% slower)
 #pragma unroll
                     for (int r = 0; r < 8; ++r) part[r] = acc[r].x + acc[r].y;
+                    const float dsum = wave_sum_uniform(kdrow * b);
                     const float s = fmaf(kdcol, b64, reduce8_consecutive(part, OpSum(), lane));
                     a = mu * __builtin_amdgcn_rcpf(s);
-                    a64 = mu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, b64, wave_sum(kdrow * b)));
+                    a64 = mu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, b64, dsum));
                     lds.va[lane] = a;
                 }
                 __syncthreads();                                 // a visible
@@ -220,7 +217,7 @@ third_fused_kernel(Fused65Args g) {
                     const float qq[8] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y};
                     const float t = fmaf(kdrow, a64, reduce8_strided(qq, OpSum(), lane));
                     b = nu * __builtin_amdgcn_rcpf(t);
-                    b64 = nu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, a64, wave_sum(kdcol * a)));
+                    b64 = nu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, a64, wave_sum_uniform(kdcol * a)));
                     lds.vb[colj] = b;
                 }
             }
@@ -234,6 +231,7 @@ third_fused_kernel(Fused65Args g) {
                 linear_done = true;
                 break;
             }
+            if (lane == 0 && g.fallbacks) atomicAdd(g.fallbacks, 1ull);
             continue;                           // guard tripped: redo with log-sum-exp sweeps
         }
 
@@ -359,6 +357,7 @@ third_fused_kernel(Fused65Args g) {
 int launch_third_fused(const Fused65Args& g0, hipStream_t st) {
     Fused65Args g = g0;
     g.linear = sinkhorn_mode() != PATS_SINKHORN_LOG;
+    g.fallbacks = fallback_counter();
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
     if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
     hipLaunchKernelGGL(third_fused_kernel, dim3((unsigned)g.P), dim3(64), 0, st, g);

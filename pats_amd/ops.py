@@ -65,6 +65,17 @@ def set_sinkhorn_mode(mode):
     return {v: k for k, v in names.items()}[prev]
 
 
+def sinkhorn_fallbacks(reset=True):
+    """Problems on the current device whose linear-domain solve left the guard band and were redone
+    with log-sum-exp sweeps since the last reset (pats_sinkhorn_fallbacks; synchronises)."""
+    import ctypes
+    n = ctypes.c_int64(0)
+    rc = _L().pats_sinkhorn_fallbacks(ctypes.byref(n), 1 if reset else 0)
+    if rc != 0:
+        raise RuntimeError(_L().pats_last_error().decode())
+    return int(n.value)
+
+
 # ------------------------------------------------------------------------------------------------
 # cost build
 # ------------------------------------------------------------------------------------------------

@@ -320,7 +320,7 @@ def test_third_level(ops, oracle, name):
                                atol=3e-5)
 
 
-def test_wide_dynamic_range_trips_guard_and_falls_back(ops, oracle):
+def test_wide_dynamic_range_trips_guard_and_falls_back(ops, oracle, sinkhorn_mode):
     """Scores spanning +-150 nats: exp(Z - r - c) underflows for most entries and the scaling
     vectors leave the 2^30 guard, so the linear-domain path must hand the problem to the
     log-sum-exp sweeps (which ATen's logsumexp-based reference handles natively)."""
@@ -329,7 +329,11 @@ def test_wide_dynamic_range_trips_guard_and_falls_back(ops, oracle):
         Z = (60.0 * rng.standard_normal((P, n, n))).astype(np.float32)
         Z[0] *= 0.02                                    # one tame problem in the same launch
         ns = rng.uniform(0.5, 2.0, (P, 1, n - 1)).astype(np.float32)
+        ops.sinkhorn_fallbacks(reset=True)
         got = ops.log_optimal_transport2(cu(Z), 1.0, cu(ns), 100).cpu().numpy()
+        # the counter sees the wild problems leave the linear path (and nothing in forced-log mode)
+        trips = ops.sinkhorn_fallbacks(reset=True)
+        assert (1 <= trips <= P - 1) if sinkhorn_mode == "kernel" else trips == 0
         want = oracle.log_optimal_transport2(Z, 1.0, ns, 100)
         assert np.isfinite(got).all()
         np.testing.assert_allclose(got, want, atol=2e-3, rtol=2e-5)     # |Z| ~ 200: fp32 ulp ~ 1.5e-5

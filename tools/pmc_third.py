@@ -15,7 +15,7 @@ ps = torch.randint(1, 23, (P, 2), device=dev) * 4
 pt = torch.randint(0, 25, (P, 2), device=dev) * 4
 torch.cuda.synchronize()
 for _ in range(3):
-    ops.third_level(d0, d1, sc, ps, pt, iters=100)
+    ops.third_level(d0, d1, sc, ps, pt, iters=int(os.environ.get("PMC_ITERS", "100")))
     ops.cost(d0, d1)
 torch.cuda.synchronize()
 print("done P=%d bytes_in_per_problem=%d" % (P, 2 * 128 * 65 * 4))
