@@ -284,10 +284,10 @@ def main():
                      "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
                      "sweep_elements_per_s": exp_rate,
                      "mfma_flops_per_s": float((2.0 * 128 * 64 * 64 * probs / (ms * 1e-3)).mean()),
-                     "note": "fused cost build (fp32 MFMA) + 100 linear-domain Sinkhorn sweeps + "
-                             "Compute_result per 65x65 problem, one wave each; descriptors are read once, "
-                             "the plan never reaches HBM; issue-bound on the sweeps' FMA/LDS-broadcast "
-                             "stream, not on HBM"},
+                     "note": "fused cost build (fp32 MFMA) + 100 linear-domain Sinkhorn sweeps + Compute_result per 65x65 problem, "
+                             "one wave each, the 65x65 block held in registers; descriptors are read once, the plan never "
+                             "reaches HBM.  HBM is the nearest of the two allowed rooflines but not the limiter: SQ counters "
+                             "(profiles/r01_pmc_third.json) show the sweeps VALU-issue bound at 92 % SIMD issue utilisation"},
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
