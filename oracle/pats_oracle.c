@@ -749,3 +749,248 @@ int oracle_third_descriptors(const float* ff0, const float* ff1, const float* mk
     }
     return err;
 }
+
+/* ==========================================================================================
+ * SURVEY.md section 8(f) "next" rows: the steps either side of the OT path.
+ * ======================================================================================== */
+
+/* ------------------------------------------------------------------------------------------
+ * f1  merge_patches_new / merge_patches_old, models/second_layer.py:137-238.
+ * Every 8-px cell of the 1/8-resolution grid (4h x 4w cells) is covered by the 96x96 windows of up
+ * to 9 coarse patches; the merge keeps one candidate per cell.  Restated step by step on full
+ * arrays in the reference's own layouts:
+ *   owner layout  A[bt][4*hh + r][4*ww + s][a*3 + c]  = window cell (a*4 + r, c*4 + s) of coarse
+ *   patch (hh, ww)  (second_layer.py:160,162-164 / :211-214), geometrically at fine cell
+ *   (4*(hh + a - 1) + r, 4*(ww + c - 1) + s).
+ * trust [B,144] and ifn_L2 [B,144] are modified in place like the reference does (:143-147 /
+ * :194-199); scores_back [batch,h*w,16,9] (fp64) receives this chunk's scores (:163 / :213).
+ * `argsort(...)[..., 0]` (:175 / :232) is restated as the first index of the minimum (ATen's CPU
+ * sort is stable); pinned by tests/golden/merge_*.npz which contain exact ties.
+ * The final scatter (:190 / :238) is sequential in source order, last write wins (ATen CPU).
+ * returns 0, -1 if the number of unmasked coarse patches != B, -2 if a scatter index leaves the
+ * tensor (the reference raises there).
+ * ---------------------------------------------------------------------------------------- */
+int oracle_merge_patches(int merge_new, int64_t B, float* trust, int H, int W, int batch_num,
+                         const uint8_t* ifn_L1, uint8_t* ifn_L2, double* scores_back, uint8_t* out) {
+    const int h = H / 32, w = W / 32, h4 = 4 * h, w4 = 4 * w;
+    const int64_t NP = (int64_t)batch_num * h * w, per = (int64_t)h4 * w4 * 9;
+    for (int64_t b = 0; b < B; ++b)
+        for (int cell = 0; cell < 144; ++cell) {
+            const int x = cell % 12, y = cell / 12;
+            float t = trust[b * 144 + cell];
+            for (int i = 0; i < 3; ++i)                                   /* :143-147 / :194-198 */
+                if (x < 3 - i || x > 7 + i || y < 3 - i || y > 7 + i) t *= 2.0f;
+            uint8_t f = ifn_L2[b * 144 + cell];
+            if (t > 2.0f) f = 1;                                          /* :148 / :199 */
+            if (x < 1 || x > 10 || y < 1 || y > 10) f = 1;                /* :149 / :200 */
+            if (merge_new && !f) t -= 10000.0f;                           /* :201 */
+            trust[b * 144 + cell] = t;
+            ifn_L2[b * 144 + cell] = f;
+        }
+    int64_t* slot = (int64_t*)malloc(sizeof(int64_t) * (size_t)NP);
+    int64_t cnt = 0;
+    for (int64_t q = 0; q < NP; ++q) slot[q] = ifn_L1[q] ? -1 : cnt++;
+    if (cnt != B) { free(slot); return -1; }
+    uint8_t* ifm = (uint8_t*)calloc((size_t)(batch_num * per), 1);
+    double* use = (double*)malloc(sizeof(double) * (size_t)(batch_num * per));
+    for (int64_t q = 0; q < NP; ++q) {
+        const int bt = (int)(q / (h * w)), hh = (int)(q % (h * w)) / w, ww = (int)(q % (h * w)) % w;
+        for (int r = 0; r < 4; ++r)
+            for (int s = 0; s < 4; ++s)
+                for (int a = 0; a < 3; ++a)
+                    for (int c = 0; c < 3; ++c) {
+                        const int64_t o = bt * per + ((int64_t)(hh * 4 + r) * w4 + ww * 4 + s) * 9 + a * 3 + c;
+                        double* sb = scores_back + (q * 16 + r * 4 + s) * 9 + a * 3 + c;
+                        if (slot[q] >= 0) {
+                            const int64_t src = slot[q] * 144 + (a * 4 + r) * 12 + c * 4 + s;
+                            ifm[o] = !ifn_L2[src];                        /* :157-160 / :206-209 */
+                            *sb = (double)trust[src];                     /* :161-163 / :210-211 */
+                        }
+                        use[o] = *sb;                                     /* :164 / :212 */
+                    }
+    }
+    uint8_t* res = (uint8_t*)malloc((size_t)(batch_num * per));
+    memset(res, 1, (size_t)(batch_num * per));                           /* :189 / :237 ones */
+    int rc = 0;
+    if (merge_new) {
+        uint8_t* ifm2 = (uint8_t*)malloc((size_t)(batch_num * per));
+        memcpy(ifm2, ifm, (size_t)(batch_num * per));                     /* :226 */
+        for (int bt = 0; bt < batch_num; ++bt)
+            for (int Y = 0; Y < h4; ++Y)
+                for (int X = 0; X < w4; ++X)
+                    for (int k = 0; k < 9; ++k) {
+                        const int a = k / 3, c = k % 3;
+                        const int by = Y + 4 * (a - 1), bx = X + 4 * (c - 1);       /* :216-220 */
+                        if (by < 0 || by >= h4 || bx < 0 || bx >= w4)
+                            use[bt * per + ((int64_t)Y * w4 + X) * 9 + k] += 100000.0; /* :221-223 */
+                    }
+        for (int i = 0; i < 9; ++i) {                                     /* :227-231 */
+            const int dy = -(i % 3 - 1), dx = -(i / 3 - 1);
+            const int y0 = 4 * (dx > 0 ? dx : 0), y1 = h4 + (dx < 0 ? dx : 0) * 4;
+            const int x0 = 4 * (dy > 0 ? dy : 0), x1 = w4 + (dy < 0 ? dy : 0) * 4;
+            for (int bt = 0; bt < batch_num; ++bt)
+                for (int Y = y0; Y < y1; ++Y)
+                    for (int X = x0; X < x1; ++X)
+                        ifm2[bt * per + ((int64_t)Y * w4 + X) * 9 + i] =
+                            ifm[bt * per + ((int64_t)(Y - 4 * dx) * w4 + (X - 4 * dy)) * 9 + 8 - i];
+        }
+        for (int bt = 0; bt < batch_num && !rc; ++bt)
+            for (int64_t n = 0; n < (int64_t)h4 * w4; ++n) {
+                const double* u = use + bt * per + n * 9;
+                int sbi = 0;                                              /* :232: argsort of scores_back_use */
+                for (int k = 1; k < 9; ++k) if (u[k] < u[sbi]) sbi = k;
+                const uint8_t m = ifm2[bt * per + n * 9 + sbi];           /* :233 */
+                const int64_t s2 = 8 - sbi + n * 9 + (int64_t)(sbi % 3 - 1) * 4 * 9 +
+                                   (int64_t)(sbi / 3 - 1) * 4 * w4 * 9;    /* :234-236 */
+                if (s2 < 0 || s2 >= per) { rc = -2; break; }
+                res[bt * per + s2] = !m;                                  /* :237-238 */
+            }
+        free(ifm2);
+    } else {
+        double* nu = (double*)malloc(sizeof(double) * (size_t)(batch_num * per));
+        uint8_t* nm = (uint8_t*)malloc((size_t)(batch_num * per));
+        memcpy(nu, use, sizeof(double) * (size_t)(batch_num * per));
+        memcpy(nm, ifm, (size_t)(batch_num * per));
+        for (int i = 0; i < 9; ++i) {                                     /* :166-171 (channel i only, src cloned) */
+            const int dy = i % 3 - 1, dx = i / 3 - 1;
+            const int y0 = 4 * (dx > 0 ? dx : 0), y1 = h4 + (dx < 0 ? dx : 0) * 4;
+            const int x0 = 4 * (dy > 0 ? dy : 0), x1 = w4 + (dy < 0 ? dy : 0) * 4;
+            for (int bt = 0; bt < batch_num; ++bt)
+                for (int Y = y0; Y < y1; ++Y)
+                    for (int X = x0; X < x1; ++X) {
+                        const int64_t d = bt * per + ((int64_t)Y * w4 + X) * 9 + i;
+                        const int64_t s = bt * per + ((int64_t)(Y - 4 * dx) * w4 + (X - 4 * dy)) * 9 + i;
+                        nu[d] = use[s];
+                        nm[d] = ifm[s];
+                    }
+        }
+        for (int64_t e = 0; e < batch_num * per; ++e) if (nm[e]) nu[e] -= 10000.0;   /* :173 */
+        for (int bt = 0; bt < batch_num; ++bt)
+            for (int64_t n = 0; n < (int64_t)h4 * w4; ++n) {
+                const double* u = nu + bt * per + n * 9;
+                int sbi = 0;                                              /* :174 */
+                for (int k = 1; k < 9; ++k) if (u[k] < u[sbi]) sbi = k;
+                uint8_t m = nm[bt * per + n * 9 + sbi];                   /* :175 */
+                int64_t s2 = sbi + n * 9 - (int64_t)(sbi % 3 - 1) * 4 * 9 -
+                             (int64_t)(sbi / 3 - 1) * 4 * w4 * 9;          /* :176-178 */
+                const int64_t hy = n / w / 4 - (sbi / 3 - 1) * 4;          /* :179-180 */
+                const int64_t wx = n % w4 - (sbi % 3 - 1) * 4;             /* :181-182 */
+                if (hy < 0 || hy >= h4 || wx < 0 || wx >= w4) m = 0;       /* :183-186 */
+                if (s2 < 0) s2 = 0;                                        /* :187 */
+                if (s2 > per - 1) s2 = per - 1;
+                res[bt * per + s2] = !m;                                   /* :188-189, in source order */
+            }
+        free(nu);
+        free(nm);
+    }
+    if (!rc)
+        for (int64_t q = 0; q < NP; ++q) {                                /* :190-191 / :239-240 */
+            if (slot[q] < 0) continue;
+            const int bt = (int)(q / (h * w)), hh = (int)(q % (h * w)) / w, ww = (int)(q % (h * w)) % w;
+            for (int a = 0; a < 3; ++a)
+                for (int r = 0; r < 4; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        for (int s = 0; s < 4; ++s)
+                            out[slot[q] * 144 + (a * 4 + r) * 12 + c * 4 + s] =
+                                res[bt * per + ((int64_t)(hh * 4 + r) * w4 + ww * 4 + s) * 9 + a * 3 + c];
+        }
+    free(slot); free(ifm); free(use); free(res);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * f3a  third-level inputs, models/pats.py:53-58: for every surviving L2 cell the source point
+ * (cell centre on the 96-px patch, in 1/2-res units x 2) and the rounded target point, (x, y) order,
+ * plus the patch row it belongs to.  torch.round = round-half-even (rintf under the default mode).
+ * ifn2 [B,144], pts [B,144,2] (row, col) -> mk0, mk1 [P,2], b_ids [P]; returns P.
+ * ---------------------------------------------------------------------------------------- */
+int64_t oracle_third_inputs(const uint8_t* ifn2, const float* pts, int64_t B, float* mk0, float* mk1,
+                            int64_t* b_ids) {
+    int64_t P = 0;
+    for (int64_t b = 0; b < B; ++b)
+        for (int cell = 0; cell < 144; ++cell) {
+            if (ifn2[b * 144 + cell]) continue;
+            mk0[P * 2 + 0] = (float)(cell % 12 * 4 + 2) * 2.0f;
+            mk0[P * 2 + 1] = (float)(cell / 12 * 4 + 2) * 2.0f;
+            mk1[P * 2 + 0] = rintf(pts[(b * 144 + cell) * 2 + 1] * 4.0f) * 2.0f;
+            mk1[P * 2 + 1] = rintf(pts[(b * 144 + cell) * 2 + 0] * 4.0f) * 2.0f;
+            b_ids[P++] = b;
+        }
+    return P;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * f3b  scatter of the third-level results back onto the L2 grid, models/pats.py:59-67:
+ * every L2 cell becomes 4x4 sub-cells; surviving cells take mkpts1_f / the label flag, the rest keep
+ * the L2 point and stay "no match"; layout [B,12,12,4,4] -> [B,12,4,12,4] = 48x48 row-major.
+ * ifn2 [B,144], pts [B,144,2], mkpts1 [P,16,2], label0 [P*16] (= label[:,0]) ->
+ * ifn16 [B,2304], pts16 [B,2304,2]
+ * ---------------------------------------------------------------------------------------- */
+void oracle_refine_scatter(const uint8_t* ifn2, const float* pts, const float* mkpts1, const float* label0,
+                           int64_t B, uint8_t* ifn16, float* pts16) {
+    int64_t P = 0;
+    for (int64_t b = 0; b < B; ++b)
+        for (int cell = 0; cell < 144; ++cell) {
+            const int cy = cell / 12, cx = cell % 12;
+            const int nom = ifn2[b * 144 + cell];
+            for (int sub = 0; sub < 16; ++sub) {
+                const int sy = sub / 4, sx = sub % 4;
+                const int64_t o = b * 2304 + (cy * 4 + sy) * 48 + cx * 4 + sx;
+                float py = pts[(b * 144 + cell) * 2], px = pts[(b * 144 + cell) * 2 + 1];
+                uint8_t f = 1;
+                if (!nom) {
+                    py = mkpts1[(P * 16 + sub) * 2];
+                    px = mkpts1[(P * 16 + sub) * 2 + 1];
+                    f = label0[P * 16 + sub] < -9.9f;
+                }
+                pts16[o * 2] = py;
+                pts16[o * 2 + 1] = px;
+                ifn16[o] = f;
+            }
+            if (!nom) ++P;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * f2  get_result (layer_num = 2), utils/utils.py:189-213: composes the coarse patch origin, the
+ * area scale and the fine offset into absolute pixel coordinates for every surviving sub-cell.
+ * Level 0: rows = bs, n0 = size0[1]*size0[2] cells of size0[0] px; level 1: rows = K surviving
+ * level-0 cells (in order), n1 = size1[1]*size1[2] sub-cells.  fp32, operation order as written
+ * there.  Returns M and writes matches_l / matches_r [M,2].
+ * ---------------------------------------------------------------------------------------- */
+int64_t oracle_get_result(int bs, const uint8_t* ifn0, const uint8_t* ifn1, const float* ap0,
+                          const float* ap1, const float* sc0, const float* sc1, const int* size0,
+                          const int* size1, const uint8_t* choice0, const uint8_t* choice1, float* ml,
+                          float* mr) {
+    const int n0 = size0[1] * size0[2], n1 = size1[1] * size1[2];
+    int64_t K = 0, M = 0;
+    for (int bt = 0; bt < bs; ++bt)
+        for (int i = 0; i < n0; ++i) {
+            const int64_t e = (int64_t)bt * n0 + i;
+            if (ifn0[e]) continue;
+            float l0[2], r0[2];
+            for (int d = 0; d < 2; ++d) {
+                const float pos = (float)((d == 0 ? i / size0[2] : i % size0[2]) * size0[0]);
+                float dl = pos + 0.5f * (float)size0[0];                              /* :204 */
+                dl = dl - (1.5f * sc0[e * 2 + 1]) * (float)size0[0];                  /* :206 */
+                const float dr = (ap0[e * 2 + d] - 1.5f * sc0[e * 2 + 0]) * (float)size0[0]; /* :207 */
+                l0[d] = 0.0f + (choice0[bt] ? dl : dr);                               /* :211-212 */
+                r0[d] = 0.0f + (choice0[bt] ? dr : dl);
+            }
+            for (int j = 0; j < n1; ++j) {
+                const int64_t f = K * n1 + j;
+                if (ifn1[f]) continue;
+                for (int d = 0; d < 2; ++d) {
+                    const float pos = (float)((d == 0 ? j / size1[2] : j % size1[2]) * size1[0]);
+                    float dl = pos + 0.5f * (float)size1[0];
+                    dl = dl * sc1[f * 2 + 1];                                         /* :209 */
+                    const float dr = (ap1[f * 2 + d] * (float)size1[0]) * sc1[f * 2 + 0]; /* :210 */
+                    ml[M * 2 + d] = l0[d] + (choice1[K] ? dl : dr);
+                    mr[M * 2 + d] = r0[d] + (choice1[K] ? dr : dl);
+                }
+                ++M;
+            }
+            ++K;
+        }
+    return M;
+}

@@ -241,3 +241,71 @@ def third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rubbish):
     if rc != 0:
         raise IndexError("third_descriptors: gather index out of range")
     return o0, o1, ps, pt
+
+
+# ---- SURVEY.md section 8(f) rows ------------------------------------------------------------------
+def merge_patches(merge_new, trust, image_shape, ifn_L1, ifn_L2, scores_back):
+    """second_layer.py:137-238.  Returns (if_nomatching [B,144] bool, trust', ifn_L2', scores_back');
+    like the reference the 'old' variant hands back a zeroed scores_back to the caller, the array
+    written during the call is returned as the 4th item for inspection."""
+    t = np.array(trust, dtype=np.float32, order="C", copy=True)
+    B = t.shape[0]
+    l1 = np.ascontiguousarray(np.asarray(ifn_L1), dtype=np.uint8)
+    bt = l1.shape[0]
+    l2 = np.array(np.asarray(ifn_L2), dtype=np.uint8, order="C", copy=True).reshape(B, 144)
+    sb = np.array(scores_back, dtype=np.float64, order="C", copy=True)
+    out = np.ones((B, 144), np.uint8)
+    lib().oracle_merge_patches.restype = ctypes.c_int
+    rc = lib().oracle_merge_patches(int(bool(merge_new)), ctypes.c_int64(B), _p(t, c_f), int(image_shape[0]),
+                                    int(image_shape[1]), int(bt), _p(l1, c_u8), _p(l2, c_u8),
+                                    sb.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _p(out, c_u8))
+    if rc == -1:
+        raise IndexError("merge_patches: number of unmasked coarse patches != rows of trust_score")
+    if rc != 0:
+        raise RuntimeError("merge_patches: scatter index out of range")
+    return out.astype(bool), t, l2.astype(bool), sb
+
+
+def third_inputs(ifn2, pts):
+    f = np.ascontiguousarray(np.asarray(ifn2), dtype=np.uint8)
+    B = f.shape[0]
+    pts, pp = _f(np.asarray(pts).reshape(B, 144, 2))
+    n = int((f == 0).sum())
+    mk0 = np.empty((n, 2), np.float32)
+    mk1 = np.empty((n, 2), np.float32)
+    b_ids = np.empty((n,), np.int64)
+    lib().oracle_third_inputs.restype = ctypes.c_int64
+    lib().oracle_third_inputs(_p(f, c_u8), pp, ctypes.c_int64(B), _p(mk0, c_f), _p(mk1, c_f), _p(b_ids, c_i64))
+    return mk0, mk1, b_ids
+
+
+def refine_scatter(ifn2, pts, mkpts1, label0):
+    f = np.ascontiguousarray(np.asarray(ifn2), dtype=np.uint8)
+    B = f.shape[0]
+    pts, pp = _f(np.asarray(pts).reshape(B, 144, 2))
+    mk, pm = _f(np.asarray(mkpts1).reshape(-1, 16, 2))
+    lb, pl = _f(np.asarray(label0).reshape(-1))
+    ifn16 = np.empty((B, 2304), np.uint8)
+    pts16 = np.empty((B, 2304, 2), np.float32)
+    lib().oracle_refine_scatter(_p(f, c_u8), pp, pm, pl, ctypes.c_int64(B), _p(ifn16, c_u8), _p(pts16, c_f))
+    return ifn16.astype(bool), pts16
+
+
+def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left_choice):
+    f0 = np.ascontiguousarray(np.asarray(if_nomatching[0]), dtype=np.uint8)
+    f1 = np.ascontiguousarray(np.asarray(if_nomatching[1]), dtype=np.uint8)
+    a0, pa0 = _f(average_point[0])
+    a1, pa1 = _f(average_point[1])
+    s0, ps0 = _f(scale[0])
+    s1, ps1 = _f(scale[1])
+    z0 = np.asarray(patch_size[0], dtype=np.int32)
+    z1 = np.asarray(patch_size[1], dtype=np.int32)
+    c0 = np.ascontiguousarray(np.asarray(left_choice[0]), dtype=np.uint8)
+    c1 = np.ascontiguousarray(np.asarray(left_choice[1]), dtype=np.uint8)
+    cap = int((f1 == 0).sum())
+    ml = np.empty((cap, 2), np.float32)
+    mr = np.empty((cap, 2), np.float32)
+    lib().oracle_get_result.restype = ctypes.c_int64
+    M = lib().oracle_get_result(int(batch_size), _p(f0, c_u8), _p(f1, c_u8), pa0, pa1, ps0, ps1, _p(z0, c_i32),
+                                _p(z1, c_i32), _p(c0, c_u8), _p(c1, c_u8), _p(ml, c_f), _p(mr, c_f))
+    return ml[:M].copy(), mr[:M].copy()

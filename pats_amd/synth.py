@@ -128,3 +128,54 @@ def third_maps(seed=SEED + 6, B=3, P=40):
     kenc = rng.standard_normal((1, 128, 64), dtype=np.float32)
     rubbish = rng.standard_normal((B, 128, 144), dtype=np.float32)
     return {"ff0": ff0, "ff1": ff1, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "kenc": kenc, "rubbish": rubbish}
+
+
+def merge_inputs(seed=SEED + 7, h=15, w=20, chunks=3, tie_step=0.125):
+    """Inputs of merge_patches_new/old (second_layer.py:137-238) for `chunks` successive L2 chunks of
+    one pair: the coarse no-match mask, and per chunk the chunk mask (first_layer.py:137-139 style:
+    a contiguous run of matched patches, neighbouring chunks overlapping by one grid row), the L2
+    trust scores [B,144] and L2 no-match flags [B,144].  Half of the trust values sit on a 1/8 grid so
+    that exact ties reach the argsort."""
+    rng = np.random.default_rng(seed)
+    N = h * w
+    ifn_all = rng.random((1, N)) < 0.12
+    cum = np.cumsum(~ifn_all, axis=1)
+    K = int(cum[0, -1])
+    edges = np.linspace(0, K, chunks + 1).astype(int)
+    out = []
+    for c in range(chunks):
+        lo = max(0, edges[c] - (w if c else 0))
+        hi = edges[c + 1]
+        ifn_L1 = ifn_all | (cum <= lo) | (cum > hi)
+        B = int((~ifn_L1).sum())
+        trust = rng.lognormal(-1.0, 0.9, (B, 144)).astype(np.float32)
+        q = rng.random((B, 144)) < 0.5
+        trust = np.where(q, np.maximum(tie_step, np.round(trust / tie_step) * tie_step), trust).astype(np.float32)
+        ifn2 = rng.random((B, 144)) < 0.25
+        out.append({"ifn_L1": ifn_L1, "trust": trust, "ifn2": ifn2})
+    return {"h": h, "w": w, "ifn_all": ifn_all, "chunks": out}
+
+
+def result_inputs(seed=SEED + 8, h=15, w=20, bs=1, mixed_choice=False):
+    """Inputs of get_result / the third-level scatter (utils.py:189-213, pats.py:53-78): L1 cells with
+    their re-centred points and scales, L2 points / flags per surviving cell, third-level outputs."""
+    rng = np.random.default_rng(seed)
+    N = h * w
+    ifn0 = rng.random((bs, N)) < 0.15
+    K = int((~ifn0).sum())
+    ap0 = (rng.uniform(1.0, [h - 1.0, w - 1.0], (bs, N, 2))).astype(np.float32)
+    sc0 = np.exp(rng.uniform(-1.2, 1.2, (bs, N, 2))).astype(np.float32)
+    ifn2 = rng.random((K, 144)) < 0.55
+    ifn2[K // 3] = True                                   # a row with nothing left (pats.py:41-42)
+    pts = rng.uniform(0.0, 12.0, (K, 144, 2)).astype(np.float32)
+    pts[0, :8] = np.array([[0.125, 0.375], [0.625, 1.125], [2.875, 3.375], [5.5, 5.5], [6.125, 0.0],
+                           [11.875, 11.625], [1.375, 2.625], [3.0, 3.0]], np.float32)   # round-half-even cases
+    P = int((~ifn2).sum())
+    mkpts1 = rng.uniform(0.0, 96.0, (P, 16, 2)).astype(np.float32)
+    label0 = np.where(rng.random((P * 16,)) < 0.2, -10.0, 1e8).astype(np.float32)
+    ch0 = np.ones((bs,), bool)
+    ch1 = np.ones((K,), bool)
+    if mixed_choice:
+        ch1 = rng.random((K,)) < 0.5
+    return {"h": h, "w": w, "ifn0": ifn0, "ap0": ap0, "sc0": sc0, "ifn2": ifn2, "pts": pts, "mkpts1": mkpts1,
+            "label0": label0, "choice0": ch0, "choice1": ch1}

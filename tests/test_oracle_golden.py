@@ -233,3 +233,57 @@ def test_third_descriptors(oracle):
     bad[0], bid[0] = [0.0, 0.0], 0                # flattened index goes negative: torch.gather raises
     with pytest.raises(IndexError):
         oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], bad, bid, inp["kenc"], inp["rubbish"])
+
+
+# ---- SURVEY.md section 8(f) rows -------------------------------------------------------------------
+def _merge_case(name):
+    g = golden(name)
+    inp = synth.merge_inputs(seed=int(g["seed"]), h=int(g["h"]), w=int(g["w"]))
+    assert synth.checksum(*[ch["trust"] for ch in inp["chunks"]]) == float(g["in_checksum"])
+    return g, inp
+
+
+@pytest.mark.parametrize("name", ["merge_new.npz", "merge_old.npz", "merge_new_portrait.npz"])
+def test_merge_patches(oracle, name):
+    """second_layer.py:137-238 over three successive chunks; bit-exact flags, trust and scores_back."""
+    g, inp = _merge_case(name)
+    new, h, w = bool(g["merge_new"]), inp["h"], inp["w"]
+    sb = np.zeros((1, h * w, 16, 9))
+    for c, ch in enumerate(inp["chunks"]):
+        out, t, f2, sb_w = oracle.merge_patches(new, ch["trust"], (h * 32, w * 32), ch["ifn_L1"], ch["ifn2"], sb)
+        assert np.array_equal(out, g["out%d" % c])
+        assert np.array_equal(t, g["trust%d" % c])
+        assert np.array_equal(f2, g["ifn2_%d" % c])
+        assert np.array_equal(sb_w.astype(np.float32), g["sb_written%d" % c])
+        assert int(g["sb_returned_zero%d" % c]) == (0 if new else 1)
+        sb = sb_w if new else np.zeros_like(sb_w)          # what the reference hands back (:191 / :240)
+    assert 0 < (~out).sum() < out.size
+
+
+def test_merge_patches_wrong_row_count_raises(oracle):
+    _, inp = _merge_case("merge_new.npz")
+    ch = inp["chunks"][0]
+    with pytest.raises(IndexError):
+        oracle.merge_patches(True, ch["trust"][:-1], (480, 640), ch["ifn_L1"], ch["ifn2"][:-1], np.zeros((1, 300, 16, 9)))
+
+
+def _result_case(name):
+    g = golden(name)
+    inp = synth.result_inputs(seed=int(g["seed"]), h=5, w=6, mixed_choice=bool(g["mixed"]))
+    assert synth.checksum(inp["ap0"], inp["sc0"], inp["pts"], inp["mkpts1"], inp["label0"]) == float(g["in_checksum"])
+    return g, inp
+
+
+@pytest.mark.parametrize("name", ["result.npz", "result_mixed.npz"])
+def test_third_inputs_scatter_and_get_result(oracle, name):
+    """pats.py:53-78 + utils.py:189-213: bit-exact (index work and a fixed fp32 operation order)."""
+    g, inp = _result_case(name)
+    mk0, mk1, b_ids = oracle.third_inputs(inp["ifn2"], inp["pts"])
+    assert np.array_equal(mk0, g["mk0"]) and np.array_equal(mk1, g["mk1"]) and np.array_equal(b_ids, g["b_ids"])
+    f16, p16 = oracle.refine_scatter(inp["ifn2"], inp["pts"], inp["mkpts1"], inp["label0"])
+    assert np.array_equal(f16, g["ifn16"]) and np.array_equal(p16, g["pts16"])
+    sc1 = np.repeat(inp["sc0"][~inp["ifn0"]].reshape(-1, 1, 2), 2304, 1)
+    ml, mr = oracle.get_result(1, [inp["ifn0"], f16], [inp["ap0"], p16[:, :, ::-1] / np.float32(2.0)],
+                               [inp["sc0"], sc1], [[32, 5, 6], [2, 48, 48]], [inp["choice0"], inp["choice1"]])
+    assert np.array_equal(ml, g["matches_l"]) and np.array_equal(mr, g["matches_r"])
+    assert ml.shape[0] > 1000

@@ -22,6 +22,10 @@ What each fixture pins (reference file:line):
   third_65.npz     L3: cost, OT2, Compute_result, outdoor label (third_layer.py:156-170,184-217)
   third_65_indoor.npz  indoor label rule
   resize_small.npz tensor_resize edge cases (1-pixel crops, borders) (setup/library.cpp:47-66)
+  merge_new.npz / merge_old.npz / merge_new_portrait.npz   merge_patches_new / _old over three
+                   successive chunks incl. the scores_back hand-over (second_layer.py:137-238)
+  result.npz / result_mixed.npz   third-level inputs, result scatter and get_result
+                   (pats.py:53-78, utils/utils.py:189-213); _mixed flips left_choice per row
 """
 import math
 import os
@@ -319,6 +323,59 @@ def gen_resize_small(R):
     save("resize_small.npz", src=src, bound=bound, out=out)
 
 
+def gen_merge(R, name, merge_new, seed, h=15, w=20):
+    """second_layer.py:137-238 run chunk after chunk with the caller's scores_back hand-over (pats.py:32,37)."""
+    inp = synth.merge_inputs(seed=seed, h=h, w=w)
+    fn = R.L2.SecondLayer.merge_patches_new if merge_new else R.L2.SecondLayer.merge_patches_old
+    sb = torch.zeros([1, h * w, 16, 9]).double()
+    arrs = {}
+    for c, ch in enumerate(inp["chunks"]):
+        tr, f2, l1 = T(ch["trust"].copy()), T(ch["ifn2"].copy()), T(ch["ifn_L1"].copy())
+        sb_arg = sb
+        out, sb = fn(None, tr.shape[0], tr, (h * 32, w * 32), l1, f2, sb_arg)
+        arrs["out%d" % c], arrs["trust%d" % c], arrs["ifn2_%d" % c] = out, tr, f2
+        arrs["sb_written%d" % c] = sb_arg.to(torch.float32)        # the argument after the in-place write (fp32 values)
+        arrs["sb_returned_zero%d" % c] = np.int64(int((sb == 0).all()))
+    save(name, merge_new=np.int64(merge_new), seed=np.int64(seed), h=np.int64(h), w=np.int64(w),
+         in_checksum=synth.checksum(*[ch["trust"] for ch in inp["chunks"]]), **arrs)
+
+
+def gen_result(R, name, seed, mixed):
+    """pats.py:53-78 re-executed verbatim on synthetic L1/L2/L3 outputs, then utils.get_result (utils.py:189-213)."""
+    inp = synth.result_inputs(seed=seed, h=5, w=6, mixed_choice=mixed)     # small grid: the fixture holds pts16 in full
+    h, w = inp["h"], inp["w"]
+    ifn2, pts = T(inp["ifn2"]), T(inp["pts"])
+    K = ifn2.shape[0]
+    # pats.py:53-58
+    sequence = torch.arange(0, 144).reshape(-1, 144, 1).repeat(K, 1, 1)
+    third_input = torch.cat([sequence % 12 * 4 + 2, sequence // 12 * 4 + 2, torch.round(pts * 4)[:, :, [1, 0]],
+                             torch.arange(K).reshape(-1, 1, 1).repeat(1, 144, 1)], dim=2)
+    third_input = third_input[torch.logical_not(ifn2)]
+    mk0, mk1, b_ids = third_input[:, :2] * 2, third_input[:, 2:4] * 2, third_input[:, -1]
+    # pats.py:59-67
+    mkpts1 = T(inp["mkpts1"]).reshape(-1, 2)
+    pts16 = pts.reshape(-1, 144, 1, 2).repeat(1, 1, 16, 1)
+    f16 = ifn2.reshape(-1, 144, 1).repeat(1, 1, 16)
+    pts16[torch.logical_not(f16)] = mkpts1.float()
+    label = torch.zeros_like(f16).float()
+    label[torch.logical_not(f16)] = T(inp["label0"])
+    f16 = torch.logical_or(f16, label < -9.9)
+    f16 = f16.reshape(-1, 12, 12, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 144 * 16)
+    pts16 = pts16.reshape(-1, 12, 12, 4, 4, 2).permute(0, 1, 3, 2, 4, 5).reshape(-1, 144 * 16, 2)
+    # pats.py:68-76
+    ifn0 = T(inp["ifn0"])
+    if_nomatching = [ifn0, f16]
+    patch_size = [[32, h, w], [2, 48, 48]]
+    sc0 = T(inp["sc0"])
+    scale = [sc0, sc0.reshape(-1, w * h, 2)[torch.logical_not(ifn0)].reshape(-1, 1, 2).repeat(1, 144 * 16, 1)]
+    average_point = [T(inp["ap0"]), pts16.flip(dims=[2]) / 2.0]
+    left_choice = [T(inp["choice0"]), T(inp["choice1"])]
+    ml, mr = R.U.get_result(ifn0.shape[0], if_nomatching, average_point, scale, patch_size, left_choice)
+    save(name, seed=np.int64(seed), mixed=np.int64(mixed), mk0=mk0, mk1=mk1, b_ids=b_ids, ifn16=f16, pts16=pts16,
+         matches_l=ml, matches_r=mr,
+         in_checksum=synth.checksum(inp["ap0"], inp["sc0"], inp["pts"], inp["mkpts1"], inp["label0"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -339,6 +396,11 @@ def main():
     gen_resize_small(R)
     gen_fine_desc(R)
     gen_third_desc(R)
+    gen_merge(R, "merge_new.npz", True, synth.SEED + 7)
+    gen_merge(R, "merge_old.npz", False, synth.SEED + 9)
+    gen_merge(R, "merge_new_portrait.npz", True, synth.SEED + 10, h=20, w=15)
+    gen_result(R, "result.npz", synth.SEED + 8, False)
+    gen_result(R, "result_mixed.npz", synth.SEED + 11, True)
 
 
 if __name__ == "__main__":
