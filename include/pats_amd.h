@@ -202,6 +202,59 @@ int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int 
                          const int64_t* p_t, int iters, int outdoor, float* mkpts0_f, float* mkpts1_f,
                          float* label, uint8_t* if_matching1, float* Z_out, pats_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The steps either side of the OT path.  bool tensors are 1 byte, 0 / 1.
+ * ---------------------------------------------------------------------------------------- */
+
+/* SecondLayer.merge_patches_new (merge_new != 0, reference models/second_layer.py:193-240) and
+ * merge_patches_old (merge_new == 0, :137-191): resolves every 8-px cell among the up to nine 96x96
+ * windows covering it.  Like the reference it works in place on trust_score [B,144] (border weighting
+ * :194-198, and -10000 on matching cells for "new" :201) and on if_nomatching1_L2 [B,144] (:199-200),
+ * and writes this chunk's scores into scores_back [batch_num, H/32*W/32, 16, 9] (fp64, :211; the
+ * "new" variant reads the other patches' entries left there by earlier chunks, pats.py:32,37).
+ * `out` [B,144] is the returned if_nomatching (rows = unmasked entries of if_nomatching1_L1, in
+ * order).  The reference raises when the number of unmasked coarse patches differs from B; here
+ * surplus patches are ignored and missing ones leave their rows "no match" - host wrappers validate. */
+size_t pats_merge_workspace_bytes(int64_t B, int H, int W, int batch_num);
+int pats_merge_patches(int merge_new, int64_t B, float* trust_score, int H, int W, int batch_num,
+                       const uint8_t* if_nomatching1_L1, uint8_t* if_nomatching1_L2, double* scores_back,
+                       uint8_t* out, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
+/* Workspace of the order-preserving compactions below over n flags. */
+size_t pats_compact_workspace_bytes(int64_t n);
+
+/* Third-level inputs (reference models/pats.py:53-58): for every L2 cell with if_nomatching == 0, in
+ * (row, cell) order, mkpts0 = ((cell % 12) * 4 + 2, (cell / 12) * 4 + 2) * 2, mkpts1 =
+ * round(pts * 4)[(1, 0)] * 2 (round half to even) and the patch row b_ids.  Writes at most `capacity`
+ * rows; *count (device int64) receives the number of surviving cells P. */
+int pats_third_inputs_f32(const uint8_t* if_nomatching, const float* pts, int64_t B, float* mkpts0,
+                          float* mkpts1, int64_t* b_ids, int64_t capacity, int64_t* count, void* workspace,
+                          size_t workspace_bytes, pats_stream_t stream);
+
+/* Scatter of the third-level results onto the 48x48 sub-cell grid (reference models/pats.py:59-67):
+ * pts16 [B,2304,2] takes mkpts1_f [P,16,2] where the L2 cell survived (else the L2 point), and
+ * if_nomatching16 [B,2304] = L2 flag OR label < -9.9; layout [B,12,4,12,4].  `label` is read with a
+ * stride (2 for the reference's label[:, 0] of a [P*16,2] tensor). */
+int pats_refine_scatter_f32(const uint8_t* if_nomatching, const float* pts, const float* mkpts1_f,
+                            const float* label, int label_stride, int64_t B, int64_t P,
+                            uint8_t* if_nomatching16, float* pts16, void* workspace,
+                            size_t workspace_bytes, pats_stream_t stream);
+
+/* get_result with layer_num = 2 (reference utils/utils.py:189-213, called at models/pats.py:73):
+ * level 0 has batch_size rows of patch_size0[1]*patch_size0[2] cells of patch_size0[0] px, level 1 has
+ * `rows1` rows (one per surviving level-0 cell, in order) of patch_size1[1]*patch_size1[2] sub-cells.
+ * scale1_cell_stride = 2: scale1 is [rows1, n1, 2] as the reference materialises it; 0: scale1 is
+ * [rows1, 2], one scale per row (what pats.py:70 repeats).  Output order = reference (row, sub-cell);
+ * at most `capacity` rows are written, *count (device int64) receives M.  fp32, operation order of the
+ * reference.  Workspace: pats_get_result_workspace_bytes(batch_size*n0, rows1, n1). */
+size_t pats_get_result_workspace_bytes(int64_t cells0, int64_t rows1, int64_t cells1);
+int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uint8_t* if_nomatching1,
+                        int64_t rows1, const float* average_point0, const float* average_point1,
+                        const float* scale0, const float* scale1, int64_t scale1_cell_stride,
+                        const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
+                        const uint8_t* left_choice1, float* matches_l, float* matches_r, int64_t capacity,
+                        int64_t* count, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,18 @@ SIGNATURES = {
     "pats_third_level_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
+    "pats_merge_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "pats_merge_patches": (c_int, [c_int, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_compact_workspace_bytes": (c_size, [c_i64]),
+    "pats_third_inputs_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
+                                      c_void_p, c_size, c_void_p]),
+    "pats_refine_scatter_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p,
+                                        c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_get_result_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
+    "pats_get_result_f32": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                                    ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
 }
 
 _lib = None

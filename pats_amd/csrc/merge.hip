@@ -1,0 +1,464 @@
+// The steps either side of the OT path on gfx950: index arithmetic on small
+// grids, one thread per element, no host round-trip inside a call.
+//   merge_patches_new / _old   models/second_layer.py:137-238
+//   third-level inputs          models/pats.py:53-58
+//   result scatter              models/pats.py:59-67
+//   get_result                  utils/utils.py:189-213
+// The reference expresses all of these as boolean-mask indexing (each one a device->host sync for
+// the output size) plus argsort / scatter on [1,4h,4w,9] tensors.  Here the order-preserving
+// compactions use one exclusive scan of the keep-flags (scan_flags) and every consumer computes its
+// own output slot; the merge is a gather ("new": each output entry finds its unique writer) or a
+// last-writer-wins scatter made deterministic with atomicMax on (source order, value) ("old").
+#include "common.hpp"
+
+namespace pats {
+
+// ---- exclusive scan of keep-flags (keep = flag byte == 0) ------------------------------------------
+// offs[i] = number of kept elements before i inside i's 2048-element tile; tile_base[t] = kept elements
+// before tile t (after scan_tiles_kernel); total = kept elements overall.
+constexpr int SCAN_TILE = 2048;
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+scan_flags_kernel(const uint8_t* __restrict__ flags, int64_t n, int32_t* __restrict__ offs,
+                  int32_t* __restrict__ tile_base) {
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_TILE + t * 8;
+    int keep[8], c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        keep[k] = (i0 + k < n) ? (flags[i0 + k] == 0) : 0;
+        c += keep[k];
+    }
+    const int incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    int run = base + incl - c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (i0 + k < n) offs[i0 + k] = run;
+        run += keep[k];
+    }
+    if (t == 255) tile_base[blockIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(1024)
+scan_tiles_kernel(int32_t* __restrict__ tile_base, int tiles, int64_t* __restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < tiles; b0 += 1024) {
+        const int v = (b0 + t < tiles) ? tile_base[b0 + t] : 0;
+        const int incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (b0 + t < tiles) tile_base[b0 + t] = base + incl - v;
+        __syncthreads();
+        if (t == 1023) carry = base + incl;
+        __syncthreads();
+    }
+    if (t == 0 && total) *total = carry;
+}
+
+struct Scan {
+    int32_t* offs;
+    int32_t* tile_base;
+    __device__ __forceinline__ int64_t at(int64_t i) const { return (int64_t)offs[i] + tile_base[i / SCAN_TILE]; }
+};
+
+static size_t scan_bytes(int64_t n) {
+    const int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    return (size_t)(((n + 3) & ~3ll) + ((tiles + 3) & ~3ll)) * sizeof(int32_t);
+}
+
+// carve a Scan out of `ws` and run it; *ws is advanced
+static int run_scan(const uint8_t* flags, int64_t n, int64_t* total_dev, char** ws, Scan* sc, hipStream_t st) {
+    const int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    sc->offs = reinterpret_cast<int32_t*>(*ws);
+    sc->tile_base = sc->offs + ((n + 3) & ~3ll);
+    *ws += scan_bytes(n);
+    if (n == 0) {
+        if (total_dev && hipMemsetAsync(total_dev, 0, sizeof(int64_t), st) != hipSuccess) return check_launch("scan memset");
+        return PATS_OK;
+    }
+    hipLaunchKernelGGL(scan_flags_kernel, dim3((unsigned)tiles), dim3(256), 0, st, flags, n, sc->offs, sc->tile_base);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sc->tile_base, (int)tiles, total_dev);
+    return check_launch("scan_flags");
+}
+
+// ---- merge_patches ----------------------------------------------------------------------------------
+// slot[q] = row of trust_score that coarse patch q owns in this chunk, or -1; patch_of[b] = its inverse
+__global__ void __launch_bounds__(256)
+merge_slots_kernel(const uint8_t* __restrict__ ifn_L1, Scan sc, int64_t NP, int64_t B, int32_t* __restrict__ slot,
+                   int32_t* __restrict__ patch_of) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= NP) return;
+    int64_t s = -1;
+    if (!ifn_L1[q]) {
+        s = sc.at(q);
+        if (s >= B) s = -1;                 // more unmasked patches than rows: ignored (host wrapper validates)
+        else patch_of[s] = (int32_t)q;
+    }
+    slot[q] = (int32_t)s;
+}
+
+// border weighting, flag update, score hand-over into scores_back (second_layer.py:140-149,161-163 / :192-201,210-211)
+__global__ void __launch_bounds__(256)
+merge_prepare_kernel(int merge_new, int64_t B, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
+                     const int32_t* __restrict__ patch_of, double* __restrict__ scores_back) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * 144) return;
+    const int64_t b = e / 144;
+    const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
+    float t = trust[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (x < 3 - i || x > 7 + i || y < 3 - i || y > 7 + i) t *= 2.0f;
+    uint8_t f = ifn_L2[e];
+    if (t > 2.0f) f = 1;
+    if (x < 1 || x > 10 || y < 1 || y > 10) f = 1;
+    if (merge_new && !f) t -= 10000.0f;
+    trust[e] = t;
+    ifn_L2[e] = f;
+    const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
+    const int64_t q = patch_of[b];
+    if (q >= 0) scores_back[(q * 16 + r * 4 + s) * 9 + a * 3 + c] = (double)t;
+}
+
+struct MergeGeom {
+    int h, w, h4, w4;
+    int64_t per;                 // 4h * 4w * 9
+};
+
+// "new" (second_layer.py:214-240) as a gather.  Output entry (patch q, window cell (a,r,c,s)) lives at
+// owner-layout position (Y', X', k') = (4hh + r, 4ww + s, 3a + c).  The only fine cell whose scatter
+// index (:234-236) can hit it is (Y, X) = (Y' + 4(a-1), X' + 4(c-1)) choosing sb = 8 - k'; that cell's
+// choice is the first minimum of ITS OWNER's nine scores (+100000 for windows leaving the grid) -
+// argsort runs on scores_back_use, not on the re-gathered copy (:232).  The value scattered is
+// if_matching2[Y, X, sb] = if_matching at the entry itself, i.e. the (updated) L2 flag.
+__global__ void __launch_bounds__(256)
+merge_select_new_kernel(MergeGeom g, int64_t B, const int32_t* __restrict__ patch_of,
+                        const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
+                        uint8_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * 144) return;
+    const int64_t b = e / 144;
+    const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
+    const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
+    const int64_t q = patch_of[b];
+    uint8_t res = 1;
+    if (q >= 0) {
+        const int hw = g.h * g.w;
+        const int64_t bt = q / hw;
+        const int p = (int)(q - bt * hw), hh = p / g.w, ww = p % g.w;
+        const int Y = 4 * hh + r + 4 * (a - 1), X = 4 * ww + s + 4 * (c - 1);
+        if (Y >= 0 && Y < g.h4 && X >= 0 && X < g.w4) {
+            const int64_t qs = bt * hw + (Y / 4) * g.w + X / 4;
+            const double* u = scores_back + (qs * 16 + (Y % 4) * 4 + X % 4) * 9;
+            int sb = 0;
+            double best = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int by = Y + 4 * (k / 3 - 1), bx = X + 4 * (k % 3 - 1);
+                double v = u[k];
+                if (by < 0 || by >= g.h4 || bx < 0 || bx >= g.w4) v += 100000.0;
+                if (k == 0 || v < best) { best = v; sb = k; }
+            }
+            if (sb == 8 - (a * 3 + c)) res = ifn_L2[e];
+        }
+    }
+    out[e] = res;
+}
+
+// "old" (second_layer.py:165-189): one thread per fine cell re-gathers its nine candidates by geometry
+// (channel k from the owner 4(a-1), 4(c-1) cells away where that slice assignment reaches, its own
+// otherwise), applies -10000 to matching ones, takes the first minimum and scatters the flag to the
+// (clamped) source entry.  ATen's CPU scatter is sequential, so the last source wins:
+// atomicMax on ((source index + 1) << 1 | value).
+__global__ void __launch_bounds__(256)
+merge_scatter_old_kernel(MergeGeom g, int batch_num, const int32_t* __restrict__ slot,
+                         const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
+                         unsigned* __restrict__ winner) {
+    const int64_t cells = (int64_t)g.h4 * g.w4;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cells * batch_num) return;
+    const int64_t bt = e / cells, n = e - bt * cells;
+    const int Y = (int)(n / g.w4), X = (int)(n % g.w4), hw = g.h * g.w;
+    int sb = 0;
+    double best = 0.0;
+    bool m_best = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dx = k / 3 - 1, dy = k % 3 - 1;
+        const bool reach = Y >= 4 * max(dx, 0) && Y < g.h4 + 4 * min(dx, 0) && X >= 4 * max(dy, 0) && X < g.w4 + 4 * min(dy, 0);
+        const int sy = reach ? Y - 4 * dx : Y, sx = reach ? X - 4 * dy : X;
+        const int64_t qs = bt * hw + (sy / 4) * g.w + sx / 4;
+        double v = scores_back[(qs * 16 + (sy % 4) * 4 + sx % 4) * 9 + k];
+        const int sl = slot[qs];
+        const bool m = sl >= 0 && !ifn_L2[(int64_t)sl * 144 + ((k / 3) * 4 + sy % 4) * 12 + (k % 3) * 4 + sx % 4];
+        if (m) v -= 10000.0;
+        if (k == 0 || v < best) { best = v; sb = k; m_best = m; }
+    }
+    int64_t s2 = sb + n * 9 - (int64_t)(sb % 3 - 1) * 36 - (int64_t)(sb / 3 - 1) * 4 * g.w4 * 9;
+    const int64_t hy = n / g.w / 4 - (sb / 3 - 1) * 4, wx = n % g.w4 - (sb % 3 - 1) * 4;
+    if (hy < 0 || hy >= g.h4 || wx < 0 || wx >= g.w4) m_best = false;
+    s2 = min(max(s2, (int64_t)0), g.per - 1);
+    atomicMax(&winner[bt * g.per + s2], (unsigned)(((n + 1) << 1) | (m_best ? 0 : 1)));
+}
+
+__global__ void __launch_bounds__(256)
+merge_finish_old_kernel(MergeGeom g, int64_t B, const int32_t* __restrict__ patch_of,
+                        const unsigned* __restrict__ winner, uint8_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * 144) return;
+    const int64_t b = e / 144;
+    const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
+    const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
+    const int64_t q = patch_of[b];
+    uint8_t res = 1;
+    if (q >= 0) {
+        const int hw = g.h * g.w;
+        const int64_t bt = q / hw;
+        const int p = (int)(q - bt * hw), hh = p / g.w, ww = p % g.w;
+        const unsigned v = winner[bt * g.per + ((int64_t)(4 * hh + r) * g.w4 + 4 * ww + s) * 9 + a * 3 + c];
+        if (v) res = (uint8_t)(v & 1u);
+    }
+    out[e] = res;
+}
+
+// ---- third-level inputs, pats.py:53-58 ---------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+third_inputs_kernel(const uint8_t* __restrict__ ifn2, const float* __restrict__ pts, int64_t n, Scan sc,
+                    int64_t capacity, float* __restrict__ mk0, float* __restrict__ mk1, int64_t* __restrict__ b_ids) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n || ifn2[e]) return;
+    const int64_t P = sc.at(e);
+    if (P >= capacity) return;
+    const int64_t b = e / 144;
+    const int cell = (int)(e - b * 144);
+    mk0[P * 2 + 0] = (float)(cell % 12 * 4 + 2) * 2.0f;
+    mk0[P * 2 + 1] = (float)(cell / 12 * 4 + 2) * 2.0f;
+    mk1[P * 2 + 0] = rintf(pts[e * 2 + 1] * 4.0f) * 2.0f;      // torch.round: half to even
+    mk1[P * 2 + 1] = rintf(pts[e * 2 + 0] * 4.0f) * 2.0f;
+    b_ids[P] = b;
+}
+
+// ---- result scatter, pats.py:59-67 -------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+refine_scatter_kernel(const uint8_t* __restrict__ ifn2, const float* __restrict__ pts, const float* __restrict__ mkpts1,
+                      const float* __restrict__ label, int label_stride, int64_t P_rows, int64_t n16, Scan sc,
+                      uint8_t* __restrict__ ifn16, float* __restrict__ pts16) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;       // output index, [B,12,4,12,4] order
+    if (o >= n16) return;
+    const int64_t b = o / 2304;
+    const int q = (int)(o - b * 2304), yy = q / 48, xx = q % 48;
+    const int cell = (yy / 4) * 12 + xx / 4, sub = (yy % 4) * 4 + xx % 4;
+    const int64_t e = b * 144 + cell;
+    float py = pts[e * 2], px = pts[e * 2 + 1];
+    uint8_t f = 1;
+    if (!ifn2[e]) {
+        const int64_t P = sc.at(e);
+        if (P < P_rows) {
+            py = mkpts1[(P * 16 + sub) * 2];
+            px = mkpts1[(P * 16 + sub) * 2 + 1];
+            f = label[(P * 16 + sub) * (int64_t)label_stride] < -9.9f;
+        }
+    }
+    pts16[o * 2] = py;
+    pts16[o * 2 + 1] = px;
+    ifn16[o] = f;
+}
+
+// ---- get_result (layer_num = 2), utils.py:189-213 -----------------------------------------------------
+__global__ void __launch_bounds__(256)
+result_rows_kernel(const uint8_t* __restrict__ ifn0, int64_t n, Scan sc, int64_t rows1, int32_t* __restrict__ row_cell) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n || ifn0[e]) return;
+    const int64_t k = sc.at(e);
+    if (k < rows1) row_cell[k] = (int32_t)e;
+}
+
+struct ResultArgs {
+    const uint8_t* ifn1;
+    const float* ap0; const float* ap1; const float* sc0; const float* sc1;
+    int64_t sc1_cell_stride;
+    int s0, h0, w0, s1, h1, w1;
+    const uint8_t* ch0; const uint8_t* ch1;
+    const int64_t* rows0_dev;    // number of surviving level-0 cells
+    int64_t rows1, capacity;
+    float* ml; float* mr;
+};
+
+__global__ void __launch_bounds__(256)
+get_result_kernel(ResultArgs g, const int32_t* __restrict__ row_cell, Scan sc1) {
+    const int n0 = g.h0 * g.w0, n1 = g.h1 * g.w1;
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= g.rows1 * n1 || g.ifn1[f]) return;
+    const int64_t k = f / n1;
+    if (k >= *g.rows0_dev) return;                  // more rows than surviving cells: ignored
+    const int64_t M = sc1.at(f);
+    if (M >= g.capacity) return;
+    const int j = (int)(f - k * n1);
+    const int64_t e = row_cell[k];
+    const int64_t bt = e / n0;
+    const int i = (int)(e - bt * n0);
+    const bool c0 = g.ch0[bt] != 0, c1 = g.ch1[k] != 0;
+    const float z0 = (float)g.s0, z1 = (float)g.s1;
+    const float sc1l = g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride + 1 : k * 2 + 1];
+    const float sc1r = g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride : k * 2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float pos0 = (float)((d == 0 ? i / g.w0 : i % g.w0) * g.s0);
+        float dl0 = pos0 + 0.5f * z0;
+        dl0 = dl0 - (1.5f * g.sc0[e * 2 + 1]) * z0;
+        const float dr0 = (g.ap0[e * 2 + d] - 1.5f * g.sc0[e * 2]) * z0;
+        const float l0 = 0.0f + (c0 ? dl0 : dr0), r0 = 0.0f + (c0 ? dr0 : dl0);
+        const float pos1 = (float)((d == 0 ? j / g.w1 : j % g.w1) * g.s1);
+        float dl1 = pos1 + 0.5f * z1;
+        dl1 = dl1 * sc1l;
+        const float dr1 = (g.ap1[f * 2 + d] * z1) * sc1r;
+        g.ml[M * 2 + d] = l0 + (c1 ? dl1 : dr1);
+        g.mr[M * 2 + d] = r0 + (c1 ? dr1 : dl1);
+    }
+}
+
+}  // namespace pats
+
+using namespace pats;
+
+static inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" size_t pats_merge_workspace_bytes(int64_t B, int H, int W, int batch_num) {
+    if (B < 0 || H < 32 || W < 32 || batch_num < 1) return 0;
+    const int64_t NP = (int64_t)batch_num * (H / 32) * (W / 32);
+    const int64_t per = (int64_t)(H / 32) * 4 * (W / 32) * 4 * 9;
+    return scan_bytes(NP) + (size_t)(((NP + 3) & ~3ll) + ((B + 4) & ~3ll) + batch_num * per) * sizeof(int32_t) + 64;
+}
+
+extern "C" int pats_merge_patches(int merge_new, int64_t B, float* trust_score, int H, int W, int batch_num,
+                                  const uint8_t* if_nomatching1_L1, uint8_t* if_nomatching1_L2,
+                                  double* scores_back, uint8_t* out, void* workspace, size_t workspace_bytes,
+                                  pats_stream_t stream) {
+    PATS_REQUIRE(B >= 0 && H >= 32 && W >= 32 && batch_num >= 1, "merge_patches: bad shape");
+    if (B == 0) return PATS_OK;
+    PATS_REQUIRE(trust_score && if_nomatching1_L1 && if_nomatching1_L2 && scores_back && out, "merge_patches: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_merge_workspace_bytes(B, H, W, batch_num),
+                 "merge_patches: workspace too small");
+    hipStream_t st = as_stream(stream);
+    MergeGeom g{H / 32, W / 32, 4 * (H / 32), 4 * (W / 32), (int64_t)(H / 32) * 4 * (W / 32) * 4 * 9};
+    const int64_t NP = (int64_t)batch_num * g.h * g.w;
+    char* ws = static_cast<char*>(workspace);
+    Scan sc;
+    int rc = run_scan(if_nomatching1_L1, NP, nullptr, &ws, &sc, st);
+    if (rc != PATS_OK) return rc;
+    int32_t* slot = reinterpret_cast<int32_t*>(ws);
+    int32_t* patch_of = slot + ((NP + 3) & ~3ll);
+    unsigned* winner = reinterpret_cast<unsigned*>(patch_of + ((B + 4) & ~3ll));
+    if (hipMemsetAsync(patch_of, 0xff, sizeof(int32_t) * (size_t)B, st) != hipSuccess) return check_launch("merge memset");
+    hipLaunchKernelGGL(merge_slots_kernel, dim3(blocks256(NP)), dim3(256), 0, st, if_nomatching1_L1, sc, NP, B, slot, patch_of);
+    hipLaunchKernelGGL(merge_prepare_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, merge_new, B, trust_score,
+                       if_nomatching1_L2, patch_of, scores_back);
+    if (merge_new) {
+        hipLaunchKernelGGL(merge_select_new_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, g, B, patch_of,
+                           if_nomatching1_L2, scores_back, out);
+    } else {
+        if (hipMemsetAsync(winner, 0, sizeof(unsigned) * (size_t)(batch_num * g.per), st) != hipSuccess)
+            return check_launch("merge memset");
+        hipLaunchKernelGGL(merge_scatter_old_kernel, dim3(blocks256((int64_t)g.h4 * g.w4 * batch_num)), dim3(256), 0, st, g,
+                           batch_num, slot, if_nomatching1_L2, scores_back, winner);
+        hipLaunchKernelGGL(merge_finish_old_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, g, B, patch_of, winner, out);
+    }
+    return check_launch("merge_patches");
+}
+
+extern "C" size_t pats_compact_workspace_bytes(int64_t n) { return n < 0 ? 0 : scan_bytes(n) + 64; }
+
+extern "C" int pats_third_inputs_f32(const uint8_t* if_nomatching, const float* pts, int64_t B, float* mkpts0,
+                                     float* mkpts1, int64_t* b_ids, int64_t capacity, int64_t* count,
+                                     void* workspace, size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(B >= 0 && capacity >= 0, "third_inputs: bad shape");
+    PATS_REQUIRE(count, "third_inputs: null count");
+    const int64_t n = B * 144;
+    PATS_REQUIRE(n == 0 || (if_nomatching && pts && (capacity == 0 || (mkpts0 && mkpts1 && b_ids))), "third_inputs: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_compact_workspace_bytes(n), "third_inputs: workspace too small");
+    char* ws = static_cast<char*>(workspace);
+    Scan sc;
+    int rc = run_scan(if_nomatching, n, count, &ws, &sc, as_stream(stream));
+    if (rc != PATS_OK || n == 0) return rc;
+    hipLaunchKernelGGL(third_inputs_kernel, dim3(blocks256(n)), dim3(256), 0, as_stream(stream), if_nomatching, pts, n, sc,
+                       capacity, mkpts0, mkpts1, b_ids);
+    return check_launch("third_inputs_kernel");
+}
+
+extern "C" int pats_refine_scatter_f32(const uint8_t* if_nomatching, const float* pts, const float* mkpts1_f,
+                                       const float* label, int label_stride, int64_t B, int64_t P,
+                                       uint8_t* if_nomatching16, float* pts16, void* workspace,
+                                       size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(B >= 0 && P >= 0 && label_stride >= 1, "refine_scatter: bad shape");
+    if (B == 0) return PATS_OK;
+    PATS_REQUIRE(if_nomatching && pts && if_nomatching16 && pts16 && (P == 0 || (mkpts1_f && label)), "refine_scatter: null pointer");
+    const int64_t n = B * 144;
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_compact_workspace_bytes(n), "refine_scatter: workspace too small");
+    char* ws = static_cast<char*>(workspace);
+    Scan sc;
+    int rc = run_scan(if_nomatching, n, nullptr, &ws, &sc, as_stream(stream));
+    if (rc != PATS_OK) return rc;
+    hipLaunchKernelGGL(refine_scatter_kernel, dim3(blocks256(B * 2304)), dim3(256), 0, as_stream(stream), if_nomatching, pts,
+                       mkpts1_f, label, label_stride, P, B * 2304, sc, if_nomatching16, pts16);
+    return check_launch("refine_scatter_kernel");
+}
+
+extern "C" size_t pats_get_result_workspace_bytes(int64_t cells0, int64_t rows1, int64_t cells1) {
+    if (cells0 < 0 || rows1 < 0 || cells1 < 0) return 0;
+    return scan_bytes(cells0) + scan_bytes(rows1 * cells1) + (size_t)((rows1 + 4) & ~3ll) * sizeof(int32_t) + 64;
+}
+
+extern "C" int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uint8_t* if_nomatching1,
+                                   int64_t rows1, const float* average_point0, const float* average_point1,
+                                   const float* scale0, const float* scale1, int64_t scale1_cell_stride,
+                                   const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
+                                   const uint8_t* left_choice1, float* matches_l, float* matches_r,
+                                   int64_t capacity, int64_t* count, void* workspace, size_t workspace_bytes,
+                                   pats_stream_t stream) {
+    PATS_REQUIRE(batch_size >= 1 && rows1 >= 0 && capacity >= 0 && patch_size0 && patch_size1, "get_result: bad shape");
+    PATS_REQUIRE(scale1_cell_stride == 0 || scale1_cell_stride == 2, "get_result: scale1_cell_stride must be 0 or 2");
+    PATS_REQUIRE(count, "get_result: null count");
+    const int64_t n0 = (int64_t)patch_size0[1] * patch_size0[2], n1 = (int64_t)patch_size1[1] * patch_size1[2];
+    PATS_REQUIRE(n0 > 0 && n1 > 0 && patch_size0[0] > 0 && patch_size1[0] > 0, "get_result: bad patch_size");
+    const int64_t cells0 = batch_size * n0;
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_get_result_workspace_bytes(cells0, rows1, n1), "get_result: workspace too small");
+    PATS_REQUIRE(if_nomatching0 && average_point0 && scale0 && left_choice0, "get_result: null pointer");
+    hipStream_t st = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    Scan s0, s1;
+    int64_t* rows0_dev = reinterpret_cast<int64_t*>(ws);     // 64 B header
+    ws += 64;
+    int rc = run_scan(if_nomatching0, cells0, rows0_dev, &ws, &s0, st);
+    if (rc != PATS_OK) return rc;
+    rc = run_scan(if_nomatching1, rows1 * n1, count, &ws, &s1, st);
+    if (rc != PATS_OK || rows1 == 0) return rc;
+    PATS_REQUIRE(if_nomatching1 && average_point1 && scale1 && left_choice1 && (capacity == 0 || (matches_l && matches_r)),
+                 "get_result: null pointer");
+    int32_t* row_cell = reinterpret_cast<int32_t*>(ws);
+    hipLaunchKernelGGL(result_rows_kernel, dim3(blocks256(cells0)), dim3(256), 0, st, if_nomatching0, cells0, s0, rows1, row_cell);
+    ResultArgs g{if_nomatching1, average_point0, average_point1, scale0, scale1, scale1_cell_stride,
+                 patch_size0[0], patch_size0[1], patch_size0[2], patch_size1[0], patch_size1[1], patch_size1[2],
+                 left_choice0, left_choice1, rows0_dev, rows1, capacity, matches_l, matches_r};
+    hipLaunchKernelGGL(get_result_kernel, dim3(blocks256(rows1 * n1)), dim3(256), 0, st, g, row_cell, s1);
+    return check_launch("get_result_kernel");
+}

@@ -713,7 +713,7 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
     constexpr int NW = 16, CW = CPL * 64, RREG = RPW - LSLOTS;
     using RSum = RowReduce<RPW, OpSum>;
     using RMax = RowReduce<RPW, OpMax>;
-    constexpr int N1 = RSum::N1, N2 = RSum::N2;
+    constexpr int N2 = RSum::N2;
     __shared__ float part[2][NW][CW];       // cross-wave column partials (double-buffered)
     __shared__ float kl[LSLOTS][NW][CW];    // the last LSLOTS row-slots of K (register budget: 128)
     __shared__ float rsave[NW][RPW + 1];    // row stabilisers r_i per (wave, slot)

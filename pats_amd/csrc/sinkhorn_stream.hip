@@ -284,7 +284,7 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
                            bv, (float*)nullptr);
     }
     if (iters == 0) {       // u = v = 0: a = exp(r), b = exp(c)  ->  Z + 0 + 0; simplest: mark for the log kernel
-        hipMemsetAsync(fail, 0xff, sizeof(int) * (size_t)batch, st);
+        (void)hipMemsetAsync(fail, 0xff, sizeof(int) * (size_t)batch, st);     // failure surfaces in check_launch
         return check_launch("streaming sinkhorn (iters == 0)");
     }
     hipLaunchKernelGGL(stream_guard_kernel, dim3((unsigned)batch), dim3(ST), 0, st, a, M, bv, N, fail);

@@ -59,7 +59,7 @@ extern "C" int pats_compute_result_f32(const float* scores, int input_is_log, in
             set_error("compute_result: hipMallocAsync failed");
             return PATS_ERR_LAUNCH;
         }
-        hipMemsetAsync(count, 0, sizeof(int), st);
+        (void)hipMemsetAsync(count, 0, sizeof(int), st);                 // failure surfaces in check_launch
     }
     hipLaunchKernelGGL(compute_result_kernel, dim3((unsigned)ceil_div(P, 4)), dim3(256), 0, st, scores,
                        input_is_log, P, scale_x, scale_y, p_s, p_t, outdoor,
@@ -70,6 +70,6 @@ extern "C" int pats_compute_result_f32(const float* scores, int input_is_log, in
                            0, st, whole_loss, P * 16, count);
         rc = check_launch("whole_loss_finish_kernel");
     }
-    if (count) hipFreeAsync(count, st);
+    if (count) (void)hipFreeAsync(count, st);
     return rc;
 }

@@ -74,7 +74,7 @@ third_fused_kernel(Fused65Args g) {
     float dual_r = 0.f, dual_c = 0.f, dual_r64 = 0.f, dual_c64 = 0.f;   // u_(8I+J), v_(8J+I), u_64, v_64
     float kb[8][8];                          // the block: Z, then K (linear) - or Z kept (log path)
     float zdrow = 0.f, zdcol = 0.f, zcorner = 0.f;
-    float sc_r = 0.f, sc_c = 0.f, sc_r64 = 0.f, sc_c64 = 0.f;          // a_(8I+J), b_(8J+I), a_64, b_64
+    float sc_r = 0.f, sc_c = 0.f, sc_c64 = 0.f;          // a_(8I+J), b_(8J+I), a_64, b_64
     bool linear_done = false;
 
 #pragma unroll
@@ -222,7 +222,7 @@ third_fused_kernel(Fused65Args g) {
                 }
             }
             if (__all(sc_ok(a) && sc_ok(b)) && sc_ok(a64) && sc_ok(b64)) {
-                sc_r = a; sc_c = b; sc_r64 = a64; sc_c64 = b64;
+                sc_r = a; sc_c = b; sc_c64 = b64;
                 // u = log a - r, v = log b - c; the plan only needs the products below
                 dual_r = logf(a) - r_own; dual_c = logf(b) - c_own;
                 dual_r64 = logf(a64) - r64; dual_c64 = logf(b64) - c64;

@@ -465,3 +465,149 @@ def third_descriptors(feat_f0, feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish
                                            P, B, _ptr(o0), _ptr(o1), _ptr(ps), _ptr(pt), _stream()),
            "third_descriptors")
     return o0, o1, ps, pt
+
+
+# ------------------------------------------------------------------------------------------------
+# the steps either side of the OT path
+# ------------------------------------------------------------------------------------------------
+def _as_flags(t, name):
+    """bool / uint8 tensor -> contiguous uint8 view sharing storage when it already is contiguous bool."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("pats_amd: %s must be a GPU tensor (no CPU fallback)" % name)
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    if t.dtype != torch.uint8:
+        raise RuntimeError("pats_amd: %s must be bool or uint8, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _merge(merge_new, patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2,
+           scores_back, validate):
+    if trust_score.dtype != torch.float32 or not trust_score.is_cuda or not trust_score.is_contiguous():
+        raise RuntimeError("merge_patches: trust_score must be a contiguous float32 GPU tensor (it is updated in place)")
+    if if_nomatching1_L2.dtype != torch.bool or not if_nomatching1_L2.is_contiguous():
+        raise RuntimeError("merge_patches: if_nomatching1_L2 must be a contiguous bool tensor (it is updated in place)")
+    if scores_back.dtype != torch.float64 or not scores_back.is_contiguous():
+        raise RuntimeError("merge_patches: scores_back must be a contiguous float64 tensor (it is updated in place)")
+    B = trust_score.shape[0]
+    if trust_score.numel() != B * 144 or if_nomatching1_L2.numel() != B * 144 or int(patch_num) != B:
+        raise RuntimeError("merge_patches: trust_score / if_nomatching1_L2 must be [patch_num,144]")
+    H, W = int(original_image_shape[0]), int(original_image_shape[1])
+    l1 = _as_flags(if_nomatching1_L1, "if_nomatching1_L1")
+    bt = l1.shape[0]
+    if l1.numel() != bt * (H // 32) * (W // 32) or scores_back.numel() != l1.numel() * 144:
+        raise RuntimeError("merge_patches: if_nomatching1_L1 must be [batch, H/32*W/32], scores_back [batch, H/32*W/32, 16, 9]")
+    if validate and int((l1 == 0).sum()) != B:          # the reference's masked assignment raises here (:160 / :209)
+        raise IndexError("merge_patches: %d unmasked coarse patches but %d rows of trust_score" % (int((l1 == 0).sum()), B))
+    dev = trust_score.device
+    out = torch.empty((B, 144), dtype=torch.bool, device=dev)
+    nws = _L().pats_merge_workspace_bytes(B, H, W, bt)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_merge_patches(1 if merge_new else 0, B, _ptr(trust_score), H, W, bt, _ptr(l1),
+                                   _ptr(if_nomatching1_L2.view(torch.uint8)), _ptr(scores_back), _ptr(out.view(torch.uint8)),
+                                   _ptr(ws), nws, _stream()), "merge_patches")
+    return out
+
+
+def merge_patches_new(patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2, scores_back,
+                      validate=True):
+    """SecondLayer.merge_patches_new (second_layer.py:193-240).  trust_score, if_nomatching1_L2 and
+    scores_back are updated in place as in the reference; returns (if_nomatching [B,144], scores_back)."""
+    out = _merge(True, patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2,
+                 scores_back, validate)
+    return out, scores_back
+
+
+def merge_patches_old(patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2, scores_back,
+                      validate=True):
+    """SecondLayer.merge_patches_old (second_layer.py:137-191); hands back a zeroed scores_back (:191)."""
+    out = _merge(False, patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2,
+                 scores_back, validate)
+    return out, torch.zeros_like(scores_back)
+
+
+def third_inputs(if_nomatching, pts):
+    """pats.py:53-58: (mkpts0_c [P,2], mkpts1_c [P,2], b_ids [P]) of the surviving L2 cells - the arguments
+    PATS.forward passes to ThirdLayer (third_input[:, :2] * 2, third_input[:, 2:4] * 2, third_input[:, -1]).
+    One host read of P (the reference's boolean-mask indexing syncs at the same point)."""
+    f = _as_flags(if_nomatching, "if_nomatching")
+    B = f.shape[0]
+    p = _dev(pts, "pts").reshape(B, 144, 2)
+    if f.numel() != B * 144:
+        raise RuntimeError("third_inputs: if_nomatching must be [B,144]")
+    dev = p.device
+    cap = B * 144
+    mk0 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    mk1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    bi = torch.empty((cap,), dtype=torch.int64, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+    nws = _L().pats_compact_workspace_bytes(cap)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_third_inputs_f32(_ptr(f), _ptr(p), B, _ptr(mk0), _ptr(mk1), _ptr(bi), cap, _ptr(cnt), _ptr(ws), nws,
+                                      _stream()), "third_inputs")
+    P = int(cnt.item())
+    return mk0[:P], mk1[:P], bi[:P]
+
+
+def refine_scatter(if_nomatching, pts, mkpts1_f, label):
+    """pats.py:59-67: (if_nomatching16 [B,2304] bool, pts16 [B,2304,2]) on the 48x48 sub-cell grid.
+    `label` is ThirdLayer's [P*16,2] tensor (column 0 is read) or a 1-D [P*16] tensor."""
+    f = _as_flags(if_nomatching, "if_nomatching")
+    B = f.shape[0]
+    p = _dev(pts, "pts").reshape(B, 144, 2)
+    mk = _dev(mkpts1_f, "mkpts1_f").reshape(-1, 16, 2)
+    P = mk.shape[0]
+    lb = _dev(label, "label")
+    stride = 2 if lb.dim() == 2 else 1
+    if lb.numel() != P * 16 * stride:
+        raise RuntimeError("refine_scatter: label must be [P*16,2] or [P*16]")
+    dev = p.device
+    f16 = torch.empty((B, 2304), dtype=torch.bool, device=dev)
+    p16 = torch.empty((B, 2304, 2), dtype=torch.float32, device=dev)
+    nws = _L().pats_compact_workspace_bytes(B * 144)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_refine_scatter_f32(_ptr(f), _ptr(p), _ptr(mk), _ptr(lb), stride, B, P, _ptr(f16.view(torch.uint8)),
+                                        _ptr(p16), _ptr(ws), nws, _stream()), "refine_scatter")
+    return f16, p16
+
+
+def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left_choice, layer_num=2, validate=True):
+    """utils.get_result (utils.py:189-213) for the two-level call of pats.py:73: returns (matches_l,
+    matches_r) [M,2].  scale[1] may be the reference's [K,n1,2] tensor or a [K,2] / [K,1,2] tensor holding
+    one scale per row (what pats.py:70 repeats over the sub-cells)."""
+    if layer_num != 2 or len(if_nomatching) != 2:
+        raise RuntimeError("get_result: only the reference's layer_num=2 call is implemented")
+    f0, f1 = _as_flags(if_nomatching[0], "if_nomatching[0]"), _as_flags(if_nomatching[1], "if_nomatching[1]")
+    z0, z1 = [int(v) for v in patch_size[0]], [int(v) for v in patch_size[1]]
+    n0, n1 = z0[1] * z0[2], z1[1] * z1[2]
+    bs, rows1 = int(batch_size), f1.shape[0]
+    if f0.numel() != bs * n0 or f1.numel() != rows1 * n1:
+        raise RuntimeError("get_result: if_nomatching shapes do not match patch_size")
+    a0, a1 = _dev(average_point[0], "average_point[0]"), _dev(average_point[1], "average_point[1]")
+    s0, s1 = _dev(scale[0], "scale[0]"), _dev(scale[1], "scale[1]")
+    if a0.numel() != bs * n0 * 2 or s0.numel() != bs * n0 * 2 or a1.numel() != rows1 * n1 * 2:
+        raise RuntimeError("get_result: average_point / scale shapes do not match")
+    if s1.numel() == rows1 * n1 * 2:
+        stride = 2
+    elif s1.numel() == rows1 * 2:
+        stride = 0
+    else:
+        raise RuntimeError("get_result: scale[1] must be [K,n1,2] or [K,2]")
+    c0, c1 = _as_flags(left_choice[0], "left_choice[0]"), _as_flags(left_choice[1], "left_choice[1]")
+    if c0.numel() != bs or c1.numel() != rows1:
+        raise RuntimeError("get_result: left_choice shapes do not match")
+    if validate and int((f0 == 0).sum()) != rows1:
+        raise IndexError("get_result: %d surviving level-0 cells but %d level-1 rows" % (int((f0 == 0).sum()), rows1))
+    dev = a0.device
+    cap = rows1 * n1
+    ml = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    mr = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+    nws = _L().pats_get_result_workspace_bytes(bs * n0, rows1, n1)
+    ws = _workspace(nws, dev)
+    ps0, ps1 = (ctypes.c_int * 3)(*z0), (ctypes.c_int * 3)(*z1)
+    _check(_L().pats_get_result_f32(bs, _ptr(f0), _ptr(f1), rows1, _ptr(a0), _ptr(a1), _ptr(s0), _ptr(s1), stride, ps0, ps1,
+                                    _ptr(c0), _ptr(c1), _ptr(ml), _ptr(mr), cap, _ptr(cnt), _ptr(ws), nws, _stream()),
+           "get_result")
+    M = int(cnt.item())
+    return ml[:M], mr[:M]

@@ -423,3 +423,106 @@ def test_roofline_config_4096_properties(ops):
     Z = ops.cost_ot(cu(inp["d0"]), cu(inp["d1"]), 1, float(inp["alpha"]), cu(inp["ns"]), 200)
     assert Z.shape == (1, 4097, 4097) and torch.isfinite(Z).all()
     _check_marginals(Z, cu(inp["ns"]), 4096.0)
+
+
+# ---- merge, third-level inputs, result scatter, get_result ---------------------
+@pytest.mark.parametrize("name", ["merge_new.npz", "merge_old.npz", "merge_new_portrait.npz"])
+def test_merge_patches_golden(ops, name):
+    """second_layer.py:137-238 over three successive chunks with the scores_back hand-over; bit-exact."""
+    g = golden(name)
+    inp = synth.merge_inputs(seed=int(g["seed"]), h=int(g["h"]), w=int(g["w"]))
+    new, h, w = bool(g["merge_new"]), inp["h"], inp["w"]
+    fn = ops.merge_patches_new if new else ops.merge_patches_old
+    sb = torch.zeros((1, h * w, 16, 9), dtype=torch.float64, device="cuda")
+    for c, ch in enumerate(inp["chunks"]):
+        tr, f2, l1 = cu(ch["trust"]), cu(ch["ifn2"]), cu(ch["ifn_L1"])
+        sb_arg = sb
+        out, sb = fn(tr.shape[0], tr, (h * 32, w * 32), l1, f2, sb_arg)
+        assert np.array_equal(out.cpu().numpy(), g["out%d" % c])
+        assert np.array_equal(tr.cpu().numpy(), g["trust%d" % c])            # in-place like the reference
+        assert np.array_equal(f2.cpu().numpy(), g["ifn2_%d" % c])
+        assert np.array_equal(sb_arg.cpu().numpy().astype(np.float32), g["sb_written%d" % c])
+        assert bool((sb == 0).all().item()) == bool(g["sb_returned_zero%d" % c])
+
+
+@pytest.mark.parametrize("new", [True, False])
+def test_merge_patches_large_and_batched(ops, oracle, new):
+    """YFCC-sized grid (24x32) and a batch of two images against the oracle."""
+    fn = ops.merge_patches_new if new else ops.merge_patches_old
+    for seed, h, w, bt in ((31, 24, 32, 1), (32, 6, 7, 2)):
+        rng = np.random.default_rng(seed)
+        l1 = rng.random((bt, h * w)) < 0.3
+        B = int((~l1).sum())
+        trust = rng.lognormal(-1.0, 0.9, (B, 144)).astype(np.float32)
+        trust[::3] = np.round(trust[::3] * 4) / 4
+        f2 = rng.random((B, 144)) < 0.3
+        sb0 = np.where(rng.random((bt, h * w, 16, 9)) < 0.5, 0.0, np.round(rng.normal(0, 1, (bt, h * w, 16, 9)), 1) - 5000.0)
+        want, wt, wf2, wsb = oracle.merge_patches(new, trust, (h * 32, w * 32), l1, f2, sb0)
+        tr, ff, sb = cu(trust), cu(f2), cu(sb0)
+        out, _ = fn(B, tr, (h * 32, w * 32), cu(l1), ff, sb)
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert np.array_equal(tr.cpu().numpy(), wt) and np.array_equal(ff.cpu().numpy(), wf2)
+        assert np.array_equal(sb.cpu().numpy(), wsb)
+        assert 0 < (~want).sum()
+
+
+def test_merge_patches_row_count_mismatch_raises(ops):
+    inp = synth.merge_inputs()
+    ch = inp["chunks"][0]
+    sb = torch.zeros((1, 300, 16, 9), dtype=torch.float64, device="cuda")
+    with pytest.raises(IndexError):
+        ops.merge_patches_new(ch["trust"].shape[0] - 1, cu(ch["trust"][:-1]), (480, 640), cu(ch["ifn_L1"]),
+                              cu(ch["ifn2"][:-1]), sb)
+    with pytest.raises(RuntimeError):                       # CPU tensors are refused, no fallback
+        ops.merge_patches_new(ch["trust"].shape[0], torch.from_numpy(ch["trust"]), (480, 640), cu(ch["ifn_L1"]),
+                              cu(ch["ifn2"]), sb)
+
+
+@pytest.mark.parametrize("name", ["result.npz", "result_mixed.npz"])
+def test_third_inputs_scatter_get_result_golden(ops, name):
+    """pats.py:53-78 + utils.py:189-213 against the reference's outputs; bit-exact."""
+    g = golden(name)
+    inp = synth.result_inputs(seed=int(g["seed"]), h=5, w=6, mixed_choice=bool(g["mixed"]))
+    mk0, mk1, b_ids = ops.third_inputs(cu(inp["ifn2"]), cu(inp["pts"]))
+    assert np.array_equal(mk0.cpu().numpy(), g["mk0"]) and np.array_equal(mk1.cpu().numpy(), g["mk1"])
+    assert np.array_equal(b_ids.cpu().numpy(), g["b_ids"])
+    label = torch.zeros((inp["label0"].shape[0], 2), device="cuda")
+    label[:, 0] = cu(inp["label0"])
+    f16, p16 = ops.refine_scatter(cu(inp["ifn2"]), cu(inp["pts"]), cu(inp["mkpts1"]), label)
+    assert np.array_equal(f16.cpu().numpy(), g["ifn16"]) and np.array_equal(p16.cpu().numpy(), g["pts16"])
+    ifn0, sc0 = cu(inp["ifn0"]), cu(inp["sc0"])
+    sc_rows = sc0.reshape(-1, 30, 2)[torch.logical_not(ifn0)]                  # [K,2]
+    args = (1, [ifn0, f16], [cu(inp["ap0"]), p16.flip(dims=[2]) / 2.0])
+    tail = ([[32, 5, 6], [2, 48, 48]], [cu(inp["choice0"]), cu(inp["choice1"])])
+    ml, mr = ops.get_result(*args, [sc0, sc_rows.reshape(-1, 1, 2).repeat(1, 2304, 1)], *tail)   # as pats.py:70 builds it
+    assert np.array_equal(ml.cpu().numpy(), g["matches_l"]) and np.array_equal(mr.cpu().numpy(), g["matches_r"])
+    ml2, mr2 = ops.get_result(*args, [sc0, sc_rows], *tail)                    # one scale per row, not materialised
+    assert torch.equal(ml2, ml) and torch.equal(mr2, mr)
+
+
+def test_result_chain_full_size(ops, oracle):
+    """The 640x480 case (15x20 coarse cells, ~255 L2 rows, ~5e5 sub-cells) against the oracle, plus the
+    size-independent property: every emitted match comes from a surviving sub-cell, in order."""
+    inp = synth.result_inputs(seed=99, h=15, w=20, mixed_choice=True)
+    mk0, mk1, b_ids = ops.third_inputs(cu(inp["ifn2"]), cu(inp["pts"]))
+    w0, w1, wb = oracle.third_inputs(inp["ifn2"], inp["pts"])
+    assert np.array_equal(mk0.cpu().numpy(), w0) and np.array_equal(mk1.cpu().numpy(), w1)
+    assert np.array_equal(b_ids.cpu().numpy(), wb)
+    f16, p16 = ops.refine_scatter(cu(inp["ifn2"]), cu(inp["pts"]), cu(inp["mkpts1"]), cu(inp["label0"]))
+    wf, wp = oracle.refine_scatter(inp["ifn2"], inp["pts"], inp["mkpts1"], inp["label0"])
+    assert np.array_equal(f16.cpu().numpy(), wf) and np.array_equal(p16.cpu().numpy(), wp)
+    sc_rows = inp["sc0"][~inp["ifn0"]]
+    ml, mr = ops.get_result(1, [cu(inp["ifn0"]), f16], [cu(inp["ap0"]), p16.flip(dims=[2]) / 2.0], [cu(inp["sc0"]), cu(sc_rows)],
+                            [[32, 15, 20], [2, 48, 48]], [cu(inp["choice0"]), cu(inp["choice1"])])
+    wl, wr = oracle.get_result(1, [inp["ifn0"], wf], [inp["ap0"], wp[:, :, ::-1] / np.float32(2.0)],
+                               [inp["sc0"], np.repeat(sc_rows.reshape(-1, 1, 2), 2304, 1)], [[32, 15, 20], [2, 48, 48]],
+                               [inp["choice0"], inp["choice1"]])
+    assert np.array_equal(ml.cpu().numpy(), wl) and np.array_equal(mr.cpu().numpy(), wr)
+    assert ml.shape[0] == int((~wf).sum()) > 50000
+    # nothing survives -> empty outputs, like the reference's empty boolean selections
+    none = torch.ones_like(f16)
+    ml0, mr0 = ops.get_result(1, [cu(inp["ifn0"]), none], [cu(inp["ap0"]), p16], [cu(inp["sc0"]), cu(sc_rows)],
+                              [[32, 15, 20], [2, 48, 48]], [cu(inp["choice0"]), cu(inp["choice1"])])
+    assert ml0.shape == (0, 2) and mr0.shape == (0, 2)
+    e0, e1, eb = ops.third_inputs(torch.ones((4, 144), dtype=torch.bool, device="cuda"), torch.zeros((4, 144, 2), device="cuda"))
+    assert e0.shape == (0, 2) and eb.shape == (0,)
