@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=4, help="image pairs per step per rank")
+    ap.add_argument("--pairs", type=int, default=16, help="image pairs per step per rank")
     ap.add_argument("--fill", type=int, default=60, help="third-level problems per fine problem (P = fill*B)")
     ap.add_argument("--per-chunk", action="store_true",
                     help="run the fine/third stages once per coarse chunk like the reference's loop")
