@@ -411,8 +411,12 @@ __global__ void __launch_bounds__(384)
 sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __restrict__ log_mu_in,
                    const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                    const float* __restrict__ one, int iters, float bias_k, int linear,
-                   float* __restrict__ out, unsigned long long* fallbacks) {
+                   float* __restrict__ out, unsigned long long* fallbacks, const int* __restrict__ only_if) {
     __shared__ __attribute__((aligned(16))) WgLds<N_> lds;     // 85 KB at N = 145 (static: no opt-in)
+    if (only_if) {                                  // re-solve pass after sinkhorn_blk145_kernel: flagged problems only
+        if (only_if[blockIdx.x] == 0) return;
+        if (threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1ull);
+    }
     constexpr int TH = 384, NN = N_ * N_, NP = (N_ + 3) & ~3;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool colw = __builtin_amdgcn_readfirstlane(wave) >= 3;   // wave-uniform orientation
@@ -957,7 +961,38 @@ constexpr int NF = 145;   // fine level (12 x 12 + dustbin)
 static inline bool resident_shape(int M, int N) { return (M == NT && N == NT) || (M == NF && N == NF); }
 static inline int use_linear() { return sinkhorn_mode() != PATS_SINKHORN_LOG; }
 
+namespace pats {
+int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
+                  const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
+                  hipStream_t st);     // sinkhorn_blk.hip
+}
+
+// 145 x 145: the register-block kernel solves in the linear domain and flags the problems whose
+// scalings left the guard band; sinkhorn_rc_kernel then re-solves exactly those with log-sum-exp
+// sweeps.  Without flag storage (no workspace), for iters == 0 or in forced-log mode the rc kernel
+// does everything, as before.
+static int launch_fine145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
+                          const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
+                          hipStream_t st) {
+    static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;      // A/B switch for benchmarking
+    const bool blk = use_linear() && iters > 0 && fail && !v1_only;
+    if (blk) {
+        int rc = launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, st);
+        if (rc) return rc;
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, log_mu,
+                           log_nu, nullptr, nullptr, iters, 0.f, blk ? 0 : (int)use_linear(), out,
+                           fallback_counter(), blk ? fail : nullptr);
+    else
+        hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, nullptr,
+                           nullptr, ns, one, iters, bias_k, blk ? 0 : (int)use_linear(), out, fallback_counter(),
+                           blk ? fail : nullptr);
+    return check_launch("sinkhorn_rc_kernel<145>");
+}
+
 extern "C" size_t pats_sinkhorn_workspace_bytes(int64_t batch, int M, int N) {
+    if (M == NF && N == NF) return (size_t)((batch + 63) & ~63ll) * sizeof(int);     // guard flags (optional: see launch_fine145)
     if (resident_shape(M, N)) return 0;
     return carve(nullptr, batch, M, N, false, false).bytes;
 }
@@ -983,9 +1018,8 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
         return check_launch("sinkhorn65_kernel<0,0,0>");
     }
     if (M == NF && N == NF) {
-        hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch,
-                           log_mu, log_nu, nullptr, nullptr, iters, 0.f, use_linear(), out, fallback_counter());
-        return check_launch("sinkhorn_rc_kernel<145,0>");
+        int* fail = (workspace && workspace_bytes >= pats_sinkhorn_workspace_bytes(batch, M, N)) ? (int*)workspace : nullptr;
+        return launch_fine145(0, Z, batch, log_mu, log_nu, nullptr, nullptr, iters, 0.f, out, fail, st);
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_sinkhorn_workspace_bytes(batch, M, N),
                  "sinkhorn: workspace too small");
@@ -1047,9 +1081,9 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
         return check_launch("sinkhorn65_kernel<2,0,0>");
     }
     if (m == NF && n == NF) {
-        hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, scores,
-                           batch, nullptr, nullptr, ns, one, iters, bias_k, use_linear(), Z, fallback_counter());
-        return check_launch("sinkhorn_rc_kernel<145,2>");
+        int* fail = nullptr;
+        if (workspace && workspace_bytes >= pats_ot_workspace_bytes(batch, m, n)) fail = carve(workspace, batch, m, n, true, true).fail;
+        return launch_fine145(2, scores, batch, nullptr, nullptr, ns, one, iters, bias_k, Z, fail, st);
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_ot_workspace_bytes(batch, m, n),
                  "log_optimal_transport2: workspace too small");   // shapes without a resident kernel
