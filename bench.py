@@ -202,12 +202,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # plumbing-test knobs (a 1-GPU box cannot host two RCCL ranks): PATS_BENCH_SHARE_DEVICE=1 maps every
+    # rank onto the visible devices modulo their count, PATS_BENCH_BACKEND=gloo swaps the backend.
+    # Neither is set by the driver; numbers from such a run are not bench lines.
+    if os.environ.get("PATS_BENCH_SHARE_DEVICE"):
+        local_rank %= torch.cuda.device_count()
+    backend = os.environ.get("PATS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from pats_amd import ops
 
     gen = torch.Generator(device=dev)
