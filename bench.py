@@ -106,9 +106,10 @@ def coarse_stage(ops, wl):
     scales = ops.colmass_sqrt(Z)
     trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (480, 640), 32)
     sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1)
+    sc_host = sum_cycle.to("cpu").numpy()          # the step's ONE host read: chunk plans and crop counts of all pairs
     plans = []
     for i in range(wl.pairs):
-        n, second, third = ops.split_patches(sum_cycle[i], wl.h, wl.w, 2 * wl.w)
+        n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, 2 * wl.w)
         if wl.per_chunk_imgs:
             # the reference's loop (first_layer.py:136-146): one Compute_imgs per chunk mask
             plan = []
@@ -122,9 +123,9 @@ def coarse_stage(ops, wl):
             # chunk c's patches are rows [lo, min(hi, K)) of the all-matched crop tensors (the cumsum is
             # monotone, so a chunk mask selects a contiguous run of matched patches): one gather per
             # pair, chunks are views of it (tests/test_gpu_parity.py::test_chunk_crops_are_slices)
+            K = int(sc_host[i, -1])
             nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], ifn1[i:i + 1], wl.left,
-                                                     wl.right, width=wl.w, height=wl.h)
-            K = int(nr.shape[0])
+                                                     wl.right, width=wl.w, height=wl.h, known_count=K)
             views = [(nl[lo:min(hi, K)], nr[lo:min(hi, K)]) for lo, hi in second]
             plan = [v[1].shape[0] for v in views]
         plans.append(plan)

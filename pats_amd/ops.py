@@ -290,8 +290,12 @@ def est_position_second(scores, scale_x, scale_y, image_shape, patch_scale):
 # chunk planner (host)
 # ------------------------------------------------------------------------------------------------
 def split_patches(sum_cycle, height, width, max_once_used=350):
-    """utils/utils.py:152-181.  One D->H copy of the cumsum, then host C++."""
-    sc = sum_cycle.detach().to("cpu", torch.int32).contiguous().numpy()
+    """utils/utils.py:152-181.  One D->H copy of the cumsum (none if it already is a CPU tensor /
+    numpy array, e.g. one row of a batch fetched once for many pairs), then host C++."""
+    if isinstance(sum_cycle, np.ndarray):
+        sc = np.ascontiguousarray(sum_cycle, dtype=np.int32)
+    else:
+        sc = sum_cycle.detach().to("cpu", torch.int32).contiguous().numpy()
     if sc.shape[0] != height * width:
         raise RuntimeError("split_patches: sum_cycle must have height*width entries")
     second = np.zeros((height + 1, 2), np.int64)
@@ -323,19 +327,21 @@ def tensor_resize(input_tensor, bound):
 
 
 def Compute_imgs(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num=0,
-                 output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32):
+                 output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32, known_count=None):
     """utils/utils.py:1343-1393 - same 5-tuple as the reference."""
     return Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num,
-                           output_path, if_view, margin, width, height, patch_scale)[:5]
+                           output_path, if_view, margin, width, height, patch_scale, known_count)[:5]
 
 
 def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num=0,
-                    output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32):
+                    output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32,
+                    known_count=None):
     """Compute_imgs plus the [K,5] bound tensor the reference hands to tensor_resize (utils.py:1382).
     utils/utils.py:1343-1393 for batch 1 (the reference's only mode, first_layer.py:135).
     Returns (new_left [K,96,96,3], new_right [K,96,96,3], x_scale_new [1,N,2], y_scale_new
     [1,N,2], average_new [1,N,2]).  One host read (K) sizes the outputs, as the reference's
-    boolean-mask indexing does."""
+    boolean-mask indexing does - unless the caller already knows K = number of matched patches
+    (`known_count`, e.g. the last entry of the cumsum it fetched for split_patches): then no sync."""
     if margin != 128 or patch_scale != 32:
         raise RuntimeError("Compute_imgs: margin=128 / patch_scale=32 are what the path uses")
     if left.shape[0] != 1:
@@ -357,7 +363,7 @@ def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right,
     _check(_L().pats_compute_imgs_bounds_f32(_ptr(xs), _ptr(ys), _ptr(ap), _ptr(ifn), Np, height, width,
                                              0, _ptr(bound5), _ptr(Kd), _ptr(xsn), _ptr(ysn), _ptr(avn),
                                              _stream()), "Compute_imgs(bounds)")
-    K = int(Kd.item())
+    K = int(Kd.item()) if known_count is None else int(known_count)
     new_left = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
     new_right = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
     _check(_L().pats_left_crops_f32(_ptr(leftf), H, W, _ptr(bound5), K, height, width, _ptr(new_left),
