@@ -76,6 +76,8 @@ class Workload:
         self.alpha = torch.tensor(float(c["alpha"]), device=dev)
         left, right = synth.image_pair()
         self.left, self.right = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
+        self.lefts = self.left.expand(pairs, -1, -1, -1).contiguous()       # every pair: the same synthetic image
+        self.rights = self.right.expand(pairs, -1, -1, -1).contiguous()
         # dry run of the coarse stage to learn the (deterministic) chunk plan
         self.plan = coarse_stage(ops, self)[0]
         B1 = sum(self.plan)
@@ -107,28 +109,35 @@ def coarse_stage(ops, wl):
     trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (480, 640), 32)
     sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1)
     sc_host = sum_cycle.to("cpu").numpy()          # the step's ONE host read: chunk plans and crop counts of all pairs
-    plans = []
+    plans, seconds = [], []
     for i in range(wl.pairs):
         n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, 2 * wl.w)
-        if wl.per_chunk_imgs:
-            # the reference's loop (first_layer.py:136-146): one Compute_imgs per chunk mask
+        seconds.append(second)
+    if wl.per_chunk_imgs:
+        # the reference's loop (first_layer.py:136-146): one Compute_imgs per pair and chunk mask
+        for i in range(wl.pairs):
             plan = []
-            for lo, hi in second:
+            for lo, hi in seconds[i]:
                 mask = torch.logical_or(ifn1[i:i + 1], torch.logical_or(sum_cycle[i:i + 1] <= lo,
                                                                         sum_cycle[i:i + 1] > hi))
                 nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left,
                                                          wl.right, width=wl.w, height=wl.h)
                 plan.append(int(nr.shape[0]))
-        else:
-            # chunk c's patches are rows [lo, min(hi, K)) of the all-matched crop tensors (the cumsum is
-            # monotone, so a chunk mask selects a contiguous run of matched patches): one gather per
-            # pair, chunks are views of it (tests/test_gpu_parity.py::test_chunk_crops_are_slices)
-            K = int(sc_host[i, -1])
-            nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], ifn1[i:i + 1], wl.left,
-                                                     wl.right, width=wl.w, height=wl.h, known_count=K)
-            views = [(nl[lo:min(hi, K)], nr[lo:min(hi, K)]) for lo, hi in second]
-            plan = [v[1].shape[0] for v in views]
-        plans.append(plan)
+            plans.append(plan)
+        return plans
+    # One gather for the whole step: Compute_imgs takes a batch of images (crops ordered image, patch),
+    # and chunk c of pair i is rows [off_i + lo, off_i + min(hi, K_i)) of it - the cumsum is monotone, so
+    # a chunk mask selects a contiguous run of matched patches
+    # (tests/test_gpu_parity.py::test_chunk_crops_are_slices, ::test_compute_imgs_batch_of_images).
+    counts = [int(sc_host[i, -1]) for i in range(wl.pairs)]
+    nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs, ys, pts, ifn1, wl.lefts, wl.rights, width=wl.w, height=wl.h,
+                                             known_count=counts)
+    off = 0
+    for i in range(wl.pairs):
+        K = counts[i]
+        views = [(nl[off + lo:off + min(hi, K)], nr[off + lo:off + min(hi, K)]) for lo, hi in seconds[i]]
+        plans.append([v[1].shape[0] for v in views])
+        off += K
     return plans
 
 

@@ -140,9 +140,10 @@ int pats_compute_imgs_bounds_f32(const float* x_scale, const float* y_scale,
                                  pats_stream_t stream);
 
 /* ---- a13: left crops = origin_extract on the 32-px padded left image  utils.py:1300-1318,1383
- * left [H,W,3] HWC fp32; bound5/K as produced above (row k's patch index = bound5[k,4] % 10000)
- * -> out [K,96,96,3]. K is read on the host side by the caller (max rows = K_cap). */
-int pats_left_crops_f32(const float* left, int H, int W, const int64_t* bound5, int64_t K,
+ * left [n_img,H,W,3] HWC fp32; bound5/K as produced above (row k: image bound5[k,4] / 10000, patch
+ * bound5[k,4] % 10000, the reference's `sequence`, utils.py:1374-1377) -> out [K,96,96,3].  K is read on
+ * the host side by the caller (max rows = K_cap). */
+int pats_left_crops_f32(const float* left, int n_img, int H, int W, const int64_t* bound5, int64_t K,
                         int height, int width, float* out, pats_stream_t stream);
 
 /* ---- a14: tensor_resize(input, bound)  setup/library.cpp:47-66 (module def :92-93) ----------

@@ -42,7 +42,7 @@ SIGNATURES = {
     "pats_compute_imgs_bounds_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p]),
-    "pats_left_crops_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_int, c_void_p,
+    "pats_left_crops_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_int, c_int, c_void_p,
                                     c_void_p]),
     "pats_tensor_resize_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p,
                                        c_void_p, c_void_p]),

@@ -77,10 +77,13 @@ imgs_bounds_kernel(const float* __restrict__ x_scale, const float* __restrict__ 
 
 // ---- left crops: 96x96 windows on the fixed grid of the 32-px zero-padded left image ---------
 __global__ void __launch_bounds__(288)
-left_crops_kernel(const float* __restrict__ left, int H, int W, const int64_t* __restrict__ bound5,
+left_crops_kernel(const float* __restrict__ left_all, int n_img, int H, int W, const int64_t* __restrict__ bound5,
                   int width, float* __restrict__ out) {
     const int64_t k = blockIdx.x;
-    const int patch = (int)(bound5[k * 5 + 4] % 10000);
+    const int64_t seq = bound5[k * 5 + 4];                 // img * 10000 + patch, utils.py:1374-1377
+    const int patch = (int)(seq % 10000);
+    const int64_t img = min(max(seq / 10000, (int64_t)0), (int64_t)n_img - 1);
+    const float* left = left_all + img * (int64_t)H * W * 3;
     const int r = patch / width, c = patch - r * width;
     const int t = threadIdx.x;                 // 0..287 = 96 pixels x 3 channels of one row
     const int x = t / 3;
@@ -207,13 +210,13 @@ extern "C" int pats_compute_imgs_bounds_f32(const float* x_scale, const float* y
     return check_launch("imgs_bounds_kernel");
 }
 
-extern "C" int pats_left_crops_f32(const float* left, int H, int W, const int64_t* bound5, int64_t K,
+extern "C" int pats_left_crops_f32(const float* left, int n_img, int H, int W, const int64_t* bound5, int64_t K,
                                    int height, int width, float* out, pats_stream_t stream) {
-    PATS_REQUIRE(K >= 0 && H > 0 && W > 0 && height > 0 && width > 0, "left_crops: bad shape");
+    PATS_REQUIRE(K >= 0 && n_img > 0 && H > 0 && W > 0 && height > 0 && width > 0, "left_crops: bad shape");
     if (K == 0) return PATS_OK;
     PATS_REQUIRE(left && bound5 && out, "left_crops: null pointer");
     hipLaunchKernelGGL(left_crops_kernel, dim3((unsigned)K, 12), dim3(288), 0, as_stream(stream),
-                       left, H, W, bound5, width, out);
+                       left, n_img, H, W, bound5, width, out);
     return check_launch("left_crops_kernel");
 }
 

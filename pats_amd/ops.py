@@ -337,38 +337,44 @@ def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right,
                     output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32,
                     known_count=None):
     """Compute_imgs plus the [K,5] bound tensor the reference hands to tensor_resize (utils.py:1382).
-    utils/utils.py:1343-1393 for batch 1 (the reference's only mode, first_layer.py:135).
+    utils/utils.py:1343-1393, any batch of images (PATS.forward uses 1, first_layer.py:135; a batch
+    yields the crops of all images in (image, patch) order - `sequence = img * 10000 + patch`, :1374-1377).
     Returns (new_left [K,96,96,3], new_right [K,96,96,3], x_scale_new [1,N,2], y_scale_new
     [1,N,2], average_new [1,N,2]).  One host read (K) sizes the outputs, as the reference's
     boolean-mask indexing does - unless the caller already knows K = number of matched patches
     (`known_count`, e.g. the last entry of the cumsum it fetched for split_patches): then no sync."""
     if margin != 128 or patch_scale != 32:
         raise RuntimeError("Compute_imgs: margin=128 / patch_scale=32 are what the path uses")
-    if left.shape[0] != 1:
-        raise RuntimeError("Compute_imgs: batch 1 only (as PATS.forward, first_layer.py:135)")
+    nb = left.shape[0]                          # images in the batch; crops come out ordered (image, patch)
     dev = x_scale.device
     Np = width * height
-    xs = _dev(x_scale.float(), "x_scale").reshape(-1)
-    ys = _dev(y_scale.float(), "y_scale").reshape(-1)
-    ap = _dev(average_point.float(), "average_point").reshape(-1, 2)
-    ifn = _dev(if_nomatching.to(torch.uint8), "if_nomatching", torch.uint8).reshape(-1)
+    xs = _dev(x_scale.float(), "x_scale").reshape(nb, Np)
+    ys = _dev(y_scale.float(), "y_scale").reshape(nb, Np)
+    ap = _dev(average_point.float(), "average_point").reshape(nb, Np, 2)
+    ifn = _dev(if_nomatching.to(torch.uint8), "if_nomatching", torch.uint8).reshape(nb, Np)
     leftf = _dev(left.float(), "left")
     rightf = _dev(right.float(), "right")
     H, W = leftf.shape[1], leftf.shape[2]
-    bound5 = torch.empty((Np, 5), dtype=torch.int64, device=dev)
-    Kd = torch.empty((1,), dtype=torch.int64, device=dev)
-    xsn = torch.empty((1, Np, 2), dtype=torch.float32, device=dev)
-    ysn = torch.empty((1, Np, 2), dtype=torch.float32, device=dev)
-    avn = torch.empty((1, Np, 2), dtype=torch.float32, device=dev)
-    _check(_L().pats_compute_imgs_bounds_f32(_ptr(xs), _ptr(ys), _ptr(ap), _ptr(ifn), Np, height, width,
-                                             0, _ptr(bound5), _ptr(Kd), _ptr(xsn), _ptr(ysn), _ptr(avn),
-                                             _stream()), "Compute_imgs(bounds)")
-    K = int(Kd.item()) if known_count is None else int(known_count)
+    if known_count is not None:
+        counts = [int(known_count)] if nb == 1 and not hasattr(known_count, "__len__") else [int(k) for k in known_count]
+        if len(counts) != nb:
+            raise RuntimeError("Compute_imgs: known_count needs one entry per image")
+    bound5 = torch.empty((nb * Np, 5), dtype=torch.int64, device=dev)
+    Kd = torch.empty((nb,), dtype=torch.int64, device=dev)
+    xsn = torch.empty((nb, Np, 2), dtype=torch.float32, device=dev)
+    ysn = torch.empty((nb, Np, 2), dtype=torch.float32, device=dev)
+    avn = torch.empty((nb, Np, 2), dtype=torch.float32, device=dev)
+    K = 0
+    for i in range(nb):                         # compacted bounds of image i start where image i-1's ended
+        _check(_L().pats_compute_imgs_bounds_f32(_ptr(xs[i]), _ptr(ys[i]), _ptr(ap[i]), _ptr(ifn[i]), Np, height, width,
+                                                 i, _ptr(bound5[K:]), _ptr(Kd[i:]), _ptr(xsn[i]), _ptr(ysn[i]),
+                                                 _ptr(avn[i]), _stream()), "Compute_imgs(bounds)")
+        K += int(Kd[i].item()) if known_count is None else counts[i]
     new_left = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
     new_right = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
-    _check(_L().pats_left_crops_f32(_ptr(leftf), H, W, _ptr(bound5), K, height, width, _ptr(new_left),
+    _check(_L().pats_left_crops_f32(_ptr(leftf), nb, H, W, _ptr(bound5), K, height, width, _ptr(new_left),
                                     _stream()), "Compute_imgs(left)")
-    _check(_L().pats_tensor_resize_hwc_f32(_ptr(rightf), 1, H, W, margin, _ptr(bound5), K,
+    _check(_L().pats_tensor_resize_hwc_f32(_ptr(rightf), nb, H, W, margin, _ptr(bound5), K,
                                            _ptr(new_right), ctypes.c_void_p(0), _stream()),
            "Compute_imgs(right)")
     new_left = new_left.to(left.dtype) if left.dtype != torch.float32 else new_left

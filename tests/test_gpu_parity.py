@@ -205,6 +205,29 @@ def test_chunk_crops_are_slices(ops):
         assert torch.equal(cr, nr[lo:min(hi, K)]) and torch.equal(cl, nl[lo:min(hi, K)])
 
 
+def test_compute_imgs_batch_of_images(ops):
+    """utils.py:1343-1393 with a batch of two images equals the two single-image calls concatenated
+    (checked against the reference itself when this test was written: sequence = img * 10000 + patch),
+    with or without the caller supplying the crop counts."""
+    g = golden("coarse_301.npz")
+    left, right = synth.image_pair()
+    L, R = cu(left), cu(right)
+    xs, ys, pts, ifn = cu(g["x_scale"]), cu(g["y_scale"]), cu(g["average_point"]), cu(g["ifn1"])
+    ifn_b = ifn.clone()
+    ifn_b[0, ::7] = True
+    xs2, ys2, pts2 = torch.cat([xs, xs * 0.9]), torch.cat([ys, ys * 1.1]), torch.cat([pts, pts])
+    ifn2, L2, R2 = torch.cat([ifn, ifn_b]), torch.cat([L, L.flip(2)]), torch.cat([R, R.flip(1)])
+    both = ops.Compute_imgs(xs2, ys2, pts2, ifn2, L2, R2, width=20, height=15)
+    a = ops.Compute_imgs(xs2[:1], ys2[:1], pts2[:1], ifn2[:1], L2[:1], R2[:1], width=20, height=15)
+    b = ops.Compute_imgs(xs2[1:], ys2[1:], pts2[1:], ifn2[1:], L2[1:], R2[1:], width=20, height=15)
+    for k in range(5):
+        assert torch.equal(both[k], torch.cat([a[k], b[k]]))
+    counts = [int((~ifn2[0]).sum()), int((~ifn2[1]).sum())]
+    known = ops.Compute_imgs(xs2, ys2, pts2, ifn2, L2, R2, width=20, height=15, known_count=counts)
+    for k in range(5):
+        assert torch.equal(known[k], both[k])
+
+
 def test_tensor_resize_edges_and_empty(ops):
     import tensor_resize
     g = golden("resize_small.npz")
