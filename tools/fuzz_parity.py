@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle cross-check (GPU box).  TEST INFRASTRUCTURE: the oracle is only the checker.
+
+Draws random shapes / seeds for every op of the path and compares the C-ABI result with
+oracle/pats_oracle.c under the gates of tests/test_gpu_parity.py.  Prints one line per failing case
+(op, seed, shape) and a summary; exit code 1 if anything failed.
+usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import pats_oracle as oracle  # noqa: E402
+from pats_amd import ops  # noqa: E402
+
+MASS_TOL = 1e-4
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def mass_close(got, want):
+    eg, ew = np.exp(got.astype(np.float64)), np.exp(want.astype(np.float64))
+    np.testing.assert_allclose(eg, ew, atol=MASS_TOL, rtol=3e-6)
+    np.testing.assert_allclose(eg.sum(-1), ew.sum(-1), atol=MASS_TOL, rtol=3e-6)
+    np.testing.assert_allclose(eg.sum(-2), ew.sum(-2), atol=MASS_TOL, rtol=3e-6)
+
+
+def rand_shape(rng):
+    """OT shapes: the resident ones, their neighbours, ragged ones, a few large."""
+    pick = rng.integers(0, 10)
+    if pick == 0:
+        return 65, 65
+    if pick == 1:
+        return 145, 145
+    if pick == 2:
+        return int(rng.integers(2, 12)), int(rng.integers(2, 12))
+    if pick == 3:
+        n = int(rng.choice([64, 66, 144, 146, 301, 302]))
+        return n, n
+    if pick == 4:
+        return int(rng.integers(280, 321)), int(rng.integers(280, 321))
+    if pick == 5:
+        return int(rng.integers(330, 700)), int(rng.integers(330, 700))
+    return int(rng.integers(2, 200)), int(rng.integers(2, 200))
+
+
+def op_sinkhorn(rng):
+    M, N = rand_shape(rng)
+    b = int(rng.integers(1, 5))
+    it = int(rng.choice([1, 2, 7, 30, 100]))
+    Z = (rng.standard_normal((b, M, N)) * rng.choice([0.3, 2.0, 6.0])).astype(np.float32)
+    mu = rng.uniform(0.2, 3.0, (b, M))
+    nu = rng.uniform(0.2, 3.0, (b, N))
+    nu *= (mu.sum(1) / nu.sum(1))[:, None]
+    lm, ln = np.log(mu).astype(np.float32), np.log(nu).astype(np.float32)
+    got = ops.log_sinkhorn_iterations(cu(Z), cu(lm), cu(ln), it).cpu().numpy()
+    mass_close(got, oracle.log_sinkhorn_iterations(Z, lm, ln, it))
+    return "b=%d %dx%d it=%d" % (b, M, N, it)
+
+
+def op_ot(rng):
+    m, n = rand_shape(rng)
+    b = int(rng.integers(1, 4))
+    S = (rng.standard_normal((b, m, n)) * rng.choice([0.5, 3.0])).astype(np.float32)
+    ns = np.exp(rng.uniform(-2.7, 2.7, (b, 1, n))).astype(np.float32)
+    alpha = float(rng.choice([0.0, 0.5, 1.3]))
+    got = ops.log_optimal_transport(cu(S), alpha, cu(ns), 100).cpu().numpy()
+    mass_close(got, oracle.log_optimal_transport(S, alpha, ns, 100))
+    return "b=%d %dx%d alpha=%g" % (b, m, n, alpha)
+
+
+def op_ot2(rng):
+    m, n = rand_shape(rng)
+    m, n = max(m, 3), max(n, 3)
+    b = int(rng.integers(1, 6))
+    S = (rng.standard_normal((b, m, n)) * rng.choice([0.5, 3.0])).astype(np.float32)
+    ns = np.exp(rng.uniform(-2.7, 2.7, (b, 1, n - 1))).astype(np.float32)
+    k = float(rng.choice([0.0, 2.0, 3.0]))
+    got = ops.log_optimal_transport2(cu(S), 1.0, cu(ns), 100, bias_k=k).cpu().numpy()
+    want = oracle.log_optimal_transport2(S, 1.0, ns, 100)
+    if k:
+        want = oracle.dustbin_bias(want, k)
+    mass_close(got, want)
+    return "b=%d %dx%d bias=%g" % (b, m, n, k)
+
+
+def op_cost(rng):
+    b = int(rng.integers(1, 4))
+    D = int(rng.choice([7, 32, 66, 128, 264, 448, int(rng.integers(1, 300))]))
+    n, m = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    if rng.random() < 0.3:
+        n = m = int(rng.choice([65, 145, 300, 160, 161, 320]))
+    d0 = rng.standard_normal((b, D, n)).astype(np.float32)
+    d1 = rng.standard_normal((b, D, m)).astype(np.float32)
+    got = ops.cost(cu(d0), cu(d1)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.cost(d0, d1), atol=3e-5, rtol=1e-5)
+    return "b=%d D=%d %dx%d" % (b, D, n, m)
+
+
+def op_expand(rng):
+    h, w = int(rng.integers(2, 26)), int(rng.integers(2, 34))
+    N = h * w
+    b = int(rng.integers(1, 4))
+    it = int(rng.choice([1, 8, 15]))
+    lb = float(rng.choice([1e-5, 1e-3]))
+    # a plan-like positive matrix with peaked rows (so rectangles grow) and a dustbin
+    base = rng.standard_normal((b, N + 1, N + 1)) * 2.0
+    for bi in range(b):
+        tgt = rng.integers(0, N, N)
+        base[bi, np.arange(N), tgt] += rng.uniform(3, 9, N)
+    P = np.exp(base - base.max(2, keepdims=True)).astype(np.float32)
+    P /= P.sum(2, keepdims=True).astype(np.float32)
+    sc = np.exp(rng.uniform(-1.0, 1.0, (b, N))).astype(np.float32)
+    want = oracle.iterative_expand(P, sc, sc, w, h, w, lb, it)                        # lim3 = limitation[3] = w
+    positions, ranges = ops.Compute_positions_and_ranges(h, w, "cuda")
+    got = ops.Iterative_expand_matrix(cu(P), cu(sc).reshape(b, -1, 1), cu(sc).reshape(b, -1, 1), [0, h, 0, w], ranges,
+                                      positions, lower_bound=lb, iter_num=it, width=w, height=h)
+    assert np.array_equal(got[5].cpu().numpy(), want[5]), "bounds differ"
+    np.testing.assert_allclose(got[0].cpu().numpy(), want[0], atol=3e-6, rtol=5e-5)
+    np.testing.assert_allclose(got[2].cpu().numpy(), want[2], atol=2e-4, rtol=2e-5)
+    np.testing.assert_allclose(got[3].cpu().numpy(), want[3], atol=1e-5, rtol=5e-5)
+    return "b=%d grid %dx%d it=%d lb=%g" % (b, h, w, it, lb)
+
+
+def op_resize(rng):
+    n_img, C = int(rng.integers(1, 3)), int(rng.choice([1, 3, 5]))
+    Hp, Wp = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+    K = int(rng.integers(0, 40))
+    src = (rng.random((n_img, C, Hp, Wp)) * 255).astype(np.float32)
+    y0 = rng.integers(0, Hp - 2, K)
+    x0 = rng.integers(0, Wp - 2, K)
+    y1 = np.minimum(Hp, y0 + 1 + rng.integers(0, Hp, K))
+    x1 = np.minimum(Wp - 1, x0 + rng.integers(0, Wp, K))
+    seq = rng.integers(0, n_img, K) * 10000 + rng.integers(0, 9999, K)
+    bound = np.stack([y0, y1, x0, x1, seq], 1).astype(np.int64).reshape(K, 5)
+    got = ops.tensor_resize(cu(src), cu(bound)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.tensor_resize(src, bound), atol=1e-4)
+    return "n=%d C=%d %dx%d K=%d" % (n_img, C, Hp, Wp, K)
+
+
+def op_merge(rng):
+    new = bool(rng.integers(0, 2))
+    h, w, bt = int(rng.integers(1, 26)), int(rng.integers(1, 34)), int(rng.integers(1, 3))
+    l1 = rng.random((bt, h * w)) < rng.choice([0.0, 0.3, 0.9])
+    B = int((~l1).sum())
+    if B == 0:
+        l1[0, 0] = False
+        B = 1
+    trust = rng.lognormal(-1.0, 0.9, (B, 144)).astype(np.float32)
+    if rng.random() < 0.5:
+        trust = (np.round(trust * 4) / 4).astype(np.float32)          # tie-heavy
+    f2 = rng.random((B, 144)) < rng.choice([0.1, 0.5, 0.95])
+    sb0 = np.where(rng.random((bt, h * w, 16, 9)) < 0.5, 0.0,
+                   np.round(rng.normal(0, 1, (bt, h * w, 16, 9)), 1) - rng.choice([0.0, 10000.0]))
+    want, wt, wf2, wsb = oracle.merge_patches(new, trust, (h * 32, w * 32), l1, f2, sb0)
+    tr, ff, sb = cu(trust), cu(f2), cu(sb0)
+    fn = ops.merge_patches_new if new else ops.merge_patches_old
+    out, _ = fn(B, tr, (h * 32, w * 32), cu(l1), ff, sb)
+    assert np.array_equal(out.cpu().numpy(), want), "%d flags differ" % int((out.cpu().numpy() != want).sum())
+    assert np.array_equal(tr.cpu().numpy(), wt) and np.array_equal(ff.cpu().numpy(), wf2)
+    assert np.array_equal(sb.cpu().numpy(), wsb)
+    return "%s grid %dx%d bt=%d B=%d" % ("new" if new else "old", h, w, bt, B)
+
+
+def op_result(rng):
+    h, w, bs = int(rng.integers(1, 12)), int(rng.integers(1, 12)), int(rng.integers(1, 3))
+    N = h * w
+    ifn0 = rng.random((bs, N)) < rng.choice([0.0, 0.3, 0.8])
+    if ifn0.all():
+        ifn0[0, 0] = False
+    K = int((~ifn0).sum())
+    ap0 = rng.uniform(0, [h, w], (bs, N, 2)).astype(np.float32)
+    sc0 = np.exp(rng.uniform(-1.2, 1.2, (bs, N, 2))).astype(np.float32)
+    ifn2 = rng.random((K, 144)) < rng.choice([0.2, 0.6, 1.0])
+    pts = (rng.integers(0, 97, (K, 144, 2)) / 8.0).astype(np.float32)          # many exact .5 cases for round-half-even
+    P = int((~ifn2).sum())
+    mk = rng.uniform(0, 96, (P, 16, 2)).astype(np.float32)
+    lab = np.where(rng.random((P * 16,)) < 0.3, -10.0, 1e8).astype(np.float32)
+    g0, g1, gb = ops.third_inputs(cu(ifn2), cu(pts))
+    w0, w1, wb = oracle.third_inputs(ifn2, pts)
+    assert np.array_equal(g0.cpu().numpy(), w0) and np.array_equal(g1.cpu().numpy(), w1) and np.array_equal(gb.cpu().numpy(), wb)
+    f16, p16 = ops.refine_scatter(cu(ifn2), cu(pts), cu(mk), cu(lab))
+    wf, wp = oracle.refine_scatter(ifn2, pts, mk, lab)
+    assert np.array_equal(f16.cpu().numpy(), wf) and np.array_equal(p16.cpu().numpy(), wp)
+    ch0, ch1 = rng.random((bs,)) < 0.7, rng.random((K,)) < 0.7
+    sc_rows = sc0[~ifn0]
+    ml, mr = ops.get_result(bs, [cu(ifn0), f16], [cu(ap0), p16.flip(dims=[2]) / 2.0], [cu(sc0), cu(sc_rows)],
+                            [[32, h, w], [2, 48, 48]], [cu(ch0), cu(ch1)])
+    wl, wr = oracle.get_result(bs, [ifn0, wf], [ap0, wp[:, :, ::-1] / np.float32(2.0)],
+                               [sc0, np.repeat(sc_rows.reshape(-1, 1, 2), 2304, 1)], [[32, h, w], [2, 48, 48]], [ch0, ch1])
+    assert np.array_equal(ml.cpu().numpy(), wl) and np.array_equal(mr.cpu().numpy(), wr)
+    return "grid %dx%d bs=%d K=%d P=%d M=%d" % (h, w, bs, K, P, wl.shape[0])
+
+
+def op_third(rng):
+    P = int(rng.integers(1, 200))
+    D = int(rng.choice([32, 64, 128, 256]))
+    outdoor = bool(rng.integers(0, 2))
+    base = rng.standard_normal((P, D, 65)).astype(np.float32)
+    amp = float(rng.choice([1.0, 3.0]))
+    d0 = (amp * (base + 0.3 * rng.standard_normal((P, D, 65)))).astype(np.float32)
+    d1 = (amp * (base + 0.3 * rng.standard_normal((P, D, 65)))).astype(np.float32)
+    scale = np.exp(rng.uniform(-2.7, 2.7, (P, 1, 64))).astype(np.float32)
+    ps = (rng.integers(1, 23, (P, 2)) * 4).astype(np.int64)
+    pt = (rng.integers(0, 25, (P, 2)) * 4).astype(np.int64)
+    m0, m1, label, ifm = ops.third_level(cu(d0), cu(d1), cu(scale), cu(ps), cu(pt), outdoor=outdoor)
+    Zr = oracle.log_optimal_transport2(oracle.cost(d0, d1), 1.0, scale, 100)
+    sq = np.sqrt(scale + np.float32(1e-8)).astype(np.float32)
+    r0, r1, rwl, rlabel, rifm = oracle.compute_result(np.exp(Zr), sq, sq, ps, pt, outdoor)
+    assert np.array_equal(m0.cpu().numpy(), r0)
+    # argmax ties between near-equal plan entries may legitimately flip under 1e-6 relative noise: compare
+    # positions only where the oracle's top two entries of a centre row are separated
+    S = np.exp(Zr)[:, :-1, :].reshape(P, 8, 8, 65)[:, 2:6, 2:6, :].reshape(P, 16, 65)
+    top2 = np.sort(S[:, :, :64], axis=2)[:, :, -2:]
+    clear = (top2[:, :, 1] - top2[:, :, 0]) > 1e-4 * top2[:, :, 1]
+    d = np.abs(m1.cpu().numpy() - r1).max(2)
+    assert (d[clear] <= 2e-3).all(), "mkpts1 differs by %g" % d[clear].max()
+    topd = np.sort(S, axis=2)[:, :, -2:]
+    cleard = (topd[:, :, 1] - topd[:, :, 0]) > 1e-4 * topd[:, :, 1]
+    assert np.array_equal(ifm.cpu().numpy().astype(bool)[cleard], rifm[cleard])
+    return "P=%d D=%d outdoor=%d" % (P, D, outdoor)
+
+
+OPS = {"sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
+       "resize": op_resize, "merge": op_merge, "result": op_result, "third": op_third}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ops", default=",".join(OPS))
+    ap.add_argument("--mode", default="auto", choices=["auto", "log", "kernel"])
+    args = ap.parse_args()
+    ops.set_sinkhorn_mode(args.mode)
+    names = args.ops.split(",")
+    t_end = time.time() + args.seconds
+    fails, runs = 0, {n: 0 for n in names}
+    case = 0
+    while time.time() < t_end:
+        for n in names:
+            seed = args.seed * 1000003 + case
+            rng = np.random.default_rng(seed)
+            try:
+                OPS[n](rng)
+            except Exception as e:   # noqa: BLE001
+                fails += 1
+                desc = str(e).strip().split("\n")
+                print("FAIL %-8s seed=%d : %s" % (n, seed, " | ".join(x.strip() for x in desc[:4])[:300]), flush=True)
+            runs[n] += 1
+            case += 1
+    print("fuzz: %d cases, %d failures; per op %s; guard fallbacks %d" % (case, fails, runs, ops.sinkhorn_fallbacks()))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
