@@ -256,6 +256,15 @@ int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uin
                         const uint8_t* left_choice1, float* matches_l, float* matches_r, int64_t capacity,
                         int64_t* count, void* workspace, size_t workspace_bytes, pats_stream_t stream);
 
+/* attention(query, key, value) of the GNN layers (reference models/modules.py:84-88; the core of
+ * MultiHeadedAttention.forward :100-105): scores = q^T k / dim**.5 per (batch, head), softmax over the
+ * keys, out = prob v.  query [batch,dim,heads,n], key / value [batch,dim,heads,m] (the view
+ * modules.py:101-102 makes of the projections) -> out [batch,dim,heads,n]; prob [batch,heads,n,m] is
+ * written only if non-null (the reference returns it, its caller discards it).  fp32 throughout; the
+ * score matrix stays in LDS.  m <= 640 (PATS_ERR_UNSUPPORTED beyond). */
+int pats_attention_f32(const float* query, const float* key, const float* value, int64_t batch, int dim,
+                       int heads, int n, int m, float* out, float* prob, pats_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

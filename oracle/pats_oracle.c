@@ -994,3 +994,51 @@ int64_t oracle_get_result(int bs, const uint8_t* ifn0, const uint8_t* ifn1, cons
         }
     return M;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * f4  attention(query, key, value), models/modules.py:84-88 (the core of MultiHeadedAttention,
+ * :100-105, inside AttentionalGNN):
+ *     scores = einsum('bdhn,bdhm->bhnm', query, key) / dim**.5
+ *     prob   = softmax(scores, dim=-1)
+ *     out    = einsum('bhnm,bdhm->bdhn', prob, value)
+ * query [b,dim,heads,n], key / value [b,dim,heads,m] -> out [b,dim,heads,n], prob [b,heads,n,m]
+ * (prob may be NULL).  Dot products and the softmax denominator accumulate in double and round once
+ * (ATen leaves their order unspecified); exp / divide are fp32 like ATen's softmax.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_attention(const float* q, const float* k, const float* v, int64_t b, int dim, int heads, int n,
+                      int m, float* out, float* prob) {
+    const float sq = (float)sqrt((double)dim);
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int h = 0; h < heads; ++h) {
+            float* row = (float*)malloc(sizeof(float) * (size_t)m);
+            double* acc = (double*)malloc(sizeof(double) * (size_t)dim);
+            for (int i = 0; i < n; ++i) {
+                float mx = -INFINITY;
+                for (int j = 0; j < m; ++j) {
+                    double s = 0.0;
+                    for (int d = 0; d < dim; ++d)
+                        s += (double)q[((bi * dim + d) * heads + h) * (int64_t)n + i] *
+                             (double)k[((bi * dim + d) * heads + h) * (int64_t)m + j];
+                    row[j] = (float)s / sq;
+                    if (row[j] > mx) mx = row[j];
+                }
+                double den = 0.0;
+                for (int j = 0; j < m; ++j) {
+                    row[j] = expf(row[j] - mx);
+                    den += (double)row[j];
+                }
+                const float fden = (float)den;
+                for (int d = 0; d < dim; ++d) acc[d] = 0.0;
+                for (int j = 0; j < m; ++j) {
+                    row[j] = row[j] / fden;
+                    if (prob) prob[((bi * heads + h) * (int64_t)n + i) * m + j] = row[j];
+                    for (int d = 0; d < dim; ++d)
+                        acc[d] += (double)row[j] * (double)v[((bi * dim + d) * heads + h) * (int64_t)m + j];
+                }
+                for (int d = 0; d < dim; ++d) out[((bi * dim + d) * heads + h) * (int64_t)n + i] = (float)acc[d];
+            }
+            free(row);
+            free(acc);
+        }
+}

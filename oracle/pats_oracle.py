@@ -309,3 +309,17 @@ def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left
     M = lib().oracle_get_result(int(batch_size), _p(f0, c_u8), _p(f1, c_u8), pa0, pa1, ps0, ps1, _p(z0, c_i32),
                                 _p(z1, c_i32), _p(c0, c_u8), _p(c1, c_u8), _p(ml, c_f), _p(mr, c_f))
     return ml[:M].copy(), mr[:M].copy()
+
+
+def attention(query, key, value, with_prob=True):
+    """modules.py:84-88: (out [b,dim,heads,n], prob [b,heads,n,m])."""
+    q, pq = _f(query)
+    k, pk = _f(key)
+    v, pv = _f(value)
+    b, dim, heads, n = q.shape
+    m = k.shape[3]
+    out = np.empty((b, dim, heads, n), np.float32)
+    prob = np.empty((b, heads, n, m), np.float32) if with_prob else None
+    lib().oracle_attention(pq, pk, pv, ctypes.c_int64(b), dim, heads, n, m, _p(out, c_f),
+                           _p(prob, c_f) if with_prob else None)
+    return out, prob

@@ -623,3 +623,19 @@ def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left
            "get_result")
     M = int(cnt.item())
     return ml[:M], mr[:M]
+
+
+def attention(query, key, value, return_prob=True):
+    """models/modules.py:84-88: returns (x [b,dim,heads,n], prob [b,heads,n,m]) like the reference;
+    return_prob=False skips materialising prob (MultiHeadedAttention discards it, :103) and returns
+    (x, None)."""
+    q, k, v = _dev(query, "query"), _dev(key, "key"), _dev(value, "value")
+    if q.dim() != 4 or k.dim() != 4 or v.shape != k.shape or k.shape[:3] != q.shape[:3]:
+        raise RuntimeError("attention: query [b,dim,heads,n], key/value [b,dim,heads,m]")
+    b, dim, heads, n = q.shape
+    m = k.shape[3]
+    out = torch.empty((b, dim, heads, n), dtype=torch.float32, device=q.device)
+    prob = torch.empty((b, heads, n, m), dtype=torch.float32, device=q.device) if return_prob else None
+    _check(_L().pats_attention_f32(_ptr(q), _ptr(k), _ptr(v), b, dim, heads, n, m, _ptr(out), _ptr(prob), _stream()),
+           "attention")
+    return out, prob

@@ -179,3 +179,14 @@ def result_inputs(seed=SEED + 8, h=15, w=20, bs=1, mixed_choice=False):
         ch1 = rng.random((K,)) < 0.5
     return {"h": h, "w": w, "ifn0": ifn0, "ap0": ap0, "sc0": sc0, "ifn2": ifn2, "pts": pts, "mkpts1": mkpts1,
             "label0": label0, "choice0": ch0, "choice1": ch1}
+
+
+def attention_inputs(seed=SEED + 12, b=3, dim=32, heads=4, n=65, m=None, amp=1.0):
+    """q, k, v of modules.py:84 ([b, dim, heads, tokens], the view MultiHeadedAttention makes of its
+    projections, :101-102).  amp scales q and k: larger values give peaked softmax rows."""
+    rng = np.random.default_rng(seed)
+    m = n if m is None else m
+    q = (amp * rng.standard_normal((b, dim, heads, n))).astype(np.float32)
+    k = (amp * rng.standard_normal((b, dim, heads, m))).astype(np.float32)
+    v = rng.standard_normal((b, dim, heads, m)).astype(np.float32)
+    return {"q": q, "k": k, "v": v}

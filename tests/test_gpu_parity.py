@@ -560,3 +560,42 @@ def test_fuzz_slice(ops, oracle, op):
     import fuzz_parity
     for case in range(6):
         fuzz_parity.OPS[op](np.random.default_rng(777000 + 31 * case + len(op)))
+
+
+# ---- attention(query, key, value), modules.py:84-88 ----------------------
+def test_attention_golden(ops):
+    g = golden("attention.npz")
+    cases = [dict(b=3, dim=32, heads=4, n=65), dict(b=2, dim=66, heads=4, n=145, amp=1.5),
+             dict(b=1, dim=112, heads=4, n=300), dict(b=2, dim=6, heads=2, n=37, m=53, amp=2.0)]
+    for c, kw in enumerate(cases):
+        inp = synth.attention_inputs(seed=synth.SEED + 12 + c, **kw)
+        x, prob = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]))
+        x, prob = x.cpu().numpy(), prob.cpu().numpy()
+        np.testing.assert_allclose(x.reshape(-1)[g["x_idx%d" % c]], g["x_val%d" % c], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(prob.reshape(-1)[g["p_idx%d" % c]], g["p_val%d" % c], atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(prob.sum(-1), g["p_rowsum%d" % c], atol=2e-6)
+        x2, none = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]), return_prob=False)
+        assert none is None and np.array_equal(x2.cpu().numpy(), x)
+
+
+def test_attention_shapes_against_oracle(ops, oracle):
+    """Ragged and degenerate shapes (one query, one key, odd dim, n != m), peaked softmax rows, the
+    third-level batch size, and the properties rows-sum-to-1 / convex combination of the values."""
+    for seed, kw in enumerate([dict(b=2, dim=7, heads=3, n=1, m=1), dict(b=1, dim=5, heads=1, n=33, m=2),
+                               dict(b=2, dim=32, heads=4, n=64, m=96, amp=4.0), dict(b=1, dim=128, heads=2, n=200, m=640),
+                               dict(b=300, dim=32, heads=4, n=65)]):
+        inp = synth.attention_inputs(seed=500 + seed, **kw)
+        x, prob = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]))
+        wx, wp = oracle.attention(inp["q"], inp["k"], inp["v"])
+        np.testing.assert_allclose(x.cpu().numpy(), wx, atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(prob.cpu().numpy(), wp, atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(prob.sum(-1).cpu().numpy(), 1.0, atol=2e-6)
+        vmin = cu(inp["v"]).amin(dim=3, keepdim=True)
+        vmax = cu(inp["v"]).amax(dim=3, keepdim=True)
+        assert bool(((x >= vmin - 1e-5) & (x <= vmax + 1e-5)).all())
+    e, _ = ops.attention(torch.zeros((0, 32, 4, 65), device="cuda"), torch.zeros((0, 32, 4, 65), device="cuda"),
+                         torch.zeros((0, 32, 4, 65), device="cuda"))
+    assert e.shape == (0, 32, 4, 65)
+    with pytest.raises(RuntimeError):
+        ops.attention(torch.zeros((1, 8, 2, 4), device="cuda"), torch.zeros((1, 8, 2, 700), device="cuda"),
+                      torch.zeros((1, 8, 2, 700), device="cuda"))

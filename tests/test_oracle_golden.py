@@ -287,3 +287,20 @@ def test_third_inputs_scatter_and_get_result(oracle, name):
                                [inp["sc0"], sc1], [[32, 5, 6], [2, 48, 48]], [inp["choice0"], inp["choice1"]])
     assert np.array_equal(ml, g["matches_l"]) and np.array_equal(mr, g["matches_r"])
     assert ml.shape[0] > 1000
+
+
+def test_attention(oracle):
+    """modules.py:84-88 at the path's three token counts and a ragged case (fp32: 1e-5 on the output,
+    2e-6 on probabilities, rows of prob sum to 1)."""
+    import sys as _s, os as _o
+    _s.path.insert(0, _o.path.join(_o.path.dirname(_o.path.dirname(_o.path.abspath(__file__))), "tools"))
+    g = golden("attention.npz")
+    cases = [dict(b=3, dim=32, heads=4, n=65), dict(b=2, dim=66, heads=4, n=145, amp=1.5),
+             dict(b=1, dim=112, heads=4, n=300), dict(b=2, dim=6, heads=2, n=37, m=53, amp=2.0)]
+    for c, kw in enumerate(cases):
+        inp = synth.attention_inputs(seed=synth.SEED + 12 + c, **kw)
+        assert synth.checksum(inp["q"], inp["k"], inp["v"]) == float(g["in_checksum%d" % c])
+        x, prob = oracle.attention(inp["q"], inp["k"], inp["v"])
+        np.testing.assert_allclose(x.reshape(-1)[g["x_idx%d" % c]], g["x_val%d" % c], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(prob.reshape(-1)[g["p_idx%d" % c]], g["p_val%d" % c], atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(prob.sum(-1), g["p_rowsum%d" % c], atol=2e-6)

@@ -24,6 +24,7 @@ What each fixture pins (reference file:line):
   resize_small.npz tensor_resize edge cases (1-pixel crops, borders) (setup/library.cpp:47-66)
   merge_new.npz / merge_old.npz / merge_new_portrait.npz   merge_patches_new / _old over three
                    successive chunks incl. the scores_back hand-over (second_layer.py:137-238)
+  attention.npz    attention(query, key, value) of the GNN layers (models/modules.py:84-88)
   result.npz / result_mixed.npz   third-level inputs, result scatter and get_result
                    (pats.py:53-78, utils/utils.py:189-213); _mixed flips left_choice per row
 """
@@ -376,6 +377,25 @@ def gen_result(R, name, seed, mixed):
          in_checksum=synth.checksum(inp["ap0"], inp["sc0"], inp["pts"], inp["mkpts1"], inp["label0"]))
 
 
+ATTENTION_CASES = [dict(b=3, dim=32, heads=4, n=65), dict(b=2, dim=66, heads=4, n=145, amp=1.5),
+                   dict(b=1, dim=112, heads=4, n=300), dict(b=2, dim=6, heads=2, n=37, m=53, amp=2.0)]
+
+
+def gen_attention(R):
+    """modules.py:84-88 at the three token counts of the path (65 / 145 / 300) and a ragged n != m case;
+    outputs sampled (4096 entries each) plus the softmax row sums."""
+    arrs = {}
+    for c, kw in enumerate(ATTENTION_CASES):
+        inp = synth.attention_inputs(seed=synth.SEED + 12 + c, **kw)
+        x, prob = R.M.attention(T(inp["q"]), T(inp["k"]), T(inp["v"]))
+        rng = np.random.default_rng(40 + c)
+        xi, pi = sample_idx(rng, x.shape, 4096), sample_idx(rng, prob.shape, 4096)
+        arrs.update({"x_idx%d" % c: xi, "x_val%d" % c: x.reshape(-1)[T(xi)], "p_idx%d" % c: pi,
+                     "p_val%d" % c: prob.reshape(-1)[T(pi)], "p_rowsum%d" % c: prob.sum(-1),
+                     "in_checksum%d" % c: synth.checksum(inp["q"], inp["k"], inp["v"])})
+    save("attention.npz", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -401,6 +421,7 @@ def main():
     gen_merge(R, "merge_new_portrait.npz", True, synth.SEED + 10, h=20, w=15)
     gen_result(R, "result.npz", synth.SEED + 8, False)
     gen_result(R, "result_mixed.npz", synth.SEED + 11, True)
+    gen_attention(R)
 
 
 if __name__ == "__main__":
