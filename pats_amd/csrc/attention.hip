@@ -18,12 +18,11 @@
 //      from the slab; the [channel][query] result tile stores 128-byte lines.
 // The n x m score matrix never reaches HBM (the stock path writes and re-reads it three times).
 // Tokens on this path: 65 / 145 / 300 per side, dim = 32 / 66 / 112, 4 heads; m <= 640 (LDS slab).
-#include "common.hpp"
+#include "cost65_device.hpp"
 
 namespace pats {
 
 namespace {
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int AR = 32;                    // query rows per workgroup
 constexpr int VST = 33;                   // stride of the private V tile
 
@@ -133,6 +132,127 @@ attention_kernel(AttnArgs g) {
     }
 }
 
+// ---- the third-level shape: 65 tokens per side, dim 32 - one wave per (batch, head) ----------------------
+// S^T = K^T Q is built with the in-wave cost machinery (cost65_device.hpp: 2x2 MFMA tiles over even / odd
+// tokens, token 64 of either side as VALU chains), i.e. with KEYS as MFMA rows and QUERIES as MFMA columns:
+// a lane then owns queries 2 li and 2 li + 1 and half of their keys sit in its accumulator registers (the
+// other half in lane ^ 32).  The softmax is therefore in-lane plus one half-wave exchange, and the
+// probabilities never move: accumulator register r of tile (key parity, query parity) IS the B operand of
+// the second product out^T = V P^T (lane l supplies B[k = l >> 5][column = l & 31] = P[query][key(r, l >> 5)]),
+// with the matching A operand V[channel = l & 31][key(r, l >> 5)] read from an 8.3 KB LDS copy of V.
+// Token 64 on the key side is one more rank-1 MFMA step, on the query side a 65-term dot product per channel.
+struct Attn65Lds {
+    float edge[1024];            // cost65_accumulate's staging of token 64's channels
+    float vt[32 * 65];           // V[channel][key]
+    float p64[72];               // probabilities of query 64
+};
+
+__global__ void __launch_bounds__(64, 2)
+attention65_kernel(AttnArgs g) {
+    __shared__ Attn65Lds lds;
+    const int lane = threadIdx.x, li = lane & 31, lk = lane >> 5;
+    const int64_t bh = blockIdx.x, bi = bh / g.heads;
+    const int h = (int)(bh - bi * g.heads);
+    const int ld = g.heads * 65;
+    const int64_t base = (bi * 32 * g.heads + h) * 65;
+    const float* Q = g.q + base;
+    const float* K = g.k + base;
+    const float* V = g.v + base;
+
+    // V -> LDS early (independent of the scores): element e = lane + 64 s of the [32][65] matrix
+    float vreg[33];
+#pragma unroll
+    for (int s = 0; s < 33; ++s) {
+        const int e = lane + 64 * s, d = e / 65, j = e - d * 65;
+        vreg[s] = e < 32 * 65 ? V[d * ld + j] : 0.f;
+    }
+    Cost65Acc c;
+    cost65_accumulate(K, Q, 32, lds.edge, lane, c, ld);          // rows = keys, columns = queries
+#pragma unroll
+    for (int s = 0; s < 33; ++s) {
+        const int e = lane + 64 * s;
+        if (e < 32 * 65) lds.vt[e] = vreg[s];
+    }
+    // ---- scale, softmax per query --------------------------------------------------------------------
+    f32x16* tiles[4] = {&c.c00, &c.c01, &c.c10, &c.c11};          // [key parity * 2 + query parity]
+    float pd[2];                                                   // probability of key 64 for queries 2 li + {0, 1}
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+        f32x16& e0 = *tiles[tq];                                   // even keys
+        f32x16& e1 = *tiles[2 + tq];                               // odd keys
+        float sd = div_invariant(tq ? c.er1 : c.er0, g.sq, g.rsq); // score against key 64
+        float mx = sd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            e0[r] = div_invariant(e0[r], g.sq, g.rsq);
+            e1[r] = div_invariant(e1[r], g.sq, g.rsq);
+            mx = fmaxf(mx, fmaxf(e0[r], e1[r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float den = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            e0[r] = fast_exp2((e0[r] - mx) * LOG2E);
+            e1[r] = fast_exp2((e1[r] - mx) * LOG2E);
+            den += e0[r] + e1[r];
+        }
+        den += __shfl_xor(den, 32);
+        sd = fast_exp2((sd - mx) * LOG2E);
+        const float inv = 1.0f / (den + sd);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { e0[r] *= inv; e1[r] *= inv; }
+        pd[tq] = sd * inv;
+    }
+    // query 64: its scores against keys 2 li, 2 li + 1 (ec0, ec1: complete in both halves) and key 64 (cn)
+    {
+        const float s0 = div_invariant(c.ec0, g.sq, g.rsq), s1 = div_invariant(c.ec1, g.sq, g.rsq);
+        const float sc = div_invariant(c.cn, g.sq, g.rsq);
+        const float mx = fmaxf(wave_max(fmaxf(s0, s1)), sc);
+        const float x0 = fast_exp2((s0 - mx) * LOG2E), x1 = fast_exp2((s1 - mx) * LOG2E), xc = fast_exp2((sc - mx) * LOG2E);
+        const float den = wave_sum(lk == 0 ? x0 + x1 : 0.f) + xc;
+        const float inv = 1.0f / den;
+        if (lk == 0) { lds.p64[2 * li] = x0 * inv; lds.p64[2 * li + 1] = x1 * inv; }
+        if (lane == 0) lds.p64[64] = xc * inv;
+    }
+    __syncthreads();                                               // vt and p64 visible (single wave: ordering only)
+    // ---- out^T = V P^T -------------------------------------------------------------------------------------
+    f32x16 o0, o1;                                                 // queries 2 li (o0) and 2 li + 1 (o1); rows = channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    const float* va = lds.vt + li * 65 + 8 * lk;                   // V[channel li][key 2 (rc0 + 4 lk) + parity]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j0 = 2 * ((r & 3) + 8 * (r >> 2));              // even key of register r for lk = 0
+        const float a_even = va[j0], a_odd = va[j0 + 1];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_even, c.c00[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_even, c.c01[r], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_odd, c.c10[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_odd, c.c11[r], o1, 0, 0, 0);
+    }
+    {   // key 64: rank-1 step (k = 0 carries it, k = 1 is zero)
+        const float a64 = lk == 0 ? lds.vt[li * 65 + 64] : 0.f;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a64, lk == 0 ? pd[0] : 0.f, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a64, lk == 0 ? pd[1] : 0.f, o1, 0, 0, 0);
+    }
+    float* O = g.out + base;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        *reinterpret_cast<f2u*>(O + d * ld + 2 * li) = f2u{o0[r], o1[r]};
+    }
+    // query 64: out[d][64] = sum_j V[d][j] p64[j], channel d = li in the lower half-wave
+    if (lk == 0) {
+        float acc0 = 0.f, acc1 = 0.f;
+        const float* vr = lds.vt + li * 65;
+#pragma unroll 8
+        for (int j = 0; j < 64; j += 2) {
+            acc0 = fmaf(vr[j], lds.p64[j], acc0);
+            acc1 = fmaf(vr[j + 1], lds.p64[j + 1], acc1);
+        }
+        O[li * ld + 64] = fmaf(vr[64], lds.p64[64], acc0 + acc1);
+    }
+}
+
 }  // namespace pats
 
 using namespace pats;
@@ -143,6 +263,14 @@ extern "C" int pats_attention_f32(const float* query, const float* key, const fl
     PATS_REQUIRE(batch >= 0 && dim > 0 && heads > 0 && n > 0 && m > 0, "attention: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(query && key && value && out, "attention: null pointer");
+    const float sq0 = (float)sqrt((double)dim);
+    static const bool general_only = getenv("PATS_ATTN_GENERAL") != nullptr;     // A/B switch for benchmarking
+    if (n == 65 && m == 65 && dim == 32 && !prob && !general_only) {            // the third-level shape
+        PATS_REQUIRE(batch * heads < (1ll << 31), "attention: grid too large (split the batch)");
+        AttnArgs g{query, key, value, dim, heads, n, m, 0, sq0, 1.0f / sq0, out, nullptr};
+        hipLaunchKernelGGL(attention65_kernel, dim3((unsigned)(batch * heads)), dim3(64), 0, as_stream(stream), g);
+        return check_launch("attention65_kernel");
+    }
     const int mt = (m + 31) / 32, mp = 32 * mt + 1;
     const size_t lds = (size_t)(AR * mp + 4 * 32 * VST) * sizeof(float);
     if (lds > 100 * 1024) {

@@ -26,10 +26,13 @@ struct Cost65Acc {
 // half-wave chains, summed at the end); their operands d0[:,64], d1[:,64] are parked in `edge_lds`
 // (2 x 512 floats of LDS the caller is not using yet).  D % 32 == 0, D <= 512.  Results are RAW dot
 // products; cost65_scale applies the reference's `/ D**.5` then `0.1 *`.
+// `ld` = elements between consecutive descriptor rows (65 for [D,65] descriptors; heads*65 for one
+// head of a [dim,heads,65] attention operand).
 __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, const float* __restrict__ B,
-                                                  int D, float* edge_lds, int lane, Cost65Acc& o) {
+                                                  int D, float* edge_lds, int lane, Cost65Acc& o,
+                                                  int ld = C65_NT) {
     const int li = lane & 31, lk = lane >> 5;
-    constexpr int NT = C65_NT, NB = C65_NB;
+    constexpr int NB = C65_NB;
     f32x16 c00, c01, c10, c11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
@@ -37,11 +40,11 @@ __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, c
     float* eA = edge_lds;
     float* eB = edge_lds + 512;
     for (int k = lane; k < D; k += 64) {
-        eA[k] = A[k * NT + NB];
-        eB[k] = B[k * NT + NB];
+        eA[k] = A[k * ld + NB];
+        eB[k] = B[k * ld + NB];
     }
-    const float* pa = A + lk * NT + 2 * li;
-    const float* pb = B + lk * NT + 2 * li;
+    const float* pa = A + lk * ld + 2 * li;
+    const float* pb = B + lk * ld + 2 * li;
     // explicit software pipeline over blocks of KB = 4 k-steps (8 descriptor rows): a ring of four
     // named register buffers keeps three blocks of loads in flight ahead of the MFMAs (deeper rings
     // were measured slower: the phase is HBM-bandwidth-bound, and the extra registers spill)
@@ -51,8 +54,8 @@ __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, c
 #pragma unroll
         for (int s_ = 0; s_ < KB; ++s_) {
             const int k = k0 + 2 * s_;                    // D % 32 == 0: whole rings only
-            q.a[s_] = *reinterpret_cast<const f2u*>(pa + k * NT);
-            q.b[s_] = *reinterpret_cast<const f2u*>(pb + k * NT);
+            q.a[s_] = *reinterpret_cast<const f2u*>(pa + k * ld);
+            q.b[s_] = *reinterpret_cast<const f2u*>(pb + k * ld);
         }
     };
     auto compute_blk = [&](int k0, const Blk& q) {

@@ -574,8 +574,10 @@ def test_attention_golden(ops):
         np.testing.assert_allclose(x.reshape(-1)[g["x_idx%d" % c]], g["x_val%d" % c], atol=1e-5, rtol=1e-5)
         np.testing.assert_allclose(prob.reshape(-1)[g["p_idx%d" % c]], g["p_val%d" % c], atol=2e-6, rtol=1e-5)
         np.testing.assert_allclose(prob.sum(-1), g["p_rowsum%d" % c], atol=2e-6)
+        # without prob the 65-token / dim-32 shape takes the one-wave-per-head kernel: same gates
         x2, none = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]), return_prob=False)
-        assert none is None and np.array_equal(x2.cpu().numpy(), x)
+        assert none is None
+        np.testing.assert_allclose(x2.cpu().numpy().reshape(-1)[g["x_idx%d" % c]], g["x_val%d" % c], atol=1e-5, rtol=1e-5)
 
 
 def test_attention_shapes_against_oracle(ops, oracle):
@@ -588,6 +590,8 @@ def test_attention_shapes_against_oracle(ops, oracle):
         x, prob = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]))
         wx, wp = oracle.attention(inp["q"], inp["k"], inp["v"])
         np.testing.assert_allclose(x.cpu().numpy(), wx, atol=2e-5, rtol=1e-5)
+        x_np, _ = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]), return_prob=False)
+        np.testing.assert_allclose(x_np.cpu().numpy(), wx, atol=2e-5, rtol=1e-5)
         np.testing.assert_allclose(prob.cpu().numpy(), wp, atol=2e-6, rtol=1e-5)
         np.testing.assert_allclose(prob.sum(-1).cpu().numpy(), 1.0, atol=2e-6)
         vmin = cu(inp["v"]).amin(dim=3, keepdim=True)
