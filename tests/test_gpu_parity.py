@@ -552,7 +552,7 @@ def test_result_chain_full_size(ops, oracle):
 
 
 # ---- randomised cross-check (a fixed-seed slice of tools/fuzz_parity.py) -------------------------------
-@pytest.mark.parametrize("op", ["sinkhorn", "ot", "ot2", "cost", "expand", "resize", "merge", "result", "third"])
+@pytest.mark.parametrize("op", ["sinkhorn", "ot", "ot2", "cost", "expand", "resize", "merge", "result", "third", "attention"])
 def test_fuzz_slice(ops, oracle, op):
     """Random shapes (ragged, tiny, resident sizes and their neighbours, tie-heavy data) against the
     oracle; tools/fuzz_parity.py runs the same generators for minutes (6 867 cases clean in round 1)."""

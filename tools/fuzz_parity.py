@@ -230,7 +230,33 @@ def op_third(rng):
     return "P=%d D=%d outdoor=%d" % (P, D, outdoor)
 
 
-OPS = {"sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
+def op_attention(rng):
+    pick = rng.integers(0, 4)
+    if pick == 0:
+        b, dim, heads, n, m = int(rng.integers(1, 40)), 32, int(rng.integers(1, 5)), 65, 65       # one-wave kernel
+    elif pick == 1:
+        b, dim, heads = int(rng.integers(1, 4)), int(rng.choice([66, 112, 32, 7])), int(rng.integers(1, 5))
+        n = m = int(rng.choice([145, 300, 65, 64, 33]))
+    else:
+        b, dim, heads = int(rng.integers(1, 4)), int(rng.integers(1, 130)), int(rng.integers(1, 5))
+        n, m = int(rng.integers(1, 200)), int(rng.integers(1, 641))
+    amp = float(rng.choice([0.3, 1.0, 3.0]))
+    q = (amp * rng.standard_normal((b, dim, heads, n))).astype(np.float32)
+    k = (amp * rng.standard_normal((b, dim, heads, m))).astype(np.float32)
+    v = rng.standard_normal((b, dim, heads, m)).astype(np.float32)
+    want_prob = bool(rng.integers(0, 2))
+    x, prob = ops.attention(cu(q), cu(k), cu(v), return_prob=want_prob)
+    wx, wp = oracle.attention(q, k, v)
+    # scores grow like amp^2 sqrt(dim); fp32 rounding of a score (any fp32 evaluation, the reference's
+    # included: torch-CPU fp32 misses the double-accumulating oracle by 3.9e-5 on seed 3000809) is
+    # amplified one-to-one into the probabilities
+    np.testing.assert_allclose(x.cpu().numpy(), wx, atol=3e-5 * max(1.0, amp * amp), rtol=2e-5)
+    if want_prob:
+        np.testing.assert_allclose(prob.cpu().numpy(), wp, atol=3e-6, rtol=2e-5)
+    return "b=%d dim=%d heads=%d n=%d m=%d prob=%d" % (b, dim, heads, n, m, want_prob)
+
+
+OPS = {"attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
        "resize": op_resize, "merge": op_merge, "result": op_result, "third": op_third}
 
 
