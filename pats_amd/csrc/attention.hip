@@ -60,11 +60,19 @@ attention_kernel(AttnArgs g) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int d0 = 0; d0 < g.dim; d0 += 2) {
-            const bool dv = d0 + lk < g.dim;
-            const float a = (qv && dv) ? qp[(int64_t)(d0 + lk) * rsn] : 0.f;
-            const float b = (kv && dv) ? kp[(int64_t)(d0 + lk) * rsm] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        // blocks of 8 k-steps: all 16 operand loads of a block are issued before its MFMAs (one load
+        // latency per block instead of one per MFMA)
+        for (int d0 = 0; d0 < g.dim; d0 += 16) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + 2 * u + lk;
+                const bool dv = d < g.dim;
+                a[u] = (qv && dv) ? qp[(int64_t)d * rsn] : 0.f;
+                b[u] = (kv && dv) ? kp[(int64_t)d * rsm] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -106,13 +114,21 @@ attention_kernel(AttnArgs g) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int j0 = 0; j0 < 32 * mt; j0 += 32) {
-            // stage V[32 td .. +31][j0 .. +31]: a half-wave reads one 128-byte line of a channel row
-#pragma unroll 4
+        // V[32 td .. +31][j0 .. +31] chunks: a half-wave reads one 128-byte line of a channel row; the next
+        // chunk is fetched into registers while the MFMAs of the current one run
+        float vr[16];
+        auto fetch = [&](int j0) {
+#pragma unroll
             for (int qd = 0; qd < 16; ++qd) {
-                const int dd = 2 * qd + lk, d = 32 * td + dd, j = j0 + li;
-                vt[dd * VST + li] = (d < g.dim && j < g.m) ? V[(int64_t)d * rsm + j] : 0.f;
+                const int d = 32 * td + 2 * qd + lk, j = j0 + li;
+                vr[qd] = (d < g.dim && j < g.m) ? V[(int64_t)d * rsm + j] : 0.f;
             }
+        };
+        fetch(0);
+        for (int j0 = 0; j0 < 32 * mt; j0 += 32) {
+#pragma unroll
+            for (int qd = 0; qd < 16; ++qd) vt[(2 * qd + lk) * VST + li] = vr[qd];
+            if (j0 + 32 < 32 * mt) fetch(j0 + 32);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: LDS is in order, only the compiler needs telling
 #pragma unroll 4
             for (int jj = 0; jj < 32; jj += 2) {
