@@ -1011,7 +1011,7 @@ extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, co
     hipStream_t st = as_stream(stream);
     if (M == NT && N == NT) {
         Ot65Args g{};
-    g.fallbacks = fallback_counter();
+        g.fallbacks = fallback_counter();
         g.Zin = Z; g.P = batch; g.log_mu = log_mu; g.log_nu = log_nu; g.iters = iters;
         g.linear = use_linear(); g.out = out;
         hipLaunchKernelGGL((sinkhorn65_kernel<0, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
@@ -1074,7 +1074,7 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     hipStream_t st = as_stream(stream);
     if (m == NT && n == NT) {
         Ot65Args g{};
-    g.fallbacks = fallback_counter();
+        g.fallbacks = fallback_counter();
         g.Zin = scores; g.P = batch; g.ns = ns; g.one = one; g.iters = iters; g.bias_k = bias_k;
         g.linear = use_linear(); g.out = Z;
         hipLaunchKernelGGL((sinkhorn65_kernel<2, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
