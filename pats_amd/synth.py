@@ -190,3 +190,25 @@ def attention_inputs(seed=SEED + 12, b=3, dim=32, heads=4, n=65, m=None, amp=1.0
     k = (amp * rng.standard_normal((b, dim, heads, m))).astype(np.float32)
     v = rng.standard_normal((b, dim, heads, m)).astype(np.float32)
     return {"q": q, "k": k, "v": v}
+
+
+class SynthNets:
+    """Deterministic stand-ins for the three networks of PATS (numpy): the tensors a layer's forward holds
+    right before its cost build.  Both the reference-side chain of tools/make_golden.py and
+    pats_amd.pipeline.forward_path consume them, so the two chains see identical inputs as long as they
+    agree on the chunk sizes B and the third-level counts P."""
+
+    def __init__(self, seed=SEED + 40, h=5, w=6):
+        self.seed, self.h, self.w = seed, h, w
+
+    def images(self):
+        return image_pair(seed=self.seed + 1, H=self.h * 32, W=self.w * 32)
+
+    def coarse(self):
+        return coarse_inputs(seed=self.seed, h=self.h, w=self.w)
+
+    def fine(self, num, B):
+        return fine_inputs(seed=self.seed + 101 + num, B=B)
+
+    def third(self, num, P):
+        return third_inputs(seed=self.seed + 201 + num, P=P)

@@ -603,3 +603,43 @@ def test_attention_shapes_against_oracle(ops, oracle):
     with pytest.raises(RuntimeError):
         ops.attention(torch.zeros((1, 8, 2, 4), device="cuda"), torch.zeros((1, 8, 2, 700), device="cuda"),
                       torch.zeros((1, 8, 2, 700), device="cuda"))
+
+
+# ---- the whole path chained: pats_amd.pipeline.forward_path vs the reference's functions in its own order ----
+class _CudaNets:
+    """synth.SynthNets (numpy) as the GPU callbacks of pats_amd.pipeline."""
+
+    def __init__(self, nets):
+        self.n = nets
+
+    def coarse(self, left, right):
+        c = self.n.coarse()
+        return cu(c["d0"]), cu(c["d1"]), cu(c["ns"]), float(c["alpha"])
+
+    def fine(self, num, new_left, new_right, mask):
+        f = self.n.fine(num, new_left.shape[0])
+        return cu(f["d0"]), cu(f["d1"]), cu(f["scale_x"]), cu(f["scale_y"])
+
+    def third(self, num, mk0, mk1, b_ids):
+        t = self.n.third(num, mk0.shape[0])
+        return cu(t["d0"]), cu(t["d1"]), cu(t["scale"])
+
+
+@pytest.mark.parametrize("name", ["pipeline_outdoor.npz", "pipeline_indoor.npz"])
+def test_pipeline_chain(name):
+    """first_layer.py:110-157 -> second_layer.py:100-124 -> pats.py:32-78 -> third_layer.py:153-170 ->
+    get_result, on synthetic network outputs: same chunk sizes, same third-level counts, same matches in
+    the same order as the reference's own functions produce (tools/make_golden.py::gen_pipeline).
+    Source-side coordinates are index arithmetic (exact); target-side ones carry the third-level
+    expectation (3e-4 px at 1/2 resolution) times the area scale."""
+    from pats_amd import pipeline
+    g = golden(name)
+    nets = synth.SynthNets(seed=int(g["seed"]), h=int(g["h"]), w=int(g["w"]))
+    left, right = [cu(x) for x in nets.images()]
+    out = pipeline.forward_path(left, right, _CudaNets(nets), if_local=bool(g["if_local"]),
+                                if_outdoor=bool(g["if_outdoor"]), merge_new=bool(g["merge_new"]))
+    assert [list(c) for c in out["chunks"]] == g["chunks"].tolist()
+    ml, mr = out["matches_l"].cpu().numpy(), out["matches_r"].cpu().numpy()
+    assert ml.shape == g["matches_l"].shape and ml.shape[0] > 500
+    np.testing.assert_allclose(ml, g["matches_l"], atol=1e-4, rtol=1e-6)
+    np.testing.assert_allclose(mr, g["matches_r"], atol=2e-2, rtol=1e-5)

@@ -24,6 +24,9 @@ What each fixture pins (reference file:line):
   resize_small.npz tensor_resize edge cases (1-pixel crops, borders) (setup/library.cpp:47-66)
   merge_new.npz / merge_old.npz / merge_new_portrait.npz   merge_patches_new / _old over three
                    successive chunks incl. the scores_back hand-over (second_layer.py:137-238)
+  pipeline_outdoor.npz / pipeline_indoor.npz   the whole path chained in the reference's order on synthetic
+                   network outputs (MegaDepth-style: local chunks, outdoor, merge_new; ScanNet-style: one
+                   chunk, indoor, merge_old) -> final matches_l / matches_r
   attention.npz    attention(query, key, value) of the GNN layers (models/modules.py:84-88)
   result.npz / result_mixed.npz   third-level inputs, result scatter and get_result
                    (pats.py:53-78, utils/utils.py:189-213); _mixed flips left_choice per row
@@ -396,6 +399,104 @@ def gen_attention(R):
     save("attention.npz", **arrs)
 
 
+def gen_pipeline(R, name, seed, h, w, if_local, if_outdoor, merge_new):
+    """The whole path in the reference's own order: first_layer.py:110-157, second_layer.py:100-124,
+    pats.py:32-78, third_layer.py:122,126-128,153-170 re-executed verbatim on the SynthNets stand-ins,
+    every function call going to the reference's code.  Pins pats_amd.pipeline.forward_path."""
+    nets = synth.SynthNets(seed=seed, h=h, w=w)
+    left, right = [T(x) for x in nets.images()]
+    H, W = h * 32, w * 32
+    c = nets.coarse()
+    one = torch.tensor(1.0)
+    # first_layer.py:110-146
+    scores = R.M.log_optimal_transport(cost(T(c["d0"]), T(c["d1"]), 448), torch.tensor(float(c["alpha"])), T(c["ns"]), iters=100)
+    scales = torch.sqrt(scores[:, :-1, :-1].exp().sum(1) + 1e-8)
+    trust, pts, xr, yr, if_nomatching1, if_nomatching2 = R.L1.FirstLayer.est_position(None, scores, scales, (H, W), 32)
+    sum_cycle = torch.cumsum(torch.logical_not(if_nomatching1).int(), dim=1)
+    max_cycle = w * 2 if if_local else 512
+    cycle_num, second_layer_set, third_layer_set = R.U.split_patches(sum_cycle[0], h, w, max_cycle)
+    matches_l, matches_r = torch.zeros([0, 2]), torch.zeros([0, 2])
+    scores_refine_iter = torch.zeros([1, h * w, 16, 9]).double()
+    info = []
+    for num in range(cycle_num):
+        mask = torch.where(torch.logical_and(if_nomatching1 == False,  # noqa: E712
+                                             torch.logical_and(sum_cycle > second_layer_set[num][0],
+                                                               sum_cycle <= second_layer_set[num][1])), False, True)
+        new_left, new_right, x_scale_new, y_scale_new, average_new = R.U.Compute_imgs(xr, yr, pts, mask, left, right,
+                                                                                        width=w, height=h)
+        B = new_left.shape[0]
+        # second_layer.py:100-124
+        f = nets.fine(num, B)
+        sx, sy = T(f["scale_x"]), T(f["scale_y"])
+        Z2 = R.M.log_optimal_transport2(cost(T(f["d0"]), T(f["d1"]), 264), one, sx * sy, iters=100)
+        bias = torch.log(one * 2) if if_outdoor else torch.log(one * 3)
+        Z2[:, :, -1] += bias
+        Z2[:, -1, :] += bias
+        trust2, pts2, _, _, ifn_L2, _ = R.L2.SecondLayer.est_position(None, Z2, sx, sy, [96, 96], 8)
+        merge = R.L2.SecondLayer.merge_patches_new if merge_new else R.L2.SecondLayer.merge_patches_old
+        ifn_L2, scores_refine_iter = merge(None, B, trust2, (H, W), mask, ifn_L2, scores_refine_iter)
+        # pats.py:38-78
+        if third_layer_set[num][1] != 0:
+            ifn_L2[-third_layer_set[num][1]:, :] = True
+        if_ndelete = torch.logical_not(ifn_L2).int().sum(1).bool()
+        ifn_L2 = ifn_L2[if_ndelete]
+        if torch.logical_not(ifn_L2).float().sum() < 0.5:
+            info.append((B, 0, 0))
+            continue
+        pts2 = pts2[if_ndelete]
+        mask[torch.logical_not(mask)] = torch.logical_not(if_ndelete)
+        nb = int(if_ndelete.sum())
+        sequence = torch.arange(0, 144).reshape(-1, 144, 1).repeat(nb, 1, 1)
+        third_input = torch.cat([sequence % 12 * 4 + 2, sequence // 12 * 4 + 2, torch.round(pts2 * 4)[:, :, [1, 0]],
+                                 torch.arange(nb).reshape(-1, 1, 1).repeat(1, 144, 1)], dim=2)
+        third_input = third_input[torch.logical_not(ifn_L2)]
+        mkpts0_c, mkpts1_c = third_input[:, :2] * 2, third_input[:, 2:4] * 2
+        P = mkpts0_c.shape[0]
+        # third_layer.py:122,126-128,153-170
+        t = nets.third(num, P)
+        mkpts0_c = torch.round(mkpts0_c / 4.0).long() * 4
+        mkpts1_c = torch.where(mkpts1_c >= 96, torch.tensor(96).float(), mkpts1_c)
+        mkpts1_c = torch.where(mkpts1_c <= 0, torch.tensor(0).float(), mkpts1_c)
+        mkpts1_c = torch.round(mkpts1_c / 4.0).long() * 4
+        scale = T(t["scale"])
+        scale_x, scale_y = (scale + 1e-8).sqrt(), (scale + 1e-8).sqrt()
+        scores_origin = R.M.log_optimal_transport2(cost(T(t["d0"]), T(t["d1"]), 128), one, scale, iters=100)
+        sc3 = torch.exp(scores_origin)
+        ns_ = types.SimpleNamespace(pad=torch.nn.ZeroPad2d(2), pad_1=torch.nn.ConstantPad2d(2, 1e-2))
+        mkpts0_f, mkpts1_f, _ = R.L3.ThirdLayer.Compute_result(ns_, sc3, 8, 5, scale_x, scale_y, mkpts0_c, mkpts1_c, 'cpu')
+        label = ((torch.zeros_like(mkpts1_c[:, None, :].expand(-1, 16, -1).float())) + 1e8).reshape(-1, 2)
+        if not if_outdoor:
+            ar = torch.arange(label.shape[0])
+            select = torch.logical_or(torch.logical_or(ar % 16 == 5, ar % 16 == 15), torch.logical_or(ar % 16 == 7, ar % 16 == 13))
+            label[:, 0] = torch.where(select, label[:, 0], torch.tensor(-10.0))
+        scores_used = sc3[:, :-1, :].reshape(P, 8, 8, -1)[:, 2:6, 2:6, :].reshape(P, 16, -1) + 1e-8
+        if_matching1 = (scores_used.max(2)[1] != 64)
+        if if_outdoor:
+            label[:, 0] = torch.where(if_matching1.reshape(-1), label[:, 0], torch.tensor(-10.0))
+        # pats.py:59-78
+        mkpts1 = mkpts1_f.reshape(-1, 2)
+        pts16 = pts2.reshape(-1, 144, 1, 2).repeat(1, 1, 16, 1)
+        f16 = ifn_L2.reshape(-1, 144, 1).repeat(1, 1, 16)
+        pts16[torch.logical_not(f16)] = mkpts1.float()
+        lab = torch.zeros_like(f16).float()
+        lab[torch.logical_not(f16)] = label[:, 0]
+        f16 = torch.logical_or(f16, lab < -9.9)
+        f16 = f16.reshape(-1, 12, 12, 4, 4).permute(0, 1, 3, 2, 4).reshape(-1, 144 * 16)
+        pts16 = pts16.reshape(-1, 12, 12, 4, 4, 2).permute(0, 1, 3, 2, 4, 5).reshape(-1, 144 * 16, 2)
+        if_nomatching = [mask, f16]
+        patch_size = [[32, h, w], [2, 48, 48]]
+        scale_l = [x_scale_new, x_scale_new.reshape(-1, w * h, 2)[torch.logical_not(mask)].reshape(-1, 1, 2).repeat(1, 144 * 16, 1)]
+        average_point = [average_new.flip(dims=[2]) / 32.0, pts16.flip(dims=[2]) / 2.0]
+        left_choice = [torch.ones([1]).bool(), torch.ones([f16.shape[0]]).bool()]
+        ml, mr = R.U.get_result(1, if_nomatching, average_point, scale_l, patch_size, left_choice)
+        matches_l, matches_r = torch.cat([matches_l, ml], dim=0), torch.cat([matches_r, mr], dim=0)
+        info.append((B, P, ml.shape[0]))
+    print("   %s: chunks (B, P, M) = %s" % (name, info))
+    save(name, seed=np.int64(seed), h=np.int64(h), w=np.int64(w), if_local=np.int64(if_local), if_outdoor=np.int64(if_outdoor),
+         merge_new=np.int64(merge_new), chunks=np.asarray(info, dtype=np.int64).reshape(-1, 3), matches_l=matches_l,
+         matches_r=matches_r)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -422,6 +523,8 @@ def main():
     gen_result(R, "result.npz", synth.SEED + 8, False)
     gen_result(R, "result_mixed.npz", synth.SEED + 11, True)
     gen_attention(R)
+    gen_pipeline(R, "pipeline_outdoor.npz", synth.SEED + 40, 5, 6, True, True, True)
+    gen_pipeline(R, "pipeline_indoor.npz", synth.SEED + 41, 4, 5, False, False, False)
 
 
 if __name__ == "__main__":
