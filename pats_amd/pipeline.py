@@ -36,10 +36,19 @@ def _round4(x, clamp96):
     return torch.round(x / 4.0).long() * 4
 
 
-def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=True, iters=100):
+def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=True, iters=100, batch_chunks=False):
     """left / right: [1,H,W,3] float32 HWC images (what first_layer.py:128-129 permutes to).
     Returns {"matches_l": [M,2], "matches_r": [M,2]} in the reference's (row, col) pixel convention and
-    order, plus "chunks": per-chunk (B, P, M) for inspection."""
+    order, plus "chunks": per-chunk (B, P, M) for inspection.
+
+    batch_chunks=True runs all chunks of the pair together (the reference walks them one by one to bound
+    memory on a 16-40 GB card): ONE fine-level cost+OT+expansion launch over the concatenated chunk rows,
+    the merges in chunk order (their only coupling is scores_back, pats.py:32,37), ONE third-level
+    launch, ONE get_result with the chunks as its batch dimension; three host reads per pair.  The
+    callbacks are then called once with num=None and the list of per-chunk row counts:
+        nets.fine(None, new_left_all, new_right_all, masks [C,N], sizes=[B_0, ...])
+        nets.third(None, mkpts0_c, mkpts1_c, b_ids (rows of the concatenation), sizes=[B_0, ...])
+    Same matches in the same order (tests/test_gpu_parity.py::test_pipeline_chain runs both modes)."""
     dev = left.device
     H, W = int(left.shape[1]), int(left.shape[2])
     h, w = H // 32, W // 32
@@ -60,6 +69,9 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
                                                           known_count=K)
     scores_back = torch.zeros([1, h * w, 16, 9], dtype=torch.float64, device=dev)     # pats.py:32
     merge = ops.merge_patches_new if merge_new else ops.merge_patches_old
+    if batch_chunks:
+        return _forward_batched(left, nets, if_outdoor, iters, merge, scores_back, ifn1, sum_cycle, second_set,
+                                third_set, K, new_left, new_right, xsn, avn, h, w, H, W)
     out_l, out_r, info = [], [], []
     for num in range(cycle_num):
         lo, hi = second_set[num]
@@ -97,3 +109,46 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
         info.append((B, P, int(ml.shape[0])))
     return {"matches_l": torch.cat(out_l) if out_l else empty, "matches_r": torch.cat(out_r) if out_r else empty,
             "chunks": info}
+
+
+def _forward_batched(left, nets, if_outdoor, iters, merge, scores_back, ifn1, sum_cycle, second_set, third_set, K,
+                     new_left, new_right, xsn, avn, h, w, H, W):
+    dev = left.device
+    empty = torch.zeros([0, 2], device=dev)
+    spans = [(lo, min(hi, K), int(tl[1])) for (lo, hi), tl in zip(second_set, third_set) if min(hi, K) - lo > 0]
+    if not spans:
+        return {"matches_l": empty, "matches_r": empty, "chunks": []}
+    sizes = [hi - lo for lo, hi, _ in spans]
+    C, Bt = len(spans), sum(sizes)
+    masks = torch.cat([torch.logical_or(ifn1, torch.logical_or(sum_cycle <= lo, sum_cycle > hi))
+                       for lo, hi in second_set if min(hi, K) - lo > 0])                  # [C,N]  (first_layer.py:137-138)
+    rows = torch.cat([torch.arange(lo, hi, device=dev) for lo, hi, _ in spans])          # overlap rows appear twice
+    f0, f1, sx, sy = nets.fine(None, new_left[rows], new_right[rows], masks, sizes=sizes)
+    Z2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0)
+    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8)
+    merged = torch.empty_like(ifn_L2)
+    off = 0
+    for c, (lo, hi, tail) in enumerate(spans):                 # chunk order: scores_back couples them
+        B = hi - lo
+        out, scores_back = merge(B, trust2[off:off + B], (H, W), masks[c:c + 1], ifn_L2[off:off + B], scores_back,
+                                 validate=False)
+        merged[off:off + B] = out
+        if tail != 0:
+            merged[off + B - tail:off + B, :] = True
+        off += B
+    mk0, mk1, b_ids = ops.third_inputs(merged, pts2)            # host read: P (all chunks)
+    if mk0.shape[0] == 0:
+        return {"matches_l": empty, "matches_r": empty, "chunks": [(b, 0, 0) for b in sizes]}
+    feat0, feat1, scale3 = nets.third(None, mk0, mk1, b_ids, sizes=sizes)
+    m0f, m1f, label, ifm = ops.third_level(feat0, feat1, scale3, _round4(mk0, False), _round4(mk1, True),
+                                           outdoor=if_outdoor, iters=iters)
+    ifn16, pts16 = ops.refine_scatter(merged, pts2, m1f, label)
+    # get_result with the chunks as level-0 batch: row k of level 1 belongs to the k-th unmasked cell in
+    # (chunk, patch) order = the concatenation order
+    xs_c, av_c = xsn.expand(C, -1, -1).contiguous(), avn.expand(C, -1, -1).contiguous()
+    sc_rows = xs_c[torch.logical_not(masks)]                                            # [Bt,2]
+    ml, mr = ops.get_result(C, [masks, ifn16], [av_c.flip(dims=[2]) / 32.0, pts16.flip(dims=[2]) / 2.0],
+                            [xs_c, sc_rows], [[32, h, w], [2, 48, 48]],
+                            [torch.ones([C], dtype=torch.bool, device=dev), torch.ones([Bt], dtype=torch.bool, device=dev)],
+                            validate=False)                       # host read: M
+    return {"matches_l": ml, "matches_r": mr, "chunks": [(b, -1, -1) for b in sizes]}

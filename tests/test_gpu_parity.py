@@ -616,17 +616,26 @@ class _CudaNets:
         c = self.n.coarse()
         return cu(c["d0"]), cu(c["d1"]), cu(c["ns"]), float(c["alpha"])
 
-    def fine(self, num, new_left, new_right, mask):
+    def fine(self, num, new_left, new_right, mask, sizes=None):
+        if num is None:                 # batched mode: the per-chunk tensors, concatenated
+            parts = [self.n.fine(c, b) for c, b in enumerate(sizes)]
+            return tuple(cu(np.concatenate([p[k] for p in parts])) for k in ("d0", "d1", "scale_x", "scale_y"))
         f = self.n.fine(num, new_left.shape[0])
         return cu(f["d0"]), cu(f["d1"]), cu(f["scale_x"]), cu(f["scale_y"])
 
-    def third(self, num, mk0, mk1, b_ids):
+    def third(self, num, mk0, mk1, b_ids, sizes=None):
+        if num is None:
+            edges = np.cumsum([0] + list(sizes))
+            per = np.histogram(b_ids.cpu().numpy(), bins=edges)[0]          # third-level problems per chunk
+            parts = [self.n.third(c, int(p)) for c, p in enumerate(per) if p > 0]
+            return tuple(cu(np.concatenate([p[k] for p in parts])) for k in ("d0", "d1", "scale"))
         t = self.n.third(num, mk0.shape[0])
         return cu(t["d0"]), cu(t["d1"]), cu(t["scale"])
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("name", ["pipeline_outdoor.npz", "pipeline_indoor.npz"])
-def test_pipeline_chain(name):
+def test_pipeline_chain(name, batched):
     """first_layer.py:110-157 -> second_layer.py:100-124 -> pats.py:32-78 -> third_layer.py:153-170 ->
     get_result, on synthetic network outputs: same chunk sizes, same third-level counts, same matches in
     the same order as the reference's own functions produce (tools/make_golden.py::gen_pipeline).
@@ -637,8 +646,11 @@ def test_pipeline_chain(name):
     nets = synth.SynthNets(seed=int(g["seed"]), h=int(g["h"]), w=int(g["w"]))
     left, right = [cu(x) for x in nets.images()]
     out = pipeline.forward_path(left, right, _CudaNets(nets), if_local=bool(g["if_local"]),
-                                if_outdoor=bool(g["if_outdoor"]), merge_new=bool(g["merge_new"]))
-    assert [list(c) for c in out["chunks"]] == g["chunks"].tolist()
+                                if_outdoor=bool(g["if_outdoor"]), merge_new=bool(g["merge_new"]), batch_chunks=batched)
+    if batched:
+        assert [c[0] for c in out["chunks"]] == g["chunks"][:, 0].tolist()
+    else:
+        assert [list(c) for c in out["chunks"]] == g["chunks"].tolist()
     ml, mr = out["matches_l"].cpu().numpy(), out["matches_r"].cpu().numpy()
     assert ml.shape == g["matches_l"].shape and ml.shape[0] > 500
     np.testing.assert_allclose(ml, g["matches_l"], atol=1e-4, rtol=1e-6)

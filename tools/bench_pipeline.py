@@ -23,22 +23,22 @@ sc3 = bench.scale_head((POOL_P, 1, 64), dev, gen)
 
 class Nets:
     def coarse(self, l, r): return d0, d1, ns, 0.0
-    def fine(self, num, nl, nr, mask):
-        B = nl.shape[0]; return f0[:B], f1[:B], sx[:B], sy[:B]
-    def third(self, num, mk0, mk1, b_ids):
+    def fine(self, num, nl, nr, mask, sizes=None):
+        idx = torch.arange(nl.shape[0], device=dev) % POOL_B
+        return f0[idx], f1[idx], sx[idx], sy[idx]
+    def third(self, num, mk0, mk1, b_ids, sizes=None):
         P = mk0.shape[0]
         idx = torch.arange(P, device=dev) % POOL_P
         return t0[idx], t1[idx], sc3[idx]
 
-def run():
-    return pipeline.forward_path(left, right, Nets(), if_local=True, if_outdoor=True, merge_new=True)
-
-out = run(); torch.cuda.synchronize()
-n = 10
-t = time.perf_counter()
-for _ in range(n): out = run()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t) / n
-print(json.dumps({"mode": "latency: one pair at a time through pipeline.forward_path", "ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt,
-                  "chunks": len(out["chunks"]), "B_total": sum(c[0] for c in out["chunks"]), "P_total": sum(c[1] for c in out["chunks"]),
-                  "matches": int(out["matches_l"].shape[0])}))
+for batched in (False, True):
+    run = lambda: pipeline.forward_path(left, right, Nets(), if_local=True, if_outdoor=True, merge_new=True, batch_chunks=batched)
+    out = run(); torch.cuda.synchronize()
+    n = 10
+    t = time.perf_counter()
+    for _ in range(n): out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    print(json.dumps({"mode": "latency: one pair at a time through pipeline.forward_path(batch_chunks=%s)" % batched,
+                      "ms_per_pair": dt * 1e3, "pairs_per_s": 1.0 / dt, "chunks": len(out["chunks"]),
+                      "B_total": sum(c[0] for c in out["chunks"])}))      # (the two modes draw different rows of the synthetic pool)
