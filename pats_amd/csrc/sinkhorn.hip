@@ -1115,7 +1115,8 @@ extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int6
                                     const int64_t* p_s, const int64_t* p_t, int iters, int outdoor,
                                     float* mkpts0_f, float* mkpts1_f, float* label,
                                     uint8_t* if_matching1, float* Z_out, pats_stream_t stream) {
-    PATS_REQUIRE(P >= 0 && D > 0 && (D % 16) == 0 && iters >= 0, "third_level: bad shape (D must be a multiple of 16)");
+    PATS_REQUIRE(P >= 0 && D > 0 && (D % 32) == 0 && D <= 512 && iters >= 0,
+                 "third_level: bad shape (D must be a multiple of 32, at most 512: the in-wave cost build runs whole prefetch rings)");
     if (P == 0) return PATS_OK;
     PATS_REQUIRE(feat0 && feat1 && scale && scale_x && scale_y && p_s && p_t && mkpts0_f && mkpts1_f &&
                      label && if_matching1, "third_level: null pointer");

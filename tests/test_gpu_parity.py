@@ -551,6 +551,15 @@ def test_result_chain_full_size(ops, oracle):
     assert e0.shape == (0, 2) and eb.shape == (0,)
 
 
+def test_third_level_rejects_unsupported_descriptor_dim(ops):
+    """D = 48 is not a whole number of prefetch rings: refused (RuntimeError, like a TORCH_CHECK), not mis-computed."""
+    P = 4
+    z = lambda *s: torch.zeros(s, device="cuda")     # noqa: E731
+    with pytest.raises(RuntimeError):
+        ops.third_level(z(P, 48, 65), z(P, 48, 65), torch.ones((P, 1, 64), device="cuda"),
+                        torch.zeros((P, 2), dtype=torch.int64, device="cuda"), torch.zeros((P, 2), dtype=torch.int64, device="cuda"))
+
+
 # ---- randomised cross-check (a fixed-seed slice of tools/fuzz_parity.py) -------------------------------
 @pytest.mark.parametrize("op", ["sinkhorn", "ot", "ot2", "cost", "expand", "resize", "merge", "result", "third", "attention"])
 def test_fuzz_slice(ops, oracle, op):
