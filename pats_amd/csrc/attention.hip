@@ -295,12 +295,9 @@ extern "C" int pats_attention_f32(const float* query, const float* key, const fl
     }
     const int64_t blocks = batch * heads * ((n + AR - 1) / AR);
     PATS_REQUIRE(blocks < (1ll << 31), "attention: grid too large (split the batch)");
-    static bool optin = false;
-    if (lds > 64 * 1024 && !optin) {
-        if (hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
-            return check_launch("attention (LDS opt-in)");
-        optin = true;
-    }
+    if (lds > 64 * 1024 &&      // per-device attribute: set whenever needed (cheap), never cached process-wide
+        hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
+        return check_launch("attention (LDS opt-in)");
     const float sq = (float)sqrt((double)dim);
     AttnArgs g{query, key, value, dim, heads, n, m, mp, sq, 1.0f / sq, out, prob};
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), g);

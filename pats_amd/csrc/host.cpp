@@ -1,6 +1,7 @@
 // Host-side pieces of libpats_amd.so: error plumbing, version, and the chunk planner.
 #include "common.hpp"
 
+#include <mutex>
 #include <string>
 
 namespace pats {
@@ -29,9 +30,11 @@ static int g_mode = PATS_SINKHORN_AUTO;
 int sinkhorn_mode() { return g_mode; }
 
 static unsigned long long* g_fallbacks[64];
+static std::mutex g_fallbacks_mu;
 unsigned long long* fallback_counter() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_fallbacks_mu);           // first use may race between host threads
     if (!g_fallbacks[dev]) {
         unsigned long long* p = nullptr;
         if (hipMalloc((void**)&p, sizeof(*p)) != hipSuccess || hipMemset(p, 0, sizeof(*p)) != hipSuccess) {
