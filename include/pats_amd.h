@@ -261,7 +261,7 @@ int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uin
  * keys, out = prob v.  query [batch,dim,heads,n], key / value [batch,dim,heads,m] (the view
  * modules.py:101-102 makes of the projections) -> out [batch,dim,heads,n]; prob [batch,heads,n,m] is
  * written only if non-null (the reference returns it, its caller discards it).  fp32 throughout; the
- * score matrix stays in LDS.  m <= 640 (PATS_ERR_UNSUPPORTED beyond). */
+ * score matrix stays in LDS.  m <= 1024 (PATS_ERR_UNSUPPORTED beyond). */
 int pats_attention_f32(const float* query, const float* key, const float* value, int64_t batch, int dim,
                        int heads, int n, int m, float* out, float* prob, pats_stream_t stream);
 

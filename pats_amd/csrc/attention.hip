@@ -17,7 +17,8 @@
 //      private LDS tile (coalesced along keys, read back channel-major), P fragments come straight
 //      from the slab; the [channel][query] result tile stores 128-byte lines.
 // The n x m score matrix never reaches HBM (the stock path writes and re-reads it three times).
-// Tokens on this path: 65 / 145 / 300 per side, dim = 32 / 66 / 112, 4 heads; m <= 640 (LDS slab).
+// Tokens on this path: 65 / 145 / 300 (768 at YFCC size) per side, dim = 32 / 66 / 112, 4 heads;
+// m <= 1024 (the slab must fit the CU's 160 KB of LDS).
 #include "cost65_device.hpp"
 
 namespace pats {
@@ -289,14 +290,14 @@ extern "C" int pats_attention_f32(const float* query, const float* key, const fl
     }
     const int mt = (m + 31) / 32, mp = 32 * mt + 1;
     const size_t lds = (size_t)(AR * mp + 4 * 32 * VST) * sizeof(float);
-    if (lds > 100 * 1024) {
-        set_error("attention: m=%d keys exceed the LDS slab (m <= 640)", m);
+    if (lds > 152 * 1024) {
+        set_error("attention: m=%d keys exceed the LDS slab (m <= 1024)", m);
         return PATS_ERR_UNSUPPORTED;
     }
     const int64_t blocks = batch * heads * ((n + AR - 1) / AR);
     PATS_REQUIRE(blocks < (1ll << 31), "attention: grid too large (split the batch)");
     if (lds > 64 * 1024 &&      // per-device attribute: set whenever needed (cheap), never cached process-wide
-        hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
+        hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return check_launch("attention (LDS opt-in)");
     const float sq = (float)sqrt((double)dim);
     AttnArgs g{query, key, value, dim, heads, n, m, mp, sq, 1.0f / sq, out, prob};

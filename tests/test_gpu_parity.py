@@ -593,7 +593,7 @@ def test_attention_shapes_against_oracle(ops, oracle):
     """Ragged and degenerate shapes (one query, one key, odd dim, n != m), peaked softmax rows, the
     third-level batch size, and the properties rows-sum-to-1 / convex combination of the values."""
     for seed, kw in enumerate([dict(b=2, dim=7, heads=3, n=1, m=1), dict(b=1, dim=5, heads=1, n=33, m=2),
-                               dict(b=2, dim=32, heads=4, n=64, m=96, amp=4.0), dict(b=1, dim=128, heads=2, n=200, m=640),
+                               dict(b=2, dim=32, heads=4, n=64, m=96, amp=4.0), dict(b=1, dim=128, heads=2, n=200, m=640), dict(b=1, dim=112, heads=4, n=769, m=769), dict(b=1, dim=8, heads=1, n=40, m=1024),
                                dict(b=300, dim=32, heads=4, n=65)]):
         inp = synth.attention_inputs(seed=500 + seed, **kw)
         x, prob = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]))
@@ -610,8 +610,8 @@ def test_attention_shapes_against_oracle(ops, oracle):
                          torch.zeros((0, 32, 4, 65), device="cuda"))
     assert e.shape == (0, 32, 4, 65)
     with pytest.raises(RuntimeError):
-        ops.attention(torch.zeros((1, 8, 2, 4), device="cuda"), torch.zeros((1, 8, 2, 700), device="cuda"),
-                      torch.zeros((1, 8, 2, 700), device="cuda"))
+        ops.attention(torch.zeros((1, 8, 2, 4), device="cuda"), torch.zeros((1, 8, 2, 1100), device="cuda"),
+                      torch.zeros((1, 8, 2, 1100), device="cuda"))
 
 
 # ---- the whole path chained: pats_amd.pipeline.forward_path vs the reference's functions in its own order ----
