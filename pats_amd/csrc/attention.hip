@@ -10,7 +10,8 @@
 // One 256-thread workgroup = (batch, head, 32 query rows):
 //   1. S = Q^T K / sqrt(dim) for the 32 rows against all m keys, one 32x32 MFMA tile per wave at a time,
 //      into a [32][m_pad] LDS slab (odd stride: conflict-free both by rows and by columns);
-//   2. row softmax in place (one wave per row at a time; max, exp, sum, IEEE divide like ATen), padded
+//   2. row softmax in place (one wave per row at a time; max, exp2 of the pre-scaled difference, sum, one
+//      reciprocal per row), padded
 //      columns zeroed; the probabilities go to HBM only if the caller asks for them (the reference's own
 //      caller discards them, modules.py:103);
 //   3. out^T = V P^T: wave w owns channel tile w; V chunks [32 channels][32 keys] are staged through a
@@ -95,14 +96,14 @@ attention_kernel(AttnArgs g) {
         mx = wave_max(mx);
         float den = 0.f;
         for (int j = lane; j < g.m; j += 64) {
-            const float e = expf(s[j] - mx);
+            const float e = fast_exp2((s[j] - mx) * LOG2E);     // v_exp_f32: ~1 ulp, far inside the 2e-6 gate on probabilities
             s[j] = e;
             den += e;
         }
-        den = wave_sum(den);
+        const float inv = 1.0f / wave_sum(den);
         float* pr = g.prob ? g.prob + ((bh * g.n + i0 + row) * (int64_t)g.m) : nullptr;
         for (int j = lane; j < 32 * mt; j += 64) {
-            const float p = j < g.m ? s[j] / den : 0.f;
+            const float p = j < g.m ? s[j] * inv : 0.f;
             s[j] = p;
             if (pr && j < g.m) pr[j] = p;
         }
