@@ -4,18 +4,28 @@
 One STEP = one pass of the hot path over a batch of `--pairs` synthetic 640x480 pairs at the
 reference's shapes, inputs resident in HBM before the timed region:
   L1  [1,448,300]^2 cost build (MFMA) -> log_optimal_transport 301x301, 100 sweeps -> column mass
-      -> argmax + 15-step area expansion -> split_patches (host, one D->H copy, cap 2w = 40 as
-      `if_local`) -> per chunk Compute_imgs (bounds, left crops, right crop+bilinear resize)
-  L2  per chunk [B,264,145]^2 cost -> log_optimal_transport2 145x145, 100 sweeps, +ln2 dustbin
+      -> argmax + 15-step area expansion -> split_patches (cap 2w = 40 as `if_local`) -> Compute_imgs
+      (bounds, left crops, right crop + bilinear resize = the native tensor_resize)
+  L2  [B,264,145]^2 cost -> log_optimal_transport2 145x145, 100 sweeps, +ln2 dustbin
       -> argmax + 8-step expansion
-  L3  per chunk [60*B,128,65]^2 cost -> log_optimal_transport2 65x65, 100 sweeps -> Compute_result
-Descriptors are synthetic (no weights/datasets exist for the reference here); P = 60*B is the
-SURVEY's chosen fill.  `value` = pairs/sec over all ranks (pairs shard across ranks, no data-path
-collective; "weak" scaling).  One JSON line on rank 0.
+  L3  [60*B,128,65]^2 cost -> log_optimal_transport2 65x65, 100 sweeps -> Compute_result + label
+  out refine scatter (pats.py:59-67) + get_result (utils.py:189-213): matches_l / matches_r
+The step makes NO host read: the chunk plan is computed on the device (pats_split_patches_device), the
+crop gathers and get_result run over their capacity with device-side counts (the reference syncs at
+every boolean mask).  Descriptors are synthetic (no weights/datasets exist for the reference here);
+P = 60*B is the SURVEY's chosen fill.  `value` = pairs/sec over all ranks (pairs shard across ranks,
+no data-path collective; "weak" scaling); after the timed region every rank's matches of its last
+step are gathered to rank 0 over RCCL (shard.gather_matches), timed separately as `gather_ms`.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself
+(torch.distributed.run on 127.0.0.1); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+One JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +38,7 @@ sys.path.insert(0, REPO)
 from pats_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 ITERS = 100
 ONE = [None]            # device-resident 1.0 (the reference's `self.one`, second_layer.py:63)
 
@@ -40,8 +51,9 @@ def parse():
     ap.add_argument("--pairs", type=int, default=16, help="image pairs per step per rank")
     ap.add_argument("--fill", type=int, default=60, help="third-level problems per fine problem (P = fill*B)")
     ap.add_argument("--per-chunk", action="store_true",
-                    help="run the fine/third stages once per coarse chunk like the reference's loop")
+                    help="run Compute_imgs once per coarse chunk like the reference's loop (one host read per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline measurements")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     return ap.parse_args()
 
@@ -63,13 +75,13 @@ def scale_head(shape, dev, gen):
 
 class Workload:
     """Device-resident synthetic inputs of `pairs` 640x480 pairs.  Stages are batched ACROSS pairs
-    (and across the coarse chunks, unless --per-chunk): the reference walks pairs and chunks in
-    Python loops (evaluate.py:25, pats.py:33) only because it targets one 16-40 GB card; every
-    coarse / fine / third-level problem is independent, so with 288 GB each stage is one launch."""
+    and across the coarse chunks: the reference walks pairs and chunks in Python loops
+    (evaluate.py:25, pats.py:33) only because it targets one 16-40 GB card; every coarse / fine /
+    third-level problem is independent, so with 288 GB each stage is one launch."""
 
     def __init__(self, ops, dev, gen, pairs, fill, per_chunk=False):
         c = synth.coarse_inputs()
-        self.pairs, self.h, self.w = pairs, c["h"], c["w"]
+        self.pairs, self.h, self.w, self.fill = pairs, c["h"], c["w"], fill
         self.per_chunk_imgs = per_chunk
         rep = lambda a: torch.from_numpy(a).to(dev).repeat(pairs, *([1] * (a.ndim - 1))).contiguous()  # noqa: E731
         self.d0, self.d1, self.ns = rep(c["d0"]), rep(c["d1"]), rep(c["ns"])
@@ -78,92 +90,166 @@ class Workload:
         self.left, self.right = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
         self.lefts = self.left.expand(pairs, -1, -1, -1).contiguous()       # every pair: the same synthetic image
         self.rights = self.right.expand(pairs, -1, -1, -1).contiguous()
-        # dry run of the coarse stage to learn the (deterministic) chunk plan
-        self.plan = coarse_stage(ops, self)[0]
+        # dry run of the coarse stage (with a host read) to learn the deterministic chunk plan
+        self.plan, self.counts = coarse_plan_host(ops, self)
+        self.C = len(self.plan)
         B1 = sum(self.plan)
-        groups = [b * pairs for b in self.plan] if per_chunk else [B1 * pairs]
-        self.chunks = []
-        for B in groups:
-            f0, f1 = desc_pair((B, 264, 145), dev, gen, drop=0.12)
-            f0[:, :, -1] *= 0.5
-            f1[:, :, -1] *= 0.5
-            sx, sy = scale_head((B, 1, 144), dev, gen), scale_head((B, 1, 144), dev, gen)
-            P = fill * B
-            t0, t1 = desc_pair((P, 128, 65), dev, gen, drop=0.12)
-            t0[:, :, -1] *= 0.5
-            t1[:, :, -1] *= 0.5
-            sc = scale_head((P, 1, 64), dev, gen)
-            p_s = (torch.randint(1, 23, (P, 2), device=dev, generator=gen) * 4)
-            p_t = (torch.randint(0, 25, (P, 2), device=dev, generator=gen) * 4)
-            self.chunks.append(dict(B=B, P=P, f0=f0, f1=f1, sx=sx, sy=sy, ns2=(sx * sy).contiguous(), t0=t0,
-                                    t1=t1, sc=sc, p_s=p_s, p_t=p_t))
-        self.B = B1
-        self.P = fill * B1
+        B = B1 * pairs
+        f0, f1 = desc_pair((B, 264, 145), dev, gen, drop=0.12)
+        f0[:, :, -1] *= 0.5
+        f1[:, :, -1] *= 0.5
+        sx, sy = scale_head((B, 1, 144), dev, gen), scale_head((B, 1, 144), dev, gen)
+        P = fill * B
+        t0, t1 = desc_pair((P, 128, 65), dev, gen, drop=0.12)
+        t0[:, :, -1] *= 0.5
+        t1[:, :, -1] *= 0.5
+        sc = scale_head((P, 1, 64), dev, gen)
+        p_s = (torch.randint(1, 23, (P, 2), device=dev, generator=gen) * 4)
+        p_t = (torch.randint(0, 25, (P, 2), device=dev, generator=gen) * 4)
+        # the merge's output stand-in (merge_patches_* is out of the bench: its chunks couple through
+        # scores_back, pats.py:32,37): exactly `fill` surviving L2 cells per row, fixed pattern, so that
+        # third-level problem p belongs to the p-th surviving cell as pats.py:53-58 orders them
+        keep = torch.zeros((B, 144), dtype=torch.bool, device=dev)
+        order = torch.argsort(torch.rand((B, 144), device=dev, generator=gen), dim=1)[:, :fill]
+        keep.scatter_(1, order, True)
+        self.chunk = dict(B=B, P=P, f0=f0, f1=f1, sx=sx, sy=sy, ns2=(sx * sy).contiguous(), t0=t0, t1=t1, sc=sc,
+                          p_s=p_s, p_t=p_t, ifn_L2=torch.logical_not(keep).contiguous())
+        self.ones_c = torch.ones((pairs * self.C,), dtype=torch.bool, device=dev)
+        self.ones_b = torch.ones((B,), dtype=torch.bool, device=dev)
+        self.B, self.P = B1, fill * B1
 
 
-def coarse_stage(ops, wl):
-    """first_layer.py:110-146 for all pairs: one batched cost+OT launch, one batched expansion; then
-    per pair the chunk plan (host) and per chunk the subdivision gather.  Returns per-pair plans."""
+def coarse_ops(ops, wl):
+    """first_layer.py:110-135 for all pairs: one batched cost+OT launch, column mass, argmax + expansion."""
     Z = ops.cost_ot(wl.d0, wl.d1, 1, wl.alpha, wl.ns, ITERS)
     scales = ops.colmass_sqrt(Z)
     trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (480, 640), 32)
-    sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1)
-    sc_host = sum_cycle.to("cpu").numpy()          # the step's ONE host read: chunk plans and crop counts of all pairs
-    plans, seconds = [], []
+    sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1, dtype=torch.int32)
+    return pts, xs, ys, ifn1, sum_cycle
+
+
+def coarse_plan_host(ops, wl):
+    """The chunk plan of pair 0 on the HOST (set-up / --per-chunk only): per-chunk row counts, crops per pair."""
+    pts, xs, ys, ifn1, sum_cycle = coarse_ops(ops, wl)
+    sc_host = sum_cycle.to("cpu").numpy()
+    plans = []
     for i in range(wl.pairs):
         n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, 2 * wl.w)
-        seconds.append(second)
+        K = int(sc_host[i, -1])
+        plans.append([min(hi, K) - lo for lo, hi in second])
+    assert all(p == plans[0] for p in plans)
+    return plans[0], [int(sc_host[i, -1]) for i in range(wl.pairs)]
+
+
+def coarse_stage(ops, wl):
+    """first_layer.py:110-146 for all pairs, no host read: OT + expansion, the chunk plan on the device, and
+    ONE subdivision gather for the whole step (Compute_imgs takes a batch of images, crops ordered
+    (image, patch); chunk c of pair i is a contiguous run of it because the cumsum is monotone -
+    tests/test_gpu_parity.py::test_chunk_crops_are_slices, ::test_compute_imgs_batch_of_images)."""
+    pts, xs, ys, ifn1, sum_cycle = coarse_ops(ops, wl)
     if wl.per_chunk_imgs:
-        # the reference's loop (first_layer.py:136-146): one Compute_imgs per pair and chunk mask
+        # the reference's loop (first_layer.py:136-146): host plan, one Compute_imgs per pair and chunk mask
+        sc_host = sum_cycle.to("cpu").numpy()
         for i in range(wl.pairs):
-            plan = []
-            for lo, hi in seconds[i]:
+            n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, 2 * wl.w)
+            for lo, hi in second:
                 mask = torch.logical_or(ifn1[i:i + 1], torch.logical_or(sum_cycle[i:i + 1] <= lo,
                                                                         sum_cycle[i:i + 1] > hi))
-                nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left,
-                                                         wl.right, width=wl.w, height=wl.h)
-                plan.append(int(nr.shape[0]))
-            plans.append(plan)
-        return plans
-    # One gather for the whole step: Compute_imgs takes a batch of images (crops ordered image, patch),
-    # and chunk c of pair i is rows [off_i + lo, off_i + min(hi, K_i)) of it - the cumsum is monotone, so
-    # a chunk mask selects a contiguous run of matched patches
-    # (tests/test_gpu_parity.py::test_chunk_crops_are_slices, ::test_compute_imgs_batch_of_images).
-    counts = [int(sc_host[i, -1]) for i in range(wl.pairs)]
-    nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs, ys, pts, ifn1, wl.lefts, wl.rights, width=wl.w, height=wl.h,
-                                             known_count=counts)
-    off = 0
-    for i in range(wl.pairs):
-        K = counts[i]
-        views = [(nl[off + lo:off + min(hi, K)], nr[off + lo:off + min(hi, K)]) for lo, hi in seconds[i]]
-        plans.append([v[1].shape[0] for v in views])
-        off += K
-    return plans
+                ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left, wl.right, width=wl.w,
+                                 height=wl.h)
+        num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, 2 * wl.w)
+        nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs, ys, pts, ifn1, wl.lefts, wl.rights, width=wl.w, height=wl.h,
+                                                 known_count=wl.counts)
+        return dict(ifn1=ifn1, sum_cycle=sum_cycle, second=second, num=num, xsn=xsn, avn=avn)
+    num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, 2 * wl.w)
+    nl, nr, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(xs, ys, pts, ifn1, wl.lefts, wl.rights,
+                                                                      width=wl.w, height=wl.h, known_count="device")
+    return dict(ifn1=ifn1, sum_cycle=sum_cycle, second=second, num=num, xsn=xsn, avn=avn, K_img=K_img)
 
 
-def fine_and_third(ops, ch, ev):
+def fine_and_third(ops, wl, co, ev):
+    ch = wl.chunk
+    if ev is not None:
+        f0_, f1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0_.record()
     Z2 = ops.cost_ot(ch["f0"], ch["f1"], 2, ONE[0], ch["ns2"], ITERS, bias_k=2.0)
-    out2 = ops.est_position_second(Z2, ch["sx"], ch["sy"], [96, 96], 8)
+    if ev is not None:
+        f1_.record()
+        ev["fine"].append((f0_, f1_))
+    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, ch["sx"], ch["sy"], [96, 96], 8)
     # third level: cost build + OT + exp + Compute_result + label in ONE launch (the dominant kernel)
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    res = ops.third_level(ch["t0"], ch["t1"], ch["sc"], ch["p_s"], ch["p_t"], outdoor=True, iters=ITERS)
+    m0f, m1f, label, ifm = ops.third_level(ch["t0"], ch["t1"], ch["sc"], ch["p_s"], ch["p_t"], outdoor=True, iters=ITERS)
     if ev is not None:
         e1.record()
-        ev.append((e0, e1, ch["P"]))
-    return out2, res
+        ev["third"].append((e0, e1, ch["P"]))
+    # results (pats.py:59-78): third-level matches scattered onto the 48x48 sub-cell grid, then get_result
+    # with the (pair, chunk) masks of first_layer.py:137-138 as its level-0 batch - all on the device
+    ifn16, pts16 = ops.refine_scatter(ch["ifn_L2"], pts2, m1f, label)
+    C, N = wl.C, wl.h * wl.w
+    lo, hi = co["second"][:, :C, 0:1], co["second"][:, :C, 1:2]                    # [pairs,C,1]
+    sc3 = co["sum_cycle"][:, None, :]
+    masks = torch.logical_or(co["ifn1"][:, None, :], torch.logical_or(sc3 <= lo, sc3 > hi)).reshape(-1, N)
+    xs_c = co["xsn"][:, None].expand(-1, C, -1, -1).reshape(-1, N, 2)
+    av_c = co["avn"][:, None].expand(-1, C, -1, -1).reshape(-1, N, 2)
+    # pats.py:70 `x_scale_new[~mask]` without its host sync: a stable sort lists the unmasked cells in order
+    cells = torch.argsort(masks.reshape(-1).to(torch.uint8), stable=True)[:ch["B"]]
+    sc_rows = xs_c.reshape(-1, 2)[cells]
+    ml, mr, M = ops.get_result(wl.pairs * C, [masks, ifn16], [av_c.flip(dims=[2]) / 32.0, pts16.flip(dims=[2]) / 2.0],
+                               [xs_c.contiguous(), sc_rows], [[32, wl.h, wl.w], [2, 48, 48]], [wl.ones_c, wl.ones_b],
+                               validate=False, sync=False)
+    return dict(ml=ml, mr=mr, M=M, masks=masks, ifn16=ifn16, label=label, ifm=ifm, m1f=m1f)
 
 
 def step(ops, wl, ev):
-    coarse_stage(ops, wl)
-    for ch in wl.chunks:
-        fine_and_third(ops, ch, ev)
+    co = coarse_stage(ops, wl)
+    return co, fine_and_third(ops, wl, co, ev)
 
 
-def cpu_baseline(pairs_B, pairs_P, seconds):
+def local_matches(wl, co, out, rank, world):
+    """Per-pair (matches_l, matches_r) of this rank's last step, outside the clock: get_result emits rows in
+    (pair, chunk, patch, sub-cell) order, so pair i owns a contiguous run whose length is the number of
+    surviving sub-cells of its rows."""
+    C = wl.C
+    rows_per_mask = torch.logical_not(out["masks"]).sum(dim=1).reshape(wl.pairs, C).sum(dim=1).cpu().tolist()
+    per_row = torch.logical_not(out["ifn16"]).sum(dim=1).cpu().numpy()
+    M = int(out["M"].item())
+    res, r0, m0 = [], 0, 0
+    for i in range(wl.pairs):
+        k = int(per_row[r0:r0 + rows_per_mask[i]].sum())
+        res.append((rank + i * world, out["ml"][m0:m0 + k], out["mr"][m0:m0 + k]))
+        r0 += rows_per_mask[i]
+        m0 += k
+    assert m0 == M, "get_result count %d != per-pair total %d" % (M, m0)
+    return res
+
+
+def torch_cpu_sinkhorn(Z, log_mu, log_nu, iters):
+    """What the reference executes on CPU (modules.py:137-143), transcribed: logsumexp row / column sweeps."""
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    return Z + u.unsqueeze(2) + v.unsqueeze(1)
+
+
+def torch_cpu_ot2(scores, ns, iters):
+    b, m, n = scores.shape
+    ms = torch.tensor(float(m - 1))
+    nssum = ns.sum(dim=2)                                             # [b,1]
+    norm = -(ms + nssum).log()
+    log_nu = torch.cat([ns.log()[:, 0] + norm, ms.log().expand(b, 1) + norm], dim=1)
+    log_mu = torch.cat([norm.expand(b, m - 1), nssum.log() + norm], dim=1)
+    return torch_cpu_sinkhorn(scores, log_mu, log_nu, iters) - norm[:, :, None]
+
+
+def cpu_baseline(ops, dev, pairs_B, pairs_P, seconds):
     """The CPU oracle ("port") on the host cores: L1 in full, bounded samples of L2/L3 scaled to one
-    pair.  Checker code timed as a baseline only - never part of the measured GPU path."""
+    pair, plus the torch-CPU transcription of the Sinkhorn loop on the same samples.  Checker code timed
+    as a baseline only - never part of the measured GPU path.  The HIP path is also run on the same L2 /
+    L3 samples and compared with the oracle's answers (reported, not asserted, as `parity_sample`)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import pats_oracle as oracle
     cores = oracle.num_threads()
@@ -181,8 +267,8 @@ def cpu_baseline(pairs_B, pairs_P, seconds):
     t0 = time.perf_counter()
     S2 = oracle.cost(f["d0"], f["d1"])
     Z2 = oracle.dustbin_bias(oracle.log_optimal_transport2(S2, 1.0, f["scale_x"] * f["scale_y"], ITERS), 2.0)
-    oracle.argmax(Z2)
-    oracle.iterative_expand(np.exp(Z2), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8)
+    r2, c2 = oracle.argmax(Z2)
+    ex2 = oracle.iterative_expand(np.exp(Z2), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8)
     t_l2 = (time.perf_counter() - t0) / nb
     # L3 sample sized to the remaining budget
     probe = synth.third_inputs(seed=78, P=4 * cores)
@@ -196,20 +282,135 @@ def cpu_baseline(pairs_B, pairs_P, seconds):
     t0 = time.perf_counter()
     S3 = oracle.cost(t3in["d0"], t3in["d1"])
     Z3 = oracle.log_optimal_transport2(S3, 1.0, t3in["scale"], ITERS)
-    oracle.compute_result(np.exp(Z3), sq, sq, t3in["p_s"], t3in["p_t"], True)
+    r0, r1, rwl, rlabel, rifm = oracle.compute_result(np.exp(Z3), sq, sq, t3in["p_s"], t3in["p_t"], True)
     t_l3 = (time.perf_counter() - t0) / np3
     per_pair = t_l1 + t_l2 * pairs_B + t_l3 * pairs_P
+
+    # the same samples through the HIP path: indices must be identical, transport mass within 1e-4
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    g0, g1, glabel, gifm = ops.third_level(td(t3in["d0"]), td(t3in["d1"]), td(t3in["scale"]), td(t3in["p_s"]),
+                                           td(t3in["p_t"]), outdoor=True, iters=ITERS)
+    gZ2 = ops.cost_ot(td(f["d0"]), td(f["d1"]), 2, 1.0, td(f["scale_x"] * f["scale_y"]), ITERS, bias_k=2.0)
+    g2 = ops.est_position_second(gZ2, td(f["scale_x"]), td(f["scale_y"]), [96, 96], 8)
+    gr2, gc2 = ops.argmax(gZ2)
+    e2, e2r = np.exp(gZ2.cpu().numpy().astype(np.float64)), np.exp(Z2.astype(np.float64))
+    parity = {
+        "l3_problems": np3, "l3_label_mismatch": int((glabel.cpu().numpy() != rlabel).sum()),
+        "l3_if_matching_mismatch": int((gifm.cpu().numpy().astype(bool) != rifm.astype(bool)).sum()),
+        "l3_mkpts0_mismatch": int((g0.cpu().numpy() != r0).sum()),
+        "l3_mkpts1_max_abs_diff_px": float(np.abs(g1.cpu().numpy() - r1).max()),
+        "l2_problems": nb, "l2_row_argmax_mismatch": int((gr2.cpu().numpy() != r2).sum()),
+        "l2_col_argmax_mismatch": int((gc2.cpu().numpy() != c2).sum()),
+        "l2_mass_max_abs_diff": float(np.abs(e2[:, :-1, :-1] - e2r[:, :-1, :-1]).max()),
+        "l2_trust_max_abs_diff": float(np.abs(g2[0].cpu().numpy() - ex2[0]).max()),
+    }
+
+    # torch-CPU transcription of modules.py:137-182 on the same L1 problem and (smaller) L2 / L3 samples
+    torch.set_num_threads(cores)
+    tS = torch.from_numpy(S)
+    tns = torch.from_numpy(c["ns"])
+    t0 = time.perf_counter()
+    b, m, n = tS.shape
+    alpha = torch.tensor(float(c["alpha"]))
+    coup = torch.cat([torch.cat([tS, alpha.expand(b, m, 1)], -1), alpha.expand(b, 1, n + 1)], 1)
+    msn = torch.tensor(float(m))
+    norm = -(msn + tns.sum(dim=2)).log()
+    log_nu = torch.cat([tns.log()[:, 0] + norm, msn.log().expand(b, 1) + norm], dim=1)
+    log_mu = torch.cat([norm.expand(b, m), tns.sum(dim=2).log() + norm], dim=1)
+    torch_cpu_sinkhorn(coup, log_mu, log_nu, ITERS)
+    tt1 = time.perf_counter() - t0
+    n2 = min(nb, 64)
+    t0 = time.perf_counter()
+    torch_cpu_ot2(torch.from_numpy(S2[:n2]), torch.from_numpy((f["scale_x"] * f["scale_y"])[:n2]), ITERS)
+    tt2 = (time.perf_counter() - t0) / n2
+    n3 = min(np3, 1024)
+    t0 = time.perf_counter()
+    torch_cpu_ot2(torch.from_numpy(S3[:n3]), torch.from_numpy(t3in["scale"][:n3]), ITERS)
+    tt3 = (time.perf_counter() - t0) / n3
+    torch_pair = tt1 + tt2 * pairs_B + tt3 * pairs_P
     return {"value": 1.0 / per_pair, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle/pats_oracle.c (OpenMP over problems): L1 301x301 in full (%.3fs), %d L2 "
-                      "problems (%.4fs each), %d L3 problems (%.5fs each), scaled to B=%d, P=%d per pair"
-                      % (t_l1, nb, t_l2, np3, t_l3, pairs_B, pairs_P)}
+            "sample": "oracle/pats_oracle.c (OpenMP over problems), EXTRAPOLATED from samples: L1 301x301 in full "
+                      "(%.3fs), %d L2 problems (%.4fs each), %d L3 problems (%.5fs each), scaled to B=%d, P=%d per pair"
+                      % (t_l1, nb, t_l2, np3, t_l3, pairs_B, pairs_P),
+            "torch_cpu": {"value": 1.0 / torch_pair, "unit": "pairs/s", "cores": cores,
+                          "sample": "torch.logsumexp transcription of modules.py:137-182 (Sinkhorn only, no cost build / "
+                                    "expansion), %d torch threads, EXTRAPOLATED: L1 301x301 (%.3fs), %d L2 (%.4fs each), "
+                                    "%d L3 (%.5fs each) scaled to B=%d, P=%d" % (cores, tt1, n2, tt2, n3, tt3, pairs_B, pairs_P)},
+            "parity_sample": parity}
+
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary_rooflines(ops, dev, wl, fine_ms):
+    """Other kernels of the path against their nearer roofline (live HIP-event timings; rocprof counterparts
+    under profiles/r02_*).  Config 5 = BASELINE.json configs[4]."""
+    out = []
+    r = synth.roofline_inputs()
+    d0, d1, ns = [torch.from_numpy(r[k]).to(dev) for k in ("d0", "d1", "ns")]
+    N, D = d0.shape[2], d0.shape[1]
+    ms = timed(lambda: ops.cost(d0, d1))
+    tf = 2.0 * D * N * N / (ms * 1e-3) / 1e12
+    out.append({"kernel": "cost_mfma_kernel, config 5 (4096^2 x %d)" % D, "bound": "mfma", "achieved": tf,
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS, "ms": ms,
+                "profile": "profiles/r02_config5_kernel_stats.md"})
+    S = ops.cost(d0, d1)
+    alpha = torch.tensor(float(r["alpha"]), device=dev)
+    iters5 = 200
+    ms = timed(lambda: ops.log_optimal_transport(S, alpha, ns, iters5), reps=3, warm=1)
+    M = N + 1
+    gbs = 8.0 * M * M * iters5 / (ms * 1e-3) / 1e9
+    out.append({"kernel": "stream_sweep_kernel, config 5 (4097^2, %d sweeps)" % iters5, "bound": "hbm", "achieved": gbs,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms,
+                "sweeps_per_s": iters5 / (ms * 1e-3),
+                "note": "algorithmic 8*M*N bytes per sweep; the 67 MB matrix is Infinity-Cache (256 MiB) resident, so "
+                        "this can exceed the DRAM roofline - labelled, not a DRAM claim",
+                "profile": "profiles/r02_config5_kernel_stats.md"})
+    del S, d0, d1
+    ch = wl.chunk
+    ms = timed(lambda: ops.cost(ch["f0"], ch["f1"]))
+    tf = 2.0 * 264 * 145 * 145 * ch["B"] / (ms * 1e-3) / 1e12
+    out.append({"kernel": "cost_mfma_kernel, fine level (%d x [264,145]^2)" % ch["B"], "bound": "mfma", "achieved": tf,
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS, "ms": ms})
+    if fine_ms is not None:
+        by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * ch["B"]
+        gbs = by / (fine_ms * 1e-3) / 1e9
+        out.append({"kernel": "fine-level cost + Sinkhorn (%d x 145x145, descriptors in, log-plan out)" % ch["B"],
+                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "ms": fine_ms, "sweep_elements_per_s": 2.0 * ITERS * 145 * 145 * ch["B"] / (fine_ms * 1e-3),
+                    "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * ch["B"] / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS})
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU over RCCL
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # plumbing-test knobs (a 1-GPU box cannot host two RCCL ranks): PATS_BENCH_SHARE_DEVICE=1 maps every
@@ -227,7 +428,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    from pats_amd import ops
+        assert dist.get_world_size() == args.gpus
+    from pats_amd import ops, shard
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(synth.SEED + rank)
@@ -242,12 +444,12 @@ def main():
 
     for _ in range(args.warmup):
         step(ops, wl, None)
-    ev = []
+    ev = {"third": [], "fine": []}
     barrier()
     ops.sinkhorn_fallbacks(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(ops, wl, ev)
+        co, out = step(ops, wl, ev)
     barrier()
     dt = time.perf_counter() - t0
     fallbacks = ops.sinkhorn_fallbacks(reset=True)       # after the timed region (it synchronises)
@@ -255,12 +457,27 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_pairs = args.pairs * args.steps * world
+    n_gpus = dist.get_world_size() if dist is not None else 1
+    total_pairs = args.pairs * args.steps * n_gpus
     value = total_pairs / dt
 
-    # dominant kernel: the 65x65 third-level Sinkhorn launch (HIP events on the launch stream)
-    ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
-    probs = np.array([p for _, _, p in ev], dtype=np.float64)
+    # the path's only exchange: the last step's matches of every rank -> rank 0 (RCCL), outside the clock
+    local = local_matches(wl, co, out, rank, n_gpus)
+    barrier()
+    t0 = time.perf_counter()
+    gathered = shard.gather_matches(local, args.pairs * n_gpus)
+    barrier()
+    gather_ms = 1e3 * (time.perf_counter() - t0)
+    matches_per_pair = None
+    if rank == 0:
+        assert all(g is not None for g in gathered), "gather_matches lost a pair"
+        matches_per_pair = float(np.mean([g[0].shape[0] for g in gathered]))
+        gather_bytes = sum(g[0].shape[0] for g in gathered) * 16
+
+    # dominant kernel: the 65x65 third-level launch (HIP events on the launch stream)
+    ms = np.array([a.elapsed_time(b) for a, b, _ in ev["third"]])
+    probs = np.array([p for _, _, p in ev["third"]], dtype=np.float64)
+    fine_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fine"]]))
     # algorithmic HBM bytes per problem of the fused third-level kernel: both descriptor blocks in
     # (2 x 128 x 65 fp32), areas + coarse points in, 16 matches + labels + flags out; the 65x65 plan
     # stays on chip (SURVEY 8d "cost build: 4*D*(M+N) in, 0 out if fused")
@@ -268,33 +485,40 @@ def main():
     alg_bytes = float(BYTES_PER_PROBLEM) * probs
     achieved = float((alg_bytes / (ms * 1e-3)).mean() / 1e9)
     exp_rate = float((2.0 * ITERS * 65 * 65 * probs / (ms * 1e-3)).mean())
+    # fp32 VALU work of the kernel as flops: 2 half-sweeps x 65 x 65 FMAs (2 flops) per sweep per problem
+    valu_tflops = float((2.0 * 2.0 * ITERS * 65 * 65 * probs / (ms * 1e-3)).mean() / 1e12)
     sweeps_per_pair = ITERS * (1 + B + P)        # one sweep = row + column normalisation of one problem
 
     # HBM traffic of the dominant kernel from rocprofv3 PMC passes (collected separately, see the file)
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_third.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
-        traffic = float(pmc["hbm_bytes_per_problem"]) * float(probs.mean())
-        traffic_src = "profiles/r01_pmc_third.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), " \
-                      "FETCH calibrated x%.2f on cost65_kernel's known byte count; per problem x problems per launch" \
-                      % pmc["fetch_calibration"]["factor"]
+    for name in ("r02_pmc_third.json", "r01_pmc_third.json"):
+        pmc_path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            traffic = float(pmc["hbm_bytes_per_problem"]) * float(probs.mean())
+            traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH calibrated " \
+                          "x%.2f on cost65_kernel's known byte count; per problem x problems per launch" \
+                          % (name, pmc["fetch_calibration"]["factor"])
+            break
 
-    out = {
+    res = {
         "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",
-        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: MegaDepth 640x480 shapes, outdoor coarse+fine+third OT + cost volume "
-                               "+ expansion + subdivision gather",
-                   "pairs_per_step_per_rank": args.pairs, "batching": "each stage is one launch over all pairs of the step", "L1": "1x[448,300]^2 -> 301x301",
-                   "L2": "%d x [264,145]^2 -> 145x145 (%d coarse chunks, %s)"
-                         % (B, len(wl.plan), "one launch per chunk" if args.per_chunk else "batched into one launch"),
+                               "+ expansion + subdivision gather + get_result",
+                   "pairs_per_step_per_rank": args.pairs,
+                   "batching": "each stage is one launch over all pairs of the step; no host read inside a step",
+                   "L1": "1x[448,300]^2 -> 301x301",
+                   "L2": "%d x [264,145]^2 -> 145x145 (%d coarse chunks, batched into one launch)" % (B, len(wl.plan)),
                    "L3": "%d x [128,65]^2 -> 65x65 (fill %d)" % (P, args.fill), "sinkhorn_iters": ITERS,
-                   "parallelism": "pairs sharded over %d rank(s), no data-path collective" % world},
+                   "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
+                                  "after the timed region (%s)" % (n_gpus, backend if dist is not None else "single process")},
         "ot_iters_per_sec": value * sweeps_per_pair,
         "guard_fallbacks_per_step": fallbacks / max(1, args.steps),
-        "roofline": {"bound": "hbm", "kernel": "third_fused_kernel (fused third level, %d problems per launch)" % wl.chunks[0]["P"],
+        "gather_ms": gather_ms, "matches_per_pair": matches_per_pair,
+        "roofline": {"bound": "hbm", "kernel": "third_fused_kernel (fused third level, %d problems per launch)" % wl.chunk["P"],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -302,18 +526,23 @@ def main():
                      "avg_launch_ms": float(ms.mean()), "launches": int(len(ms)),
                      "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
                      "sweep_elements_per_s": exp_rate,
+                     "valu_frac": valu_tflops / F32_PEAK_TFLOPS, "valu_tflops": valu_tflops,
                      "mfma_flops_per_s": float((2.0 * 128 * 64 * 64 * probs / (ms * 1e-3)).mean()),
                      "note": "fused cost build (fp32 MFMA) + 100 linear-domain Sinkhorn sweeps + Compute_result per 65x65 problem, "
                              "one wave each, the 65x65 block held in registers; descriptors are read once, the plan never "
-                             "reaches HBM.  HBM is the nearest of the two allowed rooflines but not the limiter: SQ counters "
-                             "(profiles/r01_pmc_third.json) show the sweeps VALU-issue bound at 92 % SIMD issue utilisation"},
+                             "reaches HBM.  HBM is the nearest of the two allowed rooflines but not the limiter: the sweeps "
+                             "are fp32 VALU work (valu_frac = sweep FMA flops / 157.3 TF/s vector peak)"},
     }
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(B, P, args.cpu_seconds)
+        if n_gpus > 1:
+            res["gather_bytes"] = gather_bytes
+        if not args.no_secondary and n_gpus == 1:
+            res["roofline_secondary"] = secondary_rooflines(ops, dev, wl, fine_ms)
+        if not args.no_cpu_baseline and n_gpus == 1:
+            res["cpu_baseline"] = cpu_baseline(ops, dev, B, P, args.cpu_seconds)
         else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -47,7 +47,8 @@ int pats_set_sinkhorn_mode(int mode);
 
 /* Number of problems (on the current device, since the last reset) whose linear-domain solve left the
  * guard band and was re-solved with log-sum-exp sweeps.  Results are the same either way; a high rate
- * only costs time.  Synchronous (device -> host copy of one counter).  No reference counterpart. */
+ * only costs time.  Synchronises the whole device (hipDeviceSynchronize) before the read and after the
+ * reset, so launches on any stream are counted and none races with the reset.  No reference counterpart. */
 int pats_sinkhorn_fallbacks(int64_t* count, int reset);
 
 /* ---- a1-a3: cost build -------------------------------------------------------------------
@@ -79,7 +80,10 @@ int pats_log_optimal_transport_f32(const float* scores, int64_t batch, int m, in
 /* ---- a5: log_optimal_transport2(scores, one, ns, iters)  models/modules.py:165-182 ---------
  * scores [batch,m,n] whose last row/col are already the dustbin; one: DEVICE pointer to one float
  * or NULL (= 1.0f); ns [batch,n-1] -> Z [batch,m,n].  bias_k > 0 additionally applies the
- * caller's  Z[:,:,-1] += log(k); Z[:,-1,:] += log(k)  (second_layer.py:107-112); 0 = none. */
+ * caller's  Z[:,:,-1] += log(k); Z[:,-1,:] += log(k)  (second_layer.py:107-112); 0 = none.
+ * workspace: pats_ot2_workspace_bytes(batch, m, n) - 0 for 65 x 65, one guard flag per problem for
+ * 145 x 145 (the resident kernels), pats_ot_workspace_bytes otherwise. */
+size_t pats_ot2_workspace_bytes(int64_t batch, int m, int n);
 int pats_log_optimal_transport2_f32(const float* scores, int64_t batch, int m, int n,
                                     const float* one, const float* ns, int iters, float bias_k,
                                     float* Z, void* workspace, size_t workspace_bytes,
@@ -128,6 +132,12 @@ int pats_iterative_expand_f32(const float* P, int input_is_log, int64_t batch, i
  * a negative PATS_ERR code. */
 int pats_split_patches(const int32_t* sum_cycle_host, int height, int width, int max_once_used,
                        int64_t* second_layer_set, int64_t* third_layer_set);
+/* The same planner on the DEVICE for a batch of pairs (throughput mode: no host read at all):
+ * sum_cycle [pairs, height*width] int32 device cumsums -> second/third [pairs, height+1, 2] int64
+ * (unused rows zeroed) and cycle_num [pairs] int32, all device memory.  One thread per pair. */
+int pats_split_patches_device(const int32_t* sum_cycle, int64_t pairs, int height, int width,
+                              int max_once_used, int64_t* second_layer_set, int64_t* third_layer_set,
+                              int32_t* cycle_num, pats_stream_t stream);
 
 /* ---- a13: Compute_imgs bounds  utils/utils.py:1350-1382 ------------------------------------
  * x_scale, y_scale [Np]; average_point [Np,2]; if_nomatching [Np] uint8; grid (height,width).
@@ -146,6 +156,19 @@ int pats_compute_imgs_bounds_f32(const float* x_scale, const float* y_scale,
 int pats_left_crops_f32(const float* left, int n_img, int H, int W, const int64_t* bound5, int64_t K,
                         int height, int width, float* out, pats_stream_t stream);
 
+/* a13 for a BATCH of images without host-side counts (throughput mode).  x_scale, y_scale [n_img,Np],
+ * average_point [n_img,Np,2], if_nomatching [n_img,Np] -> bound5 [n_img*Np,5] compacted in (image, patch)
+ * order (sequence = img * 10000 + patch, utils.py:1374-1377), K_img [n_img] matches per image and
+ * K_total [1] = valid rows of bound5 (DEVICE int64), x_scale_new, y_scale_new, average_new [n_img,Np,2].
+ * The `_counted` gathers are launched over K_cap rows and skip rows >= *K_dev. */
+int pats_compute_imgs_bounds_batch_f32(const float* x_scale, const float* y_scale, const float* average_point,
+                                       const uint8_t* if_nomatching, int n_img, int Np, int height, int width,
+                                       int64_t* bound5, int64_t* K_img, int64_t* K_total, float* x_scale_new,
+                                       float* y_scale_new, float* average_new, pats_stream_t stream);
+int pats_left_crops_counted_f32(const float* left, int n_img, int H, int W, const int64_t* bound5,
+                                int64_t K_cap, const int64_t* K_dev, int height, int width, float* out,
+                                pats_stream_t stream);
+
 /* ---- a14: tensor_resize(input, bound)  setup/library.cpp:47-66 (module def :92-93) ----------
  * input [n_img,C,Hp,Wp] fp32; bound [K,5] int64 (y0,y1,x0,x1,seq), image = seq / 10000;
  * crop rows [y0,y1) x cols [x0,x1] -> bilinear align_corners=True -> out [K,C,96,96].
@@ -161,6 +184,9 @@ int pats_tensor_resize_f32(const float* input, int n_img, int C, int Hp, int Wp,
 int pats_tensor_resize_hwc_f32(const float* right, int n_img, int H, int W, int margin,
                                const int64_t* bound, int64_t K, float* out, int32_t* status,
                                pats_stream_t stream);
+int pats_tensor_resize_hwc_counted_f32(const float* right, int n_img, int H, int W, int margin,
+                                       const int64_t* bound, int64_t K_cap, const int64_t* K_dev, float* out,
+                                       int32_t* status, pats_stream_t stream);
 
 /* ---- a17 + a18: ThirdLayer.Compute_result + match label  models/third_layer.py:161-170,184-217
  * scores [P,65,65] = exp(Z) (or Z when input_is_log); scale_x, scale_y [P,64]; p_s, p_t [P,2]

@@ -26,6 +26,7 @@ SIGNATURES = {
     "pats_ot_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "pats_log_optimal_transport_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_ot2_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "pats_log_optimal_transport2_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
                                                 c_f, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_cost_ot_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p,
@@ -39,6 +40,13 @@ SIGNATURES = {
                                           c_int, c_int, c_f, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "pats_split_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pats_split_patches_device": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pats_compute_imgs_bounds_batch_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pats_left_crops_counted_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p, c_int, c_int,
+                                            c_void_p, c_void_p]),
+    "pats_tensor_resize_hwc_counted_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p,
+                                                   c_void_p, c_void_p, c_void_p]),
     "pats_compute_imgs_bounds_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p]),

@@ -19,7 +19,7 @@ extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int 
     if (variant == 2 && n == 65 && m == 65 && (D % 32) == 0 && D <= 512) return 0;
     const size_t scores = align256((size_t)batch * n * m * sizeof(float));
     const int M = variant == 1 ? n + 1 : n, N = variant == 1 ? m + 1 : m;
-    return scores + pats_ot_workspace_bytes(batch, M, N);
+    return scores + (variant == 1 ? pats_ot_workspace_bytes(batch, M, N) : pats_ot2_workspace_bytes(batch, M, N));
 }
 
 extern "C" int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,

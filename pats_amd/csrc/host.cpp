@@ -75,8 +75,13 @@ extern "C" int pats_sinkhorn_fallbacks(int64_t* count, int reset) {
     unsigned long long* p = fallback_counter();
     PATS_REQUIRE(p, "sinkhorn_fallbacks: no counter on this device");
     unsigned long long v = 0;
+    // Kernels that bump the counter run on the caller's (possibly non-blocking) streams, which the
+    // null-stream copy below does not wait for: drain the device first, so that the read sees every
+    // launch issued so far and the reset cannot race with a kernel still in flight.
+    if (hipDeviceSynchronize() != hipSuccess) return check_launch("sinkhorn_fallbacks");
     if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return check_launch("sinkhorn_fallbacks");
-    if (reset && hipMemset(p, 0, sizeof(v)) != hipSuccess) return check_launch("sinkhorn_fallbacks");
+    if (reset && (hipMemset(p, 0, sizeof(v)) != hipSuccess || hipDeviceSynchronize() != hipSuccess))
+        return check_launch("sinkhorn_fallbacks");
     *count = (int64_t)v;
     return PATS_OK;
 }
@@ -86,12 +91,44 @@ extern "C" int pats_sinkhorn_fallbacks(int64_t* count, int reset) {
 // max_once_used * (chunks so far + 1); chunks overlap by one grid row (the third_layer_set pair
 // says how many leading / trailing patches of a chunk belong to the neighbouring chunk).
 // Python's negative index sum_cycle[i*width - 1] at i == 0 (last element) is reproduced.
+namespace pats {
+__host__ __device__ inline int split_patches_plan(const int32_t* sc, int height, int width, int max_once_used,
+                                                  int64_t* second, int64_t* third);
+// one thread per image pair: the plan is ~height comparisons on a cumsum that is already in L2
+__global__ void split_patches_kernel(const int32_t* __restrict__ sc, int64_t pairs, int height, int width,
+                                     int max_once_used, int64_t* __restrict__ second, int64_t* __restrict__ third,
+                                     int32_t* __restrict__ cycle_num) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pairs) return;
+    const int64_t row = 2 * (int64_t)(height + 1);
+    for (int q = 0; q < row; ++q) { second[i * row + q] = 0; third[i * row + q] = 0; }
+    cycle_num[i] = split_patches_plan(sc + i * (int64_t)height * width, height, width, max_once_used,
+                                      second + i * row, third + i * row);
+}
+}  // namespace pats
+
+extern "C" int pats_split_patches_device(const int32_t* sum_cycle, int64_t pairs, int height, int width,
+                                         int max_once_used, int64_t* second, int64_t* third, int32_t* cycle_num,
+                                         pats_stream_t stream) {
+    PATS_REQUIRE(pairs >= 0 && height > 0 && width > 0 && max_once_used > 0, "split_patches_device: bad argument");
+    if (pairs == 0) return PATS_OK;
+    PATS_REQUIRE(sum_cycle && second && third && cycle_num, "split_patches_device: null pointer");
+    hipLaunchKernelGGL(split_patches_kernel, dim3((unsigned)ceil_div(pairs, 64)), dim3(64), 0, as_stream(stream),
+                       sum_cycle, pairs, height, width, max_once_used, second, third, cycle_num);
+    return check_launch("split_patches_kernel");
+}
+
 extern "C" int pats_split_patches(const int32_t* sc, int height, int width, int max_once_used,
                                   int64_t* second, int64_t* third) {
     if (!sc || !second || !third || height <= 0 || width <= 0 || max_once_used <= 0) {
         set_error("split_patches: bad argument");
         return -PATS_ERR_INVALID;
     }
+    return split_patches_plan(sc, height, width, max_once_used, second, third);
+}
+
+__host__ __device__ inline int pats::split_patches_plan(const int32_t* sc, int height, int width, int max_once_used,
+                                                        int64_t* second, int64_t* third) {
     const int64_t L = (int64_t)height * width;
     auto at = [&](int64_t i) -> int64_t { return sc[((i % L) + L) % L]; };
     int cycle = 0, last_second = 0, last_third = 0;

@@ -14,12 +14,12 @@
 namespace pats {
 
 // ---- bounds + ordered compaction of the matched patches --------------------------------------
-__global__ void __launch_bounds__(1024)
-imgs_bounds_kernel(const float* __restrict__ x_scale, const float* __restrict__ y_scale,
-                   const float* __restrict__ average_point, const uint8_t* __restrict__ ifn, int Np,
-                   int height, int width, int img, int64_t* __restrict__ bound5,
-                   int64_t* __restrict__ K_out, float* __restrict__ xsn, float* __restrict__ ysn,
-                   float* __restrict__ avn) {
+__device__ __forceinline__ void
+imgs_bounds_block(const float* __restrict__ x_scale, const float* __restrict__ y_scale,
+                  const float* __restrict__ average_point, const uint8_t* __restrict__ ifn, int Np,
+                  int height, int width, int img, int64_t* __restrict__ bound5,
+                  int64_t* __restrict__ K_out, float* __restrict__ xsn, float* __restrict__ ysn,
+                  float* __restrict__ avn) {
     __shared__ int wave_tot[16];
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,14 +72,57 @@ imgs_bounds_kernel(const float* __restrict__ x_scale, const float* __restrict__ 
         }
         __syncthreads();
     }
-    if (tid == 0) *K_out = base_s;
+    if (tid == 0 && K_out) *K_out = base_s;
+}
+
+__global__ void __launch_bounds__(1024)
+imgs_bounds_kernel(const float* __restrict__ x_scale, const float* __restrict__ y_scale,
+                   const float* __restrict__ average_point, const uint8_t* __restrict__ ifn, int Np,
+                   int height, int width, int img, int64_t* __restrict__ bound5,
+                   int64_t* __restrict__ K_out, float* __restrict__ xsn, float* __restrict__ ysn,
+                   float* __restrict__ avn) {
+    imgs_bounds_block(x_scale, y_scale, average_point, ifn, Np, height, width, img, bound5, K_out, xsn, ysn, avn);
+}
+
+// A batch of images in one launch, no host-side counts: block i first sums the match flags of the
+// images before it (its row offset into the compacted bound table; flags are one byte per patch, so
+// even hundreds of images cost a few hundred KB of L2 reads), then compacts its own patches.
+// K_img[i] = matches of image i; K_total (written by the last block) = rows of bound5 that are valid.
+__global__ void __launch_bounds__(1024)
+imgs_bounds_batch_kernel(const float* __restrict__ x_scale, const float* __restrict__ y_scale,
+                         const float* __restrict__ average_point, const uint8_t* __restrict__ ifn, int Np,
+                         int height, int width, int64_t* __restrict__ bound5, int64_t* __restrict__ K_img,
+                         int64_t* __restrict__ K_total, float* __restrict__ xsn, float* __restrict__ ysn,
+                         float* __restrict__ avn) {
+    __shared__ int part[16];
+    __shared__ int64_t off_s;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    int cnt = 0;
+    for (int64_t k = tid; k < (int64_t)img * Np; k += 1024) cnt += ifn[k] ? 0 : 1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0) part[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t o = 0;
+        for (int q = 0; q < 16; ++q) o += part[q];
+        off_s = o;
+    }
+    __syncthreads();
+    const int64_t off = off_s;
+    __syncthreads();
+    const int64_t i = img;
+    imgs_bounds_block(x_scale + i * Np, y_scale + i * Np, average_point + i * Np * 2, ifn + i * Np, Np, height, width,
+                      img, bound5 + off * 5, K_img + i, xsn + i * Np * 2, ysn + i * Np * 2, avn + i * Np * 2);
+    if (tid == 0 && img == (int)gridDim.x - 1 && K_total) *K_total = off + K_img[i];
 }
 
 // ---- left crops: 96x96 windows on the fixed grid of the 32-px zero-padded left image ---------
 __global__ void __launch_bounds__(288)
 left_crops_kernel(const float* __restrict__ left_all, int n_img, int H, int W, const int64_t* __restrict__ bound5,
-                  int width, float* __restrict__ out) {
+                  int width, float* __restrict__ out, const int64_t* __restrict__ K_dev) {
     const int64_t k = blockIdx.x;
+    if (K_dev && k >= *K_dev) return;          // launched over the capacity: rows past the device-side count
     const int64_t seq = bound5[k * 5 + 4];                 // img * 10000 + patch, utils.py:1374-1377
     const int patch = (int)(seq % 10000);
     const int64_t img = min(max(seq / 10000, (int64_t)0), (int64_t)n_img - 1);
@@ -165,8 +208,9 @@ resize_chw_kernel(const float* __restrict__ input, int n_img, int C, int Hp, int
 __global__ void __launch_bounds__(256)
 resize_hwc_kernel(const float* __restrict__ right, int n_img, int H, int W, int margin,
                   const int64_t* __restrict__ bound, float* __restrict__ out,
-                  int32_t* __restrict__ status) {
+                  int32_t* __restrict__ status, const int64_t* __restrict__ K_dev) {
     const int64_t i = blockIdx.x;
+    if (K_dev && i >= *K_dev) return;
     const int slab = blockIdx.y;
     const int Hp = H + 2 * margin, Wp = W + 2 * margin;
     const CropGeom g = crop_geom(bound, i, n_img, Hp, Wp);
@@ -216,7 +260,32 @@ extern "C" int pats_left_crops_f32(const float* left, int n_img, int H, int W, c
     if (K == 0) return PATS_OK;
     PATS_REQUIRE(left && bound5 && out, "left_crops: null pointer");
     hipLaunchKernelGGL(left_crops_kernel, dim3((unsigned)K, 12), dim3(288), 0, as_stream(stream),
-                       left, n_img, H, W, bound5, width, out);
+                       left, n_img, H, W, bound5, width, out, (const int64_t*)nullptr);
+    return check_launch("left_crops_kernel");
+}
+
+extern "C" int pats_compute_imgs_bounds_batch_f32(const float* x_scale, const float* y_scale,
+                                                  const float* average_point, const uint8_t* if_nomatching,
+                                                  int n_img, int Np, int height, int width, int64_t* bound5,
+                                                  int64_t* K_img, int64_t* K_total, float* x_scale_new,
+                                                  float* y_scale_new, float* average_new, pats_stream_t stream) {
+    PATS_REQUIRE(n_img > 0 && n_img <= 10000 && Np > 0 && height > 0 && width > 0, "compute_imgs_bounds_batch: bad shape");
+    PATS_REQUIRE(x_scale && y_scale && average_point && if_nomatching && bound5 && K_img && x_scale_new &&
+                     y_scale_new && average_new, "compute_imgs_bounds_batch: null pointer");
+    hipLaunchKernelGGL(imgs_bounds_batch_kernel, dim3((unsigned)n_img), dim3(1024), 0, as_stream(stream), x_scale,
+                       y_scale, average_point, if_nomatching, Np, height, width, bound5, K_img, K_total,
+                       x_scale_new, y_scale_new, average_new);
+    return check_launch("imgs_bounds_batch_kernel");
+}
+
+extern "C" int pats_left_crops_counted_f32(const float* left, int n_img, int H, int W, const int64_t* bound5,
+                                           int64_t K_cap, const int64_t* K_dev, int height, int width, float* out,
+                                           pats_stream_t stream) {
+    PATS_REQUIRE(K_cap >= 0 && n_img > 0 && H > 0 && W > 0 && height > 0 && width > 0, "left_crops_counted: bad shape");
+    if (K_cap == 0) return PATS_OK;
+    PATS_REQUIRE(left && bound5 && out && K_dev, "left_crops_counted: null pointer");
+    hipLaunchKernelGGL(left_crops_kernel, dim3((unsigned)K_cap, 12), dim3(288), 0, as_stream(stream),
+                       left, n_img, H, W, bound5, width, out, K_dev);
     return check_launch("left_crops_kernel");
 }
 
@@ -239,6 +308,17 @@ extern "C" int pats_tensor_resize_hwc_f32(const float* right, int n_img, int H, 
     if (K == 0) return PATS_OK;
     PATS_REQUIRE(right && bound && out, "tensor_resize_hwc: null pointer");
     hipLaunchKernelGGL(resize_hwc_kernel, dim3((unsigned)K, 4), dim3(256), 0, as_stream(stream), right,
-                       n_img, H, W, margin, bound, out, status);
+                       n_img, H, W, margin, bound, out, status, (const int64_t*)nullptr);
+    return check_launch("resize_hwc_kernel");
+}
+
+extern "C" int pats_tensor_resize_hwc_counted_f32(const float* right, int n_img, int H, int W, int margin,
+                                                  const int64_t* bound, int64_t K_cap, const int64_t* K_dev,
+                                                  float* out, int32_t* status, pats_stream_t stream) {
+    PATS_REQUIRE(K_cap >= 0 && n_img > 0 && H > 0 && W > 0 && margin >= 0, "tensor_resize_hwc_counted: bad shape");
+    if (K_cap == 0) return PATS_OK;
+    PATS_REQUIRE(right && bound && out && K_dev, "tensor_resize_hwc_counted: null pointer");
+    hipLaunchKernelGGL(resize_hwc_kernel, dim3((unsigned)K_cap, 4), dim3(256), 0, as_stream(stream), right,
+                       n_img, H, W, margin, bound, out, status, K_dev);
     return check_launch("resize_hwc_kernel");
 }

@@ -1001,6 +1001,15 @@ extern "C" size_t pats_ot_workspace_bytes(int64_t batch, int M, int N) {
     return carve(nullptr, batch, M, N, true, true).bytes;
 }
 
+// log_optimal_transport2: the resident shapes compute their marginals in-kernel and keep the plan on
+// chip, so they need no marginal / transposed-copy storage: 65 x 65 nothing, 145 x 145 one guard flag
+// per problem (at the START of the workspace, so a flag-sized workspace is enough).
+extern "C" size_t pats_ot2_workspace_bytes(int64_t batch, int m, int n) {
+    if (m == NT && n == NT) return 0;
+    if (m == NF && n == NF) return pats_sinkhorn_workspace_bytes(batch, m, n);
+    return pats_ot_workspace_bytes(batch, m, n);
+}
+
 extern "C" int pats_sinkhorn_f32(const float* Z, int64_t batch, int M, int N, const float* log_mu,
                                  const float* log_nu, int iters, float* out, void* workspace,
                                  size_t workspace_bytes, pats_stream_t stream) {
@@ -1081,11 +1090,10 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
         return check_launch("sinkhorn65_kernel<2,0,0>");
     }
     if (m == NF && n == NF) {
-        int* fail = nullptr;
-        if (workspace && workspace_bytes >= pats_ot_workspace_bytes(batch, m, n)) fail = carve(workspace, batch, m, n, true, true).fail;
+        int* fail = (workspace && workspace_bytes >= pats_ot2_workspace_bytes(batch, m, n)) ? (int*)workspace : nullptr;
         return launch_fine145(2, scores, batch, nullptr, nullptr, ns, one, iters, bias_k, Z, fail, st);
     }
-    PATS_REQUIRE(workspace && workspace_bytes >= pats_ot_workspace_bytes(batch, m, n),
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_ot2_workspace_bytes(batch, m, n),
                  "log_optimal_transport2: workspace too small");   // shapes without a resident kernel
     OtWorkspace w = carve(workspace, batch, m, n, true, true);
     hipLaunchKernelGGL(ot_prep_kernel, dim3((unsigned)batch), dim3(256), 0, st, ns, n - 1, m, n,

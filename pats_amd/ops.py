@@ -134,7 +134,7 @@ def log_optimal_transport2(scores, one, ns, iters: int, bias_k: float = 0.0):
     ns = ns.reshape(b, n - 1)
     o = _scalar_dev(one, scores.device)
     Z = torch.empty((b, m, n), dtype=torch.float32, device=scores.device)
-    nb = _L().pats_ot_workspace_bytes(b, m, n)
+    nb = _L().pats_ot2_workspace_bytes(b, m, n)
     ws = _workspace(nb, scores.device)
     _check(_L().pats_log_optimal_transport2_f32(_ptr(scores), b, m, n, _ptr(o), _ptr(ns), int(iters),
                                                 float(bias_k), _ptr(Z), _ptr(ws), nb, _stream()),
@@ -308,12 +308,29 @@ def split_patches(sum_cycle, height, width, max_once_used=350):
     return n, second[:n].tolist(), third[:n].tolist()
 
 
+def split_patches_device(sum_cycle, height, width, max_once_used=350):
+    """split_patches (utils/utils.py:152-181) for a batch of pairs WITHOUT leaving the device:
+    sum_cycle [pairs, height*width] int32 -> (cycle_num [pairs] int32, second_layer_set [pairs,height+1,2],
+    third_layer_set [pairs,height+1,2] int64), rows past cycle_num zeroed.  No host read."""
+    sc = _dev(sum_cycle, "sum_cycle", torch.int32)
+    pairs = sc.shape[0]
+    if sc.dim() != 2 or sc.shape[1] != height * width:
+        raise RuntimeError("split_patches_device: sum_cycle must be [pairs, height*width]")
+    second = torch.empty((pairs, height + 1, 2), dtype=torch.int64, device=sc.device)
+    third = torch.empty((pairs, height + 1, 2), dtype=torch.int64, device=sc.device)
+    num = torch.empty((pairs,), dtype=torch.int32, device=sc.device)
+    _check(_L().pats_split_patches_device(_ptr(sc), pairs, int(height), int(width), int(max_once_used), _ptr(second),
+                                          _ptr(third), _ptr(num), _stream()), "split_patches_device")
+    return num, second, third
+
+
 # ------------------------------------------------------------------------------------------------
 # subdivision gather
 # ------------------------------------------------------------------------------------------------
-def tensor_resize(input_tensor, bound):
+def tensor_resize(input_tensor, bound, validate=True):
     """tensor_resize.tensor_resize(input, bound)  (setup/library.cpp:47-66,92-93).
-    input [n,C,Hp,Wp] float32, bound [K,5] int64 -> new [K,C,96,96] float32 on input.device."""
+    input [n,C,Hp,Wp] float32, bound [K,5] int64 -> new [K,C,96,96] float32 on input.device.
+    Raises RuntimeError for an empty or out-of-range crop like the reference (validate=True)."""
     inp = _dev(input_tensor, "input_tensor")
     bnd = _dev(bound, "bound", torch.int64)
     if inp.dim() != 4 or bnd.dim() != 2 or bnd.shape[1] != 5:
@@ -321,28 +338,39 @@ def tensor_resize(input_tensor, bound):
     n_img, C, Hp, Wp = inp.shape
     K = bnd.shape[0]
     out = torch.empty((K, C, 96, 96), dtype=torch.float32, device=inp.device)
+    status = torch.zeros((1,), dtype=torch.int32, device=inp.device) if validate else None
     _check(_L().pats_tensor_resize_f32(_ptr(inp), n_img, C, Hp, Wp, _ptr(bnd), K, _ptr(out),
-                                       ctypes.c_void_p(0), _stream()), "tensor_resize")
+                                       _ptr(status), _stream()), "tensor_resize")
+    if validate and K > 0 and int(status.item()) != 0:
+        # library.cpp:56-60: narrow() outside the tensor / an empty crop into upsample_bilinear2d is a
+        # c10::Error there (RuntimeError / IndexError in Python).  One host read per call (the reference
+        # makes five per crop); validate=False skips it and leaves such crops zero-filled.
+        raise RuntimeError("tensor_resize: a crop is empty or outside the %dx%d input (start/length out of range, "
+                           "or image index >= %d)" % (Hp, Wp, n_img))
     return out
 
 
 def Compute_imgs(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num=0,
-                 output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32, known_count=None):
+                 output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32, known_count=None,
+                 validate=False):
     """utils/utils.py:1343-1393 - same 5-tuple as the reference."""
     return Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num,
-                           output_path, if_view, margin, width, height, patch_scale, known_count)[:5]
+                           output_path, if_view, margin, width, height, patch_scale, known_count, validate)[:5]
 
 
 def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right, sequence_num=0,
                     output_path=None, if_view=False, margin=128, width=20, height=15, patch_scale=32,
-                    known_count=None):
+                    known_count=None, validate=False):
     """Compute_imgs plus the [K,5] bound tensor the reference hands to tensor_resize (utils.py:1382).
     utils/utils.py:1343-1393, any batch of images (PATS.forward uses 1, first_layer.py:135; a batch
     yields the crops of all images in (image, patch) order - `sequence = img * 10000 + patch`, :1374-1377).
     Returns (new_left [K,96,96,3], new_right [K,96,96,3], x_scale_new [1,N,2], y_scale_new
-    [1,N,2], average_new [1,N,2]).  One host read (K) sizes the outputs, as the reference's
-    boolean-mask indexing does - unless the caller already knows K = number of matched patches
-    (`known_count`, e.g. the last entry of the cumsum it fetched for split_patches): then no sync."""
+    [1,N,2], average_new [1,N,2], bound5 [K,5]).  One host read (K) sizes the outputs, as the reference's
+    boolean-mask indexing does - unless the caller already knows the matched patches per image
+    (`known_count`, e.g. the last entry of the cumsum it fetched for split_patches): then no sync;
+    validate=True checks those counts against the device-side ones (one host read).
+    known_count="device" never touches the host: outputs are sized for the capacity n_img*N, only the first
+    K_total rows are written, and the tuple gains (K_img [n_img], K_total [1]) int64 DEVICE tensors."""
     if margin != 128 or patch_scale != 32:
         raise RuntimeError("Compute_imgs: margin=128 / patch_scale=32 are what the path uses")
     nb = left.shape[0]                          # images in the batch; crops come out ordered (image, patch)
@@ -355,28 +383,50 @@ def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right,
     leftf = _dev(left.float(), "left")
     rightf = _dev(right.float(), "right")
     H, W = leftf.shape[1], leftf.shape[2]
-    if known_count is not None:
-        counts = [int(known_count)] if nb == 1 and not hasattr(known_count, "__len__") else [int(k) for k in known_count]
+    on_device = isinstance(known_count, str) and known_count == "device"
+    counts = None
+    if known_count is not None and not on_device:
+        counts = [int(k) for k in np.atleast_1d(np.asarray(known_count)).ravel()]
         if len(counts) != nb:
             raise RuntimeError("Compute_imgs: known_count needs one entry per image")
     bound5 = torch.empty((nb * Np, 5), dtype=torch.int64, device=dev)
     Kd = torch.empty((nb,), dtype=torch.int64, device=dev)
+    Kt = torch.empty((1,), dtype=torch.int64, device=dev)
     xsn = torch.empty((nb, Np, 2), dtype=torch.float32, device=dev)
     ysn = torch.empty((nb, Np, 2), dtype=torch.float32, device=dev)
     avn = torch.empty((nb, Np, 2), dtype=torch.float32, device=dev)
-    K = 0
-    for i in range(nb):                         # compacted bounds of image i start where image i-1's ended
-        _check(_L().pats_compute_imgs_bounds_f32(_ptr(xs[i]), _ptr(ys[i]), _ptr(ap[i]), _ptr(ifn[i]), Np, height, width,
-                                                 i, _ptr(bound5[K:]), _ptr(Kd[i:]), _ptr(xsn[i]), _ptr(ysn[i]),
-                                                 _ptr(avn[i]), _stream()), "Compute_imgs(bounds)")
-        K += int(Kd[i].item()) if known_count is None else counts[i]
+    # all images in one launch: block i offsets its compacted bounds by the matches of the images before it
+    _check(_L().pats_compute_imgs_bounds_batch_f32(_ptr(xs), _ptr(ys), _ptr(ap), _ptr(ifn), nb, Np, height, width,
+                                                   _ptr(bound5), _ptr(Kd), _ptr(Kt), _ptr(xsn), _ptr(ysn), _ptr(avn),
+                                                   _stream()), "Compute_imgs(bounds)")
+    status = torch.zeros((1,), dtype=torch.int32, device=dev) if validate else None
+    if on_device:
+        cap = nb * Np
+        new_left = torch.empty((cap, 96, 96, 3), dtype=torch.float32, device=dev)
+        new_right = torch.empty((cap, 96, 96, 3), dtype=torch.float32, device=dev)
+        _check(_L().pats_left_crops_counted_f32(_ptr(leftf), nb, H, W, _ptr(bound5), cap, _ptr(Kt), height, width,
+                                                _ptr(new_left), _stream()), "Compute_imgs(left)")
+        _check(_L().pats_tensor_resize_hwc_counted_f32(_ptr(rightf), nb, H, W, margin, _ptr(bound5), cap, _ptr(Kt),
+                                                       _ptr(new_right), _ptr(status), _stream()), "Compute_imgs(right)")
+        if validate and int(status.item()) != 0:
+            raise RuntimeError("Compute_imgs: a right crop is empty or outside the padded image")
+        return new_left, new_right, xsn, ysn, avn, bound5, Kd, Kt
+    if counts is None:
+        counts = [int(k) for k in Kd.tolist()]                  # the host read
+    elif validate:
+        got = [int(k) for k in Kd.tolist()]
+        if got != counts:
+            raise RuntimeError("Compute_imgs: known_count %s does not match the matched patches per image %s" % (counts, got))
+    K = sum(counts)
     new_left = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
     new_right = torch.empty((K, 96, 96, 3), dtype=torch.float32, device=dev)
     _check(_L().pats_left_crops_f32(_ptr(leftf), nb, H, W, _ptr(bound5), K, height, width, _ptr(new_left),
                                     _stream()), "Compute_imgs(left)")
     _check(_L().pats_tensor_resize_hwc_f32(_ptr(rightf), nb, H, W, margin, _ptr(bound5), K,
-                                           _ptr(new_right), ctypes.c_void_p(0), _stream()),
+                                           _ptr(new_right), _ptr(status), _stream()),
            "Compute_imgs(right)")
+    if validate and K > 0 and int(status.item()) != 0:
+        raise RuntimeError("Compute_imgs: a right crop is empty or outside the padded image")
     new_left = new_left.to(left.dtype) if left.dtype != torch.float32 else new_left
     return new_left, new_right, xsn, ysn, avn, bound5[:K]
 
@@ -583,10 +633,13 @@ def refine_scatter(if_nomatching, pts, mkpts1_f, label):
     return f16, p16
 
 
-def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left_choice, layer_num=2, validate=True):
+def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left_choice, layer_num=2, validate=True,
+               sync=True):
     """utils.get_result (utils.py:189-213) for the two-level call of pats.py:73: returns (matches_l,
     matches_r) [M,2].  scale[1] may be the reference's [K,n1,2] tensor or a [K,2] / [K,1,2] tensor holding
-    one scale per row (what pats.py:70 repeats over the sub-cells)."""
+    one scale per row (what pats.py:70 repeats over the sub-cells).
+    sync=False makes no host read: returns (matches_l [cap,2], matches_r [cap,2], M [1] int64 DEVICE count),
+    only the first M rows written (throughput mode; the reference reads M when it masks)."""
     if layer_num != 2 or len(if_nomatching) != 2:
         raise RuntimeError("get_result: only the reference's layer_num=2 call is implemented")
     f0, f1 = _as_flags(if_nomatching[0], "if_nomatching[0]"), _as_flags(if_nomatching[1], "if_nomatching[1]")
@@ -621,6 +674,8 @@ def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left
     _check(_L().pats_get_result_f32(bs, _ptr(f0), _ptr(f1), rows1, _ptr(a0), _ptr(a1), _ptr(s0), _ptr(s1), stride, ps0, ps1,
                                     _ptr(c0), _ptr(c1), _ptr(ml), _ptr(mr), cap, _ptr(cnt), _ptr(ws), nws, _stream()),
            "get_result")
+    if not sync:
+        return ml, mr, cnt
     M = int(cnt.item())
     return ml[:M], mr[:M]
 

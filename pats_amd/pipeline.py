@@ -132,9 +132,9 @@ def _forward_batched(left, nets, if_outdoor, iters, merge, scores_back, ifn1, su
         B = hi - lo
         out, scores_back = merge(B, trust2[off:off + B], (H, W), masks[c:c + 1], ifn_L2[off:off + B], scores_back,
                                  validate=False)
+        if tail != 0:                                           # pats.py:38-39, the reference's own expression
+            out[-tail:, :] = True                               # (identical in both modes also for a negative tail)
         merged[off:off + B] = out
-        if tail != 0:
-            merged[off + B - tail:off + B, :] = True
         off += B
     mk0, mk1, b_ids = ops.third_inputs(merged, pts2)            # host read: P (all chunks)
     if mk0.shape[0] == 0:

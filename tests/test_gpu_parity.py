@@ -664,3 +664,107 @@ def test_pipeline_chain(name, batched):
     assert ml.shape == g["matches_l"].shape and ml.shape[0] > 500
     np.testing.assert_allclose(ml, g["matches_l"], atol=1e-4, rtol=1e-6)
     np.testing.assert_allclose(mr, g["matches_r"], atol=2e-2, rtol=1e-5)
+
+
+# ---- throughput-mode variants without host reads, error paths, multi-rank plumbing (round 2) ---------
+def test_split_patches_device_matches_host(ops):
+    """pats_split_patches_device (one thread per pair, no host read) against the host planner and the
+    reference's golden plan (utils.py:152-181)."""
+    g = golden("coarse_301.npz")
+    rng = np.random.default_rng(5)
+    flags = [g["ifn1"][0]] + [rng.random(300) < p for p in (0.0, 0.05, 0.5, 0.97, 1.0)]
+    sc = torch.cumsum(torch.logical_not(cu(np.stack(flags))).int(), dim=1, dtype=torch.int32)
+    for cap in (40, 100, 512):
+        num, second, third = ops.split_patches_device(sc, 15, 20, cap)
+        num, second, third = num.cpu().numpy(), second.cpu().numpy(), third.cpu().numpy()
+        for i in range(len(flags)):
+            n, s, t = ops.split_patches(sc[i], 15, 20, cap)
+            assert n == num[i] and s == second[i, :n].tolist() and t == third[i, :n].tolist()
+            assert not second[i, n:].any() and not third[i, n:].any()
+    num, second, third = ops.split_patches_device(sc[:1], 15, 20, 40)
+    assert int(num[0]) == int(g["split40_cycle"]) and second[0, :int(num[0])].cpu().tolist() == g["split40_second"].tolist()
+
+
+def test_compute_imgs_device_counts(ops):
+    """known_count="device": same crops in the first K_total rows, no host read, counts on the device."""
+    g = golden("coarse_301.npz")
+    left, right = synth.image_pair()
+    L, R = cu(left), cu(right)
+    xs, ys, pts, ifn = cu(g["x_scale"]), cu(g["y_scale"]), cu(g["average_point"]), cu(g["ifn1"])
+    ifn_b, ifn_c = ifn.clone(), torch.ones_like(ifn)
+    ifn_b[0, ::7] = True
+    xs3, ys3, pts3 = torch.cat([xs, xs * 0.9, xs]), torch.cat([ys, ys * 1.1, ys]), torch.cat([pts, pts, pts])
+    ifn3, L3, R3 = torch.cat([ifn, ifn_c, ifn_b]), torch.cat([L, L.flip(2), L]), torch.cat([R, R.flip(1), R])
+    want = ops.Compute_imgs_ex(xs3, ys3, pts3, ifn3, L3, R3, width=20, height=15)
+    got = ops.Compute_imgs_ex(xs3, ys3, pts3, ifn3, L3, R3, width=20, height=15, known_count="device")
+    K = want[0].shape[0]
+    assert got[0].shape[0] == 3 * 300 and int(got[7].item()) == K
+    assert got[6].cpu().tolist() == [int((~ifn3[i]).sum()) for i in range(3)] and got[6][1] == 0
+    for k in (0, 1, 5):
+        assert torch.equal(got[k][:K], want[k])
+    for k in (2, 3, 4):
+        assert torch.equal(got[k], want[k])
+    # caller-supplied counts are normalised (0-d numpy) and can be validated against the device's
+    one = ops.Compute_imgs(xs, ys, pts, ifn, L, R, width=20, height=15, known_count=np.int64(int((~ifn).sum())), validate=True)
+    assert torch.equal(one[1], want[1][:one[1].shape[0]])
+    with pytest.raises(RuntimeError):
+        ops.Compute_imgs(xs, ys, pts, ifn, L, R, width=20, height=15, known_count=3, validate=True)
+
+
+def test_tensor_resize_raises_like_reference(ops):
+    """library.cpp:56-60: narrow() outside the tensor or an empty crop is a c10::Error -> RuntimeError."""
+    import tensor_resize
+    g = golden("resize_small.npz")
+    src = cu(g["src"])
+    Hp, Wp = src.shape[2], src.shape[3]
+    ok = cu(g["bound"])[:1]
+    for bad in ([0, Hp + 1, 0, 10, 0], [5, 5, 0, 10, 0], [0, 10, 4, Wp, 0], [0, 10, 0, 10, 10000 * src.shape[0]],
+                [-1, 10, 0, 10, 0]):
+        b = torch.cat([ok, torch.tensor([bad], dtype=torch.int64).cuda()])
+        with pytest.raises(RuntimeError):
+            tensor_resize.tensor_resize(src, b)
+        out = ops.tensor_resize(src, b, validate=False)           # no host read: the bad crop is zero-filled
+        assert torch.equal(out[0], tensor_resize.tensor_resize(src, ok)[0]) and not out[1].any()
+
+
+def test_get_result_without_host_read(ops):
+    inp = synth.result_inputs(seed=99, h=15, w=20, mixed_choice=True)
+    f16, p16 = ops.refine_scatter(cu(inp["ifn2"]), cu(inp["pts"]), cu(inp["mkpts1"]), cu(inp["label0"]))
+    sc_rows = inp["sc0"][~inp["ifn0"]]
+    args = (1, [cu(inp["ifn0"]), f16], [cu(inp["ap0"]), p16.flip(dims=[2]) / 2.0], [cu(inp["sc0"]), cu(sc_rows)],
+            [[32, 15, 20], [2, 48, 48]], [cu(inp["choice0"]), cu(inp["choice1"])])
+    ml, mr = ops.get_result(*args)
+    mlc, mrc, M = ops.get_result(*args, sync=False)
+    assert int(M.item()) == ml.shape[0] and mlc.shape[0] == f16.shape[0] * 2304
+    assert torch.equal(mlc[:ml.shape[0]], ml) and torch.equal(mrc[:mr.shape[0]], mr)
+
+
+def _run_bench(extra_env, gpus):
+    import json
+    import subprocess
+    env = dict(os.environ, **extra_env)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1",
+           "--pairs", "2", "--no-cpu-baseline", "--no-secondary"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks(ops, sinkhorn_mode):
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself, shards the pairs and gathers the
+    matches to rank 0.  On a 1-GPU box the two ranks share the device and talk over gloo (plumbing only);
+    with >= 2 GPUs the same command runs one rank per GPU over RCCL."""
+    if sinkhorn_mode != "kernel":
+        pytest.skip("once is enough")
+    one = _run_bench({}, 1)
+    assert one["n_gpus"] == 1 and one["matches_per_pair"] > 1000 and one["roofline"]["frac"] > 0
+    if torch.cuda.device_count() >= 2:
+        two = _run_bench({}, 2)
+    else:
+        two = _run_bench({"PATS_BENCH_SHARE_DEVICE": "1", "PATS_BENCH_BACKEND": "gloo"}, 2)
+    assert two["n_gpus"] == 2 and two["gather_bytes"] > 0
+    assert two["matches_per_pair"] > 1000

@@ -25,28 +25,32 @@ def _fake_matches(i):
     return torch.rand((k, 2), generator=g) * 480, torch.rand((k, 2), generator=g) * 640
 
 
-def _worker(rank, world, port, n_pairs, q):
+def _worker(rank, world, port, n_pairs, dst, batch_rows, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         mine = shard.my_pairs(n_pairs, rank, world)
         local = [(i,) + _fake_matches(i) for i in mine]
-        allm = shard.gather_matches(local, n_pairs)
-        ok = len(allm) == n_pairs
-        for i, (ml, mr) in enumerate(allm):
-            wl, wr = _fake_matches(i)
-            ok = ok and torch.equal(ml, wl) and torch.equal(mr, wr)
+        allm = shard.gather_matches(local, n_pairs, dst=dst, batch_rows=batch_rows)
+        if dst is not None and rank != dst:
+            ok = allm is None                                   # only `dst` receives
+        else:
+            ok = len(allm) == n_pairs
+            for i, (ml, mr) in enumerate(allm):
+                wl, wr = _fake_matches(i)
+                ok = ok and torch.equal(ml, wl) and torch.equal(mr, wr)
         q.put((rank, mine, ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs", [1, 7, 8])
-def test_two_rank_shard_and_gather(n_pairs):
+# n_pairs = 1: rank 1 owns nothing (the empty-rank case); batch_rows = 5: several bounded rounds
+@pytest.mark.parametrize("n_pairs,dst,batch_rows", [(1, 0, 1 << 20), (7, 0, 5), (8, None, 1 << 20), (7, 1, 3), (1, None, 2)])
+def test_two_rank_shard_and_gather(n_pairs, dst, batch_rows):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, dst, batch_rows, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -55,7 +59,7 @@ def test_two_rank_shard_and_gather(n_pairs):
         assert p.exitcode == 0
     owned = sorted(i for _, mine, _ in res for i in mine)
     assert owned == list(range(n_pairs))              # every pair exactly once
-    assert all(ok for _, _, ok in res)                # every rank sees all matches, in pair order
+    assert all(ok for _, _, ok in res)                # the receiver(s) see all matches, in pair order
 
 
 def test_single_process_gather_needs_no_group():
@@ -63,3 +67,15 @@ def test_single_process_gather_needs_no_group():
     out = shard.gather_matches(local, 3)
     assert all(torch.equal(out[i][0], local[i][1]) for i in range(3))
     assert shard.my_pairs(10, 3, 4) == [3, 7]
+
+
+def test_collective_device_follows_the_backend_not_the_local_tensors(monkeypatch):
+    """A rank that owns no pairs has no tensor to take a device from: under nccl (RCCL) it must still
+    feed the collective from its HIP device (round-1 bug: it fell back to the CPU there)."""
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert shard.collective_device() == torch.device("cuda", 3)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "cpu:gloo,cuda:nccl")
+    assert shard.collective_device() == torch.device("cuda", 3)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    assert shard.collective_device() == torch.device("cpu")
