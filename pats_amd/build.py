@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpats_amd.so")
-SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "gather.hip", "merge.hip", "attention.hip",
+SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip",
            "fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # per-lane and dustbin scaling updates into v_pk_mul_f32, which pins {nu, nu64} / {mu, mu64} in two
 # extra VGPRs and puts a spill reload + vmcnt(0) into every Sinkhorn sweep (+12 % kernel time,
 # measured).  The explicit float2 FMAs of the sweeps are not SLP products and stay packed.
-EXTRA_FLAGS = {"third_fused.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"third_fused.hip": ["-fno-slp-vectorize"], "third_fused3.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -44,9 +44,11 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         spath = os.path.join(CSRC, src)
+        # every object depends on every header (a struct shared through a .hpp must never be seen in two layouts)
+        headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + \
+                  [os.path.join(HERE, "..", "include", "pats_amd.h")]
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
-                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, "common.hpp"))
-                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(HERE, "..", "include", "pats_amd.h"))):
+                and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in headers)):
             continue
         cmd = [hipcc()] + FLAGS[:-2] + EXTRA_FLAGS.get(src, []) + FLAGS[-2:] + ["-c", spath, "-o", obj]
         if verbose:

@@ -33,7 +33,9 @@ struct Fused65Args {
     ComputeResultOut cr;
     int stagger;
     unsigned long long* fallbacks;   // guard-trip counter or null
+    int scan;                        // third_fused_kernel: re-solve only the problems flagged THIRD_REDO
 };
+constexpr uint8_t THIRD_REDO = 0xEE; // if_matching1[p*16] of a problem the log-domain kernel must redo
 int launch_third_fused(const Fused65Args& g, hipStream_t st);
 
 // row-level (16-lane) all-reduces: 4 DPP steps, no LDS traffic
@@ -61,8 +63,8 @@ __device__ __forceinline__ void row16_argmax(float& v, int& i) {
 // of the wave owns one centre row (lane t of the group holds targets t, t+16, t+32, t+48), so the
 // argmax / sums are 4-step row-level DPP reductions and the 5x5 taps are two per lane, gathered
 // from the plan by address.  sx / sy are indexable [64] scale vectors (global or LDS).
-// `compact_stride` == 0: Sp is the full 65 x 65 matrix (row stride 65); otherwise Sp holds only the 16
-// centre rows, row q at Sp + q * compact_stride.
+// `compact_stride` == 0: Sp is the full 65 x 65 matrix (row stride 65); > 0: Sp holds only the 16
+// centre rows, row q at Sp + q * compact_stride; < 0: see below.
 __device__ __forceinline__ void compute_result_problem(const float* Sp, int input_is_log, int64_t p,
                                                        const float* sx, const float* sy, float ps0,
                                                        float ps1, float pt0, float pt1, int outdoor,
@@ -75,7 +77,11 @@ __device__ __forceinline__ void compute_result_problem(const float* Sp, int inpu
     for (int pass = 0; pass < 4; ++pass) {
         const int q = pass * 4 + grp;
         const int qy = q / 4 + 2, qx = q % 4 + 2;                    // [:, 2:6, 2:6]  (:186,188)
-        const float* row = compact_stride ? Sp + q * compact_stride : Sp + (qy * W + qx) * NN;
+        // compact_stride > 0: row q at q * stride; < 0: the four block rows 2..5 with all eight local rows each,
+        // row (qy - 2) * 8 + qx at stride -compact_stride (third_fused3.hip)
+        const float* row = compact_stride > 0 ? Sp + q * compact_stride
+                         : compact_stride < 0 ? Sp + ((qy - 2) * 8 + qx) * (-compact_stride)
+                                              : Sp + (qy * W + qx) * NN;
         float x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -48,17 +48,8 @@ struct __attribute__((aligned(16))) BlkLds {
 __device__ __forceinline__ float lse_fin(float s, float mI) { return (fast_log2(s) + mI) * LN2; }
 __device__ __forceinline__ float uni(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
-__global__ void __launch_bounds__(64, 3)
-third_fused_kernel(Fused65Args g) {
-    __shared__ BlkLds lds;
-    const int lane = threadIdx.x, I = lane >> 3, J = lane & 7;
-    const int64_t p = blockIdx.x;
-    if (p >= g.P) return;
-    // de-phase the first wave-front (see sinkhorn65_kernel)
-    if (g.stagger > 0 && blockIdx.x < 8192u) {
-        const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
-        for (unsigned q = 0; q < slots * (unsigned)g.stagger; ++q) __builtin_amdgcn_s_sleep(127);
-    }
+__device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int64_t p, BlkLds& lds, const int lane) {
+    const int I = lane >> 3, J = lane & 7;
     const int colj = 8 * J + I;              // the column this lane owns in the column half-sweep
     // ---- marginals of log_optimal_transport2 (modules.py:169-179) --------------------------------
     // Wave-uniform quantities are pinned to SGPRs (uni): the kernel sits at the 168-VGPR budget of
@@ -354,10 +345,51 @@ third_fused_kernel(Fused65Args g) {
                            g.cr, lane, 66);
 }
 
+// direct mode: one workgroup per problem.  scan mode (g.scan): workgroup w looks at problems 64w .. 64w+63 and
+// re-solves those whose if_matching1 slot carries THIRD_REDO (left there by third_fused3_kernel's guard).
+__global__ void __launch_bounds__(64, 3)
+third_fused_kernel(Fused65Args g) {
+    __shared__ BlkLds lds;
+    const int lane = threadIdx.x;
+    if (!g.scan) {
+        const int64_t p = blockIdx.x;
+        if (p >= g.P) return;
+        // de-phase the first wave-front (see sinkhorn65_kernel)
+        if (g.stagger > 0 && blockIdx.x < 8192u) {
+            const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
+            for (unsigned q = 0; q < slots * (unsigned)g.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+        }
+        third_v2_problem(g, p, lds, lane);
+        return;
+    }
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const bool redo = base + lane < g.P && g.cr.ifm[(base + lane) * 16] == THIRD_REDO;
+    unsigned long long todo = __ballot(redo);
+    while (todo) {
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        __syncthreads();
+        third_v2_problem(g, base + k, lds, lane);
+    }
+}
+
+int launch_third_fused3(const Fused65Args& g0, hipStream_t st);      // third_fused3.hip
+
 int launch_third_fused(const Fused65Args& g0, hipStream_t st) {
     Fused65Args g = g0;
     g.linear = sinkhorn_mode() != PATS_SINKHORN_LOG;
     g.fallbacks = fallback_counter();
+    static const bool v2_only = getenv("PATS_THIRD_V2") != nullptr;     // A/B switch for benchmarking
+    if (g.linear && g.iters > 0 && !v2_only) {
+        // linear-domain solve by the third-generation kernel; it flags the problems that leave the guard
+        // band, and this file's kernel re-solves exactly those with log-sum-exp sweeps (scan mode)
+        int rc = launch_third_fused3(g, st);
+        if (rc) return rc;
+        g.linear = 0;
+        g.scan = 1;
+        hipLaunchKernelGGL(third_fused_kernel, dim3((unsigned)ceil_div(g.P, 64)), dim3(64), 0, st, g);
+        return check_launch("third_fused_kernel(scan)");
+    }
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
     if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
     hipLaunchKernelGGL(third_fused_kernel, dim3((unsigned)g.P), dim3(64), 0, st, g);

@@ -1,0 +1,460 @@
+// Third-level step of PATS, linear-domain solve, third generation of the 8x8 register-block kernel.
+//
+//   models/third_layer.py:153-170:  cost build (einsum, /sqrt(128), 0.1*) -> log_optimal_transport2
+//   (100 sweeps) -> exp -> Compute_result (:184-217) -> label (:161-170);  one wave per problem.
+//
+// Same decomposition as third_fused.hip (lane (I, J) = (lane >> 3, lane & 7) owns an 8x8 block of the
+// kernel matrix K, the dustbin row / column ride along as one element per lane), re-laid so that a
+// Sinkhorn sweep costs ~190 ns of VALU time per SIMD instead of ~260 (the kernel is VALU-bound):
+//
+//  * register row s of lane (I, J) holds matrix row 8I + rho(s, J), rho = s ^ J (s < 4), s ^ J ^ 3
+//    (s >= 4).  With that lane-dependent assignment both partners of every butterfly level keep and
+//    send the SAME register numbers, so the 8-values-over-8-lanes row reduction is 4 + 2 + 1 DPP adds
+//    and no v_cndmask (21 -> 7 instructions).  The scaling vector `a` comes back to register-row order
+//    by seven ds_swizzle (xor masks; LDS crossbar, no memory, no VALU slot).
+//  * the block is stored as diagonal pairs  Pa = {k[2i][2j], k[2i+1][2j+1]},  Pb = {k[2i+1][2j], k[2i][2j+1]}:
+//    with v_pk_fma_f32's op_sel both half-sweeps accumulate straight into {row 2i, row 2i+1} resp.
+//    {col 2j, col 2j+1} pairs - no horizontal x + y adds (8 instructions), and the column reduction's
+//    adds become v_pk_add_f32.
+//  * everything that crosses 16-lane rows goes through LDS instead of v_permlane*_swap / row broadcasts: the
+//    column reduction posts its eight partials and reads back two b128 (six swaps + selects -> seven adds),
+//    the two 64-lane dustbin dot products finish with one ds_write_b32 + one broadcast ds_read_b128.  LDS
+//    instructions are issued beside the VALU; tools/valu_cost.hip has the measured instruction costs this
+//    layout was chosen by (v_pk_fma_f32 2.05 ns per SIMD, plain fp32 add/mul/fma 1.05, DPP add / select /
+//    v_pk_add 1.75, rcp and permlane swaps 3.4, and the fp32 MFMA occupies the same FMA lanes: 13.4).
+//
+// The solve is the linear-domain one only.  A problem that trips the guard writes a sentinel into its
+// if_matching1 slot and is re-solved by third_fused_kernel (third_fused.hip, log-sum-exp sweeps) in
+// scan mode on the same stream; forced-log mode and iters == 0 go to that kernel directly.
+#include "common.hpp"
+#include "lane_reduce.hpp"
+#include "third_device.hpp"
+#include "cost65_device.hpp"
+#include <stdlib.h>
+
+namespace pats {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SST3 = 36;                 // staging row stride (floats): 16-byte aligned rows
+constexpr float GUARD3 = 1073741824.0f;  // 2^30
+__device__ __forceinline__ bool sc_ok3(float x) { return x <= GUARD3 && x > 0.f; }
+__device__ __forceinline__ float uni3(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+
+struct __attribute__((aligned(16))) Blk3Lds {
+    float vb[72];                // column-indexed vector (c, then b)
+    float erow[72];              // Z[64][j]
+    float ecol[72];              // Z[i][64]
+    float red[8];                // [0..3], [4..7]: the four 16-lane row totals of the two dustbin dot products
+    float stage[64 * SST3];      // one column parity of Z: [64 rows][32 cols]; first: cost edge columns;
+                                 // last: the plan rows of block rows 2..5, [32][RS3]
+};
+
+// value of lane (lane ^ X), X < 32: ds_swizzle bit-mask mode (and = 0x1f, or = 0, xor = X)
+template <int X>
+__device__ __forceinline__ float swz_xor(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (X << 10) | 0x1f));
+}
+// g[s] = value of the lane that owns matrix row 8I + rho(s, J)
+__device__ __forceinline__ void gather_rows(float v, float (&g)[8]) {
+    g[0] = v;
+    g[1] = swz_xor<1>(v); g[2] = swz_xor<2>(v); g[3] = swz_xor<3>(v);
+    g[4] = swz_xor<7>(v); g[5] = swz_xor<6>(v); g[6] = swz_xor<5>(v); g[7] = swz_xor<4>(v);
+}
+
+// 8 partials per lane (register-row order) reduced over the 8 lanes that share I; lane (I, J) ends with
+// the total of matrix row 8I + J.  No selects: see the header.
+template <class Op>
+__device__ __forceinline__ float reduce8_perm(const float (&p)[8], Op op) {
+    float r[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r[s] = op(p[s], dpp_f<DPP_ROW_HALF_MIRROR>(p[s + 4]));
+    const float q0 = op(r[0], dpp_f<DPP_QUAD_XOR2>(r[2])), q1 = op(r[1], dpp_f<DPP_QUAD_XOR2>(r[3]));
+    return op(q0, dpp_f<DPP_QUAD_XOR1>(q1));
+}
+
+// 64-lane sum into every lane: in-row DPP butterfly, then the four 16-lane row totals cross through LDS (one
+// ds_write_b32, one broadcast ds_read_b128: LDS instructions take no VALU issue time, and the fp32 MFMA that
+// could add the rows runs on the VALU's own FMA lanes - measured, tools/valu_cost.hip: 13 ns against 2).
+// `slot` = four floats of LDS, 16-byte aligned; one wave per workgroup, so program order is the only sync.
+__device__ __forceinline__ float wave_sum_lds(float v, float* slot, int lane) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    slot[lane >> 4] = v;
+    __syncthreads();
+    const f4v r = *reinterpret_cast<const f4v*>(slot);
+    return (r.x + r.y) + (r.z + r.w);
+}
+
+// A/B alternative: the four row totals added by one v_mfma_f32_16x16x4_f32 against a vector of ones
+__device__ __forceinline__ float wave_sum_mfma(float v) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, 1.0f, z, 0, 0, 0);
+    return d[0];
+}
+template <int DB>
+__device__ __forceinline__ float dustbin_sum(float v, float* slot, int lane) {
+    if (DB == 0) return wave_sum_uniform(v);
+    if (DB == 2) return wave_sum_mfma(v);
+    return wave_sum_lds(v, slot, lane);
+}
+
+// Column partials {c0,c1},{c2,c3},{c4,c5},{c6,c7} (this lane's eight rows) summed over the 8 lanes that share J;
+// lane (I, J) ends with the total of column 8J + I.  The exchange crosses 16-lane rows, where the VALU only has
+// v_permlane*_swap (3.4 ns each, six of them): instead every lane posts its eight partials at T[J][c][I]
+// (J-stride 72 floats: a 2-way bank conflict, free for ds_write_b32) and collects column I's eight as two
+// ds_read_b128.  T = 8 * 72 floats.
+__device__ __forceinline__ float reduce8_strided_lds(const f2v (&q)[4], float* T, int I, int J) {
+    float* w = T + J * 72 + I;
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+        w[(2 * cp) * 8] = q[cp].x;
+        w[(2 * cp + 1) * 8] = q[cp].y;
+    }
+    __syncthreads();
+    const float* r = T + J * 72 + I * 8;
+    const f4v u = *reinterpret_cast<const f4v*>(r), v = *reinterpret_cast<const f4v*>(r + 4);
+    return ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
+}
+
+// column partials {c0,c1},{c2,c3},{c4,c5},{c6,c7} reduced over the 8 lanes that share J; lane (I, J)
+// ends with the total of column 8J + I
+__device__ __forceinline__ float reduce8_strided_pk(f2v q01, f2v q23, f2v q45, f2v q67, int lane) {
+    float a0 = q01.x, a1 = q01.y, a2 = q23.x, a3 = q23.y, b0 = q45.x, b1 = q45.y, b2 = q67.x, b3 = q67.y;
+    swap32(a0, b0); swap32(a1, b1); swap32(a2, b2); swap32(a3, b3);
+    const f2v r01 = f2v{a0, a1} + f2v{b0, b1}, r23 = f2v{a2, a3} + f2v{b2, b3};   // lanes < 32: columns 0..3, >= 32: 4..7
+    float c0 = r01.x, c1 = r01.y, d0 = r23.x, d1 = r23.y;
+    swap16(c0, d0); swap16(c1, d1);
+    const f2v q = f2v{c0, c1} + f2v{d0, d1};          // even 16-rows: index 0,1; odd: 2,3 (+4 in the upper half)
+    const bool hi = lane & 8;
+    const float keep = hi ? q.y : q.x, send = hi ? q.x : q.y;
+    return keep + dpp_f<DPP_ROW_ROR8>(send);
+}
+
+// ---- ThirdLayer.Compute_result + the match label (models/third_layer.py:161-170,184-217), one pass ------------
+// All 16 centre rows at once, FOUR lanes per row (lane = 4 q + u): lane u scans columns 16u .. 16u+15 for the
+// argmax (first index wins ties, two quad-level DPP steps join the four lanes), takes the 5x5 taps u, u+4, ...
+// and the four partial expectations meet in two more DPP steps.  `rows` = the plan rows of block rows 2..5 in
+// LDS, row (qy - 2) * 8 + qx at stride RS3; sxl / syl = scale_x / scale_y of the 64 targets in LDS.
+// whole_loss (third_layer.py:213) is not produced here: nothing reads it at inference (the standalone
+// pats_compute_result_f32 still returns it).  sqrt and the two quotients use v_sqrt_f32 / v_rcp_f32 with one
+// Newton step instead of the IEEE sequences: <= 1 ulp, against a 3e-4 px gate.
+constexpr int RS3 = 68;                  // row stride of the plan rows (floats): 16-byte aligned rows
+__device__ __forceinline__ float fast_div(float x, float d) {
+    const float r = __builtin_amdgcn_rcpf(d), q = x * r;
+    return fmaf(fmaf(-q, d, x), r, q);
+}
+__device__ __forceinline__ void compute_result16(const float* rows, const float* sxl, const float* syl, int64_t p,
+                                                 float ps0, float ps1, float pt0, float pt1, int outdoor,
+                                                 const ComputeResultOut& o, int lane) {
+    constexpr int W = 8, T = 5;
+    const int q = lane >> 2, u = lane & 3;
+    const int qy = (q >> 2) + 2, qx = (q & 3) + 2;                   // [:, 2:6, 2:6]  (:186,188)
+    const float* row = rows + ((qy - 2) * 8 + qx) * RS3;
+    float bv;
+    int bi;
+    {
+        const f4v* r4 = reinterpret_cast<const f4v*>(row + 16 * u);
+        const f4v v0 = r4[0], v1 = r4[1], v2 = r4[2], v3 = r4[3];
+        const float x[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+        bv = x[0];
+        bi = 16 * u;
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+            if (x[k] > bv) { bv = x[k]; bi = 16 * u + k; }
+    }
+    argmax_step<DPP_QUAD_XOR1>(bv, bi);                             // lower index wins ties: first index over the row
+    argmax_step<DPP_QUAD_XOR2>(bv, bi);
+    const float xd = row[64];                                        // dustbin column
+    // the all-column argmax of (row + 1e-8) (:167-168) hits the dustbin only if it is strictly larger than every real entry
+    const bool matching = !((xd + 1e-8f) > (bv + 1e-8f));
+    const int mx = bi % W, my = bi / W;
+    float wpx = 0.f, wpy = 0.f, sumx = 0.f, sumy = 0.f;
+#pragma unroll
+    for (int h = 0; h < 7; ++h) {
+        const int tap = u + 4 * h;
+        if (tap < T * T) {
+            const int ty = (tap * 13) >> 6, tx = tap - 5 * ty;       // tap / 5, tap % 5 for tap < 25
+            const int ux = mx + tx - 2, uy = my + ty - 2;             // index3 on the pad-2 map (:189-191)
+            const bool inside = ux >= 0 && ux < W && uy >= 0 && uy < W;
+            const int src = inside ? uy * W + ux : 0;
+            const float sbv = inside ? row[src] : 0.0f;               // ZeroPad2d(2)           (:185)
+            const float scx = inside ? sxl[src] : 1e-2f;              // ConstantPad2d(2, 1e-2) (:195-196)
+            const float scy = inside ? syl[src] : 1e-2f;
+            const float root = __builtin_amdgcn_sqrtf(sbv + 1e-7f);
+            const float fx = fast_div(root, scx), fy = fast_div(root, scy);     // :197-198
+            wpx = fmaf(fx, (float)tx * 2.0f - (float)(T - 1), wpx);   // meshgrid * 2 - (T - 1)  (:199)
+            wpy = fmaf(fy, (float)ty * 2.0f - (float)(T - 1), wpy);
+            sumx += fx;
+            sumy += fy;
+        }
+    }
+    wpx += dpp_f<DPP_QUAD_XOR1>(wpx); wpy += dpp_f<DPP_QUAD_XOR1>(wpy);
+    sumx += dpp_f<DPP_QUAD_XOR1>(sumx); sumy += dpp_f<DPP_QUAD_XOR1>(sumy);
+    wpx += dpp_f<DPP_QUAD_XOR2>(wpx); wpy += dpp_f<DPP_QUAD_XOR2>(wpy);
+    sumx += dpp_f<DPP_QUAD_XOR2>(sumx); sumy += dpp_f<DPP_QUAD_XOR2>(sumy);
+    if (u == 0) {
+        const int64_t oo = (p * 16 + q) * 2;
+        const float m1x = fast_div(wpx, sumx) + ((float)mx + 0.5f - (float)W / 2) * 2.0f;   // :206
+        const float m1y = fast_div(wpy, sumy) + ((float)my + 0.5f - (float)W / 2) * 2.0f;   // :207
+        *reinterpret_cast<f2v*>(o.mk1 + oo) = f2v{m1x + pt0, m1y + pt1};                     // :208
+        *reinterpret_cast<f2v*>(o.mk0 + oo) = f2v{ps0 + (float)(q % 4) * 2.0f - 3.0f,        // :209-210
+                                                  ps1 + (float)(q / 4) * 2.0f - 3.0f};
+        o.ifm[p * 16 + q] = matching ? 1 : 0;
+        float l0 = 1e8f;                                                                     // :161
+        if (!outdoor) {
+            const bool select = (q == 5 || q == 15 || q == 7 || q == 13);                    // :163-166
+            l0 = select ? l0 : -10.0f;
+        } else {
+            l0 = matching ? l0 : -10.0f;                                                     // :169-170
+        }
+        *reinterpret_cast<f2v*>(o.label + oo) = f2v{l0, 1e8f};
+    }
+}
+
+// WAVES = waves per SIMD the register budget is cut for; CR = column reduction (0 swaps, 1 LDS); DB = dustbin
+// sums (0 DPP row broadcasts, 1 LDS, 2 MFMA).  The defaults are what measured fastest (launch_third_fused3).
+template <int WAVES, int CR, int DB>
+__global__ void __launch_bounds__(64, WAVES)
+third_fused3_kernel(Fused65Args g) {
+    __shared__ Blk3Lds lds;
+    const int lane = threadIdx.x, I = lane >> 3, J = lane & 7;
+    const int64_t p = blockIdx.x;
+    if (p >= g.P) return;
+    // de-phase the first wave-front (see sinkhorn65_kernel)
+    if (g.stagger > 0 && blockIdx.x < 8192u) {
+        const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
+        for (unsigned q = 0; q < slots * (unsigned)g.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+    }
+    const int colj = 8 * J + I;              // the column this lane owns in the column half-sweep
+    // ---- marginals of log_optimal_transport2 (modules.py:169-179); wave-uniform values in SGPRs -------
+    const float ns_own = g.ns[p * 64 + colj];
+    const float ns_sum = uni3(wave_sum(g.ns[p * 64 + lane]));
+    const float ms = uni3(64.0f * (g.one ? *g.one : 1.0f));
+    const float norm = uni3(-logf(ms + ns_sum));
+    const float lmu = norm, lmu64 = uni3(logf(ns_sum) + norm);
+    const float lnu = logf(ns_own) + norm, lnu64 = uni3(logf(ms) + norm);
+
+    // ---- cost build (MFMA), then fragment layout -> permuted diagonal-pair blocks through LDS -----------
+    f2v Pa[4][4], Pb[4][4];                  // [row pair][column pair], see the header
+    float zdrow, zdcol, zcorner;
+    {
+        Cost65Acc c;
+        cost65_accumulate(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
+        const int li = lane & 31, lk = lane >> 5;
+        const Cost65Scale sq(g.D);
+        // LDS offsets of this lane's eight register rows: matrix row 8I + rho(s, J), columns 4J..4J+3 of the parity
+        int roff[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) roff[s] = (8 * I + ((s ^ J) ^ (s >= 4 ? 3 : 0))) * SST3 + 4 * J;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const f32x16& even = tj == 0 ? c.c00 : c.c01;        // tile (ti, tj): element [r] <-> matrix (2 rc + ti, 2 li + tj)
+            const f32x16& odd = tj == 0 ? c.c10 : c.c11;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rc = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                lds.stage[(2 * rc) * SST3 + li] = cost65_scale(even[r], sq);
+                lds.stage[(2 * rc + 1) * SST3 + li] = cost65_scale(odd[r], sq);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f4v v = *reinterpret_cast<const f4v*>(&lds.stage[roff[s]]);    // k[s][2m + tj], m = 0..3
+                const int sp = s >> 1;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float x = m == 0 ? v.x : m == 1 ? v.y : m == 2 ? v.z : v.w;
+                    if (tj == 0) { if (s & 1) Pb[sp][m].x = x; else Pa[sp][m].x = x; }
+                    else         { if (s & 1) Pa[sp][m].y = x; else Pb[sp][m].y = x; }
+                }
+            }
+        }
+        if (lk == 0) {
+            lds.erow[2 * li] = cost65_scale(c.er0, sq);
+            lds.erow[2 * li + 1] = cost65_scale(c.er1, sq);
+            lds.ecol[2 * li] = cost65_scale(c.ec0, sq);
+            lds.ecol[2 * li + 1] = cost65_scale(c.ec1, sq);
+        }
+        zcorner = cost65_scale(c.cn, sq);
+        __syncthreads();
+        zdrow = lds.erow[colj];          // Z[64][8J+I]
+        zdcol = lds.ecol[lane];          // Z[8I+J][64]
+        __syncthreads();
+        lds.erow[lane] = g.scale_x[p * 64 + lane];       // the epilogue's target scales wait in the freed edge buffers
+        lds.ecol[lane] = g.scale_y[p * 64 + lane];
+    }
+
+    // ---- stabilisers r_i = max_j Z_ij, c_j = max_i (Z_ij - r_i); K = exp(Z - r - c) -----------------------
+    float part[8];
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+        float me = fmaxf(Pa[sp][0].x, Pb[sp][0].y), mo = fmaxf(Pb[sp][0].x, Pa[sp][0].y);
+#pragma unroll
+        for (int cp = 1; cp < 4; ++cp) {
+            me = fmaxf(me, fmaxf(Pa[sp][cp].x, Pb[sp][cp].y));
+            mo = fmaxf(mo, fmaxf(Pb[sp][cp].x, Pa[sp][cp].y));
+        }
+        part[2 * sp] = me;
+        part[2 * sp + 1] = mo;
+    }
+    const float r_own = fmaxf(reduce8_perm(part, OpMax()), zdcol);
+    const float r64 = uni3(fmaxf(wave_max(zdrow), zcorner));
+    float rl[8];
+    gather_rows(r_own, rl);
+    f2v cm[4];
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+        f2v m = {Pa[0][cp].x - rl[0], Pb[0][cp].y - rl[0]};
+        m = f2v{fmaxf(m.x, Pb[0][cp].x - rl[1]), fmaxf(m.y, Pa[0][cp].y - rl[1])};
+#pragma unroll
+        for (int sp = 1; sp < 4; ++sp) {
+            m = f2v{fmaxf(m.x, Pa[sp][cp].x - rl[2 * sp]), fmaxf(m.y, Pb[sp][cp].y - rl[2 * sp])};
+            m = f2v{fmaxf(m.x, Pb[sp][cp].x - rl[2 * sp + 1]), fmaxf(m.y, Pa[sp][cp].y - rl[2 * sp + 1])};
+        }
+        cm[cp] = m;
+    }
+    const float cpart[8] = {cm[0].x, cm[0].y, cm[1].x, cm[1].y, cm[2].x, cm[2].y, cm[3].x, cm[3].y};
+    const float c_own = fmaxf(reduce8_strided(cpart, OpMax(), lane), zdrow - r64);
+    const float c64 = uni3(fmaxf(wave_max(zdcol - r_own), zcorner - r64));
+    __syncthreads();
+    lds.vb[colj] = c_own;
+    __syncthreads();
+    {
+        const f4v v0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), v1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
+        const float cl[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+                const float r0 = rl[2 * sp], r1 = rl[2 * sp + 1], c0 = cl[2 * cp], c1 = cl[2 * cp + 1];
+                Pa[sp][cp] = f2v{fast_exp2(((Pa[sp][cp].x - r0) - c0) * LOG2E), fast_exp2(((Pa[sp][cp].y - r1) - c1) * LOG2E)};
+                Pb[sp][cp] = f2v{fast_exp2(((Pb[sp][cp].x - r1) - c0) * LOG2E), fast_exp2(((Pb[sp][cp].y - r0) - c1) * LOG2E)};
+            }
+    }
+    const float kdcol = fast_exp2(((zdcol - r_own) - c64) * LOG2E);     // K[8I+J][64]
+    const float kdrow = fast_exp2(((zdrow - r64) - c_own) * LOG2E);     // K[64][8J+I]
+    const float kcorner = uni3(fast_exp2(((zcorner - r64) - c64) * LOG2E));
+    const float mu = uni3(expf(lmu)), mu64 = uni3(expf(lmu64)), nu = expf(lnu), nu64 = uni3(expf(lnu64));
+    float a = 0.f, a64 = 0.f, b = expf(c_own), b64 = expf(c64);
+    __syncthreads();
+    lds.vb[colj] = b;
+    for (int it = 0; it < g.iters; ++it) {
+        __syncthreads();                                 // b visible
+        {   // a_i = mu_i / sum_j K_ij b_j
+            const f4v b0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), b1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
+            const f2v bp[4] = {b0.xy, b0.zw, b1.xy, b1.zw};
+            f2v acc[4];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) acc[sp] = Pa[sp][0] * bp[0];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) acc[sp] = __builtin_elementwise_fma(Pb[sp][0].yx, bp[0].yx, acc[sp]);
+#pragma unroll
+            for (int cp = 1; cp < 4; ++cp) {
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) acc[sp] = __builtin_elementwise_fma(Pa[sp][cp], bp[cp], acc[sp]);
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) acc[sp] = __builtin_elementwise_fma(Pb[sp][cp].yx, bp[cp].yx, acc[sp]);
+            }
+            const float rp[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+            const float dsum = dustbin_sum<DB>(kdrow * b, lds.red, lane);
+            const float s = fmaf(kdcol, b64, reduce8_perm(rp, OpSum()));
+            a = mu * __builtin_amdgcn_rcpf(s);
+            a64 = mu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, b64, dsum));
+        }
+        {   // b_j = nu_j / sum_i K_ij a_i
+            float al[8];
+            gather_rows(a, al);
+            const f2v ap[4] = {f2v{al[0], al[1]}, f2v{al[2], al[3]}, f2v{al[4], al[5]}, f2v{al[6], al[7]}};
+            f2v q[4];
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) q[cp] = Pa[0][cp] * ap[0];
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) q[cp] = __builtin_elementwise_fma(Pb[0][cp], ap[0].yx, q[cp]);
+#pragma unroll
+            for (int sp = 1; sp < 4; ++sp) {
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) q[cp] = __builtin_elementwise_fma(Pa[sp][cp], ap[sp], q[cp]);
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) q[cp] = __builtin_elementwise_fma(Pb[sp][cp], ap[sp].yx, q[cp]);
+            }
+            const float dsum = dustbin_sum<DB>(kdcol * a, lds.red + 4, lane);
+            const float t = fmaf(kdrow, a64, CR ? reduce8_strided_lds(q, lds.stage, I, J)
+                                                : reduce8_strided_pk(q[0], q[1], q[2], q[3], lane));
+            b = nu * __builtin_amdgcn_rcpf(t);
+            b64 = nu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, a64, dsum));
+            lds.vb[colj] = b;
+        }
+    }
+    if (!(__all(sc_ok3(a) && sc_ok3(b)) && sc_ok3(a64) && sc_ok3(b64))) {
+        // guard tripped: third_fused_kernel (log-sum-exp sweeps) redoes this problem in scan mode
+        if (lane == 0) {
+            g.cr.ifm[p * 16] = THIRD_REDO;
+            if (g.fallbacks) atomicAdd(g.fallbacks, 1ull);
+        }
+        return;
+    }
+
+    // ---- plan rows of block rows 2..5 -> LDS [(I-2)*8 + local row][RS3], then Compute_result ------------
+    // centre row q = 4 (qy - 2) + (qx - 2) is matrix row 8 qy + qx: block row qy, local row qx in 2..5.  A lane
+    // cannot tell statically which of its register rows those are, so block rows 2..5 store all eight.
+    __syncthreads();                                     // b of the last sweep visible
+    float* rows = lds.stage;
+    const float en = expf(-norm);
+    if (I >= 2 && I <= 5) {
+        const f4v v0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), v1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
+        const f2v bp[4] = {v0.xy, v0.zw, v1.xy, v1.zw};
+        float al[8];
+        gather_rows(a * en, al);                         // plan = (K a e^-norm) b
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            float* row0 = rows + ((I - 2) * 8 + ((2 * sp) ^ J ^ (sp >= 2 ? 3 : 0))) * RS3 + 8 * J;
+            float* row1 = rows + ((I - 2) * 8 + ((2 * sp + 1) ^ J ^ (sp >= 2 ? 3 : 0))) * RS3 + 8 * J;
+            const f2v a01 = {al[2 * sp], al[2 * sp + 1]};
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+                const f2v pa = (Pa[sp][cp] * a01) * bp[cp];          // {k[2sp][2cp], k[2sp+1][2cp+1]}
+                const f2v pb = (Pb[sp][cp] * a01.yx) * bp[cp];       // {k[2sp+1][2cp], k[2sp][2cp+1]}
+                *reinterpret_cast<f2v*>(row0 + 2 * cp) = f2v{pa.x, pb.y};
+                *reinterpret_cast<f2v*>(row1 + 2 * cp) = f2v{pb.x, pa.y};
+            }
+        }
+        rows[((I - 2) * 8 + J) * RS3 + 64] = (kdcol * (a * en)) * b64;     // dustbin entry of the row this lane owns
+    }
+    __syncthreads();
+    compute_result16(rows, lds.erow, lds.ecol, p, (float)g.p_s[p * 2], (float)g.p_s[p * 2 + 1], (float)g.p_t[p * 2],
+                     (float)g.p_t[p * 2 + 1], g.outdoor, g.cr, lane);
+}
+
+int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
+    Fused65Args g = g0;
+    g.linear = 1;
+    g.fallbacks = fallback_counter();
+    if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
+    if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
+    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 300;   // A/B switch
+    const dim3 grid((unsigned)g.P), block(64);
+    switch (variant) {          // digits: waves per SIMD, column reduction, dustbin sums
+        case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, 0, st, g); break;
+        case 301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1>), grid, block, 0, st, g); break;
+        case 302: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 2>), grid, block, 0, st, g); break;
+        case 310: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 0>), grid, block, 0, st, g); break;
+        case 400: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 0>), grid, block, 0, st, g); break;
+        case 401: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 1>), grid, block, 0, st, g); break;
+        case 410: hipLaunchKernelGGL((third_fused3_kernel<4, 1, 0>), grid, block, 0, st, g); break;
+        case 411: hipLaunchKernelGGL((third_fused3_kernel<4, 1, 1>), grid, block, 0, st, g); break;
+        default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0>), grid, block, 0, st, g); break;
+    }
+    return check_launch("third_fused3_kernel");
+}
+
+}  // namespace pats

@@ -497,11 +497,34 @@ def gen_pipeline(R, name, seed, h, w, if_local, if_outdoor, merge_new):
          matches_r=matches_r)
 
 
+def gen_roofline(R):
+    """BASELINE.json configs[4] through the reference itself: cost einsum at [1,448,4096]^2, then
+    log_optimal_transport on 4097x4097 with 200 iterations (modules.py:145-162; ~10 s on 8 cores).  Stored:
+    sampled scores and log-plan entries, both argmax vectors, the marginals of exp(Z)."""
+    inp = synth.roofline_inputs()
+    d0, d1, ns = T(inp["d0"]), T(inp["d1"]), T(inp["ns"])
+    S = cost(d0, d1, d0.shape[1])
+    Z = R.M.log_optimal_transport(S, torch.tensor(float(inp["alpha"])), ns, 200)
+    rng = np.random.default_rng(3)
+    si, zi = sample_idx(rng, S.shape, 8192), sample_idx(rng, Z.shape, 16384)
+    E = Z.double().exp()
+    save("roofline_4097.npz", in_checksum=synth.checksum(inp["d0"][:, :, :64], inp["ns"]), iters=np.int64(200),
+         S_idx=si, S_val=S.reshape(-1)[T(si)], Z_idx=zi, Z_val=Z.reshape(-1)[T(zi)],
+         max0=Z.max(2).indices[0], max1=Z.max(1).indices[0], row_mass=E.sum(2)[0], col_mass=E.sum(1)[0],
+         Z_last_row=Z[0, -1, ::8], Z_last_col=Z[0, ::8, -1])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_import.load()
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]     # e.g. `make_golden.py big` regenerates only the
+    if only == ["big"]:                                           # bench-size fixtures added in round 2
+        gen_pipeline(R, "pipeline_640x480_outdoor.npz", synth.SEED + 50, 15, 20, True, True, True)
+        gen_pipeline(R, "pipeline_640x480_indoor.npz", synth.SEED + 51, 15, 20, False, False, False)
+        gen_roofline(R)
+        return
     gen_kat(R)
     gen_sinkhorn_raw(R)
     gen_ties(R)
@@ -525,6 +548,9 @@ def main():
     gen_attention(R)
     gen_pipeline(R, "pipeline_outdoor.npz", synth.SEED + 40, 5, 6, True, True, True)
     gen_pipeline(R, "pipeline_indoor.npz", synth.SEED + 41, 4, 5, False, False, False)
+    gen_pipeline(R, "pipeline_640x480_outdoor.npz", synth.SEED + 50, 15, 20, True, True, True)
+    gen_pipeline(R, "pipeline_640x480_indoor.npz", synth.SEED + 51, 15, 20, False, False, False)
+    gen_roofline(R)
 
 
 if __name__ == "__main__":
