@@ -122,8 +122,8 @@ class Workload:
 def coarse_ops(ops, wl):
     """first_layer.py:110-135 for all pairs: one batched cost+OT launch, column mass, argmax + expansion."""
     Z = ops.cost_ot(wl.d0, wl.d1, 1, wl.alpha, wl.ns, ITERS)
-    scales = ops.colmass_sqrt(Z)
-    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (480, 640), 32)
+    scales, cflag = ops.colmass_sqrt(Z, return_flags=True)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (480, 640), 32, col_nomatch=cflag)
     sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1, dtype=torch.int32)
     return pts, xs, ys, ifn1, sum_cycle
 
@@ -172,11 +172,11 @@ def fine_and_third(ops, wl, co, ev):
     if ev is not None:
         f0_, f1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0_.record()
-    Z2 = ops.cost_ot(ch["f0"], ch["f1"], 2, ONE[0], ch["ns2"], ITERS, bias_k=2.0)
+    Z2, cflag2 = ops.cost_ot(ch["f0"], ch["f1"], 2, ONE[0], ch["ns2"], ITERS, bias_k=2.0, return_flags=True)
     if ev is not None:
         f1_.record()
         ev["fine"].append((f0_, f1_))
-    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, ch["sx"], ch["sy"], [96, 96], 8)
+    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, ch["sx"], ch["sy"], [96, 96], 8, col_nomatch=cflag2)
     # third level: cost build + OT + exp + Compute_result + label in ONE launch (the dominant kernel)
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

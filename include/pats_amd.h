@@ -84,6 +84,13 @@ int pats_log_optimal_transport_f32(const float* scores, int64_t batch, int m, in
  * workspace: pats_ot2_workspace_bytes(batch, m, n) - 0 for 65 x 65, one guard flag per problem for
  * 145 x 145 (the resident kernels), pats_ot_workspace_bytes otherwise. */
 size_t pats_ot2_workspace_bytes(int64_t batch, int m, int n);
+/* the same plus est_position's if_nomatching2 = (Z.max(1).indices == m-1) for the first n-1 columns
+ * (second_layer.py:243,248; first index wins ties): col_nomatch [batch,n-1] uint8, written by the 145 x 145
+ * kernel's own epilogue (other shapes: one extra pass over Z).  Row flags come from pats_iterative_expand_f32. */
+int pats_log_optimal_transport2_flags_f32(const float* scores, int64_t batch, int m, int n,
+                                          const float* one, const float* ns, int iters, float bias_k,
+                                          float* Z, uint8_t* col_nomatch, void* workspace,
+                                          size_t workspace_bytes, pats_stream_t stream);
 int pats_log_optimal_transport2_f32(const float* scores, int64_t batch, int m, int n,
                                     const float* one, const float* ns, int iters, float bias_k,
                                     float* Z, void* workspace, size_t workspace_bytes,
@@ -97,6 +104,11 @@ int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch, int D, int
                      int variant, const float* scalar, const float* ns, int iters, float bias_k,
                      float* Z, void* workspace, size_t workspace_bytes, pats_stream_t stream);
 size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int variant);
+/* variant 2 with the column flags of pats_log_optimal_transport2_flags_f32 (same workspace). */
+int pats_cost_ot_flags_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
+                           int variant, const float* scalar, const float* ns, int iters, float bias_k,
+                           float* Z, uint8_t* col_nomatch, void* workspace, size_t workspace_bytes,
+                           pats_stream_t stream);
 
 /* ---- a7: post-OT reductions ----------------------------------------------------------------
  * colmass: out[b,j] = sqrtf(sum_{i<M-1} expf(Z[b,i,j]) + 1e-8f), j < N-1   first_layer.py:117-118
@@ -104,6 +116,10 @@ size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int vari
  * exp    : out = expf(Z)                                                    third_layer.py:159 */
 int pats_colmass_sqrt_f32(const float* Z, int64_t batch, int M, int N, float* out,
                           pats_stream_t stream);
+/* colmass plus est_position's if_nomatching2 = (scores.max(1).indices == M-1) in the same pass over the
+ * columns (first_layer.py:163,167): col_nomatch [batch,N-1] uint8.  Either output may be NULL. */
+int pats_colmass_flags_f32(const float* Z, int64_t batch, int M, int N, float* out, uint8_t* col_nomatch,
+                           pats_stream_t stream);
 int pats_dustbin_bias_inplace_f32(float* Z, int64_t batch, int M, int N, float k,
                                   pats_stream_t stream);
 int pats_exp_f32(const float* Z, int64_t count, float* out, pats_stream_t stream);
@@ -119,12 +135,16 @@ int pats_argmax_f32(const float* Z, int64_t batch, int M, int N, int64_t* row_ar
  * scalex, scaley [batch,N-1]; lim3 = limitation[3]; (h, w) = the TRUE grid the caller built
  * positions/ranges for (Compute_positions_and_ranges, utils.py:1527-1537).
  * outputs: whole_cost, core_cost, x_scale, y_scale [batch,M-1]; average_point [batch,M-1,2];
- * bound [batch,M-1,4] int64 (up,down,left,right). */
+ * bound [batch,M-1,4] int64 (up,down,left,right).
+ *
+ * row_nomatch (optional, [batch,M-1] uint8): est_position's if_nomatching1 = (scores.max(2).indices == N-1)
+ * (first_layer.py:162-164, second_layer.py:243-245) taken from the values as handed in - the row is in LDS
+ * here anyway, so the separate argmax pass over the plan disappears. */
 int pats_iterative_expand_f32(const float* P, int input_is_log, int64_t batch, int M, int N,
                               const float* scalex, const float* scaley, int lim3, int h, int w,
                               float lower_bound, int iter_num, float* whole_cost, float* core_cost,
                               float* average_point, float* x_scale, float* y_scale, int64_t* bound,
-                              pats_stream_t stream);
+                              uint8_t* row_nomatch, pats_stream_t stream);
 
 /* ---- a12: split_patches(sum_cycle, height, width, max_once_used)  utils/utils.py:152-181 ----
  * HOST function on a host copy of the int32 cumsum (the reference syncs per comparison; here the

@@ -31,6 +31,11 @@ SIGNATURES = {
                                                 c_f, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_cost_ot_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                  c_void_p, c_int, c_f, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_cost_ot_flags_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_void_p, c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_log_optimal_transport2_flags_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
+                                                      c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_colmass_flags_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pats_cost_ot_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int]),
     "pats_colmass_sqrt_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p]),
     "pats_dustbin_bias_inplace_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_f, c_void_p]),
@@ -38,7 +43,7 @@ SIGNATURES = {
     "pats_argmax_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pats_iterative_expand_f32": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
                                           c_int, c_int, c_f, c_int, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pats_split_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pats_split_patches_device": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pats_compute_imgs_bounds_batch_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -34,6 +34,7 @@ struct ExpandArgs {
     int iter_num;
     float *whole_cost, *core_cost, *average_point, *x_scale, *y_scale;
     int64_t* bound;
+    uint8_t* row_nomatch;     // optional: scores.max(2).indices == N - 1 of the INPUT values (first_layer.py:162-164)
 };
 
 __device__ __forceinline__ float range_val(int d, int k) { return k <= d ? (float)k : 1e7f; }
@@ -65,10 +66,19 @@ expand_kernel(ExpandArgs a) {
     const float* oppsrc = Pb + (int64_t)(M - 1) * N;              // scores_in[:, -1, :-1]   (:1183)
     const float* sx = a.scalex + b * (int64_t)n;
     const float* sy = a.scaley + b * (int64_t)n;
+    // the caller's "no match" flag is the argmax of the values as handed in (the LOG plan when input_is_log:
+    // exp can round two distinct logs to one float, so the flag must not come from the exponentiated row)
+    float fv = -INFINITY;
+    int fi = 0x7fffffff;
     for (int j = t; j < N; j += 16) {
         const float x = src[j], o = oppsrc[j];
+        if (x > fv || fi == 0x7fffffff) { fv = x; fi = j; }
         prow[j] = a.input_is_log ? expf(x) : x;
         popp[j] = a.input_is_log ? expf(o) : o;
+    }
+    if (a.row_nomatch) {
+        row16_argmax(fv, fi);
+        if (t == 0 && active) a.row_nomatch[gr] = fi == N - 1;
     }
     __syncthreads();     // every thread gets here (idle groups shadow the last row)
 
@@ -230,7 +240,7 @@ extern "C" int pats_iterative_expand_f32(const float* P, int input_is_log, int64
                                          int h, int w, float lower_bound, int iter_num,
                                          float* whole_cost, float* core_cost, float* average_point,
                                          float* x_scale, float* y_scale, int64_t* bound,
-                                         pats_stream_t stream) {
+                                         uint8_t* row_nomatch, pats_stream_t stream) {
     PATS_REQUIRE(batch >= 0 && M > 1 && N > 1 && h > 0 && w > 0 && lim3 > 0 && iter_num >= 1,
                  "iterative_expand: bad argument");
     PATS_REQUIRE(h * w == N - 1, "iterative_expand: grid %dx%d does not match %d target columns", h,
@@ -239,7 +249,7 @@ extern "C" int pats_iterative_expand_f32(const float* P, int input_is_log, int64
     PATS_REQUIRE(P && scalex && scaley && whole_cost && core_cost && average_point && x_scale &&
                      y_scale && bound, "iterative_expand: null pointer");
     ExpandArgs a{P, input_is_log, batch * (int64_t)(M - 1), M, N, scalex, scaley, lim3, h, w,
-                 lower_bound, iter_num, whole_cost, core_cost, average_point, x_scale, y_scale, bound};
+                 lower_bound, iter_num, whole_cost, core_cost, average_point, x_scale, y_scale, bound, row_nomatch};
     int rows_per_wg = 16;
     size_t lds = 2 * (size_t)rows_per_wg * (size_t)(N + 3) * sizeof(float);
     if (lds > 48 * 1024) {

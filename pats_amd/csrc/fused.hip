@@ -10,6 +10,8 @@ using namespace pats;
 namespace pats {
 int launch_cost_ot65(const float*, const float*, int64_t, int, const float*, const float*, int, float, float*,
                      pats_stream_t);
+int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_nomatch, const int* only_if,
+                     hipStream_t st);
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -22,16 +24,40 @@ extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int 
     return scores + (variant == 1 ? pats_ot_workspace_bytes(batch, M, N) : pats_ot2_workspace_bytes(batch, M, N));
 }
 
+static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, int n, int m, int variant,
+                        const float* scalar, const float* ns, int iters, float bias_k, float* Z, uint8_t* col_nomatch,
+                        void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
 extern "C" int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
                                 int variant, const float* scalar, const float* ns, int iters,
                                 float bias_k, float* Z, void* workspace, size_t workspace_bytes,
                                 pats_stream_t stream) {
+    return cost_ot_impl(d0, d1, batch, D, n, m, variant, scalar, ns, iters, bias_k, Z, nullptr, workspace,
+                        workspace_bytes, stream);
+}
+
+// variant 2 only: additionally est_position's if_nomatching2 (second_layer.py:243,248) from the OT epilogue
+extern "C" int pats_cost_ot_flags_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
+                                      int variant, const float* scalar, const float* ns, int iters,
+                                      float bias_k, float* Z, uint8_t* col_nomatch, void* workspace,
+                                      size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(variant == 2, "cost_ot_flags: column flags come from the log_optimal_transport2 epilogue (variant 2); "
+                               "for variant 1 use pats_colmass_flags_f32, which the coarse level needs anyway");
+    return cost_ot_impl(d0, d1, batch, D, n, m, variant, scalar, ns, iters, bias_k, Z, col_nomatch, workspace,
+                        workspace_bytes, stream);
+}
+
+static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, int n, int m, int variant,
+                        const float* scalar, const float* ns, int iters, float bias_k, float* Z, uint8_t* col_nomatch,
+                        void* workspace, size_t workspace_bytes, pats_stream_t stream) {
     PATS_REQUIRE(variant == 1 || variant == 2, "cost_ot: variant must be 1 or 2");
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost_ot: bad shape");
     if (batch == 0) return PATS_OK;
     if (variant == 2 && n == 65 && m == 65 && (D % 32) == 0 && D <= 512) {
         PATS_REQUIRE(d0 && d1 && ns && Z, "cost_ot: null pointer");
-        return launch_cost_ot65(d0, d1, batch, D, scalar, ns, iters, bias_k, Z, stream);
+        int rc = launch_cost_ot65(d0, d1, batch, D, scalar, ns, iters, bias_k, Z, stream);
+        if (!rc && col_nomatch) rc = launch_col_flags(Z, batch, n, m, col_nomatch, nullptr, (hipStream_t)stream);
+        return rc;
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_cost_ot_workspace_bytes(batch, D, n, m, variant),
                  "cost_ot: workspace too small");
@@ -46,6 +72,6 @@ extern "C" int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch,
         return pats_log_optimal_transport_f32(scores, batch, n, m, scalar, ns, iters, Z, ws2,
                                               workspace_bytes - off, stream);
     }
-    return pats_log_optimal_transport2_f32(scores, batch, n, m, scalar, ns, iters, bias_k, Z, ws2,
-                                           workspace_bytes - off, stream);
+    return pats_log_optimal_transport2_flags_f32(scores, batch, n, m, scalar, ns, iters, bias_k, Z, col_nomatch, ws2,
+                                                 workspace_bytes - off, stream);
 }

@@ -10,20 +10,31 @@
 
 namespace pats {
 
+// out (optional): sqrt(column mass + 1e-8); col_nomatch (optional): scores.max(1).indices == M - 1, i.e. the
+// dustbin row strictly above every real row (first index wins ties)   first_layer.py:117-118,163,167
 __global__ void __launch_bounds__(256)
-colmass_kernel(const float* __restrict__ Z, int M, int N, float* __restrict__ out) {
+colmass_kernel(const float* __restrict__ Z, int M, int N, float* __restrict__ out, uint8_t* __restrict__ col_nomatch,
+               const int* __restrict__ only_if) {
     const int64_t b = blockIdx.y;
+    if (only_if && !only_if[b]) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= N - 1) return;
     const float* z = Z + b * (int64_t)M * N + j;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, mx = -INFINITY;
     int i = 0;
     for (; i + 1 < M - 1; i += 2) {
-        s0 += expf(z[(int64_t)i * N]);
-        s1 += expf(z[(int64_t)(i + 1) * N]);
+        const float x0 = z[(int64_t)i * N], x1 = z[(int64_t)(i + 1) * N];
+        s0 += expf(x0);
+        s1 += expf(x1);
+        mx = fmaxf(mx, fmaxf(x0, x1));
     }
-    if (i < M - 1) s0 += expf(z[(int64_t)i * N]);
-    out[b * (N - 1) + j] = sqrtf((s0 + s1) + 1e-8f);
+    if (i < M - 1) {
+        const float x0 = z[(int64_t)i * N];
+        s0 += expf(x0);
+        mx = fmaxf(mx, x0);
+    }
+    if (out) out[b * (N - 1) + j] = sqrtf((s0 + s1) + 1e-8f);
+    if (col_nomatch) col_nomatch[b * (N - 1) + j] = z[(int64_t)(M - 1) * N] > mx;
 }
 
 __global__ void __launch_bounds__(256)
@@ -93,9 +104,34 @@ extern "C" int pats_colmass_sqrt_f32(const float* Z, int64_t batch, int M, int N
     PATS_REQUIRE(Z && out, "colmass: null pointer");
     PATS_REQUIRE(batch <= 65535, "colmass: batch too large");
     hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)batch),
-                       dim3(256), 0, as_stream(stream), Z, M, N, out);
+                       dim3(256), 0, as_stream(stream), Z, M, N, out, (uint8_t*)nullptr, (const int*)nullptr);
     return check_launch("colmass_kernel");
 }
+
+extern "C" int pats_colmass_flags_f32(const float* Z, int64_t batch, int M, int N, float* out, uint8_t* col_nomatch,
+                                      pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && M > 1 && N > 1, "colmass_flags: bad shape");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(Z && (out || col_nomatch), "colmass_flags: null pointer");
+    PATS_REQUIRE(batch <= 65535, "colmass_flags: batch too large");
+    hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)batch),
+                       dim3(256), 0, as_stream(stream), Z, M, N, out, col_nomatch, (const int*)nullptr);
+    return check_launch("colmass_kernel");
+}
+
+namespace pats {
+// column flags of the problems with only_if[b] != 0 (all when only_if is null): the OT entry points use it for the
+// shapes / problems whose Sinkhorn kernel does not emit the flags from its own epilogue
+int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_nomatch, const int* only_if, hipStream_t st) {
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+        const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)nb), dim3(256), 0, st,
+                           Z + b0 * (int64_t)M * N, M, N, (float*)nullptr, col_nomatch + b0 * (N - 1),
+                           only_if ? only_if + b0 : nullptr);
+    }
+    return check_launch("colmass_kernel(flags)");
+}
+}  // namespace pats
 
 extern "C" int pats_dustbin_bias_inplace_f32(float* Z, int64_t batch, int M, int N, float k,
                                              pats_stream_t stream) {

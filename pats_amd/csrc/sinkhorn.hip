@@ -964,7 +964,9 @@ static inline int use_linear() { return sinkhorn_mode() != PATS_SINKHORN_LOG; }
 namespace pats {
 int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                   const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
-                  hipStream_t st);     // sinkhorn_blk.hip
+                  uint8_t* col_nomatch, hipStream_t st);     // sinkhorn_blk.hip
+int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_nomatch, const int* only_if,
+                     hipStream_t st);                       // post.hip
 }
 
 // 145 x 145: the register-block kernel solves in the linear domain and flags the problems whose
@@ -973,11 +975,11 @@ int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, 
 // does everything, as before.
 static int launch_fine145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                           const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
-                          hipStream_t st) {
+                          hipStream_t st, uint8_t* col_nomatch = nullptr) {
     static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;      // A/B switch for benchmarking
     const bool blk = use_linear() && iters > 0 && fail && !v1_only;
     if (blk) {
-        int rc = launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, st);
+        int rc = launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st);
         if (rc) return rc;
     }
     if (mode == 0)
@@ -988,7 +990,10 @@ static int launch_fine145(int mode, const float* Z, int64_t batch, const float* 
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, nullptr,
                            nullptr, ns, one, iters, bias_k, blk ? 0 : (int)use_linear(), out, fallback_counter(),
                            blk ? fail : nullptr);
-    return check_launch("sinkhorn_rc_kernel<145>");
+    int rc = check_launch("sinkhorn_rc_kernel<145>");
+    // column flags of the problems the log-domain kernel (re-)solved: all of them without the block kernel
+    if (!rc && col_nomatch) rc = launch_col_flags(out, batch, NF, NF, col_nomatch, blk ? fail : nullptr, st);
+    return rc;
 }
 
 extern "C" size_t pats_sinkhorn_workspace_bytes(int64_t batch, int M, int N) {
@@ -1073,10 +1078,27 @@ extern "C" int pats_log_optimal_transport_f32(const float* scores, int64_t batch
     return launch_wg(src, batch, M, N, w.log_mu, w.log_nu, w.norm, iters, 0.f, Z, w.Zw, w.Zt, st);
 }
 
+static int ot2_impl(const float* scores, int64_t batch, int m, int n, const float* one, const float* ns, int iters,
+                    float bias_k, float* Z, void* workspace, size_t workspace_bytes, pats_stream_t stream,
+                    uint8_t* col_nomatch);
+
 extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batch, int m, int n,
                                                const float* one, const float* ns, int iters,
                                                float bias_k, float* Z, void* workspace,
                                                size_t workspace_bytes, pats_stream_t stream) {
+    return ot2_impl(scores, batch, m, n, one, ns, iters, bias_k, Z, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int pats_log_optimal_transport2_flags_f32(const float* scores, int64_t batch, int m, int n,
+                                                     const float* one, const float* ns, int iters,
+                                                     float bias_k, float* Z, uint8_t* col_nomatch, void* workspace,
+                                                     size_t workspace_bytes, pats_stream_t stream) {
+    return ot2_impl(scores, batch, m, n, one, ns, iters, bias_k, Z, workspace, workspace_bytes, stream, col_nomatch);
+}
+
+static int ot2_impl(const float* scores, int64_t batch, int m, int n, const float* one, const float* ns, int iters,
+                    float bias_k, float* Z, void* workspace, size_t workspace_bytes, pats_stream_t stream,
+                    uint8_t* col_nomatch) {
     PATS_REQUIRE(batch >= 0 && m > 1 && n > 1 && iters >= 0, "log_optimal_transport2: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(scores && ns && Z, "log_optimal_transport2: null pointer");
@@ -1087,11 +1109,13 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
         g.Zin = scores; g.P = batch; g.ns = ns; g.one = one; g.iters = iters; g.bias_k = bias_k;
         g.linear = use_linear(); g.out = Z;
         hipLaunchKernelGGL((sinkhorn65_kernel<2, 0, 0>), dim3((unsigned)batch), dim3(64), 0, st, g);
-        return check_launch("sinkhorn65_kernel<2,0,0>");
+        int rc = check_launch("sinkhorn65_kernel<2,0,0>");
+        if (!rc && col_nomatch) rc = launch_col_flags(Z, batch, m, n, col_nomatch, nullptr, st);
+        return rc;
     }
     if (m == NF && n == NF) {
         int* fail = (workspace && workspace_bytes >= pats_ot2_workspace_bytes(batch, m, n)) ? (int*)workspace : nullptr;
-        return launch_fine145(2, scores, batch, nullptr, nullptr, ns, one, iters, bias_k, Z, fail, st);
+        return launch_fine145(2, scores, batch, nullptr, nullptr, ns, one, iters, bias_k, Z, fail, st, col_nomatch);
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_ot2_workspace_bytes(batch, m, n),
                  "log_optimal_transport2: workspace too small");   // shapes without a resident kernel
@@ -1101,7 +1125,9 @@ extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batc
     int rc = check_launch("ot_prep_kernel");
     if (rc) return rc;
     SrcView src{scores, (int64_t)m * n, n, m, n, nullptr};
-    return launch_wg(src, batch, m, n, w.log_mu, w.log_nu, w.norm, iters, bias_k, Z, nullptr, w.Zt, st);
+    rc = launch_wg(src, batch, m, n, w.log_mu, w.log_nu, w.norm, iters, bias_k, Z, nullptr, w.Zt, st);
+    if (!rc && col_nomatch) rc = launch_col_flags(Z, batch, m, n, col_nomatch, nullptr, st);
+    return rc;
 }
 
 // descriptors -> log-plan for 65x65 problems in one launch (cost build + OT2), used by pats_cost_ot_f32

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256, 3)
 sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ log_mu_in,
                        const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                        const float* __restrict__ one, int iters, float bias_k, float* __restrict__ out,
-                       int* __restrict__ fail) {
+                       int* __restrict__ fail, uint8_t* __restrict__ col_nomatch) {
     __shared__ BlkLds lds;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, J = t & 15, I = t >> 4, rho = lane >> 4;
     const int64_t p = blockIdx.x;
@@ -269,22 +269,44 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     load9(&lds.vb[J * VS], vl);
     const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
     float* Op = out + p * (N_ * N_);
+    float cm[BS];                      // column maxima of the OUTPUT over this lane's nine (real) rows
+#pragma unroll
+    for (int c = 0; c < BS; ++c) cm[c] = -INFINITY;
 #pragma unroll
     for (int r = 0; r < BS; ++r)
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
             const int e = (BS * I + r) * N_ + BS * J + c;
-            Op[e] = ((Zp[e] + ul[r]) + vl[c]) - norm;
+            const float o = ((Zp[e] + ul[r]) + vl[c]) - norm;
+            Op[e] = o;
+            cm[c] = fmaxf(cm[c], o);
         }
     if (rown) {
         float z = ((zdc + (logf(a) - r_own)) + v_d) - norm;
         if (bias_k > 0.f) z += lb;
         Op[rowi * N_ + NB] = z;
     }
+    float zrow = 0.f;
     if (cown) {
         float z = ((zdr + u_d) + (logf(b) - c_own)) - norm;
         if (bias_k > 0.f) z += lb;
         Op[NB * N_ + colj] = z;
+        zrow = z;
+    }
+    if (col_nomatch) {
+        // est_position's if_nomatching2 = (scores.max(1).indices == 144), second_layer.py:243,248: the dustbin row
+        // strictly above every real row of the column (first index wins ties); partial maxima cross the 16 lanes
+        // that share J through LDS, as for the stabilisers
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < BS; ++c) lds.tmp[(BS * J + c) * 17 + I] = cm[c];
+        __syncthreads();
+        if (cown) {
+            float x = lds.tmp[colj * 17];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) x = fmaxf(x, lds.tmp[colj * 17 + k]);
+            col_nomatch[p * NB + colj] = zrow > x;
+        }
     }
     if (t == 0) {
         float z = ((zcorner + u_d) + v_d) - norm;
@@ -296,13 +318,13 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
 // fail must hold `batch` ints
 int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                   const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
-                  hipStream_t st) {
+                  uint8_t* col_nomatch, hipStream_t st) {
     if (mode == 0)
         hipLaunchKernelGGL((sinkhorn_blk145_kernel<0>), dim3((unsigned)batch), dim3(256), 0, st, Z, log_mu, log_nu,
-                           (const float*)nullptr, (const float*)nullptr, iters, 0.f, out, fail);
+                           (const float*)nullptr, (const float*)nullptr, iters, 0.f, out, fail, col_nomatch);
     else
         hipLaunchKernelGGL((sinkhorn_blk145_kernel<2>), dim3((unsigned)batch), dim3(256), 0, st, Z,
-                           (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail);
+                           (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch);
     return check_launch("sinkhorn_blk145_kernel");
 }
 

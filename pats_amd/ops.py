@@ -142,8 +142,10 @@ def log_optimal_transport2(scores, one, ns, iters: int, bias_k: float = 0.0):
     return Z
 
 
-def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0):
-    """descriptors -> log-plan (cost build + OT on one stream, score matrix never returned)."""
+def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0, return_flags=False):
+    """descriptors -> log-plan (cost build + OT on one stream, score matrix never returned).
+    return_flags (variant 2): also est_position's if_nomatching2 [b, m-1] (bool) from the OT epilogue ->
+    (Z, col_nomatch); hand it to est_position_second(col_nomatch=...)."""
     d0, d1 = _dev(mdesc0, "mdesc0"), _dev(mdesc1, "mdesc1")
     b, D, n = d0.shape
     m = d1.shape[2]
@@ -153,6 +155,14 @@ def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0
     Z = torch.empty(shape, dtype=torch.float32, device=d0.device)
     nb = _L().pats_cost_ot_workspace_bytes(b, D, n, m, variant)
     ws = _workspace(nb, d0.device)
+    if return_flags:
+        if variant != 2:
+            raise RuntimeError("cost_ot: return_flags needs variant 2 (the coarse level gets them from colmass_sqrt)")
+        flags = torch.empty((b, m - 1), dtype=torch.bool, device=d0.device)
+        _check(_L().pats_cost_ot_flags_f32(_ptr(d0), _ptr(d1), b, D, n, m, int(variant), _ptr(s), _ptr(ns), int(iters),
+                                           float(bias_k), _ptr(Z), _ptr(flags.view(torch.uint8)), _ptr(ws), nb, _stream()),
+               "cost_ot")
+        return Z, flags
     _check(_L().pats_cost_ot_f32(_ptr(d0), _ptr(d1), b, D, n, m, int(variant), _ptr(s), _ptr(ns),
                                  int(iters), float(bias_k), _ptr(Z), _ptr(ws), nb, _stream()), "cost_ot")
     return Z
@@ -161,11 +171,18 @@ def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0
 # ------------------------------------------------------------------------------------------------
 # post-OT
 # ------------------------------------------------------------------------------------------------
-def colmass_sqrt(Z):
-    """sqrt(exp(Z[:, :-1, :-1]).sum(1) + 1e-8)   (first_layer.py:117-118)."""
+def colmass_sqrt(Z, return_flags=False):
+    """sqrt(exp(Z[:, :-1, :-1]).sum(1) + 1e-8)   (first_layer.py:117-118).
+    return_flags: the same pass over the columns also yields est_position's if_nomatching2 (first_layer.py:163,167)
+    -> (scales, col_nomatch [b, N-1] bool)."""
     Z = _dev(Z, "Z")
     b, M, N = Z.shape
     out = torch.empty((b, N - 1), dtype=torch.float32, device=Z.device)
+    if return_flags:
+        flags = torch.empty((b, N - 1), dtype=torch.bool, device=Z.device)
+        _check(_L().pats_colmass_flags_f32(_ptr(Z), b, M, N, _ptr(out), _ptr(flags.view(torch.uint8)), _stream()),
+               "colmass_sqrt")
+        return out, flags
     _check(_L().pats_colmass_sqrt_f32(_ptr(Z), b, M, N, _ptr(out), _stream()), "colmass_sqrt")
     return out
 
@@ -226,7 +243,7 @@ def _grid_of(positions, ranges):
 
 def Iterative_expand_matrix(scores_in, scalex, scaley, limitation, ranges, positions,
                             lower_bound=1e-3, upper_bound=1e7, iter_num=15, width=20, height=15,
-                            type="distance", input_is_log=False):
+                            type="distance", input_is_log=False, row_nomatch=None):
     """utils/utils.py:1179-1297.  Returns (whole_cost, core_cost, average_point, x_scale, y_scale,
     bound) with the reference's shapes/dtypes.  `width`/`height`/`upper_bound`/`type` are accepted
     and ignored exactly as the reference ignores them (it re-derives width/height at :1181)."""
@@ -254,36 +271,43 @@ def Iterative_expand_matrix(scores_in, scalex, scaley, limitation, ranges, posit
     _check(_L().pats_iterative_expand_f32(_ptr(P), int(bool(input_is_log)), b, M, N, _ptr(sx), _ptr(sy),
                                           lim3, h, w, float(lower_bound), int(iter_num), _ptr(whole),
                                           _ptr(core), _ptr(avg), _ptr(xs), _ptr(ys), _ptr(bound),
+                                          _ptr(row_nomatch.view(torch.uint8)) if row_nomatch is not None else _ptr(None),
                                           _stream()), "Iterative_expand_matrix")
     return whole, core, avg, xs, ys, bound
 
 
-def _est_position(scores, scale_x, scale_y, H, W, patch_scale, iter_num, lower_bound):
-    b = scores.shape[0]
+def _est_position(scores, scale_x, scale_y, H, W, patch_scale, iter_num, lower_bound, col_nomatch=None):
+    """est_position (first_layer.py:159-178 / second_layer.py:240-259) without a separate argmax pass: the row flag
+    `scores.max(2).indices[:, :-1] == h*w` comes out of the expansion kernel (which holds every row anyway), the
+    column flag from the caller (OT epilogue / colmass pass) or, failing that, from one pass over the columns."""
+    b, M, N = scores.shape
     h, w = H // patch_scale, W // patch_scale
-    max0, max1 = argmax(scores)
-    max0, max1 = max0[:, :-1], max1[:, :-1]
-    if_nomatching1 = max0 == h * w
-    if_nomatching2 = max1 == h * w
+    if col_nomatch is None:
+        col_nomatch = torch.empty((b, N - 1), dtype=torch.bool, device=scores.device)
+        _check(_L().pats_colmass_flags_f32(_ptr(_dev(scores, "scores")), b, M, N, _ptr(None),
+                                           _ptr(col_nomatch.view(torch.uint8)), _stream()), "est_position")
+    if_nomatching1 = torch.empty((b, M - 1), dtype=torch.bool, device=scores.device)
     positions1, ranges1 = Compute_positions_and_ranges(h, w, scores.device)
     limitation1 = [0, h, 0, w]
     trust_score, _, average_point1, x_scale, y_scale, _ = Iterative_expand_matrix(
         scores, scale_x.reshape(b, -1, 1), scale_y.reshape(b, -1, 1), limitation1, ranges1, positions1,
-        height=h, width=w, iter_num=iter_num, lower_bound=lower_bound, input_is_log=True)
-    return trust_score, average_point1, x_scale, y_scale, if_nomatching1, if_nomatching2
+        height=h, width=w, iter_num=iter_num, lower_bound=lower_bound, input_is_log=True, row_nomatch=if_nomatching1)
+    return trust_score, average_point1, x_scale, y_scale, if_nomatching1, col_nomatch
 
 
-def est_position_first(scores, scale_src, image_shape, patch_scale):
+def est_position_first(scores, scale_src, image_shape, patch_scale, col_nomatch=None):
     """FirstLayer.est_position (first_layer.py:159-178): scores is the LOG plan; exp() is fused
-    into the expansion kernel's load."""
+    into the expansion kernel's load.  col_nomatch: if_nomatching2 when the caller already has it
+    (colmass_sqrt(return_flags=True))."""
     H, W = image_shape
-    return _est_position(scores, scale_src, scale_src, H, W, patch_scale, 15, 1e-5)
+    return _est_position(scores, scale_src, scale_src, H, W, patch_scale, 15, 1e-5, col_nomatch)
 
 
-def est_position_second(scores, scale_x, scale_y, image_shape, patch_scale):
-    """SecondLayer.est_position (second_layer.py:240-259)."""
+def est_position_second(scores, scale_x, scale_y, image_shape, patch_scale, col_nomatch=None):
+    """SecondLayer.est_position (second_layer.py:240-259).  col_nomatch: if_nomatching2 from
+    cost_ot(..., return_flags=True)."""
     H, W = image_shape
-    return _est_position(scores, scale_x, scale_y, H, W, patch_scale, 8, 1e-3)
+    return _est_position(scores, scale_x, scale_y, H, W, patch_scale, 8, 1e-3, col_nomatch)
 
 
 # ------------------------------------------------------------------------------------------------

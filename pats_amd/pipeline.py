@@ -56,8 +56,8 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
     # ---- first layer tail (first_layer.py:110-146) ------------------------------------------------
     mdesc0, mdesc1, scale, alpha = nets.coarse(left, right)
     scores = ops.cost_ot(mdesc0, mdesc1, 1, alpha, scale, iters)
-    scales = ops.colmass_sqrt(scores)
-    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(scores, scales, (H, W), 32)
+    scales, cflag = ops.colmass_sqrt(scores, return_flags=True)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(scores, scales, (H, W), 32, col_nomatch=cflag)
     sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1)
     sc_host = sum_cycle.to("cpu").numpy()                       # host read 1: chunk plan + crop counts
     if int(sc_host[0, -1]) <= 0:                                # pats.py:27-31
@@ -82,8 +82,9 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
         mask = torch.logical_or(ifn1, torch.logical_or(sum_cycle <= lo, sum_cycle > hi))    # first_layer.py:137-138
         # ---- second layer tail (second_layer.py:100-124) --------------------------------------------
         f0, f1, sx, sy = nets.fine(num, new_left[lo:hi_c], new_right[lo:hi_c], mask)
-        Z2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0)
-        trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8)
+        Z2, cflag2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0,
+                                 return_flags=True)
+        trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
         ifn_L2, scores_back = merge(B, trust2, (H, W), mask, ifn_L2, scores_back, validate=False)
         tail = int(third_set[num][1])
         if tail != 0:                                           # pats.py:38-39
@@ -124,8 +125,9 @@ def _forward_batched(left, nets, if_outdoor, iters, merge, scores_back, ifn1, su
                        for lo, hi in second_set if min(hi, K) - lo > 0])                  # [C,N]  (first_layer.py:137-138)
     rows = torch.cat([torch.arange(lo, hi, device=dev) for lo, hi, _ in spans])          # overlap rows appear twice
     f0, f1, sx, sy = nets.fine(None, new_left[rows], new_right[rows], masks, sizes=sizes)
-    Z2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0)
-    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8)
+    Z2, cflag2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0,
+                             return_flags=True)
+    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
     merged = torch.empty_like(ifn_L2)
     off = 0
     for c, (lo, hi, tail) in enumerate(spans):                 # chunk order: scores_back couples them

@@ -859,3 +859,35 @@ def test_bench_spawns_its_own_ranks(ops, sinkhorn_mode):
         two = _run_bench({"PATS_BENCH_SHARE_DEVICE": "1", "PATS_BENCH_BACKEND": "gloo"}, 2)
     assert two["n_gpus"] == 2 and two["gather_bytes"] > 0
     assert two["matches_per_pair"] > 1000
+
+
+def test_flags_from_the_ot_epilogue_and_the_expansion(ops, oracle):
+    """est_position's two flag vectors without an argmax pass (first_layer.py:162-167, second_layer.py:243-248):
+    if_nomatching2 from the 145 x 145 Sinkhorn epilogue (or the colmass pass), if_nomatching1 from the expansion
+    kernel - identical to the argmax of the returned log-plan, also for problems the guard re-solves."""
+    f = synth.fine_inputs(seed=synth.SEED + 62, B=40)
+    d0 = f["d0"].copy()
+    d0[3] *= 60.0                                               # +-150-nat scores: this problem trips the guard
+    ns = cu(f["scale_x"] * f["scale_y"])
+    Z, cflag = ops.cost_ot(cu(d0), cu(f["d1"]), 2, 1.0, ns, 100, bias_k=2.0, return_flags=True)
+    Zp = ops.cost_ot(cu(d0), cu(f["d1"]), 2, 1.0, ns, 100, bias_k=2.0)
+    assert torch.equal(Z, Zp)
+    r, c = ops.argmax(Z)
+    assert torch.equal(cflag, c[:, :-1] == 144)
+    out = ops.est_position_second(Z, cu(f["scale_x"]), cu(f["scale_y"]), [96, 96], 8, col_nomatch=cflag)
+    assert torch.equal(out[4], r[:, :-1] == 144) and torch.equal(out[5], c[:, :-1] == 144)
+    alone = ops.est_position_second(Z, cu(f["scale_x"]), cu(f["scale_y"]), [96, 96], 8)      # flags from one colmass-style pass
+    assert torch.equal(alone[4], out[4]) and torch.equal(alone[5], out[5]) and torch.equal(alone[0], out[0])
+    # coarse level: scales and the column flags in one pass
+    ci = synth.coarse_inputs()
+    Zc = ops.cost_ot(cu(ci["d0"]), cu(ci["d1"]), 1, float(ci["alpha"]), cu(ci["ns"]), 100)
+    scales, cf = ops.colmass_sqrt(Zc, return_flags=True)
+    assert torch.equal(scales, ops.colmass_sqrt(Zc))
+    rc_, cc_ = ops.argmax(Zc)
+    assert torch.equal(cf, cc_[:, :-1] == 300)
+    o1 = ops.est_position_first(Zc, scales, (480, 640), 32, col_nomatch=cf)
+    assert torch.equal(o1[4], rc_[:, :-1] == 300) and torch.equal(o1[5], cf)
+    # 65 x 65 (generic pass after the kernel)
+    t = synth.third_inputs(seed=5, P=16)
+    Z3, c3 = ops.cost_ot(cu(t["d0"]), cu(t["d1"]), 2, 1.0, cu(t["scale"]), 100, return_flags=True)
+    assert torch.equal(c3, ops.argmax(Z3)[1][:, :-1] == 64)

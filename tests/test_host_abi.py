@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pats_log_optimal_transport_f32(None, 0, 3, 3, None, None, 100, None, None, 0, None) == 0
     with pytest.raises(RuntimeError):
         _lib.check(lib.pats_iterative_expand_f32(None, 0, 1, 5, 5, None, None, 2, 3, 3, 1e-3, 8, None, None,
-                                                 None, None, None, None, None), "expand")
+                                                 None, None, None, None, None, None), "expand")
     assert lib.pats_ot_workspace_bytes(2, 301, 301) >= 2 * 2 * 301 * 301 * 4
     assert lib.pats_sinkhorn_workspace_bytes(1000, 65, 65) == 0
 
