@@ -28,6 +28,7 @@ struct Cost65Acc {
 // products; cost65_scale applies the reference's `/ D**.5` then `0.1 *`.
 // `ld` = elements between consecutive descriptor rows (65 for [D,65] descriptors; heads*65 for one
 // head of a [dim,heads,65] attention operand).
+template <bool NO_MFMA = false>     // NO_MFMA: timing ablation only (loads and edge chains stay, the four MFMAs become one add)
 __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, const float* __restrict__ B,
                                                   int D, float* edge_lds, int lane, Cost65Acc& o,
                                                   int ld = C65_NT) {
@@ -63,10 +64,14 @@ __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, c
         for (int s_ = 0; s_ < KB; ++s_) {
             const f2u av = q.a[s_], bv = q.b[s_];
             const float ea = eA[k0 + 2 * s_ + lk], eb = eB[k0 + 2 * s_ + lk];
+            if (NO_MFMA) {
+                c00[s_ & 15] += av.x * bv.x + av.y * bv.y;
+            } else {
             c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, c00, 0, 0, 0);
             c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, c01, 0, 0, 0);
             c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, c10, 0, 0, 0);
             c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, c11, 0, 0, 0);
+            }
             er0 = fmaf(ea, bv.x, er0);
             er1 = fmaf(ea, bv.y, er1);
             ec0 = fmaf(av.x, eb, ec0);

@@ -102,7 +102,7 @@ __device__ __forceinline__ float wave_sum_mfma(float v) {
 }
 template <int DB>
 __device__ __forceinline__ float dustbin_sum(float v, float* slot, int lane) {
-    if (DB == 0 || DB >= 8) return wave_sum_uniform(v);
+    if (DB == 0 || DB >= 7) return wave_sum_uniform(v);
     if (DB == 2) return wave_sum_mfma(v);
     return wave_sum_lds(v, slot, lane);
 }
@@ -251,6 +251,8 @@ third_fused3_kernel(Fused65Args g) {
         if (DB == 9) {      // timing ablation only: no cost build (results are garbage)
             for (int r = 0; r < 16; ++r) { c.c00[r] = (float)(lane + r) * 0.01f; c.c01[r] = -c.c00[r]; c.c10[r] = c.c00[r] * 0.5f; c.c11[r] = 0.25f; }
             c.er0 = c.er1 = c.ec0 = c.ec1 = c.cn = 0.f;
+        } else if (DB == 7) {   // timing ablation only: descriptor loads without the MFMAs
+            cost65_accumulate<true>(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
         } else
         cost65_accumulate(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
         const int li = lane & 31, lk = lane >> 5;
@@ -452,6 +454,7 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, 0, st, g); break;
         case 301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1>), grid, block, 0, st, g); break;
         case 302: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 2>), grid, block, 0, st, g); break;
+        case 307: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 7>), grid, block, 0, st, g); break;
         case 308: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 8>), grid, block, 0, st, g); break;
         case 309: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 9>), grid, block, 0, st, g); break;
         case 310: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 0>), grid, block, 0, st, g); break;

@@ -1,0 +1,149 @@
+"""Runtime drop-in: rebind the reference's hot-path functions to pats_amd.ops so that the reference's own
+drivers (`evaluate.py:106-108`, `demo.py`) run unchanged.
+
+    import pats_amd.dropin
+    pats_amd.dropin.install()        # before or after `from models.pats import PATS`
+    model = PATS(config) ...         # the reference's code from here on
+
+What is rebound (reference path:line -> replacement), in every already-imported module of the reference
+that holds the name (the layer files do `from .modules import ...` / `from utils.utils import ...`, so the
+functions live in several namespaces), and in `sys.modules` for the native extension:
+
+    tensor_resize (module; setup/library.cpp:92-93, imported at utils/utils.py:17)   -> the repo's tensor_resize.py
+    models/modules.py:137,145,165  log_sinkhorn_iterations / log_optimal_transport / log_optimal_transport2
+    models/modules.py:84           attention
+    utils/utils.py:1179,1527       Iterative_expand_matrix / Compute_positions_and_ranges
+    utils/utils.py:152,1343,189    split_patches / Compute_imgs / get_result
+    models/second_layer.py:137,193 SecondLayer.merge_patches_old / merge_patches_new   (methods: `self` dropped)
+    models/third_layer.py:184      ThirdLayer.Compute_result                          (method: 3-tuple as the reference)
+
+Nothing of the reference is copied or imported here unless the caller has imported it already (or
+`import_reference=True` and the reference is on sys.path).  `uninstall()` restores the originals.
+"""
+import importlib
+import sys
+
+_FUNCTIONS = {
+    # name -> (defining reference module, attribute of pats_amd.ops)
+    "log_sinkhorn_iterations": ("models.modules", "log_sinkhorn_iterations"),
+    "log_optimal_transport": ("models.modules", "log_optimal_transport"),
+    "log_optimal_transport2": ("models.modules", "log_optimal_transport2"),
+    "attention": ("models.modules", "attention"),
+    "Iterative_expand_matrix": ("utils.utils", "Iterative_expand_matrix"),
+    "Compute_positions_and_ranges": ("utils.utils", "Compute_positions_and_ranges"),
+    "split_patches": ("utils.utils", "split_patches"),
+    "Compute_imgs": ("utils.utils", "Compute_imgs"),
+    "get_result": ("utils.utils", "get_result"),
+}
+_REFERENCE_MODULES = ("models.modules", "utils.utils", "models.first_layer", "models.second_layer",
+                      "models.third_layer", "models.pats")
+_saved = []          # (object, attribute name, original value) in installation order
+_MISSING = object()
+
+
+def _set(obj, name, value):
+    _saved.append((obj, name, getattr(obj, name, _MISSING)))
+    setattr(obj, name, value)
+
+
+def _methods(ops):
+    def merge_patches_new(self, patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2,
+                          scores_back):
+        return ops.merge_patches_new(patch_num, trust_score, original_image_shape, if_nomatching1_L1,
+                                     if_nomatching1_L2, scores_back)
+
+    def merge_patches_old(self, patch_num, trust_score, original_image_shape, if_nomatching1_L1, if_nomatching1_L2,
+                          scores_back):
+        return ops.merge_patches_old(patch_num, trust_score, original_image_shape, if_nomatching1_L1,
+                                     if_nomatching1_L2, scores_back)
+
+    def Compute_result(self, scores, W, T, scale_x, scale_y, p_s, p_t, device):
+        # third_layer.py:184-217 returns (mkpts0_f, mkpts1_f, whole_loss); the label of :161-170 stays with the caller
+        return ops.Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device)[:3]
+
+    return {"models.second_layer": ("SecondLayer", {"merge_patches_new": merge_patches_new,
+                                                    "merge_patches_old": merge_patches_old}),
+            "models.third_layer": ("ThirdLayer", {"Compute_result": Compute_result})}
+
+
+def install(import_reference=False):
+    """Rebinds the names listed in the module docstring; returns the list of "module.name" it touched.
+    Idempotent (a second call first undoes the first).  Needs the HIP library: pats_amd.ops raises if
+    libpats_amd.so is missing - there is no CPU fallback to fall back to."""
+    if _saved:
+        uninstall()
+    from . import ops
+    native = _load_native()
+    touched = []
+    _set_module("tensor_resize", native)
+    touched.append("sys.modules[tensor_resize]")
+    if import_reference:
+        for name in _REFERENCE_MODULES:
+            try:
+                importlib.import_module(name)
+            except Exception:                        # the reference's optional dependencies may be absent
+                pass
+    originals = {}
+    for fname, (home, _) in _FUNCTIONS.items():
+        mod = sys.modules.get(home)
+        if mod is not None and hasattr(mod, fname):
+            originals[fname] = getattr(mod, fname)
+    for mname in _REFERENCE_MODULES:
+        mod = sys.modules.get(mname)
+        if mod is None:
+            continue
+        if getattr(mod, "tensor_resize", None) is not None and mname == "utils.utils":
+            _set(mod, "tensor_resize", native)       # `import tensor_resize` at utils/utils.py:17 bound the module object
+            touched.append(mname + ".tensor_resize")
+        for fname, (home, attr) in _FUNCTIONS.items():
+            if not hasattr(mod, fname):
+                continue
+            cur = getattr(mod, fname)
+            if mname == home or cur is originals.get(fname):
+                _set(mod, fname, getattr(ops, attr))
+                touched.append(mname + "." + fname)
+    for mname, (cls_name, methods) in _methods(ops).items():
+        mod = sys.modules.get(mname)
+        cls = getattr(mod, cls_name, None) if mod is not None else None
+        if cls is None:
+            continue
+        for meth, fn in methods.items():
+            if hasattr(cls, meth):
+                _set(cls, meth, fn)
+                touched.append("%s.%s.%s" % (mname, cls_name, meth))
+    return touched
+
+
+def _load_native():
+    """This repository's tensor_resize.py, loaded by path: `import tensor_resize` could hand back the reference's
+    compiled extension if that is already in sys.modules."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tensor_resize.py")
+    spec = importlib.util.spec_from_file_location("tensor_resize", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _set_module(name, module):
+    _saved.append((sys.modules, name, sys.modules.get(name, _MISSING)))
+    sys.modules[name] = module
+
+
+def uninstall():
+    """Restores everything install() replaced."""
+    while _saved:
+        obj, name, old = _saved.pop()
+        if obj is sys.modules:
+            if old is _MISSING:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
+        elif old is _MISSING:
+            try:
+                delattr(obj, name)
+            except AttributeError:
+                pass
+        else:
+            setattr(obj, name, old)

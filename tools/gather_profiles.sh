@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-2 evidence run (on the GPU box, through gpurun): bench line, kernel traces, PMC passes.  Writes gpurun_out/r02_*.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+python $R/bench.py > $O/r02_bench.json 2> $O/r02_bench.err
+rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/kt1 -name "*.db" | head -1) "bench.py --steps 5 --warmup 2 (16 pairs per step; includes workload set-up kernels)" > $O/r02_bench_kernel_stats.md 2>&1
+python $R/tools/bench_config5.py > $O/r02_config5.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/kt2 -- python $R/tools/bench_config5.py > /dev/null 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) "tools/bench_config5.py (config 5: 4096^2 x 448 cost GEMM, 4097^2 Sinkhorn 200 sweeps)" > $O/r02_config5_kernel_stats.md 2>&1
+# PMC passes, third level at the bench's launch size (each counter set in its own run, no trace domains)
+export PMC_CALIB=1
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pmcT_$tag -- python $R/tools/pmc_third.py > /dev/null 2>&1
+  echo "## third level, counters: $set" >> $O/r02_pmc_raw.txt
+  python $R/tools/pmc_sum.py /tmp/pmcT_$tag "" >> $O/r02_pmc_raw.txt
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pmcO_$tag -- python $R/tools/pmc_others.py > /dev/null 2>&1
+  echo "## other kernels, counters: $set" >> $O/r02_pmc_raw.txt
+  python $R/tools/pmc_sum.py /tmp/pmcO_$tag "" >> $O/r02_pmc_raw.txt
+done
