@@ -125,6 +125,7 @@ def test_install_against_the_real_reference_when_present():
     import ref_import
     if not ref_import.available():
         pytest.skip("reference tree not present")
+    path_before, native_before = list(sys.path), sys.modules.get("tensor_resize")
     R = ref_import.load()
     from pats_amd import dropin, ops
     originals = {n: getattr(R.M, n) for n in ("log_sinkhorn_iterations", "log_optimal_transport", "log_optimal_transport2", "attention")}
@@ -143,4 +144,11 @@ def test_install_against_the_real_reference_when_present():
         assert len(touched) >= 15
     finally:
         dropin.uninstall()
+        # ref_import put the reference's compiled extension first on sys.path / into sys.modules: later tests
+        # must find this repository's tensor_resize.py again
+        sys.path[:] = path_before
+        if native_before is None:
+            sys.modules.pop("tensor_resize", None)
+        else:
+            sys.modules["tensor_resize"] = native_before
     assert R.L1.log_optimal_transport is originals["log_optimal_transport"] and R.L2.SecondLayer.merge_patches_new is merge_new
