@@ -891,3 +891,35 @@ def test_flags_from_the_ot_epilogue_and_the_expansion(ops, oracle):
     t = synth.third_inputs(seed=5, P=16)
     Z3, c3 = ops.cost_ot(cu(t["d0"]), cu(t["d1"]), 2, 1.0, cu(t["scale"]), 100, return_flags=True)
     assert torch.equal(c3, ops.argmax(Z3)[1][:, :-1] == 64)
+
+
+def test_third_level_guard_trips_are_resolved_by_the_scan_kernel(ops, oracle, sinkhorn_mode):
+    """Fused third level with descriptors scaled so that some problems leave the linear-domain guard band: the
+    third-generation kernel flags them (sentinel in if_matching1), the log-domain kernel re-solves exactly those in
+    scan mode; tame problems in the same launch are untouched.  Results against the oracle as usual."""
+    P = 70                                                      # two scan workgroups (64 + 6 problems)
+    inp = synth.third_inputs(seed=synth.SEED + 63, P=P)
+    d0, d1 = inp["d0"].copy(), inp["d1"].copy()
+    wild = np.array([1, 17, 63, 64, 69])
+    d0[wild] *= 9.0                                             # scores of +-100 nats and more
+    d1[wild] *= 9.0
+    ops.sinkhorn_fallbacks(reset=True)
+    m0, m1, label, ifm = ops.third_level(cu(d0), cu(d1), cu(inp["scale"]), cu(inp["p_s"]), cu(inp["p_t"]), outdoor=True)
+    trips = ops.sinkhorn_fallbacks(reset=True)
+    assert (1 <= trips <= len(wild)) if sinkhorn_mode == "kernel" else trips == 0
+    assert set(np.unique(ifm.cpu().numpy().astype(np.uint8))) <= {0, 1}          # no sentinel left behind
+    Zr = oracle.log_optimal_transport2(oracle.cost(d0, d1), 1.0, inp["scale"], 100)
+    sq = np.sqrt(inp["scale"] + np.float32(1e-8)).astype(np.float32)
+    r0, r1, rwl, rlabel, rifm = oracle.compute_result(np.exp(Zr), sq, sq, inp["p_s"], inp["p_t"], True)
+    tame = np.setdiff1d(np.arange(P), wild)
+    assert np.array_equal(m0.cpu().numpy(), r0)
+    assert np.array_equal(label.cpu().numpy().reshape(P, 16, 2)[tame], rlabel.reshape(P, 16, 2)[tame])
+    assert np.array_equal(ifm.cpu().numpy().astype(bool)[tame], rifm.astype(bool)[tame])
+    assert np.abs(m1.cpu().numpy()[tame] - r1[tame]).max() <= 3e-4 * 8
+    # the wild problems: near-degenerate plans (one entry per row carries everything); flags and points where the
+    # oracle's top two entries are clearly apart
+    S = np.exp(Zr)[wild][:, :-1, :].reshape(len(wild), 8, 8, 65)[:, 2:6, 2:6, :].reshape(len(wild), 16, 65)
+    top = np.sort(S, axis=2)[:, :, -2:]
+    clear = (top[:, :, 1] - top[:, :, 0]) > 1e-3 * top[:, :, 1]
+    assert np.array_equal(ifm.cpu().numpy().astype(bool)[wild][clear], rifm.astype(bool)[wild][clear])
+    assert np.isfinite(m1.cpu().numpy()).all()
