@@ -311,6 +311,32 @@ int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uin
 int pats_attention_f32(const float* query, const float* key, const float* value, int64_t batch, int dim,
                        int heads, int n, int m, float* out, float* prob, pats_stream_t stream);
 
+/* ---- AttentionalPropagation of the GNN layers (reference models/modules.py:91-117; section 8f rank 4) ----------
+ *   message = merge(attention(proj_q(x), proj_k(source), proj_v(source)))            MultiHeadedAttention.forward :100-105
+ *   delta   = mlp(cat([x, message], dim=1)),  mlp = Conv1d(2C,2C) BatchNorm1d ReLU Conv1d(2C,C)   :107-117 (MLP :57-69)
+ *   out     = residual + delta  if residual != NULL  (AttentionalGNN.forward: desc = desc + delta, :131-133)
+ * x [batch,C,n], source [batch,C,m] (channel-major, as the reference's Conv1d sees them), out [batch,C,n].
+ * Weights are DEVICE pointers; the Conv1d matrices are handed over TRANSPOSED ([C_in][C_out], row = input channel),
+ * i.e. conv.weight[:, :, 0].t().contiguous().  BatchNorm: bn_train == 0 -> bn_a / bn_b are the folded running
+ * statistics (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale); bn_train != 0 -> bn_a /
+ * bn_b are gamma / beta and the batch statistics over (batch, n) are computed here with bn_eps (PATS.eval leaves the
+ * third layer in train mode, models/pats.py:112-120).  fp32 MFMA GEMMs (the cat is never materialised), the
+ * attention core is pats_attention_f32.  C % heads == 0, C % 8 == 0, m <= 1024. */
+typedef struct pats_propagation_weights {
+    const float *wq_t, *bq;   /* attn.proj[0]: [C][C] transposed, [C] */
+    const float *wk_t, *bk;   /* attn.proj[1] */
+    const float *wv_t, *bv;   /* attn.proj[2] */
+    const float *wm_t, *bm;   /* attn.merge */
+    const float *w1_t, *b1;   /* mlp[0]: [2C][2C] transposed, [2C] */
+    const float *bn_a, *bn_b; /* mlp[1]: [2C] each, see above */
+    const float *w2_t, *b2;   /* mlp[3]: [2C][C] transposed, [C] */
+} pats_propagation_weights;
+size_t pats_attentional_propagation_workspace_bytes(int64_t batch, int C, int n, int m);
+int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
+                                     int n, int m, const pats_propagation_weights* weights, int bn_train,
+                                     float bn_eps, const float* residual, float* out, void* workspace,
+                                     size_t workspace_bytes, pats_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1042,3 +1042,76 @@ void oracle_attention(const float* q, const float* k, const float* v, int64_t b,
             free(acc);
         }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * AttentionalPropagation (reference models/modules.py:91-117) and the residual of AttentionalGNN (:131-133).
+ *   conv1x1: y[b][o][t] = bias[o] + sum_c W[o][c] x[b][c][t]           nn.Conv1d(kernel_size=1)  (MLP :57-69, :98-99)
+ *   MultiHeadedAttention.forward (:100-105): q, k, v = proj[i](.) viewed [b, dim, heads, n]; attention; merge
+ *   AttentionalPropagation.forward (:114-117): mlp(cat([x, message], 1)), mlp = conv(2C,2C) BN ReLU conv(2C,C)
+ * Weights in the reference's own (untransposed) layout.  BatchNorm1d: eval = running statistics, train = batch
+ * statistics over (b, n) with the biased variance (what F.batch_norm normalises with).  Sums accumulate in double.
+ * ---------------------------------------------------------------------------------------- */
+static void oracle_conv1x1(const float* W, const float* bias, const float* x, int64_t b, int Cin, int Cout, int n,
+                           float* y) {
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int o = 0; o < Cout; ++o)
+            for (int t = 0; t < n; ++t) {
+                double s = 0.0;
+                for (int c = 0; c < Cin; ++c) s += (double)W[(int64_t)o * Cin + c] * (double)x[(bi * Cin + c) * (int64_t)n + t];
+                y[(bi * Cout + o) * (int64_t)n + t] = (float)s + bias[o];
+            }
+}
+
+void oracle_attentional_propagation(const float* x, const float* source, int64_t b, int C, int heads, int n, int m,
+                                    const float* wq, const float* bq, const float* wk, const float* bk,
+                                    const float* wv, const float* bv, const float* wm, const float* bm,
+                                    const float* w1, const float* b1, const float* gamma, const float* beta,
+                                    const float* rmean, const float* rvar, float eps, int bn_train,
+                                    const float* w2, const float* b2, const float* residual, float* out) {
+    const size_t qn = (size_t)b * C * n, kn = (size_t)b * C * m;
+    float* q = (float*)malloc(sizeof(float) * qn);
+    float* k = (float*)malloc(sizeof(float) * kn);
+    float* v = (float*)malloc(sizeof(float) * kn);
+    float* att = (float*)malloc(sizeof(float) * qn);
+    float* msg = (float*)malloc(sizeof(float) * qn);
+    float* cat = (float*)malloc(sizeof(float) * 2 * qn);
+    float* hid = (float*)malloc(sizeof(float) * 2 * qn);
+    oracle_conv1x1(wq, bq, x, b, C, C, n, q);
+    oracle_conv1x1(wk, bk, source, b, C, C, m, k);
+    oracle_conv1x1(wv, bv, source, b, C, C, m, v);
+    oracle_attention(q, k, v, b, C / heads, heads, n, m, att, NULL);        /* .view(b, dim, heads, -1): same memory */
+    oracle_conv1x1(wm, bm, att, b, C, C, n, msg);
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int c = 0; c < 2 * C; ++c)
+            for (int t = 0; t < n; ++t)
+                cat[(bi * 2 * C + c) * (int64_t)n + t] = c < C ? x[(bi * C + c) * (int64_t)n + t]
+                                                                : msg[(bi * C + (c - C)) * (int64_t)n + t];
+    oracle_conv1x1(w1, b1, cat, b, 2 * C, 2 * C, n, hid);
+    for (int c = 0; c < 2 * C; ++c) {
+        double mean = rmean[c], var = rvar[c];
+        if (bn_train) {
+            double s = 0.0, s2 = 0.0;
+            for (int64_t bi = 0; bi < b; ++bi)
+                for (int t = 0; t < n; ++t) s += hid[(bi * 2 * C + c) * (int64_t)n + t];
+            mean = s / (double)(b * n);
+            for (int64_t bi = 0; bi < b; ++bi)
+                for (int t = 0; t < n; ++t) {
+                    const double d = hid[(bi * 2 * C + c) * (int64_t)n + t] - mean;
+                    s2 += d * d;
+                }
+            var = s2 / (double)(b * n);
+        }
+        const float inv = 1.0f / sqrtf((float)var + eps);
+        for (int64_t bi = 0; bi < b; ++bi)
+            for (int t = 0; t < n; ++t) {
+                float* h = &hid[(bi * 2 * C + c) * (int64_t)n + t];
+                const float y = (*h - (float)mean) * inv * gamma[c] + beta[c];
+                *h = y > 0.f ? y : 0.f;
+            }
+    }
+    oracle_conv1x1(w2, b2, hid, b, 2 * C, C, n, out);
+    if (residual)
+        for (size_t e = 0; e < qn; ++e) out[e] = residual[e] + out[e];
+    free(q); free(k); free(v); free(att); free(msg); free(cat); free(hid);
+}

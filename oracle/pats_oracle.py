@@ -323,3 +323,30 @@ def attention(query, key, value, with_prob=True):
     lib().oracle_attention(pq, pk, pv, ctypes.c_int64(b), dim, heads, n, m, _p(out, c_f),
                            _p(prob, c_f) if with_prob else None)
     return out, prob
+
+
+def attentional_propagation(x, source, params, heads=4, bn_train=False, eps=1e-5, residual=None):
+    """modules.py:107-117 (+ the residual of :133 when given).  params: the reference's state_dict names
+    (attn.proj.{0,1,2}.weight/bias, attn.merge.*, mlp.0.*, mlp.1.weight/bias/running_mean/running_var, mlp.3.*)."""
+    x, px = _f(x)
+    s, ps = _f(source)
+    b, C, n = x.shape
+    m = s.shape[2]
+    keep = []
+
+    def w(name):
+        a, p = _f(np.asarray(params[name]).reshape(np.asarray(params[name]).shape[0], -1))
+        keep.append(a)
+        return p
+    out = np.empty((b, C, n), np.float32)
+    res = None
+    if residual is not None:
+        r, res = _f(residual)
+        keep.append(r)
+    lib().oracle_attentional_propagation(
+        px, ps, ctypes.c_int64(b), C, int(heads), n, m, w("attn.proj.0.weight"), w("attn.proj.0.bias"),
+        w("attn.proj.1.weight"), w("attn.proj.1.bias"), w("attn.proj.2.weight"), w("attn.proj.2.bias"),
+        w("attn.merge.weight"), w("attn.merge.bias"), w("mlp.0.weight"), w("mlp.0.bias"), w("mlp.1.weight"),
+        w("mlp.1.bias"), w("mlp.1.running_mean"), w("mlp.1.running_var"), ctypes.c_float(eps), int(bool(bn_train)),
+        w("mlp.3.weight"), w("mlp.3.bias"), res, _p(out, c_f))
+    return out

@@ -1,0 +1,252 @@
+// AttentionalPropagation of the SuperGlue-style GNN layers on gfx950.
+//   models/modules.py:91-117:
+//     MultiHeadedAttention.forward:  q, k, v = proj[i](x) (Conv1d k=1) viewed [b, dim, heads, n];
+//                                    x, _ = attention(q, k, v);  merge(x.view(b, dim*heads, n))          (:100-105)
+//     AttentionalPropagation.forward: message = attn(x, source, source)
+//                                     mlp(cat([x, message], dim=1))   with mlp = Conv1d(2C,2C) BN ReLU Conv1d(2C,C)   (:107-117, MLP :57-69)
+//     AttentionalGNN.forward:         desc = desc + delta                                                    (:131-133)
+//
+// A Conv1d with kernel 1 over [b, C_in, n] is the product W [C_out x C_in] . X_b [C_in x n] for every b, i.e. the
+// channel-major descriptor layout of the cost build with the weights as the shared (batch-stride 0) operand: the
+// same fp32 MFMA tiling (160 x 160 output tile per 256-thread workgroup, 8-row operand slabs staged global ->
+// registers -> LDS, double-buffered), generalised in three ways so that the layer needs no glue kernels:
+//   * the 160 tile columns run over the flattened (batch, token) axis - a tile spans several problems, so 65-token
+//     problems fill the tile instead of wasting 60 % of it;
+//   * the reduction dimension may come from TWO tensors (x | message): `cat` is never materialised;
+//   * input channels can carry an affine + ReLU applied while staging (BatchNorm in eval mode = its running
+//     statistics, in train mode = batch statistics from bn_stats_kernel: PATS.eval leaves the third layer in train
+//     mode, pats.py:112-120), and the epilogue adds the bias and an optional residual (desc + delta).
+// The attention core in the middle is pats_attention_f32 (attention.hip).  fp32 throughout.
+#include "common.hpp"
+
+namespace pats {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int CT = 160, KC = 8, CPT = KC * CT / 256;
+
+struct __attribute__((aligned(16))) ConvLds {
+    float a[2][KC][CT];
+    float b[2][KC][CT];
+};
+
+struct ConvArgs {
+    const float* wt;           // [K0 + K1][M]: transposed weights (row = input channel)
+    const float* x0;           // [batch, K0, n]
+    const float* x1;           // [batch, K1, n] or null (K1 = 0)
+    int K0, K1, M, n;
+    int64_t cols;              // batch * n
+    const float* in_scale;     // [K0 + K1] or null: x <- max(0, x * scale + shift) while staging
+    const float* in_shift;
+    const float* bias;         // [M] or null
+    const float* residual;     // [batch, M, n] or null
+    float* y;                  // [batch, M, n]
+};
+}  // namespace
+
+__global__ void __launch_bounds__(256, 2)
+conv1x1_kernel(ConvArgs g) {
+    __shared__ ConvLds lds;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t tiles_j = (g.cols + CT - 1) / CT;
+    const int i0 = (int)(blockIdx.x / tiles_j) * CT;
+    const int64_t j0 = (int64_t)(blockIdx.x % tiles_j) * CT;
+    const int K = g.K0 + g.K1, n = g.n, M = g.M;
+
+    // staging map: element e = t + 256 q of a slab is (row e / 160, column e % 160); columns past the edge clamp
+    float ra[CPT], rb[CPT];
+    const float* pa[CPT];
+    const float* p0[CPT];
+    const float* p1[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int e = t + 256 * q, kk = e / CT, col = e % CT;
+        pa[q] = g.wt + (int64_t)kk * M + min(i0 + col, M - 1);
+        const int64_t cg = min(j0 + col, g.cols - 1), b = cg / n;
+        const int tk = (int)(cg - b * n);
+        p0[q] = g.x0 + (b * g.K0 + kk) * (int64_t)n + tk;
+        p1[q] = g.x1 ? g.x1 + (b * g.K1 + kk) * (int64_t)n + tk : nullptr;
+    }
+    auto fetch = [&](int k0) {
+        const bool second = k0 >= g.K0;               // K0 % KC == 0: a chunk never straddles the two sources
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int kk = (t + 256 * q) / CT;
+            const bool kin = k0 + kk < K;
+            ra[q] = kin ? pa[q][(int64_t)k0 * M] : 0.f;
+            float x = 0.f;
+            if (kin) x = second ? p1[q][(int64_t)(k0 - g.K0) * n] : p0[q][(int64_t)k0 * n];
+            if (g.in_scale && kin) x = fmaxf(fmaf(x, g.in_scale[k0 + kk], g.in_shift[k0 + kk]), 0.f);
+            rb[q] = x;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int e = t + 256 * q;
+            (&lds.a[buf][0][0])[e] = ra[q];
+            (&lds.b[buf][0][0])[e] = rb[q];
+        }
+    };
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    // output-row tiles that exist: rows i0 + 32 w .. for wave w, and the fifth tile row (i0 + 128 ..) shared by all
+    const bool row4 = i0 + 128 < M;
+
+    const int nchunk = (K + KC - 1) / KC;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) fetch((c + 1) * KC);
+#pragma unroll
+        for (int kp = 0; kp < KC / 2; ++kp) {
+            const float* ar = &lds.a[buf][2 * kp + lk][0];
+            const float* br = &lds.b[buf][2 * kp + lk][0];
+            const float aw = ar[32 * wave + li], a4 = ar[128 + li], bw = br[32 * wave + li];
+            float bf[5];
+#pragma unroll
+            for (int tj = 0; tj < 5; ++tj) bf[tj] = br[32 * tj + li];
+#pragma unroll
+            for (int tj = 0; tj < 5; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bf[tj], acc[tj], 0, 0, 0);
+            if (row4) {                                 // wave-uniform: 128-channel layers skip the fifth tile row
+                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, bw, acc[5], 0, 0, 0);
+                if (wave == 0) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, bf[4], acc[6], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    auto store_tile = [&](const f32x16& cacc, int ti, int tj) {
+        const int64_t cg = j0 + 32 * tj + li;
+        if (cg >= g.cols) return;
+        const int64_t b = cg / n;
+        const int tk = (int)(cg - b * n);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < M) {
+                const int64_t o = (b * M + row) * (int64_t)n + tk;
+                float v = cacc[r];
+                if (g.bias) v += g.bias[row];
+                if (g.residual) v = g.residual[o] + v;
+                g.y[o] = v;
+            }
+        }
+    };
+#pragma unroll
+    for (int tj = 0; tj < 5; ++tj) store_tile(acc[tj], wave, tj);
+    if (row4) {
+        store_tile(acc[5], 4, wave);
+        if (wave == 0) store_tile(acc[6], 4, 4);
+    }
+}
+
+// BatchNorm1d in train mode (modules.py:66 inside MLP; the third layer's GNN runs it on batch statistics because
+// PATS.eval() does not reach it, pats.py:112-120): per channel over (batch, n), biased variance, then
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  One workgroup per channel, double accumulation.
+__global__ void __launch_bounds__(256)
+bn_stats_kernel(const float* __restrict__ h, int64_t batch, int C, int n, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double s1[256], s2[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    const int64_t total = batch * n;
+    for (int64_t e = t; e < total; e += 256) {
+        const int64_t b = e / n;
+        const float x = h[(b * C + c) * (int64_t)n + (e - b * n)];
+        a += x;
+        q += (double)x * x;
+    }
+    s1[t] = a; s2[t] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { s1[t] += s1[t + o]; s2[t] += s2[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double mean = s1[0] / (double)total;
+        double var = s2[0] / (double)total - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float sc = gamma[c] / sqrtf((float)var + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+    }
+}
+
+static int launch_conv(const ConvArgs& g, hipStream_t st) {
+    const int64_t tiles = (int64_t)((g.M + CT - 1) / CT) * ((g.cols + CT - 1) / CT);
+    PATS_REQUIRE(tiles < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+    hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)tiles), dim3(256), 0, st, g);
+    return check_launch("conv1x1_kernel");
+}
+
+}  // namespace pats
+
+using namespace pats;
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, int C, int n, int m) {
+    if (batch < 0 || C <= 0 || n <= 0 || m <= 0) return 0;
+    const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
+    // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each
+    return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float));
+}
+
+extern "C" int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
+                                                int n, int m, const pats_propagation_weights* w, int bn_train,
+                                                float bn_eps, const float* residual, float* out, void* workspace,
+                                                size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && C > 0 && heads > 0 && n > 0 && m > 0 && (C % heads) == 0,
+                 "attentional_propagation: bad shape");
+    PATS_REQUIRE((C % 8) == 0, "attentional_propagation: feature_dim must be a multiple of 8 (operand slabs of 8 channels)");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(x && source && w && out, "attentional_propagation: null pointer");
+    PATS_REQUIRE(w->wq_t && w->bq && w->wk_t && w->bk && w->wv_t && w->bv && w->wm_t && w->bm && w->w1_t && w->b1 &&
+                     w->w2_t && w->b2 && w->bn_a && w->bn_b, "attentional_propagation: null weight pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_attentional_propagation_workspace_bytes(batch, C, n, m),
+                 "attentional_propagation: workspace too small");
+    hipStream_t st = as_stream(stream);
+    char* p = (char*)workspace;
+    const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
+    float* q = (float*)p; p += qb;
+    float* att = (float*)p; p += qb;
+    float* msg = (float*)p; p += qb;
+    float* k = (float*)p; p += kb;
+    float* v = (float*)p; p += kb;
+    float* hid = (float*)p; p += al256((size_t)batch * 2 * C * n * sizeof(float));
+    float* bsc = (float*)p; p += al256((size_t)2 * C * sizeof(float));
+    float* bsh = (float*)p;
+    int rc;
+    // projections (modules.py:101-102)
+    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, st))) return rc;
+    // attention core (:103): the [b, C, n] projections ARE the [b, dim, heads, n] views
+    if ((rc = pats_attention_f32(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream))) return rc;
+    // merge (:104)
+    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, st))) return rc;
+    // mlp[0] on cat([x, message]) without the cat (:116, MLP :64)
+    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, st))) return rc;
+    // mlp[1] BatchNorm1d: eval -> the caller's folded running statistics (bn_a = scale, bn_b = shift);
+    //                      train -> batch statistics with bn_a = gamma, bn_b = beta
+    const float *sc = w->bn_a, *sh = w->bn_b;
+    if (bn_train) {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)(2 * C)), dim3(256), 0, st, hid, batch, 2 * C, n, w->bn_a, w->bn_b,
+                           bn_eps, bsc, bsh);
+        if ((rc = check_launch("bn_stats_kernel"))) return rc;
+        sc = bsc; sh = bsh;
+    }
+    // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
+    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, st);
+}

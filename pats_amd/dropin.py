@@ -16,6 +16,9 @@ functions live in several namespaces), and in `sys.modules` for the native exten
     utils/utils.py:152,1343,189    split_patches / Compute_imgs / get_result
     models/second_layer.py:137,193 SecondLayer.merge_patches_old / merge_patches_new   (methods: `self` dropped)
     models/third_layer.py:184      ThirdLayer.Compute_result                          (method: 3-tuple as the reference)
+    models/modules.py:114,127      AttentionalPropagation.forward / AttentionalGNN.forward (the layer's own parameters,
+                                   read once from its state_dict and cached on the instance; BatchNorm follows
+                                   `self.training` like the reference - the third layer's stays in train mode, pats.py:112-120)
 
 Nothing of the reference is copied or imported here unless the caller has imported it already (or
 `import_reference=True` and the reference is on sys.path).  `uninstall()` restores the originals.
@@ -61,9 +64,29 @@ def _methods(ops):
         # third_layer.py:184-217 returns (mkpts0_f, mkpts1_f, whole_loss); the label of :161-170 stays with the caller
         return ops.Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device)[:3]
 
+    def _params(layer):
+        # inference: the weights do not change between calls, so the transposed / folded copies are built once
+        p = getattr(layer, "_pats_params", None)
+        if p is None:
+            dev = next(layer.parameters()).device
+            p = ops.PropagationParams(layer.state_dict(), device=dev, eps=layer.mlp[1].eps)
+            object.__setattr__(layer, "_pats_params", p)
+        return p
+
+    def propagation_forward(self, x, source):
+        return ops.attentional_propagation(x, source, _params(self), heads=self.attn.num_heads, bn_train=self.training)
+
+    def gnn_forward(self, desc0, desc1):
+        layers = [_params(layer) for layer in self.layers]
+        heads = self.layers[0].attn.num_heads if len(self.layers) else 4
+        train = bool(len(self.layers) and self.layers[0].training)
+        return ops.attentional_gnn(desc0, desc1, layers, self.names, heads=heads, bn_train=train)
+
     return {"models.second_layer": ("SecondLayer", {"merge_patches_new": merge_patches_new,
                                                     "merge_patches_old": merge_patches_old}),
-            "models.third_layer": ("ThirdLayer", {"Compute_result": Compute_result})}
+            "models.third_layer": ("ThirdLayer", {"Compute_result": Compute_result}),
+            "models.modules": ("AttentionalPropagation", {"forward": propagation_forward}),
+            "models.modules#gnn": ("AttentionalGNN", {"forward": gnn_forward})}
 
 
 def install(import_reference=False):
@@ -102,7 +125,8 @@ def install(import_reference=False):
             if mname == home or cur is originals.get(fname):
                 _set(mod, fname, getattr(ops, attr))
                 touched.append(mname + "." + fname)
-    for mname, (cls_name, methods) in _methods(ops).items():
+    for mkey, (cls_name, methods) in _methods(ops).items():
+        mname = mkey.split("#")[0]
         mod = sys.modules.get(mname)
         cls = getattr(mod, cls_name, None) if mod is not None else None
         if cls is None:

@@ -718,3 +718,79 @@ def attention(query, key, value, return_prob=True):
     _check(_L().pats_attention_f32(_ptr(q), _ptr(k), _ptr(v), b, dim, heads, n, m, _ptr(out), _ptr(prob), _stream()),
            "attention")
     return out, prob
+
+
+# ------------------------------------------------------------------------------------------------
+# the GNN layer around the attention core
+# ------------------------------------------------------------------------------------------------
+class _PropagationWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wq_t", "bq", "wk_t", "bk", "wv_t", "bv", "wm_t", "bm", "w1_t", "b1",
+                                               "bn_a", "bn_b", "w2_t", "b2")]
+
+
+class PropagationParams:
+    """Device-resident weights of one AttentionalPropagation layer (modules.py:107-113) in the layout the C-ABI takes
+    (Conv1d matrices transposed, BatchNorm folded for eval mode).  Build it once per layer:
+        PropagationParams(layer.state_dict())          # a reference module's own parameters, or any dict with its names
+    """
+
+    def __init__(self, state, device="cuda", eps=1e-5, prefix=""):
+        def get(name):
+            t = state[prefix + name]
+            t = torch.from_numpy(np.asarray(t)) if not isinstance(t, torch.Tensor) else t
+            return t.detach().to(device=device, dtype=torch.float32)
+
+        def mat_t(name):                              # [C_out, C_in, 1] -> [C_in][C_out]
+            w = get(name)
+            return w.reshape(w.shape[0], -1).t().contiguous()
+        self.eps = float(eps)
+        self.C = get("attn.merge.bias").shape[0]
+        self.t = {"wq_t": mat_t("attn.proj.0.weight"), "bq": get("attn.proj.0.bias").contiguous(),
+                  "wk_t": mat_t("attn.proj.1.weight"), "bk": get("attn.proj.1.bias").contiguous(),
+                  "wv_t": mat_t("attn.proj.2.weight"), "bv": get("attn.proj.2.bias").contiguous(),
+                  "wm_t": mat_t("attn.merge.weight"), "bm": get("attn.merge.bias").contiguous(),
+                  "w1_t": mat_t("mlp.0.weight"), "b1": get("mlp.0.bias").contiguous(),
+                  "w2_t": mat_t("mlp.3.weight"), "b2": get("mlp.3.bias").contiguous()}
+        gamma, beta = get("mlp.1.weight"), get("mlp.1.bias")
+        scale = gamma / torch.sqrt(get("mlp.1.running_var") + self.eps)
+        self.bn = {False: (scale.contiguous(), (beta - get("mlp.1.running_mean") * scale).contiguous()),   # eval: folded
+                   True: (gamma.contiguous(), beta.contiguous())}                                       # train: gamma / beta
+
+    def struct(self, bn_train):
+        a, b = self.bn[bool(bn_train)]
+        w = _PropagationWeights()
+        for k, v in self.t.items():
+            setattr(w, k, v.data_ptr())
+        w.bn_a, w.bn_b = a.data_ptr(), b.data_ptr()
+        return w
+
+
+def attentional_propagation(x, source, params, heads=4, bn_train=False, residual=None):
+    """AttentionalPropagation.forward(x, source) (modules.py:114-117) -> delta [b,C,n]; with `residual` (= x in
+    AttentionalGNN.forward, :131-133) the sum residual + delta.  bn_train: BatchNorm on batch statistics - what the
+    third layer's GNN does under PATS.eval() (pats.py:112-120).  Six GEMM launches + the attention kernel."""
+    x, source = _dev(x, "x"), _dev(source, "source")
+    b, C, n = x.shape
+    m = source.shape[2]
+    if source.shape[0] != b or source.shape[1] != C or C != params.C:
+        raise RuntimeError("attentional_propagation: x %s / source %s / weights C=%d do not match"
+                           % (tuple(x.shape), tuple(source.shape), params.C))
+    res = _dev(residual, "residual") if residual is not None else None
+    out = torch.empty_like(x)
+    nb = _L().pats_attentional_propagation_workspace_bytes(b, C, n, m)
+    ws = _workspace(nb, x.device)
+    w = params.struct(bn_train)
+    _check(_L().pats_attentional_propagation_f32(_ptr(x), _ptr(source), b, C, int(heads), n, m, ctypes.byref(w),
+                                                 int(bool(bn_train)), float(params.eps), _ptr(res), _ptr(out), _ptr(ws), nb,
+                                                 _stream()), "attentional_propagation")
+    return out
+
+
+def attentional_gnn(desc0, desc1, layers, names, heads=4, bn_train=False):
+    """AttentionalGNN.forward (modules.py:127-134): layers = [PropagationParams, ...], names = ['self', 'cross', ...]."""
+    for p, name in zip(layers, names):
+        src0, src1 = (desc1, desc0) if name == "cross" else (desc0, desc1)
+        n0 = attentional_propagation(desc0, src0, p, heads, bn_train, residual=desc0)
+        n1 = attentional_propagation(desc1, src1, p, heads, bn_train, residual=desc1)
+        desc0, desc1 = n0, n1
+    return desc0, desc1

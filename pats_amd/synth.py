@@ -212,3 +212,32 @@ class SynthNets:
 
     def third(self, num, P):
         return third_inputs(seed=self.seed + 201 + num, P=P)
+
+
+def gnn_params(seed=SEED + 70, C=128):
+    """Weights of one AttentionalPropagation layer (modules.py:107-113) under the reference's state_dict names,
+    drawn with numpy so that fixtures, tests and the oracle regenerate them: Conv1d weights ~ U(-1/sqrt(fan_in), +),
+    BatchNorm with non-trivial affine and running statistics."""
+    rng = np.random.default_rng(seed)
+
+    def conv(cout, cin):
+        k = 1.0 / np.sqrt(cin)
+        return (rng.uniform(-k, k, (cout, cin, 1)).astype(np.float32), rng.uniform(-k, k, (cout,)).astype(np.float32))
+    p = {}
+    for i in range(3):
+        p["attn.proj.%d.weight" % i], p["attn.proj.%d.bias" % i] = conv(C, C)
+    p["attn.merge.weight"], p["attn.merge.bias"] = conv(C, C)
+    p["mlp.0.weight"], p["mlp.0.bias"] = conv(2 * C, 2 * C)
+    p["mlp.1.weight"] = rng.uniform(0.5, 1.5, (2 * C,)).astype(np.float32)
+    p["mlp.1.bias"] = (0.2 * rng.standard_normal((2 * C,))).astype(np.float32)
+    p["mlp.1.running_mean"] = (0.3 * rng.standard_normal((2 * C,))).astype(np.float32)
+    p["mlp.1.running_var"] = rng.uniform(0.5, 2.0, (2 * C,)).astype(np.float32)
+    p["mlp.3.weight"], p["mlp.3.bias"] = conv(C, 2 * C)
+    p["mlp.3.bias"][:] = 0.0                                   # nn.init.constant_(self.mlp[-1].bias, 0.0), modules.py:112
+    return p
+
+
+def gnn_inputs(seed=SEED + 71, b=3, C=128, n=65, m=None):
+    rng = np.random.default_rng(seed)
+    m = n if m is None else m
+    return {"x": rng.standard_normal((b, C, n)).astype(np.float32), "source": rng.standard_normal((b, C, m)).astype(np.float32)}

@@ -44,6 +44,14 @@ class ThirdLayer:
     def Compute_result(self, scores, W, T, scale_x, scale_y, p_s, p_t, device): return "ref"
 
 
+class AttentionalPropagation:
+    def forward(self, x, source): return "ref"
+
+
+class AttentionalGNN:
+    def forward(self, desc0, desc1): return "ref"
+
+
 REF_NAMES = ("models", "models.modules", "models.first_layer", "models.second_layer", "models.third_layer", "utils",
              "utils.utils", "tensor_resize")
 
@@ -55,7 +63,8 @@ def standins():
     _mod("models")
     _mod("utils")
     mm = _mod("models.modules", log_sinkhorn_iterations=log_sinkhorn_iterations, log_optimal_transport=log_optimal_transport,
-              log_optimal_transport2=log_optimal_transport2, attention=attention)
+              log_optimal_transport2=log_optimal_transport2, attention=attention, AttentionalPropagation=AttentionalPropagation,
+              AttentionalGNN=AttentionalGNN)
     uu = _mod("utils.utils", Iterative_expand_matrix=Iterative_expand_matrix, split_patches=split_patches,
               Compute_positions_and_ranges=Compute_positions_and_ranges, Compute_imgs=Compute_imgs, get_result=get_result,
               tensor_resize=native)
@@ -104,6 +113,9 @@ def test_install_rebinds_every_namespace_and_restores(standins):
     assert native.tensor_resize is ops.tensor_resize and s["uu"].tensor_resize is native
     assert SecondLayer.merge_patches_new is not None and SecondLayer().merge_patches_new.__func__.__module__ == "pats_amd.dropin"
     assert ThirdLayer().Compute_result.__func__.__module__ == "pats_amd.dropin"
+    assert AttentionalPropagation.forward.__module__ == "pats_amd.dropin" and AttentionalGNN.forward.__module__ == "pats_amd.dropin"
+    assert list(inspect.signature(AttentionalPropagation.forward).parameters) == ["self", "x", "source"]
+    assert list(inspect.signature(AttentionalGNN.forward).parameters) == ["self", "desc0", "desc1"]
     assert "models.first_layer.log_optimal_transport" in touched and "models.third_layer.ThirdLayer.Compute_result" in touched
     # signatures: same positional parameters as the reference's
     for ref, new in ((log_sinkhorn_iterations, ops.log_sinkhorn_iterations), (log_optimal_transport, ops.log_optimal_transport),
@@ -115,6 +127,7 @@ def test_install_rebinds_every_namespace_and_restores(standins):
     dropin.uninstall()
     assert s["l1"].log_optimal_transport is log_optimal_transport and s["uu"].get_result is get_result
     assert SecondLayer().merge_patches_new(1, 2, 3, 4, 5, 6) == "ref" and ThirdLayer().Compute_result(*range(8)) == "ref"
+    assert AttentionalPropagation().forward(1, 2) == "ref" and AttentionalGNN().forward(1, 2) == "ref"
     assert sys.modules["tensor_resize"] is s["native"]
 
 
@@ -132,6 +145,7 @@ def test_install_against_the_real_reference_when_present():
     originals.update({n: getattr(R.U, n) for n in ("Iterative_expand_matrix", "Compute_positions_and_ranges", "split_patches",
                                                    "Compute_imgs", "get_result")})
     merge_new, comp_res = R.L2.SecondLayer.merge_patches_new, R.L3.ThirdLayer.Compute_result
+    prop_fwd, gnn_fwd = R.M.AttentionalPropagation.forward, R.M.AttentionalGNN.forward
     try:
         touched = dropin.install()
         for n, ref in originals.items():
@@ -141,7 +155,9 @@ def test_install_against_the_real_reference_when_present():
         assert R.U.Compute_imgs is ops.Compute_imgs and R.U.tensor_resize.tensor_resize is ops.tensor_resize
         assert _prefix_compatible(merge_new, R.L2.SecondLayer.merge_patches_new, drop_self=True)
         assert _prefix_compatible(comp_res, R.L3.ThirdLayer.Compute_result, drop_self=True)
-        assert len(touched) >= 15
+        assert len(touched) >= 17
+        assert _prefix_compatible(prop_fwd, R.M.AttentionalPropagation.forward) and R.M.AttentionalPropagation.forward is not prop_fwd
+        assert _prefix_compatible(gnn_fwd, R.M.AttentionalGNN.forward)
     finally:
         dropin.uninstall()
         # ref_import put the reference's compiled extension first on sys.path / into sys.modules: later tests
@@ -152,3 +168,4 @@ def test_install_against_the_real_reference_when_present():
         else:
             sys.modules["tensor_resize"] = native_before
     assert R.L1.log_optimal_transport is originals["log_optimal_transport"] and R.L2.SecondLayer.merge_patches_new is merge_new
+    assert R.M.AttentionalPropagation.forward is prop_fwd and R.M.AttentionalGNN.forward is gnn_fwd

@@ -923,3 +923,130 @@ def test_third_level_guard_trips_are_resolved_by_the_scan_kernel(ops, oracle, si
     clear = (top[:, :, 1] - top[:, :, 0]) > 1e-3 * top[:, :, 1]
     assert np.array_equal(ifm.cpu().numpy().astype(bool)[wild][clear], rifm.astype(bool)[wild][clear])
     assert np.isfinite(m1.cpu().numpy()).all()
+
+
+# ---- AttentionalPropagation / AttentionalGNN around the attention core (section 8f rank 4) -------------------
+GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_attentional_propagation_golden(ops, oracle, case):
+    """modules.py:107-117 against the reference's own AttentionalPropagation (eval mode and train mode = BatchNorm on
+    batch statistics, which is what the third layer runs under PATS.eval) and against the oracle."""
+    g = golden("gnn_layer.npz")
+    kw = GNN_CASES[case]
+    params = synth.gnn_params(seed=synth.SEED + 70 + case, C=kw["C"])
+    inp = synth.gnn_inputs(seed=synth.SEED + 80 + case, b=kw["b"], C=kw["C"], n=kw["n"], m=kw["m"])
+    P = ops.PropagationParams(params)
+    x, s = cu(inp["x"]), cu(inp["source"])
+    for mode in ("eval", "train"):
+        y = ops.attentional_propagation(x, s, P, bn_train=(mode == "train")).cpu().numpy()
+        np.testing.assert_allclose(y.reshape(-1)[g["%s_idx%d" % (mode, case)]], g["%s_val%d" % (mode, case)], atol=5e-5, rtol=2e-4)
+        np.testing.assert_allclose(y.astype(np.float64).sum((1, 2)), g["%s_sum%d" % (mode, case)], atol=3e-2, rtol=2e-4)
+        want = oracle.attentional_propagation(inp["x"], inp["source"], params, bn_train=(mode == "train"))
+        np.testing.assert_allclose(y, want, atol=5e-5, rtol=2e-4)
+    assert torch.equal(x, cu(inp["x"]))                                   # inputs are borrowed
+
+
+def test_attentional_gnn_and_edge_shapes(ops, oracle):
+    g = golden("gnn_layer.npz")
+    ps = [synth.gnn_params(seed=synth.SEED + 90 + i, C=128) for i in range(2)]
+    a = synth.gnn_inputs(seed=synth.SEED + 95, b=4, C=128, n=65)
+    d0, d1 = ops.attentional_gnn(cu(a["x"]), cu(a["source"]), [ops.PropagationParams(p) for p in ps], ["self", "cross"])
+    np.testing.assert_allclose(d0.cpu().numpy().reshape(-1)[g["gnn_idx"]], g["gnn_d0"], atol=1e-4, rtol=2e-4)
+    np.testing.assert_allclose(d1.cpu().numpy().reshape(-1)[g["gnn_idx"]], g["gnn_d1"], atol=1e-4, rtol=2e-4)
+    # coarse-level width (448 channels, 300 tokens): three row tiles, ragged last tile, against the oracle
+    p = synth.gnn_params(seed=5, C=448)
+    i = synth.gnn_inputs(seed=6, b=1, C=448, n=300)
+    y = ops.attentional_propagation(cu(i["x"]), cu(i["source"]), ops.PropagationParams(p), residual=cu(i["x"])).cpu().numpy()
+    want = oracle.attentional_propagation(i["x"], i["source"], p, residual=i["x"])
+    np.testing.assert_allclose(y, want, atol=1e-4, rtol=2e-4)
+    # fine-level width 264 = 8 * 33, 145 tokens, many problems per column tile
+    p = synth.gnn_params(seed=7, C=264)
+    i = synth.gnn_inputs(seed=8, b=5, C=264, n=145)
+    y = ops.attentional_propagation(cu(i["x"]), cu(i["source"]), ops.PropagationParams(p), bn_train=True).cpu().numpy()
+    np.testing.assert_allclose(y, oracle.attentional_propagation(i["x"], i["source"], p, bn_train=True), atol=1e-4, rtol=2e-4)
+    with pytest.raises(RuntimeError):
+        ops.attentional_propagation(cu(i["x"]), cu(i["source"][:, :100]), ops.PropagationParams(p))
+
+
+def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
+    """pats_amd.dropin.install() on a module tree shaped like the reference's models/modules.py (stand-ins written with
+    torch.nn here: the reference itself does not travel to the GPU box): after install() the SAME module instances run
+    AttentionalPropagation / AttentionalGNN through the HIP kernels - eval and train mode - with the stock result."""
+    import types
+    import torch.nn as nn
+    from pats_amd import dropin
+
+    class MultiHeadedAttention(nn.Module):
+        def __init__(self, num_heads, d_model):
+            super().__init__()
+            self.dim, self.num_heads = d_model // num_heads, num_heads
+            self.merge = nn.Conv1d(d_model, d_model, kernel_size=1)
+            self.proj = nn.ModuleList([nn.Conv1d(d_model, d_model, kernel_size=1) for _ in range(3)])
+
+        def forward(self, query, key, value):
+            b = query.size(0)
+            q, k, v = [l(x).view(b, self.dim, self.num_heads, -1) for l, x in zip(self.proj, (query, key, value))]
+            sc = torch.einsum('bdhn,bdhm->bhnm', q, k) / self.dim ** .5
+            x = torch.einsum('bhnm,bdhm->bdhn', torch.softmax(sc, dim=-1), v)
+            return self.merge(x.contiguous().view(b, self.dim * self.num_heads, -1))
+
+    class AttentionalPropagation(nn.Module):
+        def __init__(self, feature_dim, num_heads):
+            super().__init__()
+            self.attn = MultiHeadedAttention(num_heads, feature_dim)
+            self.mlp = nn.Sequential(nn.Conv1d(feature_dim * 2, feature_dim * 2, 1), nn.BatchNorm1d(feature_dim * 2), nn.ReLU(),
+                                     nn.Conv1d(feature_dim * 2, feature_dim, 1))
+
+        def forward(self, x, source):
+            return self.mlp(torch.cat([x, self.attn(x, source, source)], dim=1))
+
+    class AttentionalGNN(nn.Module):
+        def __init__(self, feature_dim, layer_names):
+            super().__init__()
+            self.layers = nn.ModuleList([AttentionalPropagation(feature_dim, 4) for _ in layer_names])
+            self.names = layer_names
+
+        def forward(self, desc0, desc1):
+            for layer, name in zip(self.layers, self.names):
+                src0, src1 = (desc1, desc0) if name == 'cross' else (desc0, desc1)
+                delta0, delta1 = layer(desc0, src0), layer(desc1, src1)
+                desc0, desc1 = desc0 + delta0, desc1 + delta1
+            return desc0, desc1
+
+    saved = {n: sys.modules.get(n) for n in ("models", "models.modules")}
+    mod = types.ModuleType("models.modules")
+    mod.AttentionalPropagation, mod.AttentionalGNN = AttentionalPropagation, AttentionalGNN
+    sys.modules["models"], sys.modules["models.modules"] = types.ModuleType("models"), mod
+    try:
+        torch.manual_seed(3)
+        gnn = AttentionalGNN(128, ["self", "cross", "self"]).cuda()
+        for layer in gnn.layers:                                           # non-trivial BatchNorm statistics
+            layer.mlp[1].running_mean.normal_(0, 0.3)
+            layer.mlp[1].running_var.uniform_(0.5, 2.0)
+        d0, d1 = torch.randn(6, 128, 65, device="cuda"), torch.randn(6, 128, 65, device="cuda")
+        with torch.no_grad():
+            want_eval = gnn.eval()(d0, d1)
+            stats = [(l.mlp[1].running_mean.clone(), l.mlp[1].running_var.clone()) for l in gnn.layers]
+            want_train = gnn.train()(d0, d1)
+            for l, (mu, var) in zip(gnn.layers, stats):                    # the train-mode pass moved them
+                l.mlp[1].running_mean.copy_(mu); l.mlp[1].running_var.copy_(var)
+            touched = dropin.install()
+            assert "models.modules.AttentionalGNN.forward" in touched
+            got_eval = gnn.eval()(d0, d1)
+            got_train = gnn.train()(d0, d1)
+            one = gnn.layers[0].eval()(d0, d1)
+        dropin.uninstall()
+        with torch.no_grad():
+            one_ref = gnn.layers[0](d0, d1)
+        for a, b in ((got_eval, want_eval), (got_train, want_train)):
+            assert torch.allclose(a[0], b[0], atol=2e-4, rtol=2e-4) and torch.allclose(a[1], b[1], atol=2e-4, rtol=2e-4)
+        assert torch.allclose(one, one_ref, atol=1e-4, rtol=2e-4)
+    finally:
+        dropin.uninstall()
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m

@@ -304,3 +304,32 @@ def test_attention(oracle):
         np.testing.assert_allclose(x.reshape(-1)[g["x_idx%d" % c]], g["x_val%d" % c], atol=1e-5, rtol=1e-5)
         np.testing.assert_allclose(prob.reshape(-1)[g["p_idx%d" % c]], g["p_val%d" % c], atol=2e-6, rtol=1e-5)
         np.testing.assert_allclose(prob.sum(-1), g["p_rowsum%d" % c], atol=2e-6)
+
+
+# ---- AttentionalPropagation / AttentionalGNN (modules.py:91-134), fixtures from the reference's own classes ----
+GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_attentional_propagation_against_the_reference_class(oracle, case):
+    g = golden("gnn_layer.npz")
+    kw = GNN_CASES[case]
+    params = synth.gnn_params(seed=synth.SEED + 70 + case, C=kw["C"])
+    inp = synth.gnn_inputs(seed=synth.SEED + 80 + case, b=kw["b"], C=kw["C"], n=kw["n"], m=kw["m"])
+    assert abs(synth.checksum(inp["x"], inp["source"], params["mlp.0.weight"]) - float(g["in_checksum%d" % case])) < 1e-6
+    for mode in ("eval", "train"):
+        y = oracle.attentional_propagation(inp["x"], inp["source"], params, bn_train=(mode == "train"))
+        np.testing.assert_allclose(y.reshape(-1)[g["%s_idx%d" % (mode, case)]], g["%s_val%d" % (mode, case)], atol=3e-5, rtol=1e-4)
+        np.testing.assert_allclose(y.astype(np.float64).sum((1, 2)), g["%s_sum%d" % (mode, case)], atol=2e-2, rtol=1e-4)
+
+
+def test_attentional_gnn_two_layers(oracle):
+    g = golden("gnn_layer.npz")
+    ps = [synth.gnn_params(seed=synth.SEED + 90 + i, C=128) for i in range(2)]
+    a = synth.gnn_inputs(seed=synth.SEED + 95, b=4, C=128, n=65)
+    d0, d1 = a["x"], a["source"]
+    for p, name in zip(ps, ["self", "cross"]):
+        s0, s1 = (d1, d0) if name == "cross" else (d0, d1)
+        d0, d1 = (oracle.attentional_propagation(d0, s0, p, residual=d0), oracle.attentional_propagation(d1, s1, p, residual=d1))
+    np.testing.assert_allclose(d0.reshape(-1)[g["gnn_idx"]], g["gnn_d0"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(d1.reshape(-1)[g["gnn_idx"]], g["gnn_d1"], atol=5e-5, rtol=1e-4)

@@ -497,6 +497,47 @@ def gen_pipeline(R, name, seed, h, w, if_local, if_outdoor, merge_new):
          matches_r=matches_r)
 
 
+GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
+
+
+def gen_gnn(R):
+    """AttentionalPropagation (modules.py:107-117) instantiated from the reference itself, its parameters loaded
+    from pats_amd.synth.gnn_params, in eval mode and in train mode (BatchNorm on batch statistics), plus two layers
+    of AttentionalGNN.forward (self, cross; :127-134).  Outputs sampled (8192 entries) with their sums."""
+    arrs = {}
+    for c, kw in enumerate(GNN_CASES):
+        C = kw["C"]
+        params = synth.gnn_params(seed=synth.SEED + 70 + c, C=C)
+        inp = synth.gnn_inputs(seed=synth.SEED + 80 + c, b=kw["b"], C=C, n=kw["n"], m=kw["m"])
+        layer = R.M.AttentionalPropagation(C, 4)
+        layer.load_state_dict({k: T(v) for k, v in params.items()}, strict=False)
+        rng = np.random.default_rng(60 + c)
+        for mode in ("eval", "train"):
+            layer.train(mode == "train")
+            with torch.no_grad():
+                y = layer(T(inp["x"]), T(inp["source"]))
+            idx = sample_idx(rng, y.shape, 8192)
+            arrs.update({"%s_idx%d" % (mode, c): idx, "%s_val%d" % (mode, c): y.reshape(-1)[T(idx)],
+                         "%s_sum%d" % (mode, c): y.double().sum((1, 2))})
+            # train-mode forward updates the running statistics: restore them for the next use
+            layer.load_state_dict({k: T(v) for k, v in params.items()}, strict=False)
+        arrs["in_checksum%d" % c] = synth.checksum(inp["x"], inp["source"], params["mlp.0.weight"])
+    # two GNN layers sharing the shape of the third level: desc <- desc + delta, self then cross
+    C = 128
+    gnn = R.M.AttentionalGNN(C, ["self", "cross"])
+    ps = [synth.gnn_params(seed=synth.SEED + 90 + i, C=C) for i in range(2)]
+    for lyr, p in zip(gnn.layers, ps):
+        lyr.load_state_dict({k: T(v) for k, v in p.items()}, strict=False)
+    gnn.eval()
+    a = synth.gnn_inputs(seed=synth.SEED + 95, b=4, C=C, n=65)
+    with torch.no_grad():
+        d0, d1 = gnn(T(a["x"]), T(a["source"]))
+    rng = np.random.default_rng(77)
+    i0 = sample_idx(rng, d0.shape, 8192)
+    arrs.update(gnn_idx=i0, gnn_d0=d0.reshape(-1)[T(i0)], gnn_d1=d1.reshape(-1)[T(i0)])
+    save("gnn_layer.npz", **arrs)
+
+
 def gen_roofline(R):
     """BASELINE.json configs[4] through the reference itself: cost einsum at [1,448,4096]^2, then
     log_optimal_transport on 4097x4097 with 200 iterations (modules.py:145-162; ~10 s on 8 cores).  Stored:
@@ -525,6 +566,9 @@ def main():
         gen_pipeline(R, "pipeline_640x480_indoor.npz", synth.SEED + 51, 15, 20, False, False, False)
         gen_roofline(R)
         return
+    if only == ["gnn"]:
+        gen_gnn(R)
+        return
     gen_kat(R)
     gen_sinkhorn_raw(R)
     gen_ties(R)
@@ -546,6 +590,7 @@ def main():
     gen_result(R, "result.npz", synth.SEED + 8, False)
     gen_result(R, "result_mixed.npz", synth.SEED + 11, True)
     gen_attention(R)
+    gen_gnn(R)
     gen_pipeline(R, "pipeline_outdoor.npz", synth.SEED + 40, 5, 6, True, True, True)
     gen_pipeline(R, "pipeline_indoor.npz", synth.SEED + 41, 4, 5, False, False, False)
     gen_pipeline(R, "pipeline_640x480_outdoor.npz", synth.SEED + 50, 15, 20, True, True, True)
