@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=16, help="image pairs per step per rank")
+    ap.add_argument("--pairs", type=int, default=48,
+                    help="image pairs per step per rank (48 = about 100 GB of synthetic descriptors resident in the 288 GB of HBM)")
     ap.add_argument("--fill", type=int, default=60, help="third-level problems per fine problem (P = fill*B)")
     ap.add_argument("--per-chunk", action="store_true",
                     help="run Compute_imgs once per coarse chunk like the reference's loop (one host read per step)")
