@@ -362,6 +362,7 @@ sinkhorn65_kernel(Ot65Args g) {
 }
 
 // standalone cost build for 65-wide problems (pats_cost_f32 fast path): one wave per problem
+template <bool F16>
 __global__ void __launch_bounds__(64)
 cost65_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D, int64_t P,
               float* __restrict__ out) {
@@ -369,7 +370,7 @@ cost65_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D,
     const int lane = threadIdx.x;
     const int64_t p = blockIdx.x;
     if (p >= P) return;
-    cost65_to_tile(d0 + p * (int64_t)D * NT, d1 + p * (int64_t)D * NT, D, tile, lane);
+    cost65_to_tile<F16>(d0 + p * (int64_t)D * NT, d1 + p * (int64_t)D * NT, D, tile, lane);
     __syncthreads();
     float* Op = out + p * TILE;
 #pragma unroll 11
@@ -378,7 +379,9 @@ cost65_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D,
 }
 
 int launch_cost65(const float* d0, const float* d1, int D, int64_t P, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(cost65_kernel, dim3((unsigned)P), dim3(64), 0, st, d0, d1, D, P, out);
+    static const bool f16 = getenv("PATS_COST65_F16") != nullptr;      // diagnostic: the fp16-split contraction of the fused kernel
+    if (f16) hipLaunchKernelGGL(cost65_kernel<true>, dim3((unsigned)P), dim3(64), 0, st, d0, d1, D, P, out);
+    else hipLaunchKernelGGL(cost65_kernel<false>, dim3((unsigned)P), dim3(64), 0, st, d0, d1, D, P, out);
     return check_launch("cost65_kernel");
 }
 

@@ -23,6 +23,11 @@
 //    layout was chosen by (v_pk_fma_f32 2.05 ns per SIMD, plain fp32 add/mul/fma 1.05, DPP add / select /
 //    v_pk_add 1.75, rcp and permlane swaps 3.4, and the fp32 MFMA occupies the same FMA lanes: 13.4).
 //
+//  * the cost build splits every fp32 descriptor element into two fp16 halves and runs three exact-product passes of
+//    v_mfma_f32_32x32x16_f16 per tile instead of the fp32 MFMA (cost65_device.hpp: 96 matrix instructions of 32 cycles
+//    instead of 256 of 64; measured error against float64 below the fp32 fma chain's own).  PATS_THIRD_VARIANT=300
+//    selects the fp32-MFMA build of the same kernel.
+//
 // The solve is the linear-domain one only.  A problem that trips the guard writes a sentinel into its
 // if_matching1 slot and is re-solved by third_fused_kernel (third_fused.hip, log-sum-exp sweeps) in
 // scan mode on the same stream; forced-log mode and iters == 0 go to that kernel directly.
@@ -102,7 +107,7 @@ __device__ __forceinline__ float wave_sum_mfma(float v) {
 }
 template <int DB>
 __device__ __forceinline__ float dustbin_sum(float v, float* slot, int lane) {
-    if (DB == 0 || DB >= 7) return wave_sum_uniform(v);
+    if (DB == 0 || DB >= 6) return wave_sum_uniform(v);
     if (DB == 2) return wave_sum_mfma(v);
     return wave_sum_lds(v, slot, lane);
 }
@@ -220,9 +225,10 @@ __device__ __forceinline__ void compute_result16(const float* rows, const float*
     }
 }
 
-// WAVES = waves per SIMD the register budget is cut for; CR = column reduction (0 swaps, 1 LDS); DB = dustbin
+// WAVES = waves per SIMD the register budget is cut for; CR = column reduction (0 swaps, 1 LDS); CF = cost build
+// (0 fp32 MFMA, 1 fp16-split operands); DB = dustbin
 // sums (0 DPP row broadcasts, 1 LDS, 2 MFMA).  The defaults are what measured fastest (launch_third_fused3).
-template <int WAVES, int CR, int DB>
+template <int WAVES, int CR, int DB, int CF = 0>
 __global__ void __launch_bounds__(64, WAVES)
 third_fused3_kernel(Fused65Args g) {
     __shared__ Blk3Lds lds;
@@ -253,6 +259,8 @@ third_fused3_kernel(Fused65Args g) {
             c.er0 = c.er1 = c.ec0 = c.ec1 = c.cn = 0.f;
         } else if (DB == 7) {   // timing ablation only: descriptor loads without the MFMAs
             cost65_accumulate<true>(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
+        } else if (CF == 1) {   // fp16-split operands, three exact-product MFMA passes (cost65_device.hpp)
+            cost65_accumulate_f16x2(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
         } else
         cost65_accumulate(g.d0 + p * (int64_t)g.D * 65, g.d1 + p * (int64_t)g.D * 65, g.D, lds.stage, lane, c);
         const int li = lane & 31, lk = lane >> 5;
@@ -298,6 +306,23 @@ third_fused3_kernel(Fused65Args g) {
         __syncthreads();
         lds.erow[lane] = g.scale_x[p * 64 + lane];       // the epilogue's target scales wait in the freed edge buffers
         lds.ecol[lane] = g.scale_y[p * 64 + lane];
+    }
+
+    if (DB == 6) {      // diagnostic: checksums of the score matrix this wave built (no solve)
+        float sblk = 0.f, sabs = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+                sblk += (Pa[sp][cp].x + Pa[sp][cp].y) + (Pb[sp][cp].x + Pb[sp][cp].y);
+                sabs += (fabsf(Pa[sp][cp].x) + fabsf(Pa[sp][cp].y)) + (fabsf(Pb[sp][cp].x) + fabsf(Pb[sp][cp].y));
+            }
+        const float a0 = wave_sum(sblk), a1 = wave_sum(sabs), a2 = wave_sum(zdrow), a3 = wave_sum(zdcol);
+        if (lane == 0) {
+            g.cr.mk1[p * 32 + 0] = a0; g.cr.mk1[p * 32 + 1] = a1; g.cr.mk1[p * 32 + 2] = a2; g.cr.mk1[p * 32 + 3] = a3;
+            g.cr.mk1[p * 32 + 4] = zcorner; g.cr.ifm[p * 16] = 0;
+        }
+        return;
     }
 
     // ---- stabilisers r_i = max_j Z_ij, c_j = max_i (Z_ij - r_i); K = exp(Z - r - c) -----------------------
@@ -448,10 +473,13 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     g.fallbacks = fallback_counter();
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
     if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
-    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 300;   // A/B switch
+    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 1300;   // A/B switch
     const dim3 grid((unsigned)g.P), block(64);
     switch (variant) {          // digits: waves per SIMD, column reduction, dustbin sums
         case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, 0, st, g); break;
+        case 306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 0>), grid, block, 0, st, g); break;
+        case 1306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 1>), grid, block, 0, st, g); break;
+        case 1400: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 0, 1>), grid, block, 0, st, g); break;
         case 301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1>), grid, block, 0, st, g); break;
         case 302: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 2>), grid, block, 0, st, g); break;
         case 307: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 7>), grid, block, 0, st, g); break;
@@ -462,7 +490,8 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 401: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 1>), grid, block, 0, st, g); break;
         case 410: hipLaunchKernelGGL((third_fused3_kernel<4, 1, 0>), grid, block, 0, st, g); break;
         case 411: hipLaunchKernelGGL((third_fused3_kernel<4, 1, 1>), grid, block, 0, st, g); break;
-        default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0>), grid, block, 0, st, g); break;
+        case 300: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0>), grid, block, 0, st, g); break;     // fp32 MFMA cost build
+        default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0, 1>), grid, block, 0, st, g); break;
     }
     return check_launch("third_fused3_kernel");
 }

@@ -1050,3 +1050,39 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
                 sys.modules.pop(n, None)
             else:
                 sys.modules[n] = m
+
+
+def test_third_level_fp16_split_cost_build_matches_the_fp32_build(ops, oracle):
+    """The fused third level builds its scores from fp16-split operands (three exact-product MFMA passes, fp32
+    accumulation); PATS_THIRD_VARIANT=300 is the same kernel with the fp32 MFMA.  Both must agree with the oracle to
+    the same gates - and descriptors beyond the fp16 range (|x| > 1023 after the 2^6 pre-scale) must come out right
+    through the guard (inf -> NaN scores -> re-solve by the fp32 log-domain kernel)."""
+    import subprocess
+    code = r'''
+import sys, os, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+import pats_oracle as oracle
+from pats_amd import ops, synth
+inp = synth.third_inputs(seed=synth.SEED + 64, P=512)
+d0, d1 = inp["d0"].copy(), inp["d1"].copy()
+d0[7] *= 100.0; d1[7] *= 100.0                      # elements up to ~1500: beyond the split's range
+cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+ops.sinkhorn_fallbacks(reset=True)
+m0, m1, label, ifm = ops.third_level(cu(d0), cu(d1), cu(inp["scale"]), cu(inp["p_s"]), cu(inp["p_t"]), outdoor=True)
+trips = ops.sinkhorn_fallbacks(reset=True)
+Zr = oracle.log_optimal_transport2(oracle.cost(d0, d1), 1.0, inp["scale"], 100)
+sq = np.sqrt(inp["scale"] + np.float32(1e-8)).astype(np.float32)
+r0, r1, rwl, rlabel, rifm = oracle.compute_result(np.exp(Zr), sq, sq, inp["p_s"], inp["p_t"], True)
+tame = np.setdiff1d(np.arange(512), [7])
+assert np.array_equal(label.cpu().numpy().reshape(512, 16, 2)[tame], rlabel.reshape(512, 16, 2)[tame])
+assert np.array_equal(ifm.cpu().numpy().astype(bool)[tame], rifm.astype(bool)[tame])
+assert np.array_equal(m0.cpu().numpy(), r0)
+d = np.abs(m1.cpu().numpy()[tame] - r1[tame]).max()
+assert d <= 3e-4 * 8, d
+assert np.isfinite(m1.cpu().numpy()).all() and trips >= 1
+print("OK", d, trips)
+''' % (REPO, REPO)
+    for variant in ("1300", "300"):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PATS_THIRD_VARIANT=variant), capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, variant + ": " + p.stdout[-500:] + p.stderr[-1500:]
