@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 python $R/bench.py > $O/r02_bench.json 2> $O/r02_bench.err
 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-python $R/tools/rocpd_stats.py $(find /tmp/kt1 -name "*.db" | head -1) "bench.py --steps 5 --warmup 2 (16 pairs per step; includes workload set-up kernels)" > $O/r02_bench_kernel_stats.md 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/kt1 -name "*.db" | head -1) "bench.py --steps 5 --warmup 2 (default 48 pairs per step; the table includes the set-up kernels that build the synthetic workload)" > $O/r02_bench_kernel_stats.md 2>&1
 python $R/tools/bench_config5.py > $O/r02_config5.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -- python $R/tools/bench_config5.py > /dev/null 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) "tools/bench_config5.py (config 5: 4096^2 x 448 cost GEMM, 4097^2 Sinkhorn 200 sweeps)" > $O/r02_config5_kernel_stats.md 2>&1
