@@ -43,6 +43,12 @@ ITERS = 100
 ONE = [None]            # device-resident 1.0 (the reference's `self.one`, second_layer.py:63)
 
 
+# name -> (grid h, grid w, if_local, outdoor, label); BASELINE.json configs[1..3], shapes from SURVEY.md section 8d
+WORKLOADS = {"megadepth": (15, 20, True, True, "configs[1]: MegaDepth 640x480 shapes, outdoor (if_local chunks of 2w, +ln2, label from the dustbin)"),
+             "scannet": (15, 20, False, False, "configs[2]: ScanNet 640x480 shapes, indoor (one L2 chunk, cap 512; +ln3; fixed-cell label)"),
+             "yfcc": (24, 32, True, True, "configs[3]: YFCC 768x1024 shapes (24x32 grid, 769x769 coarse problem), outdoor")}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +57,9 @@ def parse():
     ap.add_argument("--pairs", type=int, default=48,
                     help="image pairs per step per rank (48 = about 100 GB of synthetic descriptors resident in the 288 GB of HBM)")
     ap.add_argument("--fill", type=int, default=60, help="third-level problems per fine problem (P = fill*B)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="megadepth",
+                    help="megadepth = BASELINE configs[1] (the bench line); scannet = configs[2] shapes (indoor rules, one L2 chunk); "
+                         "yfcc = configs[3] shapes (768x1024 pairs, 769x769 coarse problem) - secondary measurements")
     ap.add_argument("--per-chunk", action="store_true",
                     help="run Compute_imgs once per coarse chunk like the reference's loop (one host read per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,14 +89,17 @@ class Workload:
     (evaluate.py:25, pats.py:33) only because it targets one 16-40 GB card; every coarse / fine /
     third-level problem is independent, so with 288 GB each stage is one launch."""
 
-    def __init__(self, ops, dev, gen, pairs, fill, per_chunk=False):
-        c = synth.coarse_inputs()
+    def __init__(self, ops, dev, gen, pairs, fill, per_chunk=False, workload="megadepth"):
+        h, w, self.if_local, self.outdoor, self.label = WORKLOADS[workload]
+        c = synth.coarse_inputs(h=h, w=w) if workload != "megadepth" else synth.coarse_inputs()
+        self.H, self.W, self.cap = 32 * h, 32 * w, (2 * w if self.if_local else 512)
+        self.bias_k = 2.0 if self.outdoor else 3.0
         self.pairs, self.h, self.w, self.fill = pairs, c["h"], c["w"], fill
         self.per_chunk_imgs = per_chunk
         rep = lambda a: torch.from_numpy(a).to(dev).repeat(pairs, *([1] * (a.ndim - 1))).contiguous()  # noqa: E731
         self.d0, self.d1, self.ns = rep(c["d0"]), rep(c["d1"]), rep(c["ns"])
         self.alpha = torch.tensor(float(c["alpha"]), device=dev)
-        left, right = synth.image_pair()
+        left, right = synth.image_pair(H=self.H, W=self.W)
         self.left, self.right = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
         self.lefts = self.left.expand(pairs, -1, -1, -1).contiguous()       # every pair: the same synthetic image
         self.rights = self.right.expand(pairs, -1, -1, -1).contiguous()
@@ -124,7 +136,7 @@ def coarse_ops(ops, wl):
     """first_layer.py:110-135 for all pairs: one batched cost+OT launch, column mass, argmax + expansion."""
     Z = ops.cost_ot(wl.d0, wl.d1, 1, wl.alpha, wl.ns, ITERS)
     scales, cflag = ops.colmass_sqrt(Z, return_flags=True)
-    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (480, 640), 32, col_nomatch=cflag)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (wl.H, wl.W), 32, col_nomatch=cflag)
     sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1, dtype=torch.int32)
     return pts, xs, ys, ifn1, sum_cycle
 
@@ -135,7 +147,7 @@ def coarse_plan_host(ops, wl):
     sc_host = sum_cycle.to("cpu").numpy()
     plans = []
     for i in range(wl.pairs):
-        n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, 2 * wl.w)
+        n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, wl.cap)
         K = int(sc_host[i, -1])
         plans.append([min(hi, K) - lo for lo, hi in second])
     assert all(p == plans[0] for p in plans)
@@ -152,17 +164,17 @@ def coarse_stage(ops, wl):
         # the reference's loop (first_layer.py:136-146): host plan, one Compute_imgs per pair and chunk mask
         sc_host = sum_cycle.to("cpu").numpy()
         for i in range(wl.pairs):
-            n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, 2 * wl.w)
+            n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, wl.cap)
             for lo, hi in second:
                 mask = torch.logical_or(ifn1[i:i + 1], torch.logical_or(sum_cycle[i:i + 1] <= lo,
                                                                         sum_cycle[i:i + 1] > hi))
                 ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left, wl.right, width=wl.w,
                                  height=wl.h)
-        num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, 2 * wl.w)
+        num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, wl.cap)
         nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs, ys, pts, ifn1, wl.lefts, wl.rights, width=wl.w, height=wl.h,
                                                  known_count=wl.counts)
         return dict(ifn1=ifn1, sum_cycle=sum_cycle, second=second, num=num, xsn=xsn, avn=avn)
-    num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, 2 * wl.w)
+    num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, wl.cap)
     nl, nr, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(xs, ys, pts, ifn1, wl.lefts, wl.rights,
                                                                       width=wl.w, height=wl.h, known_count="device")
     return dict(ifn1=ifn1, sum_cycle=sum_cycle, second=second, num=num, xsn=xsn, avn=avn, K_img=K_img)
@@ -173,7 +185,7 @@ def fine_and_third(ops, wl, co, ev):
     if ev is not None:
         f0_, f1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         f0_.record()
-    Z2, cflag2 = ops.cost_ot(ch["f0"], ch["f1"], 2, ONE[0], ch["ns2"], ITERS, bias_k=2.0, return_flags=True)
+    Z2, cflag2 = ops.cost_ot(ch["f0"], ch["f1"], 2, ONE[0], ch["ns2"], ITERS, bias_k=wl.bias_k, return_flags=True)
     if ev is not None:
         f1_.record()
         ev["fine"].append((f0_, f1_))
@@ -182,7 +194,7 @@ def fine_and_third(ops, wl, co, ev):
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    m0f, m1f, label, ifm = ops.third_level(ch["t0"], ch["t1"], ch["sc"], ch["p_s"], ch["p_t"], outdoor=True, iters=ITERS)
+    m0f, m1f, label, ifm = ops.third_level(ch["t0"], ch["t1"], ch["sc"], ch["p_s"], ch["p_t"], outdoor=wl.outdoor, iters=ITERS)
     if ev is not None:
         e1.record()
         ev["third"].append((e0, e1, ch["P"]))
@@ -435,7 +447,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(synth.SEED + rank)
     ONE[0] = torch.tensor(1.0, device=dev)
-    wl = Workload(ops, dev, gen, args.pairs, args.fill, args.per_chunk)
+    wl = Workload(ops, dev, gen, args.pairs, args.fill, args.per_chunk, args.workload)
     B, P = wl.B, wl.P
 
     def barrier():
@@ -507,11 +519,10 @@ def main():
         "value": value, "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: MegaDepth 640x480 shapes, outdoor coarse+fine+third OT + cost volume "
-                               "+ expansion + subdivision gather + get_result",
+        "config": {"workload": wl.label + ": coarse+fine+third OT + cost volume + expansion + subdivision gather + get_result",
                    "pairs_per_step_per_rank": args.pairs,
                    "batching": "each stage is one launch over all pairs of the step; no host read inside a step",
-                   "L1": "1x[448,300]^2 -> 301x301",
+                   "L1": "1x[448,%d]^2 -> %dx%d" % (wl.h * wl.w, wl.h * wl.w + 1, wl.h * wl.w + 1),
                    "L2": "%d x [264,145]^2 -> 145x145 (%d coarse chunks, batched into one launch)" % (B, len(wl.plan)),
                    "L3": "%d x [128,65]^2 -> 65x65 (fill %d)" % (P, args.fill), "sinkhorn_iters": ITERS,
                    "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
@@ -529,7 +540,8 @@ def main():
                      "sweep_elements_per_s": exp_rate,
                      "valu_frac": valu_tflops / F32_PEAK_TFLOPS, "valu_tflops": valu_tflops,
                      "mfma_flops_per_s": float((2.0 * 128 * 64 * 64 * probs / (ms * 1e-3)).mean()),
-                     "note": "fused cost build (fp32 MFMA) + 100 linear-domain Sinkhorn sweeps + Compute_result per 65x65 problem, "
+                     "note": "fused cost build (fp16-split operands, three exact-product f16 MFMA passes, fp32 accumulation: error vs "
+                             "float64 below the fp32 fma chain's; PATS_THIRD_VARIANT=300 = fp32 MFMA) + 100 linear-domain Sinkhorn sweeps + Compute_result per 65x65 problem, "
                              "one wave each, the 65x65 block held in registers; descriptors are read once, the plan never "
                              "reaches HBM.  HBM is the nearest of the two allowed rooflines but not the limiter: the sweeps "
                              "are fp32 VALU work (valu_frac = sweep FMA flops / 157.3 TF/s vector peak)"},

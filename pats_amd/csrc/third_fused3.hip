@@ -480,6 +480,9 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 0>), grid, block, 0, st, g); break;
         case 1306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 1>), grid, block, 0, st, g); break;
         case 1400: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 0, 1>), grid, block, 0, st, g); break;
+        case 1301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1, 1>), grid, block, 0, st, g); break;
+        case 1310: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 0, 1>), grid, block, 0, st, g); break;
+        case 1311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1, 1>), grid, block, 0, st, g); break;
         case 301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1>), grid, block, 0, st, g); break;
         case 302: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 2>), grid, block, 0, st, g); break;
         case 307: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 7>), grid, block, 0, st, g); break;

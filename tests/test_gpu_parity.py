@@ -830,19 +830,30 @@ def test_get_result_without_host_read(ops):
     assert torch.equal(mlc[:ml.shape[0]], ml) and torch.equal(mrc[:mr.shape[0]], mr)
 
 
-def _run_bench(extra_env, gpus):
+def _run_bench(extra_env, gpus, extra_args=()):
     import json
     import subprocess
     env = dict(os.environ, **extra_env)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1",
-           "--pairs", "2", "--no-cpu-baseline", "--no-secondary"]
+           "--pairs", "2", "--no-cpu-baseline", "--no-secondary"] + list(extra_args)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
+
+
+def test_bench_other_workloads(ops, sinkhorn_mode):
+    """BASELINE configs[2] (ScanNet shapes: indoor rules, one L2 chunk) and configs[3] (YFCC shapes: 769 x 769 coarse problem)
+    through the same step as the bench line."""
+    if sinkhorn_mode != "kernel":
+        pytest.skip("once is enough")
+    sc = _run_bench({}, 1, ["--workload", "scannet"])
+    assert "configs[2]" in sc["config"]["workload"] and "(1 coarse chunks" in sc["config"]["L2"] and sc["matches_per_pair"] > 1000
+    yf = _run_bench({}, 1, ["--workload", "yfcc", "--pairs", "1"])
+    assert "769x769" in yf["config"]["L1"] and yf["matches_per_pair"] > 1000 and yf["value"] > 0
 
 
 def test_bench_spawns_its_own_ranks(ops, sinkhorn_mode):
