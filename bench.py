@@ -39,6 +39,7 @@ from pats_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA
 ITERS = 100
 ONE = [None]            # device-resident 1.0 (the reference's `self.one`, second_layer.py:63)
 
@@ -373,8 +374,13 @@ def secondary_rooflines(ops, dev, wl, fine_ms):
     N, D = d0.shape[2], d0.shape[1]
     ms = timed(lambda: ops.cost(d0, d1))
     tf = 2.0 * D * N * N / (ms * 1e-3) / 1e12
+    split_note = ("fp32 operands as fp16 hi + lo pairs, three exact-product passes of v_mfma_f32_32x32x16_f16 (fp32 accumulation; "
+                  "closer to float64 than the fp32 fma chain, tools/cost_ab.py): `achieved` counts the 2*D*M*N algorithmic flops "
+                  "against the fp32 matrix peak the reference arithmetic would be priced at; the fp16 pipe executes three times "
+                  "as many (f16_pipe_*).  PATS_COST_F32=1 = the fp32-MFMA path (0.186 ms / 3.04 ms on the same shapes)")
     out.append({"kernel": "cost_mfma_kernel, config 5 (4096^2 x %d)" % D, "bound": "mfma", "achieved": tf,
                 "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS, "ms": ms,
+                "f16_pipe_tflops": 3.0 * tf, "f16_pipe_frac": 3.0 * tf / F16_PEAK_TFLOPS, "note": split_note,
                 "profile": "profiles/r02_config5_kernel_stats.md"})
     S = ops.cost(d0, d1)
     alpha = torch.tensor(float(r["alpha"]), device=dev)
@@ -392,8 +398,11 @@ def secondary_rooflines(ops, dev, wl, fine_ms):
     ch = wl.chunk
     ms = timed(lambda: ops.cost(ch["f0"], ch["f1"]))
     tf = 2.0 * 264 * 145 * 145 * ch["B"] / (ms * 1e-3) / 1e12
-    out.append({"kernel": "cost_mfma_kernel, fine level (%d x [264,145]^2)" % ch["B"], "bound": "mfma", "achieved": tf,
-                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS, "ms": ms})
+    by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * ch["B"]
+    out.append({"kernel": "cost_mfma_kernel, fine level (%d x [264,145]^2)" % ch["B"], "bound": "hbm",
+                "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms": ms, "tflops": tf, "note": "one workgroup per problem reads 306 KB of descriptors and writes 84 KB of scores: "
+                "with the fp16-split contraction the matrix pipe needs 0.4 ms of this, the rest is the descriptor stream"})
     if fine_ms is not None:
         by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * ch["B"]
         gbs = by / (fine_ms * 1e-3) / 1e9

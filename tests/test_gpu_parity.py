@@ -1063,6 +1063,53 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
                 sys.modules[n] = m
 
 
+def test_cost_fp16_split_path_against_float64_and_range_fallback(ops):
+    """csrc/cost.hip: the default contraction (fp16 hi + lo, three MFMA passes) against float64 at the coarse / fine
+    shapes, ragged channel counts and edge tiles; operands beyond the fp16 range (|x| > 1023) make the workgroup redo
+    its tile on the fp32 path in-kernel; inf / NaN inputs come out as the fp32 chain has them."""
+    rng = np.random.default_rng(21)
+
+    def run(b, D, n, m, scale=1.0, spike=None):
+        d0 = (rng.standard_normal((b, D, n)) * scale).astype(np.float32)
+        d1 = (rng.standard_normal((b, D, m)) * scale).astype(np.float32)
+        if spike is not None:
+            d0[0, D // 2, n // 3] = spike
+        with np.errstate(invalid="ignore", over="ignore"):
+            truth = np.einsum("bdn,bdm->bnm", d0.astype(np.float64), d1.astype(np.float64)) / np.sqrt(float(D)) * 0.1
+        return ops.cost(cu(d0), cu(d1)).cpu().numpy(), truth
+
+    for shape in ((2, 448, 300, 300), (3, 264, 145, 145), (2, 128, 40, 77), (2, 100, 161, 33), (2, 7, 16, 500),
+                  (1, 24, 321, 163), (2, 17, 3, 2)):
+        S, truth = run(*shape)
+        assert np.abs(S - truth).max() < 6e-7, shape                 # |S| <= 0.6: a few fp32 ulps
+    S, truth = run(2, 264, 145, 145, scale=30.0)
+    assert np.abs(S - truth).max() < 4e-4 and np.abs(truth).max() > 100
+    S, truth = run(2, 264, 145, 145, scale=1e-3)                      # far below the range where `lo` stays normal
+    assert np.abs(S - truth).max() < 1e-9
+    S, truth = run(2, 264, 145, 145, spike=5000.0)                    # hi overflows -> fp32 redo of that workgroup
+    assert np.isfinite(S).all() and np.abs(S - truth).max() < 1e-4
+    S, truth = run(2, 264, 145, 145, spike=float("inf"))
+    bad = ~np.isfinite(truth)
+    assert bad.any() and (~np.isfinite(S) == bad).all() and np.abs(S[~bad] - truth[~bad]).max() < 6e-7
+
+
+def test_cost_fp32_path_still_selectable():
+    """PATS_COST_F32=1 routes pats_cost_f32 through the fp32-MFMA contraction (the in-kernel fallback of the split path)."""
+    import subprocess
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from pats_amd import ops, synth; "
+            "inp = synth.fine_inputs(seed=3, B=4); "
+            "S = ops.cost(torch.from_numpy(inp['d0']).cuda(), torch.from_numpy(inp['d1']).cuda()).cpu().numpy(); "
+            "np.save(sys.argv[1], S)") % REPO
+    import tempfile
+    outs = []
+    for env in ({"PATS_COST_F32": "1"}, {}):
+        with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+            subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, **env), check=True)
+            outs.append(np.load(f.name))
+    assert not np.array_equal(outs[0], outs[1])                       # two different contractions ...
+    np.testing.assert_allclose(outs[0], outs[1], rtol=3e-6, atol=4e-6)   # ... a few ulps of the largest terms apart (|S| up to 16)
+
+
 def test_third_level_fp16_split_cost_build_matches_the_fp32_build(ops, oracle):
     """The fused third level builds its scores from fp16-split operands (three exact-product MFMA passes, fp32
     accumulation); PATS_THIRD_VARIANT=300 is the same kernel with the fp32 MFMA.  Both must agree with the oracle to
