@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # extra VGPRs and puts a spill reload + vmcnt(0) into every Sinkhorn sweep (+12 % kernel time,
 # measured).  The explicit float2 FMAs of the sweeps are not SLP products and stay packed.
 EXTRA_FLAGS = {"third_fused.hip": ["-fno-slp-vectorize"], "third_fused3.hip": ["-fno-slp-vectorize"],
-               "cost.hip": ["-fno-slp-vectorize"]}
+               "cost.hip": ["-fno-slp-vectorize"], "gnn.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():

@@ -8,28 +8,23 @@
 //
 // A Conv1d with kernel 1 over [b, C_in, n] is the product W [C_out x C_in] . X_b [C_in x n] for every b, i.e. the
 // channel-major descriptor layout of the cost build with the weights as the shared (batch-stride 0) operand: the
-// same fp32 MFMA tiling (160 x 160 output tile per 256-thread workgroup, 8-row operand slabs staged global ->
-// registers -> LDS, double-buffered), generalised in three ways so that the layer needs no glue kernels:
+// same 160 x 160 MFMA tile (mfma_tile.hpp: fp32 operands as fp16 hi + lo pairs, three exact-product passes, fp32
+// accumulation, in-kernel fp32 redo for operands beyond the fp16 range; PATS_COST_F32=1 selects the fp32 MFMA
+// throughout), generalised in three ways so that the layer needs no glue kernels:
 //   * the 160 tile columns run over the flattened (batch, token) axis - a tile spans several problems, so 65-token
 //     problems fill the tile instead of wasting 60 % of it;
 //   * the reduction dimension may come from TWO tensors (x | message): `cat` is never materialised;
 //   * input channels can carry an affine + ReLU applied while staging (BatchNorm in eval mode = its running
 //     statistics, in train mode = batch statistics from bn_stats_kernel: PATS.eval leaves the third layer in train
 //     mode, pats.py:112-120), and the epilogue adds the bias and an optional residual (desc + delta).
-// The attention core in the middle is pats_attention_f32 (attention.hip).  fp32 throughout.
-#include "common.hpp"
+// The attention core in the middle is pats_attention_f32 (attention.hip).
+#include "mfma_tile.hpp"
+
+#include <cstdlib>
 
 namespace pats {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 namespace {
-constexpr int CT = 160, KC = 8, CPT = KC * CT / 256;
-
-struct __attribute__((aligned(16))) ConvLds {
-    float a[2][KC][CT];
-    float b[2][KC][CT];
-};
 
 struct ConvArgs {
     const float* wt;           // [K0 + K1][M]: transposed weights (row = input channel)
@@ -43,90 +38,92 @@ struct ConvArgs {
     const float* residual;     // [batch, M, n] or null
     float* y;                  // [batch, M, n]
 };
-}  // namespace
 
-__global__ void __launch_bounds__(256, 2)
-conv1x1_kernel(ConvArgs g) {
-    __shared__ ConvLds lds;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int li = lane & 31, lk = lane >> 5;
-    const int64_t tiles_j = (g.cols + CT - 1) / CT;
-    const int i0 = (int)(blockIdx.x / tiles_j) * CT;
-    const int64_t j0 = (int64_t)(blockIdx.x % tiles_j) * CT;
-    const int K = g.K0 + g.K1, n = g.n, M = g.M;
+// operand source of mfma_tile.hpp: A = transposed weights at output rows i0.., B = activations at flattened columns j0..
+// (K0 and K1 are multiples of 8, so neither an 8-channel slab row nor a 4-channel item straddles the two inputs)
+struct ConvSrc {
+    const ConvArgs& g;
+    int i0, t, K;
+    int64_t j0;
+    const float* pw[mt::SQ];           // weights: column pointer (fp32 slab element q, or split item q when on side 0)
+    const float* p0[mt::SQ];           // activations: (batch, token) pointer into x0 / x1 at channel 0
+    const float* p1[mt::SQ];
 
-    // staging map: element e = t + 256 q of a slab is (row e / 160, column e % 160); columns past the edge clamp
-    float ra[CPT], rb[CPT];
-    const float* pa[CPT];
-    const float* p0[CPT];
-    const float* p1[CPT];
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        const int e = t + 256 * q, kk = e / CT, col = e % CT;
-        pa[q] = g.wt + (int64_t)kk * M + min(i0 + col, M - 1);
-        const int64_t cg = min(j0 + col, g.cols - 1), b = cg / n;
-        const int tk = (int)(cg - b * n);
-        p0[q] = g.x0 + (b * g.K0 + kk) * (int64_t)n + tk;
-        p1[q] = g.x1 ? g.x1 + (b * g.K1 + kk) * (int64_t)n + tk : nullptr;
+    __device__ __forceinline__ ConvSrc(const ConvArgs& g_, int i0_, int64_t j0_, int t_)
+        : g(g_), i0(i0_), t(t_), K(g_.K0 + g_.K1), j0(j0_) {}
+    __device__ __forceinline__ bool row_stored(int r) const { return i0 + r < g.M; }
+    __device__ __forceinline__ bool col_stored(int c) const { return j0 + c < g.cols; }
+
+    __device__ __forceinline__ void point(int q, int col) {
+        pw[q] = g.wt + min(i0 + col, g.M - 1);
+        const int64_t cg = min(j0 + col, g.cols - 1), b = cg / g.n;
+        const int tk = (int)(cg - b * g.n);
+        p0[q] = g.x0 + b * g.K0 * (int64_t)g.n + tk;
+        p1[q] = g.x1 ? g.x1 + b * g.K1 * (int64_t)g.n + tk : nullptr;
     }
-    auto fetch = [&](int k0) {
-        const bool second = k0 >= g.K0;               // K0 % KC == 0: a chunk never straddles the two sources
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int kk = (t + 256 * q) / CT;
-            const bool kin = k0 + kk < K;
-            ra[q] = kin ? pa[q][(int64_t)k0 * M] : 0.f;
-            float x = 0.f;
-            if (kin) x = second ? p1[q][(int64_t)(k0 - g.K0) * n] : p0[q][(int64_t)k0 * n];
-            if (g.in_scale && kin) x = fmaxf(fmaf(x, g.in_scale[k0 + kk], g.in_shift[k0 + kk]), 0.f);
-            rb[q] = x;
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int e = t + 256 * q;
-            (&lds.a[buf][0][0])[e] = ra[q];
-            (&lds.b[buf][0][0])[e] = rb[q];
-        }
-    };
+    // activation of channel k (< K) at the column of element / item q, with the staged affine + ReLU
+    __device__ __forceinline__ float act(int q, int k) const {
+        float x = k >= g.K0 ? p1[q][(int64_t)(k - g.K0) * g.n] : p0[q][(int64_t)k * g.n];
+        if (g.in_scale) x = fmaxf(fmaf(x, g.in_scale[k], g.in_shift[k]), 0.f);
+        return x;
+    }
 
-    f32x16 acc[7];
+    __device__ __forceinline__ void fetch_f32(int k0, float (&ra)[mt::CPT], float (&rb)[mt::CPT]) {
+        if (k0 == 0) {
 #pragma unroll
-    for (int q = 0; q < 7; ++q)
+            for (int q = 0; q < mt::CPT; ++q) point(q, mt::f32_col(t, q));
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    // output-row tiles that exist: rows i0 + 32 w .. for wave w, and the fifth tile row (i0 + 128 ..) shared by all
-    const bool row4 = i0 + 128 < M;
+        for (int q = 0; q < mt::CPT; ++q) {
+            const int k = k0 + mt::f32_row(t, q);
+            const bool kin = k < K;
+            ra[q] = kin ? pw[q][(int64_t)k * g.M] : 0.f;
+            rb[q] = kin ? act(q, k) : 0.f;
+        }
+    }
 
-    const int nchunk = (K + KC - 1) / KC;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) fetch((c + 1) * KC);
+    __device__ __forceinline__ void fetch_split(int k0, float (&r)[mt::SQ][4]) {
+        if (k0 == 0) {
 #pragma unroll
-        for (int kp = 0; kp < KC / 2; ++kp) {
-            const float* ar = &lds.a[buf][2 * kp + lk][0];
-            const float* br = &lds.b[buf][2 * kp + lk][0];
-            const float aw = ar[32 * wave + li], a4 = ar[128 + li], bw = br[32 * wave + li];
-            float bf[5];
+            for (int q = 0; q < mt::SQ; ++q) point(q, mt::item_col(t, q));
+        }
 #pragma unroll
-            for (int tj = 0; tj < 5; ++tj) bf[tj] = br[32 * tj + li];
+        for (int q = 0; q < mt::SQ; ++q) {
+            const int kq = k0 + 4 * mt::item_quad(t, q);
+            const bool weights = mt::item_side(t, q) == 0;
 #pragma unroll
-            for (int tj = 0; tj < 5; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bf[tj], acc[tj], 0, 0, 0);
-            if (row4) {                                 // wave-uniform: 128-channel layers skip the fifth tile row
-                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, bw, acc[5], 0, 0, 0);
-                if (wave == 0) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4, bf[4], acc[6], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                const int k = kq + e, ks = min(k, K - 1);              // past K: read a valid channel, then zero
+                const float v = weights ? pw[q][(int64_t)ks * g.M] : act(q, ks);
+                r[q][e] = k < K ? v : 0.f;
             }
         }
-        if (c + 1 < nchunk) stash(buf ^ 1);
-        __syncthreads();
     }
+    __device__ __forceinline__ void rewind() {}
+};
+
+}  // namespace
+
+template <bool SPLIT, bool ROW4>
+__global__ void __launch_bounds__(256, 2)
+conv1x1_kernel(ConvArgs g) {
+    __shared__ mt::Lds lds;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t tiles_j = (g.cols + mt::CT - 1) / mt::CT;
+    const int i0 = (int)(blockIdx.x / tiles_j) * mt::CT;
+    const int64_t j0 = (int64_t)(blockIdx.x % tiles_j) * mt::CT;
+    const int n = g.n, M = g.M;
+    // output-row tiles that exist: rows i0 + 32 w .. for wave w, and the fifth tile row (i0 + 128 ..) shared by all
+    // (workgroup-uniform: 128-channel layers skip it)
+    const bool row4 = ROW4 && i0 + 128 < M;
+
+    ConvSrc src(g, i0, j0, t);
+    mt::f32x16 acc[7];
+    const float unscale = mt::tile<SPLIT, ROW4>(src, lds, acc, g.K0 + g.K1, row4, t, wave);
 
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    auto store_tile = [&](const f32x16& cacc, int ti, int tj) {
+    auto store_tile = [&](const mt::f32x16& cacc, int ti, int tj) {
         const int64_t cg = j0 + 32 * tj + li;
         if (cg >= g.cols) return;
         const int64_t b = cg / n;
@@ -136,7 +133,7 @@ conv1x1_kernel(ConvArgs g) {
             const int row = i0 + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (row < M) {
                 const int64_t o = (b * M + row) * (int64_t)n + tk;
-                float v = cacc[r];
+                float v = cacc[r] * unscale;
                 if (g.bias) v += g.bias[row];
                 if (g.residual) v = g.residual[o] + v;
                 g.y[o] = v;
@@ -184,9 +181,13 @@ bn_stats_kernel(const float* __restrict__ h, int64_t batch, int C, int n, const 
 }
 
 static int launch_conv(const ConvArgs& g, hipStream_t st) {
-    const int64_t tiles = (int64_t)((g.M + CT - 1) / CT) * ((g.cols + CT - 1) / CT);
+    const int64_t tiles = (int64_t)((g.M + mt::CT - 1) / mt::CT) * ((g.cols + mt::CT - 1) / mt::CT);
     PATS_REQUIRE(tiles < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
-    hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)tiles), dim3(256), 0, st, g);
+    static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
+    const dim3 grid((unsigned)tiles), block(256);
+    if (fp32_only) hipLaunchKernelGGL((conv1x1_kernel<false, true>), grid, block, 0, st, g);
+    else if (g.M <= 128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), grid, block, 0, st, g);      // no fifth tile row: 32 registers less
+    else hipLaunchKernelGGL((conv1x1_kernel<true, true>), grid, block, 0, st, g);
     return check_launch("conv1x1_kernel");
 }
 
