@@ -39,14 +39,16 @@ struct ExpandArgs {
 
 __device__ __forceinline__ float range_val(int d, int k) { return k <= d ? (float)k : 1e7f; }
 
+// float -> long truncation, then anything outside [0, wh - 1] becomes the sentinel (:1220-1221).  Every f that reaches
+// here is an integral float (an integer or the 1e7 padding, times the width, plus an integer offset), so the range
+// test can be made on the float itself - no 64-bit conversion.
 __device__ __forceinline__ int clamp_seq(float f, int wh, int S) {
-    long long s = (long long)f;      // float -> long truncation
-    if (!(s >= 0)) s = S;
-    if (!(s <= wh - 1)) s = S;
-    return (int)s;
+    return (f >= 0.f && f <= (float)(wh - 1)) ? (int)f : S;
 }
 
 
+// SMALL: the grid is at most 16 wide (the fine level's 12 x 12), every strip is ONE cell per lane - no inner loops
+template <bool SMALL>
 __global__ void __launch_bounds__(256)
 expand_kernel(ExpandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -80,14 +82,16 @@ expand_kernel(ExpandArgs a) {
         row16_argmax(fv, fi);
         if (t == 0 && active) a.row_nomatch[gr] = fi == N - 1;
     }
+    // the sentinel slot: every strip index is in [0, wh - 1] or is S = wh + 1 = N, which reads the appended 1e-14 (:1205,1208)
+    if (t == 0) { prow[N] = ZERO_F; popp[N] = ZERO_F; }
     __syncthreads();     // every thread gets here (idle groups shadow the last row)
 
     const int width = a.h > a.w ? a.h : a.w;
     const int height = (a.h * a.w) / width;
     const int wh = width * height, S = wh + 1;
-    auto ES = [&](int idx) { return idx < N ? prow[idx] : ZERO_F; };                 // :1205
+    auto ES = [&](int idx) { return prow[idx]; };                                    // :1205
     auto ESC = [&](int idx) { return idx < n ? sx[idx] * sy[idx] : ZERO_F; };        // :1206-1207
-    auto EOPP = [&](int idx) { return idx < n ? popp[idx] : ZERO_F; };               // :1208
+    auto EOPP = [&](int idx) { return popp[idx]; };                                  // :1208
 
     // argmax over the real columns (:1182) and over all columns (:1191), first index on ties
     float bv = -INFINITY, bva = -INFINITY;
@@ -119,14 +123,16 @@ expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float e = 0.f, q = 0.f, c = 0.f;
-            for (int k = t; k < width; k += 16) {
+            auto cell = [&](int k) {
                 const float f = d < 2 ? range_val(sb1, k) + off[d] : range_val(sb0, k) * (float)width + off[d];
                 const int s = clamp_seq(f, wh, S);
                 const float v = ES(s);
                 e += v;
                 q += (v > a.lower_bound) ? EOPP(s) : ZERO_F;        // :1225
-                c += ESC(s);                                        // :1231
-            }
+                if (!SMALL) c += ESC(s);                            // :1231 (never consumed, see below)
+            };
+            if (SMALL) { if (t < width) cell(t); }
+            else for (int k = t; k < width; k += 16) cell(k);
             es[d] = row16_sum(e);
             nm[d] = row16_sum(q);
             sc[d] = row16_sum(c);
@@ -166,13 +172,15 @@ expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float e = 0.f, c = 0.f;
-            for (int k = t; k < width; k += 16) {
+            auto cell = [&](int k) {
                 const float f = d < 2 ? range_val(sb1, k) + eoff[d]
                                       : range_val(sb0, k) * (float)width + eoff[d];
                 const int s = clamp_seq(f, wh, S);
                 e += ES(s);
                 c += ESC(s);
-            }
+            };
+            if (SMALL) { if (t < width) cell(t); }
+            else for (int k = t; k < width; k += 16) cell(k);
             ed[d] = row16_sum(e);
             sd[d] = row16_sum(c);
         }
@@ -258,6 +266,9 @@ extern "C" int pats_iterative_expand_f32(const float* P, int input_is_log, int64
     }
     PATS_REQUIRE(lds <= 64 * 1024, "iterative_expand: N=%d too large", N);
     const int64_t blocks = ceil_div(a.rows_total, rows_per_wg);
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(16 * rows_per_wg), lds, as_stream(stream), a);
+    if (h <= 16 && w <= 16)
+        hipLaunchKernelGGL(expand_kernel<true>, dim3((unsigned)blocks), dim3(16 * rows_per_wg), lds, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(expand_kernel<false>, dim3((unsigned)blocks), dim3(16 * rows_per_wg), lds, as_stream(stream), a);
     return check_launch("expand_kernel");
 }
