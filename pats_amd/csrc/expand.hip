@@ -193,10 +193,13 @@ expand_kernel(ExpandArgs a) {
     for (int p = t; p < n; p += 16) {
         const int pyi = p / a.w, pxi = p - pyi * a.w;               // positions (:1528-1532)
         const bool crit = pyi >= up && pyi <= down && pxi >= left && pxi <= right;
-        const float root = sqrtf(prow[p] + 1e-7f);
         const float fx = sx[p], fy = sy[p];
-        const float ox = crit ? root / fx : ZERO_F;
-        const float oy = crit ? root / fy : ZERO_F;
+        float ox = ZERO_F, oy = ZERO_F;
+        if (crit) {                                                 // the rectangle is a few cells: most passes skip the sqrt and the two divisions
+            const float root = sqrtf(prow[p] + 1e-7f);
+            ox = root / fx;
+            oy = root / fy;
+        }
         wx += ox * (float)pxi;
         wy += oy * (float)pyi;
         sumx += ox;

@@ -21,6 +21,7 @@ import pats_oracle as oracle  # noqa: E402
 from pats_amd import ops  # noqa: E402
 
 MASS_TOL = 1e-4
+NEAR_TIES = 0        # expand rows whose bounds hinge on a strip-sum tie within an ulp (see op_expand)
 
 
 def cu(x):
@@ -124,7 +125,22 @@ def op_expand(rng):
     positions, ranges = ops.Compute_positions_and_ranges(h, w, "cuda")
     got = ops.Iterative_expand_matrix(cu(P), cu(sc).reshape(b, -1, 1), cu(sc).reshape(b, -1, 1), [0, h, 0, w], ranges,
                                       positions, lower_bound=lb, iter_num=it, width=w, height=h)
-    assert np.array_equal(got[5].cpu().numpy(), want[5]), "bounds differ"
+    gb = got[5].cpu().numpy()
+    bad_rows = np.argwhere((gb != want[5]).any(-1))
+    if len(bad_rows):
+        # A growth step compares four strip sums; two of them within an ulp of each other are decided by the summation
+        # order (the reference's own torch.sum differs between CPU and GPU there).  Accept a differing row only if the
+        # oracle itself changes its answer for that row under 1e-7 relative noise on the plan.
+        assert len(bad_rows) <= 2, "bounds differ in %d rows" % len(bad_rows)
+        flips = set()
+        for _ in range(6):
+            Pn = (P * (1.0 + 1e-7 * rng.standard_normal(P.shape))).astype(np.float32)
+            wn = oracle.iterative_expand(Pn, sc, sc, w, h, w, lb, it)[5]
+            flips |= {tuple(r) for r in np.argwhere((wn != want[5]).any(-1))}
+        assert all(tuple(r) in flips for r in bad_rows), "bounds differ (no near-tie)"
+        global NEAR_TIES
+        NEAR_TIES += len(bad_rows)
+        return "near tie"
     np.testing.assert_allclose(got[0].cpu().numpy(), want[0], atol=3e-6, rtol=5e-5)
     np.testing.assert_allclose(got[2].cpu().numpy(), want[2], atol=2e-4, rtol=2e-5)
     np.testing.assert_allclose(got[3].cpu().numpy(), want[3], atol=1e-5, rtol=5e-5)
@@ -284,7 +300,8 @@ def main():
                 print("FAIL %-8s seed=%d : %s" % (n, seed, " | ".join(x.strip() for x in desc[:4])[:300]), flush=True)
             runs[n] += 1
             case += 1
-    print("fuzz: %d cases, %d failures; per op %s; guard fallbacks %d" % (case, fails, runs, ops.sinkhorn_fallbacks()))
+    print("fuzz: %d cases, %d failures; per op %s; guard fallbacks %d; expand near-tie rows %d"
+          % (case, fails, runs, ops.sinkhorn_fallbacks(), NEAR_TIES))
     sys.exit(1 if fails else 0)
 
 
