@@ -128,15 +128,31 @@ left_crops_kernel(const float* __restrict__ left_all, int n_img, int H, int W, c
     const int64_t img = min(max(seq / 10000, (int64_t)0), (int64_t)n_img - 1);
     const float* left = left_all + img * (int64_t)H * W * 3;
     const int r = patch / width, c = patch - r * width;
-    const int t = threadIdx.x;                 // 0..287 = 96 pixels x 3 channels of one row
-    const int x = t / 3;
-    const int ix = c * 32 + x - 32;
+    // a row of the window is 288 contiguous floats of the source (or zeros): 72 lanes x 16 bytes, four rows per pass of
+    // the 288 threads; the source offset is only 4-byte aligned in general (W * 3 floats per image row)
+    const int t = threadIdx.x, j = t % 72, sub = t / 72;
+    typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f4s __attribute__((ext_vector_type(4)));
     float* o = out + k * (96 * 96 * 3);
-    for (int y = blockIdx.y * 8; y < blockIdx.y * 8 + 8; ++y) {
+    const int ix0 = c * 32 - 32;                // first source pixel of the row
+    for (int y = blockIdx.y * 8 + sub; y < blockIdx.y * 8 + 8; y += 4) {
         const int iy = r * 32 + y - 32;
-        float v = 0.f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = left[((int64_t)iy * W) * 3 + (c * 32 - 32) * 3 + t];
-        o[y * 288 + t] = v;
+        f4s v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H) {
+            const float* row = left + (int64_t)iy * W * 3;
+            const int e0 = ix0 * 3 + 4 * j;                            // element offset inside the source row
+            if (e0 >= 0 && e0 + 3 < W * 3) {
+                const f4a u = *reinterpret_cast<const f4a*>(row + e0);
+                v = f4s{u.x, u.y, u.z, u.w};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = e0 + q;
+                    if (e >= 0 && e < W * 3) v[q] = row[e];
+                }
+            }
+        }
+        *reinterpret_cast<f4s*>(o + y * 288 + 4 * j) = v;
     }
 }
 
@@ -222,17 +238,27 @@ resize_hwc_kernel(const float* __restrict__ right, int n_img, int H, int W, int 
     }
     const float sh = (float)(g.ih - 1) / 95.0f, sw = (float)(g.iw - 1) / 95.0f;
     const float* img = right + (int64_t)g.img * H * W * 3;
-    auto at = [&](long long y, long long x, int ch) {
-        y -= margin; x -= margin;
-        return (y >= 0 && y < H && x >= 0 && x < W) ? img[(y * W + x) * 3 + ch] : 0.f;
+    // one output PIXEL per thread and pass (taps, bounds tests and addresses once for the three channels; the three
+    // floats of a tap are 12 contiguous bytes); coordinates fit 32 bits once the crop geometry has been validated
+    const int y0 = (int)g.y0 - margin, x0 = (int)g.x0 - margin, ih = (int)g.ih, iw = (int)g.iw;
+    struct Px { float r, g, b; };
+    auto at = [&](int y, int x) {
+        Px v{0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float* q = img + ((int64_t)y * W + x) * 3;
+            v.r = q[0]; v.g = q[1]; v.b = q[2];
+        }
+        return v;
     };
-    for (int idx = threadIdx.x; idx < 24 * 288; idx += 256) {
-        const int oy = slab * 24 + idx / 288, rem = idx % 288, ox = rem / 3, ch = rem - ox * 3;
-        const Tap ty = make_tap(sh, oy, g.ih), tx = make_tap(sw, ox, g.iw);
-        const long long y = g.y0 + ty.i1, x = g.x0 + tx.i1;
-        const float p00 = at(y, x, ch), p01 = at(y, x + tx.ip, ch), p10 = at(y + ty.ip, x, ch),
-                    p11 = at(y + ty.ip, x + tx.ip, ch);
-        o[oy * 288 + rem] = ty.l0 * (tx.l0 * p00 + tx.l1 * p01) + ty.l1 * (tx.l0 * p10 + tx.l1 * p11);
+    for (int px = threadIdx.x; px < 24 * 96; px += 256) {
+        const int oy = slab * 24 + px / 96, ox = px % 96;
+        const Tap ty = make_tap(sh, oy, ih), tx = make_tap(sw, ox, iw);
+        const int y = y0 + ty.i1, x = x0 + tx.i1;
+        const Px p00 = at(y, x), p01 = at(y, x + tx.ip), p10 = at(y + ty.ip, x), p11 = at(y + ty.ip, x + tx.ip);
+        float* d = o + oy * 288 + 3 * ox;
+        d[0] = ty.l0 * (tx.l0 * p00.r + tx.l1 * p01.r) + ty.l1 * (tx.l0 * p10.r + tx.l1 * p11.r);
+        d[1] = ty.l0 * (tx.l0 * p00.g + tx.l1 * p01.g) + ty.l1 * (tx.l0 * p10.g + tx.l1 * p11.g);
+        d[2] = ty.l0 * (tx.l0 * p00.b + tx.l1 * p01.b) + ty.l1 * (tx.l0 * p10.b + tx.l1 * p11.b);
     }
 }
 
