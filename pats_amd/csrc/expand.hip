@@ -62,7 +62,7 @@ expand_kernel(ExpandArgs a) {
     const int r = (int)(gr - b * m);
     const int ld = N + 3;
     float* prow = sm + (size_t)slot * ld;
-    float* popp = sm + (size_t)ROWS_PER_WG * ld + (size_t)slot * ld;   // this batch's dustbin row
+    float* popp = sm + (size_t)ROWS_PER_WG * ld + (size_t)slot * ld;   // this batch's dustbin row (see below)
     const float* Pb = a.P + b * (int64_t)M * N;
     const float* src = Pb + (int64_t)r * N;
     const float* oppsrc = Pb + (int64_t)(M - 1) * N;              // scores_in[:, -1, :-1]   (:1183)
@@ -72,18 +72,37 @@ expand_kernel(ExpandArgs a) {
     // exp can round two distinct logs to one float, so the flag must not come from the exponentiated row)
     float fv = -INFINITY;
     int fi = 0x7fffffff;
+    // The dustbin row of the problem is the same for its m source rows: a workgroup's rows touch at most two problems
+    // (when m >= rows per workgroup), so the whole workgroup stages those two rows ONCE (the first version had every
+    // 16-lane group exponentiate its own copy: 16 x N exps per workgroup instead of 2 x N).
+    const int64_t g0 = (int64_t)blockIdx.x * ROWS_PER_WG;
+    const int64_t glast = min(g0 + ROWS_PER_WG - 1, a.rows_total - 1);
+    const int64_t b0 = g0 / m;
+    const bool shared_opp = glast / m - b0 <= 1;                  // workgroup-uniform
+    if (shared_opp) {
+        popp = sm + (size_t)ROWS_PER_WG * ld + (size_t)(b - b0) * ld;
+        for (int e = threadIdx.x; e < 2 * N; e += blockDim.x) {
+            const int which = e >= N, j = e - which * N;
+            const int64_t bb = min(b0 + which, (int64_t)(a.rows_total - 1) / m);
+            const float o = a.P[bb * (int64_t)M * N + (int64_t)(M - 1) * N + j];
+            sm[(size_t)ROWS_PER_WG * ld + (size_t)which * ld + j] = a.input_is_log ? expf(o) : o;
+        }
+    }
     for (int j = t; j < N; j += 16) {
-        const float x = src[j], o = oppsrc[j];
+        const float x = src[j];
         if (x > fv || fi == 0x7fffffff) { fv = x; fi = j; }
         prow[j] = a.input_is_log ? expf(x) : x;
-        popp[j] = a.input_is_log ? expf(o) : o;
+        if (!shared_opp) {
+            const float o = oppsrc[j];
+            popp[j] = a.input_is_log ? expf(o) : o;
+        }
     }
     if (a.row_nomatch) {
         row16_argmax(fv, fi);
         if (t == 0 && active) a.row_nomatch[gr] = fi == N - 1;
     }
     // the sentinel slot: every strip index is in [0, wh - 1] or is S = wh + 1 = N, which reads the appended 1e-14 (:1205,1208)
-    if (t == 0) { prow[N] = ZERO_F; popp[N] = ZERO_F; }
+    if (t == 0) { prow[N] = ZERO_F; popp[N] = ZERO_F; }           // (shared dustbin rows: several groups write the same value)
     __syncthreads();     // every thread gets here (idle groups shadow the last row)
 
     const int width = a.h > a.w ? a.h : a.w;
@@ -120,6 +139,8 @@ expand_kernel(ExpandArgs a) {
                               (float)(left + up * width - 1),       // :1219
                               (float)(right + up * width + 1)};     // :1220
         float es[4], nm[4], sc[4];
+        float vcell[4];          // SMALL: this lane's cell of each strip, for the one nomatching sum that is consumed
+        int scell[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             float e = 0.f, q = 0.f, c = 0.f;
@@ -128,24 +149,42 @@ expand_kernel(ExpandArgs a) {
                 const int s = clamp_seq(f, wh, S);
                 const float v = ES(s);
                 e += v;
-                q += (v > a.lower_bound) ? EOPP(s) : ZERO_F;        // :1225
-                if (!SMALL) c += ESC(s);                            // :1231 (never consumed, see below)
+                if (SMALL) { vcell[d] = v; scell[d] = s; }
+                else {
+                    q += (v > a.lower_bound) ? EOPP(s) : ZERO_F;    // :1225
+                    c += ESC(s);                                    // :1231 (never consumed, see below)
+                }
             };
-            if (SMALL) { if (t < width) cell(t); }
+            if (SMALL) { vcell[d] = 0.f; scell[d] = S; if (t < width) cell(t); }
             else for (int k = t; k < width; k += 16) cell(k);
             es[d] = row16_sum(e);
-            nm[d] = row16_sum(q);
-            sc[d] = row16_sum(c);
+            if (!SMALL) { nm[d] = row16_sum(q); sc[d] = row16_sum(c); }
         }
         if (up == 0) es[0] = ZERO_F;                                // :1227-1230
         if (down == height - 1) es[1] = ZERO_F;
         if (left == 0) es[2] = ZERO_F;
         if (right == width - 1) es[3] = ZERO_F;
         int arg = 0;
-        float mx = es[0], mnm = nm[0];
+        float mx = es[0];
 #pragma unroll
         for (int d = 1; d < 4; ++d)
-            if (es[d] > mx) { mx = es[d]; mnm = nm[d]; arg = d; }   // :1232-1234
+            if (es[d] > mx) { mx = es[d]; arg = d; }                // :1232-1234
+        float mnm;
+        if (SMALL) {
+            // the nomatching sum of the chosen strip only (the other three are never read, :1233): same cells, same order
+            float v = vcell[0];
+            int sidx = scell[0];
+#pragma unroll
+            for (int d = 1; d < 4; ++d)
+                if (arg == d) { v = vcell[d]; sidx = scell[d]; }
+            const float q = (t < width) ? ((v > a.lower_bound) ? EOPP(sidx) : ZERO_F) : 0.f;
+            mnm = row16_sum(q);
+        } else {
+            mnm = nm[0];
+#pragma unroll
+            for (int d = 1; d < 4; ++d)
+                if (arg == d) mnm = nm[d];
+        }
         (void)sc;       // last_scale is accumulated by the reference (:1242) but never consumed
         float add_sum = ZERO_F, add_nm = ZERO_F;
         if (mx > a.lower_bound) {                                   // :1235-1238
