@@ -56,10 +56,11 @@ struct ConvSrc {
 
     __device__ __forceinline__ void point(int q, int col) {
         pw[q] = g.wt + min(i0 + col, g.M - 1);
-        const int64_t cg = min(j0 + col, g.cols - 1), b = cg / g.n;
-        const int tk = (int)(cg - b * g.n);
-        p0[q] = g.x0 + b * g.K0 * (int64_t)g.n + tk;
-        p1[q] = g.x1 ? g.x1 + b * g.K1 * (int64_t)g.n + tk : nullptr;
+        // flattened column -> (batch, token) in 32-bit arithmetic (launch_conv requires batch * n < 2^31): a 64-bit
+        // division is ~150 instructions, and a thread does ten of them per workgroup
+        const unsigned cg = (unsigned)min(j0 + col, g.cols - 1), b = cg / (unsigned)g.n, tk = cg - b * (unsigned)g.n;
+        p0[q] = g.x0 + (int64_t)b * g.K0 * g.n + tk;
+        p1[q] = g.x1 ? g.x1 + (int64_t)b * g.K1 * g.n + tk : nullptr;
     }
     // activation of channel k (< K) at the column of element / item q, with the staged affine + ReLU
     __device__ __forceinline__ float act(int q, int k) const {
@@ -124,15 +125,13 @@ conv1x1_kernel(ConvArgs g) {
 
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     auto store_tile = [&](const mt::f32x16& cacc, int ti, int tj) {
-        const int64_t cg = j0 + 32 * tj + li;
-        if (cg >= g.cols) return;
-        const int64_t b = cg / n;
-        const int tk = (int)(cg - b * n);
+        if (j0 + 32 * tj + li >= g.cols) return;
+        const unsigned cg = (unsigned)(j0 + 32 * tj + li), b = cg / (unsigned)n, tk = cg - b * (unsigned)n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = i0 + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (row < M) {
-                const int64_t o = (b * M + row) * (int64_t)n + tk;
+                const int64_t o = ((int64_t)b * M + row) * n + tk;
                 float v = cacc[r] * unscale;
                 if (g.bias) v += g.bias[row];
                 if (g.residual) v = g.residual[o] + v;
@@ -182,7 +181,7 @@ bn_stats_kernel(const float* __restrict__ h, int64_t batch, int C, int n, const 
 
 static int launch_conv(const ConvArgs& g, hipStream_t st) {
     const int64_t tiles = (int64_t)((g.M + mt::CT - 1) / mt::CT) * ((g.cols + mt::CT - 1) / mt::CT);
-    PATS_REQUIRE(tiles < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+    PATS_REQUIRE(tiles < (1ll << 31) && g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
     const dim3 grid((unsigned)tiles), block(256);
     if (fp32_only) hipLaunchKernelGGL((conv1x1_kernel<false, true>), grid, block, 0, st, g);
