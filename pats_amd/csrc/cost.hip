@@ -20,73 +20,13 @@ namespace pats {
 
 namespace {
 
-// operand source of mfma_tile.hpp: A = d0 [D][n] at columns i0.., B = d1 [D][m] at columns j0..
-struct CostSrc {
-    const float *A, *B;
-    int D, n, m, i0, j0, t;
-    const float* p[mt::SQ];            // running pointers (split items, or fp32 slab elements: pa in p[0..4], pb in pq)
-    const float* pq[mt::CPT];
-
-    __device__ __forceinline__ CostSrc(const float* A_, const float* B_, int D_, int n_, int m_, int i0_, int j0_, int t_)
-        : A(A_), B(B_), D(D_), n(n_), m(m_), i0(i0_), j0(j0_), t(t_) {}
+// column addressing for mfma_tile.hpp's CmSrc: A = d0 [D][n] at columns i0.., B = d1 [D][m] at columns j0.. (clamped)
+struct CostCols {
+    int n, m, i0, j0;
+    __device__ __forceinline__ int64_t a_off(int c) const { return min(i0 + c, n - 1); }
+    __device__ __forceinline__ int64_t b_off(int c) const { return min(j0 + c, m - 1); }
     __device__ __forceinline__ bool row_stored(int r) const { return i0 + r < n; }
     __device__ __forceinline__ bool col_stored(int c) const { return j0 + c < m; }
-    __device__ __forceinline__ void rewind() {}
-
-    // only a ragged last chunk (D % 8) needs the zero-filling fetch
-    __device__ __forceinline__ void fetch_f32(int k0, float (&ra)[mt::CPT], float (&rb)[mt::CPT]) {
-        if (k0 == 0) {
-#pragma unroll
-            for (int q = 0; q < mt::CPT; ++q) {
-                const int kk = mt::f32_row(t, q), col = mt::f32_col(t, q);
-                p[q] = A + (int64_t)kk * n + min(i0 + col, n - 1);
-                pq[q] = B + (int64_t)kk * m + min(j0 + col, m - 1);
-            }
-        }
-        if (k0 + mt::KC <= D) {
-#pragma unroll
-            for (int q = 0; q < mt::CPT; ++q) { ra[q] = *p[q]; rb[q] = *pq[q]; }
-        } else {
-#pragma unroll
-            for (int q = 0; q < mt::CPT; ++q) {
-                const bool kin = k0 + mt::f32_row(t, q) < D;
-                ra[q] = kin ? *p[q] : 0.f;
-                rb[q] = kin ? *pq[q] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < mt::CPT; ++q) { p[q] += (int64_t)mt::KC * n; pq[q] += (int64_t)mt::KC * m; }
-    }
-
-    __device__ __forceinline__ void fetch_split(int k0, float (&r)[mt::SQ][4]) {
-        if (k0 == 0) {
-#pragma unroll
-            for (int q = 0; q < mt::SQ; ++q) {
-                const int col = mt::item_col(t, q), side = mt::item_side(t, q);
-                p[q] = (side ? B + min(j0 + col, m - 1) : A + min(i0 + col, n - 1)) + (int64_t)(4 * mt::item_quad(t, q)) * (side ? m : n);
-            }
-        }
-        int ld[mt::SQ];
-#pragma unroll
-        for (int q = 0; q < mt::SQ; ++q) ld[q] = mt::item_side(t, q) ? m : n;
-        if (k0 + mt::SKC <= D) {
-#pragma unroll
-            for (int q = 0; q < mt::SQ; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r[q][e] = p[q][e * ld[q]];
-        } else {
-#pragma unroll
-            for (int q = 0; q < mt::SQ; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {      // ragged last chunk: read a valid row, then zero (no predicated loads)
-                    const int row = k0 + 4 * mt::item_quad(t, q) + e, back = min(row, D - 1) - (row - e);
-                    const float v = p[q][back * ld[q]];
-                    r[q][e] = row < D ? v : 0.f;
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < mt::SQ; ++q) p[q] += mt::SKC * ld[q];
-    }
 };
 
 }  // namespace
@@ -102,11 +42,12 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
     const int64_t b = blockIdx.x / tiles;
     const int tt = (int)(blockIdx.x - b * tiles);
     const int i0 = (tt / tiles_j) * mt::CT, j0 = (tt % tiles_j) * mt::CT;
-    CostSrc src(d0 + b * (int64_t)D * n, d1 + b * (int64_t)D * m, D, n, m, i0, j0, t);
+    const CostCols cols{n, m, i0, j0};
+    mt::CmSrc<CostCols> src(d0 + b * (int64_t)D * n, n, d1 + b * (int64_t)D * m, m, D, cols, t);
     float* O = out + b * (int64_t)n * m;
 
     mt::f32x16 acc[7];
-    const float unscale = mt::tile<SPLIT, true>(src, lds, acc, D, true, t, wave);
+    const float unscale = mt::tile<SPLIT, true>(src, (mt::CmSrc<CostCols>*)nullptr, lds, acc, true, t, wave);
 
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     auto store_tile = [&](const mt::f32x16& cacc, int ti, int tj) {

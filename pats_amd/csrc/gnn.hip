@@ -39,68 +39,19 @@ struct ConvArgs {
     float* y;                  // [batch, M, n]
 };
 
-// operand source of mfma_tile.hpp: A = transposed weights at output rows i0.., B = activations at flattened columns j0..
-// (K0 and K1 are multiples of 8, so neither an 8-channel slab row nor a 4-channel item straddles the two inputs)
-struct ConvSrc {
-    const ConvArgs& g;
-    int i0, t, K;
-    int64_t j0;
-    const float* pw[mt::SQ];           // weights: column pointer (fp32 slab element q, or split item q when on side 0)
-    const float* p0[mt::SQ];           // activations: (batch, token) pointer into x0 / x1 at channel 0
-    const float* p1[mt::SQ];
-
-    __device__ __forceinline__ ConvSrc(const ConvArgs& g_, int i0_, int64_t j0_, int t_)
-        : g(g_), i0(i0_), t(t_), K(g_.K0 + g_.K1), j0(j0_) {}
-    __device__ __forceinline__ bool row_stored(int r) const { return i0 + r < g.M; }
-    __device__ __forceinline__ bool col_stored(int c) const { return j0 + c < g.cols; }
-
-    __device__ __forceinline__ void point(int q, int col) {
-        pw[q] = g.wt + min(i0 + col, g.M - 1);
-        // flattened column -> (batch, token) in 32-bit arithmetic (launch_conv requires batch * n < 2^31): a 64-bit
-        // division is ~150 instructions, and a thread does ten of them per workgroup
-        const unsigned cg = (unsigned)min(j0 + col, g.cols - 1), b = cg / (unsigned)g.n, tk = cg - b * (unsigned)g.n;
-        p0[q] = g.x0 + (int64_t)b * g.K0 * g.n + tk;
-        p1[q] = g.x1 ? g.x1 + (int64_t)b * g.K1 * g.n + tk : nullptr;
+// column addressing for mfma_tile.hpp's CmSrc: A = transposed weights at output rows i0.. (clamped), B = activations at
+// flattened (batch, token) columns j0..: tile column c -> element offset of channel 0 in a [batch, Kc, n] tensor.  The
+// decomposition is 32-bit (launch_conv requires batch * n < 2^31) and done once per item, not per chunk.
+struct ConvCols {
+    int i0, M, n, Kc;          // Kc: channels of THIS activation tensor (its batch stride is Kc * n)
+    int64_t j0, cols;
+    __device__ __forceinline__ int64_t a_off(int c) const { return min(i0 + c, M - 1); }
+    __device__ __forceinline__ int64_t b_off(int c) const {
+        const unsigned cg = (unsigned)min(j0 + c, cols - 1), b = cg / (unsigned)n, tk = cg - b * (unsigned)n;
+        return (int64_t)b * Kc * n + tk;
     }
-    // activation of channel k (< K) at the column of element / item q, with the staged affine + ReLU
-    __device__ __forceinline__ float act(int q, int k) const {
-        float x = k >= g.K0 ? p1[q][(int64_t)(k - g.K0) * g.n] : p0[q][(int64_t)k * g.n];
-        if (g.in_scale) x = fmaxf(fmaf(x, g.in_scale[k], g.in_shift[k]), 0.f);
-        return x;
-    }
-
-    __device__ __forceinline__ void fetch_f32(int k0, float (&ra)[mt::CPT], float (&rb)[mt::CPT]) {
-        if (k0 == 0) {
-#pragma unroll
-            for (int q = 0; q < mt::CPT; ++q) point(q, mt::f32_col(t, q));
-        }
-#pragma unroll
-        for (int q = 0; q < mt::CPT; ++q) {
-            const int k = k0 + mt::f32_row(t, q);
-            const bool kin = k < K;
-            ra[q] = kin ? pw[q][(int64_t)k * g.M] : 0.f;
-            rb[q] = kin ? act(q, k) : 0.f;
-        }
-    }
-
-    __device__ __forceinline__ void fetch_split(int k0, float (&r)[mt::SQ][4]) {
-        if (k0 == 0) {
-#pragma unroll
-            for (int q = 0; q < mt::SQ; ++q) point(q, mt::item_col(t, q));
-        }
-#pragma unroll
-        for (int q = 0; q < mt::SQ; ++q) {
-            const int kq = k0 + 4 * mt::item_quad(t, q);
-            const bool weights = mt::item_side(t, q) == 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = kq + e, ks = min(k, K - 1);              // past K: read a valid channel, then zero
-                const float v = weights ? pw[q][(int64_t)ks * g.M] : act(q, ks);
-                r[q][e] = k < K ? v : 0.f;
-            }
-        }
-    }
-    __device__ __forceinline__ void rewind() {}
+    __device__ __forceinline__ bool row_stored(int r) const { return i0 + r < M; }
+    __device__ __forceinline__ bool col_stored(int c) const { return j0 + c < cols; }
 };
 
 }  // namespace
@@ -119,9 +70,13 @@ conv1x1_kernel(ConvArgs g) {
     // (workgroup-uniform: 128-channel layers skip it)
     const bool row4 = ROW4 && i0 + 128 < M;
 
-    ConvSrc src(g, i0, j0, t);
+    // the reduction runs over x0's channels, then over x1's (weights rows K0..): two sources, one accumulator
+    const ConvCols c0{i0, M, n, g.K0, j0, g.cols}, c1{i0, M, n, g.K1, j0, g.cols};
+    mt::CmSrc<ConvCols> s0(g.wt, M, g.x0, n, g.K0, c0, t, g.in_scale, g.in_shift);
+    mt::CmSrc<ConvCols> s1(g.wt + (int64_t)g.K0 * M, M, g.x1, n, g.K1, c1, t, g.in_scale ? g.in_scale + g.K0 : nullptr,
+                           g.in_shift ? g.in_shift + g.K0 : nullptr);
     mt::f32x16 acc[7];
-    const float unscale = mt::tile<SPLIT, ROW4>(src, lds, acc, g.K0 + g.K1, row4, t, wave);
+    const float unscale = mt::tile<SPLIT, ROW4, !ROW4>(s0, g.K1 > 0 ? &s1 : nullptr, lds, acc, row4, t, wave);
 
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     auto store_tile = [&](const mt::f32x16& cacc, int ti, int tj) {

@@ -26,14 +26,17 @@
 //  * tile_f32 (v_mfma_f32_32x32x2_f32; bitwise a k-ordered fmaf chain): slabs of 8 channels x 160 columns per
 //    side, staged global -> registers -> LDS, double-buffered.
 //
-// Operand source (one object per thread; the staging maps are fixed here, the addressing is the source's):
+// Operands come from an operand source, one object per thread (CmSrc below: two channel-major tensors with a
+// per-column base offset; the staging maps are fixed here, the column addressing is the caller's):
+//   int  K                                                       channels of this source
 //   void fetch_f32(int k0, float (&ra)[CPT], float (&rb)[CPT])   element q of a slab = (channel k0 + (t + 256 q) / 160,
 //                                                                tile column (t + 256 q) % 160); zero beyond K
 //   void fetch_split(int k0, float (&r)[SQ][4])                  item q: id = t + 256 q, tile column id % 160,
 //                                                                side (id / 160) >> 2, channels k0 + 4 ((id / 160) & 3) + e
 //   bool row_stored(int r) / col_stored(int c)                   tile row / column inside the output
-// Calls arrive with k0 = 0, step, 2 step, ... for one path at a time, so a source may keep running pointers;
-// rewind() is called between a failed tile_split and the tile_f32 redo.
+// Calls arrive with k0 = 0, step, 2 step, ... (k0 = 0 restarts), so a source keeps running pointers.  tile() takes
+// one or two sources: the reduction may run over two tensors one after the other (x | message in the GNN's MLP -
+// `cat` is never materialised; the first source's ragged last chunk is zero-filled, so any channel count works).
 //
 // Tried and measured slower for the cost build (tools/cost_ab.py, 20 736 x [264,145]^2: tile_f32 3.04 ms, tile_split
 // 1.98 ms): 320-thread workgroups with one tile row per wave (balanced, 80 accumulator registers, but two 5-wave
@@ -81,10 +84,11 @@ __device__ __forceinline__ void clear(f32x16 (&acc)[7]) {
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 }
 
-// fp32 contraction of one 160 x 160 tile over K channels
+// fp32 contraction of one 160 x 160 tile over the channels of one source, ADDED to acc
 template <bool ROW4, class Src>
-__device__ __forceinline__ void tile_f32(Src& src, LdsF32& lds, f32x16 (&acc)[7], int K, bool row4_, int t, int wave) {
+__device__ __forceinline__ void tile_f32(Src& src, LdsF32& lds, f32x16 (&acc)[7], bool row4_, int t, int wave) {
     const bool row4 = ROW4 && row4_;
+    const int K = src.K;
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     float ra[CPT], rb[CPT];
     auto stash = [&](int buf) {
@@ -131,17 +135,18 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2c{r0, r1}, h2c));
 }
 
-// fp16-split contraction of one tile; returns false (workgroup-uniform) if an operand left the fp16 range
-template <bool ROW4, class Src>
-__device__ __forceinline__ bool tile_split(Src& src, LdsSplit& lds, f32x16 (&acc)[7], int K, bool row4_, int t, int wave) {
+// fp16-split contraction of one tile over the channels of one source, ADDED to acc
+// DEEP: two register sets, the fetch runs TWO chunks ahead (needs 20 more registers: callers without a fifth tile row)
+template <bool ROW4, bool DEEP, class Src>
+__device__ __forceinline__ void split_accumulate(Src& src, LdsSplit& lds, f32x16 (&acc)[7], bool row4_, int t, int wave) {
     const bool row4 = ROW4 && row4_;
+    const int K = src.K;
     const int lane = t & 63, li = lane & 31, kg = lane >> 5;
-    float r[SQ][4];
     uint2* dst[SQ];
 #pragma unroll
     for (int q = 0; q < SQ; ++q) dst[q] = &lds.v[0][item_side(t, q)][0][item_quad(t, q)][item_col(t, q)];
     constexpr int BUF = sizeof(lds.v[0]) / sizeof(uint2), HL = sizeof(lds.v[0][0][0]) / sizeof(uint2);
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const float (&r)[SQ][4]) {
 #pragma unroll
         for (int q = 0; q < SQ; ++q) {
             uint2 hi, lo;
@@ -155,13 +160,7 @@ __device__ __forceinline__ bool tile_split(Src& src, LdsSplit& lds, f32x16 (&acc
         const uint2 e0 = lds.v[buf][side][hl][2 * kg][col], e1 = lds.v[buf][side][hl][2 * kg + 1][col];
         return __builtin_bit_cast(h8c, u4c{e0.x, e0.y, e1.x, e1.y});
     };
-    const int nchunk = (K + SKC - 1) / SKC;
-    src.fetch_split(0, r);
-    stash(0);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunk) src.fetch_split((c + 1) * SKC, r);
+    auto mfma_chunk = [&](int buf) {
         // Phases kept apart as in cost65_accumulate_f16x2 (cost65_device.hpp): the VALU-heavy split of the next chunk
         // starts one instruction's worth of wait states after the last MFMA - the compiler's own wait states did not
         // cover a VALU write into an operand register of an MFMA still queueing on the matrix pipe (measured there).
@@ -196,11 +195,47 @@ __device__ __forceinline__ bool tile_split(Src& src, LdsSplit& lds, f32x16 (&acc
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         asm volatile("" :: "v"(awh), "v"(awl));
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunk) stash(buf ^ 1);        // last read in chunk c - 1; every wave is past that barrier
+    };
+    const int nchunk = (K + SKC - 1) / SKC;
+    if (!DEEP) {
+        float r[SQ][4];
+        src.fetch_split(0, r);
+        stash(0, r);
         __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunk) src.fetch_split((c + 1) * SKC, r);
+            mfma_chunk(buf);
+            if (c + 1 < nchunk) stash(buf ^ 1, r);   // last read in chunk c - 1; every wave is past that barrier
+            __syncthreads();
+        }
+    } else {
+        // chunk c + 1 is in flight while chunk c + 2 is requested; sources return zeros past K, so an odd chunk count
+        // simply ends with one all-zero chunk (no branch in the middle of the loop body)
+        float ra[SQ][4], rb[SQ][4];
+        src.fetch_split(0, ra);
+        stash(0, ra);
+        src.fetch_split(SKC, rb);
+        __syncthreads();
+        for (int c = 0; c < nchunk; c += 2) {
+            src.fetch_split((c + 2) * SKC, ra);
+            mfma_chunk(0);
+            stash(1, rb);
+            __syncthreads();
+            src.fetch_split((c + 3) * SKC, rb);
+            mfma_chunk(1);
+            stash(0, ra);
+            __syncthreads();
+        }
     }
-    // an operand beyond the fp16 range became an infinite hi half: every output of its row / column is then inf or NaN
-    // (inf - inf from the lo.hi pass, or inf * 0).  Only outputs that will be stored count.
+}
+
+// An operand beyond the fp16 range became an infinite hi half: every output of its row / column is then inf or NaN
+// (inf - inf from the lo.hi pass, or inf * 0).  Only outputs that will be stored count.  Workgroup-uniform result.
+template <bool ROW4, class Src>
+__device__ __forceinline__ bool split_finite(const Src& src, const f32x16 (&acc)[7], bool row4_, int t, int wave) {
+    const bool row4 = ROW4 && row4_;
+    const int lane = t & 63, li = lane & 31, kg = lane >> 5;
     bool bad = false;
     auto scan = [&](const f32x16& c, int ti, int tj) {
         const bool colin = src.col_stored(32 * tj + li);
@@ -219,17 +254,103 @@ __device__ __forceinline__ bool tile_split(Src& src, LdsSplit& lds, f32x16 (&acc
     return !__syncthreads_or(bad);
 }
 
-// both paths behind one call: accumulators and the factor the epilogue has to apply to them
+// Two channel-major operands with caller-defined column offsets: element (channel k, tile column c) of side A is
+// A[cols.a_off(c) + k * ldA], of side B  B[cols.b_off(c) + k * ldB]; optionally x <- max(0, x * scale[k] + shift[k]) on
+// side B while staging.  `Cols` also says which tile rows / columns are stored.  Running pointers, advanced per chunk;
+// only a ragged last chunk takes the zero-filling fetch (a valid channel is read, then zeroed: no predicated loads).
+template <class Cols>
+struct CmSrc {
+    const float *A, *B;
+    int ldA, ldB, K, t;
+    const Cols& cols;
+    const float *scale, *shift;
+    const float* p[SQ];                // split items, or side-A slab elements of the fp32 path
+    const float* pq[CPT];              // side-B slab elements of the fp32 path
+
+    __device__ __forceinline__ CmSrc(const float* A_, int ldA_, const float* B_, int ldB_, int K_, const Cols& c, int t_,
+                                     const float* scale_ = nullptr, const float* shift_ = nullptr)
+        : A(A_), B(B_), ldA(ldA_), ldB(ldB_), K(K_), t(t_), cols(c), scale(scale_), shift(shift_) {}
+    __device__ __forceinline__ bool row_stored(int r) const { return cols.row_stored(r); }
+    __device__ __forceinline__ bool col_stored(int c) const { return cols.col_stored(c); }
+    __device__ __forceinline__ float affine(float x, int k) const { return fmaxf(fmaf(x, scale[k], shift[k]), 0.f); }
+
+    __device__ __forceinline__ void fetch_f32(int k0, float (&ra)[CPT], float (&rb)[CPT]) {
+        if (k0 == 0) {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                p[q] = A + cols.a_off(f32_col(t, q)) + (int64_t)f32_row(t, q) * ldA;
+                pq[q] = B + cols.b_off(f32_col(t, q)) + (int64_t)f32_row(t, q) * ldB;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int k = k0 + f32_row(t, q);
+            const bool kin = k0 + KC <= K || k < K;
+            ra[q] = kin ? *p[q] : 0.f;
+            float x = kin ? *pq[q] : 0.f;
+            if (scale && kin) x = affine(x, k);
+            rb[q] = x;
+            p[q] += (int64_t)KC * ldA;
+            pq[q] += (int64_t)KC * ldB;
+        }
+    }
+
+    __device__ __forceinline__ void fetch_split(int k0, float (&r)[SQ][4]) {
+        int ld[SQ];
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) ld[q] = item_side(t, q) ? ldB : ldA;
+        if (k0 == 0) {
+#pragma unroll
+            for (int q = 0; q < SQ; ++q) {
+                const int col = item_col(t, q);
+                p[q] = (item_side(t, q) ? B + cols.b_off(col) : A + cols.a_off(col)) + (int64_t)(4 * item_quad(t, q)) * ld[q];
+            }
+        }
+        if (k0 + SKC <= K) {
+#pragma unroll
+            for (int q = 0; q < SQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[q][e] = p[q][e * ld[q]];
+        } else {
+#pragma unroll
+            for (int q = 0; q < SQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + 4 * item_quad(t, q) + e, back = min(k, K - 1) - (k - e);
+                    const float v = p[q][back * ld[q]];
+                    r[q][e] = k < K ? v : 0.f;
+                }
+        }
+        if (scale) {
+#pragma unroll
+            for (int q = 0; q < SQ; ++q)
+                if (item_side(t, q)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + 4 * item_quad(t, q) + e;
+                        if (k < K) r[q][e] = affine(r[q][e], k);
+                    }
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) p[q] += SKC * ld[q];
+    }
+};
+
+// Both paths behind one call: accumulators and the factor the epilogue has to apply to them.  `s1` (may be null): a
+// second source whose channels continue the reduction.
 // ROW4 = false: the caller never has a fifth tile row (at most 128 output rows) - acc[5], acc[6] cost no registers
-template <bool SPLIT, bool ROW4, class Src>
-__device__ __forceinline__ float tile(Src& src, Lds& lds, f32x16 (&acc)[7], int K, bool row4, int t, int wave) {
+template <bool SPLIT, bool ROW4, bool DEEP = false, class Src>
+__device__ __forceinline__ float tile(Src& s0, Src* s1, Lds& lds, f32x16 (&acc)[7], bool row4, int t, int wave) {
     clear(acc);
     if (SPLIT) {
-        if (tile_split<ROW4>(src, lds.s, acc, K, row4, t, wave)) return UNSCALE;
+        split_accumulate<ROW4, DEEP>(s0, lds.s, acc, row4, t, wave);
+        if (s1) split_accumulate<ROW4, DEEP>(*s1, lds.s, acc, row4, t, wave);
+        if (split_finite<ROW4>(s0, acc, row4, t, wave)) return UNSCALE;
         clear(acc);
-        src.rewind();
     }
-    tile_f32<ROW4>(src, lds.f, acc, K, row4, t, wave);
+    tile_f32<ROW4>(s0, lds.f, acc, row4, t, wave);
+    if (s1) tile_f32<ROW4>(*s1, lds.f, acc, row4, t, wave);
     return 1.0f;
 }
 
