@@ -354,6 +354,9 @@ def cpu_baseline(ops, dev, pairs_B, pairs_P, seconds):
 
 
 def timed(fn, reps=5, warm=2):
+    """Mean duration of one call: one HIP event pair around `reps` back-to-back calls on the stream the kernels run on.
+    For a kernel of tens of microseconds the calls must not allocate (pass out=) and reps must be large enough for
+    the queue to stay ahead of the GPU - an event pair per call adds ~35 us of marker latency to each."""
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -372,12 +375,13 @@ def secondary_rooflines(ops, dev, wl, fine_ms):
     r = synth.roofline_inputs()
     d0, d1, ns = [torch.from_numpy(r[k]).to(dev) for k in ("d0", "d1", "ns")]
     N, D = d0.shape[2], d0.shape[1]
-    ms = timed(lambda: ops.cost(d0, d1))
+    S = ops.cost(d0, d1)
+    ms = timed(lambda: ops.cost(d0, d1, out=S), reps=200, warm=20)
     tf = 2.0 * D * N * N / (ms * 1e-3) / 1e12
     split_note = ("fp32 operands as fp16 hi + lo pairs, three exact-product passes of v_mfma_f32_32x32x16_f16 (fp32 accumulation; "
                   "closer to float64 than the fp32 fma chain, tools/cost_ab.py): `achieved` counts the 2*D*M*N algorithmic flops "
                   "against the fp32 matrix peak the reference arithmetic would be priced at; the fp16 pipe executes three times "
-                  "as many (f16_pipe_*).  PATS_COST_F32=1 = the fp32-MFMA path (0.186 ms / 3.04 ms on the same shapes)")
+                  "as many (f16_pipe_*).  PATS_COST_F32=1 = the fp32-MFMA path (profiles/r02_cost_ab.txt)")
     out.append({"kernel": "cost_mfma_kernel, config 5 (4096^2 x %d)" % D, "bound": "mfma", "achieved": tf,
                 "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS, "ms": ms,
                 "f16_pipe_tflops": 3.0 * tf, "f16_pipe_frac": 3.0 * tf / F16_PEAK_TFLOPS, "note": split_note,
@@ -396,7 +400,9 @@ def secondary_rooflines(ops, dev, wl, fine_ms):
                 "profile": "profiles/r02_config5_kernel_stats.md"})
     del S, d0, d1
     ch = wl.chunk
-    ms = timed(lambda: ops.cost(ch["f0"], ch["f1"]))
+    S2 = ops.cost(ch["f0"], ch["f1"])
+    ms = timed(lambda: ops.cost(ch["f0"], ch["f1"], out=S2), reps=8, warm=2)
+    del S2
     tf = 2.0 * 264 * 145 * 145 * ch["B"] / (ms * 1e-3) / 1e12
     by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * ch["B"]
     out.append({"kernel": "cost_mfma_kernel, fine level (%d x [264,145]^2)" % ch["B"], "bound": "hbm",

@@ -79,14 +79,18 @@ def sinkhorn_fallbacks(reset=True):
 # ------------------------------------------------------------------------------------------------
 # cost build
 # ------------------------------------------------------------------------------------------------
-def cost(mdesc0, mdesc1):
-    """0.1 * (einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5)   (first_layer.py:110-114)."""
+def cost(mdesc0, mdesc1, out=None):
+    """0.1 * (einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5)   (first_layer.py:110-114).
+    out: optional preallocated [b, n, m] float32 result (as torch's `out=`)."""
     d0, d1 = _dev(mdesc0, "mdesc0"), _dev(mdesc1, "mdesc1")
     b, D, n = d0.shape
     if d1.shape[0] != b or d1.shape[1] != D:
         raise RuntimeError("cost: descriptor shapes %s / %s do not match" % (tuple(d0.shape), tuple(d1.shape)))
     m = d1.shape[2]
-    out = torch.empty((b, n, m), dtype=torch.float32, device=d0.device)
+    if out is None:
+        out = torch.empty((b, n, m), dtype=torch.float32, device=d0.device)
+    elif tuple(out.shape) != (b, n, m) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != d0.device:
+        raise RuntimeError("cost: out must be a contiguous float32 [%d, %d, %d] tensor on %s" % (b, n, m, d0.device))
     _check(_L().pats_cost_f32(_ptr(d0), _ptr(d1), b, D, n, m, _ptr(out), _stream()), "cost")
     return out
 
