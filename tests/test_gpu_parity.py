@@ -981,6 +981,33 @@ def test_attentional_gnn_and_edge_shapes(ops, oracle):
         ops.attentional_propagation(cu(i["x"]), cu(i["source"][:, :100]), ops.PropagationParams(p))
 
 
+@pytest.mark.parametrize("C,b,n,m", [(8, 37, 3, 5), (24, 9, 70, 33), (72, 4, 161, 20), (136, 3, 65, 65)])
+def test_attentional_propagation_small_widths_against_oracle(ops, oracle, C, b, n, m):
+    """Single-chunk and ragged reductions (K = 8 .. 272, the two-pass reduction of the MLP's first product with a
+    zero-filled tail in each pass), column tiles that cover many problems, train and eval BatchNorm, residual."""
+    params = synth.gnn_params(seed=100 + C, C=C)
+    inp = synth.gnn_inputs(seed=200 + C, b=b, C=C, n=n, m=m)
+    P = ops.PropagationParams(params)
+    x, s = cu(inp["x"]), cu(inp["source"])
+    for train in (False, True):
+        y = ops.attentional_propagation(x, s, P, bn_train=train, residual=x).cpu().numpy()
+        want = oracle.attentional_propagation(inp["x"], inp["source"], params, bn_train=train, residual=inp["x"])
+        np.testing.assert_allclose(y, want, atol=1e-4, rtol=2e-4)
+
+
+def test_attentional_propagation_operands_beyond_the_fp16_range(ops, oracle):
+    """The 1x1 convolutions use the fp16-split contraction; an activation beyond +-1023 sends the workgroups that read it
+    through the fp32 redo, and the layer still matches the oracle."""
+    params = synth.gnn_params(seed=11, C=128)
+    inp = synth.gnn_inputs(seed=12, b=6, C=128, n=65)
+    inp["x"][2, 17, 40] = 3000.0
+    inp["source"][4, 90, 3] = -2500.0
+    y = ops.attentional_propagation(cu(inp["x"]), cu(inp["source"]), ops.PropagationParams(params)).cpu().numpy()
+    want = oracle.attentional_propagation(inp["x"], inp["source"], params)
+    assert np.isfinite(y).all()
+    np.testing.assert_allclose(y, want, atol=5e-3, rtol=5e-4)          # outputs reach 1e3 next to the spikes
+
+
 def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
     """pats_amd.dropin.install() on a module tree shaped like the reference's models/modules.py (stand-ins written with
     torch.nn here: the reference itself does not travel to the GPU box): after install() the SAME module instances run
