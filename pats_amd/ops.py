@@ -221,9 +221,18 @@ def argmax(Z):
 # ------------------------------------------------------------------------------------------------
 # patch-area expansion
 # ------------------------------------------------------------------------------------------------
+_POS_CACHE = {}
+
+
 def Compute_positions_and_ranges(height, width, device):
     """utils/utils.py:1527-1537.  The returned tensors carry the grid as `_pats_grid` so
-    Iterative_expand_matrix does not have to read them back from the device."""
+    Iterative_expand_matrix does not have to read them back from the device.  They depend on (height, width, device)
+    only and are built once (treat them as read-only): the per-call host-to-device copies of the first version were
+    stream-ordered pageable copies, i.e. the host waited for everything queued before them."""
+    key = (int(height), int(width), str(torch.device(device)))
+    hit = _POS_CACHE.get(key)
+    if hit is not None:
+        return hit
     k = torch.arange(height * width)
     positions = torch.stack([(k // width).float(), (k % width).float()], dim=1)
     max_shape = max(height, width)
@@ -233,6 +242,7 @@ def Compute_positions_and_ranges(height, width, device):
     positions, ranges = positions.to(device), ranges.to(device)
     positions._pats_grid = (int(height), int(width))
     ranges._pats_grid = (int(height), int(width))
+    _POS_CACHE[key] = (positions, ranges)
     return positions, ranges
 
 
