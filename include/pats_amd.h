@@ -55,7 +55,9 @@ int pats_sinkhorn_fallbacks(int64_t* count, int reset);
  * out[b,i,j] = 0.1f * ( (sum_d d0[b,d,i] * d1[b,d,j]) / sqrtf(D) )
  * replaces  scores = einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5 ; 0.1 * scores
  *           models/first_layer.py:110-111,114  second_layer.py:100-101,104  third_layer.py:156-158
- * d0 [batch,D,n], d1 [batch,D,m] (channel-major), out [batch,n,m].  fp32 MFMA, fp32 accumulate. */
+ * d0 [batch,D,n], d1 [batch,D,m] (channel-major), out [batch,n,m].  fp32 in, fp32 out; the contraction splits every
+ * operand into an fp16 hi + lo pair (exact products on the fp16 matrix pipe, fp32 accumulation - at least as close to
+ * float64 as an fp32 fma chain) and redoes a tile with the fp32 MFMA when an operand exceeds +-1023. */
 int pats_cost_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m, float* out,
                   pats_stream_t stream);
 
@@ -320,7 +322,8 @@ int pats_attention_f32(const float* query, const float* key, const float* value,
  * i.e. conv.weight[:, :, 0].t().contiguous().  BatchNorm: bn_train == 0 -> bn_a / bn_b are the folded running
  * statistics (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale); bn_train != 0 -> bn_a /
  * bn_b are gamma / beta and the batch statistics over (batch, n) are computed here with bn_eps (PATS.eval leaves the
- * third layer in train mode, models/pats.py:112-120).  fp32 MFMA GEMMs (the cat is never materialised), the
+ * third layer in train mode, models/pats.py:112-120).  The 1x1 convolutions use the contraction of pats_cost_f32 (the
+ * cat is never materialised), the
  * attention core is pats_attention_f32.  C % heads == 0, C % 8 == 0, m <= 1024. */
 typedef struct pats_propagation_weights {
     const float *wq_t, *bq;   /* attn.proj[0]: [C][C] transposed, [C] */
