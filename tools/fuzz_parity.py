@@ -29,10 +29,14 @@ def cu(x):
 
 
 def mass_close(got, want):
+    # 1e-4 absolute on transport mass.  The relative term only matters where masses exceed 1 (dustbin entries under a bias of
+    # 2 or 3 with large ns: log-plan entries of 7..9): two fp32 evaluations of ((Z + u) + v) - norm + log k + log k differ by
+    # up to ~4 ulp of such a Z (five roundings and the two duals), i.e. 4e-6 relative in exp(Z); seed 101000676 of the
+    # round-2 campaign needed 3.2e-6 on one corner entry of mass 3.7e3 (oracle 0.5e-6, HIP 1.5e-6 from float64)
     eg, ew = np.exp(got.astype(np.float64)), np.exp(want.astype(np.float64))
-    np.testing.assert_allclose(eg, ew, atol=MASS_TOL, rtol=3e-6)
-    np.testing.assert_allclose(eg.sum(-1), ew.sum(-1), atol=MASS_TOL, rtol=3e-6)
-    np.testing.assert_allclose(eg.sum(-2), ew.sum(-2), atol=MASS_TOL, rtol=3e-6)
+    np.testing.assert_allclose(eg, ew, atol=MASS_TOL, rtol=5e-6)
+    np.testing.assert_allclose(eg.sum(-1), ew.sum(-1), atol=MASS_TOL, rtol=5e-6)
+    np.testing.assert_allclose(eg.sum(-2), ew.sum(-2), atol=MASS_TOL, rtol=5e-6)
 
 
 def rand_shape(rng):
