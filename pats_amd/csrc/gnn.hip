@@ -15,7 +15,7 @@
 //     problems fill the tile instead of wasting 60 % of it;
 //   * the reduction dimension may come from TWO tensors (x | message): `cat` is never materialised;
 //   * input channels can carry an affine + ReLU applied while staging (BatchNorm in eval mode = its running
-//     statistics, in train mode = batch statistics from bn_stats_kernel: PATS.eval leaves the third layer in train
+//     statistics, in train mode = batch statistics from the bn_* kernels below: PATS.eval leaves the third layer in train
 //     mode, pats.py:112-120), and the epilogue adds the bias and an optional residual (desc + delta).
 // The attention core in the middle is pats_attention_f32 (attention.hip).
 #include "mfma_tile.hpp"
@@ -104,34 +104,56 @@ conv1x1_kernel(ConvArgs g) {
 
 // BatchNorm1d in train mode (modules.py:66 inside MLP; the third layer's GNN runs it on batch statistics because
 // PATS.eval() does not reach it, pats.py:112-120): per channel over (batch, n), biased variance, then
-// scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  One workgroup per channel, double accumulation.
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  Two passes, both in double and both in a fixed order
+// (the result does not depend on scheduling): bn_partial_kernel - grid (channel, BN_SPLITS), wave w of split s sums the
+// batches s * 4 + w, + 4 * BN_SPLITS, ... (a batch's row of one channel is n contiguous floats: one coalesced read per
+// wave) - then bn_finish_kernel adds the BN_SPLITS partials of a channel.  The first version walked the flattened
+// (batch, token) index with a 64-bit division per element from ONE workgroup per channel: 3.5 ms for the 1.7 GB of the
+// third level's hidden tensor, a third of the layer.
+constexpr int BN_SPLITS = 64;
+
 __global__ void __launch_bounds__(256)
-bn_stats_kernel(const float* __restrict__ h, int64_t batch, int C, int n, const float* __restrict__ gamma,
-                const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double s1[256], s2[256];
-    const int c = blockIdx.x, t = threadIdx.x;
+bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, double* __restrict__ part) {
+    __shared__ double s1[4], s2[4];
+    const int c = blockIdx.x, split = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a = 0.0, q = 0.0;
-    const int64_t total = batch * n;
-    for (int64_t e = t; e < total; e += 256) {
-        const int64_t b = e / n;
-        const float x = h[(b * C + c) * (int64_t)n + (e - b * n)];
-        a += x;
-        q += (double)x * x;
+    for (int64_t b = (int64_t)split * 4 + wave; b < batch; b += 4 * BN_SPLITS) {
+        const float* row = h + (b * C + c) * (int64_t)n;
+        for (int t = lane; t < n; t += 64) {
+            const double x = (double)row[t];
+            a += x;
+            q += x * x;
+        }
     }
-    s1[t] = a; s2[t] = q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {          // fixed butterfly order
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+    }
+    if (lane == 0) { s1[wave] = a; s2[wave] = q; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) { s1[t] += s1[t + o]; s2[t] += s2[t + o]; }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((int64_t)c * BN_SPLITS + split) * 2 + 0] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        part[((int64_t)c * BN_SPLITS + split) * 2 + 1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
     }
-    if (t == 0) {
-        const double mean = s1[0] / (double)total;
-        double var = s2[0] / (double)total - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float sc = gamma[c] / sqrtf((float)var + eps);
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
+}
+
+__global__ void __launch_bounds__(64)
+bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, q = 0.0;
+    for (int s_ = 0; s_ < BN_SPLITS; ++s_) {
+        a += part[((int64_t)c * BN_SPLITS + s_) * 2 + 0];
+        q += part[((int64_t)c * BN_SPLITS + s_) * 2 + 1];
     }
+    const double mean = a / (double)total;
+    double var = q / (double)total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float sc = gamma[c] / sqrtf((float)var + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
 }
 
 static int launch_conv(const ConvArgs& g, hipStream_t st) {
@@ -154,8 +176,9 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, int C, int n, int m) {
     if (batch < 0 || C <= 0 || n <= 0 || m <= 0) return 0;
     const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
-    // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each
-    return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float));
+    // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each; BN partial sums
+    return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float)) +
+           al256((size_t)2 * C * pats::BN_SPLITS * 2 * sizeof(double));
 }
 
 extern "C" int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
@@ -181,7 +204,8 @@ extern "C" int pats_attentional_propagation_f32(const float* x, const float* sou
     float* v = (float*)p; p += kb;
     float* hid = (float*)p; p += al256((size_t)batch * 2 * C * n * sizeof(float));
     float* bsc = (float*)p; p += al256((size_t)2 * C * sizeof(float));
-    float* bsh = (float*)p;
+    float* bsh = (float*)p; p += al256((size_t)2 * C * sizeof(float));
+    double* bpart = (double*)p;
     int rc;
     // projections (modules.py:101-102)
     if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, st))) return rc;
@@ -197,9 +221,10 @@ extern "C" int pats_attentional_propagation_f32(const float* x, const float* sou
     //                      train -> batch statistics with bn_a = gamma, bn_b = beta
     const float *sc = w->bn_a, *sh = w->bn_b;
     if (bn_train) {
-        hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)(2 * C)), dim3(256), 0, st, hid, batch, 2 * C, n, w->bn_a, w->bn_b,
-                           bn_eps, bsc, bsh);
-        if ((rc = check_launch("bn_stats_kernel"))) return rc;
+        hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)(2 * C), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart);
+        hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, bpart, batch * (int64_t)n, 2 * C,
+                           w->bn_a, w->bn_b, bn_eps, bsc, bsh);
+        if ((rc = check_launch("bn_stats kernels"))) return rc;
         sc = bsc; sh = bsh;
     }
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)

@@ -52,6 +52,12 @@ for C, b, n, tag in ((128, 25920, 65, "third level, one pair (25 920 x 65 tokens
         err = (ref - got).abs().max().item()
         t_hip = timeit(lambda: ops.attentional_propagation(x, s, P))
         t_ref = timeit(lambda: m(x, s))
+        # BatchNorm on batch statistics: the mode the third layer runs in under PATS.eval() (pats.py:112-120)
+        t_hip_tr = timeit(lambda: ops.attentional_propagation(x, s, P, bn_train=True))
+        m.train()
+        t_ref_tr = timeit(lambda: m(x, s))
+        m.eval()
     flops = b * n * (2.0 * C * C * 4 + 2.0 * 2 * C * 2 * C + 2.0 * 2 * C * C) + b * 4 * (2.0 * n * n * (C // 4)) * 2
     print(json.dumps({"shape": tag, "C": C, "hip_ms": t_hip, "stock_pytorch_ms": t_ref, "speedup": t_ref / t_hip,
-                      "hip_tflops": flops / t_hip / 1e9, "max_abs_diff_vs_stock": err}))
+                      "hip_tflops": flops / t_hip / 1e9, "max_abs_diff_vs_stock": err,
+                      "bn_train_hip_ms": t_hip_tr, "bn_train_stock_pytorch_ms": t_ref_tr, "bn_train_speedup": t_ref_tr / t_hip_tr}))
