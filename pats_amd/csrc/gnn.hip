@@ -76,7 +76,7 @@ conv1x1_kernel(ConvArgs g) {
     mt::CmSrc<ConvCols> s1(g.wt + (int64_t)g.K0 * M, M, g.x1, n, g.K1, c1, t, g.in_scale ? g.in_scale + g.K0 : nullptr,
                            g.in_shift ? g.in_shift + g.K0 : nullptr);
     mt::f32x16 acc[7];
-    const float unscale = mt::tile<SPLIT, ROW4, !ROW4>(s0, g.K1 > 0 ? &s1 : nullptr, lds, acc, row4, t, wave);
+    const float unscale = mt::tile<SPLIT, ROW4>(s0, g.K1 > 0 ? &s1 : nullptr, lds, acc, row4, t, wave);
 
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     auto store_tile = [&](const mt::f32x16& cacc, int ti, int tj) {

@@ -136,8 +136,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 }
 
 // fp16-split contraction of one tile over the channels of one source, ADDED to acc
-// DEEP: two register sets, the fetch runs TWO chunks ahead (needs 20 more registers: callers without a fifth tile row)
-template <bool ROW4, bool DEEP, class Src>
+template <bool ROW4, class Src>
 __device__ __forceinline__ void split_accumulate(Src& src, LdsSplit& lds, f32x16 (&acc)[7], bool row4_, int t, int wave) {
     const bool row4 = ROW4 && row4_;
     const int K = src.K;
@@ -197,36 +196,18 @@ __device__ __forceinline__ void split_accumulate(Src& src, LdsSplit& lds, f32x16
         __builtin_amdgcn_sched_barrier(0);
     };
     const int nchunk = (K + SKC - 1) / SKC;
-    if (!DEEP) {
-        float r[SQ][4];
-        src.fetch_split(0, r);
-        stash(0, r);
+    // (a second register set with the fetch running two chunks ahead was measured 2 % slower on the GNN products and
+    // does not fit the register budget of the cost build)
+    float r[SQ][4];
+    src.fetch_split(0, r);
+    stash(0, r);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) src.fetch_split((c + 1) * SKC, r);
+        mfma_chunk(buf);
+        if (c + 1 < nchunk) stash(buf ^ 1, r);       // last read in chunk c - 1; every wave is past that barrier
         __syncthreads();
-        for (int c = 0; c < nchunk; ++c) {
-            const int buf = c & 1;
-            if (c + 1 < nchunk) src.fetch_split((c + 1) * SKC, r);
-            mfma_chunk(buf);
-            if (c + 1 < nchunk) stash(buf ^ 1, r);   // last read in chunk c - 1; every wave is past that barrier
-            __syncthreads();
-        }
-    } else {
-        // chunk c + 1 is in flight while chunk c + 2 is requested; sources return zeros past K, so an odd chunk count
-        // simply ends with one all-zero chunk (no branch in the middle of the loop body)
-        float ra[SQ][4], rb[SQ][4];
-        src.fetch_split(0, ra);
-        stash(0, ra);
-        src.fetch_split(SKC, rb);
-        __syncthreads();
-        for (int c = 0; c < nchunk; c += 2) {
-            src.fetch_split((c + 2) * SKC, ra);
-            mfma_chunk(0);
-            stash(1, rb);
-            __syncthreads();
-            src.fetch_split((c + 3) * SKC, rb);
-            mfma_chunk(1);
-            stash(0, ra);
-            __syncthreads();
-        }
     }
 }
 
@@ -340,12 +321,12 @@ struct CmSrc {
 // Both paths behind one call: accumulators and the factor the epilogue has to apply to them.  `s1` (may be null): a
 // second source whose channels continue the reduction.
 // ROW4 = false: the caller never has a fifth tile row (at most 128 output rows) - acc[5], acc[6] cost no registers
-template <bool SPLIT, bool ROW4, bool DEEP = false, class Src>
+template <bool SPLIT, bool ROW4, class Src>
 __device__ __forceinline__ float tile(Src& s0, Src* s1, Lds& lds, f32x16 (&acc)[7], bool row4, int t, int wave) {
     clear(acc);
     if (SPLIT) {
-        split_accumulate<ROW4, DEEP>(s0, lds.s, acc, row4, t, wave);
-        if (s1) split_accumulate<ROW4, DEEP>(*s1, lds.s, acc, row4, t, wave);
+        split_accumulate<ROW4>(s0, lds.s, acc, row4, t, wave);
+        if (s1) split_accumulate<ROW4>(*s1, lds.s, acc, row4, t, wave);
         if (split_finite<ROW4>(s0, acc, row4, t, wave)) return UNSCALE;
         clear(acc);
     }
