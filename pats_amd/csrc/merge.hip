@@ -306,29 +306,29 @@ struct ResultArgs {
 
 __global__ void __launch_bounds__(256)
 get_result_kernel(ResultArgs g, const int32_t* __restrict__ row_cell, Scan sc1) {
-    const int n0 = g.h0 * g.w0, n1 = g.h1 * g.w1;
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= g.rows1 * n1 || g.ifn1[f]) return;
-    const int64_t k = f / n1;
+    // a workgroup stays inside one level-1 row (blocks per row = ceil(n1 / 256)): the row index and everything that
+    // hangs on it is workgroup-uniform, and no thread does a 64-bit division
+    const unsigned n0 = (unsigned)(g.h0 * g.w0), n1 = (unsigned)(g.h1 * g.w1), bpr = (n1 + 255u) / 256u;
+    const unsigned krow = blockIdx.x / bpr, j = (blockIdx.x - krow * bpr) * 256u + threadIdx.x;
+    const int64_t k = krow, f = k * n1 + j;
+    if (j >= n1 || g.ifn1[f]) return;
     if (k >= *g.rows0_dev) return;                  // more rows than surviving cells: ignored
     const int64_t M = sc1.at(f);
     if (M >= g.capacity) return;
-    const int j = (int)(f - k * n1);
     const int64_t e = row_cell[k];
-    const int64_t bt = e / n0;
-    const int i = (int)(e - bt * n0);
+    const unsigned bt = (unsigned)e / n0, i = (unsigned)e - bt * n0;
     const bool c0 = g.ch0[bt] != 0, c1 = g.ch1[k] != 0;
     const float z0 = (float)g.s0, z1 = (float)g.s1;
     const float sc1l = g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride + 1 : k * 2 + 1];
     const float sc1r = g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride : k * 2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-        const float pos0 = (float)((d == 0 ? i / g.w0 : i % g.w0) * g.s0);
+        const float pos0 = (float)((d == 0 ? i / (unsigned)g.w0 : i % (unsigned)g.w0) * (unsigned)g.s0);
         float dl0 = pos0 + 0.5f * z0;
         dl0 = dl0 - (1.5f * g.sc0[e * 2 + 1]) * z0;
         const float dr0 = (g.ap0[e * 2 + d] - 1.5f * g.sc0[e * 2]) * z0;
         const float l0 = 0.0f + (c0 ? dl0 : dr0), r0 = 0.0f + (c0 ? dr0 : dl0);
-        const float pos1 = (float)((d == 0 ? j / g.w1 : j % g.w1) * g.s1);
+        const float pos1 = (float)((d == 0 ? j / (unsigned)g.w1 : j % (unsigned)g.w1) * (unsigned)g.s1);
         float dl1 = pos1 + 0.5f * z1;
         dl1 = dl1 * sc1l;
         const float dr1 = (g.ap1[f * 2 + d] * z1) * sc1r;
@@ -459,6 +459,8 @@ extern "C" int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0
     ResultArgs g{if_nomatching1, average_point0, average_point1, scale0, scale1, scale1_cell_stride,
                  patch_size0[0], patch_size0[1], patch_size0[2], patch_size1[0], patch_size1[1], patch_size1[2],
                  left_choice0, left_choice1, rows0_dev, rows1, capacity, matches_l, matches_r};
-    hipLaunchKernelGGL(get_result_kernel, dim3(blocks256(rows1 * n1)), dim3(256), 0, st, g, row_cell, s1);
+    const int64_t blocks = rows1 * (((int64_t)n1 + 255) / 256);
+    PATS_REQUIRE(blocks < (1ll << 31), "get_result: grid too large (split the batch)");
+    hipLaunchKernelGGL(get_result_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, row_cell, s1);
     return check_launch("get_result_kernel");
 }
