@@ -37,6 +37,7 @@ struct ConvArgs {
     const float* bias;         // [M] or null
     const float* residual;     // [batch, M, n] or null
     float* y;                  // [batch, M, n]
+    int tile_rows;             // output rows per workgroup: 160, or 128 when M is a multiple of 128 (no fifth tile row)
 };
 
 // column addressing for mfma_tile.hpp's CmSrc: A = transposed weights at output rows i0.. (clamped), B = activations at
@@ -63,7 +64,7 @@ conv1x1_kernel(ConvArgs g) {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int64_t tiles_j = (g.cols + mt::CT - 1) / mt::CT;
-    const int i0 = (int)(blockIdx.x / tiles_j) * mt::CT;
+    const int i0 = (int)(blockIdx.x / tiles_j) * g.tile_rows;
     const int64_t j0 = (int64_t)(blockIdx.x % tiles_j) * mt::CT;
     const int n = g.n, M = g.M;
     // output-row tiles that exist: rows i0 + 32 w .. for wave w, and the fifth tile row (i0 + 128 ..) shared by all
@@ -156,13 +157,18 @@ bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const fl
     shift[c] = beta[c] - (float)mean * sc;
 }
 
-static int launch_conv(const ConvArgs& g, hipStream_t st) {
-    const int64_t tiles = (int64_t)((g.M + mt::CT - 1) / mt::CT) * ((g.cols + mt::CT - 1) / mt::CT);
-    PATS_REQUIRE(tiles < (1ll << 31) && g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+static int launch_conv(const ConvArgs& g0, hipStream_t st) {
+    ConvArgs g = g0;
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
+    // 128-row workgroup tiles when they divide M (the 128- and 256-row products of the third level): four full tile
+    // rows per workgroup and the kernel without the fifth one - 32 registers less, no spill, no 96-row remainder tile
+    const bool rows128 = !fp32_only && (g.M <= 128 || g.M % 128 == 0);
+    g.tile_rows = rows128 ? 128 : mt::CT;
+    const int64_t tiles = (int64_t)((g.M + g.tile_rows - 1) / g.tile_rows) * ((g.cols + mt::CT - 1) / mt::CT);
+    PATS_REQUIRE(tiles < (1ll << 31) && g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
     const dim3 grid((unsigned)tiles), block(256);
     if (fp32_only) hipLaunchKernelGGL((conv1x1_kernel<false, true>), grid, block, 0, st, g);
-    else if (g.M <= 128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), grid, block, 0, st, g);      // no fifth tile row: 32 registers less
+    else if (rows128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((conv1x1_kernel<true, true>), grid, block, 0, st, g);
     return check_launch("conv1x1_kernel");
 }
