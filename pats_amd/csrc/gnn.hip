@@ -38,6 +38,8 @@ struct ConvArgs {
     const float* residual;     // [batch, M, n] or null
     float* y;                  // [batch, M, n]
     int tile_rows;             // output rows per workgroup: 160, or 128 when M is a multiple of 128 (no fifth tile row)
+    int* redo;                 // conv_lean_kernel: set to 1 by a workgroup whose outputs came out non-finite;
+                               // conv1x1_kernel: if non-null, the whole launch is a no-op unless *redo != 0
 };
 
 // column addressing for mfma_tile.hpp's CmSrc: A = transposed weights at output rows i0.. (clamped), B = activations at
@@ -61,6 +63,7 @@ template <bool SPLIT, bool ROW4>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_kernel(ConvArgs g) {
     __shared__ mt::Lds lds;
+    if (g.redo && *g.redo == 0) return;              // the second, normally empty, launch behind conv_lean_kernel
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int64_t tiles_j = (g.cols + mt::CT - 1) / mt::CT;
@@ -101,6 +104,182 @@ conv1x1_kernel(ConvArgs g) {
         store_tile(acc[5], 4, wave);
         if (wave == 0) store_tile(acc[6], 4, 4);
     }
+}
+
+// The same product for the shapes the GNN actually has - many short problems, 128..528 channels - as a LEAN tile: a
+// 256-thread workgroup owns 128 output rows x 64 flattened columns, wave w the 32 rows 32 w.. of both 32-column tiles:
+// 32 accumulator registers instead of 80-112, ~100 registers in all, so FOUR workgroups (16 waves) share a CU where
+// conv1x1_kernel fits two.  Counters and an occupancy sweep on conv1x1_kernel (one workgroup per CU: 1.5x slower than
+// two) say these products wait on their operand stream, not on the matrix pipe; more waves in flight is what helps.
+// fp16-split contraction as mfma_tile.hpp (same split, same fragment layout in LDS, same MFMA order), chunks of 16
+// channels, three 4-channel items per thread (two of weights, one of activations), double-buffered LDS, one barrier
+// per chunk, two reduction passes for the MLP's (x | message) product.  No fp32 path in here: a workgroup that finds a
+// non-finite value among its outputs raises *redo, and the launch of conv1x1_kernel queued right behind this one (a
+// no-op otherwise) recomputes the whole product with its own in-kernel fp32 redo.
+namespace {
+constexpr int LR = 128;
+template <int NT>
+struct __attribute__((aligned(16))) LeanLds {
+    uint2 a[2][2][4][LR];            // [buffer][hi | lo][channel / 4][output row]
+    uint2 b[2][2][4][32 * NT];       // [buffer][hi | lo][channel / 4][column]
+};
+}  // namespace
+
+// NT = 32-column tiles per wave (2 or 4): the workgroup tile is 128 rows x 32 NT columns
+template <int NT>
+__global__ void __launch_bounds__(256, NT == 2 ? 4 : 3)
+conv_lean_kernel(ConvArgs g) {
+    constexpr int LC = 32 * NT, NB = NT / 2;         // columns per workgroup, activation items per thread
+    __shared__ LeanLds<NT> lds;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, kg = lane >> 5;
+    // (an XCD-aware tile order - each XCD a contiguous run of column tiles, so that the two halves of a 128-byte line
+    // shared by neighbouring tiles meet in one L2 - was measured: no difference)
+    const int64_t tiles_j = (g.cols + LC - 1) / LC;
+    const int i0 = (int)(blockIdx.x / tiles_j) * LR;
+    const int64_t j0 = (int64_t)(blockIdx.x % tiles_j) * LC;
+    const int n = g.n, M = g.M;
+
+    // staging: items 0, 1 = weights (channel quad id / 128, output row id % 128, id = t + 256 q), items 2.. = activations
+    // (id = t + 256 q: channel quad id / LC, column id % LC): running pointers, advanced by 16 channels per chunk
+    const int aq0 = t / LR, ar = t % LR, aq1 = aq0 + 2;
+    const int arow = min(i0 + ar, M - 1);
+    int bq[NB], bc[NB];
+    unsigned bsq[NB], tkq[NB];                       // (batch, token) of the item's column: 32-bit, once
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int id = t + 256 * q;
+        bq[q] = id / LC;
+        bc[q] = id % LC;
+        const unsigned cgs = (unsigned)min(j0 + bc[q], g.cols - 1);
+        bsq[q] = cgs / (unsigned)n;
+        tkq[q] = cgs - bsq[q] * (unsigned)n;
+    }
+    const float *pa0, *pa1, *pb[NB];
+    float r[2 + NB][4];
+    mt::f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+
+    auto fraga = [&](int buf, int hl, int idx) {                  // planes [quad][row]: quads 2 kg, 2 kg + 1
+        const uint2 e0 = lds.a[buf][hl][2 * kg][idx], e1 = lds.a[buf][hl][2 * kg + 1][idx];
+        return __builtin_bit_cast(mt::h8c, mt::u4c{e0.x, e0.y, e1.x, e1.y});
+    };
+    auto fragb = [&](int buf, int hl, int idx) {
+        const uint2 e0 = lds.b[buf][hl][2 * kg][idx], e1 = lds.b[buf][hl][2 * kg + 1][idx];
+        return __builtin_bit_cast(mt::h8c, mt::u4c{e0.x, e0.y, e1.x, e1.y});
+    };
+
+    // one reduction pass over K channels: weights rows k_w0.., activations x (K channels per batch entry)
+    auto pass = [&](int k_w0, const float* x, int K, const float* scale, const float* shift) {
+        pa0 = g.wt + (int64_t)(k_w0 + 4 * aq0) * M + arow;
+        pa1 = g.wt + (int64_t)(k_w0 + 4 * aq1) * M + arow;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) pb[q] = x + ((int64_t)bsq[q] * K + 4 * bq[q]) * n + tkq[q];
+        auto fetch = [&](int k0) {
+            if (k0 + 16 <= K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[0][e] = pa0[e * M];
+                    r[1][e] = pa1[e * M];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) r[2 + q][e] = pb[q][e * n];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {          // ragged last chunk: read a valid channel, then zero
+                    const int ka0 = k0 + 4 * aq0 + e, ka1 = k0 + 4 * aq1 + e;
+                    const float v0 = pa0[(min(ka0, K - 1) - (ka0 - e)) * M], v1 = pa1[(min(ka1, K - 1) - (ka1 - e)) * M];
+                    r[0][e] = ka0 < K ? v0 : 0.f;
+                    r[1][e] = ka1 < K ? v1 : 0.f;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        const int kb = k0 + 4 * bq[q] + e;
+                        const float v2 = pb[q][(min(kb, K - 1) - (kb - e)) * n];
+                        r[2 + q][e] = kb < K ? v2 : 0.f;
+                    }
+                }
+            }
+            if (scale) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kb = k0 + 4 * bq[q] + e;
+                        if (kb < K) r[2 + q][e] = fmaxf(fmaf(r[2 + q][e], scale[kb], shift[kb]), 0.f);
+                    }
+            }
+            pa0 += 16 * M; pa1 += 16 * M;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) pb[q] += 16 * n;
+        };
+        auto stash = [&](int buf) {
+            uint2 hi, lo;
+            mt::split2(r[0][0], r[0][1], hi.x, lo.x); mt::split2(r[0][2], r[0][3], hi.y, lo.y);
+            lds.a[buf][0][aq0][ar] = hi; lds.a[buf][1][aq0][ar] = lo;
+            mt::split2(r[1][0], r[1][1], hi.x, lo.x); mt::split2(r[1][2], r[1][3], hi.y, lo.y);
+            lds.a[buf][0][aq1][ar] = hi; lds.a[buf][1][aq1][ar] = lo;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                mt::split2(r[2 + q][0], r[2 + q][1], hi.x, lo.x); mt::split2(r[2 + q][2], r[2 + q][3], hi.y, lo.y);
+                lds.b[buf][0][bq[q]][bc[q]] = hi; lds.b[buf][1][bq[q]][bc[q]] = lo;
+            }
+        };
+        const int nchunk = (K + 15) / 16;
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunk) fetch((c + 1) * 16);
+            // phases kept apart as in mfma_tile.hpp: fragments, the MFMAs (pass-major: consecutive ones never depend on
+            // each other), wait states, then the split of the next chunk
+            __builtin_amdgcn_sched_barrier(0);
+            const mt::h8c ah = fraga(buf, 0, 32 * wave + li), al = fraga(buf, 1, 32 * wave + li);
+            mt::h8c bh[NT], bl[NT];
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) { bh[tj] = fragb(buf, 0, 32 * tj + li); bl[tj] = fragb(buf, 1, 32 * tj + li); }
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[tj], acc[tj], 0, 0, 0);
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[tj], acc[tj], 0, 0, 0);
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[tj], acc[tj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            asm volatile("" :: "v"(ah), "v"(al));
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) asm volatile("" :: "v"(bh[tj]), "v"(bl[tj]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunk) stash(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    pass(0, g.x0, g.K0, g.in_scale, g.in_shift);
+    if (g.K1 > 0) pass(g.K0, g.x1, g.K1, g.in_scale ? g.in_scale + g.K0 : nullptr, g.in_shift ? g.in_shift + g.K0 : nullptr);
+
+    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    bool bad = false;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+        if (j0 + 32 * tj + li >= g.cols) continue;
+        const unsigned cg = (unsigned)(j0 + 32 * tj + li), b = cg / (unsigned)n, tk = cg - b * (unsigned)n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (row < M) {
+                const int64_t o = ((int64_t)b * M + row) * n + tk;
+                float v = acc[tj][e] * mt::UNSCALE;
+                bad |= !(fabsf(v) <= 3.0e38f);
+                if (g.bias) v += g.bias[row];
+                if (g.residual) v = g.residual[o] + v;
+                g.y[o] = v;
+            }
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(g.redo, 1);
 }
 
 // BatchNorm1d in train mode (modules.py:66 inside MLP; the third layer's GNN runs it on batch statistics because
@@ -157,15 +336,30 @@ bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const fl
     shift[c] = beta[c] - (float)mean * sc;
 }
 
-static int launch_conv(const ConvArgs& g0, hipStream_t st) {
+// `redo`: one int of workspace, zero on entry (conv_lean_kernel raises it; see there).  null -> conv1x1_kernel only.
+static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
     ConvArgs g = g0;
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
+    static const bool no_lean = [] { const char* e = getenv("PATS_CONV_LEAN"); return e && atoi(e) == 0; }();    // A/B switch
+    PATS_REQUIRE(g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+    const bool lean = redo && !fp32_only && !no_lean && !(g.residual && g.residual == g.y);
+    if (lean) {
+        static const int nt = getenv("PATS_CONV_NT") ? atoi(getenv("PATS_CONV_NT")) : 2;       // A/B switch: 2 or 4 column tiles
+        const int lc = 32 * (nt == 4 ? 4 : 2);
+        const int64_t lt = (int64_t)((g.M + LR - 1) / LR) * ((g.cols + lc - 1) / lc);
+        PATS_REQUIRE(lt < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+        g.redo = redo;
+        if (nt == 4) hipLaunchKernelGGL(conv_lean_kernel<4>, dim3((unsigned)lt), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(conv_lean_kernel<2>, dim3((unsigned)lt), dim3(256), 0, st, g);
+    } else {
+        g.redo = nullptr;
+    }
     // 128-row workgroup tiles when they divide M (the 128- and 256-row products of the third level): four full tile
     // rows per workgroup and the kernel without the fifth one - 32 registers less, no spill, no 96-row remainder tile
     const bool rows128 = !fp32_only && (g.M <= 128 || g.M % 128 == 0);
     g.tile_rows = rows128 ? 128 : mt::CT;
     const int64_t tiles = (int64_t)((g.M + g.tile_rows - 1) / g.tile_rows) * ((g.cols + mt::CT - 1) / mt::CT);
-    PATS_REQUIRE(tiles < (1ll << 31) && g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+    PATS_REQUIRE(tiles < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
     const dim3 grid((unsigned)tiles), block(256);
     if (fp32_only) hipLaunchKernelGGL((conv1x1_kernel<false, true>), grid, block, 0, st, g);
     else if (rows128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), grid, block, 0, st, g);
@@ -184,7 +378,7 @@ extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, in
     const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
     // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each; BN partial sums
     return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float)) +
-           al256((size_t)2 * C * pats::BN_SPLITS * 2 * sizeof(double));
+           al256((size_t)2 * C * pats::BN_SPLITS * 2 * sizeof(double)) + 256 /* six redo flags */;
 }
 
 extern "C" int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
@@ -211,18 +405,20 @@ extern "C" int pats_attentional_propagation_f32(const float* x, const float* sou
     float* hid = (float*)p; p += al256((size_t)batch * 2 * C * n * sizeof(float));
     float* bsc = (float*)p; p += al256((size_t)2 * C * sizeof(float));
     float* bsh = (float*)p; p += al256((size_t)2 * C * sizeof(float));
-    double* bpart = (double*)p;
+    double* bpart = (double*)p; p += al256((size_t)2 * C * BN_SPLITS * 2 * sizeof(double));
+    int* redo = (int*)p;
+    if (hipMemsetAsync(redo, 0, 6 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
     int rc;
     // projections (modules.py:101-102)
-    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, st))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, st))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, redo + 0, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st))) return rc;
     // attention core (:103): the [b, C, n] projections ARE the [b, dim, heads, n] views
     if ((rc = pats_attention_f32(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream))) return rc;
     // merge (:104)
-    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st))) return rc;
     // mlp[0] on cat([x, message]) without the cat (:116, MLP :64)
-    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, redo + 4, st))) return rc;
     // mlp[1] BatchNorm1d: eval -> the caller's folded running statistics (bn_a = scale, bn_b = shift);
     //                      train -> batch statistics with bn_a = gamma, bn_b = beta
     const float *sc = w->bn_a, *sh = w->bn_b;
@@ -234,5 +430,5 @@ extern "C" int pats_attentional_propagation_f32(const float* x, const float* sou
         sc = bsc; sh = bsh;
     }
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
-    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, st);
+    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st);
 }
