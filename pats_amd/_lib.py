@@ -100,6 +100,14 @@ def lib():
                 "pats_amd: %s is missing - the HIP extension was not built (run "
                 "`python -m pats_amd.build` / __graft_entry__.build()). There is no CPU fallback."
                 % LIB_PATH)
+        # PyTorch ships its own libamdhip64; if this library were loaded first it would bring in /opt/rocm's copy, torch
+        # would then load its own beside it, and the kernels launched here would talk to a runtime that has no
+        # device context ("no ROCm-capable device is detected" - seen when build() and smoke() ran in one process).
+        # Loading torch's runtime first makes both resolve to the same one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:      # a C-ABI-only consumer without torch: nothing to clash with
+            pass
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)     # AttributeError if the library lacks a declared symbol
