@@ -89,11 +89,19 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     const int rowi = BS * I + (rown ? J : 0), colj = BS * J + (cown ? I : 0);
 
     // ---- the block, the dustbin entries -----------------------------------------------------------
+    // a block row is 36 contiguous bytes: 16 + 16 + 4 byte accesses (only 4-byte aligned).  With nine 4-byte accesses
+    // per row every instruction of a wave touched 64 separate 4-byte pieces at a 36-byte stride: in isolation the
+    // 84 KB of a problem then read at a third and wrote at half the rate (tools/store_patterns.hip, patterns g / g4)
+    typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
     float kb[BS][BS];
 #pragma unroll
-    for (int r = 0; r < BS; ++r)
-#pragma unroll
-        for (int c = 0; c < BS; ++c) kb[r][c] = Zp[(BS * I + r) * N_ + BS * J + c];
+    for (int r = 0; r < BS; ++r) {
+        const float* row = Zp + (BS * I + r) * N_ + BS * J;
+        const f4a x0 = *reinterpret_cast<const f4a*>(row), x1 = *reinterpret_cast<const f4a*>(row + 4);
+        kb[r][0] = x0.x; kb[r][1] = x0.y; kb[r][2] = x0.z; kb[r][3] = x0.w;
+        kb[r][4] = x1.x; kb[r][5] = x1.y; kb[r][6] = x1.z; kb[r][7] = x1.w;
+        kb[r][8] = row[8];
+    }
     const float zdc = rown ? Zp[rowi * N_ + NB] : -INFINITY;        // Z[9I+J][144]
     const float zdr = cown ? Zp[NB * N_ + colj] : -INFINITY;        // Z[144][9J+I]
     const float zcorner = uni(Zp[NB * N_ + NB]);
@@ -273,14 +281,20 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < BS; ++c) cm[c] = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < BS; ++r)
+    for (int r = 0; r < BS; ++r) {
+        const int e0 = (BS * I + r) * N_ + BS * J;
+        const f4a x0 = *reinterpret_cast<const f4a*>(Zp + e0), x1 = *reinterpret_cast<const f4a*>(Zp + e0 + 4);
+        const float zin[BS] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, Zp[e0 + 8]};
+        float o[BS];
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
-            const int e = (BS * I + r) * N_ + BS * J + c;
-            const float o = ((Zp[e] + ul[r]) + vl[c]) - norm;
-            Op[e] = o;
-            cm[c] = fmaxf(cm[c], o);
+            o[c] = ((zin[c] + ul[r]) + vl[c]) - norm;
+            cm[c] = fmaxf(cm[c], o[c]);
         }
+        *reinterpret_cast<f4a*>(Op + e0) = f4a{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f4a*>(Op + e0 + 4) = f4a{o[4], o[5], o[6], o[7]};
+        Op[e0 + 8] = o[8];
+    }
     if (rown) {
         float z = ((zdc + (logf(a) - r_own)) + v_d) - norm;
         if (bias_k > 0.f) z += lb;

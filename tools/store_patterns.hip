@@ -64,6 +64,26 @@ __global__ void __launch_bounds__(256) pat_g(float* out, const float* in, int mo
         }
     if (mode == 1 && acc == 12345.f) Op[0] = acc;
 }
+__global__ void __launch_bounds__(256) pat_g4(float* out, const float* in, int mode) {   // the block layout with 16 + 16 + 4 byte accesses per block row
+    typedef float v4 __attribute__((ext_vector_type(4), aligned(4)));
+    const int t = threadIdx.x, J = t & 15, I = t >> 4;
+    float* Op = out + (long)blockIdx.x * 145 * 145;
+    const float* Ip = in + (long)blockIdx.x * 145 * 145;
+    float acc = 0.f;
+    for (int r = 0; r < 9; ++r) {
+        const int e = (9 * I + r) * 145 + 9 * J;
+        if (mode & 1) {
+            const v4 a = *reinterpret_cast<const v4*>(Ip + e), b = *reinterpret_cast<const v4*>(Ip + e + 4);
+            acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + Ip[e + 8];
+        }
+        if (mode & 2) {
+            *reinterpret_cast<v4*>(Op + e) = v4{acc, 1.f, 2.f, 3.f};
+            *reinterpret_cast<v4*>(Op + e + 4) = v4{acc, 1.f, 2.f, 3.f};
+            Op[e + 8] = acc;
+        }
+    }
+    if (mode == 1 && acc == 12345.f) Op[0] = acc;
+}
 __global__ void __launch_bounds__(256) pat_h(float* out, const float* in, int mode) {    // the same bytes, linear per workgroup
     float* Op = out + (long)blockIdx.x * 145 * 145;
     const float* Ip = in + (long)blockIdx.x * 145 * 145;
@@ -103,6 +123,9 @@ int main() {
         run2("g1: blk145 block layout, loads only", [&] { hipLaunchKernelGGL(pat_g, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 1); });
         run2("g2: blk145 block layout, stores only", [&] { hipLaunchKernelGGL(pat_g, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 2); });
         run2("g3: blk145 block layout, both", [&] { hipLaunchKernelGGL(pat_g, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 3); });
+        run2("g4-1: block layout, 16+16+4 B, loads only", [&] { hipLaunchKernelGGL(pat_g4, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 1); });
+        run2("g4-2: block layout, 16+16+4 B, stores only", [&] { hipLaunchKernelGGL(pat_g4, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 2); });
+        run2("g4-3: block layout, 16+16+4 B, both", [&] { hipLaunchKernelGGL(pat_g4, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 3); });
         run2("h1: linear per workgroup, loads only", [&] { hipLaunchKernelGGL(pat_h, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 1); });
         run2("h2: linear per workgroup, stores only", [&] { hipLaunchKernelGGL(pat_h, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 2); });
         run2("h3: linear per workgroup, both", [&] { hipLaunchKernelGGL(pat_h, dim3((unsigned)B), dim3(256), 0, 0, zo, zi, 3); });
