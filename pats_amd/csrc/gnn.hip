@@ -108,7 +108,7 @@ conv1x1_kernel(ConvArgs g) {
 
 // The same product for the shapes the GNN actually has - many short problems, 128..528 channels - as a LEAN tile: a
 // 256-thread workgroup owns 128 output rows x 64 flattened columns, wave w the 32 rows 32 w.. of both 32-column tiles:
-// 32 accumulator registers instead of 80-112, ~100 registers in all, so FOUR workgroups (16 waves) share a CU where
+// 32 accumulator registers instead of 80-112, 128 registers in all, so FOUR workgroups (16 waves) share a CU where
 // conv1x1_kernel fits two.  Counters and an occupancy sweep on conv1x1_kernel (one workgroup per CU: 1.5x slower than
 // two) say these products wait on their operand stream, not on the matrix pipe; more waves in flight is what helps.
 // fp16-split contraction as mfma_tile.hpp (same split, same fragment layout in LDS, same MFMA order), chunks of 16
