@@ -65,6 +65,9 @@ def parse():
                     help="run Compute_imgs once per coarse chunk like the reference's loop (one host read per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline measurements")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the coarse stage and the fine / third stage of consecutive batches one after the other "
+                         "(default: on two HIP streams, the coarse stage of batch i + 1 beside the rest of batch i)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     return ap.parse_args()
 
@@ -220,6 +223,45 @@ def fine_and_third(ops, wl, co, ev):
 def step(ops, wl, ev):
     co = coarse_stage(ops, wl)
     return co, fine_and_third(ops, wl, co, ev)
+
+
+def run_steps(ops, wl, ev, n, streams):
+    """n complete steps (batches).  streams = None: one after the other.  streams = (sA, sB): the steps of consecutive
+    batches are independent (pairs are), so the coarse stage of batch i + 1 (one-CU Sinkhorn kernels on 48 of 256 CUs,
+    HBM-bound crop gathers) runs on sA beside the fine + third stage of batch i (VALU-bound) on sB.  Every batch still
+    goes through every kernel; nothing leaves the function unfinished (the caller's stream waits for both)."""
+    if streams is None or n <= 0:
+        co = out = None
+        for _ in range(n):
+            co, out = step(ops, wl, ev)
+        return co, out
+    sA, sB = streams
+    cur = torch.cuda.current_stream()
+    sA.wait_stream(cur)
+    sB.wait_stream(cur)
+
+    def coarse():
+        with torch.cuda.stream(sA):
+            c = coarse_stage(ops, wl)
+            e = torch.cuda.Event()
+            e.record(sA)
+        return c, e
+    co, done = coarse()
+    out = None
+    for i in range(n):
+        nxt = coarse() if i + 1 < n else None
+        with torch.cuda.stream(sB):
+            sB.wait_event(done)
+            for v in co.values():                       # allocated on sA, read on sB
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(sB)
+            out = fine_and_third(ops, wl, co, ev)
+        last_co = co
+        if nxt is not None:
+            co, done = nxt
+    cur.wait_stream(sA)
+    cur.wait_stream(sB)
+    return last_co, out
 
 
 def local_matches(wl, co, out, rank, world):
@@ -470,14 +512,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(ops, wl, None)
+    streams = None if (args.no_overlap or args.per_chunk) else (torch.cuda.Stream(), torch.cuda.Stream())
+    run_steps(ops, wl, None, args.warmup, streams)
     ev = {"third": [], "fine": []}
     barrier()
     ops.sinkhorn_fallbacks(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        co, out = step(ops, wl, ev)
+    co, out = run_steps(ops, wl, ev, args.steps, streams)
     barrier()
     dt = time.perf_counter() - t0
     fallbacks = ops.sinkhorn_fallbacks(reset=True)       # after the timed region (it synchronises)
@@ -536,7 +577,9 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.label + ": coarse+fine+third OT + cost volume + expansion + subdivision gather + get_result",
                    "pairs_per_step_per_rank": args.pairs,
-                   "batching": "each stage is one launch over all pairs of the step; no host read inside a step",
+                   "batching": "each stage is one launch over all pairs of the step; no host read inside a step"
+                               + ("" if streams is None else "; the coarse stage of batch i + 1 runs on a second HIP stream "
+                                  "beside the fine / third stage of batch i (--no-overlap: one after the other)"),
                    "L1": "1x[448,%d]^2 -> %dx%d" % (wl.h * wl.w, wl.h * wl.w + 1, wl.h * wl.w + 1),
                    "L2": "%d x [264,145]^2 -> 145x145 (%d coarse chunks, batched into one launch)" % (B, len(wl.plan)),
                    "L3": "%d x [128,65]^2 -> 65x65 (fill %d)" % (P, args.fill), "sinkhorn_iters": ITERS,
