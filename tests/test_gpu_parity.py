@@ -1129,9 +1129,10 @@ def test_cost_fp32_path_still_selectable():
             "np.save(sys.argv[1], S)") % REPO
     import tempfile
     outs = []
+    base = {k: v for k, v in os.environ.items() if k != "PATS_COST_F32"}      # whatever the ambient setting is
     for env in ({"PATS_COST_F32": "1"}, {}):
         with tempfile.NamedTemporaryFile(suffix=".npy") as f:
-            subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, **env), check=True)
+            subprocess.run([sys.executable, "-c", code, f.name], env=dict(base, **env), check=True)
             outs.append(np.load(f.name))
     assert not np.array_equal(outs[0], outs[1])                       # two different contractions ...
     np.testing.assert_allclose(outs[0], outs[1], rtol=3e-6, atol=4e-6)   # ... a few ulps of the largest terms apart (|S| up to 16)
