@@ -479,6 +479,9 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, 0, st, g); break;
         case 306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 0>), grid, block, 0, st, g); break;
         case 1306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 1>), grid, block, 0, st, g); break;
+        case 1307: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 7, 1>), grid, block, 0, st, g); break;
+        case 1308: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 8, 1>), grid, block, 0, st, g); break;
+        case 1309: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 9, 1>), grid, block, 0, st, g); break;
         case 1400: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 0, 1>), grid, block, 0, st, g); break;
         case 1301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1, 1>), grid, block, 0, st, g); break;
         case 1310: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 0, 1>), grid, block, 0, st, g); break;
