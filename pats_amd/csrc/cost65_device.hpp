@@ -135,10 +135,6 @@ __device__ __forceinline__ void cost65_accumulate_f16x2(const float* __restrict_
     float er0 = 0.f, er1 = 0.f, ec0 = 0.f, ec1 = 0.f, cn = 0.f;
     float* eA = edge_lds;
     float* eB = edge_lds + 512;
-    for (int k = lane; k < D; k += 64) {
-        eA[k] = A[k * ld + NB];
-        eB[k] = B[k * ld + NB];
-    }
     const float* pa = A + (8 * kg) * ld + 2 * li;
     const float* pb = B + (8 * kg) * ld + 2 * li;
     struct Raw { f2u a[8], b[8]; };
@@ -155,6 +151,18 @@ __device__ __forceinline__ void cost65_accumulate_f16x2(const float* __restrict_
     const int nstep = D / 16;
     Raw q;
     load_blk(0, q);
+    // Edge columns (node 64 of either side) -> LDS, 128 channels per round: all of a round's loads are issued behind
+    // block 0's, and only then waited for - one memory round trip for the whole prologue (a plain k-loop was unrolled
+    // by the compiler into three load-wait-store rounds, each a full latency, ahead of block 0's loads).
+#pragma unroll 1
+    for (int k = lane; k < D; k += 128) {
+        const bool two = k + 64 < D;
+        const int k1 = two ? k + 64 : k;                 // branch-free: a conditional load would be sunk behind a wait
+        const float a0 = A[k * ld + NB], b0 = B[k * ld + NB];
+        const float a1 = A[k1 * ld + NB], b1 = B[k1 * ld + NB];
+        eA[k] = a0; eB[k] = b0;
+        eA[k1] = a1; eB[k1] = b1;
+    }
     __syncthreads();                                     // eA / eB visible
     for (int s = 0; s < nstep; ++s) {
         const int k0 = 16 * s;

@@ -242,12 +242,13 @@ third_fused3_kernel(Fused65Args g) {
     }
     const int colj = 8 * J + I;              // the column this lane owns in the column half-sweep
     // ---- marginals of log_optimal_transport2 (modules.py:169-179); wave-uniform values in SGPRs -------
+    // The loads are issued here, ahead of the descriptor stream, and first used after the cost build: one memory
+    // round trip covers them and the first descriptor block (used at once they cost two more, serialised).
     const float ns_own = g.ns[p * 64 + colj];
-    const float ns_sum = uni3(wave_sum(g.ns[p * 64 + lane]));
-    const float ms = uni3(64.0f * (g.one ? *g.one : 1.0f));
-    const float norm = uni3(-logf(ms + ns_sum));
-    const float lmu = norm, lmu64 = uni3(logf(ns_sum) + norm);
-    const float lnu = logf(ns_own) + norm, lnu64 = uni3(logf(ms) + norm);
+    const float ns_lane = g.ns[p * 64 + lane];
+    const float one_raw = *(g.one ? g.one : g.ns);       // branch-free, so that no wait lands here
+    const float one_v = g.one ? one_raw : 1.0f;
+    const float sx_lane = g.scale_x[p * 64 + lane], sy_lane = g.scale_y[p * 64 + lane];
 
     // ---- cost build (MFMA), then fragment layout -> permuted diagonal-pair blocks through LDS -----------
     f2v Pa[4][4], Pb[4][4];                  // [row pair][column pair], see the header
@@ -304,8 +305,8 @@ third_fused3_kernel(Fused65Args g) {
         zdrow = lds.erow[colj];          // Z[64][8J+I]
         zdcol = lds.ecol[lane];          // Z[8I+J][64]
         __syncthreads();
-        lds.erow[lane] = g.scale_x[p * 64 + lane];       // the epilogue's target scales wait in the freed edge buffers
-        lds.ecol[lane] = g.scale_y[p * 64 + lane];
+        lds.erow[lane] = sx_lane;                        // the epilogue's target scales wait in the freed edge buffers
+        lds.ecol[lane] = sy_lane;
     }
 
     if (DB == 6) {      // diagnostic: checksums of the score matrix this wave built (no solve)
@@ -375,6 +376,11 @@ third_fused3_kernel(Fused65Args g) {
     const float kdcol = fast_exp2(((zdcol - r_own) - c64) * LOG2E);     // K[8I+J][64]
     const float kdrow = fast_exp2(((zdrow - r64) - c_own) * LOG2E);     // K[64][8J+I]
     const float kcorner = uni3(fast_exp2(((zcorner - r64) - c64) * LOG2E));
+    const float ns_sum = uni3(wave_sum(ns_lane));
+    const float ms = uni3(64.0f * one_v);
+    const float norm = uni3(-logf(ms + ns_sum));
+    const float lmu = norm, lmu64 = uni3(logf(ns_sum) + norm);
+    const float lnu = logf(ns_own) + norm, lnu64 = uni3(logf(ms) + norm);
     const float mu = uni3(expf(lmu)), mu64 = uni3(expf(lmu64)), nu = expf(lnu), nu64 = uni3(expf(lnu64));
     float a = 0.f, a64 = 0.f, b = expf(c_own), b64 = expf(c64);
     __syncthreads();
