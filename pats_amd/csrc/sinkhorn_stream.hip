@@ -93,11 +93,24 @@ stream_colreduce_kernel(const float* __restrict__ partial, int nblk, int N,
     const int j = blockIdx.x * 64 + lane;
     const float* pb = partial + (int64_t)b * nblk * N;
     float acc = MODE == 0 ? -INFINITY : 0.f;
-    if (j < N)
-        for (int k = wave; k < nblk; k += 16) {
-            const float v = pb[(int64_t)k * N + j];
-            acc = MODE == 0 ? fmaxf(acc, v) : acc + v;
+    if (j < N) {
+        // up to 18 partials per wave (nblk <= 288) are all in flight before the first add - the plain loop waited for
+        // each load in turn, 17 memory latencies at 4097 rows; the order of the additions is the same
+        constexpr int Q = 18;
+        float v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int k = wave + 16 * q;
+            v[q] = pb[(int64_t)(k < nblk ? k : 0) * N + j];      // clamped rows are loaded and not added
         }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (wave + 16 * q < nblk) acc = MODE == 0 ? fmaxf(acc, v[q]) : acc + v[q];
+        for (int k = wave + 16 * Q; k < nblk; k += 16) {
+            const float x = pb[(int64_t)k * N + j];
+            acc = MODE == 0 ? fmaxf(acc, x) : acc + x;
+        }
+    }
     sm[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && j < N) {
@@ -250,35 +263,55 @@ static void launch_sweep(const float* K, int M, int N, const float* bvec, const 
 int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols, const float* alpha,
                   int64_t batch, int M, int N, const float* log_mu, const float* log_nu, const float* norm,
                   int iters, float* out, void* ws, int* fail, hipStream_t st) {
-    constexpr int RB = 16;
     PATS_REQUIRE(N <= ST * 9, "streaming sinkhorn: N=%d exceeds %d columns", N, ST * 9);
     PATS_REQUIRE(batch <= 65535, "streaming sinkhorn: batch too large");
     SrcViewS src{base, stride, ld, rows, cols, alpha};
-    const int nblk = (M + RB - 1) / RB;
+    const int cpt = (N + ST - 1) / ST;
+    // Rows per workgroup.  With 7+ columns per thread the K piece alone is 112+ VGPRs, so one workgroup fills a CU
+    // and the grid runs in rounds of one workgroup per CU: 4097 rows in blocks of 16 are 257 workgroups - a second
+    // round for ONE block on a 256-CU part.  Blocks of 17 rows (241 workgroups) finish in one.
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    auto rounds = [&](int rb) { return (batch * ((M + rb - 1) / rb) + n_cu - 1) / n_cu; };
+    const bool rb17 = cpt >= 7 && rounds(17) < rounds(16);
+    const int RBr = rb17 ? 17 : 16;
+    const int nblk = (M + RBr - 1) / RBr;
     char* p = (char*)ws;
     float* K = (float*)p;        p += al256((size_t)batch * M * N * 4);
-    float* partial = (float*)p;  p += al256((size_t)batch * nblk * N * 4);
+    float* partial = (float*)p;  p += al256((size_t)batch * ((M + 15) / 16) * N * 4);       // sized for blocks of 16
     float* r = (float*)p;        p += al256((size_t)batch * M * 4);
     float* a = (float*)p;        p += al256((size_t)batch * M * 4);
     float* c = (float*)p;        p += al256((size_t)batch * N * 4);
     float* bv = (float*)p;
     const dim3 rows_grid(M, (unsigned)batch), blk_grid(nblk, (unsigned)batch), col_grid((N + 63) / 64, (unsigned)batch);
     hipLaunchKernelGGL(stream_rowmax_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r);
-    hipLaunchKernelGGL((stream_colmax_partial_kernel<RB>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
+    if (rb17) hipLaunchKernelGGL((stream_colmax_partial_kernel<17>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
+    else hipLaunchKernelGGL((stream_colmax_partial_kernel<16>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
     hipLaunchKernelGGL((stream_colreduce_kernel<0>), col_grid, dim3(1024), 0, st, partial, nblk, N, log_nu, c, bv);
     hipLaunchKernelGGL(stream_kbuild_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r, c, K);
-    const int cpt = (N + ST - 1) / ST;
     for (int it = 0; it < iters; ++it) {
-        switch (cpt) {
-            case 1: launch_sweep<RB, 1>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 2: launch_sweep<RB, 2>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 3: launch_sweep<RB, 3>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 4: launch_sweep<RB, 4>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 5: launch_sweep<RB, 5>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 6: launch_sweep<RB, 6>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 7: launch_sweep<RB, 7>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            case 8: launch_sweep<RB, 8>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
-            default: launch_sweep<RB, 9>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+        if (rb17) {
+            switch (cpt) {
+                case 7: launch_sweep<17, 7>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 8: launch_sweep<17, 8>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                default: launch_sweep<17, 9>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            }
+        } else {
+            constexpr int RB = 16;
+            switch (cpt) {
+                case 1: launch_sweep<RB, 1>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 2: launch_sweep<RB, 2>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 3: launch_sweep<RB, 3>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 4: launch_sweep<RB, 4>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 5: launch_sweep<RB, 5>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 6: launch_sweep<RB, 6>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 7: launch_sweep<RB, 7>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                case 8: launch_sweep<RB, 8>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+                default: launch_sweep<RB, 9>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
+            }
         }
         hipLaunchKernelGGL((stream_colreduce_kernel<1>), col_grid, dim3(1024), 0, st, partial, nblk, N, log_nu,
                            bv, (float*)nullptr);
