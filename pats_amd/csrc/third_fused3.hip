@@ -105,9 +105,23 @@ __device__ __forceinline__ float wave_sum_mfma(float v) {
     const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, 1.0f, z, 0, 0, 0);
     return d[0];
 }
+// 64-lane sum into every lane with the two cross-row steps on the LDS crossbar: four in-row DPP adds, lane ^ 16 by
+// ds_swizzle_b32, lane ^ 32 by ds_bpermute_b32 (neither touches LDS memory nor takes a VALU issue slot) - six VALU
+// instructions where the row-broadcast form (wave_sum_uniform) needs twelve.  Every step is a symmetric exchange, so all
+// 64 lanes end with the same bits.
+__device__ __forceinline__ float wave_sum_xbar(float v, int lane) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    v += swz_xor<16>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+    return v;
+}
 template <int DB>
 __device__ __forceinline__ float dustbin_sum(float v, float* slot, int lane) {
-    if (DB == 0 || DB >= 6) return wave_sum_uniform(v);
+    if (DB == 5) return wave_sum_xbar(v, lane);
+    if (DB == 0 || DB >= 4) return wave_sum_uniform(v);
     if (DB == 2) return wave_sum_mfma(v);
     return wave_sum_lds(v, slot, lane);
 }
@@ -227,7 +241,9 @@ __device__ __forceinline__ void compute_result16(const float* rows, const float*
 
 // WAVES = waves per SIMD the register budget is cut for; CR = column reduction (0 swaps, 1 LDS); CF = cost build
 // (0 fp32 MFMA, 1 fp16-split operands); DB = dustbin
-// sums (0 DPP row broadcasts, 1 LDS, 2 MFMA).  The defaults are what measured fastest (launch_third_fused3).
+// sums (0 DPP row broadcasts, 1 LDS, 2 MFMA, 4 dustbin ROW as a ninth register row: every lane keeps K[64][8J..8J+7],
+// the sum over the row is four packed FMAs and a three-step butterfly over the 8 lanes that share I).  The defaults are what
+// measured fastest (launch_third_fused3).
 template <int WAVES, int CR, int DB, int CF = 0>
 __global__ void __launch_bounds__(64, WAVES)
 third_fused3_kernel(Fused65Args g) {
@@ -253,6 +269,8 @@ third_fused3_kernel(Fused65Args g) {
     // ---- cost build (MFMA), then fragment layout -> permuted diagonal-pair blocks through LDS -----------
     f2v Pa[4][4], Pb[4][4];                  // [row pair][column pair], see the header
     float zdrow, zdcol, zcorner;
+    float zr8[8];                            // DB == 4: Z[64][8J .. 8J+7]
+    f2v kdr[4];                              // DB == 4: the same as K, in column pairs
     {
         Cost65Acc c;
         if (DB == 9) {      // timing ablation only: no cost build (results are garbage)
@@ -304,6 +322,10 @@ third_fused3_kernel(Fused65Args g) {
         __syncthreads();
         zdrow = lds.erow[colj];          // Z[64][8J+I]
         zdcol = lds.ecol[lane];          // Z[8I+J][64]
+        if (DB == 4) {
+            const f4v e0 = *reinterpret_cast<const f4v*>(&lds.erow[8 * J]), e1 = *reinterpret_cast<const f4v*>(&lds.erow[8 * J + 4]);
+            zr8[0] = e0.x; zr8[1] = e0.y; zr8[2] = e0.z; zr8[3] = e0.w; zr8[4] = e1.x; zr8[5] = e1.y; zr8[6] = e1.z; zr8[7] = e1.w;
+        }
         __syncthreads();
         lds.erow[lane] = sx_lane;                        // the epilogue's target scales wait in the freed edge buffers
         lds.ecol[lane] = sy_lane;
@@ -372,6 +394,12 @@ third_fused3_kernel(Fused65Args g) {
                 Pa[sp][cp] = f2v{fast_exp2(((Pa[sp][cp].x - r0) - c0) * LOG2E), fast_exp2(((Pa[sp][cp].y - r1) - c1) * LOG2E)};
                 Pb[sp][cp] = f2v{fast_exp2(((Pb[sp][cp].x - r1) - c0) * LOG2E), fast_exp2(((Pb[sp][cp].y - r0) - c1) * LOG2E)};
             }
+        if (DB == 4) {
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp)
+                kdr[cp] = f2v{fast_exp2(((zr8[2 * cp] - r64) - cl[2 * cp]) * LOG2E),
+                              fast_exp2(((zr8[2 * cp + 1] - r64) - cl[2 * cp + 1]) * LOG2E)};
+        }
     }
     const float kdcol = fast_exp2(((zdcol - r_own) - c64) * LOG2E);     // K[8I+J][64]
     const float kdrow = fast_exp2(((zdrow - r64) - c_own) * LOG2E);     // K[64][8J+I]
@@ -390,6 +418,8 @@ third_fused3_kernel(Fused65Args g) {
         {   // a_i = mu_i / sum_j K_ij b_j
             const f4v b0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), b1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
             const f2v bp[4] = {b0.xy, b0.zw, b1.xy, b1.zw};
+            float dsum = 0.f;
+            if (DB == 5) dsum = wave_sum_xbar(kdrow * b, lane);      // first: its two crossbar trips run under the FMAs
             f2v acc[4];
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) acc[sp] = Pa[sp][0] * bp[0];
@@ -403,12 +433,26 @@ third_fused3_kernel(Fused65Args g) {
                 for (int sp = 0; sp < 4; ++sp) acc[sp] = __builtin_elementwise_fma(Pb[sp][cp].yx, bp[cp].yx, acc[sp]);
             }
             const float rp[8] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y, acc[2].x, acc[2].y, acc[3].x, acc[3].y};
-            const float dsum = dustbin_sum<DB>(kdrow * b, lds.red, lane);
+            if (DB == 5) {
+            } else if (DB == 4) {
+                f2v d = kdr[0] * bp[0];
+#pragma unroll
+                for (int cp = 1; cp < 4; ++cp) d = __builtin_elementwise_fma(kdr[cp], bp[cp], d);
+                float x = d.x + d.y;
+                x += dpp_f<DPP_QUAD_XOR1>(x);
+                x += dpp_f<DPP_QUAD_XOR2>(x);
+                x += dpp_f<DPP_ROW_HALF_MIRROR>(x);          // the 8 lanes that share I cover all 64 columns
+                dsum = x;
+            } else {
+                dsum = dustbin_sum<DB>(kdrow * b, lds.red, lane);
+            }
             const float s = fmaf(kdcol, b64, reduce8_perm(rp, OpSum()));
             a = mu * __builtin_amdgcn_rcpf(s);
             a64 = mu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, b64, dsum));
         }
         {   // b_j = nu_j / sum_i K_ij a_i
+            float dsum = 0.f;
+            if (DB == 5) dsum = wave_sum_xbar(kdcol * a, lane);
             float al[8];
             gather_rows(a, al);
             const f2v ap[4] = {f2v{al[0], al[1]}, f2v{al[2], al[3]}, f2v{al[4], al[5]}, f2v{al[6], al[7]}};
@@ -424,7 +468,7 @@ third_fused3_kernel(Fused65Args g) {
 #pragma unroll
                 for (int cp = 0; cp < 4; ++cp) q[cp] = __builtin_elementwise_fma(Pb[sp][cp], ap[sp].yx, q[cp]);
             }
-            const float dsum = dustbin_sum<DB>(kdcol * a, lds.red + 4, lane);
+            if (DB != 5) dsum = dustbin_sum<DB>(kdcol * a, lds.red + 4, lane);
             const float t = fmaf(kdrow, a64, CR ? reduce8_strided_lds(q, lds.stage, I, J)
                                                 : reduce8_strided_pk(q[0], q[1], q[2], q[3], lane));
             b = nu * __builtin_amdgcn_rcpf(t);
@@ -479,7 +523,7 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     g.fallbacks = fallback_counter();
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
     if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
-    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 1300;   // A/B switch
+    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 1350;   // A/B switch
     const dim3 grid((unsigned)g.P), block(64);
     switch (variant) {          // digits: waves per SIMD, column reduction, dustbin sums
         case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, 0, st, g); break;
@@ -488,6 +532,8 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 1307: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 7, 1>), grid, block, 0, st, g); break;
         case 1308: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 8, 1>), grid, block, 0, st, g); break;
         case 1309: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 9, 1>), grid, block, 0, st, g); break;
+        case 1340: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 4, 1>), grid, block, 0, st, g); break;
+        case 1350: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 5, 1>), grid, block, 0, st, g); break;
         case 1400: hipLaunchKernelGGL((third_fused3_kernel<4, 0, 0, 1>), grid, block, 0, st, g); break;
         case 1301: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 1, 1>), grid, block, 0, st, g); break;
         case 1310: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 0, 1>), grid, block, 0, st, g); break;
@@ -503,7 +549,8 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 410: hipLaunchKernelGGL((third_fused3_kernel<4, 1, 0>), grid, block, 0, st, g); break;
         case 411: hipLaunchKernelGGL((third_fused3_kernel<4, 1, 1>), grid, block, 0, st, g); break;
         case 300: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0>), grid, block, 0, st, g); break;     // fp32 MFMA cost build
-        default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0, 1>), grid, block, 0, st, g); break;
+        case 1300: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0, 1>), grid, block, 0, st, g); break;    // row-broadcast dustbin sums
+        default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 5, 1>), grid, block, 0, st, g); break;
     }
     return check_launch("third_fused3_kernel");
 }

@@ -1189,7 +1189,7 @@ assert d <= 3e-4 * 8, d
 assert np.isfinite(m1.cpu().numpy()).all() and trips >= 1
 print("OK", d, trips)
 ''' % (REPO, REPO)
-    for variant in ("1300", "300"):
+    for variant in ("1350", "1300", "300"):      # default; row-broadcast dustbin sums; fp32-MFMA cost build
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PATS_THIRD_VARIANT=variant), capture_output=True,
                            text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, variant + ": " + p.stdout[-500:] + p.stderr[-1500:]
