@@ -79,4 +79,24 @@ __device__ __forceinline__ float reduce8_strided(const float (&p)[8], Op op, int
     return op(keep, dpp_f<DPP_ROW_ROR8>(send));
 }
 
+// value of lane (lane ^ X), X < 32: ds_swizzle bit-mask mode (and = 0x1f, or = 0, xor = X)
+template <int X>
+__device__ __forceinline__ float swz_xor(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (X << 10) | 0x1f));
+}
+
+// 64-lane sum into every lane with the two cross-row steps on the LDS crossbar: four in-row DPP adds, lane ^ 16 by
+// ds_swizzle_b32, lane ^ 32 by ds_bpermute_b32 (neither touches LDS memory nor takes a VALU issue slot) - six VALU
+// instructions where the row-broadcast form (wave_sum_uniform) needs twelve.  Every step is a symmetric exchange, so all
+// 64 lanes end with the same bits.
+__device__ __forceinline__ float wave_sum_xbar(float v, int lane) {
+    v += dpp_f<DPP_QUAD_XOR1>(v);
+    v += dpp_f<DPP_QUAD_XOR2>(v);
+    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    v += swz_xor<16>(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+    return v;
+}
+
 }  // namespace pats

@@ -57,11 +57,6 @@ struct __attribute__((aligned(16))) Blk3Lds {
                                  // last: the plan rows of block rows 2..5, [32][RS3]
 };
 
-// value of lane (lane ^ X), X < 32: ds_swizzle bit-mask mode (and = 0x1f, or = 0, xor = X)
-template <int X>
-__device__ __forceinline__ float swz_xor(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (X << 10) | 0x1f));
-}
 // g[s] = value of the lane that owns matrix row 8I + rho(s, J)
 __device__ __forceinline__ void gather_rows(float v, float (&g)[8]) {
     g[0] = v;
@@ -104,19 +99,6 @@ __device__ __forceinline__ float wave_sum_mfma(float v) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(v, 1.0f, z, 0, 0, 0);
     return d[0];
-}
-// 64-lane sum into every lane with the two cross-row steps on the LDS crossbar: four in-row DPP adds, lane ^ 16 by
-// ds_swizzle_b32, lane ^ 32 by ds_bpermute_b32 (neither touches LDS memory nor takes a VALU issue slot) - six VALU
-// instructions where the row-broadcast form (wave_sum_uniform) needs twelve.  Every step is a symmetric exchange, so all
-// 64 lanes end with the same bits.
-__device__ __forceinline__ float wave_sum_xbar(float v, int lane) {
-    v += dpp_f<DPP_QUAD_XOR1>(v);
-    v += dpp_f<DPP_QUAD_XOR2>(v);
-    v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
-    v += dpp_f<DPP_ROW_MIRROR>(v);
-    v += swz_xor<16>(v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
-    return v;
 }
 template <int DB>
 __device__ __forceinline__ float dustbin_sum(float v, float* slot, int lane) {
