@@ -484,18 +484,19 @@ def test_roofline_config_4096(ops):
     assert nr <= 4 and nc <= 4             # flat N(0, 0.01) scores: a handful of exact-noise ties at most
 
 
-@pytest.mark.parametrize("M,N", [(4700, 600),      # 294 row blocks: the column reduce's tail loop (more than 18 partials per wave)
-                                 (4097, 3600),     # 8 columns per thread, blocks of 17 rows (one round of workgroups)
-                                 (4100, 3100),     # 7 columns per thread, blocks of 17 rows
-                                 (700, 4608)])     # the widest problem the streaming solver takes, blocks of 16 rows
-def test_streaming_solver_block_shapes(ops, oracle, M, N):
+@pytest.mark.parametrize("B,M,N", [(1, 4700, 600),      # 294 row blocks: the column reduce's tail loop (more than 18 partials per wave)
+                                   (1, 4097, 3600),     # 8 columns per thread, blocks of 17 rows (one round of workgroups)
+                                   (2, 4097, 3600),     # the same as a batch: 2 x 241 workgroups are two rounds, 2 x 257 three
+                                   (1, 4100, 3100),     # 7 columns per thread, blocks of 17 rows
+                                   (1, 700, 4608)])     # the widest problem the streaming solver takes, blocks of 16 rows
+def test_streaming_solver_block_shapes(ops, oracle, B, M, N):
     """csrc/sinkhorn_stream.hip picks rows per workgroup and columns per thread from the shape: every branch of that
     choice against the oracle (modules.py:137-143), four sweeps."""
-    rng = np.random.default_rng(M * 7 + N)
-    Z = rng.standard_normal((1, M, N)).astype(np.float32)
-    mu = rng.uniform(0.5, 2.0, (1, M)); nu = rng.uniform(0.5, 2.0, (1, N))
-    log_mu = np.log(mu / mu.sum()).astype(np.float32)
-    log_nu = np.log(nu / nu.sum()).astype(np.float32)
+    rng = np.random.default_rng(M * 7 + N + B)
+    Z = rng.standard_normal((B, M, N)).astype(np.float32)
+    mu = rng.uniform(0.5, 2.0, (B, M)); nu = rng.uniform(0.5, 2.0, (B, N))
+    log_mu = np.log(mu / mu.sum(1, keepdims=True)).astype(np.float32)
+    log_nu = np.log(nu / nu.sum(1, keepdims=True)).astype(np.float32)
     want = oracle.log_sinkhorn_iterations(Z, log_mu, log_nu, 4)
     got = ops.log_sinkhorn_iterations(cu(Z), cu(log_mu), cu(log_nu), 4).cpu().numpy()
     assert np.isfinite(got).all()
