@@ -507,6 +507,10 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
     static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 1350;   // A/B switch
     const dim3 grid((unsigned)g.P), block(64);
+    // last digit (dustbin sums) 6..9 = diagnostic / timing-ablation builds whose RESULTS ARE NOT the solve: never by accident
+    static const bool ablation_ok = getenv("PATS_THIRD_ABLATION") != nullptr;
+    PATS_REQUIRE(ablation_ok || variant % 10 < 6,
+                 "PATS_THIRD_VARIANT=%d is a timing ablation (wrong results by design); set PATS_THIRD_ABLATION=1 to run it", variant);
     switch (variant) {          // digits: waves per SIMD, column reduction, dustbin sums
         case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, 0, st, g); break;
         case 306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 0>), grid, block, 0, st, g); break;
