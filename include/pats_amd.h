@@ -340,6 +340,31 @@ int pats_attentional_propagation_f32(const float* x, const float* source, int64_
                                      float bn_eps, const float* residual, float* out, void* workspace,
                                      size_t workspace_bytes, pats_stream_t stream);
 
+/* ---- the descriptor heads either side of the GNN: Conv1d(kernel_size=1) and BatchNorm1d + ReLU -------------------
+ * Replaces nn.Conv1d(k=1) wherever the path uses it alone - `final_proj` right before the cost build
+ * (models/first_layer.py:34-36,105; models/second_layer.py:40-42,91) - and, chained, the MLP of
+ * models/modules.py:57-69 that KeypointEncoder is (:70-82; first_layer.py:30-31,81; third_layer.py:96-97,139-140):
+ *   y[b][o][t] = bias[o] + sum_c w[o][c] * f(x[b][c][t]),   f(v) = v                              (in_scale == NULL)
+ *                                                           f(v) = max(0, v * in_scale[c] + in_shift[c])  otherwise
+ *   (+ residual[b][o][t] if residual != NULL)
+ * i.e. the BatchNorm1d + ReLU that follows a Conv1d inside MLP is applied while the NEXT Conv1d stages its input:
+ * eval mode  -> in_scale = gamma / sqrt(running_var + eps), in_shift = beta - running_mean * in_scale (host side);
+ * train mode -> pats_bn_fold_f32 below computes them from the batch statistics of the previous layer's output.
+ * x [batch,K,n], y [batch,M,n] channel-major like the reference's Conv1d; w_t = conv.weight[:, :, 0].t().contiguous()
+ * ([K][M], row = input channel); bias [M] or NULL.  K % 8 == 0 (pad the two keypoint coordinates with zero channels).
+ * Same contraction as pats_cost_f32.  Workspace: pats_conv1x1_workspace_bytes(). */
+size_t pats_conv1x1_workspace_bytes(void);
+int pats_conv1x1_f32(const float* w_t, const float* bias, const float* x, int64_t batch, int K, int M, int n,
+                     const float* in_scale, const float* in_shift, const float* residual, float* y, void* workspace,
+                     size_t workspace_bytes, pats_stream_t stream);
+/* BatchNorm1d in TRAIN mode (F.batch_norm on batch statistics: per channel over (batch, n), biased variance), folded:
+ * scale[c] = gamma[c] / sqrt(var_c + eps), shift[c] = beta[c] - mean_c * scale[c].  Deterministic (fixed summation
+ * order, double accumulation).  PATS.eval() leaves the third layer in train mode (models/pats.py:112-120), so its
+ * KeypointEncoder normalises with these. */
+size_t pats_bn_fold_workspace_bytes(int C);
+int pats_bn_fold_f32(const float* h, int64_t batch, int C, int n, const float* gamma, const float* beta, float eps,
+                     float* scale, float* shift, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1063,6 +1063,40 @@ static void oracle_conv1x1(const float* W, const float* bias, const float* x, in
             }
 }
 
+/* nn.Conv1d(kernel_size=1) on its own: final_proj (first_layer.py:34-36,105; second_layer.py:40-42,91) and the layers of
+ * MLP (modules.py:57-69).  bias may not be NULL (pass zeros). */
+void oracle_conv1d(const float* W, const float* bias, const float* x, int64_t b, int Cin, int Cout, int n, float* y) {
+    oracle_conv1x1(W, bias, x, b, Cin, Cout, n, y);
+}
+
+/* BatchNorm1d followed by ReLU, in place on h [b][C][n] (the middle of MLP, modules.py:64-67): eval = running
+ * statistics, train = batch statistics over (b, n) with the biased variance. */
+void oracle_bn_relu(float* h, int64_t b, int C, int n, const float* gamma, const float* beta, const float* rmean,
+                    const float* rvar, float eps, int bn_train) {
+    for (int c = 0; c < C; ++c) {
+        double mean = rmean[c], var = rvar[c];
+        if (bn_train) {
+            double s = 0.0, s2 = 0.0;
+            for (int64_t bi = 0; bi < b; ++bi)
+                for (int t = 0; t < n; ++t) s += h[(bi * C + c) * (int64_t)n + t];
+            mean = s / (double)(b * n);
+            for (int64_t bi = 0; bi < b; ++bi)
+                for (int t = 0; t < n; ++t) {
+                    const double d = h[(bi * C + c) * (int64_t)n + t] - mean;
+                    s2 += d * d;
+                }
+            var = s2 / (double)(b * n);
+        }
+        const float inv = 1.0f / sqrtf((float)var + eps);
+        for (int64_t bi = 0; bi < b; ++bi)
+            for (int t = 0; t < n; ++t) {
+                float* v = &h[(bi * C + c) * (int64_t)n + t];
+                const float y = (*v - (float)mean) * inv * gamma[c] + beta[c];
+                *v = y > 0.f ? y : 0.f;
+            }
+    }
+}
+
 void oracle_attentional_propagation(const float* x, const float* source, int64_t b, int C, int heads, int n, int m,
                                     const float* wq, const float* bq, const float* wk, const float* bk,
                                     const float* wv, const float* bv, const float* wm, const float* bm,
@@ -1088,28 +1122,7 @@ void oracle_attentional_propagation(const float* x, const float* source, int64_t
                 cat[(bi * 2 * C + c) * (int64_t)n + t] = c < C ? x[(bi * C + c) * (int64_t)n + t]
                                                                 : msg[(bi * C + (c - C)) * (int64_t)n + t];
     oracle_conv1x1(w1, b1, cat, b, 2 * C, 2 * C, n, hid);
-    for (int c = 0; c < 2 * C; ++c) {
-        double mean = rmean[c], var = rvar[c];
-        if (bn_train) {
-            double s = 0.0, s2 = 0.0;
-            for (int64_t bi = 0; bi < b; ++bi)
-                for (int t = 0; t < n; ++t) s += hid[(bi * 2 * C + c) * (int64_t)n + t];
-            mean = s / (double)(b * n);
-            for (int64_t bi = 0; bi < b; ++bi)
-                for (int t = 0; t < n; ++t) {
-                    const double d = hid[(bi * 2 * C + c) * (int64_t)n + t] - mean;
-                    s2 += d * d;
-                }
-            var = s2 / (double)(b * n);
-        }
-        const float inv = 1.0f / sqrtf((float)var + eps);
-        for (int64_t bi = 0; bi < b; ++bi)
-            for (int t = 0; t < n; ++t) {
-                float* h = &hid[(bi * 2 * C + c) * (int64_t)n + t];
-                const float y = (*h - (float)mean) * inv * gamma[c] + beta[c];
-                *h = y > 0.f ? y : 0.f;
-            }
-    }
+    oracle_bn_relu(hid, b, 2 * C, n, gamma, beta, rmean, rvar, eps, bn_train);
     oracle_conv1x1(w2, b2, hid, b, 2 * C, C, n, out);
     if (residual)
         for (size_t e = 0; e < qn; ++e) out[e] = residual[e] + out[e];

@@ -350,3 +350,36 @@ def attentional_propagation(x, source, params, heads=4, bn_train=False, eps=1e-5
         w("mlp.1.bias"), w("mlp.1.running_mean"), w("mlp.1.running_var"), ctypes.c_float(eps), int(bool(bn_train)),
         w("mlp.3.weight"), w("mlp.3.bias"), res, _p(out, c_f))
     return out
+
+
+def conv1d(x, weight, bias=None):
+    """nn.Conv1d(kernel_size=1): x [b,K,n], weight [M,K(,1)], bias [M] or None -> [b,M,n]."""
+    x, px = _f(x)
+    w, pw = _f(np.asarray(weight).reshape(np.asarray(weight).shape[0], -1))
+    M, K = w.shape
+    assert x.shape[1] == K
+    bs, pb = _f(np.zeros((M,), np.float32) if bias is None else np.asarray(bias).reshape(-1))
+    out = np.empty((x.shape[0], M, x.shape[2]), np.float32)
+    lib().oracle_conv1d(pw, pb, px, ctypes.c_int64(x.shape[0]), K, M, x.shape[2], _p(out, c_f))
+    return out
+
+
+def mlp(x, state, prefix="", bn_train=False, eps=1e-5):
+    """MLP.forward (modules.py:57-69) from the nn.Sequential's state_dict names ("0.weight", "1.running_mean", ...)."""
+    names = sorted({int(k[len(prefix):].split(".")[0]) for k in state if k.startswith(prefix) and k[len(prefix):].split(".")[0].isdigit()})
+    convs = [i for i in names if np.asarray(state[prefix + "%d.weight" % i]).ndim == 3]
+    h = np.ascontiguousarray(x, np.float32)
+    for li, i in enumerate(convs):
+        h = conv1d(h, state[prefix + "%d.weight" % i], state[prefix + "%d.bias" % i])
+        if li + 1 < len(convs):
+            keep = [_f(np.asarray(state[prefix + "%d.%s" % (i + 1, nm)])) for nm in ("weight", "bias", "running_mean", "running_var")]
+            h = np.ascontiguousarray(h, np.float32)
+            lib().oracle_bn_relu(_p(h, c_f), ctypes.c_int64(h.shape[0]), h.shape[1], h.shape[2], keep[0][1], keep[1][1],
+                                 keep[2][1], keep[3][1], ctypes.c_float(eps), int(bool(bn_train)))
+    return h
+
+
+def keypoint_encoder(kpts, state, prefix="encoder.", bn_train=False, eps=1e-5):
+    """KeypointEncoder.forward (modules.py:77-82): kpts [n,2] -> [1, feature_dim, n]."""
+    k = np.ascontiguousarray(np.asarray(kpts, np.float32).T.reshape(1, 2, -1))
+    return mlp(k, state, prefix, bn_train, eps)

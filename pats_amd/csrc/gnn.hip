@@ -432,3 +432,40 @@ extern "C" int pats_attentional_propagation_f32(const float* x, const float* sou
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
     return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st);
 }
+
+// ---- the building blocks on their own: Conv1d(kernel_size = 1) and the BatchNorm1d + ReLU that follows it in MLP ------
+// (models/modules.py:57-69; KeypointEncoder :70-82; final_proj first_layer.py:34-36,105 / second_layer.py:40-42,91)
+extern "C" size_t pats_conv1x1_workspace_bytes(void) { return 256; }
+
+extern "C" int pats_conv1x1_f32(const float* w_t, const float* bias, const float* x, int64_t batch, int K, int M, int n,
+                                const float* in_scale, const float* in_shift, const float* residual, float* y,
+                                void* workspace, size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && K > 0 && M > 0 && n > 0, "conv1x1: bad shape");
+    PATS_REQUIRE((K % 8) == 0, "conv1x1: input channels must be a multiple of 8 (operand slabs of 8 channels; pad with zero channels)");
+    PATS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1: in_scale and in_shift come together");
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(w_t && x && y, "conv1x1: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_conv1x1_workspace_bytes(), "conv1x1: workspace too small");
+    hipStream_t st = as_stream(stream);
+    int* redo = (int*)workspace;
+    if (hipMemsetAsync(redo, 0, sizeof(int), st) != hipSuccess) return check_launch("conv1x1 memset");
+    return launch_conv(ConvArgs{w_t, x, nullptr, K, 0, M, n, batch * n, in_scale, in_shift, bias, residual, y}, redo, st);
+}
+
+extern "C" size_t pats_bn_fold_workspace_bytes(int C) {
+    return C > 0 ? al256((size_t)C * pats::BN_SPLITS * 2 * sizeof(double)) : 0;
+}
+
+extern "C" int pats_bn_fold_f32(const float* h, int64_t batch, int C, int n, const float* gamma, const float* beta,
+                                float eps, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                                pats_stream_t stream) {
+    PATS_REQUIRE(batch > 0 && C > 0 && n > 0, "bn_fold: bad shape (batch statistics need at least one column)");
+    PATS_REQUIRE(h && gamma && beta && scale && shift, "bn_fold: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_bn_fold_workspace_bytes(C), "bn_fold: workspace too small");
+    hipStream_t st = as_stream(stream);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)C, BN_SPLITS), dim3(256), 0, st, h, batch, C, n, part);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, part, batch * (int64_t)n, C, gamma, beta,
+                       eps, scale, shift);
+    return check_launch("bn_fold kernels");
+}

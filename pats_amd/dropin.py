@@ -16,6 +16,9 @@ functions live in several namespaces), and in `sys.modules` for the native exten
     utils/utils.py:152,1343,189    split_patches / Compute_imgs / get_result
     models/second_layer.py:137,193 SecondLayer.merge_patches_old / merge_patches_new   (methods: `self` dropped)
     models/third_layer.py:184      ThirdLayer.Compute_result                          (method: 3-tuple as the reference)
+    models/modules.py:77           KeypointEncoder.forward (six Conv1d GEMMs, BatchNorm + ReLU folded into the next
+                                   layer's staging; follows `self.training` like the reference).  `final_proj` is an
+                                   nn.Conv1d INSTANCE and is not rebound: ops.conv1d(x, m.weight, m.bias) replaces a call
     models/modules.py:114,127      AttentionalPropagation.forward / AttentionalGNN.forward (the layer's own parameters,
                                    read once from its state_dict and cached on the instance; BatchNorm follows
                                    `self.training` like the reference - the third layer's stays in train mode, pats.py:112-120)
@@ -82,7 +85,16 @@ def _methods(ops):
         train = bool(len(self.layers) and self.layers[0].training)
         return ops.attentional_gnn(desc0, desc1, layers, self.names, heads=heads, bn_train=train)
 
-    return {"models.second_layer": ("SecondLayer", {"merge_patches_new": merge_patches_new,
+    def kenc_forward(self, kpts):
+        p = getattr(self, "_pats_params", None)
+        if p is None:
+            dev = next(self.parameters()).device
+            p = ops.MLPParams(self.state_dict(), device=dev, eps=self.encoder[1].eps, prefix="encoder.")
+            object.__setattr__(self, "_pats_params", p)
+        return ops.keypoint_encoder(kpts, p, bn_train=self.training)
+
+    return {"models.modules#kenc": ("KeypointEncoder", {"forward": kenc_forward}),
+            "models.second_layer": ("SecondLayer", {"merge_patches_new": merge_patches_new,
                                                     "merge_patches_old": merge_patches_old}),
             "models.third_layer": ("ThirdLayer", {"Compute_result": Compute_result}),
             "models.modules": ("AttentionalPropagation", {"forward": propagation_forward}),

@@ -808,3 +808,121 @@ def attentional_gnn(desc0, desc1, layers, names, heads=4, bn_train=False):
         n1 = attentional_propagation(desc1, src1, p, heads, bn_train, residual=desc1)
         desc0, desc1 = n0, n1
     return desc0, desc1
+
+
+# ------------------------------------------------------------------------------------------------
+# the descriptor heads either side of the GNN: Conv1d(k=1) alone (final_proj) and chained (MLP / KeypointEncoder)
+# ------------------------------------------------------------------------------------------------
+def _pad8(t, dim):
+    """Zero channels up to a multiple of 8 along `dim` (the contraction's operand slabs are 8 channels)."""
+    k = t.shape[dim]
+    if k % 8 == 0:
+        return t
+    shape = list(t.shape)
+    shape[dim] = (-k) % 8
+    return torch.cat([t, t.new_zeros(shape)], dim=dim).contiguous()
+
+
+def conv1d(x, weight, bias=None, in_scale=None, in_shift=None, residual=None):
+    """nn.Conv1d(kernel_size=1) as the path uses it (final_proj: first_layer.py:34-36,105, second_layer.py:40-42,91;
+    the layers of MLP, modules.py:57-69): x [b,K,n], weight [M,K,1] or [M,K] (the module's own layout), bias [M] or
+    None -> [b,M,n].  in_scale / in_shift [K]: x is max(0, x * scale + shift) while it is staged - the BatchNorm1d + ReLU
+    of the previous MLP layer, folded.  residual [b,M,n] is added to the result."""
+    x = _dev(x, "x")
+    weight = _dev(weight, "weight")
+    b, K, n = x.shape
+    w2 = weight.reshape(weight.shape[0], -1)
+    M = w2.shape[0]
+    if w2.shape[1] != K:
+        raise RuntimeError("conv1d: weight %s does not take %d input channels" % (tuple(weight.shape), K))
+    w_t = _pad8(w2.t().contiguous(), 0)                 # [K][M], zero rows for the padding channels
+    xp = _pad8(x, 1)
+    sc = sh = None
+    if in_scale is not None:
+        sc = _pad8(_dev(in_scale, "in_scale").reshape(-1), 0)      # padded channels: max(0, 0 * 0 + 0) = 0
+        sh = _pad8(_dev(in_shift, "in_shift").reshape(-1), 0)
+        if sc.numel() != xp.shape[1] or sh.numel() != xp.shape[1]:
+            raise RuntimeError("conv1d: in_scale / in_shift must have %d entries" % K)
+    bs = _dev(bias, "bias").reshape(-1) if bias is not None else None
+    if bs is not None and bs.numel() != M:
+        raise RuntimeError("conv1d: bias must have %d entries" % M)
+    res = _dev(residual, "residual") if residual is not None else None
+    if res is not None and tuple(res.shape) != (b, M, n):
+        raise RuntimeError("conv1d: residual %s is not [%d,%d,%d]" % (tuple(res.shape), b, M, n))
+    y = torch.empty((b, M, n), dtype=torch.float32, device=x.device)
+    if b == 0 or n == 0:
+        return y
+    nb = _L().pats_conv1x1_workspace_bytes()
+    ws = _workspace(nb, x.device)
+    _check(_L().pats_conv1x1_f32(_ptr(w_t), _ptr(bs), _ptr(xp), b, xp.shape[1], M, n, _ptr(sc), _ptr(sh), _ptr(res), _ptr(y),
+                                 _ptr(ws), nb, _stream()), "conv1d")
+    return y
+
+
+def bn_fold(h, gamma, beta, eps=1e-5):
+    """BatchNorm1d in train mode, folded: (scale, shift) [C] each with scale = gamma / sqrt(var + eps) and
+    shift = beta - mean * scale over the batch statistics of h [b,C,n] (biased variance, what F.batch_norm
+    normalises with).  Feed them to the next conv1d as in_scale / in_shift."""
+    h, gamma, beta = _dev(h, "h"), _dev(gamma, "gamma").reshape(-1), _dev(beta, "beta").reshape(-1)
+    b, C, n = h.shape
+    if gamma.numel() != C or beta.numel() != C:
+        raise RuntimeError("bn_fold: gamma / beta must have %d entries" % C)
+    scale = torch.empty((C,), dtype=torch.float32, device=h.device)
+    shift = torch.empty_like(scale)
+    nb = _L().pats_bn_fold_workspace_bytes(C)
+    ws = _workspace(nb, h.device)
+    _check(_L().pats_bn_fold_f32(_ptr(h), b, C, n, _ptr(gamma), _ptr(beta), float(eps), _ptr(scale), _ptr(shift), _ptr(ws), nb,
+                                 _stream()), "bn_fold")
+    return scale, shift
+
+
+class MLPParams:
+    """The parameters of one `MLP(channels)` (modules.py:57-69: Conv1d [BatchNorm1d ReLU] ... Conv1d) from the
+    nn.Sequential's own state_dict ("0.weight", "0.bias", "1.weight", "1.bias", "1.running_mean", "1.running_var",
+    "3.weight", ...), device-resident.  `prefix` selects a sub-module, e.g. "encoder." for a KeypointEncoder."""
+
+    def __init__(self, state, device="cuda", eps=1e-5, prefix=""):
+        def get(name):
+            t = state[prefix + name]
+            t = torch.from_numpy(np.asarray(t)) if not isinstance(t, torch.Tensor) else t
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.eps = float(eps)
+        idx = sorted({int(k[len(prefix):].split(".")[0]) for k in state if k.startswith(prefix) and k[len(prefix):].split(".")[0].isdigit()})
+        convs = [i for i in idx if get("%d.weight" % i).dim() == 3]
+        self.layers = []
+        for li, i in enumerate(convs):
+            layer = {"weight": get("%d.weight" % i), "bias": get("%d.bias" % i), "bn": None}
+            if li + 1 < len(convs) and (prefix + "%d.running_var" % (i + 1)) in state:        # do_bn, not after the last Conv1d
+                g, bta = get("%d.weight" % (i + 1)), get("%d.bias" % (i + 1))
+                rm, rv = get("%d.running_mean" % (i + 1)), get("%d.running_var" % (i + 1))
+                sc = g / torch.sqrt(rv + self.eps)
+                layer["bn"] = {"gamma": g, "beta": bta, "eval": (sc.contiguous(), (bta - rm * sc).contiguous())}
+            self.layers.append(layer)
+
+
+def mlp(x, params, bn_train=False):
+    """MLP.forward (modules.py:57-69): Conv1d -> BatchNorm1d -> ReLU -> ... -> Conv1d.  One GEMM launch per Conv1d; each
+    BatchNorm + ReLU rides on the next layer's operand staging (eval: folded running statistics; bn_train: batch
+    statistics, pats_bn_fold_f32).  An MLP built with do_bn=False would need a ReLU-only fold: scale 1, shift 0."""
+    sc = sh = None
+    h = _dev(x, "x")
+    for i, layer in enumerate(params.layers):
+        h = conv1d(h, layer["weight"], layer["bias"], sc, sh)
+        if i + 1 < len(params.layers):
+            bn = layer["bn"]
+            if bn is None:
+                sc = torch.ones((h.shape[1],), dtype=torch.float32, device=h.device)
+                sh = torch.zeros_like(sc)
+            elif bn_train:
+                sc, sh = bn_fold(h, bn["gamma"], bn["beta"], params.eps)
+            else:
+                sc, sh = bn["eval"]
+    return h
+
+
+def keypoint_encoder(kpts, params, bn_train=False):
+    """KeypointEncoder.forward (modules.py:77-82): kpts [n,2] -> [1, feature_dim, n] (first_layer.py:81,99 adds it to the
+    coarse descriptors, third_layer.py:139-140 to the 8x8 windows).  `params` = MLPParams(kenc.state_dict(), prefix="encoder.")."""
+    kpts = _dev(kpts, "kpts")
+    inputs = kpts.transpose(0, 1).reshape(1, 2, -1).contiguous()
+    return mlp(inputs, params, bn_train)

@@ -241,3 +241,38 @@ def gnn_inputs(seed=SEED + 71, b=3, C=128, n=65, m=None):
     rng = np.random.default_rng(seed)
     m = n if m is None else m
     return {"x": rng.standard_normal((b, C, n)).astype(np.float32), "source": rng.standard_normal((b, C, m)).astype(np.float32)}
+
+
+def kenc_params(seed=SEED + 100, feature_dim=128, layers=(32, 64, 128, 256, 512)):
+    """Weights of one KeypointEncoder (modules.py:70-76: MLP([2] + layers + [feature_dim])) under the reference's
+    state_dict names ("encoder.0.weight", "encoder.1.running_mean", ...), drawn with numpy like gnn_params."""
+    rng = np.random.default_rng(seed)
+    ch = [2] + list(layers) + [feature_dim]
+    p = {}
+    for i in range(1, len(ch)):
+        k = 1.0 / np.sqrt(ch[i - 1])
+        j = 3 * (i - 1)                                # Conv1d, BatchNorm1d, ReLU per hidden layer
+        p["encoder.%d.weight" % j] = rng.uniform(-k, k, (ch[i], ch[i - 1], 1)).astype(np.float32)
+        p["encoder.%d.bias" % j] = rng.uniform(-k, k, (ch[i],)).astype(np.float32)
+        if i < len(ch) - 1:
+            p["encoder.%d.weight" % (j + 1)] = rng.uniform(0.5, 1.5, (ch[i],)).astype(np.float32)
+            p["encoder.%d.bias" % (j + 1)] = (0.2 * rng.standard_normal((ch[i],))).astype(np.float32)
+            p["encoder.%d.running_mean" % (j + 1)] = (0.1 * rng.standard_normal((ch[i],))).astype(np.float32)
+            p["encoder.%d.running_var" % (j + 1)] = rng.uniform(0.05, 0.5, (ch[i],)).astype(np.float32)
+    p["encoder.%d.bias" % (3 * (len(ch) - 2))][:] = 0.0       # nn.init.constant_(self.encoder[-1].bias, 0.0), modules.py:75
+    return p
+
+
+def grid_kpts(h, w):
+    """The keypoint grid the layers feed their encoder (first_layer.py:74-79 with h, w = the descriptor map;
+    third_layer.py:132-136 with h = w = 8): [:,0] = row / h, [:,1] = column / w, row-major."""
+    cols = (np.arange(h, dtype=np.float32).reshape(h, 1).repeat(w, 1).reshape(-1) / np.float32(h)).astype(np.float32)
+    rows = (np.arange(w, dtype=np.float32).reshape(1, w).repeat(h, 0).reshape(-1) / np.float32(w)).astype(np.float32)
+    return np.stack([cols, rows], axis=1).astype(np.float32)
+
+
+def final_proj_params(seed=SEED + 110, C=448):
+    """nn.Conv1d(C, C, kernel_size=1, bias=True) (first_layer.py:34-36, second_layer.py:40-42)."""
+    rng = np.random.default_rng(seed)
+    k = 1.0 / np.sqrt(C)
+    return {"weight": rng.uniform(-k, k, (C, C, 1)).astype(np.float32), "bias": rng.uniform(-k, k, (C,)).astype(np.float32)}

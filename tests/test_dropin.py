@@ -52,6 +52,10 @@ class AttentionalGNN:
     def forward(self, desc0, desc1): return "ref"
 
 
+class KeypointEncoder:
+    def forward(self, kpts): return "ref"
+
+
 REF_NAMES = ("models", "models.modules", "models.first_layer", "models.second_layer", "models.third_layer", "utils",
              "utils.utils", "tensor_resize")
 
@@ -64,7 +68,7 @@ def standins():
     _mod("utils")
     mm = _mod("models.modules", log_sinkhorn_iterations=log_sinkhorn_iterations, log_optimal_transport=log_optimal_transport,
               log_optimal_transport2=log_optimal_transport2, attention=attention, AttentionalPropagation=AttentionalPropagation,
-              AttentionalGNN=AttentionalGNN)
+              AttentionalGNN=AttentionalGNN, KeypointEncoder=KeypointEncoder)
     uu = _mod("utils.utils", Iterative_expand_matrix=Iterative_expand_matrix, split_patches=split_patches,
               Compute_positions_and_ranges=Compute_positions_and_ranges, Compute_imgs=Compute_imgs, get_result=get_result,
               tensor_resize=native)
@@ -116,6 +120,7 @@ def test_install_rebinds_every_namespace_and_restores(standins):
     assert AttentionalPropagation.forward.__module__ == "pats_amd.dropin" and AttentionalGNN.forward.__module__ == "pats_amd.dropin"
     assert list(inspect.signature(AttentionalPropagation.forward).parameters) == ["self", "x", "source"]
     assert list(inspect.signature(AttentionalGNN.forward).parameters) == ["self", "desc0", "desc1"]
+    assert KeypointEncoder.forward.__module__ == "pats_amd.dropin" and list(inspect.signature(KeypointEncoder.forward).parameters) == ["self", "kpts"]
     assert "models.first_layer.log_optimal_transport" in touched and "models.third_layer.ThirdLayer.Compute_result" in touched
     # signatures: same positional parameters as the reference's
     for ref, new in ((log_sinkhorn_iterations, ops.log_sinkhorn_iterations), (log_optimal_transport, ops.log_optimal_transport),
@@ -128,6 +133,7 @@ def test_install_rebinds_every_namespace_and_restores(standins):
     assert s["l1"].log_optimal_transport is log_optimal_transport and s["uu"].get_result is get_result
     assert SecondLayer().merge_patches_new(1, 2, 3, 4, 5, 6) == "ref" and ThirdLayer().Compute_result(*range(8)) == "ref"
     assert AttentionalPropagation().forward(1, 2) == "ref" and AttentionalGNN().forward(1, 2) == "ref"
+    assert KeypointEncoder().forward(1) == "ref"
     assert sys.modules["tensor_resize"] is s["native"]
 
 
@@ -146,6 +152,7 @@ def test_install_against_the_real_reference_when_present():
                                                    "Compute_imgs", "get_result")})
     merge_new, comp_res = R.L2.SecondLayer.merge_patches_new, R.L3.ThirdLayer.Compute_result
     prop_fwd, gnn_fwd = R.M.AttentionalPropagation.forward, R.M.AttentionalGNN.forward
+    kenc_fwd = R.M.KeypointEncoder.forward
     try:
         touched = dropin.install()
         for n, ref in originals.items():
@@ -158,6 +165,7 @@ def test_install_against_the_real_reference_when_present():
         assert len(touched) >= 17
         assert _prefix_compatible(prop_fwd, R.M.AttentionalPropagation.forward) and R.M.AttentionalPropagation.forward is not prop_fwd
         assert _prefix_compatible(gnn_fwd, R.M.AttentionalGNN.forward)
+        assert _prefix_compatible(kenc_fwd, R.M.KeypointEncoder.forward) and R.M.KeypointEncoder.forward is not kenc_fwd
     finally:
         dropin.uninstall()
         # ref_import put the reference's compiled extension first on sys.path / into sys.modules: later tests
@@ -169,3 +177,4 @@ def test_install_against_the_real_reference_when_present():
             sys.modules["tensor_resize"] = native_before
     assert R.L1.log_optimal_transport is originals["log_optimal_transport"] and R.L2.SecondLayer.merge_patches_new is merge_new
     assert R.M.AttentionalPropagation.forward is prop_fwd and R.M.AttentionalGNN.forward is gnn_fwd
+    assert R.M.KeypointEncoder.forward is kenc_fwd

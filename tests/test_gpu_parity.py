@@ -1003,6 +1003,64 @@ def test_attentional_gnn_and_edge_shapes(ops, oracle):
         ops.attentional_propagation(cu(i["x"]), cu(i["source"][:, :100]), ops.PropagationParams(p))
 
 
+# ---- the descriptor heads: KeypointEncoder (modules.py:70-82) and final_proj (first_layer.py:34-36,105) ----------------
+@pytest.mark.parametrize("tag,dim,h,w,seed", [("third", 128, 8, 8, synth.SEED + 100), ("first", 448, 15, 20, synth.SEED + 101)])
+def test_keypoint_encoder_golden(ops, oracle, tag, dim, h, w, seed):
+    """Six Conv1d layers with BatchNorm + ReLU between them (eval: running statistics; train: batch statistics - the third
+    layer's mode under PATS.eval when if_local is off), against the reference's own class and against the oracle."""
+    g = golden("heads.npz")
+    params = synth.kenc_params(seed=seed, feature_dim=dim)
+    P = ops.MLPParams(params, prefix="encoder.")
+    assert [tuple(l["weight"].shape[:2]) for l in P.layers] == [(32, 2), (64, 32), (128, 64), (256, 128), (512, 256), (dim, 512)]
+    kpts = cu(synth.grid_kpts(h, w))
+    for mode in ("eval", "train"):
+        y = ops.keypoint_encoder(kpts, P, bn_train=(mode == "train")).cpu().numpy()
+        assert y.shape == (1, dim, h * w)
+        want = oracle.keypoint_encoder(synth.grid_kpts(h, w), params, bn_train=(mode == "train"))
+        np.testing.assert_allclose(y, want, atol=3e-5, rtol=2e-4)
+        if tag == "third":
+            np.testing.assert_allclose(y, g["kenc_third_%s" % mode], atol=3e-5, rtol=2e-4)
+        else:
+            np.testing.assert_allclose(y.reshape(-1)[g["kenc_first_idx"]], g["kenc_first_%s" % mode], atol=3e-5, rtol=2e-4)
+
+
+@pytest.mark.parametrize("tag,C,b,n,seed", [("first", 448, 1, 300, synth.SEED + 110), ("second", 264, 6, 145, synth.SEED + 111)])
+def test_final_proj_golden(ops, oracle, tag, C, b, n, seed):
+    g = golden("heads.npz")
+    p = synth.final_proj_params(seed=seed, C=C)
+    x = synth.gnn_inputs(seed=seed + 5, b=b, C=C, n=n)["x"]
+    y = ops.conv1d(cu(x), cu(p["weight"]), cu(p["bias"])).cpu().numpy()
+    np.testing.assert_allclose(y.reshape(-1)[g["proj_%s_idx" % tag]], g["proj_%s_val" % tag], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(y, oracle.conv1d(x, p["weight"], p["bias"]), atol=2e-5, rtol=1e-4)
+    # what feeds the cost build: cost(final_proj(d0), final_proj(d1)) as first_layer.py:105-111 chains them
+    S = ops.cost(cu(y), cu(y)).cpu().numpy()
+    np.testing.assert_allclose(S, oracle.cost(y, y), atol=3e-5, rtol=1e-5)
+
+
+def test_conv1d_edge_cases(ops, oracle):
+    rng = np.random.default_rng(4)
+    # no bias, ragged channel counts (K = 5 is padded to 8 inside), residual, folded input affine + ReLU
+    x = rng.standard_normal((3, 5, 77)).astype(np.float32)
+    w = rng.standard_normal((13, 5, 1)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 5).astype(np.float32); sh = rng.standard_normal(5).astype(np.float32)
+    res = rng.standard_normal((3, 13, 77)).astype(np.float32)
+    y = ops.conv1d(cu(x), cu(w), None, cu(sc), cu(sh), cu(res)).cpu().numpy()
+    xa = np.maximum(x * sc[None, :, None] + sh[None, :, None], 0).astype(np.float32)
+    np.testing.assert_allclose(y, oracle.conv1d(xa, w) + res, atol=2e-5, rtol=1e-4)
+    assert ops.conv1d(cu(x[:0]), cu(w)).shape == (0, 13, 77)
+    with pytest.raises(RuntimeError):
+        ops.conv1d(cu(x), cu(w[:, :4]))
+    with pytest.raises(RuntimeError):
+        ops.conv1d(torch.from_numpy(x), cu(w))            # CPU tensor: no fallback
+    # batch statistics, folded: against numpy
+    h = rng.standard_normal((7, 24, 50)).astype(np.float32) * 3 + 1
+    gam = rng.uniform(0.5, 1.5, 24).astype(np.float32); bet = rng.standard_normal(24).astype(np.float32)
+    s, t = ops.bn_fold(cu(h), cu(gam), cu(bet), 1e-5)
+    mean = h.astype(np.float64).mean((0, 2)); var = h.astype(np.float64).var((0, 2))
+    np.testing.assert_allclose(s.cpu().numpy(), gam / np.sqrt(var + 1e-5), rtol=1e-5)
+    np.testing.assert_allclose(t.cpu().numpy(), bet - mean * gam / np.sqrt(var + 1e-5), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("C,b,n,m", [(8, 37, 3, 5), (24, 9, 70, 33), (72, 4, 161, 20), (136, 3, 65, 65)])
 def test_attentional_propagation_small_widths_against_oracle(ops, oracle, C, b, n, m):
     """Single-chunk and ragged reductions (K = 8 .. 272, the two-pass reduction of the MLP's first product with a
@@ -1075,9 +1133,22 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
                 desc0, desc1 = desc0 + delta0, desc1 + delta1
             return desc0, desc1
 
+    class KeypointEncoder(nn.Module):
+        def __init__(self, feature_dim, layers):
+            super().__init__()
+            ch, seq = [2] + layers + [feature_dim], []
+            for i in range(1, len(ch)):
+                seq.append(nn.Conv1d(ch[i - 1], ch[i], kernel_size=1, bias=True))
+                if i < len(ch) - 1:
+                    seq += [nn.BatchNorm1d(ch[i]), nn.ReLU()]
+            self.encoder = nn.Sequential(*seq)
+
+        def forward(self, kpts):
+            return self.encoder(kpts.transpose(0, 1).reshape(1, 2, -1))
+
     saved = {n: sys.modules.get(n) for n in ("models", "models.modules")}
     mod = types.ModuleType("models.modules")
-    mod.AttentionalPropagation, mod.AttentionalGNN = AttentionalPropagation, AttentionalGNN
+    mod.AttentionalPropagation, mod.AttentionalGNN, mod.KeypointEncoder = AttentionalPropagation, AttentionalGNN, KeypointEncoder
     sys.modules["models"], sys.modules["models.modules"] = types.ModuleType("models"), mod
     try:
         torch.manual_seed(3)
@@ -1086,6 +1157,17 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
             layer.mlp[1].running_mean.normal_(0, 0.3)
             layer.mlp[1].running_var.uniform_(0.5, 2.0)
         d0, d1 = torch.randn(6, 128, 65, device="cuda"), torch.randn(6, 128, 65, device="cuda")
+        kenc = KeypointEncoder(128, [32, 64, 128, 256, 512]).cuda()
+        for m in kenc.encoder:
+            if isinstance(m, nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.05, 0.5)
+        kstats = [(m.running_mean.clone(), m.running_var.clone()) for m in kenc.encoder if isinstance(m, nn.BatchNorm1d)]
+        kpts = cu(synth.grid_kpts(8, 8))
+        with torch.no_grad():
+            kenc_eval = kenc.eval()(kpts)
+            kenc_train = kenc.train()(kpts)
+            for m, (mu, var) in zip([m for m in kenc.encoder if isinstance(m, nn.BatchNorm1d)], kstats):
+                m.running_mean.copy_(mu); m.running_var.copy_(var)
         with torch.no_grad():
             want_eval = gnn.eval()(d0, d1)
             stats = [(l.mlp[1].running_mean.clone(), l.mlp[1].running_var.clone()) for l in gnn.layers]
@@ -1097,7 +1179,10 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
             got_eval = gnn.eval()(d0, d1)
             got_train = gnn.train()(d0, d1)
             one = gnn.layers[0].eval()(d0, d1)
+            assert "models.modules.KeypointEncoder.forward" in touched
+            got_kenc_eval, got_kenc_train = kenc.eval()(kpts), kenc.train()(kpts)
         dropin.uninstall()
+        assert torch.allclose(got_kenc_eval, kenc_eval, atol=5e-5, rtol=2e-4) and torch.allclose(got_kenc_train, kenc_train, atol=5e-5, rtol=2e-4)
         with torch.no_grad():
             one_ref = gnn.layers[0](d0, d1)
         for a, b in ((got_eval, want_eval), (got_train, want_train)):

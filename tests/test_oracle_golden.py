@@ -333,3 +333,30 @@ def test_attentional_gnn_two_layers(oracle):
         d0, d1 = (oracle.attentional_propagation(d0, s0, p, residual=d0), oracle.attentional_propagation(d1, s1, p, residual=d1))
     np.testing.assert_allclose(d0.reshape(-1)[g["gnn_idx"]], g["gnn_d0"], atol=5e-5, rtol=1e-4)
     np.testing.assert_allclose(d1.reshape(-1)[g["gnn_idx"]], g["gnn_d1"], atol=5e-5, rtol=1e-4)
+
+
+# ---- the descriptor heads: KeypointEncoder (modules.py:70-82) and final_proj (Conv1d, first_layer.py:34-36,105) ----
+@pytest.mark.parametrize("tag,dim,h,w,seed", [("third", 128, 8, 8, synth.SEED + 100), ("first", 448, 15, 20, synth.SEED + 101)])
+def test_keypoint_encoder_against_the_reference_class(oracle, tag, dim, h, w, seed):
+    g = golden("heads.npz")
+    params = synth.kenc_params(seed=seed, feature_dim=dim)
+    assert abs(synth.checksum(params["encoder.0.weight"], params["encoder.15.weight"]) - float(g["kenc_%s_checksum" % tag])) < 1e-9
+    kpts = synth.grid_kpts(h, w)
+    for mode in ("eval", "train"):
+        y = oracle.keypoint_encoder(kpts, params, bn_train=(mode == "train"))
+        assert y.shape == (1, dim, h * w)
+        if tag == "third":
+            np.testing.assert_allclose(y, g["kenc_third_%s" % mode], atol=2e-5, rtol=1e-4)
+        else:
+            np.testing.assert_allclose(y.reshape(-1)[g["kenc_first_idx"]], g["kenc_first_%s" % mode], atol=2e-5, rtol=1e-4)
+            assert abs(float(y.astype(np.float64).sum()) - float(g["kenc_first_%s_sum" % mode])) < 2e-2
+
+
+@pytest.mark.parametrize("tag,C,b,n,seed", [("first", 448, 1, 300, synth.SEED + 110), ("second", 264, 6, 145, synth.SEED + 111)])
+def test_final_proj_against_torch_conv1d(oracle, tag, C, b, n, seed):
+    g = golden("heads.npz")
+    p = synth.final_proj_params(seed=seed, C=C)
+    x = synth.gnn_inputs(seed=seed + 5, b=b, C=C, n=n)["x"]
+    y = oracle.conv1d(x, p["weight"], p["bias"])
+    np.testing.assert_allclose(y.reshape(-1)[g["proj_%s_idx" % tag]], g["proj_%s_val" % tag], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(y.astype(np.float64).sum((1, 2)), g["proj_%s_sum" % tag], atol=2e-2, rtol=1e-4)

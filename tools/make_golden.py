@@ -538,6 +538,48 @@ def gen_gnn(R):
     save("gnn_layer.npz", **arrs)
 
 
+def gen_heads(R):
+    """The descriptor heads either side of the GNN, from the reference's own modules: KeypointEncoder (modules.py:70-82) as
+    the third layer builds it (third_layer.py:96-97; 8 x 8 grid :132-136) in eval and in train mode, as the first layer
+    builds it (first_layer.py:30-31; 15 x 20 grid :74-79), and final_proj = nn.Conv1d(k=1) (first_layer.py:34-36,105;
+    second_layer.py:40-42,91) at both levels' shapes."""
+    arrs = {}
+    for tag, dim, (h, w), seed in (("third", 128, (8, 8), synth.SEED + 100), ("first", 448, (15, 20), synth.SEED + 101)):
+        params = synth.kenc_params(seed=seed, feature_dim=dim)
+        kenc = R.M.KeypointEncoder(dim, [32, 64, 128, 256, 512])
+        kenc.load_state_dict({k: T(v) for k, v in params.items()}, strict=False)
+        # the grid exactly as the layer writes it (float division of an integer arange)
+        cols = torch.arange(0, h).reshape(h, 1).repeat(1, w).reshape(-1) / float(h)
+        rows = torch.arange(0, w).reshape(1, w).repeat(h, 1).reshape(-1) / float(w)
+        kpts = torch.zeros((h * w), 2)
+        kpts[:, 0] = cols
+        kpts[:, 1] = rows
+        assert np.array_equal(npy(kpts), synth.grid_kpts(h, w))
+        for mode in ("eval", "train"):
+            kenc.train(mode == "train")
+            with torch.no_grad():
+                y = kenc(kpts)
+            if y.numel() > 16384:                       # the coarse level's [1,448,300]: 8192 sampled entries + the sum
+                idx = sample_idx(np.random.default_rng(92), y.shape, 8192)
+                arrs.update({"kenc_%s_idx" % tag: idx, "kenc_%s_%s" % (tag, mode): y.reshape(-1)[T(idx)],
+                             "kenc_%s_%s_sum" % (tag, mode): y.double().sum()})
+            else:
+                arrs["kenc_%s_%s" % (tag, mode)] = y
+            kenc.load_state_dict({k: T(v) for k, v in params.items()}, strict=False)     # train mode moved the running statistics
+        arrs["kenc_%s_checksum" % tag] = synth.checksum(params["encoder.0.weight"], params["encoder.15.weight"])
+    rng = np.random.default_rng(91)
+    for tag, C, b, n, seed in (("first", 448, 1, 300, synth.SEED + 110), ("second", 264, 6, 145, synth.SEED + 111)):
+        p = synth.final_proj_params(seed=seed, C=C)
+        conv = torch.nn.Conv1d(C, C, kernel_size=1, bias=True)
+        conv.load_state_dict({k: T(v) for k, v in p.items()})
+        x = synth.gnn_inputs(seed=seed + 5, b=b, C=C, n=n)["x"]
+        with torch.no_grad():
+            y = conv(T(x))
+        idx = sample_idx(rng, y.shape, 8192)
+        arrs.update({"proj_%s_idx" % tag: idx, "proj_%s_val" % tag: y.reshape(-1)[T(idx)], "proj_%s_sum" % tag: y.double().sum((1, 2))})
+    save("heads.npz", **arrs)
+
+
 def gen_roofline(R):
     """BASELINE.json configs[4] through the reference itself: cost einsum at [1,448,4096]^2, then
     log_optimal_transport on 4097x4097 with 200 iterations (modules.py:145-162; ~10 s on 8 cores).  Stored:
@@ -569,6 +611,9 @@ def main():
     if only == ["gnn"]:
         gen_gnn(R)
         return
+    if only == ["heads"]:
+        gen_heads(R)
+        return
     gen_kat(R)
     gen_sinkhorn_raw(R)
     gen_ties(R)
@@ -591,6 +636,7 @@ def main():
     gen_result(R, "result_mixed.npz", synth.SEED + 11, True)
     gen_attention(R)
     gen_gnn(R)
+    gen_heads(R)
     gen_pipeline(R, "pipeline_outdoor.npz", synth.SEED + 40, 5, 6, True, True, True)
     gen_pipeline(R, "pipeline_indoor.npz", synth.SEED + 41, 4, 5, False, False, False)
     gen_pipeline(R, "pipeline_640x480_outdoor.npz", synth.SEED + 50, 15, 20, True, True, True)
