@@ -4,7 +4,7 @@
 Draws random shapes / seeds for every op of the path and compares the C-ABI result with
 oracle/pats_oracle.c under the gates of tests/test_gpu_parity.py.  Prints one line per failing case
 (op, seed, shape) and a summary; exit code 1 if anything failed.
-usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
+usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops conv,attention,sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
 """
 import argparse
 import os
@@ -276,7 +276,36 @@ def op_attention(rng):
     return "b=%d dim=%d heads=%d n=%d m=%d prob=%d" % (b, dim, heads, n, m, want_prob)
 
 
-OPS = {"attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
+def op_conv(rng):
+    """Conv1d(k=1) with every optional of pats_conv1x1_f32, and the folded batch statistics (pats_bn_fold_f32)."""
+    b, n = int(rng.integers(1, 6)), int(rng.integers(1, 400))
+    K, M = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    amp = float(rng.choice([0.1, 1.0, 10.0]))
+    x = (amp * rng.standard_normal((b, K, n))).astype(np.float32)
+    w = (rng.standard_normal((M, K, 1)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(M).astype(np.float32) if rng.integers(0, 2) else None
+    res = rng.standard_normal((b, M, n)).astype(np.float32) if rng.integers(0, 2) else None
+    fold = bool(rng.integers(0, 2))
+    xa = x
+    sc = sh = None
+    if fold:
+        gam = rng.uniform(0.5, 1.5, K).astype(np.float32); bet = rng.standard_normal(K).astype(np.float32)
+        sc, sh = ops.bn_fold(cu(x), cu(gam), cu(bet), 1e-5)
+        mean = x.astype(np.float64).mean((0, 2)); var = x.astype(np.float64).var((0, 2))
+        s64 = gam / np.sqrt(var + 1e-5)
+        np.testing.assert_allclose(sc.cpu().numpy(), s64, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(sh.cpu().numpy(), bet - mean * s64, rtol=2e-4, atol=2e-5 * max(1.0, amp))
+        xa = np.maximum(x * sc.cpu().numpy()[None, :, None] + sh.cpu().numpy()[None, :, None], 0).astype(np.float32)
+    y = ops.conv1d(cu(x), cu(w), None if bias is None else cu(bias), sc, sh, None if res is None else cu(res)).cpu().numpy()
+    want = oracle.conv1d(xa, w, bias)
+    if res is not None:
+        want = want + res
+    scale = max(1.0, float(np.abs(xa).max()))
+    np.testing.assert_allclose(y, want, atol=3e-6 * scale * np.sqrt(K) + 1e-6, rtol=2e-5)
+    return "b=%d K=%d M=%d n=%d amp=%g bias=%d res=%d fold=%d" % (b, K, M, n, amp, bias is not None, res is not None, fold)
+
+
+OPS = {"conv": op_conv, "attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
        "resize": op_resize, "merge": op_merge, "result": op_result, "third": op_third}
 
 
