@@ -365,6 +365,16 @@ size_t pats_bn_fold_workspace_bytes(int C);
 int pats_bn_fold_f32(const float* h, int64_t batch, int C, int n, const float* gamma, const float* beta, float eps,
                      float* scale, float* shift, void* workspace, size_t workspace_bytes, pats_stream_t stream);
 
+/* ---- the scale head: target descriptors -> the OT problem's column marginals `ns` -------------------------------------
+ * Replaces  scale = exp(sigmoid(proj(desc1[:, :, :h*w] as [b,C,h,w])) * ln256 - ln256 / 2)  with proj = nn.Conv2d(C, 1,
+ * kernel_size=3, padding=1):  models/first_layer.py:39-40,106-107 (scalex_proj, 15x20 grid);  models/second_layer.py:33-36,
+ * 92-98 (scalex_proj and scaley_proj on the 12x12 grid, scale = scale_x * scale_y: heads = 2);  models/third_layer.py:88-89,
+ * 151-152 (scale_proj, 8x8).  x [batch,C,ld] is the tensor the cost build takes (ld = h*w, or h*w + 1 with the dustbin
+ * feature column, which the heads skip); weight [heads][C][3][3] = the Conv2d weights concatenated over heads; bias
+ * [heads]; out [batch][h*w] is `ns` as log_optimal_transport / log_optimal_transport2 take it.  h*w <= 512. */
+int pats_scale_head_f32(const float* x, int64_t batch, int C, int ld, int h, int w, const float* weight,
+                        const float* bias, int heads, float* out, pats_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1128,3 +1128,36 @@ void oracle_attentional_propagation(const float* x, const float* source, int64_t
         for (size_t e = 0; e < qn; ++e) out[e] = residual[e] + out[e];
     free(q); free(k); free(v); free(att); free(msg); free(cat); free(hid);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * The scale head: nn.Conv2d(C, 1, kernel_size=3, padding=1) on the descriptor grid, then
+ * exp(sigmoid(v) * log(256) - log(256) / 2); two heads multiply (reference models/first_layer.py:106-107,
+ * models/second_layer.py:92-98, models/third_layer.py:151-152).  x [b][C][ld], the grid is its first h*w columns;
+ * weight [heads][C][3][3]; out [b][h*w].  The stencil accumulates in double.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_scale_head(const float* x, int64_t b, int C, int ld, int h, int w, const float* weight, const float* bias,
+                       int heads, float* out) {
+    const float ln256 = (float)5.545177444479562, half = (float)2.772588722239781;
+#pragma omp parallel for schedule(static)
+    for (int64_t bi = 0; bi < b; ++bi)
+        for (int py = 0; py < h; ++py)
+            for (int px = 0; px < w; ++px) {
+                float s = 1.0f;
+                for (int hd = 0; hd < heads; ++hd) {
+                    double acc = 0.0;
+                    for (int c = 0; c < C; ++c)
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int yy = py + ky - 1, xx = px + kx - 1;
+                                if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                                acc += (double)weight[(((int64_t)hd * C + c) * 3 + ky) * 3 + kx] *
+                                       (double)x[(bi * C + c) * (int64_t)ld + yy * w + xx];
+                            }
+                    const float v = (float)acc + bias[hd];
+                    const float sig = 1.0f / (1.0f + expf(-v));
+                    const float e = expf(sig * ln256 - half);
+                    s = hd == 0 ? e : s * e;
+                }
+                out[bi * (int64_t)(h * w) + py * w + px] = s;
+            }
+}

@@ -383,3 +383,15 @@ def keypoint_encoder(kpts, state, prefix="encoder.", bn_train=False, eps=1e-5):
     """KeypointEncoder.forward (modules.py:77-82): kpts [n,2] -> [1, feature_dim, n]."""
     k = np.ascontiguousarray(np.asarray(kpts, np.float32).T.reshape(1, 2, -1))
     return mlp(k, state, prefix, bn_train, eps)
+
+
+def scale_head(desc1, h, w, weights, biases):
+    """exp(sigmoid(Conv2d(C, 1, 3, padding=1)(desc1[:, :, :h*w] as [b,C,h,w])) * ln256 - ln256 / 2), heads multiplied
+    (first_layer.py:106-107, second_layer.py:92-98, third_layer.py:151-152) -> [b,1,h*w]."""
+    x, px = _f(desc1)
+    b, C, ld = x.shape
+    wt, pw = _f(np.concatenate([np.asarray(v, np.float32).reshape(1, C, 3, 3) for v in weights], 0))
+    bs, pb = _f(np.concatenate([np.asarray(v, np.float32).reshape(1) for v in biases]))
+    out = np.empty((b, 1, h * w), np.float32)
+    lib().oracle_scale_head(px, ctypes.c_int64(b), C, ld, int(h), int(w), pw, pb, len(weights), _p(out, c_f))
+    return out

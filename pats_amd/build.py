@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpats_amd.so")
 SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip", "gnn.hip",
-           "fused.hip"]
+           "fused.hip", "scale_head.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 # third_fused.hip runs at the 168-VGPR edge (three waves per SIMD).  The SLP vectoriser pairs the

@@ -276,3 +276,12 @@ def final_proj_params(seed=SEED + 110, C=448):
     rng = np.random.default_rng(seed)
     k = 1.0 / np.sqrt(C)
     return {"weight": rng.uniform(-k, k, (C, C, 1)).astype(np.float32), "bias": rng.uniform(-k, k, (C,)).astype(np.float32)}
+
+
+def scale_head_params(seed=SEED + 120, C=128, heads=1):
+    """nn.Conv2d(C, 1, kernel_size=3, padding=1) per head (first_layer.py:39-40, second_layer.py:33-36, third_layer.py:88-89):
+    lists (weights [1,C,3,3], biases [1])."""
+    rng = np.random.default_rng(seed)
+    k = 1.0 / np.sqrt(9.0 * C)
+    return ([rng.uniform(-k, k, (1, C, 3, 3)).astype(np.float32) for _ in range(heads)],
+            [rng.uniform(-k, k, (1,)).astype(np.float32) for _ in range(heads)])

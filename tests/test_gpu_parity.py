@@ -1037,6 +1037,42 @@ def test_final_proj_golden(ops, oracle, tag, C, b, n, seed):
     np.testing.assert_allclose(S, oracle.cost(y, y), atol=3e-5, rtol=1e-5)
 
 
+SCALE_CASES = [("first", 448, 2, 15, 20, 1, False, synth.SEED + 120), ("second", 264, 6, 12, 12, 2, True, synth.SEED + 121),
+               ("third", 128, 40, 8, 8, 1, True, synth.SEED + 122)]
+
+
+@pytest.mark.parametrize("tag,C,b,h,w,heads,dust,seed", SCALE_CASES)
+def test_scale_head_golden(ops, oracle, tag, C, b, h, w, heads, dust, seed):
+    """The 3 x 3 stencil + sigmoid / exp that makes `ns` (first_layer.py:106-107, second_layer.py:92-98, third_layer.py:151-152),
+    against the reference expression on nn.Conv2d and against the oracle; its result is what the OT takes."""
+    g = golden("heads.npz")
+    ws, bs = synth.scale_head_params(seed=seed, C=C, heads=heads)
+    x = (4.0 * synth.gnn_inputs(seed=seed + 5, b=b, C=C, n=h * w + int(dust))["x"]).astype(np.float32)
+    y = ops.scale_head(cu(x), h, w, [cu(v) for v in ws], [cu(v) for v in bs])
+    assert y.shape == (b, 1, h * w)
+    np.testing.assert_allclose(y.cpu().numpy(), g["scale_%s" % tag], rtol=3e-5)
+    np.testing.assert_allclose(y.cpu().numpy(), oracle.scale_head(x, h, w, ws, bs), rtol=3e-5)
+    if tag == "third":          # straight into the solver, as third_layer.py:157-158 does
+        S = ops.cost(cu(x), cu(x))
+        Z = ops.log_optimal_transport2(S, 1.0, y, 100)
+        _check_marginals(Z, y, float(h * w))
+
+
+def test_scale_head_edge_cases(ops, oracle):
+    rng = np.random.default_rng(9)
+    for (b, C, h, w, ld, heads) in [(3, 5, 1, 1, 1, 1), (2, 17, 1, 7, 9, 2), (1, 40, 16, 32, 512, 1), (5, 33, 3, 2, 6, 2)]:
+        x = rng.standard_normal((b, C, ld)).astype(np.float32)
+        ws = [rng.standard_normal((1, C, 3, 3)).astype(np.float32) * 0.2 for _ in range(heads)]
+        bs = [rng.standard_normal(1).astype(np.float32) for _ in range(heads)]
+        y = ops.scale_head(cu(x), h, w, [cu(v) for v in ws], [cu(v) for v in bs]).cpu().numpy()
+        np.testing.assert_allclose(y, oracle.scale_head(x, h, w, ws, bs), rtol=3e-5)
+    assert ops.scale_head(cu(x[:0]), 3, 2, [cu(v) for v in ws], [cu(v) for v in bs]).shape == (0, 1, 6)
+    with pytest.raises(RuntimeError):
+        ops.scale_head(cu(x), 3, 3, [cu(v) for v in ws], [cu(v) for v in bs])           # 9 cells > ld = 6
+    with pytest.raises(RuntimeError):
+        ops.scale_head(cu(np.zeros((1, 4, 600), np.float32)), 20, 30, cu(np.zeros((1, 4, 3, 3), np.float32)), cu(np.zeros(1, np.float32)))
+
+
 def test_conv1d_edge_cases(ops, oracle):
     rng = np.random.default_rng(4)
     # no bias, ragged channel counts (K = 5 is padded to 8 inside), residual, folded input affine + ReLU

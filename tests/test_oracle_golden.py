@@ -360,3 +360,21 @@ def test_final_proj_against_torch_conv1d(oracle, tag, C, b, n, seed):
     y = oracle.conv1d(x, p["weight"], p["bias"])
     np.testing.assert_allclose(y.reshape(-1)[g["proj_%s_idx" % tag]], g["proj_%s_val" % tag], atol=1e-5, rtol=1e-4)
     np.testing.assert_allclose(y.astype(np.float64).sum((1, 2)), g["proj_%s_sum" % tag], atol=2e-2, rtol=1e-4)
+
+
+SCALE_CASES = [("first", 448, 2, 15, 20, 1, False, synth.SEED + 120), ("second", 264, 6, 12, 12, 2, True, synth.SEED + 121),
+               ("third", 128, 40, 8, 8, 1, True, synth.SEED + 122)]
+
+
+@pytest.mark.parametrize("tag,C,b,h,w,heads,dust,seed", SCALE_CASES)
+def test_scale_head_against_torch_conv2d(oracle, tag, C, b, h, w, heads, dust, seed):
+    """first_layer.py:106-107 / second_layer.py:92-98 / third_layer.py:151-152 re-executed on nn.Conv2d (tools/make_golden.py)."""
+    g = golden("heads.npz")
+    ws, bs = synth.scale_head_params(seed=seed, C=C, heads=heads)
+    x = (4.0 * synth.gnn_inputs(seed=seed + 5, b=b, C=C, n=h * w + int(dust))["x"]).astype(np.float32)
+    assert abs(synth.checksum(x, ws[0]) - float(g["scale_%s_checksum" % tag])) < 1e-6 * max(1.0, abs(float(g["scale_%s_checksum" % tag])))
+    y = oracle.scale_head(x, h, w, ws, bs)
+    want = g["scale_%s" % tag]
+    assert y.shape == want.shape == (b, 1, h * w)
+    assert want.min() >= (1 / 16) ** heads * (1 - 1e-5) and want.max() <= 16.0 ** heads * (1 + 1e-5) and want.std() > 0.05    # a non-trivial fixture
+    np.testing.assert_allclose(y, want, rtol=2e-5)

@@ -577,6 +577,25 @@ def gen_heads(R):
             y = conv(T(x))
         idx = sample_idx(rng, y.shape, 8192)
         arrs.update({"proj_%s_idx" % tag: idx, "proj_%s_val" % tag: y.reshape(-1)[T(idx)], "proj_%s_sum" % tag: y.double().sum((1, 2))})
+    # the scale heads: the expressions of first_layer.py:106-107, second_layer.py:92-98 and third_layer.py:151-152, re-executed
+    # on nn.Conv2d(C, 1, kernel_size=3, padding=1) modules as the layers build them
+    sigmoid = torch.nn.Sigmoid()
+    for tag, C, b, (h, w), heads, dust, seed in (("first", 448, 2, (15, 20), 1, False, synth.SEED + 120),
+                                                 ("second", 264, 6, (12, 12), 2, True, synth.SEED + 121),
+                                                 ("third", 128, 40, (8, 8), 1, True, synth.SEED + 122)):
+        ws, bs = synth.scale_head_params(seed=seed, C=C, heads=heads)
+        mdesc1 = T((4.0 * synth.gnn_inputs(seed=seed + 5, b=b, C=C, n=h * w + int(dust))["x"]).astype(np.float32))
+        grid = (mdesc1[:, :, :-1] if dust else mdesc1[:, :, :]).reshape(mdesc1.shape[0], -1, h, w)
+        scale = None
+        for wv, bv in zip(ws, bs):
+            proj = torch.nn.Conv2d(in_channels=C, out_channels=1, kernel_size=3, padding=1, stride=1, bias=True)
+            proj.load_state_dict({"weight": T(wv), "bias": T(bv)})
+            with torch.no_grad():
+                sc = proj(grid).reshape(mdesc1.shape[0], -1, h * w)
+                sc = torch.exp(sigmoid(sc) * math.log(256.0) - math.log(256.0) / 2)
+            scale = sc if scale is None else scale * sc
+        arrs["scale_%s" % tag] = scale
+        arrs["scale_%s_checksum" % tag] = synth.checksum(npy(mdesc1), ws[0])
     save("heads.npz", **arrs)
 
 
