@@ -4,7 +4,7 @@
 Draws random shapes / seeds for every op of the path and compares the C-ABI result with
 oracle/pats_oracle.c under the gates of tests/test_gpu_parity.py.  Prints one line per failing case
 (op, seed, shape) and a summary; exit code 1 if anything failed.
-usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops conv,attention,sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
+usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops scale,conv,attention,sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
 """
 import argparse
 import os
@@ -305,7 +305,22 @@ def op_conv(rng):
     return "b=%d K=%d M=%d n=%d amp=%g bias=%d res=%d fold=%d" % (b, K, M, n, amp, bias is not None, res is not None, fold)
 
 
-OPS = {"conv": op_conv, "attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
+def op_scale(rng):
+    """The scale head (pats_scale_head_f32) on random grids, channel counts, one or two heads, with / without the dustbin column."""
+    h, w = int(rng.integers(1, 23)), int(rng.integers(1, 23))
+    b, C, heads = int(rng.integers(1, 9)), int(rng.integers(1, 300)), int(rng.integers(1, 3))
+    ld = h * w + int(rng.integers(0, 3))
+    amp = float(rng.choice([0.3, 1.0, 4.0]))
+    x = (amp * rng.standard_normal((b, C, ld))).astype(np.float32)
+    ws = [(rng.standard_normal((1, C, 3, 3)) / np.sqrt(9.0 * C)).astype(np.float32) for _ in range(heads)]
+    bs = [rng.standard_normal(1).astype(np.float32) for _ in range(heads)]
+    y = ops.scale_head(cu(x), h, w, [cu(v) for v in ws], [cu(v) for v in bs]).cpu().numpy()
+    # d(out)/out = ln256 * sigmoid' * dv <= 1.4 dv; dv ~ a few ulp of the stencil sum
+    np.testing.assert_allclose(y, oracle.scale_head(x, h, w, ws, bs), rtol=2e-5 * max(1.0, amp))
+    return "b=%d C=%d %dx%d ld=%d heads=%d amp=%g" % (b, C, h, w, ld, heads, amp)
+
+
+OPS = {"scale": op_scale, "conv": op_conv, "attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
        "resize": op_resize, "merge": op_merge, "result": op_result, "third": op_third}
 
 
