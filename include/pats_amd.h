@@ -371,9 +371,11 @@ int pats_bn_fold_f32(const float* h, int64_t batch, int C, int n, const float* g
  * 92-98 (scalex_proj and scaley_proj on the 12x12 grid, scale = scale_x * scale_y: heads = 2);  models/third_layer.py:88-89,
  * 151-152 (scale_proj, 8x8).  x [batch,C,ld] is the tensor the cost build takes (ld = h*w, or h*w + 1 with the dustbin
  * feature column, which the heads skip); weight [heads][C][3][3] = the Conv2d weights concatenated over heads; bias
- * [heads]; out [batch][h*w] is `ns` as log_optimal_transport / log_optimal_transport2 take it.  h*w <= 512. */
+ * [heads]; out [batch][h*w] is `ns` as log_optimal_transport / log_optimal_transport2 take it; per_head (optional, NULL to
+ * skip) [batch][heads][h*w] receives the heads on their own - scale_x and scale_y, which SecondLayer.est_position takes
+ * separately (second_layer.py:116-117).  h*w <= 512. */
 int pats_scale_head_f32(const float* x, int64_t batch, int C, int ld, int h, int w, const float* weight,
-                        const float* bias, int heads, float* out, pats_stream_t stream);
+                        const float* bias, int heads, float* out, float* per_head, pats_stream_t stream);
 
 #ifdef __cplusplus
 }

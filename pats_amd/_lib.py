@@ -89,7 +89,8 @@ SIGNATURES = {
     "pats_bn_fold_workspace_bytes": (c_size, [c_int]),
     "pats_bn_fold_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_f, c_void_p, c_void_p, c_void_p,
                                  c_size, c_void_p]),
-    "pats_scale_head_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pats_scale_head_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p]),
     "pats_get_result_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
     "pats_get_result_f32": (c_int, [c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                                     ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p,

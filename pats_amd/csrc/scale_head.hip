@@ -26,7 +26,7 @@ constexpr float LN256 = 5.545177444479562f, HALF_LN256 = 2.772588722239781f;    
 template <int HEADS, int CELLS>
 __global__ void __launch_bounds__(SH_THREADS)
 scale_head_kernel(const float* __restrict__ x, int C, int ld, int h, int w, const float* __restrict__ weight,
-                  const float* __restrict__ bias, float* __restrict__ out) {
+                  const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ per_head) {
     extern __shared__ float sm[];                    // [HEADS * 9][hw + 1]; slot hw of a plane = the zero the border taps read
     const int hw = h * w, row = hw + 1;
     const int64_t b = blockIdx.x;
@@ -88,6 +88,7 @@ scale_head_kernel(const float* __restrict__ x, int C, int ld, int h, int w, cons
             const float sig = 1.0f / (1.0f + expf(-v));                  // nn.Sigmoid
             const float e = expf(sig * LN256 - HALF_LN256);
             s = hd == 0 ? e : s * e;                                      // scale_x * scale_y (second_layer.py:98)
+            if (per_head) per_head[(b * HEADS + hd) * hw + p] = e;        // scale_x, scale_y on their own (est_position takes them)
         }
         out[b * hw + p] = s;
     }
@@ -100,7 +101,7 @@ scale_head_kernel(const float* __restrict__ x, int C, int ld, int h, int w, cons
 using namespace pats;
 
 extern "C" int pats_scale_head_f32(const float* x, int64_t batch, int C, int ld, int h, int w, const float* weight,
-                                   const float* bias, int heads, float* out, pats_stream_t stream) {
+                                   const float* bias, int heads, float* out, float* per_head, pats_stream_t stream) {
     PATS_REQUIRE(batch >= 0 && C > 0 && h > 0 && w > 0 && ld >= h * w, "scale_head: bad shape");
     PATS_REQUIRE(h * w <= 2 * SH_THREADS, "scale_head: grid of %d cells exceeds %d", h * w, 2 * SH_THREADS);
     PATS_REQUIRE(heads == 1 || heads == 2, "scale_head: one head (first / third layer) or two (second layer: x, y)");
@@ -111,7 +112,7 @@ extern "C" int pats_scale_head_f32(const float* x, int64_t batch, int C, int ld,
     const size_t lds = (size_t)heads * 9 * (hw + 1) * sizeof(float);        // at most 2 heads x 9 planes x 513 floats = 36.9 KB
     const dim3 grid((unsigned)batch), block(SH_THREADS);
     hipStream_t st = as_stream(stream);
-#define PATS_SH_LAUNCH(HD, CL) hipLaunchKernelGGL((scale_head_kernel<HD, CL>), grid, block, lds, st, x, C, ld, h, w, weight, bias, out)
+#define PATS_SH_LAUNCH(HD, CL) hipLaunchKernelGGL((scale_head_kernel<HD, CL>), grid, block, lds, st, x, C, ld, h, w, weight, bias, out, per_head)
     if (heads == 1) {
         if (hw <= 64) PATS_SH_LAUNCH(1, 1); else if (hw <= 192) PATS_SH_LAUNCH(1, 3); else if (hw <= 320) PATS_SH_LAUNCH(1, 5); else PATS_SH_LAUNCH(1, 8);
     } else {

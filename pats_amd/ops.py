@@ -928,12 +928,13 @@ def keypoint_encoder(kpts, params, bn_train=False):
     return mlp(inputs, params, bn_train)
 
 
-def scale_head(desc1, height, width, weights, biases):
+def scale_head(desc1, height, width, weights, biases, return_heads=False):
     """The scale head of a layer -> `ns` [b,1,h*w] of its OT problems:
         exp(sigmoid(proj(desc1[:, :, :h*w].reshape(b, C, h, w))) * log(256) - log(256) / 2),  proj = nn.Conv2d(C, 1, 3, padding=1)
     first_layer.py:106-107 (weights = [scalex_proj.weight]); second_layer.py:92-98 (weights = [scalex_proj.weight,
     scaley_proj.weight]: the product scale_x * scale_y); third_layer.py:151-152 ([scale_proj.weight]).  desc1 [b,C,ld]
-    with ld = h*w or h*w + 1 (the dustbin feature column is skipped like `[:, :, :-1]`)."""
+    with ld = h*w or h*w + 1 (the dustbin feature column is skipped like `[:, :, :-1]`).  return_heads: also the list of
+    the heads on their own ([b,1,h*w] each: scale_x, scale_y of second_layer.py:92-97, which est_position takes separately)."""
     desc1 = _dev(desc1, "desc1")
     b, C, ld = desc1.shape
     if not isinstance(weights, (list, tuple)):
@@ -942,6 +943,9 @@ def scale_head(desc1, height, width, weights, biases):
     wt = torch.cat([_dev(wg, "weight").reshape(1, C, 3, 3) for wg in weights], dim=0).contiguous()
     bs = torch.cat([_dev(bi, "bias").reshape(1) for bi in biases]).contiguous()
     out = torch.empty((b, 1, height * width), dtype=torch.float32, device=desc1.device)
+    per = torch.empty((b, heads, height * width), dtype=torch.float32, device=desc1.device) if return_heads else None
     _check(_L().pats_scale_head_f32(_ptr(desc1), b, C, ld, int(height), int(width), _ptr(wt), _ptr(bs), heads, _ptr(out),
-                                    _stream()), "scale_head")
+                                    _ptr(per), _stream()), "scale_head")
+    if return_heads:
+        return out, [per[:, i:i + 1, :] for i in range(heads)]
     return out

@@ -1052,6 +1052,10 @@ def test_scale_head_golden(ops, oracle, tag, C, b, h, w, heads, dust, seed):
     assert y.shape == (b, 1, h * w)
     np.testing.assert_allclose(y.cpu().numpy(), g["scale_%s" % tag], rtol=3e-5)
     np.testing.assert_allclose(y.cpu().numpy(), oracle.scale_head(x, h, w, ws, bs), rtol=3e-5)
+    y2, per = ops.scale_head(cu(x), h, w, [cu(v) for v in ws], [cu(v) for v in bs], return_heads=True)
+    assert torch.equal(y2, y) and len(per) == heads
+    for i in range(heads):      # scale_x, scale_y on their own (second_layer.py:92-97)
+        np.testing.assert_allclose(per[i].cpu().numpy(), oracle.scale_head(x, h, w, ws[i:i + 1], bs[i:i + 1]), rtol=3e-5)
     if tag == "third":          # straight into the solver, as third_layer.py:157-158 does
         S = ops.cost(cu(x), cu(x))
         Z = ops.log_optimal_transport2(S, 1.0, y, 100)
