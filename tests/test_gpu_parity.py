@@ -1077,6 +1077,75 @@ def test_scale_head_edge_cases(ops, oracle):
         ops.scale_head(cu(np.zeros((1, 4, 600), np.float32)), 20, 30, cu(np.zeros((1, 4, 3, 3), np.float32)), cu(np.zeros(1, np.float32)))
 
 
+def _oracle_gnn(oracle, d0, d1, layers, names, bn_train=False):
+    for p, name in zip(layers, names):
+        s0, s1 = (d1, d0) if name == "cross" else (d0, d1)
+        d0, d1 = (oracle.attentional_propagation(d0, s0, p, bn_train=bn_train, residual=d0),
+                  oracle.attentional_propagation(d1, s1, p, bn_train=bn_train, residual=d1))
+    return d0, d1
+
+
+def test_layer_heads_against_the_oracle_chain(ops, oracle):
+    """pats_amd.heads: everything a layer computes between its backbone and its OT problem (first_layer.py:74-107,
+    second_layer.py:71-97, third_layer.py:121-152), each against the same composition of oracle functions - and the coarse
+    one on into the solver."""
+    from pats_amd import heads
+    names = ["self", "cross"]
+    dev = lambda t: [cu(v) for v in t] if isinstance(t, (list, tuple)) else cu(t)
+    # ---- coarse: 448 channels, 5 x 6 grid -------------------------------------------------------------------------------
+    h, w, C = 5, 6, 448
+    kp = synth.kenc_params(seed=1, feature_dim=C)
+    gp = [synth.gnn_params(seed=2 + i, C=C) for i in range(2)]
+    fp = synth.final_proj_params(seed=5, C=C)
+    (sw,), (sb,) = synth.scale_head_params(seed=6, C=C)
+    rng = np.random.default_rng(7)
+    dl = rng.standard_normal((1, C, h, w)).astype(np.float32); dr = rng.standard_normal((1, C, h, w)).astype(np.float32)
+    H1 = heads.CoarseHeads(ops.MLPParams(kp, prefix="encoder."), [ops.PropagationParams(p) for p in gp], names,
+                           (cu(fp["weight"]), cu(fp["bias"])), (cu(sw), cu(sb)), bin_score=-0.25)
+    m0, m1, scale, alpha = H1(cu(dl), cu(dr))
+    k = oracle.keypoint_encoder(synth.grid_kpts(h, w), kp)
+    assert np.array_equal(heads.grid_kpts(h, w, "cuda").cpu().numpy(), synth.grid_kpts(h, w))
+    o0, o1 = _oracle_gnn(oracle, dl.reshape(1, C, -1) + k, dr.reshape(1, C, -1) + k, gp, names)
+    w0, w1 = oracle.conv1d(o0, fp["weight"], fp["bias"]), oracle.conv1d(o1, fp["weight"], fp["bias"])
+    np.testing.assert_allclose(m0.cpu().numpy(), w0, atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(m1.cpu().numpy(), w1, atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(scale.cpu().numpy(), oracle.scale_head(w1, h, w, [sw], [sb]), rtol=2e-3)
+    assert alpha == 0.25
+    Z = ops.cost_ot(m0, m1, 1, alpha, scale, 100)                       # first_layer.py:110-115 on the heads' outputs
+    _check_marginals(Z, scale, float(h * w))
+    # ---- fine: the sampled descriptors of three crops ---------------------------------------------------------------------
+    fm = synth.fine_maps(seed=8, B=3)
+    gp2 = [synth.gnn_params(seed=9 + i, C=264) for i in range(2)]
+    fp2 = synth.final_proj_params(seed=12, C=264)
+    (sxw, syw), (sxb, syb) = synth.scale_head_params(seed=13, C=264, heads=2)
+    H2 = heads.FineHeads([ops.PropagationParams(p) for p in gp2], names, (cu(fp2["weight"]), cu(fp2["bias"])),
+                         (cu(sxw), cu(sxb)), (cu(syw), cu(syb)))
+    m0, m1, sx, sy = H2([cu(fm["f0"]), cu(fm["f1"]), cu(fm["f2"])], cu(fm["title"]), cu(fm["rubbish"]))
+    d = oracle.fine_descriptors(fm["f0"], fm["f1"], fm["f2"], fm["title"], fm["rubbish"])
+    o0, o1 = _oracle_gnn(oracle, d[0], d[1], gp2, names)
+    w0, w1 = oracle.conv1d(o0, fp2["weight"], fp2["bias"]), oracle.conv1d(o1, fp2["weight"], fp2["bias"])
+    np.testing.assert_allclose(m0.cpu().numpy(), w0, atol=3e-4, rtol=3e-4)
+    np.testing.assert_allclose(m1.cpu().numpy(), w1, atol=3e-4, rtol=3e-4)
+    np.testing.assert_allclose(sx.cpu().numpy(), oracle.scale_head(w1, 12, 12, [sxw], [sxb]), rtol=2e-3)
+    np.testing.assert_allclose(sy.cpu().numpy(), oracle.scale_head(w1, 12, 12, [syw], [syb]), rtol=2e-3)
+    # ---- third: window gather + KeypointEncoder, GNN on batch statistics, scale head ----------------------------------------
+    tm = synth.third_maps(seed=14, B=3, P=40)
+    kp3 = synth.kenc_params(seed=15, feature_dim=128)
+    gp3 = [synth.gnn_params(seed=16 + i, C=128) for i in range(2)]
+    (s3w,), (s3b,) = synth.scale_head_params(seed=19, C=128)
+    for train in (False, True):
+        H3 = heads.ThirdHeads(ops.MLPParams(kp3, prefix="encoder."), [ops.PropagationParams(p) for p in gp3], names,
+                              (cu(s3w), cu(s3b)), bn_train=train)
+        f0, f1, sc, ps, pt = H3(cu(tm["ff0"]), cu(tm["ff1"]), cu(tm["mk0"]), cu(tm["mk1"]), cu(tm["b_ids"]), cu(tm["rubbish"]))
+        k3 = oracle.keypoint_encoder(synth.grid_kpts(8, 8), kp3, bn_train=train)
+        u0, u1, ops_, opt = oracle.third_descriptors(tm["ff0"], tm["ff1"], tm["mk0"], tm["mk1"], tm["b_ids"], k3, tm["rubbish"])
+        assert np.array_equal(ps.cpu().numpy(), ops_) and np.array_equal(pt.cpu().numpy(), opt)
+        o0, o1 = _oracle_gnn(oracle, u0, u1, gp3, names, bn_train=train)
+        np.testing.assert_allclose(f0.cpu().numpy(), o0, atol=3e-4, rtol=3e-4)
+        np.testing.assert_allclose(f1.cpu().numpy(), o1, atol=3e-4, rtol=3e-4)
+        np.testing.assert_allclose(sc.cpu().numpy(), oracle.scale_head(o1, 8, 8, [s3w], [s3b]), rtol=2e-3)
+
+
 def test_conv1d_edge_cases(ops, oracle):
     rng = np.random.default_rng(4)
     # no bias, ragged channel counts (K = 5 is padded to 8 inside), residual, folded input affine + ReLU
