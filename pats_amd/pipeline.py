@@ -1,7 +1,7 @@
 """The control flow of PATS.forward (models/pats.py:18-85) and of the three layers' forward tails
 (first_layer.py:110-157, second_layer.py:100-124, third_layer.py:153-170) on the device-side ops
-of pats_amd, with the networks (ResNet / FPN / AttentionalGNN / projection heads - out of scope,
-DESIGN.md section 7) abstracted as three callbacks.
+of pats_amd, with what comes before them abstracted as three callbacks: the backbones (ResNet / FPN - out of scope,
+DESIGN.md section 7) followed by the heads, which pats_amd.heads provides (CoarseHeads / FineHeads / ThirdHeads).
 
 What changes against the reference's Python, and why it is equivalent:
   * every OT / expansion / gather / merge / result step is one C-ABI call (pats_amd.ops);
