@@ -282,6 +282,151 @@ conv_lean_kernel(ConvArgs g) {
     if (__any(bad) && lane == 0) atomicOr(g.redo, 1);
 }
 
+// WEIGHTS-STATIONARY variant of the lean tile for the third level's C x C products (128 channels in, one source, many
+// column tiles).  In conv_lean_kernel two thirds of the loads in flight re-fetch the 64 KB weight matrix for every 64-column
+// tile (counters: matrix pipe 11 % busy, waves waiting 71 % of their cycles).  Here ONE 1024-thread workgroup per CU - the
+// same 16 waves - splits its 128 x 128 weights ONCE into LDS (hi | lo planes, 64 KB) and walks column tiles; its four
+// 256-thread groups each own a 64-column tile and stream only activations, three 16-channel chunks in flight per thread
+// (a ring of four register slots), through a double-buffered 4 KB LDS stage per group.  The chunk
+// stream runs on across tile boundaries.  Same split, same fragment layout, same MFMA order and the same redo protocol
+// as conv_lean_kernel: the results are bit-identical to it.
+namespace {
+constexpr int WS_LC = 64;                            // columns per group tile
+constexpr int WS_NCH = 8;                            // chunks of 16 channels: K = 128
+constexpr int WS_KQ = 4 * WS_NCH;                    // channel quads
+}  // namespace
+
+__global__ void __launch_bounds__(1024)
+conv_ws_kernel(ConvArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_raw[];
+    uint2* la = reinterpret_cast<uint2*>(ws_raw);                    // [hi | lo][WS_KQ][LR]
+    uint2* lb_all = la + (size_t)2 * WS_KQ * LR;                     // [group][buffer][hi | lo][4][WS_LC]
+    const int t = threadIdx.x, grp = __builtin_amdgcn_readfirstlane(t >> 8), tt = t & 255;
+    const int lane = tt & 63, wave = __builtin_amdgcn_readfirstlane(tt >> 6);
+    const int li = lane & 31, kg = lane >> 5;
+    const int n = g.n, M = g.M;
+    constexpr int K = 16 * WS_NCH;
+    uint2* lb = lb_all + (size_t)grp * 2 * 2 * 4 * WS_LC;
+    // ---- the weights (rows 0..127 of the layer: M <= 128), all K channels, split once --------------------------------------
+    {
+        const int ar = t % LR, aq = t / LR;          // 1024 threads: rows x quads {aq} of every 32-channel step
+        const int arow = min(ar, M - 1);
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            const int q = k0 / 4 + aq;
+            const float* pw = g.wt + (int64_t)(4 * q) * M + arow;
+            uint2 hi, lo;
+            mt::split2(pw[0], pw[M], hi.x, lo.x);
+            mt::split2(pw[2 * (int64_t)M], pw[3 * (int64_t)M], hi.y, lo.y);
+            la[(0 * WS_KQ + q) * LR + ar] = hi;
+            la[(1 * WS_KQ + q) * LR + ar] = lo;
+        }
+    }
+    auto fraga = [&](int hl, int c, int idx) {       // chunk c: quads 4c + 2 kg, + 1
+        const uint2 e0 = la[(hl * WS_KQ + 4 * c + 2 * kg) * LR + idx], e1 = la[(hl * WS_KQ + 4 * c + 2 * kg + 1) * LR + idx];
+        return __builtin_bit_cast(mt::h8c, mt::u4c{e0.x, e0.y, e1.x, e1.y});
+    };
+    auto fragb = [&](int buf, int hl, int idx) {
+        const uint2* base = lb + ((size_t)(buf * 2 + hl) * 4 + 2 * kg) * WS_LC;
+        const uint2 e0 = base[idx], e1 = base[WS_LC + idx];
+        return __builtin_bit_cast(mt::h8c, mt::u4c{e0.x, e0.y, e1.x, e1.y});
+    };
+    const int64_t tiles_j = (g.cols + WS_LC - 1) / WS_LC;
+    const int64_t step = (int64_t)gridDim.x * 4;
+    const int bqd = tt / WS_LC, bc = tt % WS_LC;     // this thread's activation item: channel quad bqd of every chunk, column bc
+    auto tile_ptr = [&](int64_t ct) {                // channel 4 bqd of this thread's column in column tile ct
+        const unsigned cgs = (unsigned)min(ct * WS_LC + bc, g.cols - 1), bs = cgs / (unsigned)n, tk = cgs - bs * (unsigned)n;
+        return g.x0 + ((int64_t)bs * K + 4 * bqd) * n + tk;
+    };
+    float R[4][4];                                   // a ring of four chunks: 8 chunks per tile, so the slots line up across tiles
+    auto fetch = [&](const float* p, int c, float (&r)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = p[(16 * c + e) * n];
+    };
+    auto stash = [&](int buf, int c, const float (&r)[4]) {
+        float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        if (g.in_scale) {
+            const int kb = 16 * c + 4 * bqd;
+            r0 = fmaxf(fmaf(r0, g.in_scale[kb], g.in_shift[kb]), 0.f);
+            r1 = fmaxf(fmaf(r1, g.in_scale[kb + 1], g.in_shift[kb + 1]), 0.f);
+            r2 = fmaxf(fmaf(r2, g.in_scale[kb + 2], g.in_shift[kb + 2]), 0.f);
+            r3 = fmaxf(fmaf(r3, g.in_scale[kb + 3], g.in_shift[kb + 3]), 0.f);
+        }
+        uint2 hi, lo;
+        mt::split2(r0, r1, hi.x, lo.x); mt::split2(r2, r3, hi.y, lo.y);
+        lb[((size_t)(buf * 2 + 0) * 4 + bqd) * WS_LC + bc] = hi;
+        lb[((size_t)(buf * 2 + 1) * 4 + bqd) * WS_LC + bc] = lo;
+    };
+    bool bad = false;
+    // every group walks the same number of steps (the barriers are workgroup-wide); a group past the end works on a
+    // clamped tile and stores nothing
+    const int64_t first = (int64_t)blockIdx.x * 4 + grp;
+    const int64_t nsteps = (tiles_j + step - 1) / step;
+    const float* pcur = tile_ptr(min(first, tiles_j - 1));
+    fetch(pcur, 0, R[0]); fetch(pcur, 1, R[1]); fetch(pcur, 2, R[2]);
+    __syncthreads();                                 // the weights
+    stash(0, 0, R[0]);
+    __syncthreads();
+    for (int64_t it = 0; it < nsteps; ++it) {
+        const int64_t ct = first + it * step;
+        const bool live = ct < tiles_j;
+        const int64_t j0 = min(ct, tiles_j - 1) * WS_LC;
+        const float* pnext = tile_ptr(min(ct + step, tiles_j - 1));
+        mt::f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < WS_NCH; ++c) {
+            const int buf = c & 1;
+            // chunk c + 3 of the stream (this tile's, or the next tile's first chunks) into the slot chunk c - 1 left
+            if (c + 3 < WS_NCH) fetch(pcur, c + 3, R[(c + 3) % 4]);
+            else fetch(pnext, c + 3 - WS_NCH, R[(c + 3) % 4]);
+            __builtin_amdgcn_sched_barrier(0);
+            const mt::h8c ah = fraga(0, c, 32 * wave + li), al = fraga(1, c, 32 * wave + li);
+            mt::h8c bh[2], bl[2];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) { bh[tj] = fragb(buf, 0, 32 * tj + li); bl[tj] = fragb(buf, 1, 32 * tj + li); }
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[tj], acc[tj], 0, 0, 0);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[tj], acc[tj], 0, 0, 0);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[tj], acc[tj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            asm volatile("" :: "v"(ah), "v"(al));
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) asm volatile("" :: "v"(bh[tj]), "v"(bl[tj]));
+            __builtin_amdgcn_sched_barrier(0);
+            // the next chunk of the stream (chunk c + 1, or chunk 0 of the next tile) into the other LDS buffer
+            stash(buf ^ 1, (c + 1) % WS_NCH, R[(c + 1) % 4]);
+            __syncthreads();
+        }
+        if (live) {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                if (j0 + 32 * tj + li >= g.cols) continue;
+                const unsigned cg = (unsigned)(j0 + 32 * tj + li), b = cg / (unsigned)n, tkk = cg - b * (unsigned)n;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                    if (row < M) {
+                        const int64_t o = ((int64_t)b * M + row) * n + tkk;
+                        float v = acc[tj][e] * mt::UNSCALE;
+                        bad |= !(fabsf(v) <= 3.0e38f);
+                        if (g.bias) v += g.bias[row];
+                        if (g.residual) v = g.residual[o] + v;
+                        g.y[o] = v;
+                    }
+                }
+            }
+        }
+        pcur = pnext;
+    }
+    if (__any(bad) && lane == 0) atomicOr(g.redo, 1);
+}
+
 // BatchNorm1d in train mode (modules.py:66 inside MLP; the third layer's GNN runs it on batch statistics because
 // PATS.eval() does not reach it, pats.py:112-120): per channel over (batch, n), biased variance, then
 // scale = gamma / sqrt(var + eps), shift = beta - mean * scale.  Two passes, both in double and both in a fixed order
@@ -343,7 +488,28 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
     static const bool no_lean = [] { const char* e = getenv("PATS_CONV_LEAN"); return e && atoi(e) == 0; }();    // A/B switch
     PATS_REQUIRE(g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
     const bool lean = redo && !fp32_only && !no_lean && !(g.residual && g.residual == g.y);
-    if (lean) {
+    // weights-stationary tile: exactly 128 channels in from one source, at most 128 out, and enough column tiles for a
+    // persistent grid of 4 x CUs groups to pay (the third level: 26 325 tiles)
+    static const int ws_mode = [] { const char* e = getenv("PATS_CONV_WS"); return e ? atoi(e) : 1; }();     // A/B switch: 0 off, 2 = also on small grids (tests)
+    const bool ws = lean && ws_mode != 0 && g.K0 == 16 * WS_NCH && g.K1 == 0 && g.M <= LR && (g.cols >= 64 * 4096 || ws_mode == 2);
+    if (ws) {
+        static const int n_cu = [] {
+            int dev = 0, v = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+            return v > 0 ? v : 256;
+        }();
+        const size_t lds = (size_t)2 * WS_KQ * LR * sizeof(uint2) + (size_t)4 * 2 * 2 * 4 * WS_LC * sizeof(uint2);     // 64 + 32 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            PATS_REQUIRE(hipFuncSetAttribute((const void*)conv_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess,
+                         "conv_ws_kernel: cannot raise the dynamic LDS limit");
+            attr_set = true;
+        }
+        const int64_t tiles = (g.cols + WS_LC - 1) / WS_LC;
+        const int grid = (int)std::min<int64_t>(n_cu, (tiles + 3) / 4);
+        g.redo = redo;
+        hipLaunchKernelGGL(conv_ws_kernel, dim3((unsigned)grid), dim3(1024), lds, st, g);
+    } else if (lean) {
         static const int nt = getenv("PATS_CONV_NT") ? atoi(getenv("PATS_CONV_NT")) : 2;       // A/B switch: 2 or 4 column tiles
         const int lc = 32 * (nt == 4 ? 4 : 2);
         const int64_t lt = (int64_t)((g.M + LR - 1) / LR) * ((g.cols + lc - 1) / lc);

@@ -1146,6 +1146,61 @@ def test_layer_heads_against_the_oracle_chain(ops, oracle):
         np.testing.assert_allclose(sc.cpu().numpy(), oracle.scale_head(o1, 8, 8, [s3w], [s3b]), rtol=2e-3)
 
 
+def test_weights_stationary_conv_matches_the_lean_tile(ops, oracle):
+    """csrc/gnn.hip conv_ws_kernel (the third level's 128-channel products: weights split once per workgroup, activations
+    streamed) against the oracle, and bit for bit against the lean tile it replaces there (PATS_CONV_WS=0) - subprocesses,
+    the switch is read once per process."""
+    import subprocess
+    import tempfile
+    code = r'''
+import sys, os, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+from pats_amd import ops, synth
+import pats_oracle as oracle
+cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+out = {}
+# one whole layer at the third level's width, small batch (PATS_CONV_WS=2 takes the kernel at any size) against the oracle
+p = synth.gnn_params(seed=3, C=128); i = synth.gnn_inputs(seed=4, b=7, C=128, n=65)
+P = ops.PropagationParams(p)
+for train in (False, True):
+    y = ops.attentional_propagation(cu(i["x"]), cu(i["source"]), P, bn_train=train, residual=cu(i["x"])).cpu().numpy()
+    want = oracle.attentional_propagation(i["x"], i["source"], p, bn_train=train, residual=i["x"])
+    np.testing.assert_allclose(y, want, atol=1e-4, rtol=2e-4)
+    out["layer%%d" %% train] = y
+# a size over the kernel's own threshold with a ragged last tile, folded affine on the input, bias / residual variants, M < 128
+rng = np.random.default_rng(5)
+x = rng.standard_normal((4100, 128, 65)).astype(np.float32)            # 266 500 columns
+w = (rng.standard_normal((128, 128, 1)) / 11).astype(np.float32); bias = rng.standard_normal(128).astype(np.float32)
+sc = rng.uniform(0.5, 1.5, 128).astype(np.float32); sh = rng.standard_normal(128).astype(np.float32)
+res = rng.standard_normal((4100, 128, 65)).astype(np.float32)
+y = ops.conv1d(cu(x), cu(w), cu(bias), cu(sc), cu(sh), cu(res)).cpu().numpy()
+xa = np.maximum(x[-40:] * sc[None, :, None] + sh[None, :, None], 0).astype(np.float32)
+np.testing.assert_allclose(y[-40:], oracle.conv1d(xa, w, bias) + res[-40:], atol=5e-5, rtol=2e-4)
+out["conv"] = y[::97]
+y2 = ops.conv1d(cu(x), cu(w[:72]), None).cpu().numpy()                # 72 output rows: a partial row tile
+np.testing.assert_allclose(y2[:40], oracle.conv1d(x[:40], w[:72]), atol=5e-5, rtol=2e-4)
+np.testing.assert_allclose(y2[-40:], oracle.conv1d(x[-40:], w[:72]), atol=5e-5, rtol=2e-4)
+out["conv72"] = y2[::97]
+# operands beyond the fp16 range: the redo launch recomputes the product
+xb = x[:300].copy(); xb[5, 17, 3] = 3.0e4
+yb = ops.conv1d(cu(xb), cu(w), cu(bias)).cpu().numpy()
+assert np.isfinite(yb).all()
+np.testing.assert_allclose(yb[:8], oracle.conv1d(xb[:8], w, bias), atol=2e-2, rtol=2e-4)
+np.savez(sys.argv[1], **out)
+print("OK")
+''' % (REPO, REPO)
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("2", "0"):
+            path = os.path.join(d, "o%s.npz" % mode)
+            p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, PATS_CONV_WS=mode), capture_output=True,
+                               text=True, timeout=900)
+            assert p.returncode == 0 and "OK" in p.stdout, mode + ": " + p.stdout[-500:] + p.stderr[-2000:]
+            res[mode] = dict(np.load(path))
+    for k in res["2"]:
+        assert np.array_equal(res["2"][k], res["0"][k]), k          # same split, same MFMA order: the same bits
+
+
 def test_conv1d_edge_cases(ops, oracle):
     rng = np.random.default_rng(4)
     # no bias, ragged channel counts (K = 5 is padded to 8 inside), residual, folded input affine + ReLU
