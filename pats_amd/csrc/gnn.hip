@@ -292,12 +292,12 @@ conv_lean_kernel(ConvArgs g) {
 // as conv_lean_kernel: the results are bit-identical to it.
 namespace {
 constexpr int WS_LC = 64;                            // columns per group tile
-constexpr int WS_NCH = 8;                            // chunks of 16 channels: K = 128
-constexpr int WS_KQ = 4 * WS_NCH;                    // channel quads
 }  // namespace
 
+template <int WS_NCH, bool TWO>                     // chunks of 16 channels: K = 128 (8) or 256 (16); TWO: x | message, 128 + 128
 __global__ void __launch_bounds__(1024)
-conv_ws_kernel(ConvArgs g) {
+conv_ws_kernel(ConvArgs g, int row_tiles) {
+    constexpr int WS_KQ = 4 * WS_NCH;                // channel quads
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_raw[];
     uint2* la = reinterpret_cast<uint2*>(ws_raw);                    // [hi | lo][WS_KQ][LR]
     uint2* lb_all = la + (size_t)2 * WS_KQ * LR;                     // [group][buffer][hi | lo][4][WS_LC]
@@ -306,11 +306,13 @@ conv_ws_kernel(ConvArgs g) {
     const int li = lane & 31, kg = lane >> 5;
     const int n = g.n, M = g.M;
     constexpr int K = 16 * WS_NCH;
+    constexpr int NCH0 = TWO ? WS_NCH / 2 : WS_NCH;  // chunks of the first source (x | message: the second follows)
+    const int i0 = (int)(blockIdx.x % row_tiles) * LR;
     uint2* lb = lb_all + (size_t)grp * 2 * 2 * 4 * WS_LC;
     // ---- the weights (rows 0..127 of the layer: M <= 128), all K channels, split once --------------------------------------
     {
         const int ar = t % LR, aq = t / LR;          // 1024 threads: rows x quads {aq} of every 32-channel step
-        const int arow = min(ar, M - 1);
+        const int arow = min(i0 + ar, M - 1);
         for (int k0 = 0; k0 < K; k0 += 32) {
             const int q = k0 / 4 + aq;
             const float* pw = g.wt + (int64_t)(4 * q) * M + arow;
@@ -331,16 +333,20 @@ conv_ws_kernel(ConvArgs g) {
         return __builtin_bit_cast(mt::h8c, mt::u4c{e0.x, e0.y, e1.x, e1.y});
     };
     const int64_t tiles_j = (g.cols + WS_LC - 1) / WS_LC;
-    const int64_t step = (int64_t)gridDim.x * 4;
+    const int64_t step = (int64_t)(gridDim.x / row_tiles) * 4;
     const int bqd = tt / WS_LC, bc = tt % WS_LC;     // this thread's activation item: channel quad bqd of every chunk, column bc
-    auto tile_ptr = [&](int64_t ct) {                // channel 4 bqd of this thread's column in column tile ct
+    // element offset of channel 4 bqd of this thread's column in column tile ct - the same in both sources (equal shapes);
+    // 32 bits (launch_conv: batch * channels * n < 2^31), added to the wave-uniform base pointers
+    auto tile_off = [&](int64_t ct) {
         const unsigned cgs = (unsigned)min(ct * WS_LC + bc, g.cols - 1), bs = cgs / (unsigned)n, tk = cgs - bs * (unsigned)n;
-        return g.x0 + ((int64_t)bs * K + 4 * bqd) * n + tk;
+        return (bs * (unsigned)g.K0 + 4u * bqd) * (unsigned)n + tk;
     };
-    float R[4][4];                                   // a ring of four chunks: 8 chunks per tile, so the slots line up across tiles
-    auto fetch = [&](const float* p, int c, float (&r)[4]) {
+    float R[4][4];                                   // a ring of four chunks: 8 / 16 chunks per tile, so the slots line up across tiles
+    auto fetch = [&](unsigned off, int c, float (&r)[4]) {
+        const float* base = (TWO && c >= NCH0) ? g.x1 : g.x0;
+        const int cc = (TWO && c >= NCH0) ? c - NCH0 : c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = p[(16 * c + e) * n];
+        for (int e = 0; e < 4; ++e) r[e] = base[off + (unsigned)((16 * cc + e) * n)];
     };
     auto stash = [&](int buf, int c, const float (&r)[4]) {
         float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
@@ -359,9 +365,9 @@ conv_ws_kernel(ConvArgs g) {
     bool bad = false;
     // every group walks the same number of steps (the barriers are workgroup-wide); a group past the end works on a
     // clamped tile and stores nothing
-    const int64_t first = (int64_t)blockIdx.x * 4 + grp;
+    const int64_t first = (int64_t)(blockIdx.x / row_tiles) * 4 + grp;
     const int64_t nsteps = (tiles_j + step - 1) / step;
-    const float* pcur = tile_ptr(min(first, tiles_j - 1));
+    unsigned pcur = tile_off(min(first, tiles_j - 1));
     fetch(pcur, 0, R[0]); fetch(pcur, 1, R[1]); fetch(pcur, 2, R[2]);
     __syncthreads();                                 // the weights
     stash(0, 0, R[0]);
@@ -370,18 +376,21 @@ conv_ws_kernel(ConvArgs g) {
         const int64_t ct = first + it * step;
         const bool live = ct < tiles_j;
         const int64_t j0 = min(ct, tiles_j - 1) * WS_LC;
-        const float* pnext = tile_ptr(min(ct + step, tiles_j - 1));
+        const unsigned pnext = tile_off(min(ct + step, tiles_j - 1));
         mt::f32x16 acc[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+#pragma unroll 1
+        for (int c0 = 0; c0 < WS_NCH; c0 += 4)
 #pragma unroll
-        for (int c = 0; c < WS_NCH; ++c) {
-            const int buf = c & 1;
+        for (int u = 0; u < 4; ++u) {                // four chunks unrolled: the ring slots stay compile-time
+            const int c = c0 + u;
+            const int buf = u & 1;
             // chunk c + 3 of the stream (this tile's, or the next tile's first chunks) into the slot chunk c - 1 left
-            if (c + 3 < WS_NCH) fetch(pcur, c + 3, R[(c + 3) % 4]);
-            else fetch(pnext, c + 3 - WS_NCH, R[(c + 3) % 4]);
+            if (c + 3 < WS_NCH) fetch(pcur, c + 3, R[(u + 3) % 4]);
+            else fetch(pnext, c + 3 - WS_NCH, R[(u + 3) % 4]);
             __builtin_amdgcn_sched_barrier(0);
             const mt::h8c ah = fraga(0, c, 32 * wave + li), al = fraga(1, c, 32 * wave + li);
             mt::h8c bh[2], bl[2];
@@ -400,7 +409,7 @@ conv_ws_kernel(ConvArgs g) {
             for (int tj = 0; tj < 2; ++tj) asm volatile("" :: "v"(bh[tj]), "v"(bl[tj]));
             __builtin_amdgcn_sched_barrier(0);
             // the next chunk of the stream (chunk c + 1, or chunk 0 of the next tile) into the other LDS buffer
-            stash(buf ^ 1, (c + 1) % WS_NCH, R[(c + 1) % 4]);
+            stash(buf ^ 1, (c + 1) % WS_NCH, R[(u + 1) % 4]);
             __syncthreads();
         }
         if (live) {
@@ -410,7 +419,7 @@ conv_ws_kernel(ConvArgs g) {
                 const unsigned cg = (unsigned)(j0 + 32 * tj + li), b = cg / (unsigned)n, tkk = cg - b * (unsigned)n;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                    const int row = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * kg;
                     if (row < M) {
                         const int64_t o = ((int64_t)b * M + row) * n + tkk;
                         float v = acc[tj][e] * mt::UNSCALE;
@@ -491,24 +500,35 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
     // weights-stationary tile: exactly 128 channels in from one source, at most 128 out, and enough column tiles for a
     // persistent grid of 4 x CUs groups to pay (the third level: 26 325 tiles)
     static const int ws_mode = [] { const char* e = getenv("PATS_CONV_WS"); return e ? atoi(e) : 1; }();     // A/B switch: 0 off, 2 = also on small grids (tests)
-    const bool ws = lean && ws_mode != 0 && g.K0 == 16 * WS_NCH && g.K1 == 0 && g.M <= LR && (g.cols >= 64 * 4096 || ws_mode == 2);
+    const int Kt = g.K0 + g.K1;
+    const bool two = g.K1 > 0;
+    const bool ws = lean && ws_mode != 0 && ((Kt == 128 && !two) || (Kt == 256 && (!two || g.K0 == 128))) &&
+                    g.cols * (int64_t)std::max(g.K0, 1) < (1ll << 31) && (g.cols >= 64 * 4096 || ws_mode == 2);
     if (ws) {
         static const int n_cu = [] {
             int dev = 0, v = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
             return v > 0 ? v : 256;
         }();
-        const size_t lds = (size_t)2 * WS_KQ * LR * sizeof(uint2) + (size_t)4 * 2 * 2 * 4 * WS_LC * sizeof(uint2);     // 64 + 32 KB
+        // weights of one 128-row tile (hi | lo planes, K x 512 bytes) + four groups' double-buffered 4 KB stages: 96 KB at
+        // K = 128, the CU's whole 160 KB at K = 256
+        const size_t lds = (size_t)2 * (Kt / 4) * LR * sizeof(uint2) + (size_t)4 * 2 * 2 * 4 * WS_LC * sizeof(uint2);
         static bool attr_set = false;
         if (!attr_set) {
-            PATS_REQUIRE(hipFuncSetAttribute((const void*)conv_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess,
+            PATS_REQUIRE(hipFuncSetAttribute((const void*)conv_ws_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)conv_ws_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)conv_ws_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                          "conv_ws_kernel: cannot raise the dynamic LDS limit");
             attr_set = true;
         }
+        const int row_tiles = (g.M + LR - 1) / LR;
         const int64_t tiles = (g.cols + WS_LC - 1) / WS_LC;
-        const int grid = (int)std::min<int64_t>(n_cu, (tiles + 3) / 4);
+        int grid = (int)std::min<int64_t>(n_cu, ((tiles + 3) / 4) * row_tiles);
+        grid = std::max(row_tiles, grid - grid % row_tiles);       // whole groups of row tiles
         g.redo = redo;
-        hipLaunchKernelGGL(conv_ws_kernel, dim3((unsigned)grid), dim3(1024), lds, st, g);
+        if (Kt == 128) hipLaunchKernelGGL((conv_ws_kernel<8, false>), dim3((unsigned)grid), dim3(1024), lds, st, g, row_tiles);
+        else if (!two) hipLaunchKernelGGL((conv_ws_kernel<16, false>), dim3((unsigned)grid), dim3(1024), lds, st, g, row_tiles);
+        else hipLaunchKernelGGL((conv_ws_kernel<16, true>), dim3((unsigned)grid), dim3(1024), lds, st, g, row_tiles);
     } else if (lean) {
         static const int nt = getenv("PATS_CONV_NT") ? atoi(getenv("PATS_CONV_NT")) : 2;       // A/B switch: 2 or 4 column tiles
         const int lc = 32 * (nt == 4 ? 4 : 2);
