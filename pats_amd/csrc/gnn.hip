@@ -502,7 +502,16 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
     static const int ws_mode = [] { const char* e = getenv("PATS_CONV_WS"); return e ? atoi(e) : 1; }();     // A/B switch: 0 off, 2 = also on small grids (tests)
     const int Kt = g.K0 + g.K1;
     const bool two = g.K1 > 0;
-    const bool ws = lean && ws_mode != 0 && ((Kt == 128 && !two) || (Kt == 256 && (!two || g.K0 == 128))) &&
+    // the tile needs up to the CU's whole 160 KB of LDS as dynamic shared memory: if the runtime will not grant it, the lean
+    // tile computes the same bits
+    static const bool ws_lds_ok = [] {
+        const bool ok = hipFuncSetAttribute((const void*)conv_ws_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)conv_ws_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)conv_ws_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }();
+    const bool ws = lean && ws_mode != 0 && ws_lds_ok && ((Kt == 128 && !two) || (Kt == 256 && (!two || g.K0 == 128))) &&
                     g.cols * (int64_t)std::max(g.K0, 1) < (1ll << 31) && (g.cols >= 64 * 4096 || ws_mode == 2);
     if (ws) {
         static const int n_cu = [] {
@@ -513,14 +522,6 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
         // weights of one 128-row tile (hi | lo planes, K x 512 bytes) + four groups' double-buffered 4 KB stages: 96 KB at
         // K = 128, the CU's whole 160 KB at K = 256
         const size_t lds = (size_t)2 * (Kt / 4) * LR * sizeof(uint2) + (size_t)4 * 2 * 2 * 4 * WS_LC * sizeof(uint2);
-        static bool attr_set = false;
-        if (!attr_set) {
-            PATS_REQUIRE(hipFuncSetAttribute((const void*)conv_ws_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                         hipFuncSetAttribute((const void*)conv_ws_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                         hipFuncSetAttribute((const void*)conv_ws_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
-                         "conv_ws_kernel: cannot raise the dynamic LDS limit");
-            attr_set = true;
-        }
         const int row_tiles = (g.M + LR - 1) / LR;
         const int64_t tiles = (g.cols + WS_LC - 1) / WS_LC;
         int grid = (int)std::min<int64_t>(n_cu, ((tiles + 3) / 4) * row_tiles);
