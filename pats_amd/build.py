@@ -67,5 +67,49 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# ---- the reference's native module, compiled: tensor_resize.cpython-*.so at the repo root (setup/setup.py:107-118
+#      builds `CppExtension('tensor_resize', ['library.cpp'])`; this is the same module name over the C-ABI) ----------
+EXT_SRC = os.path.join(CSRC, "binding", "tensor_resize_ext.cpp")
+
+
+def ext_path():
+    import sysconfig
+    return os.path.join(os.path.dirname(HERE), "tensor_resize" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_tensor_resize_ext(force=False, verbose=False):
+    """g++ on the pybind11 / libtorch binding, linked against libpats_amd.so (rpath $ORIGIN/pats_amd) and torch's own
+    libraries.  Plain compiler call: the binding holds no device code, so neither hipcc nor ninja is needed."""
+    import sysconfig
+    out = ext_path()
+    deps = [EXT_SRC, os.path.join(HERE, "..", "include", "pats_amd.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) > os.path.getmtime(d) for d in deps):
+        return out
+    import torch
+    from torch.utils import cpp_extension as ce
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found - the tensor_resize extension cannot be built")
+    tlib = ce.library_paths()[0]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=tensor_resize",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for inc in ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(rocm, "include"),
+                                     os.path.join(HERE, "..", "include")]:
+        cmd += ["-isystem" if "torch" in inc or "rocm" in inc else "-I", inc]
+    # torch's libraries FIRST in the DT_NEEDED order: they bring torch's own libamdhip64 (soname libamdhip64.so.7), which
+    # libpats_amd.so's dependency of that soname then resolves to - one HIP runtime in the process even when this module
+    # is imported before torch (the other order loads /opt/rocm's copy, then torch's beside it: see _lib.py)
+    cmd += [EXT_SRC, "-o", out, "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+            "-ltorch_python", "-L" + HERE, "-l:libpats_amd.so",
+            "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN/pats_amd"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_tensor_resize_ext(force="--force" in sys.argv, verbose=True))

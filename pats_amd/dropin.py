@@ -9,7 +9,7 @@ What is rebound (reference path:line -> replacement), in every already-imported 
 that holds the name (the layer files do `from .modules import ...` / `from utils.utils import ...`, so the
 functions live in several namespaces), and in `sys.modules` for the native extension:
 
-    tensor_resize (module; setup/library.cpp:92-93, imported at utils/utils.py:17)   -> the repo's tensor_resize.py
+    tensor_resize (module; setup/library.cpp:92-93, imported at utils/utils.py:17)   -> the repo's compiled tensor_resize extension
     models/modules.py:137,145,165  log_sinkhorn_iterations / log_optimal_transport / log_optimal_transport2
     models/modules.py:84           attention
     utils/utils.py:1179,1527       Iterative_expand_matrix / Compute_positions_and_ranges
@@ -20,8 +20,11 @@ functions live in several namespaces), and in `sys.modules` for the native exten
                                    layer's staging; follows `self.training` like the reference).  `final_proj` is an
                                    nn.Conv1d INSTANCE and is not rebound: ops.conv1d(x, m.weight, m.bias) replaces a call
     models/modules.py:114,127      AttentionalPropagation.forward / AttentionalGNN.forward (the layer's own parameters,
-                                   read once from its state_dict and cached on the instance; BatchNorm follows
-                                   `self.training` like the reference - the third layer's stays in train mode, pats.py:112-120)
+                                   read from its state_dict and cached on the instance under a fingerprint of every
+                                   parameter / buffer (address, version, device) so load_state_dict / .to() / an optimizer
+                                   step rebuild them; BatchNorm follows `self.training` like the reference - the third
+                                   layer's stays in train mode, pats.py:112-120; with autograd enabled on parameters that
+                                   require grad the reference's own forward runs instead: the HIP path is inference only)
 
 Nothing of the reference is copied or imported here unless the caller has imported it already (or
 `import_reference=True` and the reference is on sys.path).  `uninstall()` restores the originals.
@@ -45,6 +48,8 @@ _REFERENCE_MODULES = ("models.modules", "utils.utils", "models.first_layer", "mo
                       "models.third_layer", "models.pats")
 _saved = []          # (object, attribute name, original value) in installation order
 _MISSING = object()
+_original = {}       # (class name, method) -> the reference's own method, for callers that need autograd
+_cached_on = set()   # modules carrying a `_pats_params` cache (cleared by uninstall)
 
 
 def _set(obj, name, value):
@@ -67,30 +72,49 @@ def _methods(ops):
         # third_layer.py:184-217 returns (mkpts0_f, mkpts1_f, whole_loss); the label of :161-170 stays with the caller
         return ops.Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device)[:3]
 
+    def _fingerprint(module):
+        # (storage address, in-place version counter, device) of every parameter and buffer: load_state_dict(), .to(),
+        # an optimizer step or a BatchNorm running-statistics update all change it
+        return tuple((t.data_ptr(), t._version, str(t.device))
+                     for t in list(module.parameters()) + list(module.buffers()))
+
+    def _cached(module, make):
+        fp = _fingerprint(module)
+        hit = getattr(module, "_pats_params", None)
+        if hit is None or hit[0] != fp:
+            hit = (fp, make(next(module.parameters()).device))
+            object.__setattr__(module, "_pats_params", hit)
+            _cached_on.add(module)
+        return hit[1]
+
     def _params(layer):
-        # inference: the weights do not change between calls, so the transposed / folded copies are built once
-        p = getattr(layer, "_pats_params", None)
-        if p is None:
-            dev = next(layer.parameters()).device
-            p = ops.PropagationParams(layer.state_dict(), device=dev, eps=layer.mlp[1].eps)
-            object.__setattr__(layer, "_pats_params", p)
-        return p
+        return _cached(layer, lambda dev: ops.PropagationParams(layer.state_dict(), device=dev, eps=layer.mlp[1].eps))
+
+    def _needs_autograd(module):
+        # the HIP path is inference only (evaluate.py:20 `@torch.no_grad()`): it returns tensors outside the autograd
+        # graph and does not update BatchNorm running statistics.  A caller that is TRAINING gets the reference's own
+        # forward back instead of silently wrong gradients.
+        import torch
+        return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
     def propagation_forward(self, x, source):
+        if _needs_autograd(self):
+            return _original[("AttentionalPropagation", "forward")](self, x, source)
         return ops.attentional_propagation(x, source, _params(self), heads=self.attn.num_heads, bn_train=self.training)
 
     def gnn_forward(self, desc0, desc1):
+        if _needs_autograd(self):
+            return _original[("AttentionalGNN", "forward")](self, desc0, desc1)
         layers = [_params(layer) for layer in self.layers]
         heads = self.layers[0].attn.num_heads if len(self.layers) else 4
         train = bool(len(self.layers) and self.layers[0].training)
         return ops.attentional_gnn(desc0, desc1, layers, self.names, heads=heads, bn_train=train)
 
     def kenc_forward(self, kpts):
-        p = getattr(self, "_pats_params", None)
-        if p is None:
-            dev = next(self.parameters()).device
-            p = ops.MLPParams(self.state_dict(), device=dev, eps=self.encoder[1].eps, prefix="encoder.")
-            object.__setattr__(self, "_pats_params", p)
+        if _needs_autograd(self):
+            return _original[("KeypointEncoder", "forward")](self, kpts)
+        p = _cached(self, lambda dev: ops.MLPParams(self.state_dict(), device=dev, eps=self.encoder[1].eps,
+                                                    prefix="encoder."))
         return ops.keypoint_encoder(kpts, p, bn_train=self.training)
 
     return {"models.modules#kenc": ("KeypointEncoder", {"forward": kenc_forward}),
@@ -145,20 +169,29 @@ def install(import_reference=False):
             continue
         for meth, fn in methods.items():
             if hasattr(cls, meth):
+                _original[(cls_name, meth)] = getattr(cls, meth)
                 _set(cls, meth, fn)
                 touched.append("%s.%s.%s" % (mname, cls_name, meth))
     return touched
 
 
 def _load_native():
-    """This repository's tensor_resize.py, loaded by path: `import tensor_resize` could hand back the reference's
-    compiled extension if that is already in sys.modules."""
+    """This repository's COMPILED tensor_resize extension (csrc/binding/tensor_resize_ext.cpp, built by
+    pats_amd.build), loaded by path: `import tensor_resize` could hand back the reference's own compiled extension if
+    that is already in sys.modules or ahead on sys.path."""
+    import importlib.machinery
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tensor_resize.py")
-    spec = importlib.util.spec_from_file_location("tensor_resize", path)
+    from . import build as _build
+    path = _build.ext_path()
+    if not os.path.exists(path):
+        raise ImportError("pats_amd.dropin: %s is missing - build it with `python -m pats_amd.build`; there is no "
+                          "Python fallback for the native module" % path)
+    import torch  # noqa: F401  (the extension's Tensor casters need torch's Python side)
+    loader = importlib.machinery.ExtensionFileLoader("tensor_resize", path)
+    spec = importlib.util.spec_from_file_location("tensor_resize", path, loader=loader)
     mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    loader.exec_module(mod)
     return mod
 
 
@@ -168,7 +201,14 @@ def _set_module(name, module):
 
 
 def uninstall():
-    """Restores everything install() replaced."""
+    """Restores everything install() replaced and drops the parameter caches it left on the reference's modules."""
+    for module in list(_cached_on):
+        try:
+            object.__delattr__(module, "_pats_params")
+        except AttributeError:
+            pass
+    _cached_on.clear()
+    _original.clear()
     while _saved:
         obj, name, old = _saved.pop()
         if obj is sys.modules:

@@ -114,7 +114,9 @@ def test_install_rebinds_every_namespace_and_restores(standins):
     assert s["l1"].unrelated() == "keep"
     import importlib
     native = importlib.import_module("tensor_resize")
-    assert native.tensor_resize is ops.tensor_resize and s["uu"].tensor_resize is native
+    # the native module is the COMPILED extension of this repository (csrc/binding/tensor_resize_ext.cpp), not a .py
+    assert native.__file__.endswith(".so") and "pats_amd" in native.__doc__ and s["uu"].tensor_resize is native
+    assert type(native.tensor_resize).__name__ == "builtin_function_or_method"
     assert SecondLayer.merge_patches_new is not None and SecondLayer().merge_patches_new.__func__.__module__ == "pats_amd.dropin"
     assert ThirdLayer().Compute_result.__func__.__module__ == "pats_amd.dropin"
     assert AttentionalPropagation.forward.__module__ == "pats_amd.dropin" and AttentionalGNN.forward.__module__ == "pats_amd.dropin"
@@ -159,7 +161,8 @@ def test_install_against_the_real_reference_when_present():
             assert _prefix_compatible(ref, getattr(ops, n)), n
         assert R.L1.log_optimal_transport is ops.log_optimal_transport
         assert R.L2.log_optimal_transport2 is ops.log_optimal_transport2 and R.L3.log_optimal_transport2 is ops.log_optimal_transport2
-        assert R.U.Compute_imgs is ops.Compute_imgs and R.U.tensor_resize.tensor_resize is ops.tensor_resize
+        assert R.U.Compute_imgs is ops.Compute_imgs and "pats_amd" in R.U.tensor_resize.__doc__ \
+            and R.U.tensor_resize.__file__.endswith(".so")
         assert _prefix_compatible(merge_new, R.L2.SecondLayer.merge_patches_new, drop_self=True)
         assert _prefix_compatible(comp_res, R.L3.ThirdLayer.Compute_result, drop_self=True)
         assert len(touched) >= 17
