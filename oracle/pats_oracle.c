@@ -289,11 +289,17 @@ static inline int64_t clamp_seq(float f, int wh, int S) {
     return s;
 }
 
-void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const float* scalex,
+/* margin (optional, [b,m,2]): how close each row came to deciding differently - the classifier the parity reports
+ * use to tell a summation-order tie from a real mismatch.  [0] = the smallest RELATIVE distance, over the initial
+ * argmax and every growth step, between the quantities a decision compares (best strip sum against lower_bound,
+ * best against second-best strip sum, best against second-best row entry): a rectangle can only differ from this
+ * one's if an implementation's sums differ from these by at least that much.  [1] = the same for the per-element
+ * test `expand_sum > lower_bound` of :1225, which feeds whole_cost only. */
+static void iterative_expand_impl(const float* P, int64_t b, int M, int N, const float* scalex,
                              const float* scaley, int lim3, int h, int w, float lower_bound,
                              int iter_num, float* whole_cost, float* core_cost,
                              float* average_point, float* x_scale, float* y_scale,
-                             int64_t* bound_out) {
+                             int64_t* bound_out, float* margin) {
     const int m = M - 1, n = N - 1;
     const int width = h > w ? h : w;            /* ranges.shape[0]          (utils.py:1181) */
     const int height = (h * w) / width;         /* positions.shape[0] // width              */
@@ -318,6 +324,9 @@ void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const floa
             for (int j = 1; j < n; ++j) if (c.prow[j] > c.prow[max0]) max0 = j;
             for (int j = 1; j < N; ++j) if (c.prow[j] > c.prow[maxall]) maxall = j;
             const int if_nomatching = (maxall == m); /* `== scores.shape[1]` (:1191) */
+            float mg_bound = INFINITY, mg_elem = INFINITY;
+            for (int j = 0; j < n; ++j)
+                if (j != max0) mg_bound = fminf(mg_bound, (c.prow[max0] - c.prow[j]) / fabsf(c.prow[max0]));
             float last_nomatching = opp[max0];       /* :1184 */
             int64_t up = max0 / lim3, down = up, left = max0 % lim3, right = left; /* :1189-1197 */
             int bd0 = 0, bd1 = 0, sb0 = 0, sb1 = 0;  /* bound_difference; sb* = the copy the LAST
@@ -340,6 +349,7 @@ void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const floa
                         float v = ES(&c, s);
                         e_sum[d] += (double)v;
                         nm_sum[d] += (double)(v > lower_bound ? EOPP(&c, s) : ZERO_F); /* :1225 */
+                        mg_elem = fminf(mg_elem, fabsf(v - lower_bound) / lower_bound);
                         sc_sum[d] += (double)ESC(&c, s);                               /* :1231 */
                     }
                 float es[4];
@@ -352,6 +362,10 @@ void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const floa
                 for (int d = 1; d < 4; ++d) if (es[d] > es[arg]) arg = d; /* :1232 */
                 const float max_sum = es[arg];
                 float add_sum = ZERO_F, add_scale = ZERO_F, add_nm = ZERO_F;
+                mg_bound = fminf(mg_bound, fabsf(max_sum - lower_bound) / lower_bound);
+                if (max_sum > lower_bound)
+                    for (int d = 0; d < 4; ++d)
+                        if (d != arg) mg_bound = fminf(mg_bound, (max_sum - es[d]) / max_sum);
                 if (max_sum > lower_bound) {              /* :1235-1238 */
                     if (arg == 0) up -= 1; else if (arg == 1) down += 1;
                     else if (arg == 2) left -= 1; else right += 1;
@@ -430,12 +444,34 @@ void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const floa
             bound_out[o2 * 4 + 1] = down;
             bound_out[o2 * 4 + 2] = left;
             bound_out[o2 * 4 + 3] = right;
+            if (margin) {
+                margin[o2 * 2 + 0] = mg_bound;
+                margin[o2 * 2 + 1] = mg_elem;
+            }
         }
         free(scale);
         free(ox);
         free(oy);
     }
     free(positions);
+}
+
+void oracle_iterative_expand(const float* P, int64_t b, int M, int N, const float* scalex,
+                             const float* scaley, int lim3, int h, int w, float lower_bound,
+                             int iter_num, float* whole_cost, float* core_cost,
+                             float* average_point, float* x_scale, float* y_scale,
+                             int64_t* bound_out) {
+    iterative_expand_impl(P, b, M, N, scalex, scaley, lim3, h, w, lower_bound, iter_num, whole_cost, core_cost,
+                          average_point, x_scale, y_scale, bound_out, NULL);
+}
+
+void oracle_iterative_expand_margin(const float* P, int64_t b, int M, int N, const float* scalex,
+                                    const float* scaley, int lim3, int h, int w, float lower_bound,
+                                    int iter_num, float* whole_cost, float* core_cost,
+                                    float* average_point, float* x_scale, float* y_scale,
+                                    int64_t* bound_out, float* margin) {
+    iterative_expand_impl(P, b, M, N, scalex, scaley, lim3, h, w, lower_bound, iter_num, whole_cost, core_cost,
+                          average_point, x_scale, y_scale, bound_out, margin);
 }
 
 /* ------------------------------------------------------------------------------------------

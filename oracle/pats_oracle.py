@@ -124,7 +124,9 @@ def argmax(Z):
     return r, c
 
 
-def iterative_expand(P, scalex, scaley, lim3, h, w, lower_bound, iter_num):
+def iterative_expand(P, scalex, scaley, lim3, h, w, lower_bound, iter_num, with_margin=False):
+    """with_margin: a seventh output [b,m,2], the smallest relative distance by which (0) a rectangle decision and
+    (1) a per-element `> lower_bound` test (whole_cost only) could have gone the other way - see pats_oracle.c."""
     P, pp = _f(P)
     b, M, N = P.shape
     scalex, px = _f(np.asarray(scalex).reshape(b, N - 1))
@@ -136,6 +138,13 @@ def iterative_expand(P, scalex, scaley, lim3, h, w, lower_bound, iter_num):
     xs = np.empty((b, m), np.float32)
     ys = np.empty((b, m), np.float32)
     bound = np.empty((b, m, 4), np.int64)
+    if with_margin:
+        margin = np.empty((b, m, 2), np.float32)
+        lib().oracle_iterative_expand_margin(pp, ctypes.c_int64(b), M, N, px, py, int(lim3), int(h), int(w),
+                                             ctypes.c_float(lower_bound), int(iter_num), _p(whole, c_f),
+                                             _p(core, c_f), _p(avg, c_f), _p(xs, c_f), _p(ys, c_f),
+                                             _p(bound, c_i64), _p(margin, c_f))
+        return whole, core, avg, xs, ys, bound, margin
     lib().oracle_iterative_expand(pp, ctypes.c_int64(b), M, N, px, py, int(lim3), int(h), int(w),
                                   ctypes.c_float(lower_bound), int(iter_num), _p(whole, c_f),
                                   _p(core, c_f), _p(avg, c_f), _p(xs, c_f), _p(ys, c_f),

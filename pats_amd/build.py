@@ -7,6 +7,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpats_amd.so")
+# diagnostic twin: the same objects, third_fused3.hip compiled with -DPATS_DIAG (every sweep-loop variant and the timing
+# ablations whose results are wrong by design).  Built on request only (`--diag`); never loaded unless PATS_AMD_DIAG_LIB=1.
+LIB_DIAG = os.path.join(HERE, "libpats_amd_diag.so")
+DIAG_SOURCES = {"third_fused3.hip": ["-DPATS_DIAG=1"]}
 SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip", "gnn.hip",
            "fused.hip", "scale_head.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
@@ -32,6 +36,27 @@ def needs_build():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pats_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_diag(force=False, verbose=False):
+    """libpats_amd_diag.so = the production objects with the DIAG_SOURCES recompiled under their extra defines."""
+    build(force=force, verbose=verbose)
+    objdir = os.path.join(HERE, "build")
+    objs = []
+    for src in SOURCES:
+        stem = os.path.splitext(src)[0]
+        if src not in DIAG_SOURCES:
+            objs.append(os.path.join(objdir, stem + ".o"))
+            continue
+        obj = os.path.join(objdir, stem + "_diag.o")
+        cmd = [hipcc()] + FLAGS[:-2] + EXTRA_FLAGS.get(src, []) + DIAG_SOURCES[src] + FLAGS[-2:] + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_DIAG])
+    return LIB_DIAG
 
 
 def build(force=False, verbose=False):
@@ -112,4 +137,6 @@ def build_tensor_resize_ext(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--diag" in sys.argv:
+        print(build_diag(verbose=True))
     print(build_tensor_resize_ext(force="--force" in sys.argv, verbose=True))

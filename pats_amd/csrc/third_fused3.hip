@@ -505,8 +505,19 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     g.fallbacks = fallback_counter();
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
     if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
-    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 1350;   // A/B switch
     const dim3 grid((unsigned)g.P), block(64);
+    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 1350;   // A/B switch
+#ifndef PATS_DIAG
+    // The production library carries exactly two instantiations, both of which compute the solve: the default and
+    // the same kernel with the fp32-MFMA cost build (its in-family A/B partner).  Every other sweep-loop variant and
+    // every timing ablation (builds whose results are wrong by design) lives in libpats_amd_diag.so only
+    // (`python -m pats_amd.build --diag`, loaded with PATS_AMD_DIAG_LIB=1).
+    PATS_REQUIRE(variant == 1350 || variant == 300,
+                 "PATS_THIRD_VARIANT=%d is a diagnostic build: it is compiled into libpats_amd_diag.so only "
+                 "(python -m pats_amd.build --diag; PATS_AMD_DIAG_LIB=1)", variant);
+    if (variant == 300) hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0>), grid, block, 0, st, g);       // fp32 MFMA cost build
+    else hipLaunchKernelGGL((third_fused3_kernel<3, 0, 5, 1>), grid, block, 0, st, g);
+#else
     // last digit (dustbin sums) 6..9 = diagnostic / timing-ablation builds whose RESULTS ARE NOT the solve: never by accident
     static const bool ablation_ok = getenv("PATS_THIRD_ABLATION") != nullptr;
     PATS_REQUIRE(ablation_ok || variant % 10 < 6,
@@ -538,6 +549,7 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         case 1300: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0, 1>), grid, block, 0, st, g); break;    // row-broadcast dustbin sums
         default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 5, 1>), grid, block, 0, st, g); break;
     }
+#endif
     return check_launch("third_fused3_kernel");
 }
 

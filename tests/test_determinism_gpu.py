@@ -1,0 +1,96 @@
+"""Run-to-run determinism of the three kernels that carry the MFMA operand write-after-read workaround
+(cost65_device.hpp / mfma_tile.hpp / gnn.hip: `sched_barrier` + `s_nop` fences between the VALU conversions that rewrite
+the A / B registers and the MFMAs that read them), AT THE LAUNCH SIZES THE BENCH USES.  The hazard only showed with
+three waves per SIMD queueing on the matrix pipe and hit 100-600 of 65 536 rows, different ones every run - a
+4 096-problem parity test does not load the chip enough to see it.  Each case: three launches on the same inputs must
+be bit-identical, and a slice is held to the CPU oracle.  A compiler bump that re-opens the hazard fails here."""
+import numpy as np
+import pytest
+import torch
+
+from pats_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from pats_amd import ops as o
+    return o
+
+
+def _desc_pair(shape, gen, drop=0.12):
+    dev = "cuda"
+    base = torch.randn(shape, device=dev, generator=gen)
+    d0 = 3.0 * (base + 0.3 * torch.randn(shape, device=dev, generator=gen))
+    d1 = 3.0 * (base + 0.3 * torch.randn(shape, device=dev, generator=gen))
+    gone = torch.rand((shape[0], 1, shape[2]), device=dev, generator=gen) < drop
+    d0 = torch.where(gone, 3.12 * torch.randn(shape, device=dev, generator=gen), d0)
+    d0[:, :, -1] *= 0.5
+    d1[:, :, -1] *= 0.5
+    return d0.contiguous(), d1.contiguous()
+
+
+def test_third_level_414720_problems_three_launches_identical(ops, oracle):
+    """ops.third_level (third_fused3_kernel: in-wave fp16-split cost build, 3 waves per SIMD) at the 414 720 problems of
+    a 16-pair launch; the first 4 096 problems against the oracle."""
+    P = 414720
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(synth.SEED + 300)
+    d0, d1 = _desc_pair((P, 128, 65), gen)
+    sc = torch.exp(torch.sigmoid(0.3 * torch.randn((P, 1, 64), device="cuda", generator=gen)) * synth.LN256 - synth.LN256 / 2)
+    p_s = torch.randint(1, 23, (P, 2), device="cuda", generator=gen) * 4
+    p_t = torch.randint(0, 25, (P, 2), device="cuda", generator=gen) * 4
+    ops.sinkhorn_fallbacks(reset=True)
+    runs = [ops.third_level(d0, d1, sc, p_s, p_t, outdoor=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        for a, b, name in zip(runs[0], r, ("mkpts0_f", "mkpts1_f", "label", "if_matching1")):
+            diff = int((a != b).sum())
+            assert diff == 0, "%s differs between two launches on the same inputs in %d entries" % (name, diff)
+    n = 4096
+    S = oracle.cost(d0[:n].cpu().numpy(), d1[:n].cpu().numpy())
+    scn = sc[:n].cpu().numpy()
+    Zr = oracle.log_optimal_transport2(S, 1.0, scn, 100)
+    sq = np.sqrt(scn + np.float32(1e-8)).astype(np.float32)
+    r0, r1, _, rlabel, rifm = oracle.compute_result(np.exp(Zr), sq, sq, p_s[:n].cpu().numpy(), p_t[:n].cpu().numpy(), True)
+    m0, m1, label, ifm = runs[0]
+    assert np.array_equal(label[:n * 16].cpu().numpy(), rlabel)
+    assert np.array_equal(ifm[:n].cpu().numpy().astype(bool), rifm.astype(bool))
+    assert np.array_equal(m0[:n].cpu().numpy(), r0)
+    assert np.abs(m1[:n].cpu().numpy() - r1).max() <= 3e-4 * 8
+
+
+def test_cost_20736_fine_problems_three_launches_identical(ops, oracle):
+    """ops.cost (cost_mfma_kernel, mfma_tile.hpp) at 20 736 x [264,145]: the fine level of a 48-pair step."""
+    B = 20736
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(synth.SEED + 301)
+    d0, d1 = _desc_pair((B, 264, 145), gen)
+    outs = [ops.cost(d0, d1) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for sl in (slice(0, 48), slice(B - 48, B)):
+        want = np.einsum("bdn,bdm->bnm", d0[sl].cpu().numpy().astype(np.float64), d1[sl].cpu().numpy().astype(np.float64)) \
+            / np.sqrt(264.0) * 0.1
+        got = outs[0][sl].cpu().numpy()
+        assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+        np.testing.assert_allclose(got, oracle.cost(d0[sl].cpu().numpy(), d1[sl].cpu().numpy()), atol=2e-5, rtol=1e-5)
+
+
+def test_weights_stationary_conv_8192_problems_three_launches_identical(ops, oracle):
+    """ops.conv1d on a 128 -> 128 channel product over 8 192 x 65 columns: conv_ws_kernel (gnn.hip), the tile the
+    third-level GNN layers run on."""
+    b = 8192
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(synth.SEED + 302)
+    x = torch.randn((b, 128, 65), device="cuda", generator=gen)
+    w = torch.randn((128, 128, 1), device="cuda", generator=gen) / 11.0
+    bias = torch.randn((128,), device="cuda", generator=gen)
+    outs = [ops.conv1d(x, w, bias) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for sl in (slice(0, 40), slice(b - 40, b)):
+        want = oracle.conv1d(x[sl].cpu().numpy(), w.cpu().numpy(), bias.cpu().numpy())
+        np.testing.assert_allclose(outs[0][sl].cpu().numpy(), want, atol=5e-5, rtol=2e-4)

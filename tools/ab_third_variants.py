@@ -29,7 +29,7 @@ t100 = timeit(lambda: ops.third_level(d0, d1, sc, ps, pt, iters=100))
 t200 = timeit(lambda: ops.third_level(d0, d1, sc, ps, pt, iters=200))
 print("%%s  100 sweeps %%.3f ms   200 sweeps %%.3f ms   per sweep %%.1f us   rest %%.2f ms" %% (os.environ.get("TAG"), t100, t200, (t200 - t100) * 10, 2 * t100 - t200))
 ''' % HERE
-for tag, env in [("v2", {"PATS_THIRD_V2": "1"})] + [(v, {"PATS_THIRD_VARIANT": v}) for v in sys.argv[1:]]:
+for tag, env in [("v2", {"PATS_THIRD_V2": "1"})] + [(v, {"PATS_THIRD_VARIANT": v, "PATS_AMD_DIAG_LIB": "1", "PATS_THIRD_ABLATION": "1"}) for v in sys.argv[1:]]:
     e = dict(os.environ, TAG=tag, **env)
     out = subprocess.run([sys.executable, "-c", CODE], env=e, capture_output=True, text=True)
     print(out.stdout.strip() or out.stderr[-500:])

@@ -20,7 +20,7 @@ np.save(os.environ["OUT"], np.stack(outs))
 res = {}
 for v in ("306", "1306"):
     out = "/tmp/dbg_%s.npy" % v
-    subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, PATS_THIRD_VARIANT=v, PATS_THIRD_ABLATION="1", OUT=out, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), check=True)
+    subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, PATS_THIRD_VARIANT=v, PATS_THIRD_ABLATION="1", PATS_AMD_DIAG_LIB="1", OUT=out, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), check=True)
     res[v] = np.load(out)
 for v, a in res.items():
     print(v, "run-to-run identical:", np.array_equal(a[0], a[1]), np.array_equal(a[1], a[2]), " problems differing between runs:", int((a[0] != a[1]).any(1).sum()))
