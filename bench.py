@@ -301,11 +301,85 @@ def torch_cpu_ot2(scores, ns, iters):
     return torch_cpu_sinkhorn(scores, log_mu, log_nu, iters) - norm[:, :, None]
 
 
+ULP4 = 4.0 * 2.0 ** -23     # "a threshold tie": the deciding quantities agree to 4 ulp
+
+
+def expansion_parity(ops, oracle, dev, f, gZ2, g2, Z2, ex2, r2, c2):
+    """Area expansion of the L2 sample (utils.py:1213-1243), HIP against the oracle, every differing row classified.
+
+    (1) SAME INPUT: the oracle expands the plan the GPU produced (exp on the GPU, the identical fp32 array on both
+        sides), so the only freedom left is the summation order of a strip.  A row whose rectangle differs is a
+        threshold tie if the oracle's own decision margin - the relative distance between the strip sum that decided
+        and `lower_bound` / the competing strip (oracle_iterative_expand_margin) - is within 4 ulp; anything else is a
+        REAL mismatch, and the bench asserts there is none.
+    (2) END TO END: each side expands its OWN plan.  The plans agree to the 1e-4 transport-mass gate, not bit for bit,
+        and `lower_bound` = 1e-3 is only 10x that gate, so a strip sum that lands within the measured plan difference
+        of the threshold grows on one side and not on the other; such a row then carries a different rectangle AND a
+        different trust score (whole_cost) - this is where round 2's unexplained max |d trust| = 0.04 came from.
+        A differing row is "explained" if its margin is below what the measured plan difference of its problem can
+        move a strip sum by (12 cells x max |dP|, relative to lower_bound); anything else is REAL and asserted zero."""
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    nb = gZ2.shape[0]
+    pos, rng_ = ops.Compute_positions_and_ranges(12, 12, dev)
+    gP = ops.exp(gZ2)
+    gsame = ops.Iterative_expand_matrix(gP, td(f["scale_x"]).reshape(nb, -1, 1), td(f["scale_y"]).reshape(nb, -1, 1),
+                                        [0, 12, 0, 12], rng_, pos, lower_bound=1e-3, iter_num=8, width=12, height=12)
+    gbound = gsame[5].cpu().numpy()
+    gtrust = gsame[0].cpu().numpy()
+    osame = oracle.iterative_expand(gP.cpu().numpy(), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8, with_margin=True)
+    diff_rows = (gbound != osame[5]).any(axis=2)
+    margin = osame[6][..., 0]
+    tie = diff_rows & (margin <= ULP4)
+    real_same = diff_rows & ~tie
+    # trust of rows whose rectangles agree: same strips, same sums up to order
+    same_rows = ~diff_rows
+    # the per-element `> lower_bound` test of :1225 only feeds whole_cost: a row with an element within 4 ulp of the
+    # threshold may differ in trust although its rectangle agrees
+    elem_tie = osame[6][..., 1] <= ULP4
+    dtrust = np.abs(gtrust - osame[0])
+    trust_same = float(dtrust[same_rows & ~elem_tie].max()) if (same_rows & ~elem_tie).any() else 0.0
+    # end to end (each side its own plan)
+    ebound_diff = (gbound != ex2[5]).any(axis=2)
+    dP = np.abs(np.exp(gZ2.cpu().numpy().astype(np.float64)) - np.exp(Z2.astype(np.float64)))[:, :-1, :].max(axis=(1, 2))
+    own = oracle.iterative_expand(np.exp(Z2), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8, with_margin=True)
+    reach = (12.0 * dP / 1e-3 + ULP4)[:, None]
+    explained = ebound_diff & (own[6][..., 0] <= reach)
+    real_e2e = ebound_diff & ~explained
+    dtrust_e2e = np.abs(g2[0].cpu().numpy() - ex2[0])
+    agree = ~ebound_diff & (own[6][..., 1] > reach)
+    # a row whose trust differs although its rectangle agrees: the per-element test `expand_sum > lower_bound` of :1225
+    # decides whether the opposite dustbin mass of a strip cell is charged to the row (whole_cost = ... + nomatching / 4),
+    # and a cell whose mass is within the plan difference of lower_bound is charged on one side only
+    tol_t = 1e-4 + 1e-4 * np.abs(ex2[0])
+    tdiff = (dtrust_e2e > tol_t) & ~ebound_diff
+    t_explained = tdiff & (own[6][..., 1] <= reach)
+    ifn1 = g2[4].cpu().numpy()
+    ifn2 = g2[5].cpu().numpy()
+    flag_mismatch = int((ifn1 != (r2[:, :-1] == 144)).sum() + (ifn2 != (c2[:, :-1] == 144)).sum())
+    return {
+        "l2_rows": int(diff_rows.size),
+        "l2_bound_mismatch_same_input": int(diff_rows.sum()), "l2_bound_threshold_ties": int(tie.sum()),
+        "l2_bound_real_mismatch": int(real_same.sum() + real_e2e.sum()),
+        "l2_trust_max_abs_diff_same_input_same_rectangle": trust_same,
+        "l2_bound_mismatch_end_to_end": int(ebound_diff.sum()),
+        "l2_bound_mismatch_end_to_end_explained_by_plan_difference": int(explained.sum()),
+        "l2_plan_max_abs_diff": float(dP.max()),
+        "l2_smallest_margin_of_a_differing_row": float(own[6][..., 0][ebound_diff].min()) if ebound_diff.any() else None,
+        "l2_trust_max_abs_diff": float(dtrust_e2e.max()), "l2_trust_max_abs": float(np.abs(ex2[0]).max()),
+        "l2_trust_max_abs_diff_where_rectangles_agree": float(dtrust_e2e[agree].max()) if agree.any() else 0.0,
+        "l2_trust_rows_differing_with_equal_rectangles": int(tdiff.sum()),
+        "l2_trust_rows_explained_by_element_threshold": int(t_explained.sum()),
+        "l2_trust_real_mismatch": int((tdiff & ~t_explained).sum()),
+        "l2_flag_mismatch": flag_mismatch,
+    }
+
+
 def cpu_baseline(ops, dev, pairs_B, pairs_P, seconds):
     """The CPU oracle ("port") on the host cores: L1 in full, bounded samples of L2/L3 scaled to one
     pair, plus the torch-CPU transcription of the Sinkhorn loop on the same samples.  Checker code timed
     as a baseline only - never part of the measured GPU path.  The HIP path is also run on the same L2 /
-    L3 samples and compared with the oracle's answers (reported, not asserted, as `parity_sample`)."""
+    L3 samples and compared with the oracle's answers (`parity_sample`): index outputs and expansion rectangles are
+    ASSERTED - every differing row must classify as a threshold tie (expansion_parity)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import pats_oracle as oracle
     cores = oracle.num_threads()
@@ -358,8 +432,11 @@ def cpu_baseline(ops, dev, pairs_B, pairs_P, seconds):
         "l2_problems": nb, "l2_row_argmax_mismatch": int((gr2.cpu().numpy() != r2).sum()),
         "l2_col_argmax_mismatch": int((gc2.cpu().numpy() != c2).sum()),
         "l2_mass_max_abs_diff": float(np.abs(e2[:, :-1, :-1] - e2r[:, :-1, :-1]).max()),
-        "l2_trust_max_abs_diff": float(np.abs(g2[0].cpu().numpy() - ex2[0]).max()), "l2_trust_max_abs": float(np.abs(ex2[0]).max()),
     }
+    parity.update(expansion_parity(ops, oracle, dev, f, gZ2, g2, Z2, ex2, r2, c2))
+    assert parity["l2_bound_real_mismatch"] == 0 and parity["l2_flag_mismatch"] == 0, parity
+    assert parity["l2_trust_real_mismatch"] == 0, parity
+    assert parity["l3_label_mismatch"] == 0 and parity["l3_if_matching_mismatch"] == 0 and parity["l3_mkpts0_mismatch"] == 0, parity
 
     # torch-CPU transcription of modules.py:137-182 on the same L1 problem and (smaller) L2 / L3 samples
     torch.set_num_threads(cores)

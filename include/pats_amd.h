@@ -251,9 +251,57 @@ int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int 
                          const int64_t* p_t, int iters, int outdoor, float* mkpts0_f, float* mkpts1_f,
                          float* label, uint8_t* if_matching1, float* Z_out, pats_stream_t stream);
 
+/* a16 / the third-level step when the number of problems lives on the DEVICE (throughput mode: the merge decides P and
+ * nothing reads it back): the launch covers the capacity P_cap, workgroups past *P_dev leave at once and their output rows
+ * are not written.  pats_third_level_counted_f32 takes scale_x = scale_y = NULL to form sqrt(scale + 1e-8)
+ * (third_layer.py:153-154) in the kernel instead of reading the caller's copies. */
+int pats_third_descriptors_counted_f32(const float* feat_f0, const float* feat_f1, const float* mkpts0_c,
+                                       const float* mkpts1_c, const int64_t* b_ids, const float* kenc,
+                                       const float* rubbish, int64_t P_cap, const int64_t* P_dev, int64_t B,
+                                       float* out0, float* out1, int64_t* p_s_out, int64_t* p_t_out,
+                                       pats_stream_t stream);
+int pats_third_level_counted_f32(const float* feat0, const float* feat1, int64_t P_cap, const int64_t* P_dev, int D,
+                                 const float* scale, const float* scale_x, const float* scale_y, const int64_t* p_s,
+                                 const int64_t* p_t, int iters, int outdoor, float* mkpts0_f, float* mkpts1_f,
+                                 float* label, uint8_t* if_matching1, pats_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * The steps either side of the OT path.  bool tensors are 1 byte, 0 / 1.
  * ---------------------------------------------------------------------------------------- */
+
+/* ---- f3, throughput mode: the chunk loop of PATS.forward for a BATCH of pairs without a host read ----------------
+ * Reference: models/first_layer.py:130-146 (cumsum of the matched flags, split_patches, one boolean mask + crop gather
+ * + SecondLayer call per chunk), models/pats.py:33-39 (the loop; `if_nomatching1[-third_layer_set[num][1]:, :] = True`).
+ * From if_nomatching1 [pairs, N] (N = height * width) this builds, on the device:
+ *   sum_cycle [pairs,N] int32, cycle_num [pairs], second / third [pairs, height+1, 2]   (= pats_split_patches_device)
+ *   masks [Cmax, pairs, N]      the chunk masks of first_layer.py:137-138 (1 = cell not in the chunk), chunk-major
+ *   the fine level's ROW TABLE, rows ordered (chunk, pair, cell): chunk c of every pair is the contiguous block
+ *     [chunk_base[c], chunk_base[c+1]) - chunk_base [Cmax+1], chunk_base[Cmax] = total rows;
+ *     row_cell [rows_cap] = pair * N + cell (-1 past the total); row_crop [rows_cap] = the row's crop in the (image,
+ *     patch)-ordered crop table of pats_compute_imgs_bounds_batch_f32 (crop_base [pairs+1] = first crop of every pair);
+ *     row_forced [rows_cap] = 1 for the trailing rows pats.py:38-39 masks (and for padding); row_slot [Cmax, pairs*N] =
+ *     the row of (chunk, cell) or -1.
+ * Capacities are host-side: Cmax >= the largest chunk count (<= floor((N-1)/max_once_used) + 1 and <= height + 1),
+ * rows_cap >= total rows (<= pairs * (N + (Cmax-1) * width)).  status (device int32): bit 0 = a pair had more than Cmax
+ * chunks, bit 1 = more rows than rows_cap (rows were dropped) - read it when convenient, e.g. with the results. */
+size_t pats_chunk_rows_workspace_bytes(int64_t pairs, int Cmax);
+int pats_chunk_rows_device(const uint8_t* if_nomatching1, int64_t pairs, int height, int width, int max_once_used,
+                           int Cmax, int64_t rows_cap, int32_t* sum_cycle, int32_t* cycle_num, int64_t* second,
+                           int64_t* third, uint8_t* masks, int64_t* chunk_base, int64_t* crop_base, int32_t* row_cell,
+                           uint8_t* row_forced, int32_t* row_crop, int32_t* row_slot, int32_t* status, void* workspace,
+                           size_t workspace_bytes, pats_stream_t stream);
+
+/* SecondLayer.merge_patches_new / _old (models/second_layer.py:137-238) for every chunk of every pair of the row table
+ * above, in the reference's order: chunk blocks one after the other (the chunks of a pair couple through scores_back,
+ * pats.py:32,37), each block over all pairs at once.  trust_score / if_nomatching1_L2 [rows_cap,144] are updated in place
+ * like the reference; scores_back [pairs, N, 16, 9] fp64 (zeros before the first chunk, pats.py:32); out [rows_cap,144] =
+ * the returned if_nomatching with pats.py:38-39 applied (row_forced) and padding rows all "no match". */
+size_t pats_merge_batch_workspace_bytes(int64_t pairs, int H, int W);
+int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, int H, int W, int64_t rows_cap,
+                             const int64_t* chunk_base, const int32_t* row_cell, const int32_t* row_slot,
+                             const uint8_t* row_forced, float* trust_score, uint8_t* if_nomatching1_L2,
+                             double* scores_back, uint8_t* out, void* workspace, size_t workspace_bytes,
+                             pats_stream_t stream);
 
 /* SecondLayer.merge_patches_new (merge_new != 0, reference models/second_layer.py:193-240) and
  * merge_patches_old (merge_new == 0, :137-191): resolves every 8-px cell among the up to nine 96x96
@@ -303,6 +351,19 @@ int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uin
                         const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
                         const uint8_t* left_choice1, float* matches_l, float* matches_r, int64_t capacity,
                         int64_t* count, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
+/* get_result for every (chunk, pair) of a batch in ONE call (models/pats.py:68-73, utils/utils.py:189-213): level-0
+ * batch = the Cmax * pairs chunk masks, level-1 rows = the row table of pats_chunk_rows_device.  pts_new, scales
+ * [pairs, N, 2] are the per-pair tensors of Compute_imgs (not expanded over the chunks, not flipped - pats.py:71's
+ * `.flip(dims=[2]) / 32.0` happens on load), pts16 [rows_cap, n1, 2] un-flipped (`/ 2.0` on load), the level-1 scale of a
+ * row is the level-0 scale of its cell (pats.py:70).  match_row [capacity] (optional) = the row of every match: row_cell
+ * [match_row] / N is its pair.  Same arithmetic and output order as pats_get_result_f32 on the expanded tensors. */
+int pats_get_result_chunks_f32(int Cmax, int64_t pairs, const uint8_t* masks, const uint8_t* if_nomatching16,
+                               int64_t rows_cap, const float* pts_new, const float* pts16, const float* scales,
+                               const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
+                               const uint8_t* left_choice1, float* matches_l, float* matches_r, int32_t* match_row,
+                               int64_t capacity, int64_t* count, void* workspace, size_t workspace_bytes,
+                               pats_stream_t stream);
 
 /* attention(query, key, value) of the GNN layers (reference models/modules.py:84-88; the core of
  * MultiHeadedAttention.forward :100-105): scores = q^T k / dim**.5 per (batch, head), softmax over the

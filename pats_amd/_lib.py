@@ -74,6 +74,19 @@ SIGNATURES = {
     "pats_third_level_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
+    "pats_third_descriptors_counted_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pats_third_level_counted_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
+    "pats_chunk_rows_workspace_bytes": (c_size, [c_i64, c_int]),
+    "pats_chunk_rows_device": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_int, c_i64] + [c_void_p] * 13 +
+                               [c_size, c_void_p]),
+    "pats_merge_batch_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "pats_merge_patches_batch": (c_int, [c_int, c_int, c_i64, c_int, c_int, c_i64] + [c_void_p] * 9 + [c_size, c_void_p]),
+    "pats_get_result_chunks_f32": (c_int, [c_int, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+                                           ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_merge_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "pats_merge_patches": (c_int, [c_int, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size, c_void_p]),

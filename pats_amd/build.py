@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libpats_amd.so")
 LIB_DIAG = os.path.join(HERE, "libpats_amd_diag.so")
 DIAG_SOURCES = {"third_fused3.hip": ["-DPATS_DIAG=1"]}
 SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip", "gnn.hip",
-           "fused.hip", "scale_head.hip"]
+           "fused.hip", "scale_head.hip", "batch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 # third_fused.hip runs at the 168-VGPR edge (three waves per SIMD).  The SLP vectoriser pairs the

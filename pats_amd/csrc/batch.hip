@@ -1,0 +1,203 @@
+// Throughput mode of the chunk loop of PATS.forward (models/pats.py:33-39) for a BATCH of image pairs, with no host
+// read: the reference walks `result_first['output_list']` (first_layer.py:131-146: one boolean mask, one crop gather
+// and one SecondLayer call per chunk, each boolean-mask indexing a device->host sync) - here one launch sequence
+// expands the chunk plans of all pairs into the fine level's ROW TABLE:
+//
+//   row r  <->  (chunk c, pair p, matched coarse cell q),  rows ordered (chunk, pair, cell).
+//
+// Chunk-major order makes "chunk c of every pair" one contiguous block of rows [chunk_base[c], chunk_base[c+1]), which
+// is what SecondLayer.merge_patches_* needs: the chunks of ONE pair couple through scores_back (pats.py:32,37) and must
+// run in order, the pairs are independent - so the merge is Cmax launch groups, each over all pairs (merge.hip).  The
+// same order is the level-1 row order of get_result when the (chunk, pair) masks are its level-0 batch (pats.py:68-73).
+//
+// Everything is sized by capacities known on the host (rows_cap, Cmax); the actual counts stay on the device.
+#include "common.hpp"
+#include "chunk_plan.hpp"
+
+namespace pats {
+
+struct ChunkRowsArgs {
+    const uint8_t* ifn1;      // [pairs, N]   if_nomatching1 of the coarse level (first_layer.py:162-167)
+    int64_t pairs;
+    int h, w, cap, Cmax;
+    int64_t rows_cap;
+    int32_t* sum_cycle;       // [pairs, N]   cumsum of matched flags (first_layer.py:130)
+    int32_t* cycle_num;       // [pairs]
+    int64_t* second;          // [pairs, h+1, 2]
+    int64_t* third;           // [pairs, h+1, 2]
+    uint8_t* masks;           // [Cmax, pairs, N]  chunk masks (first_layer.py:137-138), 1 = not in this chunk
+    int64_t* chunk_base;      // [Cmax + 1]   first row of every chunk block; [Cmax] = total rows
+    int64_t* crop_base;       // [pairs + 1]  first crop of every pair in the (image, patch)-ordered crop table
+    int32_t* row_cell;        // [rows_cap]   p * N + q, or -1 beyond the total
+    uint8_t* row_forced;      // [rows_cap]   1: the row is one of the chunk's last `third_layer_set[c][1]` rows (pats.py:38-39) or padding
+    int32_t* row_crop;        // [rows_cap]   crop index of the row's patch
+    int32_t* row_slot;        // [Cmax, pairs * N]  row of (chunk, cell) or -1
+    int32_t* counts;          // workspace [Cmax * pairs]
+    int64_t* pair_base;       // workspace [Cmax * pairs]
+    int32_t* status;          // bit 0: a pair has more than Cmax chunks; bit 1: more rows than rows_cap (both: rows dropped)
+};
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// one 256-thread workgroup per pair: cumulative match count, chunk plan, rows per chunk
+__global__ void __launch_bounds__(256)
+chunk_plan_kernel(ChunkRowsArgs g) {
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int64_t p = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, N = g.h * g.w;
+    const uint8_t* f = g.ifn1 + p * N;
+    int32_t* sc = g.sum_cycle + p * N;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < N; q0 += 256) {
+        const int q = q0 + t;
+        const int keep = (q < N) ? (f[q] == 0) : 0;
+        const int incl = wave_incl_scan_i(keep, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = carry;
+        for (int k = 0; k < wave; ++k) base += wsum[k];
+        if (q < N) sc[q] = base + incl;
+        __syncthreads();
+        if (t == 255) carry = base + incl;
+        __syncthreads();
+    }
+    if (t != 0) return;
+    const int row = 2 * (g.h + 1);
+    int64_t* second = g.second + p * row;
+    int64_t* third = g.third + p * row;
+    for (int k = 0; k < row; ++k) { second[k] = 0; third[k] = 0; }
+    const int num = split_patches_plan(sc, g.h, g.w, g.cap, second, third);
+    g.cycle_num[p] = num;
+    const int64_t K = sc[N - 1];
+    if (num > g.Cmax) atomicOr(g.status, 1);
+    for (int c = 0; c < g.Cmax; ++c) {
+        int64_t n = 0;
+        if (c < num) {
+            const int64_t lo = second[2 * c], hi = second[2 * c + 1];
+            n = (hi < K ? hi : K) - lo;
+            if (n < 0) n = 0;
+        }
+        g.counts[(int64_t)c * g.pairs + p] = (int32_t)n;
+    }
+    g.crop_base[p + 1] = K;        // turned into a prefix by chunk_prefix_kernel
+}
+
+// one workgroup: exclusive prefix of the (chunk, pair) row counts in chunk-major order, and of the crop counts
+__global__ void __launch_bounds__(256)
+chunk_prefix_kernel(ChunkRowsArgs g) {
+    __shared__ int64_t wsum[4];
+    __shared__ int64_t carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t n = (int64_t)g.Cmax * g.pairs;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        const int64_t i = i0 + t;
+        const int v = i < n ? g.counts[i] : 0;
+        const int incl = wave_incl_scan_i(v, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int64_t base = carry;
+        for (int k = 0; k < wave; ++k) base += wsum[k];
+        if (i < n) {
+            g.pair_base[i] = base + incl - v;
+            if (i % g.pairs == 0) g.chunk_base[i / g.pairs] = base + incl - v;
+        }
+        __syncthreads();
+        if (t == 255) carry = base + incl;
+        __syncthreads();
+    }
+    if (t == 0) {
+        g.chunk_base[g.Cmax] = carry;
+        if (carry > g.rows_cap) atomicOr(g.status, 2);
+        int64_t run = 0;
+        g.crop_base[0] = 0;
+        for (int64_t p = 0; p < g.pairs; ++p) { run += g.crop_base[p + 1]; g.crop_base[p + 1] = run; }
+    }
+}
+
+// one thread per (pair, cell): its chunk masks and, where it belongs to a chunk, its row
+__global__ void __launch_bounds__(256)
+chunk_fill_kernel(ChunkRowsArgs g) {
+    const int N = g.h * g.w;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.pairs * N) return;
+    const int64_t p = e / N;
+    const int q = (int)(e - p * N);
+    const int num = g.cycle_num[p];
+    const int32_t sc = g.sum_cycle[e];
+    const bool nomatch = g.ifn1[e] != 0;
+    const int64_t K = g.sum_cycle[p * N + N - 1];
+    const int row = 2 * (g.h + 1);
+    for (int c = 0; c < g.Cmax; ++c) {
+        bool m = true;
+        int32_t slot = -1;
+        if (c < num) {
+            const int64_t lo = g.second[p * row + 2 * c], hi = g.second[p * row + 2 * c + 1];
+            m = nomatch || sc <= lo || sc > hi;                         // first_layer.py:137-138
+            if (!m) {
+                const int64_t n = (hi < K ? hi : K) - lo, rank = sc - lo - 1;
+                const int64_t r = g.pair_base[(int64_t)c * g.pairs + p] + rank;
+                if (r < g.rows_cap) {
+                    const int64_t tail = g.third[p * row + 2 * c + 1];  // pats.py:38-39: if_nomatching1[-tail:, :] = True
+                    const bool forced = tail > 0 ? rank >= n - tail : (tail < 0 ? rank >= -tail : false);
+                    g.row_cell[r] = (int32_t)e;
+                    g.row_forced[r] = forced ? 1 : 0;
+                    g.row_crop[r] = (int32_t)(g.crop_base[p] + sc - 1);
+                    slot = (int32_t)r;
+                }
+            }
+        }
+        g.masks[((int64_t)c * g.pairs + p) * N + q] = m ? 1 : 0;
+        g.row_slot[(int64_t)c * g.pairs * N + e] = slot;
+    }
+}
+
+}  // namespace pats
+
+using namespace pats;
+
+extern "C" size_t pats_chunk_rows_workspace_bytes(int64_t pairs, int Cmax) {
+    if (pairs < 0 || Cmax < 1) return 0;
+    const int64_t n = pairs * Cmax;
+    return (size_t)(((n + 3) & ~3ll) * sizeof(int32_t) + n * sizeof(int64_t) + 64);
+}
+
+extern "C" int pats_chunk_rows_device(const uint8_t* if_nomatching1, int64_t pairs, int height, int width,
+                                      int max_once_used, int Cmax, int64_t rows_cap, int32_t* sum_cycle,
+                                      int32_t* cycle_num, int64_t* second, int64_t* third, uint8_t* masks,
+                                      int64_t* chunk_base, int64_t* crop_base, int32_t* row_cell, uint8_t* row_forced,
+                                      int32_t* row_crop, int32_t* row_slot, int32_t* status, void* workspace,
+                                      size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(pairs >= 0 && height > 0 && width > 0 && max_once_used > 0 && Cmax >= 1 && Cmax <= height + 1 && rows_cap >= 0,
+                 "chunk_rows_device: bad argument (1 <= Cmax <= height + 1)");
+    if (pairs == 0) return PATS_OK;
+    PATS_REQUIRE(if_nomatching1 && sum_cycle && cycle_num && second && third && masks && chunk_base && crop_base && row_cell &&
+                     row_forced && row_crop && row_slot && status, "chunk_rows_device: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_chunk_rows_workspace_bytes(pairs, Cmax), "chunk_rows_device: workspace too small");
+    PATS_REQUIRE(pairs * (int64_t)height * width < (1ll << 31) && rows_cap < (1ll << 31), "chunk_rows_device: batch too large");
+    hipStream_t st = as_stream(stream);
+    const int64_t n = pairs * Cmax;
+    int64_t* pair_base = reinterpret_cast<int64_t*>(workspace);
+    int32_t* counts = reinterpret_cast<int32_t*>(pair_base + n);
+    ChunkRowsArgs g{if_nomatching1, pairs, height, width, max_once_used, Cmax, rows_cap, sum_cycle, cycle_num, second, third,
+                    masks, chunk_base, crop_base, row_cell, row_forced, row_crop, row_slot, counts, pair_base, status};
+    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess ||
+        (rows_cap > 0 && (hipMemsetAsync(row_cell, 0xff, sizeof(int32_t) * (size_t)rows_cap, st) != hipSuccess ||
+                          hipMemsetAsync(row_crop, 0xff, sizeof(int32_t) * (size_t)rows_cap, st) != hipSuccess ||
+                          hipMemsetAsync(row_forced, 1, (size_t)rows_cap, st) != hipSuccess)))
+        return check_launch("chunk_rows memset");
+    hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)pairs), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(chunk_fill_kernel, dim3((unsigned)ceil_div(pairs * height * width, 256)), dim3(256), 0, st, g);
+    return check_launch("chunk_rows_device");
+}

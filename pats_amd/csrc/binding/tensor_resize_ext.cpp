@@ -6,8 +6,10 @@
 // pointers + the caller's current HIP stream to the C-ABI `pats_tensor_resize_f32` of libpats_amd.so
 // (include/pats_amd.h), where the gather kernel lives (csrc/resize.hip).  There is no host path: a CPU tensor raises.
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm keeps the device type named `cuda` (torch.device("cuda") IS the MI355X), so the guard and the stream
+// come from the HIP implementations registered under that name; the plain c10::hip::HIPGuard refuses such a device.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "pats_amd.h"
 
@@ -28,7 +30,7 @@ torch::Tensor resize(const torch::Tensor& input_tensor, const torch::Tensor& bou
   TORCH_CHECK(input_tensor.size(0) < (1 << 30) && input_tensor.size(1) < (1 << 30) &&
               input_tensor.size(2) < (1 << 30) && input_tensor.size(3) < (1 << 30), "tensor_resize: input too large");
 
-  const c10::hip::HIPGuard guard(input_tensor.device());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(input_tensor.device());
   const auto in = input_tensor.contiguous();      // borrowed; a strided view is packed, never written
   const auto bnd = bound.contiguous();
   const int64_t K = bnd.size(0);
@@ -39,7 +41,7 @@ torch::Tensor resize(const torch::Tensor& input_tensor, const torch::Tensor& bou
   // memory-safe for any bound (it clamps) and raises this flag instead; reading it back is the call's one host sync
   // (the reference makes five per crop).
   auto status = torch::zeros({1}, bnd.options().dtype(torch::kInt));
-  const auto stream = c10::hip::getCurrentHIPStream(input_tensor.device().index());
+  const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(input_tensor.device().index());
   const int rc = pats_tensor_resize_f32(in.data_ptr<float>(), static_cast<int>(in.size(0)), static_cast<int>(in.size(1)),
                                         static_cast<int>(in.size(2)), static_cast<int>(in.size(3)),
                                         bnd.data_ptr<int64_t>(), K, out.data_ptr<float>(), status.data_ptr<int32_t>(),

@@ -63,9 +63,10 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
                   const int64_t* __restrict__ b_ids, const float* __restrict__ kenc,
                   const float* __restrict__ rubbish, int64_t P, int64_t B,
                   float* __restrict__ out0, float* __restrict__ out1, int64_t* __restrict__ ps_out,
-                  int64_t* __restrict__ pt_out) {
+                  int64_t* __restrict__ pt_out, const int64_t* __restrict__ P_dev) {
     constexpr int W = 8, M = 52, C = 128;
     const int64_t p = blockIdx.x;
+    if (P_dev && p >= *P_dev) return;        // throughput mode: the launch covers the capacity, the count is on the device
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = b_ids[p];
     // mkpts0_c = round(mkpts0_c / 4) * 4                                    third_layer.py:124
@@ -134,6 +135,20 @@ extern "C" int pats_third_descriptors_f32(const float* feat_f0, const float* fea
     PATS_REQUIRE(feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
                  "third_descriptors: null pointer");
     hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)P), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
-                       mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P, B, out0, out1, p_s_out, p_t_out);
+                       mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P, B, out0, out1, p_s_out, p_t_out, (const int64_t*)nullptr);
+    return check_launch("third_desc_kernel");
+}
+
+extern "C" int pats_third_descriptors_counted_f32(const float* feat_f0, const float* feat_f1,
+                                                  const float* mkpts0_c, const float* mkpts1_c,
+                                                  const int64_t* b_ids, const float* kenc, const float* rubbish,
+                                                  int64_t P_cap, const int64_t* P_dev, int64_t B, float* out0, float* out1,
+                                                  int64_t* p_s_out, int64_t* p_t_out, pats_stream_t stream) {
+    PATS_REQUIRE(P_cap >= 0 && B > 0, "third_descriptors_counted: bad shape");
+    if (P_cap == 0) return PATS_OK;
+    PATS_REQUIRE(P_dev && feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
+                 "third_descriptors_counted: null pointer");
+    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)P_cap), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
+                       mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P_cap, B, out0, out1, p_s_out, p_t_out, P_dev);
     return check_launch("third_desc_kernel");
 }

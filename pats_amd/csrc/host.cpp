@@ -1,5 +1,6 @@
 // Host-side pieces of libpats_amd.so: error plumbing, version, and the chunk planner.
 #include "common.hpp"
+#include "chunk_plan.hpp"
 
 #include <mutex>
 #include <string>
@@ -92,8 +93,6 @@ extern "C" int pats_sinkhorn_fallbacks(int64_t* count, int reset) {
 // says how many leading / trailing patches of a chunk belong to the neighbouring chunk).
 // Python's negative index sum_cycle[i*width - 1] at i == 0 (last element) is reproduced.
 namespace pats {
-__host__ __device__ inline int split_patches_plan(const int32_t* sc, int height, int width, int max_once_used,
-                                                  int64_t* second, int64_t* third);
 // one thread per image pair: the plan is ~height comparisons on a cumsum that is already in L2
 __global__ void split_patches_kernel(const int32_t* __restrict__ sc, int64_t pairs, int height, int width,
                                      int max_once_used, int64_t* __restrict__ second, int64_t* __restrict__ third,
@@ -125,31 +124,4 @@ extern "C" int pats_split_patches(const int32_t* sc, int height, int width, int 
         return -PATS_ERR_INVALID;
     }
     return split_patches_plan(sc, height, width, max_once_used, second, third);
-}
-
-__host__ __device__ inline int pats::split_patches_plan(const int32_t* sc, int height, int width, int max_once_used,
-                                                        int64_t* second, int64_t* third) {
-    const int64_t L = (int64_t)height * width;
-    auto at = [&](int64_t i) -> int64_t { return sc[((i % L) + L) % L]; };
-    int cycle = 0, last_second = 0, last_third = 0;
-    for (int i = 0; i < height; ++i) {
-        const int64_t num = at((int64_t)(i + 1) * width - 1);
-        if (num > (int64_t)max_once_used * (cycle + 1)) {
-            const int64_t origin = last_second == 0 ? 0 : at((int64_t)last_second * width - 1);
-            second[2 * cycle] = origin;
-            second[2 * cycle + 1] = num;
-            third[2 * cycle] = at((int64_t)last_third * width) - origin;
-            third[2 * cycle + 1] = num - at((int64_t)i * width - 1);
-            ++cycle;
-            last_second = i;
-            last_third = i + 1;
-        }
-    }
-    const int64_t origin = last_second == 0 ? 0 : at((int64_t)last_second * width - 1);
-    second[2 * cycle] = origin;
-    second[2 * cycle + 1] = L;
-    const int64_t end_num = (last_third == height) ? origin : at((int64_t)last_third * width);
-    third[2 * cycle] = end_num - origin;
-    third[2 * cycle + 1] = 0;
-    return cycle + 1;
 }

@@ -102,6 +102,18 @@ static int run_scan(const uint8_t* flags, int64_t n, int64_t* total_dev, char** 
 }
 
 // ---- merge_patches ----------------------------------------------------------------------------------
+// The rows one merge call works on.  Single-chunk API: rows [0, count) of the caller's tensors.  Batch mode
+// (pats_merge_patches_batch): block [blk[0], blk[1]) of the row table of batch.hip, read from DEVICE memory - the launch
+// covers the block's capacity and threads past its end leave.
+struct RowBlock {
+    const int64_t* blk;
+    int64_t count;
+    __device__ __forceinline__ void get(int64_t& base, int64_t& n) const {
+        base = blk ? blk[0] : 0;
+        n = blk ? blk[1] - blk[0] : count;
+    }
+};
+
 // slot[q] = row of trust_score that coarse patch q owns in this chunk, or -1; patch_of[b] = its inverse
 __global__ void __launch_bounds__(256)
 merge_slots_kernel(const uint8_t* __restrict__ ifn_L1, Scan sc, int64_t NP, int64_t B, int32_t* __restrict__ slot,
@@ -119,11 +131,13 @@ merge_slots_kernel(const uint8_t* __restrict__ ifn_L1, Scan sc, int64_t NP, int6
 
 // border weighting, flag update, score hand-over into scores_back (second_layer.py:140-149,161-163 / :192-201,210-211)
 __global__ void __launch_bounds__(256)
-merge_prepare_kernel(int merge_new, int64_t B, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
+merge_prepare_kernel(int merge_new, RowBlock rb, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
                      const int32_t* __restrict__ patch_of, double* __restrict__ scores_back) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= B * 144) return;
-    const int64_t b = e / 144;
+    int64_t base, B;
+    rb.get(base, B);
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= B * 144) return;
+    const int64_t e = el + base * 144, b = e / 144;
     const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
     float t = trust[e];
 #pragma unroll
@@ -152,12 +166,14 @@ struct MergeGeom {
 // argsort runs on scores_back_use, not on the re-gathered copy (:232).  The value scattered is
 // if_matching2[Y, X, sb] = if_matching at the entry itself, i.e. the (updated) L2 flag.
 __global__ void __launch_bounds__(256)
-merge_select_new_kernel(MergeGeom g, int64_t B, const int32_t* __restrict__ patch_of,
+merge_select_new_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ patch_of,
                         const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
-                        uint8_t* __restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= B * 144) return;
-    const int64_t b = e / 144;
+                        const uint8_t* __restrict__ row_forced, uint8_t* __restrict__ out) {
+    int64_t base, B;
+    rb.get(base, B);
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= B * 144) return;
+    const int64_t e = el + base * 144, b = e / 144;
     const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
     const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
     const int64_t q = patch_of[b];
@@ -182,6 +198,7 @@ merge_select_new_kernel(MergeGeom g, int64_t B, const int32_t* __restrict__ patc
             if (sb == 8 - (a * 3 + c)) res = ifn_L2[e];
         }
     }
+    if (row_forced && row_forced[b]) res = 1;          // pats.py:38-39 on the returned flags (batch mode)
     out[e] = res;
 }
 
@@ -222,11 +239,14 @@ merge_scatter_old_kernel(MergeGeom g, int batch_num, const int32_t* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-merge_finish_old_kernel(MergeGeom g, int64_t B, const int32_t* __restrict__ patch_of,
-                        const unsigned* __restrict__ winner, uint8_t* __restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= B * 144) return;
-    const int64_t b = e / 144;
+merge_finish_old_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ patch_of,
+                        const unsigned* __restrict__ winner, const uint8_t* __restrict__ row_forced,
+                        uint8_t* __restrict__ out) {
+    int64_t base, B;
+    rb.get(base, B);
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= B * 144) return;
+    const int64_t e = el + base * 144, b = e / 144;
     const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
     const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
     const int64_t q = patch_of[b];
@@ -238,6 +258,7 @@ merge_finish_old_kernel(MergeGeom g, int64_t B, const int32_t* __restrict__ patc
         const unsigned v = winner[bt * g.per + ((int64_t)(4 * hh + r) * g.w4 + 4 * ww + s) * 9 + a * 3 + c];
         if (v) res = (uint8_t)(v & 1u);
     }
+    if (row_forced && row_forced[b]) res = 1;
     out[e] = res;
 }
 
@@ -302,6 +323,13 @@ struct ResultArgs {
     const int64_t* rows0_dev;    // number of surviving level-0 cells
     int64_t rows1, capacity;
     float* ml; float* mr;
+    // chunk-batch mode (pats_get_result_chunks_f32): the level-0 tensors cover `period0` cells (pairs * N) and every
+    // chunk of the level-0 batch reads the same ones (e % period0); points arrive un-flipped and un-divided
+    // (pats.py:71: `.flip(dims=[2]) / 32.0`, `/ 2.0` - done on load); the level-1 scale of row k is the level-0 scale of
+    // its cell (pats.py:70); match_row (optional) receives the level-1 row of every match
+    int64_t period0;
+    float ap0_div, ap1_div;
+    int32_t* match_row;
 };
 
 __global__ void __launch_bounds__(256)
@@ -315,23 +343,27 @@ get_result_kernel(ResultArgs g, const int32_t* __restrict__ row_cell, Scan sc1) 
     if (k >= *g.rows0_dev) return;                  // more rows than surviving cells: ignored
     const int64_t M = sc1.at(f);
     if (M >= g.capacity) return;
-    const int64_t e = row_cell[k];
-    const unsigned bt = (unsigned)e / n0, i = (unsigned)e - bt * n0;
+    const int64_t ecell = row_cell[k];
+    const unsigned bt = (unsigned)ecell / n0, i = (unsigned)ecell - bt * n0;
+    const int64_t e = g.period0 ? ecell % g.period0 : ecell;      // where the level-0 point / scale of that cell live
     const bool c0 = g.ch0[bt] != 0, c1 = g.ch1[k] != 0;
     const float z0 = (float)g.s0, z1 = (float)g.s1;
-    const float sc1l = g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride + 1 : k * 2 + 1];
-    const float sc1r = g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride : k * 2];
+    const float sc1l = g.sc1 ? g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride + 1 : k * 2 + 1] : g.sc0[e * 2 + 1];
+    const float sc1r = g.sc1 ? g.sc1[g.sc1_cell_stride ? f * g.sc1_cell_stride : k * 2] : g.sc0[e * 2];
+    if (g.match_row) g.match_row[M] = (int32_t)k;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
         const float pos0 = (float)((d == 0 ? i / (unsigned)g.w0 : i % (unsigned)g.w0) * (unsigned)g.s0);
         float dl0 = pos0 + 0.5f * z0;
         dl0 = dl0 - (1.5f * g.sc0[e * 2 + 1]) * z0;
-        const float dr0 = (g.ap0[e * 2 + d] - 1.5f * g.sc0[e * 2]) * z0;
+        const float a0 = g.ap0_div != 0.0f ? g.ap0[e * 2 + (1 - d)] / g.ap0_div : g.ap0[e * 2 + d];
+        const float a1 = g.ap1_div != 0.0f ? g.ap1[f * 2 + (1 - d)] / g.ap1_div : g.ap1[f * 2 + d];
+        const float dr0 = (a0 - 1.5f * g.sc0[e * 2]) * z0;
         const float l0 = 0.0f + (c0 ? dl0 : dr0), r0 = 0.0f + (c0 ? dr0 : dl0);
         const float pos1 = (float)((d == 0 ? j / (unsigned)g.w1 : j % (unsigned)g.w1) * (unsigned)g.s1);
         float dl1 = pos1 + 0.5f * z1;
         dl1 = dl1 * sc1l;
-        const float dr1 = (g.ap1[f * 2 + d] * z1) * sc1r;
+        const float dr1 = (a1 * z1) * sc1r;
         g.ml[M * 2 + d] = l0 + (c1 ? dl1 : dr1);
         g.mr[M * 2 + d] = r0 + (c1 ? dr1 : dl1);
     }
@@ -371,19 +403,67 @@ extern "C" int pats_merge_patches(int merge_new, int64_t B, float* trust_score, 
     unsigned* winner = reinterpret_cast<unsigned*>(patch_of + ((B + 4) & ~3ll));
     if (hipMemsetAsync(patch_of, 0xff, sizeof(int32_t) * (size_t)B, st) != hipSuccess) return check_launch("merge memset");
     hipLaunchKernelGGL(merge_slots_kernel, dim3(blocks256(NP)), dim3(256), 0, st, if_nomatching1_L1, sc, NP, B, slot, patch_of);
-    hipLaunchKernelGGL(merge_prepare_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, merge_new, B, trust_score,
+    const RowBlock rb{nullptr, B};
+    hipLaunchKernelGGL(merge_prepare_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, merge_new, rb, trust_score,
                        if_nomatching1_L2, patch_of, scores_back);
     if (merge_new) {
-        hipLaunchKernelGGL(merge_select_new_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, g, B, patch_of,
-                           if_nomatching1_L2, scores_back, out);
+        hipLaunchKernelGGL(merge_select_new_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, g, rb, patch_of,
+                           if_nomatching1_L2, scores_back, (const uint8_t*)nullptr, out);
     } else {
         if (hipMemsetAsync(winner, 0, sizeof(unsigned) * (size_t)(batch_num * g.per), st) != hipSuccess)
             return check_launch("merge memset");
         hipLaunchKernelGGL(merge_scatter_old_kernel, dim3(blocks256((int64_t)g.h4 * g.w4 * batch_num)), dim3(256), 0, st, g,
                            batch_num, slot, if_nomatching1_L2, scores_back, winner);
-        hipLaunchKernelGGL(merge_finish_old_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, g, B, patch_of, winner, out);
+        hipLaunchKernelGGL(merge_finish_old_kernel, dim3(blocks256(B * 144)), dim3(256), 0, st, g, rb, patch_of, winner,
+                           (const uint8_t*)nullptr, out);
     }
     return check_launch("merge_patches");
+}
+
+// ---- the merges of a batch of pairs: chunk blocks in order, every block over all pairs (row table of batch.hip) ----
+extern "C" size_t pats_merge_batch_workspace_bytes(int64_t pairs, int H, int W) {
+    if (pairs < 1 || H < 32 || W < 32) return 0;
+    return (size_t)(pairs * (int64_t)(H / 32) * 4 * (W / 32) * 4 * 9) * sizeof(unsigned) + 64;
+}
+
+extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, int H, int W, int64_t rows_cap,
+                                        const int64_t* chunk_base, const int32_t* row_cell, const int32_t* row_slot,
+                                        const uint8_t* row_forced, float* trust_score, uint8_t* if_nomatching1_L2,
+                                        double* scores_back, uint8_t* out, void* workspace, size_t workspace_bytes,
+                                        pats_stream_t stream) {
+    PATS_REQUIRE(Cmax >= 1 && pairs >= 0 && H >= 32 && W >= 32 && rows_cap >= 0, "merge_patches_batch: bad shape");
+    if (pairs == 0 || rows_cap == 0) return PATS_OK;
+    PATS_REQUIRE(chunk_base && row_cell && row_slot && row_forced && trust_score && if_nomatching1_L2 && scores_back && out,
+                 "merge_patches_batch: null pointer");
+    PATS_REQUIRE(merge_new || (workspace && workspace_bytes >= pats_merge_batch_workspace_bytes(pairs, H, W)),
+                 "merge_patches_batch: workspace too small");
+    hipStream_t st = as_stream(stream);
+    MergeGeom g{H / 32, W / 32, 4 * (H / 32), 4 * (W / 32), (int64_t)(H / 32) * 4 * (W / 32) * 4 * 9};
+    const int64_t NP = pairs * g.h * g.w;
+    const int64_t block_cap = NP < rows_cap ? NP : rows_cap;       // a chunk block holds at most one row per coarse cell
+    unsigned* winner = reinterpret_cast<unsigned*>(workspace);
+    // rows outside every block (padding past the total) are never visited: "no match"
+    if (hipMemsetAsync(out, 1, (size_t)rows_cap * 144, st) != hipSuccess) return check_launch("merge_batch memset");
+    for (int c = 0; c < Cmax; ++c) {
+        const RowBlock rb{chunk_base + c, 0};
+        hipLaunchKernelGGL(merge_prepare_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, merge_new, rb, trust_score,
+                           if_nomatching1_L2, row_cell, scores_back);
+        if (merge_new) {
+            hipLaunchKernelGGL(merge_select_new_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, g, rb, row_cell,
+                               if_nomatching1_L2, scores_back, row_forced, out);
+        } else {
+            if (hipMemsetAsync(winner, 0, sizeof(unsigned) * (size_t)(pairs * g.per), st) != hipSuccess)
+                return check_launch("merge_batch memset");
+            hipLaunchKernelGGL(merge_scatter_old_kernel, dim3(blocks256((int64_t)g.h4 * g.w4 * pairs)), dim3(256), 0, st, g,
+                               (int)pairs, row_slot + (int64_t)c * NP, if_nomatching1_L2, scores_back, winner);
+            hipLaunchKernelGGL(merge_finish_old_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, g, rb, row_cell, winner,
+                               row_forced, out);
+            // merge_patches_old hands back a zeroed scores_back (second_layer.py:191): the next chunk starts from zeros
+            if (hipMemsetAsync(scores_back, 0, sizeof(double) * (size_t)(NP * 144), st) != hipSuccess)
+                return check_launch("merge_batch memset");
+        }
+    }
+    return check_launch("merge_patches_batch");
 }
 
 extern "C" size_t pats_compact_workspace_bytes(int64_t n) { return n < 0 ? 0 : scan_bytes(n) + 64; }
@@ -428,13 +508,13 @@ extern "C" size_t pats_get_result_workspace_bytes(int64_t cells0, int64_t rows1,
     return scan_bytes(cells0) + scan_bytes(rows1 * cells1) + (size_t)((rows1 + 4) & ~3ll) * sizeof(int32_t) + 64;
 }
 
-extern "C" int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uint8_t* if_nomatching1,
+static int get_result_impl(int batch_size, const uint8_t* if_nomatching0, const uint8_t* if_nomatching1,
                                    int64_t rows1, const float* average_point0, const float* average_point1,
                                    const float* scale0, const float* scale1, int64_t scale1_cell_stride,
                                    const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
                                    const uint8_t* left_choice1, float* matches_l, float* matches_r,
                                    int64_t capacity, int64_t* count, void* workspace, size_t workspace_bytes,
-                                   pats_stream_t stream) {
+                                   pats_stream_t stream, int64_t period0, float ap0_div, float ap1_div, int32_t* match_row) {
     PATS_REQUIRE(batch_size >= 1 && rows1 >= 0 && capacity >= 0 && patch_size0 && patch_size1, "get_result: bad shape");
     PATS_REQUIRE(scale1_cell_stride == 0 || scale1_cell_stride == 2, "get_result: scale1_cell_stride must be 0 or 2");
     PATS_REQUIRE(count, "get_result: null count");
@@ -452,15 +532,46 @@ extern "C" int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0
     if (rc != PATS_OK) return rc;
     rc = run_scan(if_nomatching1, rows1 * n1, count, &ws, &s1, st);
     if (rc != PATS_OK || rows1 == 0) return rc;
-    PATS_REQUIRE(if_nomatching1 && average_point1 && scale1 && left_choice1 && (capacity == 0 || (matches_l && matches_r)),
+    PATS_REQUIRE(if_nomatching1 && average_point1 && (scale1 || period0) && left_choice1 && (capacity == 0 || (matches_l && matches_r)),
                  "get_result: null pointer");
     int32_t* row_cell = reinterpret_cast<int32_t*>(ws);
     hipLaunchKernelGGL(result_rows_kernel, dim3(blocks256(cells0)), dim3(256), 0, st, if_nomatching0, cells0, s0, rows1, row_cell);
     ResultArgs g{if_nomatching1, average_point0, average_point1, scale0, scale1, scale1_cell_stride,
                  patch_size0[0], patch_size0[1], patch_size0[2], patch_size1[0], patch_size1[1], patch_size1[2],
-                 left_choice0, left_choice1, rows0_dev, rows1, capacity, matches_l, matches_r};
+                 left_choice0, left_choice1, rows0_dev, rows1, capacity, matches_l, matches_r, period0, ap0_div, ap1_div,
+                 match_row};
     const int64_t blocks = rows1 * (((int64_t)n1 + 255) / 256);
     PATS_REQUIRE(blocks < (1ll << 31), "get_result: grid too large (split the batch)");
     hipLaunchKernelGGL(get_result_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, row_cell, s1);
     return check_launch("get_result_kernel");
+}
+
+extern "C" int pats_get_result_f32(int batch_size, const uint8_t* if_nomatching0, const uint8_t* if_nomatching1,
+                                   int64_t rows1, const float* average_point0, const float* average_point1,
+                                   const float* scale0, const float* scale1, int64_t scale1_cell_stride,
+                                   const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
+                                   const uint8_t* left_choice1, float* matches_l, float* matches_r,
+                                   int64_t capacity, int64_t* count, void* workspace, size_t workspace_bytes,
+                                   pats_stream_t stream) {
+    return get_result_impl(batch_size, if_nomatching0, if_nomatching1, rows1, average_point0, average_point1, scale0, scale1,
+                           scale1_cell_stride, patch_size0, patch_size1, left_choice0, left_choice1, matches_l, matches_r,
+                           capacity, count, workspace, workspace_bytes, stream, 0, 0.0f, 0.0f, nullptr);
+}
+
+// get_result of a batch of pairs in one call (pats.py:68-73 for every (chunk, pair) at once): level-0 batch = the
+// Cmax * pairs chunk masks of batch.hip, level-1 rows = the row table; pts_new / scales are the PER-PAIR tensors
+// [pairs, N, 2] (never expanded over the chunks), points un-flipped; match_row tells which row - hence which pair -
+// every match belongs to.
+extern "C" int pats_get_result_chunks_f32(int Cmax, int64_t pairs, const uint8_t* masks, const uint8_t* if_nomatching16,
+                                          int64_t rows_cap, const float* pts_new, const float* pts16, const float* scales,
+                                          const int* patch_size0, const int* patch_size1, const uint8_t* left_choice0,
+                                          const uint8_t* left_choice1, float* matches_l, float* matches_r,
+                                          int32_t* match_row, int64_t capacity, int64_t* count, void* workspace,
+                                          size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(Cmax >= 1 && pairs >= 1 && patch_size0, "get_result_chunks: bad shape");
+    PATS_REQUIRE((int64_t)Cmax * pairs < (1ll << 31), "get_result_chunks: batch too large");
+    const int64_t period0 = pairs * (int64_t)patch_size0[1] * patch_size0[2];
+    return get_result_impl((int)(Cmax * pairs), masks, if_nomatching16, rows_cap, pts_new, pts16, scales, nullptr, 0,
+                           patch_size0, patch_size1, left_choice0, left_choice1, matches_l, matches_r, capacity, count,
+                           workspace, workspace_bytes, stream, period0, 32.0f, 2.0f, match_row);
 }

@@ -1147,6 +1147,23 @@ int launch_cost_ot65(const float* d0, const float* d1, int64_t batch, int D, con
 }  // namespace pats
 
 
+// third-level step of a batch whose problem count lives on the device (throughput mode: no host read between the merge
+// that decides P and this launch): the grid covers the capacity P_cap, waves past *P_dev leave at once
+extern "C" int pats_third_level_counted_f32(const float* feat0, const float* feat1, int64_t P_cap, const int64_t* P_dev, int D,
+                                            const float* scale, const float* scale_x, const float* scale_y,
+                                            const int64_t* p_s, const int64_t* p_t, int iters, int outdoor,
+                                            float* mkpts0_f, float* mkpts1_f, float* label, uint8_t* if_matching1,
+                                            pats_stream_t stream) {
+    PATS_REQUIRE(P_cap >= 0 && D > 0 && (D % 32) == 0 && D <= 512 && iters >= 0,
+                 "third_level_counted: bad shape (D must be a multiple of 32, at most 512)");
+    if (P_cap == 0) return PATS_OK;
+    PATS_REQUIRE(P_dev && feat0 && feat1 && scale && p_s && p_t && mkpts0_f && mkpts1_f && label && if_matching1 &&
+                     ((scale_x == nullptr) == (scale_y == nullptr)), "third_level_counted: null pointer");
+    Fused65Args f{feat0, feat1, D, P_cap, scale, nullptr, iters, 1, scale_x, scale_y, p_s, p_t, outdoor,
+                  ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr}, 0, nullptr, 0, P_dev};
+    return launch_third_fused(f, as_stream(stream));
+}
+
 extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int64_t P, int D,
                                     const float* scale, const float* scale_x, const float* scale_y,
                                     const int64_t* p_s, const int64_t* p_t, int iters, int outdoor,

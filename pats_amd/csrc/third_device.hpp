@@ -34,7 +34,14 @@ struct Fused65Args {
     int stagger;
     unsigned long long* fallbacks;   // guard-trip counter or null
     int scan;                        // third_fused_kernel: re-solve only the problems flagged THIRD_REDO
+    const int64_t* P_dev;            // throughput mode: the launch covers the capacity P, *P_dev problems exist (or null)
 };
+// number of problems that exist: min(capacity, device-side count)
+__device__ __forceinline__ int64_t live_problems(const Fused65Args& g) {
+    if (!g.P_dev) return g.P;
+    const int64_t n = *g.P_dev;
+    return n < g.P ? n : g.P;
+}
 constexpr uint8_t THIRD_REDO = 0xEE; // if_matching1[p*16] of a problem the log-domain kernel must redo
 int launch_third_fused(const Fused65Args& g, hipStream_t st);
 
@@ -69,7 +76,7 @@ __device__ __forceinline__ void compute_result_problem(const float* Sp, int inpu
                                                        const float* sx, const float* sy, float ps0,
                                                        float ps1, float pt0, float pt1, int outdoor,
                                                        const ComputeResultOut& o, int lane,
-                                                       int compact_stride = 0) {
+                                                       int compact_stride = 0, bool scale_is_area = false) {
     constexpr int W = 8, T = 5, NN = 65;
     const int grp = lane >> 4, t = lane & 15;
     int local_count = 0;
@@ -115,8 +122,11 @@ __device__ __forceinline__ void compute_result_problem(const float* Sp, int inpu
                 float sbv = row[src];
                 if (input_is_log) sbv = expf(sbv);
                 sbv = inside ? sbv : 0.0f;                            // ZeroPad2d(2)           (:185)
-                const float scx = inside ? sx[src] : 1e-2f;           // ConstantPad2d(2, 1e-2) (:195-196)
-                const float scy = inside ? sy[src] : 1e-2f;
+                // scale_is_area: sx = sy = the OT's target areas and scale_x = scale_y = sqrt(area + 1e-8) is formed here
+                // (third_layer.py:153-154) instead of by the caller
+                float scx = inside ? sx[src] : 1e-2f;                 // ConstantPad2d(2, 1e-2) (:195-196)
+                float scy = inside ? sy[src] : 1e-2f;
+                if (scale_is_area && inside) scx = scy = sqrtf(scx + 1e-8f);
                 const float root = sqrtf(sbv + 1e-7f);
                 const float fx = root / scx, fy = root / scy;         // :197-198
                 wpx += fx * ((float)tx * 2.0f - (float)(T - 1));      // meshgrid * 2 - (T - 1)  (:199)

@@ -340,9 +340,11 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
         }
     }
     __syncthreads();
-    compute_result_problem(rows16, 0, p, g.scale_x + p * 64, g.scale_y + p * 64, (float)g.p_s[p * 2],
-                           (float)g.p_s[p * 2 + 1], (float)g.p_t[p * 2], (float)g.p_t[p * 2 + 1], g.outdoor,
-                           g.cr, lane, 66);
+    // scale_x == NULL: scale_x = scale_y = sqrt(ns + 1e-8) (third_layer.py:153-154) is formed in the kernel
+    const bool area = g.scale_x == nullptr;
+    compute_result_problem(rows16, 0, p, (area ? g.ns : g.scale_x) + p * 64, (area ? g.ns : g.scale_y) + p * 64,
+                           (float)g.p_s[p * 2], (float)g.p_s[p * 2 + 1], (float)g.p_t[p * 2], (float)g.p_t[p * 2 + 1],
+                           g.outdoor, g.cr, lane, 66, area);
 }
 
 // direct mode: one workgroup per problem.  scan mode (g.scan): workgroup w looks at problems 64w .. 64w+63 and
@@ -353,7 +355,7 @@ third_fused_kernel(Fused65Args g) {
     const int lane = threadIdx.x;
     if (!g.scan) {
         const int64_t p = blockIdx.x;
-        if (p >= g.P) return;
+        if (p >= live_problems(g)) return;
         // de-phase the first wave-front (see sinkhorn65_kernel)
         if (g.stagger > 0 && blockIdx.x < 8192u) {
             const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
@@ -363,7 +365,7 @@ third_fused_kernel(Fused65Args g) {
         return;
     }
     const int64_t base = (int64_t)blockIdx.x * 64;
-    const bool redo = base + lane < g.P && g.cr.ifm[(base + lane) * 16] == THIRD_REDO;
+    const bool redo = base + lane < live_problems(g) && g.cr.ifm[(base + lane) * 16] == THIRD_REDO;
     unsigned long long todo = __ballot(redo);
     while (todo) {
         const int k = __ffsll((long long)todo) - 1;

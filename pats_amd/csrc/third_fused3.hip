@@ -232,7 +232,7 @@ third_fused3_kernel(Fused65Args g) {
     __shared__ Blk3Lds lds;
     const int lane = threadIdx.x, I = lane >> 3, J = lane & 7;
     const int64_t p = blockIdx.x;
-    if (p >= g.P) return;
+    if (p >= live_problems(g)) return;
     // de-phase the first wave-front (see sinkhorn65_kernel)
     if (g.stagger > 0 && blockIdx.x < 8192u) {
         const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
@@ -246,7 +246,9 @@ third_fused3_kernel(Fused65Args g) {
     const float ns_lane = g.ns[p * 64 + lane];
     const float one_raw = *(g.one ? g.one : g.ns);       // branch-free, so that no wait lands here
     const float one_v = g.one ? one_raw : 1.0f;
-    const float sx_lane = g.scale_x[p * 64 + lane], sy_lane = g.scale_y[p * 64 + lane];
+    // scale_x == NULL: scale_x = scale_y = sqrt(ns + 1e-8) (third_layer.py:153-154) is formed here, not by the caller
+    const float sx_in = g.scale_x ? g.scale_x[p * 64 + lane] : 0.0f, sy_in = g.scale_x ? g.scale_y[p * 64 + lane] : 0.0f;
+    const float sx_lane = g.scale_x ? sx_in : sqrtf(ns_lane + 1e-8f), sy_lane = g.scale_x ? sy_in : sx_lane;
 
     // ---- cost build (MFMA), then fragment layout -> permuted diagonal-pair blocks through LDS -----------
     f2v Pa[4][4], Pb[4][4];                  // [row pair][column pair], see the header

@@ -417,7 +417,7 @@ def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right,
     xs = _dev(x_scale.float(), "x_scale").reshape(nb, Np)
     ys = _dev(y_scale.float(), "y_scale").reshape(nb, Np)
     ap = _dev(average_point.float(), "average_point").reshape(nb, Np, 2)
-    ifn = _dev(if_nomatching.to(torch.uint8), "if_nomatching", torch.uint8).reshape(nb, Np)
+    ifn = _as_flags(if_nomatching, "if_nomatching").reshape(nb, Np)         # bool viewed as bytes: no copy kernel
     leftf = _dev(left.float(), "left")
     rightf = _dev(right.float(), "right")
     H, W = leftf.shape[1], leftf.shape[2]
@@ -499,22 +499,36 @@ def Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device=None, outdoo
 
 
 def third_level(feat_f0_unfold, feat_f1_unfold, scale, mkpts0_c, mkpts1_c, outdoor=True, iters=100,
-                return_plan=False):
+                return_plan=False, count=None):
     """The third layer's whole OT step in one launch (third_layer.py:153-170):
         scale_x = scale_y = sqrt(scale + 1e-8)
         scores  = exp(log_optimal_transport2(0.1 * einsum(f0, f1) / 128**.5, 1, scale, 100))
         mkpts0_f, mkpts1_f, _ = Compute_result(scores, 8, 5, scale_x, scale_y, mkpts0_c, mkpts1_c)
         label / if_matching1 as :161-170
-    Returns (mkpts0_f, mkpts1_f, label, if_matching1[, Z]).  The 65x65 plans stay on chip."""
+    Returns (mkpts0_f, mkpts1_f, label, if_matching1[, Z]).  The 65x65 plans stay on chip.
+    count: a DEVICE int64 [1] holding the number of problems that exist (throughput mode: the tensors are sized for a
+    capacity, nothing is read back); rows past it are not written, and sqrt(scale + 1e-8) is formed in the kernel."""
     f0, f1 = _dev(feat_f0_unfold, "feat_f0_unfold"), _dev(feat_f1_unfold, "feat_f1_unfold")
     P, D, n = f0.shape
     if n != 65 or tuple(f1.shape) != (P, D, 65):
         raise RuntimeError("third_level: descriptors must be [P,D,65]")
     sc = _dev(scale, "scale").reshape(P, 64)
-    sxy = torch.sqrt(sc + 1e-8)
     ps = _dev(mkpts0_c.to(torch.int64), "mkpts0_c", torch.int64).reshape(P, 2)
     pt = _dev(mkpts1_c.to(torch.int64), "mkpts1_c", torch.int64).reshape(P, 2)
     dev = f0.device
+    if count is not None:
+        if return_plan:
+            raise RuntimeError("third_level: return_plan is not available with a device-side count")
+        cnt = _dev(count, "count", torch.int64).reshape(1)
+        m0 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
+        m1 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
+        label = torch.empty((P * 16, 2), dtype=torch.float32, device=dev)
+        ifm = torch.empty((P, 16), dtype=torch.uint8, device=dev)
+        _check(_L().pats_third_level_counted_f32(_ptr(f0), _ptr(f1), P, _ptr(cnt), D, _ptr(sc), _ptr(None), _ptr(None), _ptr(ps),
+                                                 _ptr(pt), int(iters), int(bool(outdoor)), _ptr(m0), _ptr(m1), _ptr(label),
+                                                 _ptr(ifm), _stream()), "third_level")
+        return m0, m1, label, ifm.view(torch.bool)
+    sxy = torch.sqrt(sc + 1e-8)
     m0 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
     m1 = torch.empty((P, 16, 2), dtype=torch.float32, device=dev)
     label = torch.empty((P * 16, 2), dtype=torch.float32, device=dev)
@@ -526,7 +540,7 @@ def third_level(feat_f0_unfold, feat_f1_unfold, scale, mkpts0_c, mkpts1_c, outdo
     return (m0, m1, label, ifm.bool(), Z) if return_plan else (m0, m1, label, ifm.bool())
 
 
-def fine_descriptors(desc0_, title, rubbish):
+def fine_descriptors(desc0_, title, rubbish, out=None):
     """second_layer.py:71-86: desc0_ = the three maps of ResNet2.forward2 on the stacked crops
     ([2B,64,48,48], [2B,64,24,24], [2B,128,12,12]); title [B,8] = compress_1(desc_l); rubbish [B,264]
     = compress_2(desc_l).  Returns desc [2,B,264,145] (desc[0], desc[1] feed the GNN)."""
@@ -537,15 +551,19 @@ def fine_descriptors(desc0_, title, rubbish):
         raise RuntimeError("fine_descriptors: unexpected feature-map shapes")
     ti = _dev(title, "title").reshape(B, 8)
     ru = _dev(rubbish, "rubbish").reshape(B, 264)
-    desc = torch.empty((2, B, 264, 145), dtype=torch.float32, device=f0.device)
+    desc = torch.empty((2, B, 264, 145), dtype=torch.float32, device=f0.device) if out is None else _dev(out, "out")
+    if tuple(desc.shape) != (2, B, 264, 145) or (out is not None and desc.data_ptr() != out.data_ptr()):
+        raise RuntimeError("fine_descriptors: out must be a contiguous [2,B,264,145] tensor")
     _check(_L().pats_fine_descriptors_f32(_ptr(f0), _ptr(f1), _ptr(f2), _ptr(ti), _ptr(ru), B, _ptr(desc),
                                           _stream()), "fine_descriptors")
     return desc
 
 
-def third_descriptors(feat_f0, feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish):
+def third_descriptors(feat_f0, feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, count=None, out=None):
     """third_layer.py:121-146.  Returns (feat_f0_unfold, feat_f1_unfold [P,128,65], mkpts0_c,
-    mkpts1_c [P,2] int64 rounded to the 4-px lattice as the reference reassigns them)."""
+    mkpts1_c [P,2] int64 rounded to the 4-px lattice as the reference reassigns them).
+    count: DEVICE int64 [1], the number of points that exist (the tensors are a capacity; rows past it are not written);
+    out: optional (o0, o1) to write into."""
     f0, f1 = _dev(feat_f0, "feat_f0"), _dev(feat_f1, "feat_f1")
     B = f0.shape[0]
     if tuple(f0.shape[1:]) != (128, 52, 52) or f1.shape != f0.shape:
@@ -557,10 +575,21 @@ def third_descriptors(feat_f0, feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish
     ke = _dev(kenc, "kenc").reshape(128, 64)
     ru = _dev(rubbish, "rubbish").reshape(B, 128, 144)
     dev = f0.device
-    o0 = torch.empty((P, 128, 65), dtype=torch.float32, device=dev)
-    o1 = torch.empty((P, 128, 65), dtype=torch.float32, device=dev)
+    if out is not None:
+        o0, o1 = _dev(out[0], "out[0]"), _dev(out[1], "out[1]")
+        if tuple(o0.shape) != (P, 128, 65) or o1.shape != o0.shape or o0.data_ptr() != out[0].data_ptr():
+            raise RuntimeError("third_descriptors: out must be two contiguous [P,128,65] tensors")
+    else:
+        o0 = torch.empty((P, 128, 65), dtype=torch.float32, device=dev)
+        o1 = torch.empty((P, 128, 65), dtype=torch.float32, device=dev)
     ps = torch.empty((P, 2), dtype=torch.int64, device=dev)
     pt = torch.empty((P, 2), dtype=torch.int64, device=dev)
+    if count is not None:
+        cnt = _dev(count, "count", torch.int64).reshape(1)
+        _check(_L().pats_third_descriptors_counted_f32(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), _ptr(bi), _ptr(ke), _ptr(ru),
+                                                       P, _ptr(cnt), B, _ptr(o0), _ptr(o1), _ptr(ps), _ptr(pt), _stream()),
+               "third_descriptors")
+        return o0, o1, ps, pt
     _check(_L().pats_third_descriptors_f32(_ptr(f0), _ptr(f1), _ptr(m0), _ptr(m1), _ptr(bi), _ptr(ke), _ptr(ru),
                                            P, B, _ptr(o0), _ptr(o1), _ptr(ps), _ptr(pt), _stream()),
            "third_descriptors")
@@ -626,25 +655,29 @@ def merge_patches_old(patch_num, trust_score, original_image_shape, if_nomatchin
     return out, torch.zeros_like(scores_back)
 
 
-def third_inputs(if_nomatching, pts):
+def third_inputs(if_nomatching, pts, capacity=None, sync=True):
     """pats.py:53-58: (mkpts0_c [P,2], mkpts1_c [P,2], b_ids [P]) of the surviving L2 cells - the arguments
     PATS.forward passes to ThirdLayer (third_input[:, :2] * 2, third_input[:, 2:4] * 2, third_input[:, -1]).
-    One host read of P (the reference's boolean-mask indexing syncs at the same point)."""
+    One host read of P (the reference's boolean-mask indexing syncs at the same point).
+    sync=False makes none: returns (mkpts0_c [cap,2], mkpts1_c [cap,2], b_ids [cap], P [1] int64 DEVICE count) with
+    `capacity` rows (default B*144), only the first min(P, cap) written."""
     f = _as_flags(if_nomatching, "if_nomatching")
     B = f.shape[0]
     p = _dev(pts, "pts").reshape(B, 144, 2)
     if f.numel() != B * 144:
         raise RuntimeError("third_inputs: if_nomatching must be [B,144]")
     dev = p.device
-    cap = B * 144
+    cap = B * 144 if capacity is None else int(capacity)
     mk0 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
     mk1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
     bi = torch.empty((cap,), dtype=torch.int64, device=dev)
-    cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int64, device=dev)                  # always written by the scan
     nws = _L().pats_compact_workspace_bytes(cap)
     ws = _workspace(nws, dev)
     _check(_L().pats_third_inputs_f32(_ptr(f), _ptr(p), B, _ptr(mk0), _ptr(mk1), _ptr(bi), cap, _ptr(cnt), _ptr(ws), nws,
                                       _stream()), "third_inputs")
+    if not sync:
+        return mk0, mk1, bi, cnt
     P = int(cnt.item())
     return mk0[:P], mk1[:P], bi[:P]
 
@@ -705,7 +738,7 @@ def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left
     cap = rows1 * n1
     ml = torch.empty((cap, 2), dtype=torch.float32, device=dev)
     mr = torch.empty((cap, 2), dtype=torch.float32, device=dev)
-    cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int64, device=dev)                  # always written by the scan
     nws = _L().pats_get_result_workspace_bytes(bs * n0, rows1, n1)
     ws = _workspace(nws, dev)
     ps0, ps1 = (ctypes.c_int * 3)(*z0), (ctypes.c_int * 3)(*z1)
@@ -716,6 +749,126 @@ def get_result(batch_size, if_nomatching, average_point, scale, patch_size, left
         return ml, mr, cnt
     M = int(cnt.item())
     return ml[:M], mr[:M]
+
+
+# ------------------------------------------------------------------------------------------------
+# throughput mode: the chunk loop of PATS.forward for a batch of pairs, no host read (csrc/batch.hip)
+# ------------------------------------------------------------------------------------------------
+class ChunkRows:
+    """The row table pats_chunk_rows_device builds (include/pats_amd.h): device tensors only."""
+    __slots__ = ("pairs", "h", "w", "Cmax", "rows_cap", "sum_cycle", "cycle_num", "second", "third", "masks", "chunk_base",
+                 "crop_base", "row_cell", "row_forced", "row_crop", "row_slot", "status")
+
+
+def max_chunks(height, width, max_once_used):
+    """Upper bound of split_patches' chunk count: a chunk closes when the cumulative match count passes a multiple of
+    max_once_used (utils.py:157), at most once per grid row."""
+    return min(height + 1, (height * width - 1) // int(max_once_used) + 1)
+
+
+def chunk_rows(if_nomatching1, height, width, max_once_used, Cmax=None, rows_cap=None):
+    """first_layer.py:130-146 + pats.py:33-39 for a batch of pairs on the device: cumulative match counts, chunk plans,
+    chunk masks and the fine level's row table in (chunk, pair, cell) order.  if_nomatching1 [pairs, h*w] bool."""
+    f = _as_flags(if_nomatching1, "if_nomatching1")
+    pairs, N = f.shape[0], height * width
+    if f.numel() != pairs * N:
+        raise RuntimeError("chunk_rows: if_nomatching1 must be [pairs, height*width]")
+    r = ChunkRows()
+    r.pairs, r.h, r.w = pairs, int(height), int(width)
+    r.Cmax = max_chunks(height, width, max_once_used) if Cmax is None else int(Cmax)
+    r.rows_cap = pairs * (N + (r.Cmax - 1) * width) if rows_cap is None else int(rows_cap)
+    dev = f.device
+    i32, i64, u8 = torch.int32, torch.int64, torch.uint8
+    r.sum_cycle = torch.empty((pairs, N), dtype=i32, device=dev)
+    r.cycle_num = torch.empty((pairs,), dtype=i32, device=dev)
+    r.second = torch.empty((pairs, height + 1, 2), dtype=i64, device=dev)
+    r.third = torch.empty((pairs, height + 1, 2), dtype=i64, device=dev)
+    r.masks = torch.empty((r.Cmax, pairs, N), dtype=torch.bool, device=dev)
+    r.chunk_base = torch.empty((r.Cmax + 1,), dtype=i64, device=dev)
+    r.crop_base = torch.empty((pairs + 1,), dtype=i64, device=dev)
+    r.row_cell = torch.empty((r.rows_cap,), dtype=i32, device=dev)
+    r.row_forced = torch.empty((r.rows_cap,), dtype=u8, device=dev)
+    r.row_crop = torch.empty((r.rows_cap,), dtype=i32, device=dev)
+    r.row_slot = torch.empty((r.Cmax, pairs * N), dtype=i32, device=dev)
+    r.status = torch.empty((1,), dtype=i32, device=dev)
+    nws = _L().pats_chunk_rows_workspace_bytes(pairs, r.Cmax)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_chunk_rows_device(_ptr(f), pairs, int(height), int(width), int(max_once_used), r.Cmax, r.rows_cap,
+                                       _ptr(r.sum_cycle), _ptr(r.cycle_num), _ptr(r.second), _ptr(r.third),
+                                       _ptr(r.masks.view(u8)), _ptr(r.chunk_base), _ptr(r.crop_base), _ptr(r.row_cell),
+                                       _ptr(r.row_forced), _ptr(r.row_crop), _ptr(r.row_slot), _ptr(r.status), _ptr(ws), nws,
+                                       _stream()), "chunk_rows")
+    return r
+
+
+def merge_patches_batch(merge_new, rows, trust_score, original_image_shape, if_nomatching1_L2, scores_back=None):
+    """SecondLayer.merge_patches_new / _old (second_layer.py:137-238) for every chunk of every pair of a ChunkRows table,
+    chunk blocks in order, pats.py:38-39 applied.  trust_score / if_nomatching1_L2 [rows_cap,144] are updated in place;
+    scores_back [pairs, N, 16, 9] float64 (zeros if None, pats.py:32).  Returns if_nomatching [rows_cap,144] bool."""
+    if trust_score.dtype != torch.float32 or not trust_score.is_cuda or not trust_score.is_contiguous():
+        raise RuntimeError("merge_patches_batch: trust_score must be a contiguous float32 GPU tensor (it is updated in place)")
+    if if_nomatching1_L2.dtype != torch.bool or not if_nomatching1_L2.is_contiguous():
+        raise RuntimeError("merge_patches_batch: if_nomatching1_L2 must be a contiguous bool tensor (it is updated in place)")
+    H, W = int(original_image_shape[0]), int(original_image_shape[1])
+    if trust_score.numel() != rows.rows_cap * 144 or if_nomatching1_L2.numel() != rows.rows_cap * 144 or \
+            H // 32 != rows.h or W // 32 != rows.w:
+        raise RuntimeError("merge_patches_batch: tensors must be [rows_cap,144] on the table's grid")
+    dev = trust_score.device
+    if scores_back is None:
+        scores_back = torch.zeros((rows.pairs, rows.h * rows.w, 16, 9), dtype=torch.float64, device=dev)
+    elif scores_back.dtype != torch.float64 or not scores_back.is_contiguous() or \
+            scores_back.numel() != rows.pairs * rows.h * rows.w * 144:
+        raise RuntimeError("merge_patches_batch: scores_back must be a contiguous float64 [pairs, N, 16, 9] tensor")
+    out = torch.empty((rows.rows_cap, 144), dtype=torch.bool, device=dev)
+    nws = _L().pats_merge_batch_workspace_bytes(rows.pairs, H, W)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_merge_patches_batch(1 if merge_new else 0, rows.Cmax, rows.pairs, H, W, rows.rows_cap,
+                                         _ptr(rows.chunk_base), _ptr(rows.row_cell), _ptr(rows.row_slot), _ptr(rows.row_forced),
+                                         _ptr(trust_score), _ptr(if_nomatching1_L2.view(torch.uint8)), _ptr(scores_back),
+                                         _ptr(out.view(torch.uint8)), _ptr(ws), nws, _stream()), "merge_patches_batch")
+    return out
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (int(n), str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((int(n),), dtype=torch.uint8, device=device)
+    return t
+
+
+def get_result_chunks(rows, if_nomatching16, pts_new, pts16, scales, patch_size=((32, None, None), (2, 48, 48))):
+    """get_result (utils.py:189-213) for every (chunk, pair) of a ChunkRows table in one call, as PATS.forward issues it per
+    chunk (pats.py:68-73): pts_new / scales = Compute_imgs' per-pair [pairs,N,2] tensors, pts16 [rows_cap,2304,2] /
+    if_nomatching16 [rows_cap,2304] from refine_scatter.  No host read.  Returns (matches_l [cap,2], matches_r [cap,2],
+    match_row [cap] int32, M [1] int64 device): the first M rows are valid, match_row -> rows.row_cell // N = pair."""
+    f16 = _as_flags(if_nomatching16, "if_nomatching16")
+    z0 = [int(patch_size[0][0]), rows.h, rows.w]
+    z1 = [int(v) for v in patch_size[1]]
+    n1 = z1[1] * z1[2]
+    if f16.numel() != rows.rows_cap * n1:
+        raise RuntimeError("get_result_chunks: if_nomatching16 must be [rows_cap, %d]" % n1)
+    a0, a1, s0 = _dev(pts_new, "pts_new"), _dev(pts16, "pts16"), _dev(scales, "scales")
+    N = rows.h * rows.w
+    if a0.numel() != rows.pairs * N * 2 or s0.numel() != rows.pairs * N * 2 or a1.numel() != rows.rows_cap * n1 * 2:
+        raise RuntimeError("get_result_chunks: pts_new / scales must be [pairs,N,2], pts16 [rows_cap,%d,2]" % n1)
+    dev = a0.device
+    cap = rows.rows_cap * n1
+    ml = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    mr = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    mrow = torch.empty((cap,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int64, device=dev)
+    nws = _L().pats_get_result_workspace_bytes(rows.Cmax * rows.pairs * N, rows.rows_cap, n1)
+    ws = _workspace(nws, dev)
+    ps0, ps1 = (ctypes.c_int * 3)(*z0), (ctypes.c_int * 3)(*z1)
+    _check(_L().pats_get_result_chunks_f32(rows.Cmax, rows.pairs, _ptr(rows.masks.view(torch.uint8)), _ptr(f16), rows.rows_cap,
+                                           _ptr(a0), _ptr(a1), _ptr(s0), ps0, ps1, _ptr(_ones(rows.Cmax * rows.pairs, dev)),
+                                           _ptr(_ones(rows.rows_cap, dev)), _ptr(ml), _ptr(mr), _ptr(mrow), cap, _ptr(cnt),
+                                           _ptr(ws), nws, _stream()), "get_result_chunks")
+    return ml, mr, mrow, cnt
 
 
 def attention(query, key, value, return_prob=True):

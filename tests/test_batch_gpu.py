@@ -1,0 +1,132 @@
+"""Throughput mode (pats_amd.batch.forward_pairs: a batch of pairs, every stage one launch, NO host read) against
+ (a) the reference's own chained functions (tests/golden/pipeline_*.npz, tools/make_golden.py::gen_pipeline) and
+ (b) pats_amd.pipeline.forward_path run pair by pair (itself held to those goldens): bit-identical matches.
+The network callbacks of these tests place synthetic per-chunk tensors by reading the row table back - the PATH makes
+no host read, its stand-in networks may."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from pats_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+class _BatchNets:
+    """synth.SynthNets (numpy, one per pair) as the callbacks of pats_amd.batch: chunk c of pair p gets
+    nets[p].fine(c, B) / nets[p].third(c, P) - the same tensors pipeline.forward_path hands its per-chunk calls."""
+
+    def __init__(self, nets):
+        self.nets = nets
+
+    def coarse(self, lefts, rights):
+        c = [n.coarse() for n in self.nets]
+        return (cu(np.concatenate([x["d0"] for x in c])), cu(np.concatenate([x["d1"] for x in c])),
+                cu(np.concatenate([x["ns"] for x in c])), float(c[0]["alpha"]))
+
+    def fine(self, rows, new_left, new_right):
+        cell = rows.row_cell.cpu().numpy()
+        base = rows.chunk_base.cpu().numpy()
+        N = rows.h * rows.w
+        f0 = np.zeros((rows.rows_cap, 264, 145), np.float32)
+        f1 = np.zeros_like(f0)
+        sx = np.ones((rows.rows_cap, 1, 144), np.float32)
+        sy = np.ones_like(sx)
+        self.blocks = []                                  # (chunk, pair, first row, rows)
+        for c in range(rows.Cmax):
+            r0, r1 = int(base[c]), int(base[c + 1])
+            pair = cell[r0:r1] // N
+            for p in np.unique(pair):
+                idx = np.nonzero(pair == p)[0] + r0
+                assert (np.diff(idx) == 1).all()          # a (chunk, pair) block is contiguous
+                f = self.nets[p].fine(c, len(idx))
+                f0[idx], f1[idx], sx[idx], sy[idx] = f["d0"], f["d1"], f["scale_x"], f["scale_y"]
+                self.blocks.append((c, int(p), int(idx[0]), len(idx)))
+        return cu(f0), cu(f1), cu(sx), cu(sy)
+
+    def third(self, rows, mk0, mk1, b_ids, P_dev):
+        P = int(P_dev.item())
+        cap = mk0.shape[0]
+        assert P <= cap
+        b = b_ids[:P].cpu().numpy()
+        d0 = np.zeros((cap, 128, 65), np.float32)
+        d1 = np.zeros_like(d0)
+        sc = np.ones((cap, 1, 64), np.float32)
+        for c, p, r0, n in self.blocks:
+            idx = np.nonzero((b >= r0) & (b < r0 + n))[0]
+            if len(idx) == 0:
+                continue
+            assert (np.diff(idx) == 1).all()
+            t = self.nets[p].third(c, len(idx))
+            d0[idx], d1[idx], sc[idx] = t["d0"], t["d1"], t["scale"]
+        return cu(d0), cu(d1), cu(sc)
+
+
+@pytest.mark.parametrize("name", ["pipeline_outdoor.npz", "pipeline_indoor.npz", "pipeline_640x480_outdoor.npz",
+                                  "pipeline_640x480_indoor.npz"])
+def test_one_pair_against_the_reference_chain(name):
+    from pats_amd import batch
+    g = golden(name)
+    nets = synth.SynthNets(seed=int(g["seed"]), h=int(g["h"]), w=int(g["w"]))
+    left, right = [cu(x) for x in nets.images()]
+    cap = batch.Capacities(1, int(g["h"]), int(g["w"]), if_local=bool(g["if_local"]))
+    out = batch.forward_pairs(left, right, _BatchNets([nets]), cap, if_outdoor=bool(g["if_outdoor"]),
+                              merge_new=bool(g["merge_new"]))
+    (ml, mr), = batch.split_by_pair(out, cap)
+    ml, mr = ml.cpu().numpy(), mr.cpu().numpy()
+    assert ml.shape == g["matches_l"].shape and ml.shape[0] > 500
+    np.testing.assert_allclose(ml, g["matches_l"], atol=1e-4, rtol=1e-6)
+    np.testing.assert_allclose(mr, g["matches_r"], atol=6e-3, rtol=1e-6)       # gate of test_pipeline_chain
+    chunks = g["chunks"]
+    base = out["rows"].chunk_base.cpu().numpy()
+    assert np.diff(base)[:len(chunks)].tolist() == chunks[:, 0].tolist() and int(base[-1]) == int(chunks[:, 0].sum())
+    assert int(out["P"].item()) == int(chunks[:, 1].sum()) and int(out["M"].item()) == int(chunks[:, 2].sum())
+
+
+@pytest.mark.parametrize("if_local,outdoor,new", [(True, True, True), (False, False, False)])
+def test_three_different_pairs_equal_the_per_pair_path(if_local, outdoor, new):
+    """Pairs with different match counts, chunk counts and crops in ONE batch: every pair's matches are bit-identical
+    to pipeline.forward_path on that pair alone (same kernels, same per-problem inputs - nothing may leak between
+    pairs, chunk blocks or padding rows)."""
+    from pats_amd import batch, pipeline
+    from test_gpu_parity import _CudaNets
+    h, w = 15, 20
+    seeds = [synth.SEED + 40, synth.SEED + 1040, synth.SEED + 2040]
+    nets = [synth.SynthNets(seed=s, h=h, w=w) for s in seeds]
+    imgs = [n.images() for n in nets]
+    lefts = cu(np.concatenate([i[0] for i in imgs]))
+    rights = cu(np.concatenate([i[1] for i in imgs]))
+    cap = batch.Capacities(3, h, w, if_local=if_local)
+    out = batch.forward_pairs(lefts, rights, _BatchNets(nets), cap, if_outdoor=outdoor, merge_new=new)
+    per_pair = batch.split_by_pair(out, cap)
+    total = 0
+    for p, n in enumerate(nets):
+        ref = pipeline.forward_path(lefts[p:p + 1], rights[p:p + 1], _CudaNets(n), if_local=if_local, if_outdoor=outdoor,
+                                    merge_new=new)
+        assert ref["matches_l"].shape[0] > 500
+        assert torch.equal(per_pair[p][0], ref["matches_l"]) and torch.equal(per_pair[p][1], ref["matches_r"]), p
+        total += ref["matches_l"].shape[0]
+    assert total == int(out["M"].item())
+    assert len({pp[0].shape[0] for pp in per_pair}) == 3           # the pairs really differ
+
+
+def test_capacity_overflow_is_reported_not_silent():
+    from pats_amd import batch
+    nets = synth.SynthNets(seed=synth.SEED + 40, h=15, w=20)
+    left, right = [cu(x) for x in nets.images()]
+    cap = batch.Capacities(1, 15, 20, if_local=True, p_cap_per_pair=64)
+
+    class Small(_BatchNets):
+        def third(self, rows, mk0, mk1, b_ids, P_dev):
+            cap_ = mk0.shape[0]
+            return (torch.zeros((cap_, 128, 65), device="cuda"), torch.zeros((cap_, 128, 65), device="cuda"),
+                    torch.ones((cap_, 1, 64), device="cuda"))
+    out = batch.forward_pairs(left, right, Small([nets]), cap)
+    assert int(out["P"].item()) > cap.P_cap
+    with pytest.raises(RuntimeError, match="P_cap"):
+        batch.split_by_pair(out, cap)

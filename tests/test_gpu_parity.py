@@ -245,25 +245,21 @@ def test_tensor_resize_edges_and_empty(ops):
 
 def test_tensor_resize_against_compiled_reference(ops):
     """When the reference's own library.cpp build travelled (oracle/_ref), compare against it
-    directly on CPU tensors - the strongest pin of the native boundary."""
-    ref_dir = os.path.join(REPO, "oracle", "_ref")
-    so = [f for f in os.listdir(ref_dir)] if os.path.isdir(ref_dir) else []
-    if not any(f.startswith("tensor_resize") for f in so):
-        pytest.skip("oracle/_ref not built")
-    import importlib.util
-    path = os.path.join(ref_dir, [f for f in so if f.startswith("tensor_resize")][0])
-    spec = importlib.util.spec_from_file_location("tensor_resize", path)
-    ref = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ref)
+    directly (the reference on CPU tensors, in a subprocess) - the strongest pin of the native boundary."""
+    from conftest import reference_tensor_resize
     rng = np.random.default_rng(7)
-    src = torch.from_numpy(rng.uniform(0, 255, (2, 3, 200, 240)).astype(np.float32))
+    src = rng.uniform(0, 255, (2, 3, 200, 240)).astype(np.float32)
     y0 = rng.integers(0, 150, 64); x0 = rng.integers(0, 180, 64)
     bound = np.stack([y0, y0 + rng.integers(1, 50, 64), x0, x0 + rng.integers(0, 59, 64),
                       rng.integers(0, 2, 64) * 10000 + np.arange(64)], 1).astype(np.int64)
-    want = ref.tensor_resize(src, torch.from_numpy(bound))
+    want = reference_tensor_resize(src, bound)
+    if want is None:
+        pytest.skip("oracle/_ref not built")
     import tensor_resize
-    got = tensor_resize.tensor_resize(src.cuda(), torch.from_numpy(bound).cuda())
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+    got = tensor_resize.tensor_resize(torch.from_numpy(src).cuda(), torch.from_numpy(bound).cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-4)
+    np.testing.assert_allclose(ops.tensor_resize(torch.from_numpy(src).cuda(), torch.from_numpy(bound).cuda()).cpu().numpy(),
+                               want, atol=1e-4)                      # the ctypes route over the same C-ABI symbol
 
 
 # ---- fine level --------------------------------------------------------------------------------
@@ -1439,7 +1435,13 @@ assert d <= 3e-4 * 8, d
 assert np.isfinite(m1.cpu().numpy()).all() and trips >= 1
 print("OK", d, trips)
 ''' % (REPO, REPO)
-    for variant in ("1350", "1300", "300"):      # default; row-broadcast dustbin sums; fp32-MFMA cost build
+    for variant in ("1350", "300"):      # default; fp32-MFMA cost build - the two instantiations the production library holds
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PATS_THIRD_VARIANT=variant), capture_output=True,
                            text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, variant + ": " + p.stdout[-500:] + p.stderr[-1500:]
+    # every other variant (sweep-loop experiments, timing ablations that are wrong by design) is refused by the production
+    # library: it exists in libpats_amd_diag.so only (csrc/third_fused3.hip, -DPATS_DIAG)
+    for variant in ("1300", "1308"):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PATS_THIRD_VARIANT=variant, PATS_THIRD_ABLATION="1"),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and "libpats_amd_diag.so" in p.stderr, variant

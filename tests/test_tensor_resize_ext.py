@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, golden
+from conftest import REPO, golden, reference_tensor_resize
 
 
 def _load_by_path(path, name="tensor_resize"):
@@ -81,22 +81,16 @@ def _cases():
     return src, torch.from_numpy(bound)
 
 
-def _reference_module():
-    ref_dir = os.path.join(REPO, "oracle", "_ref")
-    so = [f for f in os.listdir(ref_dir) if f.startswith("tensor_resize")] if os.path.isdir(ref_dir) else []
-    return _load_by_path(os.path.join(ref_dir, so[0]), "tensor_resize_reference") if so else None
-
-
 @pytest.mark.gpu
 def test_against_the_compiled_reference_on_64_crops(ext, oracle):
     src, bound = _cases()
     got = ext.tensor_resize(src.cuda(), bound.cuda())
     assert got.shape == (64, 3, 96, 96) and got.dtype == torch.float32 and got.is_cuda
-    ref = _reference_module()          # library.cpp itself, compiled unmodified by oracle/build_ref.sh
-    if ref is not None:
-        want = ref.tensor_resize(src, bound).numpy()
-    else:
+    want = reference_tensor_resize(src.numpy(), bound.numpy())     # library.cpp itself, compiled unmodified (oracle/build_ref.sh)
+    if want is None:
         want = oracle.tensor_resize(src.numpy(), bound.numpy())
+    else:
+        np.testing.assert_allclose(oracle.tensor_resize(src.numpy(), bound.numpy()), want, atol=1e-4)
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-4)
     maps = open("/proc/self/maps").read()
     assert os.path.basename(ext.__file__) in maps and "libpats_amd.so" in maps
