@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libpats_amd.so")
 # PATS_AMD_DIAG_LIB=1 (profiling tools only): the diagnostic twin with every third-level sweep variant and the timing
 # ablations (`python -m pats_amd.build --diag`).  The production library refuses those variants.
 if os.environ.get("PATS_AMD_DIAG_LIB", "") not in ("", "0"):
-    LIB_PATH = os.path.join(_HERE, "libpats_amd_diag.so")
+    _sfx = os.environ["PATS_AMD_DIAG_LIB"]
+    LIB_PATH = os.path.join(_HERE, "libpats_amd_diag%s.so" % ("" if _sfx == "1" else _sfx))
 
 c_void_p, c_int, c_i64, c_f, c_size = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                        ctypes.c_size_t)

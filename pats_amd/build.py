@@ -38,9 +38,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_diag(force=False, verbose=False):
-    """libpats_amd_diag.so = the production objects with the DIAG_SOURCES recompiled under their extra defines."""
+def build_diag(force=False, verbose=False, suffix="", defines=()):
+    """libpats_amd_diag<suffix>.so = the production objects with the DIAG_SOURCES recompiled under their extra defines
+    (+ `defines`, e.g. an experiment hook like -DPATS_EXP_SWAP_NOPS; _lib.py loads it with PATS_AMD_DIAG_LIB=<suffix>)."""
     build(force=force, verbose=verbose)
+    lib_out = os.path.join(HERE, "libpats_amd_diag%s.so" % suffix)
     objdir = os.path.join(HERE, "build")
     objs = []
     for src in SOURCES:
@@ -48,15 +50,15 @@ def build_diag(force=False, verbose=False):
         if src not in DIAG_SOURCES:
             objs.append(os.path.join(objdir, stem + ".o"))
             continue
-        obj = os.path.join(objdir, stem + "_diag.o")
-        cmd = [hipcc()] + FLAGS[:-2] + EXTRA_FLAGS.get(src, []) + DIAG_SOURCES[src] + FLAGS[-2:] + \
+        obj = os.path.join(objdir, stem + "_diag%s.o" % suffix)
+        cmd = [hipcc()] + FLAGS[:-2] + EXTRA_FLAGS.get(src, []) + DIAG_SOURCES[src] + list(defines) + FLAGS[-2:] + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_DIAG])
-    return LIB_DIAG
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_out])
+    return lib_out
 
 
 def build(force=False, verbose=False):

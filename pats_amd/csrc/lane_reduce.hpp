@@ -12,6 +12,13 @@
 
 namespace pats {
 
+// experiment hook (tools/third_determinism.py): wait states on both sides of every v_permlane*_swap
+#ifdef PATS_EXP_SWAP_NOPS
+#define PATS_SWAP_FENCE(x, y) asm volatile("s_nop 1" : "+v"(x), "+v"(y))
+#else
+#define PATS_SWAP_FENCE(x, y) do { } while (0)
+#endif
+
 constexpr int DPP_ROW_ROR8 = 0x128;      // row_ror:8  == lane ^ 8 inside a 16-lane row
 
 template <class Op>
@@ -43,18 +50,22 @@ __device__ __forceinline__ float reduce8_consecutive(const float (&p)[8], Op op,
 __device__ __forceinline__ void swap32(float& x, float& y) {
     unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
     asm volatile("" : "+v"(b));
+    PATS_SWAP_FENCE(a, b);
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     unsigned c = r[0], d = r[1];
     asm volatile("" : "+v"(c), "+v"(d));
+    PATS_SWAP_FENCE(c, d);
     x = __builtin_bit_cast(float, c);
     y = __builtin_bit_cast(float, d);
 }
 __device__ __forceinline__ void swap16(float& x, float& y) {
     unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
     asm volatile("" : "+v"(b));
+    PATS_SWAP_FENCE(a, b);
     auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
     unsigned c = r[0], d = r[1];
     asm volatile("" : "+v"(c), "+v"(d));
+    PATS_SWAP_FENCE(c, d);
     x = __builtin_bit_cast(float, c);
     y = __builtin_bit_cast(float, d);
 }
@@ -82,7 +93,11 @@ __device__ __forceinline__ float reduce8_strided(const float (&p)[8], Op op, int
 // value of lane (lane ^ X), X < 32: ds_swizzle bit-mask mode (and = 0x1f, or = 0, xor = X)
 template <int X>
 __device__ __forceinline__ float swz_xor(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (X << 10) | 0x1f));
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (X << 10) | 0x1f));
+#ifdef PATS_EXP_XBAR_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));      // experiment: every crossbar result is waited for on its own
+#endif
+    return r;
 }
 
 // 64-lane sum into every lane with the two cross-row steps on the LDS crossbar: four in-row DPP adds, lane ^ 16 by
@@ -95,7 +110,11 @@ __device__ __forceinline__ float wave_sum_xbar(float v, int lane) {
     v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_f<DPP_ROW_MIRROR>(v);
     v += swz_xor<16>(v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+#ifdef PATS_EXP_XBAR_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
+#endif
+    v += r;
     return v;
 }
 

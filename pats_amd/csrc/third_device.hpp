@@ -35,6 +35,9 @@ struct Fused65Args {
     unsigned long long* fallbacks;   // guard-trip counter or null
     int scan;                        // third_fused_kernel: re-solve only the problems flagged THIRD_REDO
     const int64_t* P_dev;            // throughput mode: the launch covers the capacity P, *P_dev problems exist (or null)
+    int fingerprint;                 // libpats_amd_diag.so only: leave a fingerprint of the score matrix in label[p*16][1]
+    int lds_poison_on;               // libpats_amd_diag.so only: fill the workgroup's LDS with lds_poison first
+    unsigned lds_poison;
 };
 // number of problems that exist: min(capacity, device-side count)
 __device__ __forceinline__ int64_t live_problems(const Fused65Args& g) {

@@ -672,7 +672,7 @@ def third_inputs(if_nomatching, pts, capacity=None, sync=True):
     mk1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
     bi = torch.empty((cap,), dtype=torch.int64, device=dev)
     cnt = torch.empty((1,), dtype=torch.int64, device=dev)                  # always written by the scan
-    nws = _L().pats_compact_workspace_bytes(cap)
+    nws = _L().pats_compact_workspace_bytes(B * 144)
     ws = _workspace(nws, dev)
     _check(_L().pats_third_inputs_f32(_ptr(f), _ptr(p), B, _ptr(mk0), _ptr(mk1), _ptr(bi), cap, _ptr(cnt), _ptr(ws), nws,
                                       _stream()), "third_inputs")
