@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
 """bench.py - image-pairs/sec of the PATS OT hot path on MI355X (BASELINE.json configs[1]).
 
-One STEP = one pass of the hot path over a batch of `--pairs` synthetic 640x480 pairs at the
-reference's shapes, inputs resident in HBM before the timed region:
-  L1  [1,448,300]^2 cost build (MFMA) -> log_optimal_transport 301x301, 100 sweeps -> column mass
-      -> argmax + 15-step area expansion -> split_patches (cap 2w = 40 as `if_local`) -> Compute_imgs
-      (bounds, left crops, right crop + bilinear resize = the native tensor_resize)
-  L2  [B,264,145]^2 cost -> log_optimal_transport2 145x145, 100 sweeps, +ln2 dustbin
-      -> argmax + 8-step expansion
-  L3  [60*B,128,65]^2 cost -> log_optimal_transport2 65x65, 100 sweeps -> Compute_result + label
-  out refine scatter (pats.py:59-67) + get_result (utils.py:189-213): matches_l / matches_r
-The step makes NO host read: the chunk plan is computed on the device (pats_split_patches_device), the
-crop gathers and get_result run over their capacity with device-side counts (the reference syncs at
-every boolean mask).  Descriptors are synthetic (no weights/datasets exist for the reference here);
-P = 60*B is the SURVEY's chosen fill.  `value` = pairs/sec over all ranks (pairs shard across ranks,
-no data-path collective; "weak" scaling); after the timed region every rank's matches of its last
-step are gathered to rank 0 over RCCL (shard.gather_matches), timed separately as `gather_ms`.
+One STEP = one pass of the hot path over a batch of `--pairs` synthetic 640x480 pairs at the reference's shapes
+(SURVEY.md 8d config 2), through pats_amd.batch (every stage ONE launch over all pairs and chunks, NO host read):
+  L1    [1,448,300]^2 cost build (MFMA) -> log_optimal_transport 301x301, 100 sweeps -> column mass -> 15-step area
+        expansion -> cumulative match counts, split_patches (cap 2w = 40 as `if_local`), chunk masks, the fine level's
+        row table -> Compute_imgs for all pairs (bounds, left crops, right crop + bilinear resize = the native tensor_resize)
+  L2    descriptor sampling (second_layer.py:71-86) from synthetic backbone maps -> [B,264,145]^2 cost ->
+        log_optimal_transport2 145x145, 100 sweeps, +ln2 dustbin -> 8-step expansion -> merge_patches_new for every chunk
+        of every pair in the reference's order (scores_back hand-over) -> pats.py:38-39 tail rows
+  L3    surviving cells -> points (pats.py:53-58) -> 8x8 window gather (third_layer.py:121-146) from synthetic maps ->
+        [P,128,65]^2 cost -> log_optimal_transport2 65x65, 100 sweeps -> Compute_result + label, P decided by the MERGE
+  out   refine scatter (pats.py:59-67) + get_result for all chunks (utils.py:189-213): matches_l / matches_r
+What is synthetic: the networks' outputs (ResNet / FPN maps, GNN + final_proj as the identity, scale heads) - there are no
+weights or datasets here; every pair of a step has its own descriptors, maps and images.  The number of third-level
+problems is whatever the merge leaves (every 8-px cell belongs to at most one window per chunk: <= 16 h w per pair), not
+a chosen fill - rounds 1-2 fixed P = 60 B with a stand-in keep mask and no merge.
+`value` = pairs/sec over all ranks (pairs shard across ranks, no data-path collective; "weak" scaling); after the timed
+region every rank's matches of its last step are gathered to rank 0 over RCCL (shard.gather_matches), timed separately.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself
 (torch.distributed.run on 127.0.0.1); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
@@ -41,13 +43,12 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA
 ITERS = 100
-ONE = [None]            # device-resident 1.0 (the reference's `self.one`, second_layer.py:63)
+DTYPE = "f32 (contractions: fp32 operands split into fp16 hi + lo, three exact-product MFMA passes, fp32 accumulate)"
 
-
-# name -> (grid h, grid w, if_local, outdoor, label); BASELINE.json configs[1..3], shapes from SURVEY.md section 8d
-WORKLOADS = {"megadepth": (15, 20, True, True, "configs[1]: MegaDepth 640x480 shapes, outdoor (if_local chunks of 2w, +ln2, label from the dustbin)"),
-             "scannet": (15, 20, False, False, "configs[2]: ScanNet 640x480 shapes, indoor (one L2 chunk, cap 512; +ln3; fixed-cell label)"),
-             "yfcc": (24, 32, True, True, "configs[3]: YFCC 768x1024 shapes (24x32 grid, 769x769 coarse problem), outdoor")}
+# name -> (grid h, grid w, if_local, outdoor, default pairs per step, label); BASELINE.json configs[1..3], SURVEY.md 8d
+WORKLOADS = {"megadepth": (15, 20, True, True, 48, "configs[1]: MegaDepth 640x480 shapes, outdoor (if_local chunks of 2w, +ln2, label from the dustbin, merge_new)"),
+             "scannet": (15, 20, False, False, 48, "configs[2]: ScanNet 640x480 shapes, indoor (one L2 chunk, cap 512; +ln3; fixed-cell label; merge_old)"),
+             "yfcc": (24, 32, True, True, 16, "configs[3]: YFCC 768x1024 shapes (24x32 grid, 769x769 coarse problem), outdoor, merge_new")}
 
 
 def parse():
@@ -55,31 +56,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=48,
-                    help="image pairs per step per rank (48 = about 100 GB of synthetic descriptors resident in the 288 GB of HBM)")
-    ap.add_argument("--fill", type=int, default=60, help="third-level problems per fine problem (P = fill*B)")
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="image pairs per step per rank (default 48 at 640x480: about 130 GB of synthetic backbone maps "
+                         "resident in the 288 GB of HBM; 16 at YFCC size)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="megadepth",
                     help="megadepth = BASELINE configs[1] (the bench line); scannet = configs[2] shapes (indoor rules, one L2 chunk); "
                          "yfcc = configs[3] shapes (768x1024 pairs, 769x769 coarse problem) - secondary measurements")
-    ap.add_argument("--per-chunk", action="store_true",
-                    help="run Compute_imgs once per coarse chunk like the reference's loop (one host read per step)")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="strong-scaling mode (configs[3]: 4000 YFCC pairs): this many pairs in all, split over the ranks by "
+                         "shard.my_pairs; every rank walks its share in steps of --pairs (the last one partly filled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the coarse stage and the fine / third stage of consecutive batches one after the other "
                          "(default: on two HIP streams, the coarse stage of batch i + 1 beside the rest of batch i)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     return ap.parse_args()
 
 
-def desc_pair(shape, dev, gen, drop=0.0):
-    base = torch.randn(shape, device=dev, generator=gen)
-    d0 = 3.0 * (base + 0.3 * torch.randn(shape, device=dev, generator=gen))
-    d1 = 3.0 * (base + 0.3 * torch.randn(shape, device=dev, generator=gen))
-    if drop > 0:
-        gone = torch.rand((shape[0], 1, shape[2]), device=dev, generator=gen) < drop
-        d0 = torch.where(gone, 3.12 * torch.randn(shape, device=dev, generator=gen), d0)
-    return d0.contiguous(), d1.contiguous()
+def correlated_pair(shape, dev, gen, noise=0.3, amp=3.0, chunk=2048):
+    """[2, rows, ...]: two views of the same random base with independent noise - what a backbone makes of the left and
+    the right crop of a matching patch.  Built in row chunks so that the temporaries stay small."""
+    out = torch.empty((2,) + tuple(shape), dtype=torch.float32, device=dev)
+    for r0 in range(0, shape[0], chunk):
+        sub = (min(chunk, shape[0] - r0),) + tuple(shape[1:])
+        base = torch.randn(sub, device=dev, generator=gen)
+        out[0, r0:r0 + sub[0]] = amp * (base + noise * torch.randn(sub, device=dev, generator=gen))
+        out[1, r0:r0 + sub[0]] = amp * (base + noise * torch.randn(sub, device=dev, generator=gen))
+    return out
 
 
 def scale_head(shape, dev, gen):
@@ -87,154 +90,81 @@ def scale_head(shape, dev, gen):
     return torch.exp(torch.sigmoid(x) * synth.LN256 - synth.LN256 / 2)
 
 
-class Workload:
-    """Device-resident synthetic inputs of `pairs` 640x480 pairs.  Stages are batched ACROSS pairs
-    and across the coarse chunks: the reference walks pairs and chunks in Python loops
-    (evaluate.py:25, pats.py:33) only because it targets one 16-40 GB card; every coarse / fine /
-    third-level problem is independent, so with 288 GB each stage is one launch."""
+class BenchNets:
+    """The network outputs the path consumes, synthetic and RESIDENT in HBM before the timed region (the callbacks of
+    pats_amd.batch): coarse descriptors per pair; per row of the fine level's table the three ResNet2.forward2 maps of its
+    left / right crop, title / dustbin features and the two scale heads; per row the two half-resolution maps of the third
+    level, its dustbin features, and one scale-head row per third-level problem slot.  Inside the step the callbacks only
+    run the path's own gathers (a15: ops.fine_descriptors, a16: ops.third_descriptors); GNN + final_proj = identity."""
 
-    def __init__(self, ops, dev, gen, pairs, fill, per_chunk=False, workload="megadepth"):
-        h, w, self.if_local, self.outdoor, self.label = WORKLOADS[workload]
-        c = synth.coarse_inputs(h=h, w=w) if workload != "megadepth" else synth.coarse_inputs()
-        self.H, self.W, self.cap = 32 * h, 32 * w, (2 * w if self.if_local else 512)
-        self.bias_k = 2.0 if self.outdoor else 3.0
-        self.pairs, self.h, self.w, self.fill = pairs, c["h"], c["w"], fill
-        self.per_chunk_imgs = per_chunk
-        rep = lambda a: torch.from_numpy(a).to(dev).repeat(pairs, *([1] * (a.ndim - 1))).contiguous()  # noqa: E731
-        self.d0, self.d1, self.ns = rep(c["d0"]), rep(c["d1"]), rep(c["ns"])
-        self.alpha = torch.tensor(float(c["alpha"]), device=dev)
-        left, right = synth.image_pair(H=self.H, W=self.W)
-        self.left, self.right = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
-        self.lefts = self.left.expand(pairs, -1, -1, -1).contiguous()       # every pair: the same synthetic image
-        self.rights = self.right.expand(pairs, -1, -1, -1).contiguous()
-        # dry run of the coarse stage (with a host read) to learn the deterministic chunk plan
-        self.plan, self.counts = coarse_plan_host(ops, self)
-        self.C = len(self.plan)
-        B1 = sum(self.plan)
-        B = B1 * pairs
-        f0, f1 = desc_pair((B, 264, 145), dev, gen, drop=0.12)
-        f0[:, :, -1] *= 0.5
-        f1[:, :, -1] *= 0.5
-        sx, sy = scale_head((B, 1, 144), dev, gen), scale_head((B, 1, 144), dev, gen)
-        P = fill * B
-        t0, t1 = desc_pair((P, 128, 65), dev, gen, drop=0.12)
-        t0[:, :, -1] *= 0.5
-        t1[:, :, -1] *= 0.5
-        sc = scale_head((P, 1, 64), dev, gen)
-        p_s = (torch.randint(1, 23, (P, 2), device=dev, generator=gen) * 4)
-        p_t = (torch.randint(0, 25, (P, 2), device=dev, generator=gen) * 4)
-        # the merge's output stand-in (merge_patches_* is out of the bench: its chunks couple through
-        # scores_back, pats.py:32,37): exactly `fill` surviving L2 cells per row, fixed pattern, so that
-        # third-level problem p belongs to the p-th surviving cell as pats.py:53-58 orders them
-        keep = torch.zeros((B, 144), dtype=torch.bool, device=dev)
-        order = torch.argsort(torch.rand((B, 144), device=dev, generator=gen), dim=1)[:, :fill]
-        keep.scatter_(1, order, True)
-        self.chunk = dict(B=B, P=P, f0=f0, f1=f1, sx=sx, sy=sy, ns2=(sx * sy).contiguous(), t0=t0, t1=t1, sc=sc,
-                          p_s=p_s, p_t=p_t, ifn_L2=torch.logical_not(keep).contiguous())
-        self.ones_c = torch.ones((pairs * self.C,), dtype=torch.bool, device=dev)
-        self.ones_b = torch.ones((B,), dtype=torch.bool, device=dev)
-        self.B, self.P = B1, fill * B1
+    def __init__(self, ops, dev, gen, cap, h, w):
+        self.ops, self.cap = ops, cap
+        pairs, N, R, Pc = cap.pairs, h * w, cap.rows_cap, cap.P_cap
+        c = correlated_pair((pairs, 448, N), dev, gen)
+        self.d0, self.d1 = c[0].contiguous(), c[1].contiguous()
+        gone = torch.rand((pairs, 1, N), device=dev, generator=gen) < 0.03         # a few coarse cells without a partner
+        self.d0 = torch.where(gone, 3.12 * torch.randn((pairs, 448, N), device=dev, generator=gen), self.d0).contiguous()
+        self.ns = scale_head((pairs, 1, N), dev, gen)
+        self.alpha = torch.tensor(0.0, device=dev)
+        img = torch.randint(0, 256, (2, pairs, 32 * h, 32 * w, 3), device=dev, generator=gen).float()
+        self.lefts, self.rights = img[0].contiguous(), (0.5 * img[1] + 0.5 * torch.roll(img[1], 1, dims=2)).contiguous()
+        # fine level: ResNet2.forward2 maps of the stacked (left | right) crops, second_layer.py:69-70
+        self.m0 = correlated_pair((R, 64, 48, 48), dev, gen).reshape(2 * R, 64, 48, 48)
+        self.m1 = correlated_pair((R, 64, 24, 24), dev, gen).reshape(2 * R, 64, 24, 24)
+        self.m2 = correlated_pair((R, 128, 12, 12), dev, gen).reshape(2 * R, 128, 12, 12)
+        self.title = 0.5 * torch.randn((R, 8), device=dev, generator=gen)
+        self.rubbish = 1.5 * torch.randn((R, 264), device=dev, generator=gen)
+        self.sx, self.sy = scale_head((R, 1, 144), dev, gen), scale_head((R, 1, 144), dev, gen)
+        self.ns2 = (self.sx * self.sy).contiguous()
+        self.desc = torch.empty((2, R, 264, 145), dtype=torch.float32, device=dev)
+        # third level: the 1/2-resolution maps (padded to 52x52) of both crops, third_layer.py:112-120
+        f = correlated_pair((R, 128, 52, 52), dev, gen, chunk=1024)
+        self.ff0, self.ff1 = f[0], f[1]
+        self.kenc = 0.1 * torch.randn((128, 64), device=dev, generator=gen)
+        self.rubbish3 = 1.5 * torch.randn((R, 128, 144), device=dev, generator=gen)
+        self.scale3 = scale_head((Pc, 1, 64), dev, gen)
+        self.t0 = torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev)
+        self.t1 = torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev)
 
+    def resident_bytes(self):
+        return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
 
-def coarse_ops(ops, wl):
-    """first_layer.py:110-135 for all pairs: one batched cost+OT launch, column mass, argmax + expansion."""
-    Z = ops.cost_ot(wl.d0, wl.d1, 1, wl.alpha, wl.ns, ITERS)
-    scales, cflag = ops.colmass_sqrt(Z, return_flags=True)
-    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (wl.H, wl.W), 32, col_nomatch=cflag)
-    sum_cycle = torch.cumsum(torch.logical_not(ifn1).int(), dim=1, dtype=torch.int32)
-    return pts, xs, ys, ifn1, sum_cycle
+    def coarse(self, lefts, rights):
+        return self.d0, self.d1, self.ns, self.alpha
+
+    def fine(self, rows, new_left, new_right):
+        self.ops.fine_descriptors([self.m0, self.m1, self.m2], self.title, self.rubbish, out=self.desc)       # a15
+        return self.desc[0], self.desc[1], self.sx, self.sy, self.ns2
+
+    def third(self, rows, mk0, mk1, b_ids, P_dev):
+        t0, t1, ps, pt = self.ops.third_descriptors(self.ff0, self.ff1, mk0, mk1, b_ids, self.kenc, self.rubbish3,
+                                                    count=P_dev, out=(self.t0, self.t1))                     # a16
+        return t0, t1, self.scale3, ps, pt
 
 
-def coarse_plan_host(ops, wl):
-    """The chunk plan of pair 0 on the HOST (set-up / --per-chunk only): per-chunk row counts, crops per pair."""
-    pts, xs, ys, ifn1, sum_cycle = coarse_ops(ops, wl)
-    sc_host = sum_cycle.to("cpu").numpy()
-    plans = []
-    for i in range(wl.pairs):
-        n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, wl.cap)
-        K = int(sc_host[i, -1])
-        plans.append([min(hi, K) - lo for lo, hi in second])
-    assert all(p == plans[0] for p in plans)
-    return plans[0], [int(sc_host[i, -1]) for i in range(wl.pairs)]
+def _tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif hasattr(obj, "__slots__"):
+        for k in obj.__slots__:
+            yield from _tensors(getattr(obj, k, None))
 
 
-def coarse_stage(ops, wl):
-    """first_layer.py:110-146 for all pairs, no host read: OT + expansion, the chunk plan on the device, and
-    ONE subdivision gather for the whole step (Compute_imgs takes a batch of images, crops ordered
-    (image, patch); chunk c of pair i is a contiguous run of it because the cumsum is monotone -
-    tests/test_gpu_parity.py::test_chunk_crops_are_slices, ::test_compute_imgs_batch_of_images)."""
-    pts, xs, ys, ifn1, sum_cycle = coarse_ops(ops, wl)
-    if wl.per_chunk_imgs:
-        # the reference's loop (first_layer.py:136-146): host plan, one Compute_imgs per pair and chunk mask
-        sc_host = sum_cycle.to("cpu").numpy()
-        for i in range(wl.pairs):
-            n, second, third = ops.split_patches(sc_host[i], wl.h, wl.w, wl.cap)
-            for lo, hi in second:
-                mask = torch.logical_or(ifn1[i:i + 1], torch.logical_or(sum_cycle[i:i + 1] <= lo,
-                                                                        sum_cycle[i:i + 1] > hi))
-                ops.Compute_imgs(xs[i:i + 1], ys[i:i + 1], pts[i:i + 1], mask, wl.left, wl.right, width=wl.w,
-                                 height=wl.h)
-        num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, wl.cap)
-        nl, nr, xsn, ysn, avn = ops.Compute_imgs(xs, ys, pts, ifn1, wl.lefts, wl.rights, width=wl.w, height=wl.h,
-                                                 known_count=wl.counts)
-        return dict(ifn1=ifn1, sum_cycle=sum_cycle, second=second, num=num, xsn=xsn, avn=avn)
-    num, second, third = ops.split_patches_device(sum_cycle, wl.h, wl.w, wl.cap)
-    nl, nr, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(xs, ys, pts, ifn1, wl.lefts, wl.rights,
-                                                                      width=wl.w, height=wl.h, known_count="device")
-    return dict(ifn1=ifn1, sum_cycle=sum_cycle, second=second, num=num, xsn=xsn, avn=avn, K_img=K_img)
-
-
-def fine_and_third(ops, wl, co, ev):
-    ch = wl.chunk
-    if ev is not None:
-        f0_, f1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0_.record()
-    Z2, cflag2 = ops.cost_ot(ch["f0"], ch["f1"], 2, ONE[0], ch["ns2"], ITERS, bias_k=wl.bias_k, return_flags=True)
-    if ev is not None:
-        f1_.record()
-        ev["fine"].append((f0_, f1_))
-    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, ch["sx"], ch["sy"], [96, 96], 8, col_nomatch=cflag2)
-    # third level: cost build + OT + exp + Compute_result + label in ONE launch (the dominant kernel)
-    if ev is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    m0f, m1f, label, ifm = ops.third_level(ch["t0"], ch["t1"], ch["sc"], ch["p_s"], ch["p_t"], outdoor=wl.outdoor, iters=ITERS)
-    if ev is not None:
-        e1.record()
-        ev["third"].append((e0, e1, ch["P"]))
-    # results (pats.py:59-78): third-level matches scattered onto the 48x48 sub-cell grid, then get_result
-    # with the (pair, chunk) masks of first_layer.py:137-138 as its level-0 batch - all on the device
-    ifn16, pts16 = ops.refine_scatter(ch["ifn_L2"], pts2, m1f, label)
-    C, N = wl.C, wl.h * wl.w
-    lo, hi = co["second"][:, :C, 0:1], co["second"][:, :C, 1:2]                    # [pairs,C,1]
-    sc3 = co["sum_cycle"][:, None, :]
-    masks = torch.logical_or(co["ifn1"][:, None, :], torch.logical_or(sc3 <= lo, sc3 > hi)).reshape(-1, N)
-    xs_c = co["xsn"][:, None].expand(-1, C, -1, -1).reshape(-1, N, 2)
-    av_c = co["avn"][:, None].expand(-1, C, -1, -1).reshape(-1, N, 2)
-    # pats.py:70 `x_scale_new[~mask]` without its host sync: a stable sort lists the unmasked cells in order
-    cells = torch.argsort(masks.reshape(-1).to(torch.uint8), stable=True)[:ch["B"]]
-    sc_rows = xs_c.reshape(-1, 2)[cells]
-    ml, mr, M = ops.get_result(wl.pairs * C, [masks, ifn16], [av_c.flip(dims=[2]) / 32.0, pts16.flip(dims=[2]) / 2.0],
-                               [xs_c.contiguous(), sc_rows], [[32, wl.h, wl.w], [2, 48, 48]], [wl.ones_c, wl.ones_b],
-                               validate=False, sync=False)
-    return dict(ml=ml, mr=mr, M=M, masks=masks, ifn16=ifn16, label=label, ifm=ifm, m1f=m1f)
-
-
-def step(ops, wl, ev):
-    co = coarse_stage(ops, wl)
-    return co, fine_and_third(ops, wl, co, ev)
-
-
-def run_steps(ops, wl, ev, n, streams):
-    """n complete steps (batches).  streams = None: one after the other.  streams = (sA, sB): the steps of consecutive
-    batches are independent (pairs are), so the coarse stage of batch i + 1 (one-CU Sinkhorn kernels on 48 of 256 CUs,
-    HBM-bound crop gathers) runs on sA beside the fine + third stage of batch i (VALU-bound) on sB.  Every batch still
-    goes through every kernel; nothing leaves the function unfinished (the caller's stream waits for both)."""
+def run_steps(batch, nets, cap, wl, ev, n, streams):
+    """n complete steps (batches).  streams = None: one after the other.  streams = (sA, sB): consecutive batches are
+    independent (pairs are), so the coarse stage of batch i + 1 (one-CU Sinkhorn kernels on a few CUs, HBM-bound crop
+    gathers) runs on sA beside the fine + third stage of batch i (VALU-bound) on sB.  Every batch still goes through
+    every kernel; nothing leaves the function unfinished (the caller's stream waits for both)."""
+    kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
     if streams is None or n <= 0:
-        co = out = None
+        out = None
         for _ in range(n):
-            co, out = step(ops, wl, ev)
-        return co, out
+            co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
+            out = batch.fine_third_stage(co, nets, cap, events=ev, **kw)
+        return out
     sA, sB = streams
     cur = torch.cuda.current_stream()
     sA.wait_stream(cur)
@@ -242,7 +172,7 @@ def run_steps(ops, wl, ev, n, streams):
 
     def coarse():
         with torch.cuda.stream(sA):
-            c = coarse_stage(ops, wl)
+            c = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
             e = torch.cuda.Event()
             e.record(sA)
         return c, e
@@ -252,34 +182,16 @@ def run_steps(ops, wl, ev, n, streams):
         nxt = coarse() if i + 1 < n else None
         with torch.cuda.stream(sB):
             sB.wait_event(done)
-            for v in co.values():                       # allocated on sA, read on sB
-                if isinstance(v, torch.Tensor):
-                    v.record_stream(sB)
-            out = fine_and_third(ops, wl, co, ev)
-        last_co = co
+            for t in _tensors(co):                       # allocated on sA, read on sB
+                t.record_stream(sB)
+            out = batch.fine_third_stage(co, nets, cap, events=ev, **kw)
         if nxt is not None:
             co, done = nxt
     cur.wait_stream(sA)
     cur.wait_stream(sB)
-    return last_co, out
-
-
-def local_matches(wl, co, out, rank, world):
-    """Per-pair (matches_l, matches_r) of this rank's last step, outside the clock: get_result emits rows in
-    (pair, chunk, patch, sub-cell) order, so pair i owns a contiguous run whose length is the number of
-    surviving sub-cells of its rows."""
-    C = wl.C
-    rows_per_mask = torch.logical_not(out["masks"]).sum(dim=1).reshape(wl.pairs, C).sum(dim=1).cpu().tolist()
-    per_row = torch.logical_not(out["ifn16"]).sum(dim=1).cpu().numpy()
-    M = int(out["M"].item())
-    res, r0, m0 = [], 0, 0
-    for i in range(wl.pairs):
-        k = int(per_row[r0:r0 + rows_per_mask[i]].sum())
-        res.append((rank + i * world, out["ml"][m0:m0 + k], out["mr"][m0:m0 + k]))
-        r0 += rows_per_mask[i]
-        m0 += k
-    assert m0 == M, "get_result count %d != per-pair total %d" % (M, m0)
-    return res
+    for t in _tensors(out):                              # allocated on sB, read by the caller
+        t.record_stream(cur)
+    return out
 
 
 def torch_cpu_sinkhorn(Z, log_mu, log_nu, iters):
@@ -291,7 +203,9 @@ def torch_cpu_sinkhorn(Z, log_mu, log_nu, iters):
     return Z + u.unsqueeze(2) + v.unsqueeze(1)
 
 
-def torch_cpu_ot2(scores, ns, iters):
+def torch_cpu_cost_ot2(d0, d1, ns, iters):
+    """second_layer.py:100-104 / third_layer.py:156-158 on CPU tensors: einsum cost build + log_optimal_transport2."""
+    scores = 0.1 * (torch.einsum("bdn,bdm->bnm", d0, d1) / d0.shape[1] ** .5)
     b, m, n = scores.shape
     ms = torch.tensor(float(m - 1))
     nssum = ns.sum(dim=2)                                             # [b,1]
@@ -304,8 +218,8 @@ def torch_cpu_ot2(scores, ns, iters):
 ULP4 = 4.0 * 2.0 ** -23     # "a threshold tie": the deciding quantities agree to 4 ulp
 
 
-def expansion_parity(ops, oracle, dev, f, gZ2, g2, Z2, ex2, r2, c2):
-    """Area expansion of the L2 sample (utils.py:1213-1243), HIP against the oracle, every differing row classified.
+def expansion_parity(ops, oracle, dev, sx, sy, gZ2, Z2):
+    """Area expansion of pair 0's fine problems (utils.py:1213-1243), HIP against the oracle, every differing row classified.
 
     (1) SAME INPUT: the oracle expands the plan the GPU produced (exp on the GPU, the identical fp32 array on both
         sides), so the only freedom left is the summation order of a strip.  A row whose rectangle differs is a
@@ -313,49 +227,38 @@ def expansion_parity(ops, oracle, dev, f, gZ2, g2, Z2, ex2, r2, c2):
         and `lower_bound` / the competing strip (oracle_iterative_expand_margin) - is within 4 ulp; anything else is a
         REAL mismatch, and the bench asserts there is none.
     (2) END TO END: each side expands its OWN plan.  The plans agree to the 1e-4 transport-mass gate, not bit for bit,
-        and `lower_bound` = 1e-3 is only 10x that gate, so a strip sum that lands within the measured plan difference
-        of the threshold grows on one side and not on the other; such a row then carries a different rectangle AND a
-        different trust score (whole_cost) - this is where round 2's unexplained max |d trust| = 0.04 came from.
-        A differing row is "explained" if its margin is below what the measured plan difference of its problem can
-        move a strip sum by (12 cells x max |dP|, relative to lower_bound); anything else is REAL and asserted zero."""
+        and `lower_bound` = 1e-3 is only 10x that gate, so a strip sum - or a single strip cell, for the per-element test
+        of :1225 that charges the opposite dustbin mass to whole_cost - that lands within the measured plan difference of
+        the threshold is counted on one side only; such a row carries a different trust score (this is where round 2's
+        unexplained max |d trust| = 0.04 came from: one row, one cell) and possibly a different rectangle.  A differing
+        row is "explained" if its margin is below what the measured plan difference of its problem can move a strip sum
+        by (12 cells x max |dP|, relative to lower_bound); anything else is REAL and asserted zero."""
     td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     nb = gZ2.shape[0]
     pos, rng_ = ops.Compute_positions_and_ranges(12, 12, dev)
     gP = ops.exp(gZ2)
-    gsame = ops.Iterative_expand_matrix(gP, td(f["scale_x"]).reshape(nb, -1, 1), td(f["scale_y"]).reshape(nb, -1, 1),
-                                        [0, 12, 0, 12], rng_, pos, lower_bound=1e-3, iter_num=8, width=12, height=12)
-    gbound = gsame[5].cpu().numpy()
-    gtrust = gsame[0].cpu().numpy()
-    osame = oracle.iterative_expand(gP.cpu().numpy(), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8, with_margin=True)
+    gsame = ops.Iterative_expand_matrix(gP, td(sx).reshape(nb, -1, 1), td(sy).reshape(nb, -1, 1), [0, 12, 0, 12], rng_, pos,
+                                        lower_bound=1e-3, iter_num=8, width=12, height=12)
+    gbound, gtrust = gsame[5].cpu().numpy(), gsame[0].cpu().numpy()
+    osame = oracle.iterative_expand(gP.cpu().numpy(), sx, sy, 12, 12, 12, 1e-3, 8, with_margin=True)
     diff_rows = (gbound != osame[5]).any(axis=2)
-    margin = osame[6][..., 0]
-    tie = diff_rows & (margin <= ULP4)
+    tie = diff_rows & (osame[6][..., 0] <= ULP4)
     real_same = diff_rows & ~tie
-    # trust of rows whose rectangles agree: same strips, same sums up to order
-    same_rows = ~diff_rows
-    # the per-element `> lower_bound` test of :1225 only feeds whole_cost: a row with an element within 4 ulp of the
-    # threshold may differ in trust although its rectangle agrees
     elem_tie = osame[6][..., 1] <= ULP4
     dtrust = np.abs(gtrust - osame[0])
-    trust_same = float(dtrust[same_rows & ~elem_tie].max()) if (same_rows & ~elem_tie).any() else 0.0
+    ok_rows = ~diff_rows & ~elem_tie
+    trust_same = float(dtrust[ok_rows].max()) if ok_rows.any() else 0.0
     # end to end (each side its own plan)
-    ebound_diff = (gbound != ex2[5]).any(axis=2)
+    own = oracle.iterative_expand(np.exp(Z2), sx, sy, 12, 12, 12, 1e-3, 8, with_margin=True)
+    ebound_diff = (gbound != own[5]).any(axis=2)
     dP = np.abs(np.exp(gZ2.cpu().numpy().astype(np.float64)) - np.exp(Z2.astype(np.float64)))[:, :-1, :].max(axis=(1, 2))
-    own = oracle.iterative_expand(np.exp(Z2), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8, with_margin=True)
     reach = (12.0 * dP / 1e-3 + ULP4)[:, None]
     explained = ebound_diff & (own[6][..., 0] <= reach)
     real_e2e = ebound_diff & ~explained
-    dtrust_e2e = np.abs(g2[0].cpu().numpy() - ex2[0])
-    agree = ~ebound_diff & (own[6][..., 1] > reach)
-    # a row whose trust differs although its rectangle agrees: the per-element test `expand_sum > lower_bound` of :1225
-    # decides whether the opposite dustbin mass of a strip cell is charged to the row (whole_cost = ... + nomatching / 4),
-    # and a cell whose mass is within the plan difference of lower_bound is charged on one side only
-    tol_t = 1e-4 + 1e-4 * np.abs(ex2[0])
+    dtrust_e2e = np.abs(gtrust - own[0])
+    tol_t = 1e-4 + 1e-4 * np.abs(own[0])
     tdiff = (dtrust_e2e > tol_t) & ~ebound_diff
     t_explained = tdiff & (own[6][..., 1] <= reach)
-    ifn1 = g2[4].cpu().numpy()
-    ifn2 = g2[5].cpu().numpy()
-    flag_mismatch = int((ifn1 != (r2[:, :-1] == 144)).sum() + (ifn2 != (c2[:, :-1] == 144)).sum())
     return {
         "l2_rows": int(diff_rows.size),
         "l2_bound_mismatch_same_input": int(diff_rows.sum()), "l2_bound_threshold_ties": int(tie.sum()),
@@ -364,111 +267,178 @@ def expansion_parity(ops, oracle, dev, f, gZ2, g2, Z2, ex2, r2, c2):
         "l2_bound_mismatch_end_to_end": int(ebound_diff.sum()),
         "l2_bound_mismatch_end_to_end_explained_by_plan_difference": int(explained.sum()),
         "l2_plan_max_abs_diff": float(dP.max()),
-        "l2_smallest_margin_of_a_differing_row": float(own[6][..., 0][ebound_diff].min()) if ebound_diff.any() else None,
-        "l2_trust_max_abs_diff": float(dtrust_e2e.max()), "l2_trust_max_abs": float(np.abs(ex2[0]).max()),
-        "l2_trust_max_abs_diff_where_rectangles_agree": float(dtrust_e2e[agree].max()) if agree.any() else 0.0,
+        "l2_trust_max_abs_diff": float(dtrust_e2e.max()), "l2_trust_max_abs": float(np.abs(own[0]).max()),
         "l2_trust_rows_differing_with_equal_rectangles": int(tdiff.sum()),
         "l2_trust_rows_explained_by_element_threshold": int(t_explained.sum()),
         "l2_trust_real_mismatch": int((tdiff & ~t_explained).sum()),
-        "l2_flag_mismatch": flag_mismatch,
     }
 
 
-def cpu_baseline(ops, dev, pairs_B, pairs_P, seconds):
-    """The CPU oracle ("port") on the host cores: L1 in full, bounded samples of L2/L3 scaled to one
-    pair, plus the torch-CPU transcription of the Sinkhorn loop on the same samples.  Checker code timed
-    as a baseline only - never part of the measured GPU path.  The HIP path is also run on the same L2 /
-    L3 samples and compared with the oracle's answers (`parity_sample`): index outputs and expansion rectangles are
-    ASSERTED - every differing row must classify as a threshold tie (expansion_parity)."""
+def cpu_baseline(ops, batch, dev, nets, cap, wl, out):
+    """The CPU oracle ("port") on the host cores over ONE WHOLE PAIR (pair 0 of a step: L1 in full, every fine problem,
+    every third-level problem the merge left, the merges, the scatter and get_result) - measured, not extrapolated.
+    Each stage is fed what the GPU handed its own next stage, so the same run is a stage-by-stage parity check on the
+    bench's own data (`parity_sample`; index outputs are ASSERTED).  Beside it the torch-CPU transcription of
+    modules.py:137-182 + the einsum cost builds, on samples.  Checker code, timed as a baseline only."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import pats_oracle as oracle
     cores = oracle.num_threads()
-    c = synth.coarse_inputs()
+    h, w, N = cap.h, cap.w, cap.N
+    H, W = 32 * h, 32 * w
+    st, rows, co = out["stages"], out["rows"], out["coarse"]
+    cell = rows.row_cell.cpu().numpy()
+    total = int(rows.chunk_base[-1].item())
+    rows0 = np.nonzero((cell[:total] >= 0) & (cell[:total] // N == 0))[0]
+    B0 = len(rows0)
+    base = rows.chunk_base.cpu().numpy()
+    r0t = torch.from_numpy(rows0).to(dev)
+    cpu = lambda t: t.detach().cpu().numpy()   # noqa: E731
+    times = {}
+
+    # ---- L1 (first_layer.py:110-127) -------------------------------------------------------------------------------
+    d0, d1, ns = cpu(nets.d0[0:1]), cpu(nets.d1[0:1]), cpu(nets.ns[0:1])
     t0 = time.perf_counter()
-    S = oracle.cost(c["d0"], c["d1"])
-    Z = oracle.log_optimal_transport(S, c["alpha"], c["ns"], ITERS)
+    S = oracle.cost(d0, d1)
+    Z = oracle.log_optimal_transport(S, float(nets.alpha.item()), ns, ITERS)
     sc = oracle.colmass_sqrt(Z)
-    oracle.argmax(Z)
-    oracle.iterative_expand(np.exp(Z), sc, sc, 20, 15, 20, 1e-5, 15)
-    t_l1 = time.perf_counter() - t0
-    # L2 sample
-    nb = max(cores, 8)
-    f = synth.fine_inputs(seed=77, B=nb)
+    r1, c1 = oracle.argmax(Z)
+    oracle.iterative_expand(np.exp(Z), sc, sc, w, h, w, 1e-5, 15)
+    times["L1"] = time.perf_counter() - t0
+    ifn1_o = (r1[:, :-1] == N)
+    parity = {"pair": 0, "l1_if_nomatching_mismatch": int((ifn1_o[0] != cpu(co["ifn1"][0])).sum()),
+              "l1_matched_patches": int((~ifn1_o).sum())}
+
+    # ---- L2 (second_layer.py:100-118) on the descriptors the GPU's gather produced ---------------------------------
+    f0, f1 = cpu(st["f0"][r0t]), cpu(st["f1"][r0t])
+    sx, sy = cpu(st["sx"][r0t]), cpu(st["sy"][r0t])
     t0 = time.perf_counter()
-    S2 = oracle.cost(f["d0"], f["d1"])
-    Z2 = oracle.dustbin_bias(oracle.log_optimal_transport2(S2, 1.0, f["scale_x"] * f["scale_y"], ITERS), 2.0)
+    S2 = oracle.cost(f0, f1)
+    Z2 = oracle.dustbin_bias(oracle.log_optimal_transport2(S2, 1.0, sx * sy, ITERS), wl["bias_k"])
     r2, c2 = oracle.argmax(Z2)
-    ex2 = oracle.iterative_expand(np.exp(Z2), f["scale_x"], f["scale_y"], 12, 12, 12, 1e-3, 8)
-    t_l2 = (time.perf_counter() - t0) / nb
-    # L3 sample sized to the remaining budget
-    probe = synth.third_inputs(seed=78, P=4 * cores)
-    t0 = time.perf_counter()
-    S3 = oracle.cost(probe["d0"], probe["d1"])
-    oracle.log_optimal_transport2(S3, 1.0, probe["scale"], ITERS)
-    per = (time.perf_counter() - t0) / (4 * cores)
-    np3 = int(max(4 * cores, min(4096, (seconds - t_l1 - t_l2 * nb) / max(per, 1e-6))))
-    t3in = synth.third_inputs(seed=79, P=np3)
-    sq = np.sqrt(t3in["scale"] + np.float32(1e-8)).astype(np.float32)
-    t0 = time.perf_counter()
-    S3 = oracle.cost(t3in["d0"], t3in["d1"])
-    Z3 = oracle.log_optimal_transport2(S3, 1.0, t3in["scale"], ITERS)
-    r0, r1, rwl, rlabel, rifm = oracle.compute_result(np.exp(Z3), sq, sq, t3in["p_s"], t3in["p_t"], True)
-    t_l3 = (time.perf_counter() - t0) / np3
-    per_pair = t_l1 + t_l2 * pairs_B + t_l3 * pairs_P
-
-    # the same samples through the HIP path: indices must be identical, transport mass within 1e-4
-    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    g0, g1, glabel, gifm = ops.third_level(td(t3in["d0"]), td(t3in["d1"]), td(t3in["scale"]), td(t3in["p_s"]),
-                                           td(t3in["p_t"]), outdoor=True, iters=ITERS)
-    gZ2 = ops.cost_ot(td(f["d0"]), td(f["d1"]), 2, 1.0, td(f["scale_x"] * f["scale_y"]), ITERS, bias_k=2.0)
-    g2 = ops.est_position_second(gZ2, td(f["scale_x"]), td(f["scale_y"]), [96, 96], 8)
+    oracle.iterative_expand(np.exp(Z2), sx, sy, 12, 12, 12, 1e-3, 8)
+    times["L2"] = time.perf_counter() - t0
+    gZ2 = st["Z2"][r0t].contiguous()
     gr2, gc2 = ops.argmax(gZ2)
-    e2, e2r = np.exp(gZ2.cpu().numpy().astype(np.float64)), np.exp(Z2.astype(np.float64))
-    parity = {
-        "l3_problems": np3, "l3_label_mismatch": int((glabel.cpu().numpy() != rlabel).sum()),
-        "l3_if_matching_mismatch": int((gifm.cpu().numpy().astype(bool) != rifm.astype(bool)).sum()),
-        "l3_mkpts0_mismatch": int((g0.cpu().numpy() != r0).sum()),
-        "l3_mkpts1_max_abs_diff_px": float(np.abs(g1.cpu().numpy() - r1).max()),
-        "l2_problems": nb, "l2_row_argmax_mismatch": int((gr2.cpu().numpy() != r2).sum()),
-        "l2_col_argmax_mismatch": int((gc2.cpu().numpy() != c2).sum()),
-        "l2_mass_max_abs_diff": float(np.abs(e2[:, :-1, :-1] - e2r[:, :-1, :-1]).max()),
-    }
-    parity.update(expansion_parity(ops, oracle, dev, f, gZ2, g2, Z2, ex2, r2, c2))
-    assert parity["l2_bound_real_mismatch"] == 0 and parity["l2_flag_mismatch"] == 0, parity
-    assert parity["l2_trust_real_mismatch"] == 0, parity
-    assert parity["l3_label_mismatch"] == 0 and parity["l3_if_matching_mismatch"] == 0 and parity["l3_mkpts0_mismatch"] == 0, parity
+    e2, e2r = np.exp(cpu(gZ2).astype(np.float64)), np.exp(Z2.astype(np.float64))
+    pre = ops.est_position_second(gZ2, st["sx"][r0t].contiguous(), st["sy"][r0t].contiguous(), [96, 96], 8)   # before the merge
+    parity.update({"l2_problems": B0, "l2_row_argmax_mismatch": int((cpu(gr2) != r2).sum()),
+                   "l2_col_argmax_mismatch": int((cpu(gc2) != c2).sum()),
+                   "l2_mass_max_abs_diff": float(np.abs(e2[:, :-1, :-1] - e2r[:, :-1, :-1]).max()),
+                   "l2_flag_mismatch": int((cpu(pre[4]) != (r2[:, :-1] == 144)).sum() + (cpu(pre[5]) != (c2[:, :-1] == 144)).sum())})
+    parity.update(expansion_parity(ops, oracle, dev, sx, sy, gZ2, Z2))
 
-    # torch-CPU transcription of modules.py:137-182 on the same L1 problem and (smaller) L2 / L3 samples
-    torch.set_num_threads(cores)
-    tS = torch.from_numpy(S)
-    tns = torch.from_numpy(c["ns"])
+    # ---- merge (second_layer.py:119-122, pats.py:38-39): the oracle on the GPU's trust scores, chunk after chunk -----
+    trust_g, ifn_g = cpu(pre[0]), cpu(pre[4])
+    masks0 = cpu(rows.masks[:, 0, :])
+    third_set = cpu(rows.third[0])
+    nchunks = int(rows.cycle_num[0].item())
+    merged_o = np.ones((B0, 144), bool)
+    scores_back = np.zeros((1, N, 16, 9), np.float64)
     t0 = time.perf_counter()
-    b, m, n = tS.shape
-    alpha = torch.tensor(float(c["alpha"]))
-    coup = torch.cat([torch.cat([tS, alpha.expand(b, m, 1)], -1), alpha.expand(b, 1, n + 1)], 1)
+    o = 0
+    for c in range(min(nchunks, cap.Cmax)):
+        n = int(((cell[int(base[c]):int(base[c + 1])] // N) == 0).sum())
+        if n == 0:
+            continue
+        res, _, _, sb = oracle.merge_patches(wl["merge_new"], trust_g[o:o + n], (H, W), masks0[c:c + 1], ifn_g[o:o + n], scores_back)
+        scores_back = sb if wl["merge_new"] else np.zeros_like(sb)
+        tail = int(third_set[c, 1])
+        if tail != 0:
+            res[-tail:, :] = True
+        merged_o[o:o + n] = res
+        o += n
+    times["merge"] = time.perf_counter() - t0
+    merged_g = cpu(out["merged"][r0t])
+    parity["merge_if_nomatching_mismatch"] = int((merged_g != merged_o).sum())
+
+    # ---- L3 (pats.py:53-58, third_layer.py:153-170) on the descriptors the GPU's window gather produced --------------
+    P = int(out["P"].item())
+    b_ids = cpu(st["b_ids"][:P])
+    idx3 = np.nonzero(np.isin(b_ids, rows0))[0]
+    i3t = torch.from_numpy(idx3).to(dev)
+    P0 = len(idx3)
+    t3a, t3b, sc3 = cpu(st["feat0"][i3t]), cpu(st["feat1"][i3t]), cpu(st["scale3"][i3t])
+    ps3, pt3 = cpu(st["p_s"][i3t]), cpu(st["p_t"][i3t])
+    sq = np.sqrt(sc3 + np.float32(1e-8)).astype(np.float32)
+    pts2_0 = cpu(st["pts2"][r0t])
+    t0 = time.perf_counter()
+    mk0_o, mk1_o, bid_o = oracle.third_inputs(merged_o, pts2_0)
+    S3 = oracle.cost(t3a, t3b)
+    Z3 = oracle.log_optimal_transport2(S3, 1.0, sc3, ITERS)
+    q0, q1, _, qlabel, qifm = oracle.compute_result(np.exp(Z3), sq, sq, ps3, pt3, wl["outdoor"])
+    times["L3"] = time.perf_counter() - t0
+    g1 = cpu(st["m1f"][i3t])
+    glabel = cpu(st["label"].reshape(-1, 16, 2)[i3t])
+    parity.update({"l3_problems": P0,
+                   "l3_points_mismatch": int((mk0_o != cpu(st["mk0"][i3t])).sum() + (mk1_o != cpu(st["mk1"][i3t])).sum()) if len(mk0_o) == P0 else -1,
+                   "l3_label_mismatch": int((glabel.reshape(-1, 2) != qlabel).sum()),
+                   "l3_if_matching_mismatch": int((cpu(st["ifm"][i3t]).astype(bool) != qifm.astype(bool)).sum()),
+                   "l3_mkpts0_mismatch": int((cpu(st["m0f"][i3t]) != q0).sum()),
+                   "l3_mkpts1_max_abs_diff_px": float(np.abs(g1 - q1).max()) if P0 else 0.0})
+
+    # ---- results (pats.py:59-78): the oracle's scatter + get_result on the GPU's third-level output -----------------
+    t0 = time.perf_counter()
+    ifn16_o, pts16_o = oracle.refine_scatter(merged_o, pts2_0, g1, glabel[:, :, 0].reshape(-1))
+    C = masks0.shape[0]
+    xs0, av0 = cpu(co["xsn"][0:1]), cpu(co["avn"][0:1])
+    xs_c, av_c = np.repeat(xs0, C, axis=0), np.repeat(av0, C, axis=0)
+    sc_rows = xs_c[~masks0]
+    ml_o, mr_o = oracle.get_result(C, [masks0, ifn16_o], [np.ascontiguousarray(av_c[:, :, ::-1]) / np.float32(32.0),
+                                                          np.ascontiguousarray(pts16_o[:, :, ::-1]) / np.float32(2.0)],
+                                   [xs_c, np.repeat(sc_rows.reshape(-1, 1, 2), 2304, 1)], [[32, h, w], [2, 48, 48]],
+                                   [np.ones(C, bool), np.ones(B0, bool)])
+    times["result"] = time.perf_counter() - t0
+    ml_g, mr_g = [cpu(t) for t in batch.split_by_pair(out, cap)[0]]
+    same_count = ml_g.shape == ml_o.shape
+    parity.update({"matches_pair0": int(ml_g.shape[0]), "matches_count_equal": bool(same_count),
+                   "matches_l_mismatch": int((ml_g != ml_o).sum()) if same_count else -1,
+                   "matches_r_mismatch": int((mr_g != mr_o).sum()) if same_count else -1})
+    if same_count and parity["matches_l_mismatch"]:
+        sys.stderr.write("matches_l gpu %s\noracle %s\nmatches_r gpu %s\noracle %s\n" % (ml_g[:4], ml_o[:4], mr_g[:4], mr_o[:4]))
+    assert parity["l1_if_nomatching_mismatch"] == 0 and parity["l2_flag_mismatch"] == 0, parity
+    assert parity["l2_row_argmax_mismatch"] == 0 and parity["l2_col_argmax_mismatch"] == 0, parity
+    assert parity["l2_bound_real_mismatch"] == 0 and parity["l2_trust_real_mismatch"] == 0, parity
+    assert parity["merge_if_nomatching_mismatch"] == 0 and parity["l3_points_mismatch"] == 0, parity
+    assert parity["l3_label_mismatch"] == 0 and parity["l3_if_matching_mismatch"] == 0 and parity["l3_mkpts0_mismatch"] == 0, parity
+    assert parity["l3_mkpts1_max_abs_diff_px"] <= 3e-4 * 8 and parity["l2_mass_max_abs_diff"] <= 1e-4, parity
+    assert same_count and parity["matches_l_mismatch"] == 0 and parity["matches_r_mismatch"] == 0, parity
+    per_pair = sum(times.values())
+
+    # ---- torch-CPU transcription of what the reference executes (einsum cost + logsumexp sweeps), on samples ----------
+    torch.set_num_threads(cores)
+    tns = torch.from_numpy(ns)
+    t0 = time.perf_counter()
+    sco = 0.1 * (torch.einsum("bdn,bdm->bnm", torch.from_numpy(d0), torch.from_numpy(d1)) / 448 ** .5)
+    b, m, n = sco.shape
+    alpha = torch.tensor(float(nets.alpha.item()))
+    coup = torch.cat([torch.cat([sco, alpha.expand(b, m, 1)], -1), alpha.expand(b, 1, n + 1)], 1)
     msn = torch.tensor(float(m))
     norm = -(msn + tns.sum(dim=2)).log()
     log_nu = torch.cat([tns.log()[:, 0] + norm, msn.log().expand(b, 1) + norm], dim=1)
     log_mu = torch.cat([norm.expand(b, m), tns.sum(dim=2).log() + norm], dim=1)
     torch_cpu_sinkhorn(coup, log_mu, log_nu, ITERS)
     tt1 = time.perf_counter() - t0
-    n2 = min(nb, 64)
+    n2 = min(B0, 96)
     t0 = time.perf_counter()
-    torch_cpu_ot2(torch.from_numpy(S2[:n2]), torch.from_numpy((f["scale_x"] * f["scale_y"])[:n2]), ITERS)
-    tt2 = (time.perf_counter() - t0) / n2
-    n3 = min(np3, 1024)
+    torch_cpu_cost_ot2(torch.from_numpy(f0[:n2]), torch.from_numpy(f1[:n2]), torch.from_numpy((sx * sy)[:n2]), ITERS)
+    tt2 = (time.perf_counter() - t0) / max(n2, 1)
+    n3 = min(P0, 1024)
     t0 = time.perf_counter()
-    torch_cpu_ot2(torch.from_numpy(S3[:n3]), torch.from_numpy(t3in["scale"][:n3]), ITERS)
-    tt3 = (time.perf_counter() - t0) / n3
-    torch_pair = tt1 + tt2 * pairs_B + tt3 * pairs_P
+    if n3:
+        torch_cpu_cost_ot2(torch.from_numpy(t3a[:n3]), torch.from_numpy(t3b[:n3]), torch.from_numpy(sc3[:n3]), ITERS)
+    tt3 = (time.perf_counter() - t0) / max(n3, 1)
+    torch_pair = tt1 + tt2 * B0 + tt3 * P0
     return {"value": 1.0 / per_pair, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle/pats_oracle.c (OpenMP over problems), EXTRAPOLATED from samples: L1 301x301 in full "
-                      "(%.3fs), %d L2 problems (%.4fs each), %d L3 problems (%.5fs each), scaled to B=%d, P=%d per pair"
-                      % (t_l1, nb, t_l2, np3, t_l3, pairs_B, pairs_P),
+            "sample": "oracle/pats_oracle.c (OpenMP over problems) on ONE WHOLE PAIR, measured: pair 0 of a step - L1 %dx%d "
+                      "(%.3fs), its %d fine problems (%.3fs), the merges of its %d chunks (%.3fs), its %d third-level problems "
+                      "(%.3fs), scatter + get_result (%.3fs)" % (N + 1, N + 1, times["L1"], B0, times["L2"], nchunks, times["merge"],
+                                                                  P0, times["L3"], times["result"]),
+            "seconds_per_pair": per_pair,
             "torch_cpu": {"value": 1.0 / torch_pair, "unit": "pairs/s", "cores": cores,
-                          "sample": "torch.logsumexp transcription of modules.py:137-182 (Sinkhorn only, no cost build / "
-                                    "expansion), %d torch threads, EXTRAPOLATED: L1 301x301 (%.3fs), %d L2 (%.4fs each), "
-                                    "%d L3 (%.5fs each) scaled to B=%d, P=%d" % (cores, tt1, n2, tt2, n3, tt3, pairs_B, pairs_P)},
+                          "sample": "torch transcription of the reference's CPU arithmetic (einsum cost builds + modules.py:137-182 "
+                                    "logsumexp sweeps; no expansion / merge), %d torch threads: L1 in full (%.3fs), %d of the pair's %d "
+                                    "fine problems (%.4fs each), %d of its %d third-level problems (%.5fs each), scaled to the pair"
+                                    % (cores, tt1, n2, B0, tt2, n3, P0, tt3)},
             "parity_sample": parity}
 
 
@@ -487,55 +457,67 @@ def timed(fn, reps=5, warm=2):
     return e0.elapsed_time(e1) / reps
 
 
-def secondary_rooflines(ops, dev, wl, fine_ms):
+def secondary_rooflines(ops, dev, other):
     """Other kernels of the path against their nearer roofline (live HIP-event timings; rocprof counterparts
-    under profiles/r02_*).  Config 5 = BASELINE.json configs[4]."""
-    out = []
+    under profiles/).  Config 5 = BASELINE.json configs[4]."""
+    res = [other]
     r = synth.roofline_inputs()
     d0, d1, ns = [torch.from_numpy(r[k]).to(dev) for k in ("d0", "d1", "ns")]
     N, D = d0.shape[2], d0.shape[1]
     S = ops.cost(d0, d1)
     ms = timed(lambda: ops.cost(d0, d1, out=S), reps=200, warm=20)
     tf = 2.0 * D * N * N / (ms * 1e-3) / 1e12
-    split_note = ("fp32 operands as fp16 hi + lo pairs, three exact-product passes of v_mfma_f32_32x32x16_f16 (fp32 accumulation; "
-                  "closer to float64 than the fp32 fma chain, tools/cost_ab.py): `achieved` counts the 2*D*M*N algorithmic flops "
-                  "against the fp32 matrix peak the reference arithmetic would be priced at; the fp16 pipe executes three times "
-                  "as many (f16_pipe_*).  PATS_COST_F32=1 = the fp32-MFMA path (profiles/r02_cost_ab.txt)")
-    out.append({"kernel": "cost_mfma_kernel, config 5 (4096^2 x %d)" % D, "bound": "mfma", "achieved": tf,
-                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS, "ms": ms,
-                "f16_pipe_tflops": 3.0 * tf, "f16_pipe_frac": 3.0 * tf / F16_PEAK_TFLOPS, "note": split_note,
-                "profile": "profiles/r02_config5_kernel_stats.md"})
-    S = ops.cost(d0, d1)
+    res.append({"kernel": "cost_mfma_kernel, config 5 (4096^2 x %d)" % D, "bound": "mfma", "achieved": 3.0 * tf,
+                "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3.0 * tf / F16_PEAK_TFLOPS, "ms": ms,
+                "algorithmic_tflops": tf, "fp32_equivalent_frac": tf / F32_PEAK_TFLOPS,
+                "note": "priced on the pipe the kernel uses: fp32 operands as fp16 hi + lo pairs, THREE exact-product passes of "
+                        "v_mfma_f32_32x32x16_f16 per tile (fp32 accumulation) = 3 x the 2*D*M*N algorithmic flops against the dense fp16 "
+                        "matrix peak; the limiter is the descriptor stream, the LDS staging and the VALU split, not the matrix pipe.  "
+                        "fp32_equivalent_frac = algorithmic flops against the 157.3 TF/s fp32 matrix peak the reference arithmetic "
+                        "would be priced at (a note, not the claim)"})
     alpha = torch.tensor(float(r["alpha"]), device=dev)
     iters5 = 200
     ms = timed(lambda: ops.log_optimal_transport(S, alpha, ns, iters5), reps=3, warm=1)
     M = N + 1
     gbs = 8.0 * M * M * iters5 / (ms * 1e-3) / 1e9
-    out.append({"kernel": "stream_sweep_kernel, config 5 (4097^2, %d sweeps)" % iters5, "bound": "hbm", "achieved": gbs,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms,
-                "sweeps_per_s": iters5 / (ms * 1e-3),
+    res.append({"kernel": "stream_sweep_kernel, config 5 (4097^2, %d sweeps)" % iters5, "bound": "hbm", "achieved": gbs,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms, "sweeps_per_s": iters5 / (ms * 1e-3),
                 "note": "algorithmic 8*M*N bytes per sweep; the 67 MB matrix is Infinity-Cache (256 MiB) resident, so "
-                        "this can exceed the DRAM roofline - labelled, not a DRAM claim",
-                "profile": "profiles/r02_config5_kernel_stats.md"})
-    del S, d0, d1
-    ch = wl.chunk
-    S2 = ops.cost(ch["f0"], ch["f1"])
-    ms = timed(lambda: ops.cost(ch["f0"], ch["f1"], out=S2), reps=8, warm=2)
-    del S2
-    tf = 2.0 * 264 * 145 * 145 * ch["B"] / (ms * 1e-3) / 1e12
-    by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * ch["B"]
-    out.append({"kernel": "cost_mfma_kernel, fine level (%d x [264,145]^2)" % ch["B"], "bound": "hbm",
-                "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "ms": ms, "tflops": tf, "note": "one workgroup per problem reads 306 KB of descriptors and writes 84 KB of scores: "
-                "with the fp16-split contraction the matrix pipe needs 0.4 ms of this, the rest is the descriptor stream"})
-    if fine_ms is not None:
-        by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * ch["B"]
-        gbs = by / (fine_ms * 1e-3) / 1e9
-        out.append({"kernel": "fine-level cost + Sinkhorn (%d x 145x145, descriptors in, log-plan out)" % ch["B"],
-                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "ms": fine_ms, "sweep_elements_per_s": 2.0 * ITERS * 145 * 145 * ch["B"] / (fine_ms * 1e-3),
-                    "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * ch["B"] / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS})
-    return out
+                        "this can exceed the DRAM roofline - labelled, not a DRAM claim"})
+    return res
+
+
+def guard_trip_sweep(ops, batch, nets, cap, wl, fracs=(0.01, 0.10)):
+    """pairs/s when a fraction of the fine / third-level problems leaves the linear-domain solver's guard band and is
+    re-solved in the log domain: the rows' backbone maps are scaled by 40 (scores of +-150 nats), three steps are timed,
+    the maps restored."""
+    res = []
+    R = cap.rows_cap
+    g = torch.Generator(device=nets.m0.device)
+    g.manual_seed(12345)
+    kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
+    for frac in fracs:
+        pick = torch.nonzero(torch.rand((R,), device=nets.m0.device, generator=g) < frac).flatten()
+        both = torch.cat([pick, pick + R])
+        for t in (nets.m0, nets.m1, nets.m2):
+            t[both] *= 40.0
+        nets.ff0[pick] *= 40.0
+        nets.ff1[pick] *= 40.0
+        torch.cuda.synchronize()
+        ops.sinkhorn_fallbacks(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            batch.forward_pairs(nets.lefts, nets.rights, nets, cap, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        trips = ops.sinkhorn_fallbacks(reset=True)
+        for t in (nets.m0, nets.m1, nets.m2):
+            t[both] /= 40.0
+        nets.ff0[pick] /= 40.0
+        nets.ff1[pick] /= 40.0
+        res.append({"wild_row_fraction": frac, "pairs_per_s": 3 * cap.pairs / dt, "guard_fallbacks_per_step": trips / 3.0,
+                    "note": "no stream overlap in this leg"})
+    return res
 
 
 def free_port():
@@ -563,9 +545,12 @@ def main():
     # plumbing-test knobs (a 1-GPU box cannot host two RCCL ranks): PATS_BENCH_SHARE_DEVICE=1 maps every
     # rank onto the visible devices modulo their count, PATS_BENCH_BACKEND=gloo swaps the backend.
     # Neither is set by the driver; numbers from such a run are not bench lines.
+    backend = os.environ.get("PATS_BENCH_BACKEND", "nccl")
     if os.environ.get("PATS_BENCH_SHARE_DEVICE"):
         local_rank %= torch.cuda.device_count()
-    backend = os.environ.get("PATS_BENCH_BACKEND", "nccl")
+    elif torch.cuda.device_count() < max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible (one rank per GPU over RCCL)"
+                         % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -576,118 +561,153 @@ def main():
         else:
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
-    from pats_amd import ops, shard
+    from pats_amd import batch, ops, shard
 
+    h, w, if_local, outdoor, default_pairs, label = WORKLOADS[args.workload]
+    pairs = args.pairs if args.pairs else default_pairs
+    wl = {"outdoor": outdoor, "merge_new": outdoor, "bias_k": 2.0 if outdoor else 3.0}
     gen = torch.Generator(device=dev)
     gen.manual_seed(synth.SEED + rank)
-    ONE[0] = torch.tensor(1.0, device=dev)
-    wl = Workload(ops, dev, gen, args.pairs, args.fill, args.per_chunk, args.workload)
-    B, P = wl.B, wl.P
+    cap = batch.Capacities(pairs, h, w, if_local=if_local)
+    nets = BenchNets(ops, dev, gen, cap, h, w)
+    n_gpus = dist.get_world_size() if dist is not None else 1
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    streams = None if (args.no_overlap or args.per_chunk) else (torch.cuda.Stream(), torch.cuda.Stream())
-    run_steps(ops, wl, None, args.warmup, streams)
-    ev = {"third": [], "fine": []}
+    # strong-scaling mode: --total-pairs split over the ranks; a rank with k pairs runs ceil(k / pairs) steps (each step
+    # walks `pairs` slots; the slots past its share in the last step are real work on synthetic pairs and are not counted)
+    steps = args.steps
+    if args.total_pairs > 0:
+        steps = (len(shard.my_pairs(args.total_pairs, rank, n_gpus)) + pairs - 1) // pairs
+
+    streams = None if args.no_overlap else (torch.cuda.Stream(), torch.cuda.Stream())
+    run_steps(batch, nets, cap, wl, None, args.warmup, streams)
+    ev = {}
     barrier()
     ops.sinkhorn_fallbacks(reset=True)
+    ops.profile_marker(1)                                # kernel traces are cut to the steps between the two markers
     t0 = time.perf_counter()
-    co, out = run_steps(ops, wl, ev, args.steps, streams)
+    out = run_steps(batch, nets, cap, wl, ev, steps, streams)
     barrier()
     dt = time.perf_counter() - t0
+    ops.profile_marker(2)
+    rank_ms_per_step = 1e3 * dt / max(steps, 1)
     fallbacks = ops.sinkhorn_fallbacks(reset=True)       # after the timed region (it synchronises)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_gpus = dist.get_world_size() if dist is not None else 1
-    total_pairs = args.pairs * args.steps * n_gpus
+    total_pairs = args.total_pairs if args.total_pairs > 0 else pairs * steps * n_gpus
     value = total_pairs / dt
 
     # the path's only exchange: the last step's matches of every rank -> rank 0 (RCCL), outside the clock
-    local = local_matches(wl, co, out, rank, n_gpus)
+    if out is not None:
+        per_pair = batch.split_by_pair(out, cap)
+        local = [(rank + i * n_gpus, ml, mr) for i, (ml, mr) in enumerate(per_pair)]
+    else:
+        local = []                                       # a rank that owns no pair (strong scaling with few pairs)
     barrier()
     t0 = time.perf_counter()
-    gathered = shard.gather_matches(local, args.pairs * n_gpus)
+    gathered = shard.gather_matches(local, pairs * n_gpus)
     barrier()
     gather_ms = 1e3 * (time.perf_counter() - t0)
-    matches_per_pair = None
+    matches_per_pair = gather_bytes = None
     if rank == 0:
-        assert all(g is not None for g in gathered), "gather_matches lost a pair"
-        matches_per_pair = float(np.mean([g[0].shape[0] for g in gathered]))
-        gather_bytes = sum(g[0].shape[0] for g in gathered) * 16
+        got = [g_ for g_ in gathered if g_ is not None]
+        assert len(got) == len(gathered) or args.total_pairs > 0, "gather_matches lost a pair"
+        matches_per_pair = float(np.mean([g_[0].shape[0] for g_ in got])) if got else 0.0
+        gather_bytes = sum(g_[0].shape[0] for g_ in got) * 16
+    rank_ms = [rank_ms_per_step]
+    if dist is not None:
+        tl = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(n_gpus)]
+        dist.all_gather(tl, torch.tensor([rank_ms_per_step], device=dev, dtype=torch.float64))
+        rank_ms = [float(x.item()) for x in tl]
 
-    # dominant kernel: the 65x65 third-level launch (HIP events on the launch stream)
-    ms = np.array([a.elapsed_time(b) for a, b, _ in ev["third"]])
-    probs = np.array([p for _, _, p in ev["third"]], dtype=np.float64)
-    fine_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fine"]]))
-    # algorithmic HBM bytes per problem of the fused third-level kernel: both descriptor blocks in
-    # (2 x 128 x 65 fp32), areas + coarse points in, 16 matches + labels + flags out; the 65x65 plan
-    # stays on chip (SURVEY 8d "cost build: 4*D*(M+N) in, 0 out if fused")
-    BYTES_PER_PROBLEM = 2 * 128 * 65 * 4 + 64 * 4 + 2 * 2 * 8 + 2 * 16 * 2 * 4 + 16 * 2 * 4 + 16
-    alg_bytes = float(BYTES_PER_PROBLEM) * probs
-    achieved = float((alg_bytes / (ms * 1e-3)).mean() / 1e9)
-    exp_rate = float((2.0 * ITERS * 65 * 65 * probs / (ms * 1e-3)).mean())
-    # fp32 VALU work of the kernel as flops: 2 half-sweeps x 65 x 65 FMAs (2 flops) per sweep per problem
-    valu_tflops = float((2.0 * 2.0 * ITERS * 65 * 65 * probs / (ms * 1e-3)).mean() / 1e12)
-    sweeps_per_pair = ITERS * (1 + B + P)        # one sweep = row + column normalisation of one problem
-
-    # HBM traffic of the dominant kernel from rocprofv3 PMC passes (collected separately, see the file)
-    traffic, traffic_src = None, None
-    for name in ("r02_pmc_third.json", "r01_pmc_third.json"):
-        pmc_path = os.path.join(REPO, "profiles", name)
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            traffic = float(pmc["hbm_bytes_per_problem"]) * float(probs.mean())
-            traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH calibrated " \
-                          "x%.2f on cost65_kernel's known byte count; per problem x problems per launch" \
-                          % (name, pmc["fetch_calibration"]["factor"])
-            break
-
-    res = {
-        "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",
-        "value": value, "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl.label + ": coarse+fine+third OT + cost volume + expansion + subdivision gather + get_result",
-                   "pairs_per_step_per_rank": args.pairs,
-                   "batching": "each stage is one launch over all pairs of the step; no host read inside a step"
-                               + ("" if streams is None else "; the coarse stage of batch i + 1 runs on a second HIP stream "
-                                  "beside the fine / third stage of batch i (--no-overlap: one after the other)"),
-                   "L1": "1x[448,%d]^2 -> %dx%d" % (wl.h * wl.w, wl.h * wl.w + 1, wl.h * wl.w + 1),
-                   "L2": "%d x [264,145]^2 -> 145x145 (%d coarse chunks, batched into one launch)" % (B, len(wl.plan)),
-                   "L3": "%d x [128,65]^2 -> 65x65 (fill %d)" % (P, args.fill), "sinkhorn_iters": ITERS,
-                   "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
-                                  "after the timed region (%s)" % (n_gpus, backend if dist is not None else "single process")},
-        "ot_iters_per_sec": value * sweeps_per_pair,
-        "guard_fallbacks_per_step": fallbacks / max(1, args.steps),
-        "gather_ms": gather_ms, "matches_per_pair": matches_per_pair,
-        "roofline": {"bound": "hbm", "kernel": "third_fused_kernel (fused third level, %d problems per launch)" % wl.chunk["P"],
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
-                     "avg_launch_ms": float(ms.mean()), "launches": int(len(ms)),
-                     "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
-                     "sweep_elements_per_s": exp_rate,
-                     "valu_frac": valu_tflops / F32_PEAK_TFLOPS, "valu_tflops": valu_tflops,
-                     "mfma_flops_per_s": float((2.0 * 128 * 64 * 64 * probs / (ms * 1e-3)).mean()),
-                     "note": "fused cost build (fp16-split operands, three exact-product f16 MFMA passes, fp32 accumulation: error vs "
-                             "float64 below the fp32 fma chain's; PATS_THIRD_VARIANT=300 = fp32 MFMA) + 100 linear-domain Sinkhorn sweeps + Compute_result per 65x65 problem, "
-                             "one wave each, the 65x65 block held in registers; descriptors are read once, the plan never "
-                             "reaches HBM.  HBM is the nearest of the two allowed rooflines but not the limiter: the sweeps "
-                             "are fp32 VALU work (valu_frac = sweep FMA flops / 157.3 TF/s vector peak)"},
-    }
+    res = other = None
+    if out is not None:
+        P_step = int(out["P"].item())
+        rows_step = int(out["rows"].chunk_base[-1].item())
+        third_ms = np.array([a.elapsed_time(b) for a, b in ev["third"]])
+        fine_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fine"]]))
+        # algorithmic HBM bytes per problem of the fused third-level kernel: both descriptor blocks in
+        # (2 x 128 x 65 fp32), areas + coarse points in, 16 matches + labels + flags out; the 65x65 plan
+        # stays on chip (SURVEY 8d "cost build: 4*D*(M+N) in, 0 out if fused")
+        BYTES_PER_PROBLEM = 2 * 128 * 65 * 4 + 64 * 4 + 2 * 2 * 8 + 2 * 16 * 2 * 4 + 16 * 2 * 4 + 16
+        t_ach = float(BYTES_PER_PROBLEM * P_step / (third_ms.mean() * 1e-3) / 1e9)
+        t_valu = float(2.0 * 2.0 * ITERS * 65 * 65 * P_step / (third_ms.mean() * 1e-3) / 1e12)
+        traffic, traffic_src = None, None
+        for name in ("r03_pmc_third.json", "r02_pmc_third.json"):
+            pmc_path = os.path.join(REPO, "profiles", name)
+            if os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                traffic = float(pmc["hbm_bytes_per_problem"]) * P_step
+                traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH calibrated " \
+                              "x%.2f on cost65_kernel's known byte count; per problem x problems per launch" \
+                              % (name, pmc["fetch_calibration"]["factor"])
+                break
+        third_roof = {"bound": "hbm", "kernel": "third_fused3_kernel (fused third level, %d problems per launch over a capacity of %d)"
+                      % (P_step, cap.P_cap), "achieved": t_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS,
+                      "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                      "algorithmic_bytes_per_launch": float(BYTES_PER_PROBLEM * P_step), "avg_launch_ms": float(third_ms.mean()),
+                      "launches": int(len(third_ms)), "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
+                      "valu_frac": t_valu / F32_PEAK_TFLOPS, "valu_tflops": t_valu,
+                      "note": "fused cost build + 100 linear-domain Sinkhorn sweeps + Compute_result per 65x65 problem, one wave each, the "
+                              "block held in registers; descriptors are read once, the plan never reaches HBM.  HBM is the nearer of the "
+                              "two allowed rooflines but not the limiter: the sweeps are fp32 VALU work (valu_frac = sweep FMA flops / "
+                              "157.3 TF/s vector peak)"}
+        # fine level: descriptors in, log-plan out
+        f_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * cap.rows_cap
+        f_ach = f_by / (fine_ms * 1e-3) / 1e9
+        fine_roof = {"bound": "hbm", "kernel": "fine-level cost + Sinkhorn (%d x 145x145 = the row capacity, %d rows in use)"
+                     % (cap.rows_cap, rows_step), "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_ach / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": f_by, "avg_launch_ms": fine_ms, "launches": int(len(ev["fine"])),
+                     "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
+                     "note": "descriptors in (2 x 264 x 145 fp32), log-plan out (145 x 145 fp32) per problem; the 100 sweeps run on the "
+                             "register-resident blocks (VALU-bound)"}
+        dominant, other = (third_roof, fine_roof) if third_ms.mean() >= fine_ms else (fine_roof, third_roof)
+        sweeps_per_pair = ITERS * (1 + (rows_step + P_step) / float(pairs))
+        res = {
+            "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",
+            "value": value, "unit": "pairs/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(steps, 1), "higher_is_better": True,
+            "scaling": "strong" if args.total_pairs > 0 else "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": label + ": coarse + fine + third OT, cost volumes, area expansions, subdivision gather (crops), "
+                                           "descriptor gathers (a15 / a16) from synthetic backbone maps, merge_patches per chunk in order, "
+                                           "third-level inputs decided by the merge, result scatter, get_result",
+                       "pairs_per_step_per_rank": pairs,
+                       "batching": "each stage is one launch over all pairs and chunks of the step (pats_amd.batch); no host read inside a step"
+                                   + ("" if streams is None else "; the coarse stage of batch i + 1 runs on a second HIP stream "
+                                      "beside the fine / third stage of batch i (--no-overlap: one after the other)"),
+                       "L1": "%d x [448,%d]^2 -> %dx%d (every pair its own descriptors)" % (pairs, h * w, h * w + 1, h * w + 1),
+                       "L2": "%d rows x [264,145]^2 -> 145x145 in use per step (%.1f per pair; row capacity %d, at most %d chunks per pair)"
+                             % (rows_step, rows_step / float(pairs), cap.rows_cap, cap.Cmax),
+                       "L3": "%d x [128,65]^2 -> 65x65 per step, decided by the merge (%.1f per pair; capacity %d)"
+                             % (P_step, P_step / float(pairs), cap.P_cap),
+                       "resident_synthetic_GB": nets.resident_bytes() / 1e9, "sinkhorn_iters": ITERS,
+                       "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
+                                      "after the timed region (%s)" % (n_gpus, backend if dist is not None else "single process")},
+            "ot_iters_per_sec": value * sweeps_per_pair,
+            "guard_fallbacks_per_step": fallbacks / max(1, steps),
+            "gather_ms": gather_ms, "matches_per_pair": matches_per_pair,
+            "rank_ms_per_step": rank_ms,
+            "roofline": dominant,
+        }
     if rank == 0:
+        assert res is not None, "rank 0 owns no pair"
         if n_gpus > 1:
             res["gather_bytes"] = gather_bytes
         if not args.no_secondary and n_gpus == 1:
-            res["roofline_secondary"] = secondary_rooflines(ops, dev, wl, fine_ms)
+            res["roofline_secondary"] = secondary_rooflines(ops, dev, other)
+            res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
         if not args.no_cpu_baseline and n_gpus == 1:
-            res["cpu_baseline"] = cpu_baseline(ops, dev, B, P, args.cpu_seconds)
+            # one more step outside the clock, keeping the coarse tensors the parity leg needs
+            co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
+            o2 = batch.fine_third_stage(co, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
+            o2["coarse"] = co
+            res["cpu_baseline"] = cpu_baseline(ops, batch, dev, nets, cap, wl, o2)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

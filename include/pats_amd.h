@@ -291,17 +291,22 @@ int pats_chunk_rows_device(const uint8_t* if_nomatching1, int64_t pairs, int hei
                            uint8_t* row_forced, int32_t* row_crop, int32_t* row_slot, int32_t* status, void* workspace,
                            size_t workspace_bytes, pats_stream_t stream);
 
+/* Profiling aid, no reference counterpart: launches an empty kernel named pats::profile_marker_kernel on `stream`, so that
+ * a kernel trace can be cut to the region between two markers (bench.py brackets its timed steps with it). */
+int pats_profile_marker(int tag, pats_stream_t stream);
+
 /* SecondLayer.merge_patches_new / _old (models/second_layer.py:137-238) for every chunk of every pair of the row table
  * above, in the reference's order: chunk blocks one after the other (the chunks of a pair couple through scores_back,
  * pats.py:32,37), each block over all pairs at once.  trust_score / if_nomatching1_L2 [rows_cap,144] are updated in place
- * like the reference; scores_back [pairs, N, 16, 9] fp64 (zeros before the first chunk, pats.py:32); out [rows_cap,144] =
+ * like the reference; scores_back [pairs, N, 16, 9] fp64 (zeros before the first chunk, pats.py:32: zero_scores_back != 0
+ * clears it here); out [rows_cap,144] =
  * the returned if_nomatching with pats.py:38-39 applied (row_forced) and padding rows all "no match". */
 size_t pats_merge_batch_workspace_bytes(int64_t pairs, int H, int W);
 int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, int H, int W, int64_t rows_cap,
                              const int64_t* chunk_base, const int32_t* row_cell, const int32_t* row_slot,
                              const uint8_t* row_forced, float* trust_score, uint8_t* if_nomatching1_L2,
-                             double* scores_back, uint8_t* out, void* workspace, size_t workspace_bytes,
-                             pats_stream_t stream);
+                             double* scores_back, int zero_scores_back, uint8_t* out, void* workspace,
+                             size_t workspace_bytes, pats_stream_t stream);
 
 /* SecondLayer.merge_patches_new (merge_new != 0, reference models/second_layer.py:193-240) and
  * merge_patches_old (merge_new == 0, :137-191): resolves every 8-px cell among the up to nine 96x96

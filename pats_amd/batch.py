@@ -71,17 +71,28 @@ def _round4(x, clamp96):
     return torch.round(x / 4.0).long() * 4
 
 
-def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
-    """lefts / rights [pairs,H,W,3] float32 HWC.  Returns a dict of DEVICE tensors:
-        matches_l, matches_r [M_cap,2]   the first M rows valid, reference order inside every pair (chunk, patch, sub-cell)
-        match_row [M_cap] int32          row of the table per match;  rows.row_cell[match_row] // N = pair
-        M, P [1] int64, status [1] int32 match count, third-level problem count (P > cap.P_cap = overflow), table status
-        rows                             the ops.ChunkRows table
-    No host read happens in here.  events: optional dict; ("third", "fine") receive (start, end) torch.cuda.Event pairs
-    around the dominant launches (bench.py's roofline legs)."""
+def coarse_stage(lefts, rights, nets, cap, iters=100):
+    """The first layer's tail for all pairs + the chunk plan / row table + the crops (first_layer.py:110-146,
+    utils.py:1343-1393).  Independent of every other batch: a caller may run it on a second stream beside the
+    fine / third stage of the previous batch (bench.py does)."""
     H, W = int(lefts.shape[1]), int(lefts.shape[2])
     h, w = cap.h, cap.w
     assert (H // 32, W // 32) == (h, w) and lefts.shape[0] == cap.pairs
+    mdesc0, mdesc1, scale, alpha = nets.coarse(lefts, rights)
+    Z = ops.cost_ot(mdesc0, mdesc1, 1, alpha, scale, iters)
+    scales, cflag = ops.colmass_sqrt(Z, return_flags=True)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (H, W), 32, col_nomatch=cflag)
+    rows = ops.chunk_rows(ifn1, h, w, cap.chunk_cap, Cmax=cap.Cmax, rows_cap=cap.rows_cap)
+    new_left, new_right, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(
+        xs, ys, pts, ifn1, lefts, rights, width=w, height=h, known_count="device")
+    return {"rows": rows, "new_left": new_left, "new_right": new_right, "xsn": xsn, "avn": avn, "K_img": K_img,
+            "ifn1": ifn1, "H": H, "W": W}
+
+
+def fine_third_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
+    """second_layer.py:100-122, pats.py:38-78, third_layer.py:153-170 for every row / surviving cell of a coarse_stage
+    result.  events: optional dict; "fine" / "third" receive (start, end) torch.cuda.Event pairs around those launches."""
+    rows, H, W = co["rows"], co["H"], co["W"]
 
     def timed(tag):
         if events is None:
@@ -91,26 +102,15 @@ def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, ite
         e0.record()
         return e1
 
-    # ---- first layer tail (first_layer.py:110-127) ----------------------------------------------------------------
-    mdesc0, mdesc1, scale, alpha = nets.coarse(lefts, rights)
-    Z = ops.cost_ot(mdesc0, mdesc1, 1, alpha, scale, iters)
-    scales, cflag = ops.colmass_sqrt(Z, return_flags=True)
-    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (H, W), 32, col_nomatch=cflag)
-    # ---- chunk plan + row table (first_layer.py:130-146), crops for all pairs (utils.py:1343-1393) --------------
-    rows = ops.chunk_rows(ifn1, h, w, cap.chunk_cap, Cmax=cap.Cmax, rows_cap=cap.rows_cap)
-    new_left, new_right, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(
-        xs, ys, pts, ifn1, lefts, rights, width=w, height=h, known_count="device")
-    # ---- second layer tail (second_layer.py:100-122) --------------------------------------------------------------
-    fine = nets.fine(rows, new_left, new_right)
+    fine = nets.fine(rows, co["new_left"], co["new_right"])
     f0, f1, sx, sy = fine[:4]
     ns2 = fine[4] if len(fine) > 4 else (sx * sy).contiguous()
     e = timed("fine")
-    Z2, cflag2 = ops.cost_ot(f0, f1, 2, _one(lefts.device), ns2, iters, bias_k=2.0 if if_outdoor else 3.0, return_flags=True)
+    Z2, cflag2 = ops.cost_ot(f0, f1, 2, _one(f0.device), ns2, iters, bias_k=2.0 if if_outdoor else 3.0, return_flags=True)
     if e is not None:
         e.record()
     trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
     merged = ops.merge_patches_batch(merge_new, rows, trust2, (H, W), ifn_L2)
-    # ---- third layer (pats.py:53-58, third_layer.py:121-128,153-170) ----------------------------------------------
     mk0, mk1, b_ids, P = ops.third_inputs(merged, pts2, capacity=cap.P_cap, sync=False)
     third = nets.third(rows, mk0, mk1, b_ids, P)
     feat0, feat1, scale3 = third[:3]
@@ -119,11 +119,25 @@ def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, ite
     m0f, m1f, label, ifm = ops.third_level(feat0, feat1, scale3, p_s, p_t, outdoor=if_outdoor, iters=iters, count=P)
     if e is not None:
         e.record()
-    # ---- results (pats.py:59-78) ------------------------------------------------------------------------------------
     ifn16, pts16 = ops.refine_scatter(merged, pts2, m1f, label)
-    ml, mr, mrow, M = ops.get_result_chunks(rows, ifn16, avn, pts16, xsn)
+    ml, mr, mrow, M = ops.get_result_chunks(rows, ifn16, co["avn"], pts16, co["xsn"])
     return {"matches_l": ml, "matches_r": mr, "match_row": mrow, "M": M, "P": P, "status": rows.status, "rows": rows,
-            "if_nomatching16": ifn16, "merged": merged, "K_img": K_img, "crops": (new_left, new_right)}
+            "if_nomatching16": ifn16, "merged": merged, "K_img": co["K_img"], "crops": (co["new_left"], co["new_right"]),
+            "stages": {"Z2": Z2, "trust2": trust2, "pts2": pts2, "ifn_L2": ifn_L2, "sx": sx, "sy": sy, "f0": f0, "f1": f1,
+                       "ns2": ns2, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "feat0": feat0, "feat1": feat1, "scale3": scale3,
+                       "p_s": p_s, "p_t": p_t, "m0f": m0f, "m1f": m1f, "label": label, "ifm": ifm, "pts16": pts16}}
+
+
+def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
+    """lefts / rights [pairs,H,W,3] float32 HWC.  Returns a dict of DEVICE tensors:
+        matches_l, matches_r [M_cap,2]   the first M rows valid, reference order inside every pair (chunk, patch, sub-cell)
+        match_row [M_cap] int32          row of the table per match;  rows.row_cell[match_row] // N = pair
+        M, P [1] int64, status [1] int32 match count, third-level problem count (P > cap.P_cap = overflow), table status
+        rows                             the ops.ChunkRows table
+        stages                           the intermediate tensors (parity checks; nothing reads them here)
+    No host read happens in here."""
+    co = coarse_stage(lefts, rights, nets, cap, iters)
+    return fine_third_stage(co, nets, cap, if_outdoor, merge_new, iters, events)
 
 
 def split_by_pair(out, cap):

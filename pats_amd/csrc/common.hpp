@@ -133,6 +133,10 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 
 inline hipStream_t as_stream(pats_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// memset as a kernel of this library (host.cpp): the throughput path's steps then consist of pats:: kernels only, and a
+// fill is stream-ordered like every other launch (hipMemsetAsync turns into a runtime-internal fill kernel)
+int fill_bytes(void* p, int value, size_t n, hipStream_t st);
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace pats

@@ -16,38 +16,66 @@
 namespace pats {
 
 // ---- fine level ------------------------------------------------------------------------------
-// grid: (2*B, 264 / 8); block 256 = 8 channels x 32 lanes... simpler: one workgroup per (s*B + b),
-// threads stride over the 264 x 145 outputs of that descriptor block (consecutive lanes ->
-// consecutive points of one channel).
+// One 256-thread workgroup per stacked image n = s * B + b (left crops first).  Wave w takes channels w, w + 4, ...;
+// a lane owns the points l, l + 64, l + 128 (< 145) of every channel it visits, so the source offsets of the three maps are
+// computed ONCE per lane (no division in the channel loop) and a channel's 145 outputs leave as three coalesced stores.
+// The channel loop is split by source (title / map 0 / map 1 / map 2): wave-uniform, branch-free bodies.
 __global__ void __launch_bounds__(256)
 fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                  const float* __restrict__ f2, const float* __restrict__ title,
                  const float* __restrict__ rubbish, int64_t B, float* __restrict__ desc) {
-    const int64_t n = blockIdx.x;              // s * B + b : index into the stacked maps (left crops first)
+    const int64_t n = blockIdx.x;              // s * B + b : index into the stacked maps
     const int64_t b = n % B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* o = desc + n * 264 * 145;
-    for (int e = threadIdx.x; e < 264 * 145; e += 256) {
-        const int ch = e / 145, p = e - ch * 145;
-        float v;
-        if (p == 144) {
-            v = rubbish[b * 264 + ch];                                   // second_layer.py:83,85
-        } else if (ch < 8) {
-            v = title[b * 8 + ch];                                       // :82,84
-        } else {
-            const int r = p / 12, c = p - r * 12;                        // positions (k // 12, k % 12)
-            if (ch < 72) {            // map 0: [.,64,48,48], avgpool -> 49x49, index (4r+2, 4c+2)   :73-79
-                const float* m = f0 + (n * 64 + (ch - 8)) * 48 * 48;
-                const int y = 4 * r + 1, x = 4 * c + 1;                  // window rows y..y+1, cols x..x+1
-                v = (((m[y * 48 + x] + m[y * 48 + x + 1]) + m[(y + 1) * 48 + x]) + m[(y + 1) * 48 + x + 1]) / 4.0f;
-            } else if (ch < 136) {    // map 1: [.,64,24,24], avgpool -> 25x25, index (2r+1, 2c+1)
-                const float* m = f1 + (n * 64 + (ch - 72)) * 24 * 24;
-                const int y = 2 * r, x = 2 * c;
-                v = (((m[y * 24 + x] + m[y * 24 + x + 1]) + m[(y + 1) * 24 + x]) + m[(y + 1) * 24 + x + 1]) / 4.0f;
-            } else {                  // map 2: [.,128,12,12], no pooling, index (r, c)
-                v = f2[(n * 128 + (ch - 136)) * 144 + p];
-            }
+    int pt[3], off0[3], off1[3];
+    bool live[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int p = lane + 64 * g;
+        live[g] = p < 145;
+        pt[g] = p < 144 ? p : 0;                               // positions (k // 12, k % 12); the dustbin column reads nothing
+        const int r = pt[g] / 12, c = pt[g] - r * 12;
+        off0[g] = (4 * r + 1) * 48 + 4 * c + 1;                // map 0: avgpool(2,1,1) -> 49x49, sample (4r+2, 4c+2)   :73-79
+        off1[g] = (2 * r) * 24 + 2 * c;                        // map 1: avgpool -> 25x25, sample (2r+1, 2c+1)
+    }
+    const bool dust = lane == 16;                              // group 2 of lane 16 is point 144: the dustbin feature column
+    auto put = [&](int ch, float v0, float v1, float v2) {
+        float* row = o + ch * 145;
+        row[lane] = v0;
+        row[lane + 64] = v1;
+        if (live[2]) row[lane + 128] = dust ? rubbish[b * 264 + ch] : v2;           // second_layer.py:83,85
+    };
+    for (int ch = wave; ch < 8; ch += 4) {                     // the 8-channel "title"                         :82,84
+        const float v = title[b * 8 + ch];
+        put(ch, v, v, v);
+    }
+#pragma unroll 2
+    for (int ch = 8 + wave; ch < 72; ch += 4) {                // map 0: [.,64,48,48]
+        const float* m = f0 + (n * 64 + (ch - 8)) * 48 * 48;
+        float v[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float* q = m + off0[g];
+            v[g] = (((q[0] + q[1]) + q[48]) + q[49]) / 4.0f;
         }
-        o[e] = v;
+        put(ch, v[0], v[1], v[2]);
+    }
+#pragma unroll 2
+    for (int ch = 72 + wave; ch < 136; ch += 4) {              // map 1: [.,64,24,24]
+        const float* m = f1 + (n * 64 + (ch - 72)) * 24 * 24;
+        float v[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float* q = m + off1[g];
+            v[g] = (((q[0] + q[1]) + q[24]) + q[25]) / 4.0f;
+        }
+        put(ch, v[0], v[1], v[2]);
+    }
+#pragma unroll 4
+    for (int ch = 136 + wave; ch < 264; ch += 4) {             // map 2: [.,128,12,12], no pooling, sample (r, c)
+        const float* m = f2 + (n * 128 + (ch - 136)) * 144;
+        put(ch, m[pt[0]], m[pt[1]], m[pt[2]]);
     }
 }
 
@@ -56,7 +84,9 @@ __device__ __forceinline__ long long round_half_even_div(float x, float d) {
     return (long long)rintf(x / d);      // torch.round = round half to even = rintf in the default mode
 }
 
-// one workgroup (256 threads = 4 waves) per point; wave w handles channels w, w+4, ...; lane = window cell
+// one workgroup (256 threads = 4 waves) per point; wave w handles channels 32w .. 32w+31, eight at a time (sixteen
+// window loads in flight, then sixteen stores); lane = window cell.  The dustbin feature column is written once per wave
+// by 32 lanes (one channel each) instead of by lane 0 inside the channel loop.
 __global__ void __launch_bounds__(256)
 third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
                   const float* __restrict__ mk0, const float* __restrict__ mk1,
@@ -98,15 +128,28 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
     const long long bb1 = i1 / (M * M), r1 = i1 - bb1 * (M * M);
     float* o0 = out0 + p * C * 65;
     float* o1 = out1 + p * C * 65;
-    for (int ch = wave; ch < C; ch += 4) {
-        const float ke = kenc[ch * 64 + lane];                                   // + self.kenc(kpts)   :139-140
-        o0[ch * 65 + lane] = ff0[(bb0 * C + ch) * (M * M) + r0] + ke;
-        o1[ch * 65 + lane] = ff1[(bb1 * C + ch) * (M * M) + r1] + ke;
-        if (lane == 0) {
-            const float rb = rubbish[(b * C + ch) * 144 + i2];
-            o0[ch * 65 + 64] = rb;                                               // :145-146
-            o1[ch * 65 + 64] = rb;
+    const float* src0 = ff0 + bb0 * C * (M * M) + r0;
+    const float* src1 = ff1 + bb1 * C * (M * M) + r1;
+#pragma unroll 1
+    for (int c0 = 32 * wave; c0 < 32 * wave + 32; c0 += 8) {
+        float a[8], c[8], ke[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = src0[(int64_t)(c0 + k) * (M * M)];
+            c[k] = src1[(int64_t)(c0 + k) * (M * M)];
+            ke[k] = kenc[(c0 + k) * 64 + lane];                                  // + self.kenc(kpts)   :139-140
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o0[(c0 + k) * 65 + lane] = a[k] + ke[k];
+            o1[(c0 + k) * 65 + lane] = c[k] + ke[k];
+        }
+    }
+    if (lane < 32) {
+        const int ch = 32 * wave + lane;
+        const float rb = rubbish[(b * C + ch) * 144 + i2];
+        o0[ch * 65 + 64] = rb;                                                   // :145-146
+        o1[ch * 65 + 64] = rb;
     }
 }
 

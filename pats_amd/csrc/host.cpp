@@ -27,6 +27,25 @@ int check_launch(const char* what) {
     return PATS_OK;
 }
 
+// 16 bytes per thread; base pointers come from the caller's allocator (>= 16-byte aligned), the tail goes byte by byte
+__global__ void __launch_bounds__(256) fill_bytes_kernel(unsigned char* p, unsigned word, size_t n) {
+    const size_t o = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (o >= n) return;
+    if (o + 16 <= n && ((reinterpret_cast<uintptr_t>(p) + o) & 15) == 0) {
+        *reinterpret_cast<uint4*>(p + o) = make_uint4(word, word, word, word);
+    } else {
+        for (size_t k = o; k < n && k < o + 16; ++k) p[k] = (unsigned char)word;
+    }
+}
+
+int fill_bytes(void* p, int value, size_t n, hipStream_t st) {
+    if (n == 0) return PATS_OK;
+    const unsigned b = (unsigned)value & 0xffu, word = b | (b << 8) | (b << 16) | (b << 24);
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, st,
+                       static_cast<unsigned char*>(p), word, n);
+    return check_launch("fill_bytes_kernel");
+}
+
 static int g_mode = PATS_SINKHORN_AUTO;
 int sinkhorn_mode() { return g_mode; }
 

@@ -429,8 +429,8 @@ extern "C" size_t pats_merge_batch_workspace_bytes(int64_t pairs, int H, int W) 
 extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, int H, int W, int64_t rows_cap,
                                         const int64_t* chunk_base, const int32_t* row_cell, const int32_t* row_slot,
                                         const uint8_t* row_forced, float* trust_score, uint8_t* if_nomatching1_L2,
-                                        double* scores_back, uint8_t* out, void* workspace, size_t workspace_bytes,
-                                        pats_stream_t stream) {
+                                        double* scores_back, int zero_scores_back, uint8_t* out, void* workspace,
+                                        size_t workspace_bytes, pats_stream_t stream) {
     PATS_REQUIRE(Cmax >= 1 && pairs >= 0 && H >= 32 && W >= 32 && rows_cap >= 0, "merge_patches_batch: bad shape");
     if (pairs == 0 || rows_cap == 0) return PATS_OK;
     PATS_REQUIRE(chunk_base && row_cell && row_slot && row_forced && trust_score && if_nomatching1_L2 && scores_back && out,
@@ -443,7 +443,9 @@ extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, 
     const int64_t block_cap = NP < rows_cap ? NP : rows_cap;       // a chunk block holds at most one row per coarse cell
     unsigned* winner = reinterpret_cast<unsigned*>(workspace);
     // rows outside every block (padding past the total) are never visited: "no match"
-    if (hipMemsetAsync(out, 1, (size_t)rows_cap * 144, st) != hipSuccess) return check_launch("merge_batch memset");
+    if (fill_bytes(out, 1, (size_t)rows_cap * 144, st)) return PATS_ERR_LAUNCH;
+    // pats.py:32: every pair starts from a zeroed scores_back
+    if (zero_scores_back && fill_bytes(scores_back, 0, sizeof(double) * (size_t)(NP * 144), st)) return PATS_ERR_LAUNCH;
     for (int c = 0; c < Cmax; ++c) {
         const RowBlock rb{chunk_base + c, 0};
         hipLaunchKernelGGL(merge_prepare_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, merge_new, rb, trust_score,
@@ -452,15 +454,13 @@ extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, 
             hipLaunchKernelGGL(merge_select_new_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, g, rb, row_cell,
                                if_nomatching1_L2, scores_back, row_forced, out);
         } else {
-            if (hipMemsetAsync(winner, 0, sizeof(unsigned) * (size_t)(pairs * g.per), st) != hipSuccess)
-                return check_launch("merge_batch memset");
+            if (fill_bytes(winner, 0, sizeof(unsigned) * (size_t)(pairs * g.per), st)) return PATS_ERR_LAUNCH;
             hipLaunchKernelGGL(merge_scatter_old_kernel, dim3(blocks256((int64_t)g.h4 * g.w4 * pairs)), dim3(256), 0, st, g,
                                (int)pairs, row_slot + (int64_t)c * NP, if_nomatching1_L2, scores_back, winner);
             hipLaunchKernelGGL(merge_finish_old_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, g, rb, row_cell, winner,
                                row_forced, out);
             // merge_patches_old hands back a zeroed scores_back (second_layer.py:191): the next chunk starts from zeros
-            if (hipMemsetAsync(scores_back, 0, sizeof(double) * (size_t)(NP * 144), st) != hipSuccess)
-                return check_launch("merge_batch memset");
+            if (fill_bytes(scores_back, 0, sizeof(double) * (size_t)(NP * 144), st)) return PATS_ERR_LAUNCH;
         }
     }
     return check_launch("merge_patches_batch");

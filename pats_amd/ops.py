@@ -814,8 +814,9 @@ def merge_patches_batch(merge_new, rows, trust_score, original_image_shape, if_n
             H // 32 != rows.h or W // 32 != rows.w:
         raise RuntimeError("merge_patches_batch: tensors must be [rows_cap,144] on the table's grid")
     dev = trust_score.device
-    if scores_back is None:
-        scores_back = torch.zeros((rows.pairs, rows.h * rows.w, 16, 9), dtype=torch.float64, device=dev)
+    fresh = scores_back is None
+    if fresh:
+        scores_back = torch.empty((rows.pairs, rows.h * rows.w, 16, 9), dtype=torch.float64, device=dev)   # cleared by the call
     elif scores_back.dtype != torch.float64 or not scores_back.is_contiguous() or \
             scores_back.numel() != rows.pairs * rows.h * rows.w * 144:
         raise RuntimeError("merge_patches_batch: scores_back must be a contiguous float64 [pairs, N, 16, 9] tensor")
@@ -825,7 +826,7 @@ def merge_patches_batch(merge_new, rows, trust_score, original_image_shape, if_n
     _check(_L().pats_merge_patches_batch(1 if merge_new else 0, rows.Cmax, rows.pairs, H, W, rows.rows_cap,
                                          _ptr(rows.chunk_base), _ptr(rows.row_cell), _ptr(rows.row_slot), _ptr(rows.row_forced),
                                          _ptr(trust_score), _ptr(if_nomatching1_L2.view(torch.uint8)), _ptr(scores_back),
-                                         _ptr(out.view(torch.uint8)), _ptr(ws), nws, _stream()), "merge_patches_batch")
+                                         int(fresh), _ptr(out.view(torch.uint8)), _ptr(ws), nws, _stream()), "merge_patches_batch")
     return out
 
 
@@ -869,6 +870,11 @@ def get_result_chunks(rows, if_nomatching16, pts_new, pts16, scales, patch_size=
                                            _ptr(_ones(rows.rows_cap, dev)), _ptr(ml), _ptr(mr), _ptr(mrow), cap, _ptr(cnt),
                                            _ptr(ws), nws, _stream()), "get_result_chunks")
     return ml, mr, mrow, cnt
+
+
+def profile_marker(tag=0):
+    """An empty, uniquely named kernel on the current stream: brackets a region of a kernel trace."""
+    _check(_L().pats_profile_marker(int(tag), _stream()), "profile_marker")
 
 
 def attention(query, key, value, return_prob=True):

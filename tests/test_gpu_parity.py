@@ -869,7 +869,7 @@ def test_bench_other_workloads(ops, sinkhorn_mode):
     if sinkhorn_mode != "kernel":
         pytest.skip("once is enough")
     sc = _run_bench({}, 1, ["--workload", "scannet"])
-    assert "configs[2]" in sc["config"]["workload"] and "(1 coarse chunks" in sc["config"]["L2"] and sc["matches_per_pair"] > 1000
+    assert "configs[2]" in sc["config"]["workload"] and "at most 1 chunks per pair" in sc["config"]["L2"] and sc["matches_per_pair"] > 1000
     yf = _run_bench({}, 1, ["--workload", "yfcc", "--pairs", "1"])
     assert "769x769" in yf["config"]["L1"] and yf["matches_per_pair"] > 1000 and yf["value"] > 0
 
