@@ -67,9 +67,12 @@ def parse():
                          "shard.my_pairs; every rank walks its share in steps of --pairs (the last one partly filled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run the coarse stage and the fine / third stage of consecutive batches one after the other "
-                         "(default: on two HIP streams, the coarse stage of batch i + 1 beside the rest of batch i)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="three-stage software pipeline over three HIP streams (the HBM-bound gathers of one batch beside the "
+                         "VALU-bound solvers of its neighbours).  Measured SLOWER than one stream on MI355X (30.3 against 26.7 ms per "
+                         "48-pair step: every stage's kernels fill the GPU on their own and time-slice badly), so the default is one "
+                         "stream, stage after stage")
+    ap.add_argument("--no-overlap", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
     return ap.parse_args()
 
 
@@ -116,29 +119,54 @@ class BenchNets:
         self.rubbish = 1.5 * torch.randn((R, 264), device=dev, generator=gen)
         self.sx, self.sy = scale_head((R, 1, 144), dev, gen), scale_head((R, 1, 144), dev, gen)
         self.ns2 = (self.sx * self.sy).contiguous()
-        self.desc = torch.empty((2, R, 264, 145), dtype=torch.float32, device=dev)
+        # outputs of the two gathers, double-buffered: with the stages of consecutive batches on different streams the
+        # gather of batch i + 1 writes while a solver of batch i still reads
+        self.desc = [torch.empty((2, R, 264, 145), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.fine_calls = self.third_calls = 0
+        self.ev = None                       # dict of lists of (start, end) HIP events while the timed steps run
         # third level: the 1/2-resolution maps (padded to 52x52) of both crops, third_layer.py:112-120
         f = correlated_pair((R, 128, 52, 52), dev, gen, chunk=1024)
         self.ff0, self.ff1 = f[0], f[1]
         self.kenc = 0.1 * torch.randn((128, 64), device=dev, generator=gen)
         self.rubbish3 = 1.5 * torch.randn((R, 128, 144), device=dev, generator=gen)
         self.scale3 = scale_head((Pc, 1, 64), dev, gen)
-        self.t0 = torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev)
-        self.t1 = torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev)
+        self.t0 = [torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.t1 = [torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev) for _ in range(2)]
 
     def resident_bytes(self):
-        return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
+        flat = []
+        for v in vars(self).values():
+            flat += v if isinstance(v, list) else [v]
+        return sum(t.numel() * t.element_size() for t in flat if isinstance(t, torch.Tensor))
 
     def coarse(self, lefts, rights):
         return self.d0, self.d1, self.ns, self.alpha
 
+    def _timed(self, tag):
+        if self.ev is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.ev.setdefault(tag, []).append((e0, e1))
+        e0.record()
+        return e1
+
     def fine(self, rows, new_left, new_right):
-        self.ops.fine_descriptors([self.m0, self.m1, self.m2], self.title, self.rubbish, out=self.desc)       # a15
-        return self.desc[0], self.desc[1], self.sx, self.sy, self.ns2
+        desc = self.desc[self.fine_calls & 1]
+        self.fine_calls += 1
+        e = self._timed("fine_desc")
+        self.ops.fine_descriptors([self.m0, self.m1, self.m2], self.title, self.rubbish, out=desc)            # a15
+        if e is not None:
+            e.record()
+        return desc[0], desc[1], self.sx, self.sy, self.ns2
 
     def third(self, rows, mk0, mk1, b_ids, P_dev):
+        k = self.third_calls & 1
+        self.third_calls += 1
+        e = self._timed("third_desc")
         t0, t1, ps, pt = self.ops.third_descriptors(self.ff0, self.ff1, mk0, mk1, b_ids, self.kenc, self.rubbish3,
-                                                    count=P_dev, out=(self.t0, self.t1))                     # a16
+                                                    count=P_dev, out=(self.t0[k], self.t1[k]))               # a16
+        if e is not None:
+            e.record()
         return t0, t1, self.scale3, ps, pt
 
 
@@ -154,43 +182,81 @@ def _tensors(obj):
 
 
 def run_steps(batch, nets, cap, wl, ev, n, streams):
-    """n complete steps (batches).  streams = None: one after the other.  streams = (sA, sB): consecutive batches are
-    independent (pairs are), so the coarse stage of batch i + 1 (one-CU Sinkhorn kernels on a few CUs, HBM-bound crop
-    gathers) runs on sA beside the fine + third stage of batch i (VALU-bound) on sB.  Every batch still goes through
-    every kernel; nothing leaves the function unfinished (the caller's stream waits for both)."""
-    kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
-    if streams is None or n <= 0:
+    """n complete steps (batches).  streams = None: the stages of a batch one after the other on the current stream.
+    streams = (s1, s2, s3): consecutive batches are independent (pairs are), so the step is a three-stage software
+    pipeline over three HIP streams -
+        s1  batch i + 2: coarse level, chunk rows, crops, fine descriptor gather      (HBM-bound)
+        s2  batch i + 1: fine cost + OT, expansion, merges, third-level window gather  (VALU-bound, then HBM-bound)
+        s3  batch i    : third-level cost + OT + Compute_result, scatter, get_result   (VALU-bound)
+    so that the memory-bound gathers of one batch share the GPU with the VALU-bound solvers of its neighbours.  Every
+    batch still goes through every kernel inside the timed region; nothing leaves the function unfinished (the caller's
+    stream waits for all three).  The gather outputs are double-buffered (BenchNets)."""
+    kw = dict(if_outdoor=wl["outdoor"], iters=ITERS)
+    if n <= 0:
+        return None
+    if streams is None:
         out = None
         for _ in range(n):
             co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
-            out = batch.fine_third_stage(co, nets, cap, events=ev, **kw)
+            fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
+            out = batch.third_stage(fs, nets, cap, events=ev, **kw)
         return out
-    sA, sB = streams
+    s1, s2, s3 = streams
     cur = torch.cuda.current_stream()
-    sA.wait_stream(cur)
-    sB.wait_stream(cur)
+    for s_ in streams:
+        s_.wait_stream(cur)
 
-    def coarse():
-        with torch.cuda.stream(sA):
-            c = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
+    def hand_over(obj, to):
+        for t in _tensors(obj):                          # allocated on one stream, read on the next
+            t.record_stream(to)
+
+    def stage1():
+        with torch.cuda.stream(s1):
+            co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
             e = torch.cuda.Event()
-            e.record(sA)
-        return c, e
-    co, done = coarse()
-    out = None
-    for i in range(n):
-        nxt = coarse() if i + 1 < n else None
-        with torch.cuda.stream(sB):
-            sB.wait_event(done)
-            for t in _tensors(co):                       # allocated on sA, read on sB
-                t.record_stream(sB)
-            out = batch.fine_third_stage(co, nets, cap, events=ev, **kw)
-        if nxt is not None:
-            co, done = nxt
-    cur.wait_stream(sA)
-    cur.wait_stream(sB)
-    for t in _tensors(out):                              # allocated on sB, read by the caller
-        t.record_stream(cur)
+            e.record(s1)
+        return co, e
+
+    def stage2(co, e_in):
+        with torch.cuda.stream(s2):
+            s2.wait_event(e_in)
+            hand_over(co, s2)
+            fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
+            e = torch.cuda.Event()
+            e.record(s2)
+        return fs, e
+
+    def stage3(fs, e_in):
+        with torch.cuda.stream(s3):
+            s3.wait_event(e_in)
+            hand_over(fs, s3)
+            o = batch.third_stage(fs, nets, cap, events=ev, **kw)
+            e = torch.cuda.Event()
+            e.record(s3)
+        return o, e
+    # issue order per tick: the oldest batch first, so that each stream's queue never waits on work issued later.
+    # A gather buffer is reused every second batch: stage 1 of batch i + 2 must wait for stage 2 of batch i (fine
+    # descriptors), stage 2 of batch i + 2 for stage 3 of batch i (third-level descriptors).
+    q1, q2, out = [], [], None
+    done2, done3 = [], []
+    for tick in range(n + 2):
+        if q2:
+            fs, e = q2.pop(0)
+            out, e3 = stage3(fs, e)
+            done3.append(e3)
+        if q1:
+            co, e = q1.pop(0)
+            if len(done3) >= 2:
+                s2.wait_event(done3[-2])
+            q2.append(stage2(co, e))
+            done2.append(q2[-1][1])
+        if tick < n:
+            if len(done2) >= 2:
+                s1.wait_event(done2[-2])
+            q1.append(stage1())
+    for s_ in streams:
+        cur.wait_stream(s_)
+    hand_over(out, cur)
     return out
 
 
@@ -457,10 +523,10 @@ def timed(fn, reps=5, warm=2):
     return e0.elapsed_time(e1) / reps
 
 
-def secondary_rooflines(ops, dev, other):
-    """Other kernels of the path against their nearer roofline (live HIP-event timings; rocprof counterparts
-    under profiles/).  Config 5 = BASELINE.json configs[4]."""
-    res = [other]
+def secondary_rooflines(ops, dev):
+    """Kernels of BASELINE.json configs[4] (config 5 of SURVEY 8d) against their nearer roofline (live HIP-event timings;
+    rocprof counterparts under profiles/)."""
+    res = []
     r = synth.roofline_inputs()
     d0, d1, ns = [torch.from_numpy(r[k]).to(dev) for k in ("d0", "d1", "ns")]
     N, D = d0.shape[2], d0.shape[1]
@@ -583,9 +649,10 @@ def main():
     if args.total_pairs > 0:
         steps = (len(shard.my_pairs(args.total_pairs, rank, n_gpus)) + pairs - 1) // pairs
 
-    streams = None if args.no_overlap else (torch.cuda.Stream(), torch.cuda.Stream())
+    streams = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()) if args.overlap else None
     run_steps(batch, nets, cap, wl, None, args.warmup, streams)
     ev = {}
+    nets.ev = ev
     barrier()
     ops.sinkhorn_fallbacks(reset=True)
     ops.profile_marker(1)                                # kernel traces are cut to the steps between the two markers
@@ -594,6 +661,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.profile_marker(2)
+    nets.ev = None
     rank_ms_per_step = 1e3 * dt / max(steps, 1)
     fallbacks = ops.sinkhorn_fallbacks(reset=True)       # after the timed region (it synchronises)
     if dist is not None:
@@ -626,7 +694,7 @@ def main():
         dist.all_gather(tl, torch.tensor([rank_ms_per_step], device=dev, dtype=torch.float64))
         rank_ms = [float(x.item()) for x in tl]
 
-    res = other = None
+    res, other = None, []
     if out is not None:
         P_step = int(out["P"].item())
         rows_step = int(out["rows"].chunk_base[-1].item())
@@ -638,16 +706,23 @@ def main():
         BYTES_PER_PROBLEM = 2 * 128 * 65 * 4 + 64 * 4 + 2 * 2 * 8 + 2 * 16 * 2 * 4 + 16 * 2 * 4 + 16
         t_ach = float(BYTES_PER_PROBLEM * P_step / (third_ms.mean() * 1e-3) / 1e9)
         t_valu = float(2.0 * 2.0 * ITERS * 65 * 65 * P_step / (third_ms.mean() * 1e-3) / 1e12)
-        traffic, traffic_src = None, None
-        for name in ("r03_pmc_third.json", "r02_pmc_third.json"):
-            pmc_path = os.path.join(REPO, "profiles", name)
-            if os.path.exists(pmc_path):
-                pmc = json.load(open(pmc_path))
-                traffic = float(pmc["hbm_bytes_per_problem"]) * P_step
-                traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH calibrated " \
-                              "x%.2f on cost65_kernel's known byte count; per problem x problems per launch" \
-                              % (name, pmc["fetch_calibration"]["factor"])
-                break
+        # HBM traffic per launch from rocprofv3 PMC passes over this same step (tools/pmc_step.sh -> profiles/r03_pmc_step.json:
+        # FETCH_SIZE and WRITE_SIZE in separate runs, calibrated on the cost build's known byte count in the same run)
+        pmc, pmc_src = {}, None
+        pmc_path = os.path.join(REPO, "profiles", "r03_pmc_step.json")
+        if os.path.exists(pmc_path):
+            pj = json.load(open(pmc_path))
+            if int(pj.get("rows_cap", -1)) == cap.rows_cap and args.workload == "megadepth":
+                pmc = pj["kernels"]
+                pmc_src = "profiles/r03_pmc_step.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over bench.py), factors " \
+                          "from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the third-level " \
+                          "kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
+                          % (pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
+
+        def traffic_of(prefix):
+            hit = [v for k, v in pmc.items() if k.startswith(prefix)]
+            return (float(max(hit, key=lambda v: v["hbm_bytes"])["hbm_bytes"]), pmc_src) if hit else (None, None)
+        traffic, traffic_src = traffic_of("pats::third_fused3_kernel")
         third_roof = {"bound": "hbm", "kernel": "third_fused3_kernel (fused third level, %d problems per launch over a capacity of %d)"
                       % (P_step, cap.P_cap), "achieved": t_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS,
                       "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -667,7 +742,33 @@ def main():
                      "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
                      "note": "descriptors in (2 x 264 x 145 fp32), log-plan out (145 x 145 fp32) per problem; the 100 sweeps run on the "
                              "register-resident blocks (VALU-bound)"}
-        dominant, other = (third_roof, fine_roof) if third_ms.mean() >= fine_ms else (fine_roof, third_roof)
+        # the two descriptor gathers (a15 / a16): HBM-bound copies with index arithmetic
+        fd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fine_desc"]]))
+        td_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["third_desc"]]))
+        # a15, algorithmic bytes per stacked image: every sampled input element once (64 ch x 144 points x 4 pooled taps on the
+        # two high-resolution maps, 128 ch x 144 on the third, title + dustbin features) and the [264,145] block out
+        FD_BYTES = (2 * 64 * 144 * 4 + 128 * 144 + 8 + 264) * 4 + 264 * 145 * 4
+        fd_by = float(FD_BYTES) * 2 * cap.rows_cap
+        fd_roof = {"bound": "hbm", "kernel": "fine_desc_kernel (a15: fine descriptor sampling, %d stacked crops)" % (2 * cap.rows_cap),
+                   "achieved": fd_by / (fd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": fd_by / (fd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::fine_desc_kernel")[0],
+                   "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": fd_by,
+                   "algorithmic_bytes_per_image": FD_BYTES, "avg_launch_ms": fd_ms, "launches": int(len(ev["fine_desc"])),
+                   "note": "reads every sampled element of the three backbone maps once and writes the [2,B,264,145] block; the "
+                           "2x2 pooled taps use 8 of every 16 bytes of half of the rows of the 48x48 maps, so the lines touched are "
+                           "about 1.4x the algorithmic bytes"}
+        # a16: two 8x8 windows x 128 channels in, two [128,65] blocks out per point
+        TD_BYTES = 2 * 128 * 64 * 4 + 128 * 4 + 2 * 128 * 65 * 4 + 2 * 2 * 4 + 8 + 2 * 2 * 8
+        td_by = float(TD_BYTES) * P_step
+        td_roof = {"bound": "hbm", "kernel": "third_desc_kernel (a16: third-level window gather, %d points)" % P_step,
+                   "achieved": td_by / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": td_by / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::third_desc_kernel")[0],
+                   "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": td_by,
+                   "algorithmic_bytes_per_point": TD_BYTES, "avg_launch_ms": td_ms, "launches": int(len(ev["third_desc"])),
+                   "note": "a window row is 32 bytes of a 128-byte line of a channel-major 52x52 map: the lines touched are about 4x "
+                           "the algorithmic bytes unless neighbouring points meet in L2 (XCD-aware workgroup order)"}
+        ranked = sorted([third_roof, fine_roof, fd_roof, td_roof], key=lambda r: -r["avg_launch_ms"])
+        dominant, other = ranked[0], ranked[1:]
         sweeps_per_pair = ITERS * (1 + (rows_step + P_step) / float(pairs))
         res = {
             "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",
@@ -679,8 +780,9 @@ def main():
                                            "third-level inputs decided by the merge, result scatter, get_result",
                        "pairs_per_step_per_rank": pairs,
                        "batching": "each stage is one launch over all pairs and chunks of the step (pats_amd.batch); no host read inside a step"
-                                   + ("" if streams is None else "; the coarse stage of batch i + 1 runs on a second HIP stream "
-                                      "beside the fine / third stage of batch i (--no-overlap: one after the other)"),
+                                   + ("" if streams is None else "; three-stage software pipeline over three HIP streams: coarse level + "
+                                      "crops + fine gather of batch i + 2 | fine OT + merges + third gather of batch i + 1 | third OT + "
+                                      "results of batch i (--no-overlap: one after the other)"),
                        "L1": "%d x [448,%d]^2 -> %dx%d (every pair its own descriptors)" % (pairs, h * w, h * w + 1, h * w + 1),
                        "L2": "%d rows x [264,145]^2 -> 145x145 in use per step (%.1f per pair; row capacity %d, at most %d chunks per pair)"
                              % (rows_step, rows_step / float(pairs), cap.rows_cap, cap.Cmax),
@@ -700,13 +802,11 @@ def main():
         if n_gpus > 1:
             res["gather_bytes"] = gather_bytes
         if not args.no_secondary and n_gpus == 1:
-            res["roofline_secondary"] = secondary_rooflines(ops, dev, other)
+            res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
         if not args.no_cpu_baseline and n_gpus == 1:
             # one more step outside the clock, keeping the coarse tensors the parity leg needs
-            co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
-            o2 = batch.fine_third_stage(co, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
-            o2["coarse"] = co
+            o2 = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
             res["cpu_baseline"] = cpu_baseline(ops, batch, dev, nets, cap, wl, o2)
         else:
             res["cpu_baseline"] = None

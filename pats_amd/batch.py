@@ -71,10 +71,11 @@ def _round4(x, clamp96):
     return torch.round(x / 4.0).long() * 4
 
 
-def coarse_stage(lefts, rights, nets, cap, iters=100):
+def coarse_stage(lefts, rights, nets, cap, iters=100, fine_inputs=True):
     """The first layer's tail for all pairs + the chunk plan / row table + the crops (first_layer.py:110-146,
-    utils.py:1343-1393).  Independent of every other batch: a caller may run it on a second stream beside the
-    fine / third stage of the previous batch (bench.py does)."""
+    utils.py:1343-1393) and - fine_inputs=True - the second layer's descriptors for those rows (nets.fine: backbone on the
+    crops + the a15 gather).  Independent of every other batch and HBM-bound (crops, gathers): a caller may run it on a
+    stream of its own beside the solver stages of the previous batches (bench.py does)."""
     H, W = int(lefts.shape[1]), int(lefts.shape[2])
     h, w = cap.h, cap.w
     assert (H // 32, W // 32) == (h, w) and lefts.shape[0] == cap.pairs
@@ -85,27 +86,31 @@ def coarse_stage(lefts, rights, nets, cap, iters=100):
     rows = ops.chunk_rows(ifn1, h, w, cap.chunk_cap, Cmax=cap.Cmax, rows_cap=cap.rows_cap)
     new_left, new_right, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(
         xs, ys, pts, ifn1, lefts, rights, width=w, height=h, known_count="device")
-    return {"rows": rows, "new_left": new_left, "new_right": new_right, "xsn": xsn, "avn": avn, "K_img": K_img,
-            "ifn1": ifn1, "H": H, "W": W}
+    co = {"rows": rows, "new_left": new_left, "new_right": new_right, "xsn": xsn, "avn": avn, "K_img": K_img,
+          "ifn1": ifn1, "H": H, "W": W}
+    if fine_inputs:
+        co["fine"] = nets.fine(rows, new_left, new_right)
+    return co
 
 
-def fine_third_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
-    """second_layer.py:100-122, pats.py:38-78, third_layer.py:153-170 for every row / surviving cell of a coarse_stage
-    result.  events: optional dict; "fine" / "third" receive (start, end) torch.cuda.Event pairs around those launches."""
+def _timed(events, tag):
+    if events is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    events.setdefault(tag, []).append((e0, e1))
+    e0.record()
+    return e1
+
+
+def fine_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
+    """second_layer.py:100-122 + pats.py:38-39,53-58 for every row of a coarse_stage result: cost + OT + expansion, the
+    merges in chunk order, the surviving cells' points, and the third layer's descriptors for them (nets.third: backbone
+    maps + the a16 window gather)."""
     rows, H, W = co["rows"], co["H"], co["W"]
-
-    def timed(tag):
-        if events is None:
-            return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        events.setdefault(tag, []).append((e0, e1))
-        e0.record()
-        return e1
-
-    fine = nets.fine(rows, co["new_left"], co["new_right"])
+    fine = co["fine"] if "fine" in co else nets.fine(rows, co["new_left"], co["new_right"])
     f0, f1, sx, sy = fine[:4]
     ns2 = fine[4] if len(fine) > 4 else (sx * sy).contiguous()
-    e = timed("fine")
+    e = _timed(events, "fine")
     Z2, cflag2 = ops.cost_ot(f0, f1, 2, _one(f0.device), ns2, iters, bias_k=2.0 if if_outdoor else 3.0, return_flags=True)
     if e is not None:
         e.record()
@@ -115,17 +120,32 @@ def fine_third_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, 
     third = nets.third(rows, mk0, mk1, b_ids, P)
     feat0, feat1, scale3 = third[:3]
     p_s, p_t = third[3:5] if len(third) > 3 else (_round4(mk0, False), _round4(mk1, True))
-    e = timed("third")
-    m0f, m1f, label, ifm = ops.third_level(feat0, feat1, scale3, p_s, p_t, outdoor=if_outdoor, iters=iters, count=P)
+    return {"co": co, "merged": merged, "pts2": pts2, "P": P, "feat0": feat0, "feat1": feat1, "scale3": scale3, "p_s": p_s,
+            "p_t": p_t, "stages": {"Z2": Z2, "trust2": trust2, "pts2": pts2, "ifn_L2": ifn_L2, "sx": sx, "sy": sy, "f0": f0,
+                                   "f1": f1, "ns2": ns2, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "feat0": feat0,
+                                   "feat1": feat1, "scale3": scale3, "p_s": p_s, "p_t": p_t}}
+
+
+def third_stage(fs, nets, cap, if_outdoor=True, iters=100, events=None):
+    """third_layer.py:153-170 over the capacity with the count on the device, then pats.py:59-78: the scatter onto the
+    sub-cell grid and get_result for every chunk of every pair."""
+    co, rows, P = fs["co"], fs["co"]["rows"], fs["P"]
+    e = _timed(events, "third")
+    m0f, m1f, label, ifm = ops.third_level(fs["feat0"], fs["feat1"], fs["scale3"], fs["p_s"], fs["p_t"], outdoor=if_outdoor,
+                                           iters=iters, count=P)
     if e is not None:
         e.record()
-    ifn16, pts16 = ops.refine_scatter(merged, pts2, m1f, label)
+    ifn16, pts16 = ops.refine_scatter(fs["merged"], fs["pts2"], m1f, label)
     ml, mr, mrow, M = ops.get_result_chunks(rows, ifn16, co["avn"], pts16, co["xsn"])
+    stages = dict(fs["stages"], m0f=m0f, m1f=m1f, label=label, ifm=ifm, pts16=pts16)
     return {"matches_l": ml, "matches_r": mr, "match_row": mrow, "M": M, "P": P, "status": rows.status, "rows": rows,
-            "if_nomatching16": ifn16, "merged": merged, "K_img": co["K_img"], "crops": (co["new_left"], co["new_right"]),
-            "stages": {"Z2": Z2, "trust2": trust2, "pts2": pts2, "ifn_L2": ifn_L2, "sx": sx, "sy": sy, "f0": f0, "f1": f1,
-                       "ns2": ns2, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "feat0": feat0, "feat1": feat1, "scale3": scale3,
-                       "p_s": p_s, "p_t": p_t, "m0f": m0f, "m1f": m1f, "label": label, "ifm": ifm, "pts16": pts16}}
+            "if_nomatching16": ifn16, "merged": fs["merged"], "K_img": co["K_img"], "crops": (co["new_left"], co["new_right"]),
+            "coarse": co, "stages": stages}
+
+
+def fine_third_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
+    fs = fine_stage(co, nets, cap, if_outdoor, merge_new, iters, events)
+    return third_stage(fs, nets, cap, if_outdoor, iters, events)
 
 
 def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
@@ -136,7 +156,7 @@ def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, ite
         rows                             the ops.ChunkRows table
         stages                           the intermediate tensors (parity checks; nothing reads them here)
     No host read happens in here."""
-    co = coarse_stage(lefts, rights, nets, cap, iters)
+    co = coarse_stage(lefts, rights, nets, cap, iters, fine_inputs=False)
     return fine_third_stage(co, nets, cap, if_outdoor, merge_new, iters, events)
 
 

@@ -95,8 +95,15 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
                   float* __restrict__ out0, float* __restrict__ out1, int64_t* __restrict__ ps_out,
                   int64_t* __restrict__ pt_out, const int64_t* __restrict__ P_dev) {
     constexpr int W = 8, M = 52, C = 128;
-    const int64_t p = blockIdx.x;
-    if (P_dev && p >= *P_dev) return;        // throughput mode: the launch covers the capacity, the count is on the device
+    // throughput mode: the launch covers the capacity, the count is on the device.
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the points of one fine
+    // row - consecutive p - read overlapping windows of the same two maps (neighbouring cells are 2 map pixels apart, a
+    // window row is 32 bytes of a 128-byte line): workgroup k takes point (k % 8) * ceil(P / 8) + k / 8, so that
+    // neighbours in p run on the SAME XCD one after the other and meet in its L2 instead of each fetching its own lines.
+    int64_t live = P;
+    if (P_dev) { const int64_t n = *P_dev; live = n < P ? n : P; }
+    const int64_t per = (live + 7) >> 3, p = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per || p >= live) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = b_ids[p];
     // mkpts0_c = round(mkpts0_c / 4) * 4                                    third_layer.py:124
@@ -177,7 +184,7 @@ extern "C" int pats_third_descriptors_f32(const float* feat_f0, const float* fea
     if (P == 0) return PATS_OK;
     PATS_REQUIRE(feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
                  "third_descriptors: null pointer");
-    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)P), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
+    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)((P + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
                        mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P, B, out0, out1, p_s_out, p_t_out, (const int64_t*)nullptr);
     return check_launch("third_desc_kernel");
 }
@@ -191,7 +198,7 @@ extern "C" int pats_third_descriptors_counted_f32(const float* feat_f0, const fl
     if (P_cap == 0) return PATS_OK;
     PATS_REQUIRE(P_dev && feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
                  "third_descriptors_counted: null pointer");
-    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)P_cap), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
+    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)((P_cap + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
                        mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P_cap, B, out0, out1, p_s_out, p_t_out, P_dev);
     return check_launch("third_desc_kernel");
 }
