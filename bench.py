@@ -647,7 +647,7 @@ def main():
     # walks `pairs` slots; the slots past its share in the last step are real work on synthetic pairs and are not counted)
     steps = args.steps
     if args.total_pairs > 0:
-        steps = (len(shard.my_pairs(args.total_pairs, rank, n_gpus)) + pairs - 1) // pairs
+        steps = shard.steps_for(args.total_pairs, rank, n_gpus, pairs)
 
     streams = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()) if args.overlap else None
     run_steps(batch, nets, cap, wl, None, args.warmup, streams)

@@ -39,6 +39,12 @@ enum {
 enum { PATS_SINKHORN_AUTO = 0, PATS_SINKHORN_LOG = 1, PATS_SINKHORN_KERNEL = 2 };
 
 const char* pats_version(void);
+/* The ABI this header describes.  It is bumped whenever an exported function changes its argument list (round 2 added
+ * `row_nomatch` to pats_iterative_expand_f32 under the same symbol: a caller built against the older header would pass
+ * its stream where the new pointer goes).  A C consumer checks `pats_abi_version() == PATS_ABI_VERSION` once after
+ * loading the library; pats_amd/_lib.py does.  New arguments now come with new entry points instead. */
+#define PATS_ABI_VERSION 3
+int pats_abi_version(void);
 const char* pats_last_error(void);
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
 int pats_device_count(void);
@@ -56,8 +62,9 @@ int pats_sinkhorn_fallbacks(int64_t* count, int reset);
  * replaces  scores = einsum('bdn,bdm->bnm', mdesc0, mdesc1) / D**.5 ; 0.1 * scores
  *           models/first_layer.py:110-111,114  second_layer.py:100-101,104  third_layer.py:156-158
  * d0 [batch,D,n], d1 [batch,D,m] (channel-major), out [batch,n,m].  fp32 in, fp32 out; the contraction splits every
- * operand into an fp16 hi + lo pair (exact products on the fp16 matrix pipe, fp32 accumulation - at least as close to
- * float64 as an fp32 fma chain) and redoes a tile with the fp32 MFMA when an operand exceeds +-1023. */
+ * operand into an fp16 hi + lo pair (exact products on the fp16 matrix pipe, fp32 accumulation: on operands of magnitude
+ * 0.004 .. 1023 at least as close to float64 as an fp32 fma chain; an operand below 0.004 has a subnormal lo half, which the
+ * matrix pipe flushes, and is carried with an absolute error <= 2^-20, i.e. <= 1e-6 |y| per product) and redoes a tile with the fp32 MFMA when an operand exceeds +-1023. */
 int pats_cost_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m, float* out,
                   pats_stream_t stream);
 
@@ -218,6 +225,13 @@ int pats_compute_result_f32(const float* scores, int input_is_log, int64_t P, co
                             const float* scale_y, const int64_t* p_s, const int64_t* p_t,
                             int outdoor, float* mkpts0_f, float* mkpts1_f, float* whole_loss,
                             float* label, uint8_t* if_matching1, pats_stream_t stream);
+/* the same with the 4 bytes of device workspace whole_loss needs (its cross-problem count, :215) handed in by the
+ * caller: no allocation inside the call (pats_compute_result_f32 takes a stream-ordered one), capturable in a HIP graph */
+int pats_compute_result_ws_f32(const float* scores, int input_is_log, int64_t P, const float* scale_x,
+                               const float* scale_y, const int64_t* p_s, const int64_t* p_t,
+                               int outdoor, float* mkpts0_f, float* mkpts1_f, float* whole_loss,
+                               float* label, uint8_t* if_matching1, void* workspace, size_t workspace_bytes,
+                               pats_stream_t stream);
 
 /* ---- a15: fine-level descriptor sampling  models/second_layer.py:71-86 -----------------------
  * feat0 [2B,64,48,48], feat1 [2B,64,24,24], feat2 [2B,128,12,12] (ResNet2.forward2 of the stacked

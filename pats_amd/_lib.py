@@ -17,9 +17,12 @@ if os.environ.get("PATS_AMD_DIAG_LIB", "") not in ("", "0"):
 c_void_p, c_int, c_i64, c_f, c_size = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                        ctypes.c_size_t)
 
+ABI_VERSION = 3      # include/pats_amd.h PATS_ABI_VERSION
+
 # name -> (restype, argtypes); must list every symbol include/pats_amd.h declares
 SIGNATURES = {
     "pats_version": (ctypes.c_char_p, []),
+    "pats_abi_version": (c_int, []),
     "pats_last_error": (ctypes.c_char_p, []),
     "pats_device_count": (c_int, []),
     "pats_set_sinkhorn_mode": (c_int, [c_int]),
@@ -69,6 +72,9 @@ SIGNATURES = {
     "pats_compute_result_f32": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
+    "pats_compute_result_ws_f32": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_size, c_void_p]),
     "pats_fine_descriptors_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "pats_third_descriptors_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -141,6 +147,9 @@ def lib():
             fn = getattr(handle, name)     # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if handle.pats_abi_version() != ABI_VERSION:
+            raise ImportError("pats_amd: %s exports ABI %d, these bindings were written for ABI %d - rebuild the library "
+                              "(python -m pats_amd.build)" % (LIB_PATH, handle.pats_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -504,21 +504,28 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
     const bool two = g.K1 > 0;
     // the tile needs up to the CU's whole 160 KB of LDS as dynamic shared memory: if the runtime will not grant it, the lean
     // tile computes the same bits
-    static const bool ws_lds_ok = [] {
+    // Both the attribute and the CU count belong to a DEVICE: cached per device id (one process may drive several GPUs;
+    // attention.hip sets its attribute on every launch for the same reason), never process-wide.
+    struct PerDevice { int state = 0; int n_cu = 256; };      // state: 0 unknown, 1 granted, -1 refused
+    static PerDevice per_dev[64];
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = 0; }
+    PerDevice& pd = per_dev[dev_id];
+    if (pd.state == 0) {
         const bool ok = hipFuncSetAttribute((const void*)conv_ws_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                         hipFuncSetAttribute((const void*)conv_ws_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                         hipFuncSetAttribute((const void*)conv_ws_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!ok) (void)hipGetLastError();
-        return ok;
-    }();
+        int v = 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) (void)hipGetLastError();
+        pd.n_cu = v > 0 ? v : 256;
+        pd.state = ok ? 1 : -1;
+    }
+    const bool ws_lds_ok = pd.state == 1;
     const bool ws = lean && ws_mode != 0 && ws_lds_ok && ((Kt == 128 && !two) || (Kt == 256 && (!two || g.K0 == 128))) &&
                     g.cols * (int64_t)std::max(g.K0, 1) < (1ll << 31) && (g.cols >= 64 * 4096 || ws_mode == 2);
     if (ws) {
-        static const int n_cu = [] {
-            int dev = 0, v = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-            return v > 0 ? v : 256;
-        }();
+        const int n_cu = pd.n_cu;
         // weights of one 128-row tile (hi | lo planes, K x 512 bytes) + four groups' double-buffered 4 KB stages: 96 KB at
         // K = 128, the CU's whole 160 KB at K = 256
         const size_t lds = (size_t)2 * (Kt / 4) * LR * sizeof(uint2) + (size_t)4 * 2 * 2 * 4 * WS_LC * sizeof(uint2);

@@ -70,7 +70,9 @@ unsigned long long* fallback_counter() {
 
 using namespace pats;
 
-extern "C" const char* pats_version(void) { return "pats_amd 0.1.0 (gfx950)"; }
+extern "C" const char* pats_version(void) { return "pats_amd 0.3.0 (gfx950)"; }
+
+extern "C" int pats_abi_version(void) { return PATS_ABI_VERSION; }
 
 extern "C" const char* pats_last_error(void) { return g_last_error.c_str(); }
 

@@ -41,6 +41,41 @@ whole_loss_finish_kernel(float* __restrict__ wl, int64_t n, const int* __restric
 
 using namespace pats;
 
+static int compute_result_impl(const float* scores, int input_is_log, int64_t P, const float* scale_x, const float* scale_y,
+                               const int64_t* p_s, const int64_t* p_t, int outdoor, float* mkpts0_f, float* mkpts1_f,
+                               float* whole_loss, float* label, uint8_t* if_matching1, int* count, hipStream_t st) {
+    if (whole_loss && fill_bytes(count, 0, sizeof(int), st)) return PATS_ERR_LAUNCH;
+    hipLaunchKernelGGL(compute_result_kernel, dim3((unsigned)ceil_div(P, 4)), dim3(256), 0, st, scores,
+                       input_is_log, P, scale_x, scale_y, p_s, p_t, outdoor,
+                       ComputeResultOut{mkpts0_f, mkpts1_f, whole_loss, label, if_matching1, whole_loss ? count : nullptr});
+    int rc = check_launch("compute_result_kernel");
+    if (whole_loss && rc == PATS_OK) {
+        hipLaunchKernelGGL(whole_loss_finish_kernel, dim3((unsigned)ceil_div(P * 16, 256)), dim3(256),
+                           0, st, whole_loss, P * 16, count);
+        rc = check_launch("whole_loss_finish_kernel");
+    }
+    return rc;
+}
+
+// whole_loss needs one cross-problem count (:215).  This entry takes it from the caller (4 bytes of device workspace):
+// no allocation, no synchronisation, safe inside a HIP graph capture.
+extern "C" int pats_compute_result_ws_f32(const float* scores, int input_is_log, int64_t P,
+                                          const float* scale_x, const float* scale_y,
+                                          const int64_t* p_s, const int64_t* p_t, int outdoor,
+                                          float* mkpts0_f, float* mkpts1_f, float* whole_loss,
+                                          float* label, uint8_t* if_matching1, void* workspace, size_t workspace_bytes,
+                                          pats_stream_t stream) {
+    PATS_REQUIRE(P >= 0, "compute_result: bad shape");
+    if (P == 0) return PATS_OK;
+    PATS_REQUIRE(scores && scale_x && scale_y && p_s && p_t && mkpts0_f && mkpts1_f && label &&
+                     if_matching1, "compute_result: null pointer");
+    PATS_REQUIRE(!whole_loss || (workspace && workspace_bytes >= sizeof(int)), "compute_result: whole_loss needs 4 bytes of workspace");
+    return compute_result_impl(scores, input_is_log, P, scale_x, scale_y, p_s, p_t, outdoor, mkpts0_f, mkpts1_f, whole_loss, label,
+                               if_matching1, static_cast<int*>(workspace), as_stream(stream));
+}
+
+// The round-1 signature, kept for callers built against it: without a workspace argument the count is a 4-byte
+// stream-ordered allocation owned by the call (hipMallocAsync / hipFreeAsync on `stream`; not capturable).
 extern "C" int pats_compute_result_f32(const float* scores, int input_is_log, int64_t P,
                                        const float* scale_x, const float* scale_y,
                                        const int64_t* p_s, const int64_t* p_t, int outdoor,
@@ -51,25 +86,13 @@ extern "C" int pats_compute_result_f32(const float* scores, int input_is_log, in
     PATS_REQUIRE(scores && scale_x && scale_y && p_s && p_t && mkpts0_f && mkpts1_f && label &&
                      if_matching1, "compute_result: null pointer");
     hipStream_t st = as_stream(stream);
-    // whole_loss needs one cross-problem count (:215): a 4-byte stream-ordered allocation owned
-    // by this call (no device synchronisation).
     int* count = nullptr;
-    if (whole_loss) {
-        if (hipMallocAsync((void**)&count, sizeof(int), st) != hipSuccess) {
-            set_error("compute_result: hipMallocAsync failed");
-            return PATS_ERR_LAUNCH;
-        }
-        (void)hipMemsetAsync(count, 0, sizeof(int), st);                 // failure surfaces in check_launch
+    if (whole_loss && hipMallocAsync((void**)&count, sizeof(int), st) != hipSuccess) {
+        set_error("compute_result: hipMallocAsync failed");
+        return PATS_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(compute_result_kernel, dim3((unsigned)ceil_div(P, 4)), dim3(256), 0, st, scores,
-                       input_is_log, P, scale_x, scale_y, p_s, p_t, outdoor,
-                       ComputeResultOut{mkpts0_f, mkpts1_f, whole_loss, label, if_matching1, count});
-    int rc = check_launch("compute_result_kernel");
-    if (whole_loss && rc == PATS_OK) {
-        hipLaunchKernelGGL(whole_loss_finish_kernel, dim3((unsigned)ceil_div(P * 16, 256)), dim3(256),
-                           0, st, whole_loss, P * 16, count);
-        rc = check_launch("whole_loss_finish_kernel");
-    }
+    const int rc = compute_result_impl(scores, input_is_log, P, scale_x, scale_y, p_s, p_t, outdoor, mkpts0_f, mkpts1_f, whole_loss,
+                                       label, if_matching1, count, st);
     if (count) (void)hipFreeAsync(count, st);
     return rc;
 }

@@ -424,6 +424,8 @@ def Compute_imgs_ex(x_scale, y_scale, average_point, if_nomatching, left, right,
     on_device = isinstance(known_count, str) and known_count == "device"
     counts = None
     if known_count is not None and not on_device:
+        if isinstance(known_count, torch.Tensor):
+            known_count = known_count.tolist()          # a (GPU) tensor of counts: one host read, like int(tensor)
         counts = [int(k) for k in np.atleast_1d(np.asarray(known_count)).ravel()]
         if len(counts) != nb:
             raise RuntimeError("Compute_imgs: known_count needs one entry per image")
@@ -492,9 +494,10 @@ def Compute_result(scores, W, T, scale_x, scale_y, p_s, p_t, device=None, outdoo
     wl = torch.empty((P, 16), dtype=torch.float32, device=dev)
     label = torch.empty((P * 16, 2), dtype=torch.float32, device=dev)
     ifm = torch.empty((P, 16), dtype=torch.uint8, device=dev)
-    _check(_L().pats_compute_result_f32(_ptr(S), int(bool(input_is_log)), P, _ptr(sx), _ptr(sy), _ptr(ps),
-                                        _ptr(pt), int(bool(outdoor)), _ptr(m0), _ptr(m1), _ptr(wl),
-                                        _ptr(label), _ptr(ifm), _stream()), "Compute_result")
+    ws = torch.empty((1,), dtype=torch.int32, device=dev)          # whole_loss' cross-problem count: no allocation in the call
+    _check(_L().pats_compute_result_ws_f32(_ptr(S), int(bool(input_is_log)), P, _ptr(sx), _ptr(sy), _ptr(ps),
+                                           _ptr(pt), int(bool(outdoor)), _ptr(m0), _ptr(m1), _ptr(wl),
+                                           _ptr(label), _ptr(ifm), _ptr(ws), 4, _stream()), "Compute_result")
     return m0, m1, wl, label, ifm.bool()
 
 
@@ -982,11 +985,13 @@ def _pad8(t, dim):
     return torch.cat([t, t.new_zeros(shape)], dim=dim).contiguous()
 
 
-def conv1d(x, weight, bias=None, in_scale=None, in_shift=None, residual=None):
+def conv1d(x, weight, bias=None, in_scale=None, in_shift=None, residual=None, weight_t=None):
     """nn.Conv1d(kernel_size=1) as the path uses it (final_proj: first_layer.py:34-36,105, second_layer.py:40-42,91;
     the layers of MLP, modules.py:57-69): x [b,K,n], weight [M,K,1] or [M,K] (the module's own layout), bias [M] or
     None -> [b,M,n].  in_scale / in_shift [K]: x is max(0, x * scale + shift) while it is staged - the BatchNorm1d + ReLU
-    of the previous MLP layer, folded.  residual [b,M,n] is added to the result."""
+    of the previous MLP layer, folded.  residual [b,M,n] is added to the result.
+    weight_t: the weight already in the C-ABI's layout ([K8][M]: transposed, input channels zero-padded to a multiple of
+    8 - MLPParams keeps it), so that no transpose / pad kernel runs per call."""
     x = _dev(x, "x")
     weight = _dev(weight, "weight")
     b, K, n = x.shape
@@ -994,7 +999,12 @@ def conv1d(x, weight, bias=None, in_scale=None, in_shift=None, residual=None):
     M = w2.shape[0]
     if w2.shape[1] != K:
         raise RuntimeError("conv1d: weight %s does not take %d input channels" % (tuple(weight.shape), K))
-    w_t = _pad8(w2.t().contiguous(), 0)                 # [K][M], zero rows for the padding channels
+    if weight_t is not None:
+        w_t = _dev(weight_t, "weight_t")
+        if tuple(w_t.shape) != (K + (-K) % 8, M):
+            raise RuntimeError("conv1d: weight_t must be [%d,%d]" % (K + (-K) % 8, M))
+    else:
+        w_t = _pad8(w2.t().contiguous(), 0)             # [K][M], zero rows for the padding channels
     xp = _pad8(x, 1)
     sc = sh = None
     if in_scale is not None:
@@ -1050,7 +1060,9 @@ class MLPParams:
         convs = [i for i in idx if get("%d.weight" % i).dim() == 3]
         self.layers = []
         for li, i in enumerate(convs):
-            layer = {"weight": get("%d.weight" % i), "bias": get("%d.bias" % i), "bn": None}
+            wgt = get("%d.weight" % i)
+            layer = {"weight": wgt, "bias": get("%d.bias" % i), "bn": None,
+                     "weight_t": _pad8(wgt.reshape(wgt.shape[0], -1).t().contiguous(), 0)}       # once, not per call
             if li + 1 < len(convs) and (prefix + "%d.running_var" % (i + 1)) in state:        # do_bn, not after the last Conv1d
                 g, bta = get("%d.weight" % (i + 1)), get("%d.bias" % (i + 1))
                 rm, rv = get("%d.running_mean" % (i + 1)), get("%d.running_var" % (i + 1))
@@ -1066,7 +1078,7 @@ def mlp(x, params, bn_train=False):
     sc = sh = None
     h = _dev(x, "x")
     for i, layer in enumerate(params.layers):
-        h = conv1d(h, layer["weight"], layer["bias"], sc, sh)
+        h = conv1d(h, layer["weight"], layer["bias"], sc, sh, weight_t=layer.get("weight_t"))
         if i + 1 < len(params.layers):
             bn = layer["bn"]
             if bn is None:

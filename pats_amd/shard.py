@@ -26,6 +26,13 @@ def my_pairs(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
+def steps_for(n_pairs, rank, world, pairs_per_step):
+    """Strong scaling (BASELINE configs[3]: 4 000 YFCC pairs over 1 / 2 / 4 / 8 ranks): the number of steps of
+    `pairs_per_step` pairs rank `rank` needs for its share, the last one partly filled; 0 for a rank that owns no pair."""
+    mine = len(my_pairs(n_pairs, rank, world))
+    return (mine + pairs_per_step - 1) // pairs_per_step
+
+
 def collective_device(group=None):
     """The device collectives of `group` must be fed from: the current HIP device under nccl/RCCL
     (also for a rank that owns no pairs and so has no tensor to take a device from), else the CPU."""

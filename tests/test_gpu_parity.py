@@ -999,6 +999,38 @@ def test_attentional_gnn_and_edge_shapes(ops, oracle):
         ops.attentional_propagation(cu(i["x"]), cu(i["source"][:, :100]), ops.PropagationParams(p))
 
 
+def test_gnn_ten_layers_with_small_magnitude_weights(ops, oracle):
+    """The fp16-split contraction carries an operand below 0.004 with a flushed lo half (absolute error <= 2^-20): trained
+    Conv1d weights and post-ReLU activations live there.  Ten third-level layers (self / cross alternating, BatchNorm on
+    batch statistics like PATS.eval leaves the third layer) with weights of std 1e-3 .. 3e-2 against the oracle, which
+    accumulates every dot product in double: the error stays at the 1e-5 level of the descriptors' unit scale and does not
+    compound over the layers (the residual path carries the descriptors; the deltas are what the split touches)."""
+    rng = np.random.default_rng(77)
+    C, b, n = 128, 6, 65
+    layers = []
+    for k in range(10):
+        p = synth.gnn_params(seed=200 + k, C=C)
+        scale = (1e-3, 3e-3, 1e-2, 3e-2)[k % 4] * np.sqrt(C)      # gnn_params draws U(-1/sqrt(fan_in), +): rescale to a std
+        for name in list(p):
+            if name.endswith("weight") and p[name].ndim == 3:
+                p[name] = (p[name] * scale).astype(np.float32)
+        layers.append(p)
+    names = ["self", "cross"] * 5
+    x0 = rng.standard_normal((b, C, n)).astype(np.float32)
+    x1 = rng.standard_normal((b, C, n)).astype(np.float32)
+    g0, g1 = ops.attentional_gnn(cu(x0), cu(x1), [ops.PropagationParams(p) for p in layers], names, bn_train=True)
+    w0, w1 = x0, x1
+    for p, name in zip(layers, names):
+        s0, s1 = (w1, w0) if name == "cross" else (w0, w1)
+        n0 = oracle.attentional_propagation(w0, s0, p, bn_train=True, residual=w0)
+        n1 = oracle.attentional_propagation(w1, s1, p, bn_train=True, residual=w1)
+        w0, w1 = n0, n1
+    err = max(np.abs(g0.cpu().numpy() - w0).max(), np.abs(g1.cpu().numpy() - w1).max())
+    moved = np.abs(w0 - x0).max()
+    print("ten layers, small weights: max |error| = %.2e on descriptors of scale 1 (the layers moved them by up to %.2e)" % (err, moved))
+    assert moved > 1e-3 and err <= 2e-5
+
+
 # ---- the descriptor heads: KeypointEncoder (modules.py:70-82) and final_proj (first_layer.py:34-36,105) ----------------
 @pytest.mark.parametrize("tag,dim,h,w,seed", [("third", 128, 8, 8, synth.SEED + 100), ("first", 448, 15, 20, synth.SEED + 101)])
 def test_keypoint_encoder_golden(ops, oracle, tag, dim, h, w, seed):

@@ -45,21 +45,38 @@ def _worker(rank, world, port, n_pairs, dst, batch_rows, q):
 
 
 # n_pairs = 1: rank 1 owns nothing (the empty-rank case); batch_rows = 5: several bounded rounds
-@pytest.mark.parametrize("n_pairs,dst,batch_rows", [(1, 0, 1 << 20), (7, 0, 5), (8, None, 1 << 20), (7, 1, 3), (1, None, 2)])
-def test_two_rank_shard_and_gather(n_pairs, dst, batch_rows):
-    world, port = 2, _free_port()
+# world 8 (one node of MI355X): 4 001 pairs = configs[3]'s 4 000 + 1 (ranks own 501 / 500: the remainder), and 5 pairs
+# (ranks 5..7 own nothing and must still take part in every collective)
+@pytest.mark.parametrize("world,n_pairs,dst,batch_rows", [(2, 1, 0, 1 << 20), (2, 7, 0, 5), (2, 8, None, 1 << 20), (2, 7, 1, 3),
+                                                         (2, 1, None, 2), (8, 4001, 0, 1 << 20), (8, 5, 0, 4), (8, 13, None, 3)])
+def test_shard_and_gather(world, n_pairs, dst, batch_rows):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, dst, batch_rows, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     owned = sorted(i for _, mine, _ in res for i in mine)
     assert owned == list(range(n_pairs))              # every pair exactly once
     assert all(ok for _, _, ok in res)                # the receiver(s) see all matches, in pair order
+
+
+def test_strong_scaling_split_of_4000_and_4001_pairs():
+    """bench.py --total-pairs: every pair belongs to exactly one rank, shares differ by at most one, and the step counts
+    cover them (the last step partly filled); a rank without pairs runs no step."""
+    for total in (4000, 4001, 5):
+        for world in (1, 2, 4, 8):
+            shares = [shard.my_pairs(total, r, world) for r in range(world)]
+            assert sorted(i for s_ in shares for i in s_) == list(range(total))
+            assert max(map(len, shares)) - min(map(len, shares)) <= 1
+            for r in range(world):
+                st = shard.steps_for(total, r, world, 16)
+                assert (st - 1) * 16 < len(shares[r]) <= st * 16 if shares[r] else st == 0
+    assert shard.steps_for(4001, 0, 8, 16) == 32 and shard.steps_for(4001, 1, 8, 16) == 32 and shard.steps_for(5, 7, 8, 16) == 0
 
 
 def test_single_process_gather_needs_no_group():
