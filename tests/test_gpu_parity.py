@@ -1373,6 +1373,38 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
             one = gnn.layers[0].eval()(d0, d1)
             assert "models.modules.KeypointEncoder.forward" in touched
             got_kenc_eval, got_kenc_train = kenc.eval()(kpts), kenc.train()(kpts)
+            # the parameter caches follow the weights (round-2 advice): a checkpoint loaded AFTER the first forward, an
+            # in-place optimizer-style update and a running-statistics change are all picked up
+            gnn.eval()
+            original = {k: v.clone() for k, v in gnn.state_dict().items()}
+            other = AttentionalGNN(128, ["self", "cross", "self"]).cuda().eval()
+            for layer in other.layers:
+                layer.mlp[1].running_mean.normal_(0, 0.3)
+                layer.mlp[1].running_var.uniform_(0.5, 2.0)
+            gnn.load_state_dict(other.state_dict())
+            after_load = gnn(d0, d1)
+            gnn.layers[1].attn.merge.weight.mul_(1.5)
+            after_step = gnn(d0, d1)
+        dropin.uninstall()
+        with torch.no_grad():
+            want_load = other(d0, d1)
+            other.layers[1].attn.merge.weight.mul_(1.5)
+            want_step = other(d0, d1)
+        for a, b in ((after_load, want_load), (after_step, want_step)):
+            assert torch.allclose(a[0], b[0], atol=2e-4, rtol=2e-4) and torch.allclose(a[1], b[1], atol=2e-4, rtol=2e-4)
+        assert not torch.allclose(after_load[0], got_eval[0], atol=1e-3) and not torch.allclose(after_step[0], after_load[0], atol=1e-4)
+        assert not hasattr(gnn.layers[0], "_pats_params")                # uninstall() dropped the caches
+        # with autograd on and parameters that require grad the reference's own forward runs (the HIP path is inference only)
+        dropin.install()
+        gnn.train()
+        x0 = d0.clone().requires_grad_(True)
+        y0, _ = gnn(x0, d1)
+        y0.sum().backward()
+        assert x0.grad is not None and gnn.layers[0].attn.merge.weight.grad is not None
+        gnn.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            gnn.load_state_dict(original)                                # back to the compared weights for the checks below
+        gnn.layers[0].eval()
         dropin.uninstall()
         assert torch.allclose(got_kenc_eval, kenc_eval, atol=5e-5, rtol=2e-4) and torch.allclose(got_kenc_train, kenc_train, atol=5e-5, rtol=2e-4)
         with torch.no_grad():
