@@ -100,9 +100,9 @@ class BenchNets:
     level, its dustbin features, and one scale-head row per third-level problem slot.  Inside the step the callbacks only
     run the path's own gathers (a15: ops.fine_descriptors, a16: ops.third_descriptors); GNN + final_proj = identity."""
 
-    def __init__(self, ops, dev, gen, cap, h, w):
-        self.ops, self.cap = ops, cap
-        pairs, N, R, Pc = cap.pairs, h * w, cap.rows_cap, cap.P_cap
+    def __init__(self, ops, dev, gen, cap, h, w, batch=None):
+        self.ops = ops
+        pairs, N = cap.pairs, h * w
         c = correlated_pair((pairs, 448, N), dev, gen)
         self.d0, self.d1 = c[0].contiguous(), c[1].contiguous()
         gone = torch.rand((pairs, 1, N), device=dev, generator=gen) < 0.03         # a few coarse cells without a partner
@@ -111,6 +111,14 @@ class BenchNets:
         self.alpha = torch.tensor(0.0, device=dev)
         img = torch.randint(0, 256, (2, pairs, 32 * h, 32 * w, 3), device=dev, generator=gen).float()
         self.lefts, self.rights = img[0].contiguous(), (0.5 * img[1] + 0.5 * torch.roll(img[1], 1, dims=2)).contiguous()
+        # capacity planning, outside the timed region (the one host read of the set-up): a dry run of the coarse stage tells
+        # how many rows the fine level's table holds for THESE pairs; the row capacity becomes that + 1 % (a batch that
+        # outgrew it would raise when its matches are fetched) instead of the worst case N + (Cmax - 1) w per pair
+        if batch is not None:
+            total = int(batch.coarse_stage(self.lefts, self.rights, self, cap, ITERS, fine_inputs="rows_only")["rows"].chunk_base[-1].item())
+            cap.rows_cap = min(cap.rows_cap, (int(total * 1.01) + 63) // 64 * 64)
+        self.cap = cap
+        R, Pc = cap.rows_cap, cap.P_cap
         # fine level: ResNet2.forward2 maps of the stacked (left | right) crops, second_layer.py:69-70
         self.m0 = correlated_pair((R, 64, 48, 48), dev, gen).reshape(2 * R, 64, 48, 48)
         self.m1 = correlated_pair((R, 64, 24, 24), dev, gen).reshape(2 * R, 64, 24, 24)
@@ -635,7 +643,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(synth.SEED + rank)
     cap = batch.Capacities(pairs, h, w, if_local=if_local)
-    nets = BenchNets(ops, dev, gen, cap, h, w)
+    nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch)
     n_gpus = dist.get_world_size() if dist is not None else 1
 
     def barrier():

@@ -42,12 +42,15 @@ class Capacities:
     8-px cell to at most one window per chunk, so 16*h*w cells is the natural size (cells handed over between chunks can
     add a few; the default keeps 25 % headroom; an overflow is reported in the result, never silent)."""
 
-    def __init__(self, pairs, h, w, if_local=True, p_cap_per_pair=None):
+    def __init__(self, pairs, h, w, if_local=True, p_cap_per_pair=None, rows_cap=None):
         self.pairs, self.h, self.w = int(pairs), int(h), int(w)
         self.N = self.h * self.w
         self.chunk_cap = 2 * self.w if if_local else 512                      # first_layer.py:131-135
         self.Cmax = ops.max_chunks(self.h, self.w, self.chunk_cap)
-        self.rows_cap = self.pairs * (self.N + (self.Cmax - 1) * self.w)
+        # worst case: every cell matched, every chunk boundary repeats one grid row.  A caller that knows its data (a dry
+        # run of the coarse stage) may pass a tighter rows_cap: the fine level then runs fewer padding rows, and a batch
+        # that does not fit is reported through `status` (split_by_pair raises), never truncated silently.
+        self.rows_cap = self.pairs * (self.N + (self.Cmax - 1) * self.w) if rows_cap is None else int(rows_cap)
         per_pair = int(1.25 * 16 * self.N) if p_cap_per_pair is None else int(p_cap_per_pair)
         self.P_cap = self.pairs * per_pair
 
@@ -72,7 +75,8 @@ def _round4(x, clamp96):
 
 
 def coarse_stage(lefts, rights, nets, cap, iters=100, fine_inputs=True):
-    """The first layer's tail for all pairs + the chunk plan / row table + the crops (first_layer.py:110-146,
+    """(fine_inputs="rows_only": stop after the row table - capacity planning.)
+    The first layer's tail for all pairs + the chunk plan / row table + the crops (first_layer.py:110-146,
     utils.py:1343-1393) and - fine_inputs=True - the second layer's descriptors for those rows (nets.fine: backbone on the
     crops + the a15 gather).  Independent of every other batch and HBM-bound (crops, gathers): a caller may run it on a
     stream of its own beside the solver stages of the previous batches (bench.py does)."""
@@ -84,6 +88,8 @@ def coarse_stage(lefts, rights, nets, cap, iters=100, fine_inputs=True):
     scales, cflag = ops.colmass_sqrt(Z, return_flags=True)
     trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(Z, scales, (H, W), 32, col_nomatch=cflag)
     rows = ops.chunk_rows(ifn1, h, w, cap.chunk_cap, Cmax=cap.Cmax, rows_cap=cap.rows_cap)
+    if fine_inputs == "rows_only":
+        return {"rows": rows, "ifn1": ifn1}
     new_left, new_right, xsn, ysn, avn, bound5, K_img, K_tot = ops.Compute_imgs_ex(
         xs, ys, pts, ifn1, lefts, rights, width=w, height=h, known_count="device")
     co = {"rows": rows, "new_left": new_left, "new_right": new_right, "xsn": xsn, "avn": avn, "K_img": K_img,

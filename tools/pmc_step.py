@@ -3,7 +3,7 @@
 WRITE_SIZE in separate passes, no trace domains beside them; FETCH_SIZE calibrated on a kernel of known byte count in
 the same run, because other access widths than 16 B / lane are uncalibrated on gfx950).
 
-usage: pmc_step.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <rows_cap> > profiles/r03_pmc_step.json
+usage: pmc_step.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> [rows_cap] > profiles/r03_pmc_step.json
 Both passes ran `bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline` (tools/pmc_step.sh)."""
 import collections
 import csv
@@ -28,7 +28,9 @@ def load(d, counter):
 def main():
     fetch, nf = load(sys.argv[1], "FETCH_SIZE")
     write, _ = load(sys.argv[2], "WRITE_SIZE")
-    rows_cap = int(sys.argv[3])
+    # the fine level's cost build is the cost_mfma_kernel launch with the largest grid: one 256-thread workgroup per row
+    grids = [k[1] for k in fetch if k[0].startswith("pats::cost_mfma_kernel")]
+    rows_cap = max(grids) // 256 if grids else int(sys.argv[3])
     # rocprofv3 reports both counters in KB
     KB = 1024.0
     # calibrator: the fine-level cost build reads exactly 2 x 264 x 145 fp32 per problem (8-byte lane loads, coalesced)
