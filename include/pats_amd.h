@@ -389,7 +389,8 @@ int pats_get_result_chunks_f32(int Cmax, int64_t pairs, const uint8_t* masks, co
  * keys, out = prob v.  query [batch,dim,heads,n], key / value [batch,dim,heads,m] (the view
  * modules.py:101-102 makes of the projections) -> out [batch,dim,heads,n]; prob [batch,heads,n,m] is
  * written only if non-null (the reference returns it, its caller discards it).  fp32 throughout; the
- * score matrix stays in LDS.  m <= 1024 (PATS_ERR_UNSUPPORTED beyond). */
+ * score matrix stays in LDS (32 query rows per workgroup up to m = 1024, 16 / 8 / 4 rows beyond; m <= 8416, PATS_ERR_UNSUPPORTED
+ * past that). */
 int pats_attention_f32(const float* query, const float* key, const float* value, int64_t batch, int dim,
                        int heads, int n, int m, float* out, float* prob, pats_stream_t stream);
 
@@ -404,7 +405,7 @@ int pats_attention_f32(const float* query, const float* key, const float* value,
  * bn_b are gamma / beta and the batch statistics over (batch, n) are computed here with bn_eps (PATS.eval leaves the
  * third layer in train mode, models/pats.py:112-120).  The 1x1 convolutions use the contraction of pats_cost_f32 (the
  * cat is never materialised), the
- * attention core is pats_attention_f32.  C % heads == 0, C % 8 == 0, m <= 1024. */
+ * attention core is pats_attention_f32.  C % heads == 0, C % 8 == 0, m <= 8416. */
 typedef struct pats_propagation_weights {
     const float *wq_t, *bq;   /* attn.proj[0]: [C][C] transposed, [C] */
     const float *wk_t, *bk;   /* attn.proj[1] */

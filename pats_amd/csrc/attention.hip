@@ -19,7 +19,7 @@
 //      from the slab; the [channel][query] result tile stores 128-byte lines.
 // The n x m score matrix never reaches HBM (the stock path writes and re-reads it three times).
 // Tokens on this path: 65 / 145 / 300 (768 at YFCC size) per side, dim = 32 / 66 / 112, 4 heads;
-// m <= 1024 (the slab must fit the CU's 160 KB of LDS).
+// the [rows][m] slab must fit the CU's 160 KB of LDS: 32 query rows per workgroup up to m = 1024, 16 / 8 / 4 beyond (m <= 8416).
 #include "cost65_device.hpp"
 
 namespace pats {
@@ -31,6 +31,7 @@ constexpr int VST = 33;                   // stride of the private V tile
 struct AttnArgs {
     const float* q; const float* k; const float* v;
     int dim, heads, n, m, mp;             // mp: slab stride (odd, >= 32 * ceil(m / 32))
+    int rows;                             // query rows per workgroup: 32, or 16 / 8 / 4 when m is too large for a 32-row slab
     float sq, rsq;                        // dim**.5 and its reciprocal
     float* out; float* prob;
 };
@@ -38,12 +39,15 @@ struct AttnArgs {
 
 __global__ void __launch_bounds__(256)
 attention_kernel(AttnArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float slab[];          // [AR][mp], then 4 x [32][VST]
+    extern __shared__ __attribute__((aligned(16))) float slab[];          // [rows][mp], then 4 x [32][VST]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
-    const int slabs = (g.n + AR - 1) / AR;
+    // beyond 1024 keys a 32-row slab no longer fits the CU's LDS: the workgroup then takes 16 / 8 / 4 query rows (the MFMA
+    // tiles stay 32 wide, their unused rows carry zeros and are neither stored nor read back)
+    const int R = g.rows;
+    const int slabs = (g.n + R - 1) / R;
     const int64_t bh = blockIdx.x / slabs;
-    const int i0 = (int)(blockIdx.x - bh * slabs) * AR;
+    const int i0 = (int)(blockIdx.x - bh * slabs) * R;
     const int64_t bi = bh / g.heads;
     const int h = (int)(bh - bi * g.heads);
     const int64_t rsn = (int64_t)g.heads * g.n, rsm = (int64_t)g.heads * g.m;      // channel strides
@@ -51,10 +55,10 @@ attention_kernel(AttnArgs g) {
     const float* K = g.k + (bi * g.dim * g.heads + h) * (int64_t)g.m;
     const float* V = g.v + (bi * g.dim * g.heads + h) * (int64_t)g.m;
     const int mt = (g.m + 31) / 32;
-    float* vt = slab + AR * g.mp + wave * (32 * VST);
+    float* vt = slab + R * g.mp + wave * (32 * VST);
 
     // ---- 1. scores -------------------------------------------------------------------------------
-    const bool qv = i0 + li < g.n;
+    const bool qv = li < R && i0 + li < g.n;
     const float* qp = Q + (qv ? i0 + li : 0);
     for (int tj = wave; tj < mt; tj += 4) {
         const bool kv = 32 * tj + li < g.m;
@@ -79,13 +83,13 @@ attention_kernel(AttnArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            slab[row * g.mp + 32 * tj + li] = div_invariant(acc[r], g.sq, g.rsq);      // `/ dim**.5`
+            if (row < R) slab[row * g.mp + 32 * tj + li] = div_invariant(acc[r], g.sq, g.rsq);      // `/ dim**.5`
         }
     }
     __syncthreads();
 
     // ---- 2. softmax over the keys, one wave per row ------------------------------------------------
-    for (int row = wave; row < AR; row += 4) {
+    for (int row = wave; row < R; row += 4) {
         float* s = slab + row * g.mp;
         if (i0 + row >= g.n) {                              // rows past the end: zero probabilities
             for (int j = lane; j < 32 * mt; j += 64) s[j] = 0.f;
@@ -135,7 +139,7 @@ attention_kernel(AttnArgs g) {
 #pragma unroll 4
             for (int jj = 0; jj < 32; jj += 2) {
                 const float a = vt[li * VST + jj + lk];                      // A[d = li][k = jj + lk]
-                const float b = slab[li * g.mp + j0 + jj + lk];              // B[k][i = li] = P[i][j]
+                const float b = li < R ? slab[li * g.mp + j0 + jj + lk] : 0.f;   // B[k][i = li] = P[i][j]
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile consumed before the next chunk overwrites it
@@ -145,7 +149,7 @@ attention_kernel(AttnArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = 32 * td + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (d < g.dim && i < g.n) O[(int64_t)d * rsn + i] = acc[r];
+            if (d < g.dim && li < R && i < g.n) O[(int64_t)d * rsn + i] = acc[r];
         }
     }
 }
@@ -285,23 +289,30 @@ extern "C" int pats_attention_f32(const float* query, const float* key, const fl
     static const bool general_only = getenv("PATS_ATTN_GENERAL") != nullptr;     // A/B switch for benchmarking
     if (n == 65 && m == 65 && dim == 32 && !prob && !general_only) {            // the third-level shape
         PATS_REQUIRE(batch * heads < (1ll << 31), "attention: grid too large (split the batch)");
-        AttnArgs g{query, key, value, dim, heads, n, m, 0, sq0, 1.0f / sq0, out, nullptr};
+        AttnArgs g{query, key, value, dim, heads, n, m, 0, 32, sq0, 1.0f / sq0, out, nullptr};
         hipLaunchKernelGGL(attention65_kernel, dim3((unsigned)(batch * heads)), dim3(64), 0, as_stream(stream), g);
         return check_launch("attention65_kernel");
     }
     const int mt = (m + 31) / 32, mp = 32 * mt + 1;
-    const size_t lds = (size_t)(AR * mp + 4 * 32 * VST) * sizeof(float);
+    // query rows per workgroup: 32 while the [rows][m] score slab fits the CU's LDS (m <= 1024), then 16 / 8 / 4
+    // (m <= 2 080 / 4 192 / 8 416: the reference's demo runs 1 900 tokens, demo.py:36)
+    int rows = AR;
+    size_t lds = (size_t)(rows * mp + 4 * 32 * VST) * sizeof(float);
+    while (lds > 152 * 1024 && rows > 4) {
+        rows >>= 1;
+        lds = (size_t)(rows * mp + 4 * 32 * VST) * sizeof(float);
+    }
     if (lds > 152 * 1024) {
-        set_error("attention: m=%d keys exceed the LDS slab (m <= 1024)", m);
+        set_error("attention: m=%d keys exceed the LDS slab even at 4 query rows per workgroup (m <= 8416)", m);
         return PATS_ERR_UNSUPPORTED;
     }
-    const int64_t blocks = batch * heads * ((n + AR - 1) / AR);
+    const int64_t blocks = batch * heads * ((n + rows - 1) / rows);
     PATS_REQUIRE(blocks < (1ll << 31), "attention: grid too large (split the batch)");
     if (lds > 64 * 1024 &&      // per-device attribute: set whenever needed (cheap), never cached process-wide
         hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return check_launch("attention (LDS opt-in)");
     const float sq = (float)sqrt((double)dim);
-    AttnArgs g{query, key, value, dim, heads, n, m, mp, sq, 1.0f / sq, out, prob};
+    AttnArgs g{query, key, value, dim, heads, n, m, mp, rows, sq, 1.0f / sq, out, prob};
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), g);
     return check_launch("attention_kernel");
 }

@@ -648,6 +648,10 @@ def test_attention_shapes_against_oracle(ops, oracle):
     third-level batch size, and the properties rows-sum-to-1 / convex combination of the values."""
     for seed, kw in enumerate([dict(b=2, dim=7, heads=3, n=1, m=1), dict(b=1, dim=5, heads=1, n=33, m=2),
                                dict(b=2, dim=32, heads=4, n=64, m=96, amp=4.0), dict(b=1, dim=128, heads=2, n=200, m=640), dict(b=1, dim=112, heads=4, n=769, m=769), dict(b=1, dim=8, heads=1, n=40, m=1024),
+                               # beyond 1 024 keys the workgroup takes 16 / 8 / 4 query rows: the reference's demo size (1 900 tokens,
+                               # demo.py:36, dim 112 x 4 heads), a ragged 16-row case and an 8-row one
+                               dict(b=1, dim=112, heads=4, n=1901, m=1901), dict(b=2, dim=24, heads=2, n=37, m=1100),
+                               dict(b=1, dim=16, heads=1, n=19, m=4100),
                                dict(b=300, dim=32, heads=4, n=65)]):
         inp = synth.attention_inputs(seed=500 + seed, **kw)
         x, prob = ops.attention(cu(inp["q"]), cu(inp["k"]), cu(inp["v"]))
@@ -663,9 +667,9 @@ def test_attention_shapes_against_oracle(ops, oracle):
     e, _ = ops.attention(torch.zeros((0, 32, 4, 65), device="cuda"), torch.zeros((0, 32, 4, 65), device="cuda"),
                          torch.zeros((0, 32, 4, 65), device="cuda"))
     assert e.shape == (0, 32, 4, 65)
-    with pytest.raises(RuntimeError):
-        ops.attention(torch.zeros((1, 8, 2, 4), device="cuda"), torch.zeros((1, 8, 2, 1100), device="cuda"),
-                      torch.zeros((1, 8, 2, 1100), device="cuda"))
+    with pytest.raises(RuntimeError):          # even four query rows of 9 000 keys do not fit the LDS slab
+        ops.attention(torch.zeros((1, 8, 2, 4), device="cuda"), torch.zeros((1, 8, 2, 9000), device="cuda"),
+                      torch.zeros((1, 8, 2, 9000), device="cuda"))
 
 
 # ---- the whole path chained: pats_amd.pipeline.forward_path vs the reference's functions in its own order ----
