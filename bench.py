@@ -67,11 +67,12 @@ def parse():
                          "shard.my_pairs; every rank walks its share in steps of --pairs (the last one partly filled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
-    ap.add_argument("--overlap", action="store_true",
-                    help="three-stage software pipeline over three HIP streams (the HBM-bound gathers of one batch beside the "
-                         "VALU-bound solvers of its neighbours).  Measured SLOWER than one stream on MI355X (30.3 against 26.7 ms per "
-                         "48-pair step: every stage's kernels fill the GPU on their own and time-slice badly), so the default is one "
-                         "stream, stage after stage")
+    ap.add_argument("--overlap", type=int, default=0, metavar="K",
+                    help="K > 0: two HIP streams with disjoint compute-unit masks - the HBM-bound stages (crops, descriptor gathers) of "
+                         "one batch on K of every 8 CUs of each shader engine, the VALU-bound solver stages of its neighbour on the other "
+                         "8 - K (ops.masked_stream).  0 = one stream, stage after stage.  (Plain, unmasked streams were measured SLOWER than "
+                         "one stream: 30.3 against 26.7 ms per 48-pair step - every kernel of the path fills all CUs' registers on its own, "
+                         "so they only time-slice)")
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
     return ap.parse_args()
 
@@ -191,14 +192,14 @@ def _tensors(obj):
 
 def run_steps(batch, nets, cap, wl, ev, n, streams):
     """n complete steps (batches).  streams = None: the stages of a batch one after the other on the current stream.
-    streams = (s1, s2, s3): consecutive batches are independent (pairs are), so the step is a three-stage software
-    pipeline over three HIP streams -
-        s1  batch i + 2: coarse level, chunk rows, crops, fine descriptor gather      (HBM-bound)
-        s2  batch i + 1: fine cost + OT, expansion, merges, third-level window gather  (VALU-bound, then HBM-bound)
-        s3  batch i    : third-level cost + OT + Compute_result, scatter, get_result   (VALU-bound)
-    so that the memory-bound gathers of one batch share the GPU with the VALU-bound solvers of its neighbours.  Every
-    batch still goes through every kernel inside the timed region; nothing leaves the function unfinished (the caller's
-    stream waits for all three).  The gather outputs are double-buffered (BenchNets)."""
+    streams = (sG, sS): two HIP streams with DISJOINT compute-unit masks (ops.masked_stream) -
+        sG  the HBM-bound stages: coarse level + chunk rows + crops + fine descriptor gather of batch i, third-level window
+            gather of batch i - 1
+        sS  the VALU-bound stages: fine cost + OT + expansion + merges of batch i, third-level OT + results of batch i - 1
+    Consecutive batches are independent (pairs are), so the memory-bound gathers of one batch run beside the solvers of its
+    neighbour on different CUs (plain streams only time-slice: every kernel of the path fills all CUs' registers on its own).
+    Every batch still goes through every kernel inside the timed region; nothing leaves the function unfinished (the
+    caller's stream waits for both).  The gather outputs are double-buffered (BenchNets)."""
     kw = dict(if_outdoor=wl["outdoor"], iters=ITERS)
     if n <= 0:
         return None
@@ -209,61 +210,49 @@ def run_steps(batch, nets, cap, wl, ev, n, streams):
             fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
             out = batch.third_stage(fs, nets, cap, events=ev, **kw)
         return out
-    s1, s2, s3 = streams
+    sG, sS = streams
     cur = torch.cuda.current_stream()
-    for s_ in streams:
-        s_.wait_stream(cur)
+    sG.wait_stream(cur)
+    sS.wait_stream(cur)
 
     def hand_over(obj, to):
-        for t in _tensors(obj):                          # allocated on one stream, read on the next
+        for t in _tensors(obj):                          # allocated on one stream, read on the other
             t.record_stream(to)
 
-    def stage1():
-        with torch.cuda.stream(s1):
-            co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
-            e = torch.cuda.Event()
-            e.record(s1)
-        return co, e
-
-    def stage2(co, e_in):
-        with torch.cuda.stream(s2):
-            s2.wait_event(e_in)
-            hand_over(co, s2)
-            fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
-            e = torch.cuda.Event()
-            e.record(s2)
-        return fs, e
-
-    def stage3(fs, e_in):
-        with torch.cuda.stream(s3):
-            s3.wait_event(e_in)
-            hand_over(fs, s3)
-            o = batch.third_stage(fs, nets, cap, events=ev, **kw)
-            e = torch.cuda.Event()
-            e.record(s3)
-        return o, e
-    # issue order per tick: the oldest batch first, so that each stream's queue never waits on work issued later.
-    # A gather buffer is reused every second batch: stage 1 of batch i + 2 must wait for stage 2 of batch i (fine
-    # descriptors), stage 2 of batch i + 2 for stage 3 of batch i (third-level descriptors).
-    q1, q2, out = [], [], None
-    done2, done3 = [], []
-    for tick in range(n + 2):
-        if q2:
-            fs, e = q2.pop(0)
-            out, e3 = stage3(fs, e)
-            done3.append(e3)
-        if q1:
-            co, e = q1.pop(0)
-            if len(done3) >= 2:
-                s2.wait_event(done3[-2])
-            q2.append(stage2(co, e))
-            done2.append(q2[-1][1])
-        if tick < n:
-            if len(done2) >= 2:
-                s1.wait_event(done2[-2])
-            q1.append(stage1())
-    for s_ in streams:
-        cur.wait_stream(s_)
+    def mark(stream):
+        e = torch.cuda.Event()
+        e.record(stream)
+        return e
+    co, fs, eC, eFS, eG, eT, out = {}, {}, {}, {}, {}, {}, None
+    for i in range(n + 1):
+        j = i - 1
+        with torch.cuda.stream(sG):
+            if i < n:                                    # (the fine-descriptor buffer of batch i - 2 is free: sG already waited
+                co[i] = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)    # for eFS[i - 2] one tick ago)
+                eC[i] = mark(sG)
+            if 0 <= j < n:
+                sG.wait_event(eFS[j])                    # the points of batch j exist
+                if j - 2 in eT:
+                    sG.wait_event(eT[j - 2])             # the third-level descriptor buffer of batch j - 2 has been read
+                hand_over(fs[j], sG)
+                batch.third_gather_stage(fs[j], nets, cap)
+                eG[j] = mark(sG)
+        with torch.cuda.stream(sS):
+            if i < n:
+                sS.wait_event(eC[i])
+                hand_over(co[i], sS)
+                fs[i] = batch.fine_solve_stage(co[i], nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
+                eFS[i] = mark(sS)
+            if 0 <= j < n:
+                sS.wait_event(eG[j])
+                hand_over(fs[j], sS)
+                out = batch.third_stage(fs[j], nets, cap, events=ev, **kw)
+                eT[j] = mark(sS)
+                co.pop(j, None)
+                if j - 1 in fs:
+                    fs.pop(j - 1)
+    cur.wait_stream(sG)
+    cur.wait_stream(sS)
     hand_over(out, cur)
     return out
 
@@ -657,7 +646,13 @@ def main():
     if args.total_pairs > 0:
         steps = shard.steps_for(args.total_pairs, rank, n_gpus, pairs)
 
-    streams = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()) if args.overlap else None
+    streams = None
+    if args.overlap > 0:
+        # mask bit c <-> shader engine c % 32, CU c / 32 of that engine (measured, tools/cu_mask_probe*.py: a VALU-bound kernel
+        # slows down by the engine with the fewest enabled CUs; a mask that empties an engine is ignored by the runtime)
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        k = min(max(args.overlap, 1), 7)
+        streams = (ops.masked_stream([c for c in range(n_cu) if c // 32 < k]), ops.masked_stream([c for c in range(n_cu) if c // 32 >= k]))
     run_steps(batch, nets, cap, wl, None, args.warmup, streams)
     ev = {}
     nets.ev = ev
@@ -788,9 +783,9 @@ def main():
                                            "third-level inputs decided by the merge, result scatter, get_result",
                        "pairs_per_step_per_rank": pairs,
                        "batching": "each stage is one launch over all pairs and chunks of the step (pats_amd.batch); no host read inside a step"
-                                   + ("" if streams is None else "; three-stage software pipeline over three HIP streams: coarse level + "
-                                      "crops + fine gather of batch i + 2 | fine OT + merges + third gather of batch i + 1 | third OT + "
-                                      "results of batch i (--no-overlap: one after the other)"),
+                                   + ("" if streams is None else "; two HIP streams with disjoint CU masks (%d / %d of every 8 CUs per shader engine): "
+                                      "the gathers + crops + coarse level of batch i beside the fine and third-level solvers of batches i, i - 1"
+                                      % (min(max(args.overlap, 1), 7), 8 - min(max(args.overlap, 1), 7))),
                        "L1": "%d x [448,%d]^2 -> %dx%d (every pair its own descriptors)" % (pairs, h * w, h * w + 1, h * w + 1),
                        "L2": "%d rows x [264,145]^2 -> 145x145 in use per step (%.1f per pair; row capacity %d, at most %d chunks per pair)"
                              % (rows_step, rows_step / float(pairs), cap.rows_cap, cap.Cmax),
@@ -812,6 +807,22 @@ def main():
         if not args.no_secondary and n_gpus == 1:
             res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
+            if streams is None:
+                # the same steps with the HBM-bound and the VALU-bound stages of neighbouring batches on two HIP streams with
+                # disjoint CU masks (3 / 5 of every 8 CUs per shader engine; --overlap 3): a secondary number, the bench line and
+                # its rooflines stay on one stream where every kernel has the whole GPU
+                try:
+                    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                    ms_ = (ops.masked_stream([c for c in range(n_cu) if c // 32 < 3]), ops.masked_stream([c for c in range(n_cu) if c // 32 >= 3]))
+                    run_steps(batch, nets, cap, wl, None, 2, ms_)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    run_steps(batch, nets, cap, wl, None, 6, ms_)
+                    torch.cuda.synchronize()
+                    res["overlap_cu_masked"] = {"pairs_per_s": 6 * pairs / (time.perf_counter() - t0), "gather_stream_cus": 96, "solver_stream_cus": 160,
+                                                "note": "bench.py --overlap 3; profiles/r03_cu_mask_probe.txt"}
+                except RuntimeError as err:
+                    res["overlap_cu_masked"] = {"error": str(err)[:200]}
         if not args.no_cpu_baseline and n_gpus == 1:
             # one more step outside the clock, keeping the coarse tensors the parity leg needs
             o2 = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)

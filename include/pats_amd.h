@@ -305,6 +305,13 @@ int pats_chunk_rows_device(const uint8_t* if_nomatching1, int64_t pairs, int hei
                            uint8_t* row_forced, int32_t* row_crop, int32_t* row_slot, int32_t* status, void* workspace,
                            size_t workspace_bytes, pats_stream_t stream);
 
+/* Scheduling aid, no reference counterpart: a HIP stream restricted to the compute units set in cu_mask (bit i of word
+ * i / 32 = CU i; `words` 32-bit words - 8 for the 256 CUs of an MI355X).  The throughput path runs its HBM-bound stages
+ * (crops, descriptor gathers) and its VALU-bound stages (the three solvers) of consecutive batches on two such streams with
+ * disjoint masks (bench.py --overlap); wrap the handle with torch.cuda.ExternalStream to use it from PyTorch. */
+int pats_stream_create_cu_mask(const uint32_t* cu_mask, int words, pats_stream_t* stream);
+int pats_stream_destroy(pats_stream_t stream);
+
 /* Profiling aid, no reference counterpart: launches an empty kernel named pats::profile_marker_kernel on `stream`, so that
  * a kernel trace can be cut to the region between two markers (bench.py brackets its timed steps with it). */
 int pats_profile_marker(int tag, pats_stream_t stream);

@@ -90,6 +90,8 @@ SIGNATURES = {
     "pats_chunk_rows_device": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_int, c_i64] + [c_void_p] * 13 +
                                [c_size, c_void_p]),
     "pats_profile_marker": (c_int, [c_int, c_void_p]),
+    "pats_stream_create_cu_mask": (c_int, [c_void_p, c_int, c_void_p]),
+    "pats_stream_destroy": (c_int, [c_void_p]),
     "pats_merge_batch_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "pats_merge_patches_batch": (c_int, [c_int, c_int, c_i64, c_int, c_int, c_i64] + [c_void_p] * 7 + [c_int, c_void_p, c_void_p,
                                          c_size, c_void_p]),

@@ -108,10 +108,9 @@ def _timed(events, tag):
     return e1
 
 
-def fine_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
+def fine_solve_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
     """second_layer.py:100-122 + pats.py:38-39,53-58 for every row of a coarse_stage result: cost + OT + expansion, the
-    merges in chunk order, the surviving cells' points, and the third layer's descriptors for them (nets.third: backbone
-    maps + the a16 window gather)."""
+    merges in chunk order, the surviving cells' points (VALU-bound)."""
     rows, H, W = co["rows"], co["H"], co["W"]
     fine = co["fine"] if "fine" in co else nets.fine(rows, co["new_left"], co["new_right"])
     f0, f1, sx, sy = fine[:4]
@@ -123,13 +122,24 @@ def fine_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events
     trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
     merged = ops.merge_patches_batch(merge_new, rows, trust2, (H, W), ifn_L2)
     mk0, mk1, b_ids, P = ops.third_inputs(merged, pts2, capacity=cap.P_cap, sync=False)
-    third = nets.third(rows, mk0, mk1, b_ids, P)
+    return {"co": co, "merged": merged, "pts2": pts2, "P": P, "mk0": mk0, "mk1": mk1, "b_ids": b_ids,
+            "stages": {"Z2": Z2, "trust2": trust2, "pts2": pts2, "ifn_L2": ifn_L2, "sx": sx, "sy": sy, "f0": f0,
+                       "f1": f1, "ns2": ns2, "mk0": mk0, "mk1": mk1, "b_ids": b_ids}}
+
+
+def third_gather_stage(fs, nets, cap):
+    """The third layer's descriptors for the surviving cells (nets.third: backbone maps + the a16 window gather;
+    HBM-bound).  Completes a fine_solve_stage result in place."""
+    third = nets.third(fs["co"]["rows"], fs["mk0"], fs["mk1"], fs["b_ids"], fs["P"])
     feat0, feat1, scale3 = third[:3]
-    p_s, p_t = third[3:5] if len(third) > 3 else (_round4(mk0, False), _round4(mk1, True))
-    return {"co": co, "merged": merged, "pts2": pts2, "P": P, "feat0": feat0, "feat1": feat1, "scale3": scale3, "p_s": p_s,
-            "p_t": p_t, "stages": {"Z2": Z2, "trust2": trust2, "pts2": pts2, "ifn_L2": ifn_L2, "sx": sx, "sy": sy, "f0": f0,
-                                   "f1": f1, "ns2": ns2, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "feat0": feat0,
-                                   "feat1": feat1, "scale3": scale3, "p_s": p_s, "p_t": p_t}}
+    p_s, p_t = third[3:5] if len(third) > 3 else (_round4(fs["mk0"], False), _round4(fs["mk1"], True))
+    fs.update(feat0=feat0, feat1=feat1, scale3=scale3, p_s=p_s, p_t=p_t)
+    fs["stages"].update(feat0=feat0, feat1=feat1, scale3=scale3, p_s=p_s, p_t=p_t)
+    return fs
+
+
+def fine_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, events=None):
+    return third_gather_stage(fine_solve_stage(co, nets, cap, if_outdoor, merge_new, iters, events), nets, cap)
 
 
 def third_stage(fs, nets, cap, if_outdoor=True, iters=100, events=None):

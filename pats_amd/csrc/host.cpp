@@ -74,6 +74,23 @@ extern "C" const char* pats_version(void) { return "pats_amd 0.3.0 (gfx950)"; }
 
 extern "C" int pats_abi_version(void) { return PATS_ABI_VERSION; }
 
+// A HIP stream whose kernels may only run on the compute units set in `cu_mask` (bit i of word i / 32 = CU i).
+// MI355X has 256 CUs; the HBM-bound stages of the path (crop and descriptor gathers) saturate the memory system from a
+// fraction of them, the VALU-bound solvers want the rest: two masked streams let consecutive batches share the GPU
+// SPATIALLY, where plain streams only time-slice (every kernel of the path fills all CUs' registers on its own).
+extern "C" int pats_stream_create_cu_mask(const uint32_t* cu_mask, int words, pats_stream_t* stream) {
+    PATS_REQUIRE(cu_mask && words > 0 && stream, "stream_create_cu_mask: bad argument");
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask) != hipSuccess) return check_launch("hipExtStreamCreateWithCUMask");
+    *stream = reinterpret_cast<pats_stream_t>(st);
+    return PATS_OK;
+}
+
+extern "C" int pats_stream_destroy(pats_stream_t stream) {
+    if (stream && hipStreamDestroy(as_stream(stream)) != hipSuccess) return check_launch("hipStreamDestroy");
+    return PATS_OK;
+}
+
 extern "C" const char* pats_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int pats_device_count(void) {

@@ -875,6 +875,22 @@ def get_result_chunks(rows, if_nomatching16, pts_new, pts16, scales, patch_size=
     return ml, mr, mrow, cnt
 
 
+def masked_stream(cus):
+    """A torch stream (torch.cuda.ExternalStream over a HIP stream of this library) whose kernels may only run on the
+    compute units listed in `cus` (indices 0..255 on MI355X) - see pats_stream_create_cu_mask.  The stream lives as long as
+    the process (it is not destroyed: torch may still hold references to it)."""
+    n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for c in cus:
+        if not 0 <= int(c) < n_cu:
+            raise RuntimeError("masked_stream: CU %d outside 0..%d" % (c, n_cu - 1))
+        mask[int(c) // 32] |= 1 << (int(c) % 32)
+    handle = ctypes.c_void_p()
+    _check(_L().pats_stream_create_cu_mask(mask, words, ctypes.byref(handle)), "masked_stream")
+    return torch.cuda.ExternalStream(handle.value)
+
+
 def profile_marker(tag=0):
     """An empty, uniquely named kernel on the current stream: brackets a region of a kernel trace."""
     _check(_L().pats_profile_marker(int(tag), _stream()), "profile_marker")
