@@ -130,3 +130,61 @@ def test_capacity_overflow_is_reported_not_silent():
     assert int(out["P"].item()) > cap.P_cap
     with pytest.raises(RuntimeError, match="P_cap"):
         batch.split_by_pair(out, cap)
+
+
+def test_row_table_against_the_host_planner_on_random_grids():
+    """ops.chunk_rows (csrc/batch.hip) against a numpy restatement built on the HOST planner ops.split_patches (itself held
+    to the reference's golden plans): cumulative counts, plans, chunk masks (first_layer.py:137-138), the rows in (chunk,
+    pair, cell) order, the tail rows of pats.py:38-39, crop indices - on random grids, chunk caps and match densities,
+    including pairs without a match and fully matched ones."""
+    from pats_amd import ops
+    rng = np.random.default_rng(404)
+    for trial in range(40):
+        h, w = int(rng.integers(2, 25)), int(rng.integers(2, 33))
+        N = h * w
+        cap = int(rng.choice([2 * w, 512, max(2, w // 2), 7]))
+        pairs = int(rng.integers(1, 6))
+        dens = rng.choice([0.0, 0.05, 0.5, 0.9, 1.0], size=pairs)
+        ifn1 = np.stack([rng.random(N) >= d for d in dens])                 # True = no match
+        Cmax = ops.max_chunks(h, w, cap)
+        rows = ops.chunk_rows(cu(ifn1), h, w, cap)
+        assert rows.Cmax == Cmax and int(rows.status.item()) == 0
+        sc = np.cumsum(~ifn1, axis=1).astype(np.int32)
+        assert np.array_equal(rows.sum_cycle.cpu().numpy(), sc)
+        want_cell, want_forced, want_crop, base = [], [], [], [0]
+        masks = np.ones((Cmax, pairs, N), bool)
+        plans = [ops.split_patches(sc[p], h, w, cap) for p in range(pairs)]
+        crop_base = np.concatenate([[0], np.cumsum(sc[:, -1])])
+        for c in range(Cmax):
+            for p in range(pairs):
+                n, second, third = plans[p]
+                if c >= n:
+                    continue
+                lo, hi = second[c]
+                m = ifn1[p] | (sc[p] <= lo) | (sc[p] > hi)
+                masks[c, p] = m
+                cells = np.nonzero(~m)[0]
+                tail = third[c][1]
+                for rank, q in enumerate(cells):
+                    want_cell.append(p * N + q)
+                    want_forced.append(bool(rank >= len(cells) - tail) if tail > 0 else (bool(rank >= -tail) if tail < 0 else False))
+                    want_crop.append(crop_base[p] + sc[p, q] - 1)
+            base.append(len(want_cell))
+        total = len(want_cell)
+        assert rows.chunk_base.cpu().numpy().tolist() == base, (trial, h, w, cap)
+        assert np.array_equal(rows.masks.cpu().numpy(), masks)
+        assert np.array_equal(rows.row_cell.cpu().numpy()[:total], np.array(want_cell, np.int32).reshape(-1))
+        assert np.array_equal(rows.row_forced.cpu().numpy()[:total].astype(bool), np.array(want_forced, bool).reshape(-1))
+        assert np.array_equal(rows.row_crop.cpu().numpy()[:total], np.array(want_crop, np.int32).reshape(-1))
+        assert (rows.row_cell.cpu().numpy()[total:] == -1).all() and (rows.row_forced.cpu().numpy()[total:] == 1).all()
+        for p in range(pairs):
+            n, second, third = plans[p]
+            assert int(rows.cycle_num[p].item()) == n
+            assert rows.second[p, :n].cpu().numpy().tolist() == [list(x) for x in second]
+            assert rows.third[p, :n].cpu().numpy().tolist() == [list(x) for x in third]
+    # capacities that do not hold the batch are reported, not silently truncated
+    ifn1 = np.zeros((2, 300), bool)
+    small = ops.chunk_rows(cu(ifn1), 15, 20, 40, rows_cap=100)
+    assert int(small.status.item()) & 2
+    few = ops.chunk_rows(cu(ifn1), 15, 20, 40, Cmax=2)
+    assert int(few.status.item()) & 1
