@@ -188,3 +188,62 @@ def test_row_table_against_the_host_planner_on_random_grids():
     assert int(small.status.item()) & 2
     few = ops.chunk_rows(cu(ifn1), 15, 20, 40, Cmax=2)
     assert int(few.status.item()) & 1
+
+
+@pytest.mark.parametrize("new", [True, False])
+def test_batched_merge_and_result_against_the_single_chunk_ops(new):
+    """ops.merge_patches_batch / ops.get_result_chunks on random trust scores and flags against the per-chunk ops the
+    reference's loop would call (ops.merge_patches_new / _old chunk after chunk with the scores_back hand-over and the
+    pats.py:38-39 tail rows; ops.get_result with the expanded (chunk, pair) batch): bit-identical."""
+    from pats_amd import ops
+    rng = np.random.default_rng(99 + int(new))
+    pairs, h, w, cap = 3, 6, 7, 14
+    N, H, W = h * w, 32 * h, 32 * w
+    ifn1 = np.stack([rng.random(N) >= d for d in (0.9, 0.5, 0.97)])
+    rows = ops.chunk_rows(cu(ifn1), h, w, cap)
+    total = int(rows.chunk_base[-1].item())
+    R = rows.rows_cap
+    trust = (rng.random((R, 144)) * 1.2).astype(np.float32)
+    ifn2 = rng.random((R, 144)) < 0.3
+    t_b, f_b = cu(trust.copy()), cu(ifn2.copy())
+    merged = ops.merge_patches_batch(new, rows, t_b, (H, W), f_b)
+    # the reference's order: per pair, chunk after chunk
+    cell = rows.row_cell.cpu().numpy()
+    base = rows.chunk_base.cpu().numpy()
+    masks = rows.masks.cpu().numpy()
+    third = rows.third.cpu().numpy()
+    want = np.ones((R, 144), bool)
+    merge = ops.merge_patches_new if new else ops.merge_patches_old
+    for p in range(pairs):
+        sb = torch.zeros((1, N, 16, 9), dtype=torch.float64, device="cuda")
+        for c in range(rows.Cmax):
+            idx = np.nonzero(cell[base[c]:base[c + 1]] // N == p)[0] + int(base[c])
+            if len(idx) == 0:
+                continue
+            out, sb = merge(len(idx), cu(trust[idx].copy()), (H, W), cu(masks[c, p:p + 1]), cu(ifn2[idx].copy()), sb)
+            out = out.cpu().numpy()
+            tail = int(third[p, c, 1])
+            if tail != 0:
+                out[-tail:, :] = True
+            want[idx] = out
+    assert np.array_equal(merged.cpu().numpy(), want)
+    assert merged[total:].all()
+    # get_result for all chunks in one call against the expanded batch
+    f16 = rng.random((R, 2304)) < 0.7
+    f16[total:] = True
+    pts16 = (rng.random((R, 2304, 2)) * 96).astype(np.float32)
+    avn = (rng.random((pairs, N, 2)) * 600).astype(np.float32)
+    xsn = (0.2 + rng.random((pairs, N, 2))).astype(np.float32)
+    ml, mr, mrow, M = ops.get_result_chunks(rows, cu(f16), cu(avn), cu(pts16), cu(xsn))
+    C = rows.Cmax
+    masks_flat = cu(masks.reshape(C * pairs, N))
+    av_c = cu(np.tile(avn, (C, 1, 1)))
+    xs_c = cu(np.tile(xsn, (C, 1, 1)))
+    sc_rows = xs_c.reshape(-1, 2)[torch.nonzero(~masks_flat.reshape(-1)).flatten()]
+    wl, wr = ops.get_result(C * pairs, [masks_flat, cu(f16[:total])], [av_c.flip(dims=[2]) / 32.0, cu(pts16[:total]).flip(dims=[2]) / 2.0],
+                            [xs_c, sc_rows], [[32, h, w], [2, 48, 48]],
+                            [torch.ones(C * pairs, dtype=torch.bool, device="cuda"), torch.ones(total, dtype=torch.bool, device="cuda")])
+    m = int(M.item())
+    assert m == wl.shape[0] > 1000
+    assert torch.equal(ml[:m], wl) and torch.equal(mr[:m], wr)
+    assert bool((mrow[:m] >= 0).all()) and bool((mrow[:m] < total).all())
