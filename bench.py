@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="strong-scaling mode (configs[3]: 4000 YFCC pairs): this many pairs in all, split over the ranks by "
                          "shard.my_pairs; every rank walks its share in steps of --pairs (the last one partly filled)")
+    ap.add_argument("--maps", choices=["nhwc", "nchw"], default="nhwc",
+                    help="memory order of the synthetic backbone maps the two descriptor gathers read: torch.channels_last "
+                         "(default) or NCHW-contiguous; same logical tensors, same outputs bit for bit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
@@ -77,10 +80,15 @@ def parse():
     return ap.parse_args()
 
 
-def correlated_pair(shape, dev, gen, noise=0.3, amp=3.0, chunk=2048):
+def correlated_pair(shape, dev, gen, noise=0.3, amp=3.0, chunk=2048, channels_last=False):
     """[2, rows, ...]: two views of the same random base with independent noise - what a backbone makes of the left and
-    the right crop of a matching patch.  Built in row chunks so that the temporaries stay small."""
-    out = torch.empty((2,) + tuple(shape), dtype=torch.float32, device=dev)
+    the right crop of a matching patch.  Built in row chunks so that the temporaries stay small.
+    channels_last: [2, rows, C, H, W] whose [rows, C, H, W] halves lie in torch.channels_last memory order."""
+    if channels_last:
+        r, c, hh, ww = shape
+        out = torch.empty((2, r, hh, ww, c), dtype=torch.float32, device=dev).permute(0, 1, 4, 2, 3)
+    else:
+        out = torch.empty((2,) + tuple(shape), dtype=torch.float32, device=dev)
     for r0 in range(0, shape[0], chunk):
         sub = (min(chunk, shape[0] - r0),) + tuple(shape[1:])
         base = torch.randn(sub, device=dev, generator=gen)
@@ -101,8 +109,9 @@ class BenchNets:
     level, its dustbin features, and one scale-head row per third-level problem slot.  Inside the step the callbacks only
     run the path's own gathers (a15: ops.fine_descriptors, a16: ops.third_descriptors); GNN + final_proj = identity."""
 
-    def __init__(self, ops, dev, gen, cap, h, w, batch=None):
+    def __init__(self, ops, dev, gen, cap, h, w, batch=None, channels_last=True):
         self.ops = ops
+        self.channels_last = cl = bool(channels_last)
         pairs, N = cap.pairs, h * w
         c = correlated_pair((pairs, 448, N), dev, gen)
         self.d0, self.d1 = c[0].contiguous(), c[1].contiguous()
@@ -121,9 +130,12 @@ class BenchNets:
         self.cap = cap
         R, Pc = cap.rows_cap, cap.P_cap
         # fine level: ResNet2.forward2 maps of the stacked (left | right) crops, second_layer.py:69-70
-        self.m0 = correlated_pair((R, 64, 48, 48), dev, gen).reshape(2 * R, 64, 48, 48)
-        self.m1 = correlated_pair((R, 64, 24, 24), dev, gen).reshape(2 * R, 64, 24, 24)
-        self.m2 = correlated_pair((R, 128, 12, 12), dev, gen).reshape(2 * R, 128, 12, 12)
+        # memory order of the backbone maps: torch.channels_last (the default: what a backbone run under MIOpen emits, and
+        # the order in which the gathers' per-pixel reads are contiguous) or NCHW (--maps nchw: a torch conv's default)
+        self.m0 = correlated_pair((R, 64, 48, 48), dev, gen, channels_last=cl).reshape(2 * R, 64, 48, 48)
+        self.m1 = correlated_pair((R, 64, 24, 24), dev, gen, channels_last=cl).reshape(2 * R, 64, 24, 24)
+        self.m2 = correlated_pair((R, 128, 12, 12), dev, gen, channels_last=cl).reshape(2 * R, 128, 12, 12)
+        assert all(m.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format) for m in (self.m0, self.m1, self.m2))
         self.title = 0.5 * torch.randn((R, 8), device=dev, generator=gen)
         self.rubbish = 1.5 * torch.randn((R, 264), device=dev, generator=gen)
         self.sx, self.sy = scale_head((R, 1, 144), dev, gen), scale_head((R, 1, 144), dev, gen)
@@ -134,8 +146,9 @@ class BenchNets:
         self.fine_calls = self.third_calls = 0
         self.ev = None                       # dict of lists of (start, end) HIP events while the timed steps run
         # third level: the 1/2-resolution maps (padded to 52x52) of both crops, third_layer.py:112-120
-        f = correlated_pair((R, 128, 52, 52), dev, gen, chunk=1024)
+        f = correlated_pair((R, 128, 52, 52), dev, gen, chunk=1024, channels_last=cl)
         self.ff0, self.ff1 = f[0], f[1]
+        assert self.ff0.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
         self.kenc = 0.1 * torch.randn((128, 64), device=dev, generator=gen)
         self.rubbish3 = 1.5 * torch.randn((R, 128, 144), device=dev, generator=gen)
         self.scale3 = scale_head((Pc, 1, 64), dev, gen)
@@ -550,6 +563,53 @@ def secondary_rooflines(ops, dev):
     return res
 
 
+def gather_layout_ab(ops, dev, cap, P_step, rows=2048):
+    """The two descriptor gathers on the SAME logical maps in both memory orders (a sample of `rows` fine rows and the
+    matching share of third-level points, times scaled to the step's launch sizes): outputs compared bit for bit."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    R = min(rows, cap.rows_cap)
+    P = max(64, int(P_step * R / float(cap.rows_cap)))
+
+    def timed(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    maps = [torch.randn(sh, device=dev, generator=gen) for sh in ((2 * R, 64, 48, 48), (2 * R, 64, 24, 24), (2 * R, 128, 12, 12))]
+    title, rub = torch.randn((R, 8), device=dev, generator=gen), torch.randn((R, 264), device=dev, generator=gen)
+    out = torch.empty((2, R, 264, 145), dtype=torch.float32, device=dev)
+    f_nchw = timed(lambda: ops.fine_descriptors(maps, title, rub, out=out))
+    ref = out.clone()
+    maps = [cl(m) for m in maps]
+    f_nhwc = timed(lambda: ops.fine_descriptors(maps, title, rub, out=out))
+    same = torch.equal(ref, out)
+    del maps, out, ref
+    ff0, ff1 = (torch.randn((R, 128, 52, 52), device=dev, generator=gen) for _ in range(2))
+    mk0 = (torch.randint(1, 11, (P, 2), device=dev, generator=gen) * 8 + 4).float()
+    mk1 = torch.rand((P, 2), device=dev, generator=gen) * 96
+    b_ids = torch.sort(torch.randint(0, R, (P,), device=dev, generator=gen))[0]
+    kenc, rub3 = torch.randn((128, 64), device=dev, generator=gen), torch.randn((R, 128, 144), device=dev, generator=gen)
+    o = (torch.empty((P, 128, 65), device=dev), torch.empty((P, 128, 65), device=dev))
+    t_nchw = timed(lambda: ops.third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rub3, out=o))
+    r0, r1 = o[0].clone(), o[1].clone()
+    ff0, ff1 = cl(ff0), cl(ff1)
+    t_nhwc = timed(lambda: ops.third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rub3, out=o))
+    same = same and torch.equal(r0, o[0]) and torch.equal(r1, o[1])
+    assert same, "the channels-last gathers differ from the NCHW gathers"
+    kf, kt = cap.rows_cap / float(R), P_step / float(P)
+    return {"sample": "%d fine rows, %d third-level points; ms scaled to %d rows / %d points" % (R, P, cap.rows_cap, P_step),
+            "fine_desc_ms": {"nchw": f_nchw * kf, "channels_last": f_nhwc * kf},
+            "third_desc_ms": {"nchw": t_nchw * kt, "channels_last": t_nhwc * kt}, "outputs_bit_identical": bool(same)}
+
+
 def guard_trip_sweep(ops, batch, nets, cap, wl, fracs=(0.01, 0.10)):
     """pairs/s when a fraction of the fine / third-level problems leaves the linear-domain solver's guard band and is
     re-solved in the log domain: the rows' backbone maps are scaled by 32 (both sides: scores x 1024, far outside the band),
@@ -632,7 +692,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(synth.SEED + rank)
     cap = batch.Capacities(pairs, h, w, if_local=if_local)
-    nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch)
+    nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch, channels_last=args.maps == "nhwc")
     n_gpus = dist.get_world_size() if dist is not None else 1
 
     def barrier():
@@ -752,24 +812,35 @@ def main():
         # two high-resolution maps, 128 ch x 144 on the third, title + dustbin features) and the [264,145] block out
         FD_BYTES = (2 * 64 * 144 * 4 + 128 * 144 + 8 + 264) * 4 + 264 * 145 * 4
         fd_by = float(FD_BYTES) * 2 * cap.rows_cap
-        fd_roof = {"bound": "hbm", "kernel": "fine_desc_kernel (a15: fine descriptor sampling, %d stacked crops)" % (2 * cap.rows_cap),
+        cl = nets.channels_last
+        fd_name, td_name = ("fine_desc_nhwc_kernel", "third_desc_nhwc_kernel") if cl else ("fine_desc_kernel", "third_desc_kernel")
+        fd_roof = {"bound": "hbm", "kernel": "%s (a15: fine descriptor sampling, %d stacked crops, %s maps)"
+                                             % (fd_name, 2 * cap.rows_cap, "channels-last" if cl else "NCHW"),
                    "achieved": fd_by / (fd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": fd_by / (fd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::fine_desc_kernel")[0],
+                   "frac": fd_by / (fd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + fd_name + " ")[0],
                    "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": fd_by,
                    "algorithmic_bytes_per_image": FD_BYTES, "avg_launch_ms": fd_ms, "launches": int(len(ev["fine_desc"])),
-                   "note": "reads every sampled element of the three backbone maps once and writes the [2,B,264,145] block; the "
-                           "2x2 pooled taps use 8 of every 16 bytes of half of the rows of the 48x48 maps, so the lines touched are "
-                           "about 1.4x the algorithmic bytes"}
+                   "note": ("reads every sampled pixel of the three backbone maps once - a pixel's 64 / 128 channels are one run of "
+                            "256 / 512 bytes in channels-last memory, so every 64-byte granule fetched is used in full - turns the "
+                            "64-channel tiles through LDS and writes the [2,B,264,145] block as float4") if cl else
+                           ("reads every sampled element of the three backbone maps once and writes the [2,B,264,145] block; the "
+                            "2x2 pooled taps use 8 of every 16 bytes of half of the rows of the NCHW 48x48 maps, so the granules "
+                            "touched are about 1.4x the algorithmic bytes (--maps nhwc: the channels-last gather)")}
         # a16: two 8x8 windows x 128 channels in, two [128,65] blocks out per point
         TD_BYTES = 2 * 128 * 64 * 4 + 128 * 4 + 2 * 128 * 65 * 4 + 2 * 2 * 4 + 8 + 2 * 2 * 8
         td_by = float(TD_BYTES) * P_step
-        td_roof = {"bound": "hbm", "kernel": "third_desc_kernel (a16: third-level window gather, %d points)" % P_step,
+        td_roof = {"bound": "hbm", "kernel": "%s (a16: third-level window gather, %d points, %s maps)"
+                                             % (td_name, P_step, "channels-last" if cl else "NCHW"),
                    "achieved": td_by / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": td_by / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::third_desc_kernel")[0],
+                   "frac": td_by / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + td_name + " ")[0],
                    "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": td_by,
                    "algorithmic_bytes_per_point": TD_BYTES, "avg_launch_ms": td_ms, "launches": int(len(ev["third_desc"])),
-                   "note": "a window row is 32 bytes of a 128-byte line of a channel-major 52x52 map: the lines touched are about 4x "
-                           "the algorithmic bytes unless neighbouring points meet in L2 (XCD-aware workgroup order)"}
+                   "note": ("a window cell is one 512-byte run (128 channels) of the channels-last 52x52 map: 64 such runs in per "
+                            "(point, side), turned through LDS into the [128,65] block the cost build reads, kenc added on the way "
+                            "out; XCD-aware workgroup order") if cl else
+                           ("a window row is 32 bytes of a 208-byte row of a channel-major 52x52 map: 2.75 64-byte granules fetched "
+                            "per 32 bytes used unless neighbouring points meet in L2 (XCD-aware workgroup order); --maps nhwc: the "
+                            "channels-last gather")}
         ranked = sorted([third_roof, fine_roof, fd_roof, td_roof], key=lambda r: -r["avg_launch_ms"])
         dominant, other = ranked[0], ranked[1:]
         sweeps_per_pair = ITERS * (1 + (rows_step + P_step) / float(pairs))
@@ -791,6 +862,8 @@ def main():
                              % (rows_step, rows_step / float(pairs), cap.rows_cap, cap.Cmax),
                        "L3": "%d x [128,65]^2 -> 65x65 per step, decided by the merge (%.1f per pair; capacity %d)"
                              % (P_step, P_step / float(pairs), cap.P_cap),
+                       "map_layout": "torch.channels_last (logical [B,C,H,W], memory [B,H,W,C]) for the five backbone maps the gathers read"
+                                     if nets.channels_last else "NCHW-contiguous backbone maps",
                        "resident_synthetic_GB": nets.resident_bytes() / 1e9, "sinkhorn_iters": ITERS,
                        "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
                                       "after the timed region (%s)" % (n_gpus, backend if dist is not None else "single process")},
@@ -807,6 +880,7 @@ def main():
         if not args.no_secondary and n_gpus == 1:
             res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
+            res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)
             if streams is None:
                 # the same steps with the HBM-bound and the VALU-bound stages of neighbouring batches on two HIP streams with
                 # disjoint CU masks (3 / 5 of every 8 CUs per shader engine; --overlap 3): a secondary number, the bench line and

@@ -43,7 +43,7 @@ const char* pats_version(void);
  * `row_nomatch` to pats_iterative_expand_f32 under the same symbol: a caller built against the older header would pass
  * its stream where the new pointer goes).  A C consumer checks `pats_abi_version() == PATS_ABI_VERSION` once after
  * loading the library; pats_amd/_lib.py does.  New arguments now come with new entry points instead. */
-#define PATS_ABI_VERSION 3
+#define PATS_ABI_VERSION 4
 int pats_abi_version(void);
 const char* pats_last_error(void);
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
@@ -278,6 +278,21 @@ int pats_third_level_counted_f32(const float* feat0, const float* feat1, int64_t
                                  const float* scale, const float* scale_x, const float* scale_y, const int64_t* p_s,
                                  const int64_t* p_t, int iters, int outdoor, float* mkpts0_f, float* mkpts1_f,
                                  float* label, uint8_t* if_matching1, pats_stream_t stream);
+
+/* a15 / a16 on CHANNELS-LAST maps (torch.channels_last: logical [B,C,H,W], memory [B,H,W,C]) - the layout a backbone run
+ * under MIOpen emits natively, and the one in which the per-pixel reads of second_layer.py:73-79 and of
+ * `feat.permute(0, 2, 3, 1).reshape(-1, C)` + torch.gather (third_layer.py:139-140) are contiguous runs of 256 / 512
+ * bytes.  Arguments, outputs and every output bit as in pats_fine_descriptors_f32 / pats_third_descriptors_*_f32; only
+ * the memory order of feat0/1/2 ([2B,48,48,64], [2B,24,24,64], [2B,12,12,128]) and feat_f0/f1 ([B,52,52,128]) differs
+ * (title, rubbish, kenc as before).  Maps and desc 16-byte aligned.  P_dev may be NULL (then P_cap points exist). */
+int pats_fine_descriptors_nhwc_f32(const float* feat0, const float* feat1, const float* feat2,
+                                   const float* title, const float* rubbish, int64_t B, float* desc,
+                                   pats_stream_t stream);
+int pats_third_descriptors_nhwc_f32(const float* feat_f0, const float* feat_f1, const float* mkpts0_c,
+                                    const float* mkpts1_c, const int64_t* b_ids, const float* kenc,
+                                    const float* rubbish, int64_t P_cap, const int64_t* P_dev, int64_t B,
+                                    float* out0, float* out1, int64_t* p_s_out, int64_t* p_t_out,
+                                    pats_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The steps either side of the OT path.  bool tensors are 1 byte, 0 / 1.

@@ -763,8 +763,10 @@ int oracle_third_descriptors(const float* ff0, const float* ff1, const float* mk
         const long long q0 = (long long)rintf(t0 / 4.0f) * 4, q1 = (long long)rintf(t1 / 4.0f) * 4;                   /* :130 */
         ps[p * 2] = s0; ps[p * 2 + 1] = s1; pt[p * 2] = q0; pt[p * 2 + 1] = q1;
         const long long x2 = (long long)rintf((float)s0 / 8.0f), y2 = (long long)rintf((float)s1 / 8.0f);              /* :141-142 */
-        const long long i2 = y2 * 12 + x2;
-        if (i2 < 0 || i2 > 143 || b < 0 || b >= B) { err = -1; continue; }
+        /* index2 = b*144 + y2*12 + x2 is a ROW of rubbish.permute(0,2,1).reshape(-1,128) (:143-144): cell 11 of a patch
+         * (round(92/8) = 12) reads the next patch's feature; only leaving the whole tensor raises */
+        const long long i2 = b * 144 + y2 * 12 + x2;
+        if (i2 < 0 || i2 >= B * 144 || b < 0 || b >= B) { err = -1; continue; }
         for (int t = 0; t < 64; ++t) {
             const int wx = t % W, wy = t / W;
             const long long x0 = floordiv2(s0) + wx - W / 2 + 2, y0 = floordiv2(s1) + wy - W / 2 + 2;   /* :125-126 */
@@ -778,7 +780,7 @@ int oracle_third_descriptors(const float* ff0, const float* ff1, const float* mk
             }
         }
         for (int ch = 0; ch < C; ++ch) {
-            const float rb = rubbish[(b * C + ch) * 144 + i2];                                              /* :143-146 */
+            const float rb = rubbish[((i2 / 144) * C + ch) * 144 + i2 % 144];                                              /* :143-146 */
             out0[(p * C + ch) * 65 + 64] = rb;
             out1[(p * C + ch) * 65 + 64] = rb;
         }

@@ -17,7 +17,7 @@ if os.environ.get("PATS_AMD_DIAG_LIB", "") not in ("", "0"):
 c_void_p, c_int, c_i64, c_f, c_size = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                        ctypes.c_size_t)
 
-ABI_VERSION = 3      # include/pats_amd.h PATS_ABI_VERSION
+ABI_VERSION = 4      # include/pats_amd.h PATS_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol include/pats_amd.h declares
 SIGNATURES = {
@@ -83,6 +83,9 @@ SIGNATURES = {
                                      c_void_p]),
     "pats_third_descriptors_counted_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pats_fine_descriptors_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pats_third_descriptors_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pats_third_level_counted_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p]),

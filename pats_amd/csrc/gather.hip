@@ -127,9 +127,13 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
     i0 = i0 < 0 ? 0 : (i0 > lim ? lim : i0);      // memory safety (torch.gather would raise out of range)
     i1 = i1 < 0 ? 0 : (i1 > lim ? lim : i1);
     // dustbin feature: rubbish[b, :, y2*12 + x2], x2 = round(mk0x / 8), y2 = round(mk0y / 8)   :141-144
+    // as a row of the flattened [B*144, 128] view, like the reference: cell 11 of a patch (round(92 / 8) = 12) reads the NEXT
+    // patch's feature (PATS itself never sends the border ring here: second_layer.py:140-149,176-184)
     long long x2 = round_half_even_div((float)s0, 8.0f), y2 = round_half_even_div((float)s1, 8.0f);
-    long long i2 = y2 * 12 + x2;
-    i2 = i2 < 0 ? 0 : (i2 > 143 ? 143 : i2);
+    long long i2 = b * 144 + y2 * 12 + x2;
+    i2 = i2 < 0 ? 0 : (i2 > B * 144 - 1 ? B * 144 - 1 : i2);      // memory safety (torch.gather would raise out of range)
+    const long long bb2 = i2 / 144;
+    i2 -= bb2 * 144;
     // NHWC row index -> (batch, y, x) of the NCHW map
     const long long bb0 = i0 / (M * M), r0 = i0 - bb0 * (M * M);
     const long long bb1 = i1 / (M * M), r1 = i1 - bb1 * (M * M);
@@ -154,10 +158,161 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
     }
     if (lane < 32) {
         const int ch = 32 * wave + lane;
-        const float rb = rubbish[(b * C + ch) * 144 + i2];
+        const float rb = rubbish[(bb2 * C + ch) * 144 + i2];
         o0[ch * 65 + 64] = rb;                                                   // :145-146
         o1[ch * 65 + 64] = rb;
     }
+}
+
+
+// ---- the same two gathers on CHANNELS-LAST maps ----------------------------------------------------------------------
+// The reference gathers from `feat.permute(0, 2, 3, 1).reshape(-1, C)` (third_layer.py:139-140) and samples single pixels
+// of AvgPool'd maps (second_layer.py:73-79): per-PIXEL reads of all channels.  On the NCHW tensors a torch conv emits by
+// default a pixel's channels lie H*W*4 bytes apart - a third-level window row is 32 bytes of every 208-byte map row (2.75
+// 64-byte HBM granules fetched per 32 bytes used, measured), the stride-4 samples of the 48x48 map touch half of its
+// granules for a sixteenth of its pixels.  A backbone run in torch.channels_last (MIOpen's native layout; the logical
+// shape stays [B,C,H,W]) puts a pixel's channels in ONE contiguous run of 256 / 512 bytes: every granule fetched is
+// used in full.  Lanes then run over channels while the outputs want lanes over nodes ([C, nodes] rows for the MFMA cost
+// builds), so the tile turns through LDS and leaves as one linear, 16-byte-vectorised copy.  Same values, same
+// operation order per element as the NCHW kernels: bit-identical outputs (tests/test_gpu_parity.py).
+
+// one workgroup per (point, side): 64 pixels x 128 channels = 32 KB in, [128, 65] out
+__global__ void __launch_bounds__(256)
+third_desc_nhwc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
+                       const float* __restrict__ mk0, const float* __restrict__ mk1,
+                       const int64_t* __restrict__ b_ids, const float* __restrict__ kenc,
+                       const float* __restrict__ rubbish, int64_t P, int64_t B,
+                       float* __restrict__ out0, float* __restrict__ out1, int64_t* __restrict__ ps_out,
+                       int64_t* __restrict__ pt_out, const int64_t* __restrict__ P_dev) {
+    constexpr int W = 8, M = 52, C = 128, NT = 65;
+    __shared__ __attribute__((aligned(16))) float tile[C * NT];
+    int64_t live = P;
+    if (P_dev) { const int64_t n = *P_dev; live = n < P ? n : P; }
+    // XCD-aware order as in third_desc_kernel; the two sides of a point follow each other on the same XCD (they share
+    // the dustbin feature's lines)
+    const unsigned k = blockIdx.x >> 3;
+    const int side = k & 1;
+    const int64_t per = (live + 7) >> 3, p = (int64_t)(blockIdx.x & 7) * per + (k >> 1);
+    if ((int64_t)(k >> 1) >= per || p >= live) return;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t b = b_ids[p];
+    const long long s0 = round_half_even_div(mk0[p * 2 + 0], 4.0f) * 4, s1 = round_half_even_div(mk0[p * 2 + 1], 4.0f) * 4;   // :124
+    float t0 = mk1[p * 2 + 0], t1 = mk1[p * 2 + 1];                                                                          // :128-130
+    t0 = t0 >= 96.f ? 96.f : t0; t1 = t1 >= 96.f ? 96.f : t1;
+    t0 = t0 <= 0.f ? 0.f : t0;   t1 = t1 <= 0.f ? 0.f : t1;
+    const long long q0 = round_half_even_div(t0, 4.0f) * 4, q1 = round_half_even_div(t1, 4.0f) * 4;
+    if (t == 0 && side == 0) {
+        if (ps_out) { ps_out[p * 2] = s0; ps_out[p * 2 + 1] = s1; }
+        if (pt_out) { pt_out[p * 2] = q0; pt_out[p * 2 + 1] = q1; }
+    }
+    auto fdiv2 = [](long long v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };      // python floor division
+    // row of the NHWC view of window cell (0, 0): b M M + (y // 2 - W/2 + 2) M + (x // 2 - W/2 + 2)      :125-127,131-133
+    const long long i00 = b * M * M + (fdiv2(side ? q1 : s1) - W / 2 + 2) * M + (fdiv2(side ? q0 : s0) - W / 2 + 2);
+    const long long lim = B * M * M - 1;
+    const float* __restrict__ ff = side ? ff1 : ff0;
+    // dustbin feature: rubbish[b, :, y2*12 + x2]                                                           :141-144
+    long long i2 = b * 144 + round_half_even_div((float)s1, 8.0f) * 12 + round_half_even_div((float)s0, 8.0f);
+    i2 = i2 < 0 ? 0 : (i2 > B * 144 - 1 ? B * 144 - 1 : i2);      // a row of the flattened [B*144, 128] view, see third_desc_kernel
+    const long long bb2 = i2 / 144;
+    i2 -= bb2 * 144;
+    float rb = 0.f;
+    if (t < C) rb = rubbish[(bb2 * C + t) * 144 + i2];
+    // wave w brings window cells 16w .. 16w+15, lane l channels l and l + 64 of each: 32 loads of 256 contiguous bytes in flight
+    float v0[16], v1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        long long i = i00 + (2 * wave + (j >> 3)) * M + (j & 7);
+        i = i < 0 ? 0 : (i > lim ? lim : i);          // memory safety (torch.gather would raise out of range)
+        const float* src = ff + i * C;
+        v0[j] = src[lane];
+        v1[j] = src[lane + 64];
+    }
+    // + self.kenc(kpts) rides on the way out: element e = c * 65 + n of the output takes kenc[c, n]       :139-140
+    float ke[33];
+#pragma unroll
+    for (int r = 0; r < 33; ++r) {
+        const int e = t + 256 * r, c = e / NT, n = e - c * NT;
+        ke[r] = kenc[(e < C * NT && n < 64) ? c * 64 + n : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        tile[lane * NT + 16 * wave + j] = v0[j];
+        tile[(lane + 64) * NT + 16 * wave + j] = v1[j];
+    }
+    if (t < C) tile[t * NT + 64] = rb;                                                                      // :145-146
+    __syncthreads();
+    float* o = (side ? out1 : out0) + p * C * NT;
+#pragma unroll
+    for (int r = 0; r < 33; ++r) {
+        const int e = t + 256 * r, c = e / NT, n = e - c * NT;
+        if (e < C * NT) o[e] = n < 64 ? tile[e] + ke[r] : tile[e];
+    }
+}
+
+// one workgroup per stacked image; the 264 output channels leave in four 64-channel tiles (map 0, map 1, the two halves of
+// map 2), each gathered with 16-byte loads - lane = (node % 4, four channels) - pooled in registers, turned in LDS and
+// copied out as float4.  `cpp` = channels per pixel of the map, `ch0` = first of the 64 channels this pass takes.
+template <int TAPS>
+__device__ __forceinline__ void fine_tile_pass(const float* __restrict__ img, int cpp, int ch0, int rowpix, int step, int first,
+                                               float* tile, float* __restrict__ o, const float* __restrict__ rub, int t) {
+    constexpr int NP = 145;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = t & 63, wave = t >> 6, cg = lane & 15, sub = lane >> 4;
+    constexpr int GR = TAPS == 1 ? 9 : 3;          // node groups per round: 9 or 12 loads of 16 bytes in flight per lane
+    float dust = 0.f;
+    if (t < 64) dust = rub[t];                                                                   // second_layer.py:83,85
+#pragma unroll 1
+    for (int g0 = 0; g0 < 9; g0 += GR) {
+        f4 q[GR][TAPS];
+#pragma unroll
+        for (int g = 0; g < GR; ++g) {
+            const int nd = 16 * (g0 + g) + 4 * wave + sub, r = nd / 12, c = nd - 12 * r;       // positions (k // 12, k % 12)
+            const float* px = img + ((step * r + first) * rowpix + step * c + first) * cpp + ch0 + 4 * cg;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+                q[g][tap] = *reinterpret_cast<const f4*>(px + ((tap >> 1) * rowpix + (tap & 1)) * cpp);
+        }
+#pragma unroll
+        for (int g = 0; g < GR; ++g) {
+            const int nd = 16 * (g0 + g) + 4 * wave + sub;
+            f4 v = q[g][0];
+            if (TAPS == 4) v = (((q[g][0] + q[g][1]) + q[g][2]) + q[g][3]) / 4.0f;              // AvgPool2d(2, 1, 1)  :73-79
+            tile[(4 * cg + 0) * NP + nd] = v.x;
+            tile[(4 * cg + 1) * NP + nd] = v.y;
+            tile[(4 * cg + 2) * NP + nd] = v.z;
+            tile[(4 * cg + 3) * NP + nd] = v.w;
+        }
+    }
+    if (t < 64) tile[t * NP + 144] = dust;
+    __syncthreads();
+    const f4* src = reinterpret_cast<const f4*>(tile);
+    f4* dst = reinterpret_cast<f4*>(o);
+    for (int e = t; e < 64 * NP / 4; e += 256) dst[e] = src[e];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+fine_desc_nhwc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                      const float* __restrict__ f2, const float* __restrict__ title,
+                      const float* __restrict__ rubbish, int64_t B, float* __restrict__ desc) {
+    constexpr int NP = 145;
+    __shared__ __attribute__((aligned(16))) float tile[64 * NP];
+    const int64_t n = blockIdx.x;              // s * B + b : index into the stacked maps
+    const int64_t b = n % B;
+    const int t = threadIdx.x;
+    float* o = desc + n * 264 * NP;
+    const float* rub = rubbish + b * 264;
+    for (int e = t; e < 8 * NP; e += 256) {                    // the 8-channel "title"                         :82,84
+        const int ch = e / NP, p = e - ch * NP;
+        o[e] = p == 144 ? rub[ch] : title[b * 8 + ch];
+    }
+    // map 0 [.,48,48,64]: avgpool(2,1,1) -> 49x49, sample (4r+2, 4c+2) = mean of pixels (4r+1.., 4c+1..)
+    fine_tile_pass<4>(f0 + n * 48 * 48 * 64, 64, 0, 48, 4, 1, tile, o + 8 * NP, rub + 8, t);
+    // map 1 [.,24,24,64]: avgpool -> 25x25, sample (2r+1, 2c+1) = mean of pixels (2r.., 2c..)
+    fine_tile_pass<4>(f1 + n * 24 * 24 * 64, 64, 0, 24, 2, 0, tile, o + 72 * NP, rub + 72, t);
+    // map 2 [.,12,12,128]: no pooling, sample (r, c)
+    fine_tile_pass<1>(f2 + n * 144 * 128, 128, 0, 12, 1, 0, tile, o + 136 * NP, rub + 136, t);
+    fine_tile_pass<1>(f2 + n * 144 * 128, 128, 64, 12, 1, 0, tile, o + 200 * NP, rub + 200, t);
 }
 
 }  // namespace pats
@@ -201,4 +356,31 @@ extern "C" int pats_third_descriptors_counted_f32(const float* feat_f0, const fl
     hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)((P_cap + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
                        mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P_cap, B, out0, out1, p_s_out, p_t_out, P_dev);
     return check_launch("third_desc_kernel");
+}
+
+extern "C" int pats_fine_descriptors_nhwc_f32(const float* feat0, const float* feat1, const float* feat2,
+                                              const float* title, const float* rubbish, int64_t B,
+                                              float* desc, pats_stream_t stream) {
+    PATS_REQUIRE(B >= 0, "fine_descriptors_nhwc: bad shape");
+    if (B == 0) return PATS_OK;
+    PATS_REQUIRE(feat0 && feat1 && feat2 && title && rubbish && desc, "fine_descriptors_nhwc: null pointer");
+    PATS_REQUIRE(((uintptr_t)feat0 | (uintptr_t)feat1 | (uintptr_t)feat2 | (uintptr_t)desc) % 16 == 0,
+                 "fine_descriptors_nhwc: maps and desc must be 16-byte aligned");
+    hipLaunchKernelGGL(fine_desc_nhwc_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, as_stream(stream), feat0, feat1,
+                       feat2, title, rubbish, B, desc);
+    return check_launch("fine_desc_nhwc_kernel");
+}
+
+extern "C" int pats_third_descriptors_nhwc_f32(const float* feat_f0, const float* feat_f1,
+                                               const float* mkpts0_c, const float* mkpts1_c,
+                                               const int64_t* b_ids, const float* kenc, const float* rubbish,
+                                               int64_t P_cap, const int64_t* P_dev, int64_t B, float* out0, float* out1,
+                                               int64_t* p_s_out, int64_t* p_t_out, pats_stream_t stream) {
+    PATS_REQUIRE(P_cap >= 0 && B > 0, "third_descriptors_nhwc: bad shape");
+    if (P_cap == 0) return PATS_OK;
+    PATS_REQUIRE(feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
+                 "third_descriptors_nhwc: null pointer");
+    hipLaunchKernelGGL(third_desc_nhwc_kernel, dim3((unsigned)((P_cap + 7) / 8 * 16)), dim3(256), 0, as_stream(stream), feat_f0,
+                       feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P_cap, B, out0, out1, p_s_out, p_t_out, P_dev);
+    return check_launch("third_desc_nhwc_kernel");
 }

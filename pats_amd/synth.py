@@ -130,6 +130,26 @@ def third_maps(seed=SEED + 6, B=3, P=40):
     return {"ff0": ff0, "ff1": ff1, "mk0": mk0, "mk1": mk1, "b_ids": b_ids, "kenc": kenc, "rubbish": rubbish}
 
 
+def third_maps_ring(seed=SEED + 60, B=4, P=48):
+    """a16 inputs with source points on the BORDER RING of the 12x12 cell grid (cells 0 and 11: 8c+4 = 4 and 92), where
+    the reference's window leaves the 52x52 map on one side and wraps into the neighbouring row / image of the flattened
+    NHWC view (third_layer.py:127) and its dustbin index round(92 / 8) = 12 reads the NEXT patch's feature (:141-144).
+    Patches 1 .. B-2 only: from the first / last patch those indices leave the tensor and torch.gather raises."""
+    rng = np.random.default_rng(seed)
+    d = third_maps(seed=seed, B=B, P=P)
+    cells = rng.integers(0, 12, size=(P, 2))
+    ring = rng.integers(0, 2, size=(P, 2)) * 11
+    pick = rng.integers(0, 3, size=P)                        # ring in x, ring in y, ring in both
+    cells[pick != 1, 0] = ring[pick != 1, 0]
+    cells[pick != 0, 1] = ring[pick != 0, 1]
+    cells[:4] = [[11, 11], [0, 0], [11, 0], [0, 11]]
+    d["mk0"] = (cells * 8 + 4).astype(np.float32)
+    d["mk1"] = (rng.integers(-8, 209, size=(P, 2)) * 0.5).astype(np.float32)       # -4.0 .. 104.0: clamped to [0, 96] (:128-129)
+    d["mk1"][:4] = np.array([[96, 96], [0, 0], [97.5, -3], [-0.5, 200]], np.float32)
+    d["b_ids"] = rng.integers(1, B - 1, size=(P,)).astype(np.int64)
+    return d
+
+
 def merge_inputs(seed=SEED + 7, h=15, w=20, chunks=3, tie_step=0.125):
     """Inputs of merge_patches_new/old (second_layer.py:137-238) for `chunks` successive L2 chunks of
     one pair: the coarse no-match mask, and per chunk the chunk mask (first_layer.py:137-139 style:

@@ -399,6 +399,72 @@ def test_third_descriptors(ops, oracle):
     assert m0.shape == (o0.shape[0], 16, 2) and torch.isfinite(m1).all()
 
 
+def test_descriptor_gathers_on_channels_last_maps_give_the_same_bits(ops, oracle):
+    """Maps in torch.channels_last (what a backbone run under MIOpen emits) take the channels-last gathers: golden
+    vectors, the oracle and the NCHW kernels' outputs, bit for bit; with the edge cases of the window gather (points at
+    0 and 96 whose windows leave the map and wrap / clamp, first and last image) and a device-side count."""
+    cl = lambda a: cu(a).contiguous(memory_format=torch.channels_last)
+    inp = synth.fine_maps()
+    maps = [cl(inp["f0"]), cl(inp["f1"]), cl(inp["f2"])]
+    assert not maps[0].is_contiguous()
+    desc = ops.fine_descriptors(maps, cu(inp["title"]), cu(inp["rubbish"]))
+    np.testing.assert_array_equal(desc.cpu().numpy(), oracle.fine_descriptors(inp["f0"], inp["f1"], inp["f2"], inp["title"], inp["rubbish"]))
+    g = golden("fine_desc.npz")
+    np.testing.assert_array_equal(desc.cpu().numpy().reshape(-1)[g["idx"]], g["val"])
+    assert torch.equal(desc, ops.fine_descriptors([cu(inp["f0"]), cu(inp["f1"]), cu(inp["f2"])], cu(inp["title"]), cu(inp["rubbish"])))
+    # mixed memory formats fall back to the NCHW kernel
+    assert torch.equal(desc, ops.fine_descriptors([maps[0], cu(inp["f1"]), maps[2]], cu(inp["title"]), cu(inp["rubbish"])))
+
+    inp = synth.third_maps()
+    g = golden("third_desc.npz")
+    o0, o1, ps, pt = ops.third_descriptors(cl(inp["ff0"]), cl(inp["ff1"]), cu(inp["mk0"]), cu(inp["mk1"]),
+                                           cu(inp["b_ids"]), cu(inp["kenc"]), cu(inp["rubbish"]))
+    assert np.array_equal(ps.cpu().numpy(), g["p_s"]) and np.array_equal(pt.cpu().numpy(), g["p_t"])
+    np.testing.assert_array_equal(o0.cpu().numpy()[:, ::4, :], g["out0"])
+    np.testing.assert_array_equal(o1.cpu().numpy()[:, ::4, :], g["out1"])
+    # the border ring of the cell grid (fixture from the reference's lines): wrapped windows, the next patch's dustbin feature
+    inp = synth.third_maps_ring()
+    g = golden("third_desc_ring.npz")
+    for fmt in (cu, cl):
+        o0, o1, ps, pt = ops.third_descriptors(fmt(inp["ff0"]), fmt(inp["ff1"]), cu(inp["mk0"]), cu(inp["mk1"]),
+                                               cu(inp["b_ids"]), cu(inp["kenc"]), cu(inp["rubbish"]))
+        assert np.array_equal(ps.cpu().numpy(), g["p_s"]) and np.array_equal(pt.cpu().numpy(), g["p_t"])
+        np.testing.assert_array_equal(o0.cpu().numpy()[:, ::4, :], g["out0"])
+        np.testing.assert_array_equal(o1.cpu().numpy()[:, ::4, :], g["out1"])
+    # random maps, points on and beyond the borders (clamped / wrapped windows), every image incl. the first and the last
+    rng = np.random.default_rng(5)
+    B, P = 5, 203
+    ff0, ff1 = rng.standard_normal((2, B, 128, 52, 52)).astype(np.float32)
+    mk0 = (rng.random((P, 2)) * 96).astype(np.float32)
+    mk1 = (rng.random((P, 2)) * 130 - 17).astype(np.float32)
+    mk0[:8] = [[0, 0], [96, 96], [0, 96], [96, 0], [2, 2], [94, 94], [0, 50], [50, 0]]
+    mk1[:8] = [[-5, -5], [200, 200], [0, 96], [96, 0], [1.9, 2.1], [94, 97], [0, 50], [50, 0]]
+    b_ids = rng.integers(1, B - 1, P).astype(np.int64)      # first / last image: below (a window leaving them leaves the tensor)
+    b_ids[:8] = [1, B - 2, 1, B - 2, 2, 3, 1, 2]      # windows that leave the map wrap into the neighbouring image (:127)
+    kenc = rng.standard_normal((128, 64)).astype(np.float32)
+    rub = rng.standard_normal((B, 128, 144)).astype(np.float32)
+    rub[0, :7, :] = -0.0
+    want = oracle.third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rub)
+    got_n = ops.third_descriptors(cu(ff0), cu(ff1), cu(mk0), cu(mk1), cu(b_ids), cu(kenc), cu(rub))
+    got_c = ops.third_descriptors(cl(ff0), cl(ff1), cu(mk0), cu(mk1), cu(b_ids), cu(kenc), cu(rub))
+    for a, b_, w in zip(got_n, got_c, want):
+        assert torch.equal(a, b_)
+        np.testing.assert_array_equal(b_.cpu().numpy().view(np.uint32 if w.dtype == np.float32 else w.dtype),
+                                      w.view(np.uint32 if w.dtype == np.float32 else w.dtype))
+    # indices beyond the first / last image (torch.gather would raise, so would the oracle): both kernels clamp alike
+    b_ids[:4] = [0, B - 1, 0, B - 1]
+    b_ids[100:] = rng.integers(0, B, P - 100)
+    got_n = ops.third_descriptors(cu(ff0), cu(ff1), cu(mk0), cu(mk1), cu(b_ids), cu(kenc), cu(rub))
+    got_c = ops.third_descriptors(cl(ff0), cl(ff1), cu(mk0), cu(mk1), cu(b_ids), cu(kenc), cu(rub))
+    assert all(torch.equal(a, b_) for a, b_ in zip(got_n, got_c))
+    # device-side count: rows past it are not written
+    cnt = torch.tensor([77], dtype=torch.int64, device="cuda")
+    out = (torch.full((P, 128, 65), 7.0, device="cuda"), torch.full((P, 128, 65), 7.0, device="cuda"))
+    c0, c1, _, _ = ops.third_descriptors(cl(ff0), cl(ff1), cu(mk0), cu(mk1), cu(b_ids), cu(kenc), cu(rub), count=cnt, out=out)
+    assert torch.equal(c0[:77], got_c[0][:77]) and torch.equal(c1[:77], got_c[1][:77])
+    assert bool((c0[77:] == 7.0).all()) and bool((c1[77:] == 7.0).all())
+
+
 # ---- properties at the reference's full sizes (oracle would take minutes) ------------------------
 def _check_marginals(Z, ns, ms):
     """Each sweep ends with the column update (modules.py:142), so after any number of sweeps the

@@ -235,6 +235,26 @@ def test_third_descriptors(oracle):
         oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], bad, bid, inp["kenc"], inp["rubbish"])
 
 
+def test_third_descriptors_on_the_border_ring(oracle):
+    """Source points on cells 0 / 11 of the 12x12 grid (third_desc_ring.npz, made from the reference's own lines): windows
+    that wrap in the flattened NHWC view, and the dustbin index round(92 / 8) = 12 that reads the NEXT patch's feature
+    (third_layer.py:127,141-144) - rows of the flattened views, not clamped per map."""
+    g = golden("third_desc_ring.npz")
+    inp = synth.third_maps_ring()
+    o0, o1, ps, pt = oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], inp["b_ids"],
+                                              inp["kenc"], inp["rubbish"])
+    assert np.array_equal(ps, g["p_s"]) and np.array_equal(pt, g["p_t"])
+    np.testing.assert_array_equal(o0[:, ::4, :], g["out0"])
+    np.testing.assert_array_equal(o1[:, ::4, :], g["out1"])
+    np.testing.assert_allclose(o0.astype(np.float64).sum((1, 2)), g["sum0"], rtol=1e-12)
+    np.testing.assert_allclose(o1.astype(np.float64).sum((1, 2)), g["sum1"], rtol=1e-12)
+    assert (inp["mk0"] == 92).any(1).sum() > 8 and (ps == 92).all(1).any()
+    last = inp["b_ids"].copy()
+    last[0] = inp["ff0"].shape[0] - 1               # cell (11, 11) of the LAST patch: the dustbin row leaves the tensor
+    with pytest.raises(IndexError):
+        oracle.third_descriptors(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], last, inp["kenc"], inp["rubbish"])
+
+
 # ---- SURVEY.md section 8(f) rows -------------------------------------------------------------------
 def _merge_case(name):
     g = golden(name)

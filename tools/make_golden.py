@@ -28,6 +28,8 @@ What each fixture pins (reference file:line):
                    network outputs (MegaDepth-style: local chunks, outdoor, merge_new; ScanNet-style: one
                    chunk, indoor, merge_old) -> final matches_l / matches_r
   attention.npz    attention(query, key, value) of the GNN layers (models/modules.py:84-88)
+  third_desc_ring.npz  the a16 gather for source points on the border ring of the cell grid: windows that wrap
+                   in the flattened NHWC view, the dustbin index that reads the next patch (third_layer.py:127,141-144)
   result.npz / result_mixed.npz   third-level inputs, result scatter and get_result
                    (pats.py:53-78, utils/utils.py:189-213); _mixed flips left_choice per row
 """
@@ -279,9 +281,9 @@ def gen_fine_desc(R):
          first=desc[:, 0, :, :].clone()[:, ::7, ::5])
 
 
-def gen_third_desc(R):
+def gen_third_desc(R, name="third_desc.npz", inp=None):
     """third_layer.py:121-146 re-executed verbatim (self.W = 8, self.M = 52, :108-110)."""
-    inp = synth.third_maps()
+    inp = synth.third_maps() if inp is None else inp
     feat_f0, feat_f1 = T(inp["ff0"]), T(inp["ff1"])
     mkpts0_c, mkpts1_c, b_ids = T(inp["mk0"]), T(inp["mk1"]), T(inp["b_ids"])
     kenc_out = T(inp["kenc"])                               # stands for self.kenc(kpts)
@@ -306,7 +308,7 @@ def gen_third_desc(R):
     rubbish_unfold = torch.gather(rubbish.permute(0, 2, 1).reshape(-1, 128), 0, index2).reshape(-1, 128, 1)
     feat_f0_unfold = torch.cat([feat_f0_unfold, rubbish_unfold], dim=2)
     feat_f1_unfold = torch.cat([feat_f1_unfold, rubbish_unfold], dim=2)
-    save("third_desc.npz", in_checksum=synth.checksum(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], inp["kenc"], inp["rubbish"]),
+    save(name, in_checksum=synth.checksum(inp["ff0"], inp["ff1"], inp["mk0"], inp["mk1"], inp["kenc"], inp["rubbish"]),
          p_s=mkpts0_c, p_t=mkpts1_c, out0=feat_f0_unfold[:, ::4, :], out1=feat_f1_unfold[:, ::4, :],
          sum0=feat_f0_unfold.double().sum((1, 2)), sum1=feat_f1_unfold.double().sum((1, 2)))
 
@@ -633,6 +635,9 @@ def main():
     if only == ["heads"]:
         gen_heads(R)
         return
+    if only == ["ring"]:                                          # round 3: the a16 gather on the border ring of the cell grid
+        gen_third_desc(R, "third_desc_ring.npz", synth.third_maps_ring())
+        return
     gen_kat(R)
     gen_sinkhorn_raw(R)
     gen_ties(R)
@@ -648,6 +653,7 @@ def main():
     gen_resize_small(R)
     gen_fine_desc(R)
     gen_third_desc(R)
+    gen_third_desc(R, "third_desc_ring.npz", synth.third_maps_ring())
     gen_merge(R, "merge_new.npz", True, synth.SEED + 7)
     gen_merge(R, "merge_old.npz", False, synth.SEED + 9)
     gen_merge(R, "merge_new_portrait.npz", True, synth.SEED + 10, h=20, w=15)
