@@ -799,9 +799,13 @@ def main():
         # fine level: descriptors in, log-plan out
         f_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * cap.rows_cap
         f_ach = f_by / (fine_ms * 1e-3) / 1e9
+        f_parts = [traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145_kernel")[0]]
+        f_traffic = float(sum(f_parts)) if all(v is not None for v in f_parts) else None
         fine_roof = {"bound": "hbm", "kernel": "fine-level cost + Sinkhorn (%d x 145x145 = the row capacity, %d rows in use)"
                      % (cap.rows_cap, rows_step), "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_ach / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": f_by, "avg_launch_ms": fine_ms, "launches": int(len(ev["fine"])),
+                     "traffic": f_traffic, "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145_kernel: includes the "
+                     "score matrix written by the first and read by the second)", "traffic_source": pmc_src if f_traffic is not None else None,
+                     "algorithmic_bytes_per_launch": f_by, "avg_launch_ms": fine_ms, "launches": int(len(ev["fine"])),
                      "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
                      "note": "descriptors in (2 x 264 x 145 fp32), log-plan out (145 x 145 fp32) per problem; the 100 sweeps run on the "
                              "register-resident blocks (VALU-bound)"}
@@ -880,7 +884,6 @@ def main():
         if not args.no_secondary and n_gpus == 1:
             res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
-            res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)
             if streams is None:
                 # the same steps with the HBM-bound and the VALU-bound stages of neighbouring batches on two HIP streams with
                 # disjoint CU masks (3 / 5 of every 8 CUs per shader engine; --overlap 3): a secondary number, the bench line and
@@ -897,6 +900,8 @@ def main():
                                                 "note": "bench.py --overlap 3; profiles/r03_cu_mask_probe.txt"}
                 except RuntimeError as err:
                     res["overlap_cu_masked"] = {"error": str(err)[:200]}
+            res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline and n_gpus == 1:
             # one more step outside the clock, keeping the coarse tensors the parity leg needs
             o2 = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)

@@ -88,10 +88,19 @@ expand_kernel(ExpandArgs a) {
             sm[(size_t)ROWS_PER_WG * ld + (size_t)which * ld + j] = a.input_is_log ? expf(o) : o;
         }
     }
+    // the same pass takes the argmax over the real columns (:1182) and over all columns (:1191), first index on ties,
+    // and the row sum (:1288) of the values it stages: lane t sees cells t, t + 16, ... in the order a second pass would
+    float bv = -INFINITY, bva = -INFINITY;
+    int bi = 0x7fffffff, bia = 0x7fffffff;
+    float rowsum = 0.f;
     for (int j = t; j < N; j += 16) {
-        const float x = src[j];
-        if (x > fv || fi == 0x7fffffff) { fv = x; fi = j; }
-        prow[j] = a.input_is_log ? expf(x) : x;
+        const float x0 = src[j];
+        if (x0 > fv || fi == 0x7fffffff) { fv = x0; fi = j; }
+        const float x = a.input_is_log ? expf(x0) : x0;
+        prow[j] = x;
+        rowsum += x;
+        if (j < N - 1 && (x > bv || bi == 0x7fffffff)) { bv = x; bi = j; }
+        if (x > bva || bia == 0x7fffffff) { bva = x; bia = j; }
         if (!shared_opp) {
             const float o = oppsrc[j];
             popp[j] = a.input_is_log ? expf(o) : o;
@@ -112,16 +121,6 @@ expand_kernel(ExpandArgs a) {
     auto ESC = [&](int idx) { return idx < n ? sx[idx] * sy[idx] : ZERO_F; };        // :1206-1207
     auto EOPP = [&](int idx) { return popp[idx]; };                                  // :1208
 
-    // argmax over the real columns (:1182) and over all columns (:1191), first index on ties
-    float bv = -INFINITY, bva = -INFINITY;
-    int bi = 0x7fffffff, bia = 0x7fffffff;
-    float rowsum = 0.f;
-    for (int j = t; j < N; j += 16) {
-        const float x = prow[j];
-        rowsum += x;
-        if (j < n && (x > bv || bi == 0x7fffffff)) { bv = x; bi = j; }
-        if (x > bva || bia == 0x7fffffff) { bva = x; bia = j; }
-    }
     row16_argmax(bv, bi);
     row16_argmax(bva, bia);
     const float the_scale = row16_sum(rowsum);                      // scores.sum(2)  (:1288)
@@ -229,9 +228,14 @@ expand_kernel(ExpandArgs a) {
 
     // in-rectangle weights, centroid and scale (:1254-1273, Compute_scaling :1321-1340)
     float wx = 0.f, wy = 0.f, sumx = 0.f, sumy = 0.f, ws = 0.f, so = 0.f;
-    for (int p = t; p < n; p += 16) {
-        const int pyi = p / a.w, pxi = p - pyi * a.w;               // positions (:1528-1532)
+    // positions (:1528-1532) of cells t, t + 16, ... kept incrementally (one division for the whole loop); a 16-cell band that
+    // no rectangle of the wave's four rows reaches adds exact zeros to every accumulator and is skipped as a whole
+    const int q16 = 16 / a.w, r16 = 16 - q16 * a.w;
+    int pyi = t / a.w, pxi = t - pyi * a.w;
+    for (int p = t; p < n; p += 16, pyi += q16, pxi += r16) {
+        if (pxi >= a.w) { pxi -= a.w; ++pyi; }
         const bool crit = pyi >= up && pyi <= down && pxi >= left && pxi <= right;
+        if (!__any(crit)) continue;
         const float fx = sx[p], fy = sy[p];
         float ox = ZERO_F, oy = ZERO_F;
         if (crit) {                                                 // the rectangle is a few cells: most passes skip the sqrt and the two divisions
