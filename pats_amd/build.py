@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libpats_amd.so")
 # diagnostic twin: the same objects, third_fused3.hip compiled with -DPATS_DIAG (every sweep-loop variant and the timing
 # ablations whose results are wrong by design).  Built on request only (`--diag`); never loaded unless PATS_AMD_DIAG_LIB=1.
 LIB_DIAG = os.path.join(HERE, "libpats_amd_diag.so")
-DIAG_SOURCES = {"third_fused3.hip": ["-DPATS_DIAG=1"]}
+DIAG_SOURCES = {"third_fused3.hip": ["-DPATS_DIAG=1"], "sinkhorn_blk.hip": ["-DPATS_DIAG=1"]}
 SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip", "gnn.hip",
            "fused.hip", "scale_head.hip", "batch.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
@@ -30,11 +30,67 @@ def hipcc():
     return exe
 
 
+def llvm_tool(name):
+    for d in (os.path.join(os.path.dirname(os.path.realpath(hipcc())), "..", "lib", "llvm", "bin"), "/opt/rocm/lib/llvm/bin"):
+        exe = os.path.join(d, name)
+        if os.path.exists(exe):
+            return exe
+    raise RuntimeError("%s not found next to hipcc - libpats_amd.so cannot be built" % name)
+
+
+def compile_tu(spath, obj, extra=(), verbose=False):
+    """One translation unit -> host object with the gfx950 code object embedded, in hipcc's own steps, with the device
+    ASSEMBLY passed through pats_amd/asm_pass.py in between (the LDS wait hipcc leaves out in front of some barriers: see
+    that file): device compile to .s -> fix-ups -> assemble -> link the code object -> bundle -> host compile embedding it."""
+    from . import asm_pass
+    stem = obj[:-2]
+    flags = FLAGS[:-2] + list(extra) + FLAGS[-2:]
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if p.returncode != 0:
+            sys.stderr.write(p.stdout.decode())
+            raise RuntimeError("build step failed on %s: %s" % (os.path.basename(spath), " ".join(cmd[:3])))
+        return p.stdout.decode()
+
+    asm = stem + ".gfx950.s"
+    run([hipcc()] + flags + ["-S", "--offload-device-only", spath, "-o", asm])
+    with open(asm) as f:
+        # PATS_BUILD_TRANS_FENCE / PATS_BUILD_NO_BARRIER_WAIT: experiment switches for A/B builds of the diagnostic library
+        text, fences = asm_pass.fence_asm(f.read(), trans="PATS_BUILD_TRANS_FENCE" in os.environ,
+                                          barriers="PATS_BUILD_NO_BARRIER_WAIT" not in os.environ)
+    with open(asm, "w") as f:
+        f.write(text)
+    run([llvm_tool("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", stem + ".gfx950.o"])
+    run([llvm_tool("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", stem + ".hsaco", stem + ".gfx950.o"])
+    run([llvm_tool("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + stem + ".hsaco",
+         "-output=" + stem + ".hipfb"])
+    out = run([hipcc()] + flags + ["-c", spath, "--offload-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb",
+                                   "-o", obj])
+    if verbose:
+        print("%s: %d assembly fix-ups" % (os.path.basename(spath), fences))
+        if out:
+            print(out)
+    return fences
+
+
+def compile_many(jobs, verbose=False):
+    """jobs: [(source path, object path, extra flags)] compiled concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        futs = [ex.submit(compile_tu, s, o, e, verbose) for s, o, e in jobs]
+        return [f.result() for f in futs]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pats_amd.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pats_amd.h"),
+                                                                os.path.join(HERE, "asm_pass.py")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -51,11 +107,7 @@ def build_diag(force=False, verbose=False, suffix="", defines=()):
             objs.append(os.path.join(objdir, stem + ".o"))
             continue
         obj = os.path.join(objdir, stem + "_diag%s.o" % suffix)
-        cmd = [hipcc()] + FLAGS[:-2] + EXTRA_FLAGS.get(src, []) + DIAG_SOURCES[src] + list(defines) + FLAGS[-2:] + \
-              ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        compile_tu(os.path.join(CSRC, src), obj, EXTRA_FLAGS.get(src, []) + DIAG_SOURCES[src] + list(defines), verbose)
         objs.append(obj)
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_out])
     return lib_out
@@ -67,28 +119,21 @@ def build(force=False, verbose=False):
     objs = []
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    procs = []
+    jobs = []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         spath = os.path.join(CSRC, src)
         # every object depends on every header (a struct shared through a .hpp must never be seen in two layouts)
         headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + \
-                  [os.path.join(HERE, "..", "include", "pats_amd.h")]
+                  [os.path.join(HERE, "..", "include", "pats_amd.h"), os.path.join(HERE, "asm_pass.py")]
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
                 and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in headers)):
             continue
-        cmd = [hipcc()] + FLAGS[:-2] + EXTRA_FLAGS.get(src, []) + FLAGS[-2:] + ["-c", spath, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            sys.stderr.write(out.decode())
-            raise RuntimeError("hipcc failed on %s" % src)
-        if verbose and out:
-            print(out.decode())
+        jobs.append((spath, obj, EXTRA_FLAGS.get(src, [])))
+    fences = compile_many(jobs, verbose)
+    if verbose and jobs:
+        print("assembly fix-ups (barrier waits): %d" % sum(fences))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     subprocess.check_call(cmd)
     return LIB

@@ -54,32 +54,59 @@ struct OpMax {
     __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
 };
 
+// ---- exchanges between the halves of a wave / between neighbouring 16-lane rows --------------------------------------
+// lane_swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b; lane_swap16(a, b): the odd 16-lane rows of a <-> the even rows
+// of b, in place (v_permlane32_swap_b32 / v_permlane16_swap_b32).  The builtin returns both registers; hipcc (ROCm 7.2)
+// mis-folds the pair when it can see through it - op(r[0], r[1]) came out as op(r[0], r[0]) (a wave sum returned 4 x the row
+// total on hardware) - so the second operand and both results pass through empty asm to stay opaque.
+// -DPATS_NO_PERMLANE_SWAP: the same exchanges on the LDS crossbar (ds_bpermute_b32 / ds_swizzle_b32; every lane hands its
+// partner the one value the partner wants) - the A/B partner used while hunting the round-3 barrier bug (asm_pass.py).
+#ifndef PATS_NO_PERMLANE_SWAP
+__device__ __forceinline__ void lane_swap32(unsigned& a, unsigned& b) {
+    asm volatile("" : "+v"(b));
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap16(unsigned& a, unsigned& b) {
+    asm volatile("" : "+v"(b));
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+}
+#else
+__device__ __forceinline__ void lane_swap32(unsigned& a, unsigned& b) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool lo = lane < 32u;
+    const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)(lo ? b : a));
+    a = lo ? a : got;
+    b = lo ? got : b;
+}
+__device__ __forceinline__ void lane_swap16(unsigned& a, unsigned& b) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool even = (lane & 16u) == 0u;
+    const unsigned got = (unsigned)__builtin_amdgcn_ds_swizzle((int)(even ? b : a), (16 << 10) | 0x1f);     // lane ^ 16
+    a = even ? a : got;
+    b = even ? got : b;
+}
+#endif
+
 template <class Op>
 __device__ __forceinline__ float wave_allreduce(float v, Op op) {
     v = op(v, dpp_f<DPP_QUAD_XOR1>(v));
     v = op(v, dpp_f<DPP_QUAD_XOR2>(v));
     v = op(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
     v = op(v, dpp_f<DPP_ROW_MIRROR>(v));
-    // rows of 16 now hold their totals; exchange rows 0<->1, 2<->3 then halves 0<->1.
-    // v_permlane{16,32}_swap exchange IN PLACE between two distinct VGPRs and the builtin returns
-    // both.  hipcc (ROCm 7.2) mis-folds the pair when it can see through it - op(r[0], r[1]) came
-    // out as op(r[0], r[0]) (a wave sum returned 4 x the row total on hardware) - so the second
-    // operand and both results are passed through empty asm to keep them opaque.
+    // rows of 16 now hold their totals; exchange rows 0<->1, 2<->3 then halves 0<->1
     {
         unsigned x = __builtin_bit_cast(unsigned, v), y = x;
-        asm volatile("" : "+v"(y));
-        auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
-        unsigned a = r[0], b = r[1];
-        asm volatile("" : "+v"(a), "+v"(b));
-        v = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+        lane_swap16(x, y);
+        v = op(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
     }
     {
         unsigned x = __builtin_bit_cast(unsigned, v), y = x;
-        asm volatile("" : "+v"(y));
-        auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-        unsigned a = r[0], b = r[1];
-        asm volatile("" : "+v"(a), "+v"(b));
-        v = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+        lane_swap32(x, y);
+        v = op(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
     }
     return v;
 }

@@ -45,29 +45,22 @@ __device__ __forceinline__ float reduce8_consecutive(const float (&p)[8], Op op,
     return b0 ? y : x;
 }
 
-// in-place exchange of two registers between wave halves / 16-lane rows, with the operands and
-// results kept opaque (see common.hpp: hipcc mis-folds the paired result otherwise)
+// in-place exchange of two registers between wave halves / 16-lane rows (common.hpp: lane_swap32 / lane_swap16)
 __device__ __forceinline__ void swap32(float& x, float& y) {
     unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
-    asm volatile("" : "+v"(b));
     PATS_SWAP_FENCE(a, b);
-    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    unsigned c = r[0], d = r[1];
-    asm volatile("" : "+v"(c), "+v"(d));
-    PATS_SWAP_FENCE(c, d);
-    x = __builtin_bit_cast(float, c);
-    y = __builtin_bit_cast(float, d);
+    lane_swap32(a, b);
+    PATS_SWAP_FENCE(a, b);
+    x = __builtin_bit_cast(float, a);
+    y = __builtin_bit_cast(float, b);
 }
 __device__ __forceinline__ void swap16(float& x, float& y) {
     unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
-    asm volatile("" : "+v"(b));
     PATS_SWAP_FENCE(a, b);
-    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    unsigned c = r[0], d = r[1];
-    asm volatile("" : "+v"(c), "+v"(d));
-    PATS_SWAP_FENCE(c, d);
-    x = __builtin_bit_cast(float, c);
-    y = __builtin_bit_cast(float, d);
+    lane_swap16(a, b);
+    PATS_SWAP_FENCE(a, b);
+    x = __builtin_bit_cast(float, a);
+    y = __builtin_bit_cast(float, b);
 }
 
 template <class Op>

@@ -688,21 +688,15 @@ struct RowReduce {
         for (int i = 0; i < N1; ++i) {
             unsigned x = __builtin_bit_cast(unsigned, pf(i));
             unsigned y = __builtin_bit_cast(unsigned, (i + N1 < RPW) ? pf(i + N1 < RPW ? i + N1 : 0) : identity);
-            asm volatile("" : "+v"(y));
-            auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-            unsigned a = r[0], b = r[1];
-            asm volatile("" : "+v"(a), "+v"(b));
-            a1[i] = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+            lane_swap32(x, y);
+            a1[i] = op(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
         }
 #pragma unroll
         for (int i = 0; i < N2; ++i) {
             unsigned x = __builtin_bit_cast(unsigned, a1[i]);
             unsigned y = __builtin_bit_cast(unsigned, (i + N2 < N1) ? a1[i + N2] : identity);
-            asm volatile("" : "+v"(y));
-            auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
-            unsigned a = r[0], b = r[1];
-            asm volatile("" : "+v"(a), "+v"(b));
-            float v = op(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+            lane_swap16(x, y);
+            float v = op(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
             v = op(v, dpp_f<DPP_QUAD_XOR1>(v));
             v = op(v, dpp_f<DPP_QUAD_XOR2>(v));
             v = op(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));

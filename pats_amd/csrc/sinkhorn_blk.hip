@@ -20,6 +20,7 @@
 // VALU-bound.  A problem whose scalings leave the guard band sets fail[p]; the host re-runs those
 // with sinkhorn_rc_kernel's log-sum-exp sweeps.
 #include "lane_reduce.hpp"
+#include <stdlib.h>
 
 namespace pats {
 
@@ -43,6 +44,30 @@ struct __attribute__((aligned(16))) BlkLds {
     float misc[8];
     float tmp[NB * 17];          // one-time: partial maxima for the stabilisers
 };
+
+// experiment hooks (libpats_amd_diag<suffix>.so, tools/fine_determinism4.py)
+#ifdef PATS_EXPB_WSUM
+#define BLK_WSUM(x) wave_sum(x)                 // crossbar all-reduce instead of row_bcast DPP + v_readlane
+#else
+#define BLK_WSUM(x) wave_sum_uniform(x)
+#endif
+typedef float f2e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2e blk_fma2(f2e a, f2e b, f2e c) {
+#ifdef PATS_EXPB_NOPK
+    return f2e{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};      // two v_fma_f32 instead of v_pk_fma_f32 (build with -fno-slp-vectorize)
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+__device__ __forceinline__ f2e blk_mul2(f2e a, f2e b) {
+#ifdef PATS_EXPB_NOPK
+    return f2e{a.x * b.x, a.y * b.y};
+#else
+    return a * b;
+#endif
+}
+
+__device__ __forceinline__ float mul_rcp(float num, float den) { return num * __builtin_amdgcn_rcpf(den); }
 
 __device__ __forceinline__ void load9(const float* v, float (&o)[BS]) {
     const f4v a = *reinterpret_cast<const f4v*>(v), b = *reinterpret_cast<const f4v*>(v + 4);
@@ -194,25 +219,25 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             const f2v b01 = {bl[0], bl[1]}, b23 = {bl[2], bl[3]}, b45 = {bl[4], bl[5]}, b67 = {bl[6], bl[7]};
             f2v acc[BS];
 #pragma unroll
-            for (int r = 0; r < BS; ++r) acc[r] = f2v{kb[r][0], kb[r][1]} * b01;
+            for (int r = 0; r < BS; ++r) acc[r] = blk_mul2(f2v{kb[r][0], kb[r][1]}, b01);
 #pragma unroll
-            for (int r = 0; r < BS; ++r) acc[r] = __builtin_elementwise_fma(f2v{kb[r][2], kb[r][3]}, b23, acc[r]);
+            for (int r = 0; r < BS; ++r) acc[r] = blk_fma2(f2v{kb[r][2], kb[r][3]}, b23, acc[r]);
 #pragma unroll
-            for (int r = 0; r < BS; ++r) acc[r] = __builtin_elementwise_fma(f2v{kb[r][4], kb[r][5]}, b45, acc[r]);
+            for (int r = 0; r < BS; ++r) acc[r] = blk_fma2(f2v{kb[r][4], kb[r][5]}, b45, acc[r]);
 #pragma unroll
-            for (int r = 0; r < BS; ++r) acc[r] = __builtin_elementwise_fma(f2v{kb[r][6], kb[r][7]}, b67, acc[r]);
+            for (int r = 0; r < BS; ++r) acc[r] = blk_fma2(f2v{kb[r][6], kb[r][7]}, b67, acc[r]);
 #pragma unroll
             for (int r = 0; r < BS; ++r) part[r] = fmaf(kb[r][8], bl[8], acc[r].x) + acc[r].y;
-            const float dsum = wave_sum_uniform(kdr * b);
+            const float dsum = BLK_WSUM(kdr * b);
             const float s = fmaf(kdc, b_d, row16_reduce9(part, lane));
-            a = mu * __builtin_amdgcn_rcpf(s);
+            a = mul_rcp(mu, s);
             if (rown) lds.va[I * VS + J] = a;
             if (lane == 0) lds.red_r[wave] = dsum;
         }
         __syncthreads();                              // a and the dustbin-row partials visible
         {   // ---- b_j = nu_j / sum_i K_ij a_i -----------------------------------------------------
             const f4v dr = *reinterpret_cast<const f4v*>(lds.red_r);
-            a_d = mu_d * __builtin_amdgcn_rcpf(fmaf(kcorner, b_d, (dr.x + dr.y) + (dr.z + dr.w)));
+            a_d = mul_rcp(mu_d, fmaf(kcorner, b_d, (dr.x + dr.y) + (dr.z + dr.w)));
             float al[BS];
             load9(&lds.va[I * VS], al);
             f2v q01 = {0.f, 0.f}, q23 = {0.f, 0.f}, q45 = {0.f, 0.f}, q67 = {0.f, 0.f};
@@ -220,10 +245,10 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
                 const f2v ar = {al[r], al[r]};
-                q01 = __builtin_elementwise_fma(f2v{kb[r][0], kb[r][1]}, ar, q01);
-                q23 = __builtin_elementwise_fma(f2v{kb[r][2], kb[r][3]}, ar, q23);
-                q45 = __builtin_elementwise_fma(f2v{kb[r][4], kb[r][5]}, ar, q45);
-                q67 = __builtin_elementwise_fma(f2v{kb[r][6], kb[r][7]}, ar, q67);
+                q01 = blk_fma2(f2v{kb[r][0], kb[r][1]}, ar, q01);
+                q23 = blk_fma2(f2v{kb[r][2], kb[r][3]}, ar, q23);
+                q45 = blk_fma2(f2v{kb[r][4], kb[r][5]}, ar, q45);
+                q67 = blk_fma2(f2v{kb[r][6], kb[r][7]}, ar, q67);
                 q8 = fmaf(kb[r][8], al[r], q8);
             }
             // over the wave's four DPP rows: permlane32 pairs (0,1)(2,3)(4,5)(6,7), then permlane16 pairs;
@@ -242,16 +267,16 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             lds.cpart[(BS * J + cA) * 4 + wave] = z0;
             lds.cpart[(BS * J + cA + 4) * 4 + wave] = z1;
             if (rho == 0) lds.cpart[(BS * J + 8) * 4 + wave] = z2;
-            const float dsum = wave_sum_uniform(kdc * a);
+            const float dsum = BLK_WSUM(kdc * a);
             if (lane == 0) lds.red_c[wave] = dsum;
         }
         __syncthreads();                              // column partials visible
         {
             const f4v dc = *reinterpret_cast<const f4v*>(lds.red_c);
-            b_d = nu_d * __builtin_amdgcn_rcpf(fmaf(kcorner, a_d, (dc.x + dc.y) + (dc.z + dc.w)));
+            b_d = mul_rcp(nu_d, fmaf(kcorner, a_d, (dc.x + dc.y) + (dc.z + dc.w)));
             const f4v cp = *reinterpret_cast<const f4v*>(&lds.cpart[colj * 4]);
             const float tsum = fmaf(kdr, a_d, (cp.x + cp.y) + (cp.z + cp.w));
-            b = nu * __builtin_amdgcn_rcpf(tsum);
+            b = mul_rcp(nu, tsum);
             if (cown) lds.vb[J * VS + I] = b;
         }
     }
@@ -333,11 +358,18 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
 int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                   const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
                   uint8_t* col_nomatch, hipStream_t st) {
+    // libpats_amd_diag.so only: dynamic LDS the kernel never touches lowers the occupancy (13.7 KB per workgroup: three per
+    // CU by registers; + 41 KB = the cost build's staging area -> two) - what the sweeps would cost inside a kernel that
+    // also holds the cost build's LDS and registers ("fine-level fusion")
+    unsigned pad = 0;
+#ifdef PATS_DIAG
+    if (const char* e = getenv("PATS_BLK_LDS_PAD")) pad = (unsigned)atoi(e);
+#endif
     if (mode == 0)
-        hipLaunchKernelGGL((sinkhorn_blk145_kernel<0>), dim3((unsigned)batch), dim3(256), 0, st, Z, log_mu, log_nu,
+        hipLaunchKernelGGL((sinkhorn_blk145_kernel<0>), dim3((unsigned)batch), dim3(256), pad, st, Z, log_mu, log_nu,
                            (const float*)nullptr, (const float*)nullptr, iters, 0.f, out, fail, col_nomatch);
     else
-        hipLaunchKernelGGL((sinkhorn_blk145_kernel<2>), dim3((unsigned)batch), dim3(256), 0, st, Z,
+        hipLaunchKernelGGL((sinkhorn_blk145_kernel<2>), dim3((unsigned)batch), dim3(256), pad, st, Z,
                            (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch);
     return check_launch("sinkhorn_blk145_kernel");
 }

@@ -115,3 +115,36 @@ def test_production_library_carries_no_diagnostic_kernels(lib):
     inst = sorted(set(re.findall(r"third_fused3_kernel<[^>]*>", syms)))
     assert inst == ["third_fused3_kernel<3, 0, 0, 0>", "third_fused3_kernel<3, 0, 5, 1>"], inst
     assert "libpats_amd.so" in _lib.LIB_PATH and "diag" not in os.path.basename(_lib.LIB_PATH)
+
+
+def test_every_barrier_of_the_shipped_code_waits_for_lds_first():
+    """pats_amd/asm_pass.py rule 1 on the code objects INSIDE the built library: hipcc (ROCm 7.2) leaves `s_waitcnt
+    lgkmcnt(0)` out in front of some s_barrier (25 of 219 here, e.g. the top of the fine-level sweep loop, whose latch ends
+    in the ds_write of this wave's part of the scaling vector) and on MI355X the waves the barrier releases then read LDS
+    the late wave has not written: the run-to-run differences tests/test_determinism_gpu.py now guards against.  The
+    build inserts the wait; this asserts that what ships has it everywhere."""
+    import importlib.util
+    import shutil
+    if shutil.which("llvm-objdump") is None and not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("check_code_objects", os.path.join(REPO, "tools", "check_code_objects.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from pats_amd import build
+    t = mod.check(build.LIB)
+    assert t["objects"] >= 15 and t["barriers"] > 150
+    assert t["bare"] == [], "s_barrier without an LDS wait in: %s" % sorted({k for k, _ in t["bare"]})
+
+
+def test_asm_pass_puts_the_wait_behind_a_label_and_leaves_existing_ones_alone():
+    from pats_amd import asm_pass
+    src = "\n".join(["k:", "\tds_write_b32 v1, v2 offset:768", "\ts_branch .L1", ".L0:", "\ts_waitcnt lgkmcnt(0)", "\ts_barrier",
+                     ".L1:", "\ts_barrier", "\tds_read_b32 v3, v1", "\ts_waitcnt vmcnt(0) lgkmcnt(0)", "\ts_barrier",
+                     "\ts_waitcnt lgkmcnt(0)", ".L2:", "\ts_barrier", "\ts_endpgm"])
+    out, n = asm_pass.fence_asm(src)
+    lines = [ln.strip() for ln in out.split("\n")]
+    assert n == 2                                           # behind .L1 and behind .L2 (a label separates the wait from the barrier)
+    for k, ln in enumerate(lines):
+        if ln == "s_barrier":
+            assert lines[k - 1].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[k - 1]
+    assert lines.count("s_barrier") == 4 and out.count("s_waitcnt") == 5
