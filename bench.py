@@ -884,22 +884,6 @@ def main():
         if not args.no_secondary and n_gpus == 1:
             res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
-            if streams is None:
-                # the same steps with the HBM-bound and the VALU-bound stages of neighbouring batches on two HIP streams with
-                # disjoint CU masks (3 / 5 of every 8 CUs per shader engine; --overlap 3): a secondary number, the bench line and
-                # its rooflines stay on one stream where every kernel has the whole GPU
-                try:
-                    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-                    ms_ = (ops.masked_stream([c for c in range(n_cu) if c // 32 < 3]), ops.masked_stream([c for c in range(n_cu) if c // 32 >= 3]))
-                    run_steps(batch, nets, cap, wl, None, 2, ms_)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    run_steps(batch, nets, cap, wl, None, 6, ms_)
-                    torch.cuda.synchronize()
-                    res["overlap_cu_masked"] = {"pairs_per_s": 6 * pairs / (time.perf_counter() - t0), "gather_stream_cus": 96, "solver_stream_cus": 160,
-                                                "note": "bench.py --overlap 3; profiles/r03_cu_mask_probe.txt"}
-                except RuntimeError as err:
-                    res["overlap_cu_masked"] = {"error": str(err)[:200]}
             res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and n_gpus == 1:

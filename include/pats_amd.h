@@ -50,6 +50,12 @@ const char* pats_last_error(void);
 int pats_device_count(void);
 /* process-wide default for PATS_SINKHORN_AUTO (returns the previous value) */
 int pats_set_sinkhorn_mode(int mode);
+/* Fine level of pats_cost_ot_f32 / pats_cost_ot_flags_f32 (variant 2, 145 x 145): 0 (default) = the MFMA cost kernel, then the
+ * register-block Sinkhorn kernel; 1 = ONE kernel that builds the score tile, turns it into the register blocks through LDS
+ * and solves - the scores never reach HBM (second_layer.py:100-105 in one launch).  Same bits either way
+ * (tests/test_gpu_parity.py); measured 5.69 against 5.62 ms per 20 224 problems.  Returns the
+ * previous setting; PATS_FINE_FUSED=1 in the environment sets the initial one. */
+int pats_set_fine_fused(int on);
 
 /* Number of problems (on the current device, since the last reset) whose linear-domain solve left the
  * guard band and was re-solved with log-sum-exp sweeps.  Results are the same either way; a high rate

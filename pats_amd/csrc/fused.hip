@@ -14,6 +14,11 @@ int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_n
                      hipStream_t st);
 }
 
+namespace pats {
+int launch_fine145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
+                         float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied);
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int variant) {
@@ -64,6 +69,15 @@ static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, 
     float* scores = (float*)workspace;
     const size_t off = align256((size_t)batch * n * m * sizeof(float));
     void* ws2 = (char*)workspace + off;
+    if (variant == 2 && n == 145 && m == 145) {
+        // the fine level: cost build and OT in ONE kernel, the score matrix never reaches HBM (sinkhorn_blk.hip, FUSED);
+        // the guard flags sit where the unfused path keeps them
+        PATS_REQUIRE(d0 && d1 && ns && Z, "cost_ot: null pointer");
+        bool applied = false;
+        int rc = launch_fine145_fused(d0, d1, D, batch, ns, scalar, iters, bias_k, Z, (int*)ws2, col_nomatch, (hipStream_t)stream,
+                                      &applied);
+        if (rc || applied) return rc;
+    }
     int rc = pats_cost_f32(d0, d1, batch, D, n, m, scores, stream);
     if (rc) return rc;
     if (variant == 1) {

@@ -1,5 +1,6 @@
 // Host-side pieces of libpats_amd.so: error plumbing, version, and the chunk planner.
 #include "common.hpp"
+#include <stdlib.h>
 #include "chunk_plan.hpp"
 
 #include <mutex>
@@ -106,6 +107,16 @@ extern "C" int pats_set_sinkhorn_mode(int mode) {
     const int prev = g_mode;
     if (mode == PATS_SINKHORN_AUTO || mode == PATS_SINKHORN_LOG || mode == PATS_SINKHORN_KERNEL)
         g_mode = mode;
+    return prev;
+}
+
+// fine level (145 x 145, pats_cost_ot_f32 variant 2): 0 = cost_mfma_kernel + sinkhorn_blk145_kernel (default: measured 1 % faster),
+// 1 = the fused kernel (sinkhorn_blk.hip FUSED: no score matrix in HBM, two workgroups per CU).  PATS_FINE_FUSED=1 sets the default.
+static int g_fine_fused = getenv("PATS_FINE_FUSED") && atoi(getenv("PATS_FINE_FUSED")) != 0;
+namespace pats { bool fine_fused() { return g_fine_fused != 0; } }
+extern "C" int pats_set_fine_fused(int on) {
+    const int prev = g_fine_fused;
+    g_fine_fused = on != 0;
     return prev;
 }
 

@@ -993,6 +993,29 @@ static int launch_fine145(int mode, const float* Z, int64_t batch, const float* 
     return rc;
 }
 
+// The fused fine-level step (sinkhorn_blk.hip, FUSED): descriptors -> log-plan in one kernel; problems that leave the guard
+// band come back as their raw scores in `out` and the log-domain kernel redoes them IN PLACE (it stages the whole matrix in
+// LDS before it writes).  *applied = false: the caller takes the two-kernel path (the default; also forced log domain, iters == 0).
+namespace pats {
+bool fine_fused();       // host.cpp
+int launch_blk145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
+                        float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st);
+int launch_fine145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
+                         float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied) {
+    static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;
+    *applied = fine_fused() && use_linear() && iters > 0 && fail && !v1_only && D > 0;       // pats_set_fine_fused / PATS_FINE_FUSED
+    if (!*applied) return PATS_OK;
+    int rc = launch_blk145_fused(d0, d1, D, batch, ns, one, iters, bias_k, out, fail, col_nomatch, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, (const float*)out, batch,
+                       (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, 0, out, fallback_counter(),
+                       (const int*)fail);
+    rc = check_launch("sinkhorn_rc_kernel<145>(redo)");
+    if (!rc && col_nomatch) rc = launch_col_flags(out, batch, NF, NF, col_nomatch, fail, st);
+    return rc;
+}
+}  // namespace pats
+
 extern "C" size_t pats_sinkhorn_workspace_bytes(int64_t batch, int M, int N) {
     if (M == NF && N == NF) return (size_t)((batch + 63) & ~63ll) * sizeof(int);     // guard flags (optional: see launch_fine145)
     if (resident_shape(M, N)) return 0;

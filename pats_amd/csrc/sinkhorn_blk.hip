@@ -20,6 +20,7 @@
 // VALU-bound.  A problem whose scalings leave the guard band sets fail[p]; the host re-runs those
 // with sinkhorn_rc_kernel's log-sum-exp sweeps.
 #include "lane_reduce.hpp"
+#include "mfma_tile.hpp"
 #include <stdlib.h>
 
 namespace pats {
@@ -97,15 +98,92 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// ---- FUSED: the score matrix built in the kernel (second_layer.py:100-101,104 -> :105 in one launch) ---------------------
+// The workgroup first runs the 160 x 160 MFMA tile of mfma_tile.hpp on the problem's two [D,145] descriptor blocks (the
+// same code, the same bits as cost_mfma_kernel), then turns the accumulator fragments into the 9 x 9 register blocks of
+// the sweeps through a 32-row band buffer in LDS (the staging area of the cost build, free by then): tile row b of the
+// five is written by the wave(s) that hold it, every lane picks up the rows of its block that lie in the band.  The scores
+// never reach HBM; the lane keeps its block (Z, 81 registers) beside K for the epilogue's ((Z + u) + v) - norm, which is why
+// this variant is built for two workgroups per CU (256 VGPRs): tools/fine_fusion_probe.py measured the sweeps of the
+// unfused kernel at that occupancy within 1-3 % of three workgroups per CU.
+struct FineCols {
+    __device__ __forceinline__ int64_t a_off(int c) const { return c < N_ ? c : N_ - 1; }
+    __device__ __forceinline__ int64_t b_off(int c) const { return c < N_ ? c : N_ - 1; }
+    __device__ __forceinline__ bool row_stored(int r) const { return r < N_; }
+    __device__ __forceinline__ bool col_stored(int c) const { return c < N_; }
+};
+constexpr int BAND_LD = 164;
+union __attribute__((aligned(16))) FusedLds {
+    mt::Lds cost;
+    float band[32 * BAND_LD];
+};
+
+__device__ __forceinline__ void fine_cost_block(const float* __restrict__ A, const float* __restrict__ B, int D, float rsqrtD,
+                                                float sqrtD, FusedLds& fl, float (&zb)[BS][BS], float& zdc, float& zdr,
+                                                float& zcorner, int t) {
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lk = lane >> 5;
+    const int J = t & 15, I = t >> 4;
+    const bool rown = J < BS, cown = I < BS;
+    const int rowi = BS * I + (rown ? J : 0), colj = BS * J + (cown ? I : 0);
+    const FineCols cols;
+    mt::CmSrc<FineCols> src(A, N_, B, N_, D, cols, t);
+    mt::f32x16 acc[7];
+    const float unscale = mt::tile<true, true>(src, (mt::CmSrc<FineCols>*)nullptr, fl.cost, acc, true, t, wave);
+    // `scores / D ** .5`, then `0.1 * scores`, exactly as cost_mfma_kernel stores them
+    auto scaled = [&](float x) { return 0.1f * div_invariant(x * unscale, sqrtD, rsqrtD); };
+    zdc = -INFINITY;
+    zdr = -INFINITY;
+    zcorner = 0.f;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        __syncthreads();                                  // the band buffer (b == 0: the cost build's staging area) is free
+        if (b < 4) {
+            if (wave == b) {
+#pragma unroll
+                for (int tj = 0; tj < 5; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        fl.band[((r & 3) + 8 * (r >> 2) + 4 * lk) * BAND_LD + 32 * tj + li] = scaled(acc[tj][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fl.band[((r & 3) + 8 * (r >> 2) + 4 * lk) * BAND_LD + 32 * wave + li] = scaled(acc[5][r]);
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fl.band[((r & 3) + 8 * (r >> 2) + 4 * lk) * BAND_LD + 128 + li] = scaled(acc[6][r]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            const int row = BS * I + r;
+            if ((row >> 5) == b) {
+                const float* src_row = &fl.band[(row - 32 * b) * BAND_LD + BS * J];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) zb[r][c] = src_row[c];
+            }
+        }
+        if (rown && (rowi >> 5) == b) zdc = fl.band[(rowi - 32 * b) * BAND_LD + NB];
+        if (b == 4) {
+            if (cown) zdr = fl.band[(NB - 128) * BAND_LD + colj];
+            zcorner = fl.band[(NB - 128) * BAND_LD + NB];
+        }
+    }
+    __syncthreads();
+}
+
 }  // namespace
 
 // MODE 0: log_mu / log_nu given (a6)      MODE 2: ns given, log_optimal_transport2 marginals (a5)
-template <int MODE>
-__global__ void __launch_bounds__(256, 3)
+// FUSED: Zin unused, the scores come from the descriptor blocks d0, d1 [batch, D, 145] (see fine_cost_block)
+template <int MODE, bool FUSED = false>
+__global__ void __launch_bounds__(256, FUSED ? 2 : 3)
 sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ log_mu_in,
                        const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                        const float* __restrict__ one, int iters, float bias_k, float* __restrict__ out,
-                       int* __restrict__ fail, uint8_t* __restrict__ col_nomatch) {
+                       int* __restrict__ fail, uint8_t* __restrict__ col_nomatch,
+                       const float* __restrict__ d0 = nullptr, const float* __restrict__ d1 = nullptr, int D = 0,
+                       float rsqrtD = 0.f, float sqrtD = 0.f) {
     __shared__ BlkLds lds;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, J = t & 15, I = t >> 4, rho = lane >> 4;
     const int64_t p = blockIdx.x;
@@ -119,17 +197,30 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     // 84 KB of a problem then read at a third and wrote at half the rate (tools/store_patterns.hip, patterns g / g4)
     typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
     float kb[BS][BS];
+    float zb[FUSED ? BS : 1][FUSED ? BS : 1];          // FUSED: the scores of this lane's block, kept for the epilogue
+    float zdc, zdr, zcorner;                            // Z[9I+J][144], Z[144][9J+I], Z[144][144]
+    if constexpr (FUSED) {
+        __shared__ FusedLds fl;
+        float zc;
+        fine_cost_block(d0 + p * (int64_t)D * N_, d1 + p * (int64_t)D * N_, D, rsqrtD, sqrtD, fl, zb, zdc, zdr, zc, t);
+        zcorner = uni(zc);
 #pragma unroll
-    for (int r = 0; r < BS; ++r) {
-        const float* row = Zp + (BS * I + r) * N_ + BS * J;
-        const f4a x0 = *reinterpret_cast<const f4a*>(row), x1 = *reinterpret_cast<const f4a*>(row + 4);
-        kb[r][0] = x0.x; kb[r][1] = x0.y; kb[r][2] = x0.z; kb[r][3] = x0.w;
-        kb[r][4] = x1.x; kb[r][5] = x1.y; kb[r][6] = x1.z; kb[r][7] = x1.w;
-        kb[r][8] = row[8];
+        for (int r = 0; r < BS; ++r)
+#pragma unroll
+            for (int c = 0; c < BS; ++c) kb[r][c] = zb[r][c];
+    } else {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            const float* row = Zp + (BS * I + r) * N_ + BS * J;
+            const f4a x0 = *reinterpret_cast<const f4a*>(row), x1 = *reinterpret_cast<const f4a*>(row + 4);
+            kb[r][0] = x0.x; kb[r][1] = x0.y; kb[r][2] = x0.z; kb[r][3] = x0.w;
+            kb[r][4] = x1.x; kb[r][5] = x1.y; kb[r][6] = x1.z; kb[r][7] = x1.w;
+            kb[r][8] = row[8];
+        }
+        zdc = rown ? Zp[rowi * N_ + NB] : -INFINITY;
+        zdr = cown ? Zp[NB * N_ + colj] : -INFINITY;
+        zcorner = uni(Zp[NB * N_ + NB]);
     }
-    const float zdc = rown ? Zp[rowi * N_ + NB] : -INFINITY;        // Z[9I+J][144]
-    const float zdr = cown ? Zp[NB * N_ + colj] : -INFINITY;        // Z[144][9J+I]
-    const float zcorner = uni(Zp[NB * N_ + NB]);
 
     // ---- marginals (modules.py:169-179) -------------------------------------------------------------
     float lmu, lnu, lmu_d, lnu_d, norm = 0.f;
@@ -289,6 +380,18 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     __syncthreads();
     if ((lds.misc[0] * lds.misc[1]) * (lds.misc[2] * lds.misc[3]) < 0.5f) {
         if (t == 0) fail[p] = 1;
+        if constexpr (FUSED) {
+            // the log-domain kernel redoes this problem from its scores: they exist only here, so they go where the plan would
+            // have gone (sinkhorn_rc_kernel stages the whole matrix in LDS before it writes: in place is safe)
+            float* Sp = out + p * (N_ * N_);
+#pragma unroll
+            for (int r = 0; r < BS; ++r)
+#pragma unroll
+                for (int c = 0; c < BS; ++c) Sp[(BS * I + r) * N_ + BS * J + c] = zb[r][c];
+            if (rown) Sp[rowi * N_ + NB] = zdc;
+            if (cown) Sp[NB * N_ + colj] = zdr;
+            if (t == 0) Sp[NB * N_ + NB] = zcorner;
+        }
         return;
     }
     if (t == 0) fail[p] = 0;
@@ -308,8 +411,16 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < BS; ++r) {
         const int e0 = (BS * I + r) * N_ + BS * J;
-        const f4a x0 = *reinterpret_cast<const f4a*>(Zp + e0), x1 = *reinterpret_cast<const f4a*>(Zp + e0 + 4);
-        const float zin[BS] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, Zp[e0 + 8]};
+        float zin[BS];
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int c = 0; c < BS; ++c) zin[c] = zb[r][c];
+        } else {
+            const f4a x0 = *reinterpret_cast<const f4a*>(Zp + e0), x1 = *reinterpret_cast<const f4a*>(Zp + e0 + 4);
+            zin[0] = x0.x; zin[1] = x0.y; zin[2] = x0.z; zin[3] = x0.w;
+            zin[4] = x1.x; zin[5] = x1.y; zin[6] = x1.z; zin[7] = x1.w;
+            zin[8] = Zp[e0 + 8];
+        }
         float o[BS];
 #pragma unroll
         for (int c = 0; c < BS; ++c) {
@@ -372,6 +483,16 @@ int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, 
         hipLaunchKernelGGL((sinkhorn_blk145_kernel<2>), dim3((unsigned)batch), dim3(256), pad, st, Z,
                            (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch);
     return check_launch("sinkhorn_blk145_kernel");
+}
+
+// the fused fine-level step: descriptors [batch, D, 145] x 2 -> log-plan, log_optimal_transport2 marginals (MODE 2)
+int launch_blk145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
+                        float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st) {
+    const float sq = (float)sqrt((double)D);
+    hipLaunchKernelGGL((sinkhorn_blk145_kernel<2, true>), dim3((unsigned)batch), dim3(256), 0, st, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch, d0, d1, D,
+                       1.0f / sq, sq);
+    return check_launch("sinkhorn_blk145_kernel<2, fused>");
 }
 
 }  // namespace pats

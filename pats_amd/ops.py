@@ -80,6 +80,12 @@ def set_sinkhorn_mode(mode):
     return {v: k for k, v in names.items()}[prev]
 
 
+def set_fine_fused(on):
+    """Fine level of cost_ot (variant 2, 145 x 145): True = the fused cost -> OT kernel (no score matrix in HBM), False (default)
+    = MFMA cost kernel + Sinkhorn kernel.  Same bits; returns the previous setting."""
+    return bool(_L().pats_set_fine_fused(1 if on else 0))
+
+
 def sinkhorn_fallbacks(reset=True):
     """Problems on the current device whose linear-domain solve left the guard band and were redone
     with log-sum-exp sweeps since the last reset (pats_sinkhorn_fallbacks; synchronises)."""
