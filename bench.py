@@ -610,6 +610,33 @@ def gather_layout_ab(ops, dev, cap, P_step, rows=2048):
             "third_desc_ms": {"nchw": t_nchw * kt, "channels_last": t_nhwc * kt}, "outputs_bit_identical": bool(same)}
 
 
+def step_determinism(batch, nets, cap, wl, n=4):
+    """The bench's steps all run on the same resident inputs: n more of them, every stage's output compared bit for bit with
+    the first one's (the fine-level log-plans, the third-level points, the matches).  Before the round-3 barrier fix
+    (pats_amd/asm_pass.py) the fine level differed in ~10 of 20 224 problems in every step."""
+    kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
+    ref, rep = None, {"steps": n, "fine_log_plan_problems_differing": [], "third_level_points_differing": [],
+                      "matches_differing": [], "match_count_equal": True}
+    for k in range(n):
+        out = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, **kw)
+        M = int(out["M"].item())
+        cur = {"Z2": out["stages"]["Z2"].clone(), "m1f": out["stages"]["m1f"].clone(), "ml": out["matches_l"][:M].clone(),
+               "mr": out["matches_r"][:M].clone(), "M": M, "P": int(out["P"].item())}
+        if ref is None:
+            ref = cur
+            continue
+        rep["fine_log_plan_problems_differing"].append(int((cur["Z2"] != ref["Z2"]).flatten(1).any(1).sum().item()))
+        P = min(cur["P"], ref["P"])
+        rep["third_level_points_differing"].append(int((cur["m1f"][:P] != ref["m1f"][:P]).flatten(1).any(1).sum().item()))
+        same = cur["M"] == ref["M"]
+        rep["match_count_equal"] = rep["match_count_equal"] and same
+        rep["matches_differing"].append(int(((cur["ml"] != ref["ml"]) | (cur["mr"] != ref["mr"])).any(1).sum().item()) if same else -1)
+        del cur
+    rep["identical"] = rep["match_count_equal"] and not any(rep["fine_log_plan_problems_differing"] + rep["third_level_points_differing"]
+                                                              + rep["matches_differing"])
+    return rep
+
+
 def guard_trip_sweep(ops, batch, nets, cap, wl, fracs=(0.01, 0.10)):
     """pairs/s when a fraction of the fine / third-level problems leaves the linear-domain solver's guard band and is
     re-solved in the log domain: the rows' backbone maps are scaled by 32 (both sides: scores x 1024, far outside the band),
@@ -884,6 +911,7 @@ def main():
         if not args.no_secondary and n_gpus == 1:
             res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
+            res["step_determinism"] = step_determinism(batch, nets, cap, wl)
             res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and n_gpus == 1:
