@@ -828,7 +828,7 @@ def main():
         f_ach = f_by / (fine_ms * 1e-3) / 1e9
         f_parts = [traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145_kernel")[0]]
         f_traffic = float(sum(f_parts)) if all(v is not None for v in f_parts) else None
-        fine_roof = {"bound": "hbm", "kernel": "fine-level cost + Sinkhorn (%d x 145x145 = the row capacity, %d rows in use)"
+        fine_roof = {"bound": "hbm", "kernel": "fine-level launch pair as timed inside the steps: cost_mfma_kernel + sinkhorn_blk145_kernel (%d x 145x145 = the row capacity, %d rows in use)"
                      % (cap.rows_cap, rows_step), "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_ach / HBM_PEAK_GBS,
                      "traffic": f_traffic, "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145_kernel: includes the "
                      "score matrix written by the first and read by the second)", "traffic_source": pmc_src if f_traffic is not None else None,
@@ -836,6 +836,55 @@ def main():
                      "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
                      "note": "descriptors in (2 x 264 x 145 fp32), log-plan out (145 x 145 fp32) per problem; the 100 sweeps run on the "
                              "register-resident blocks (VALU-bound)"}
+        # The fine level is TWO kernels inside one C call (pats_cost_ot_flags_f32): the contract's roofline is per kernel, so each is
+        # timed on its own after the timed steps - same descriptors, same launch sizes, HIP events around ops.cost and around
+        # ops.log_optimal_transport2 on its output (their sum must reproduce the pair's in-step time; both are reported)
+        fine_split = None
+        try:
+            dsc = nets.desc[(nets.fine_calls - 1) & 1]
+            one_t = torch.ones(1, device=dev)
+
+            def _ev_time(fn, reps=5):
+                fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps
+            S_buf = ops.cost(dsc[0], dsc[1])
+            c_ms = _ev_time(lambda: ops.cost(dsc[0], dsc[1]))
+            s_ms = _ev_time(lambda: ops.log_optimal_transport2(S_buf, one_t, nets.ns2, ITERS, bias_k=2.0 if wl["outdoor"] else 3.0))
+            del S_buf
+            fine_split = (c_ms, s_ms)
+        except RuntimeError:
+            pass
+        split_roofs = []
+        if fine_split is not None:
+            c_ms, s_ms = fine_split
+            c_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * cap.rows_cap
+            s_by = (2.0 * 145 * 145 * 4 + 144 * 4) * cap.rows_cap
+            c_tr = traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0]
+            s_tr = traffic_of("pats::sinkhorn_blk145_kernel")[0]
+            split_roofs = [
+                {"bound": "hbm", "kernel": "sinkhorn_blk145_kernel<2> (fine-level OT: %d x 145x145, 100 sweeps)" % cap.rows_cap,
+                 "achieved": s_by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "traffic": s_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if s_tr is not None else None,
+                 "algorithmic_bytes_per_launch": s_by, "avg_launch_ms": s_ms, "launches": 5,
+                 "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (s_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
+                 "timed": "on its own after the timed steps (one C call holds both fine-level kernels); in-step pair %.3f ms" % fine_ms,
+                 "note": "scores in, log-plan out (2 x 145 x 145 fp32 per problem); HBM is the nearer allowed roofline but not the limiter: "
+                         "100 sweeps on register-resident 9x9 blocks, VALU issue (valu_frac = sweep FMA flops / 157.3 TF/s; 203 "
+                         "instructions per wave and sweep, 85 of them packed FMAs)"},
+                {"bound": "hbm", "kernel": "cost_mfma_kernel<true> (fine-level cost build: %d x [264,145]^2)" % cap.rows_cap,
+                 "achieved": c_by / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_by / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "traffic": c_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if c_tr is not None else None,
+                 "algorithmic_bytes_per_launch": c_by, "avg_launch_ms": c_ms, "launches": 5,
+                 "timed": "on its own after the timed steps; in-step pair %.3f ms" % fine_ms,
+                 "note": "both descriptor blocks in, the score matrix out: a streaming kernel (the fp16-split MFMA passes hide under the "
+                         "descriptor stream)"}]
         # the two descriptor gathers (a15 / a16): HBM-bound copies with index arithmetic
         fd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fine_desc"]]))
         td_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["third_desc"]]))
@@ -872,8 +921,9 @@ def main():
                            ("a window row is 32 bytes of a 208-byte row of a channel-major 52x52 map: 2.75 64-byte granules fetched "
                             "per 32 bytes used unless neighbouring points meet in L2 (XCD-aware workgroup order); --maps nhwc: the "
                             "channels-last gather")}
-        ranked = sorted([third_roof, fine_roof, fd_roof, td_roof], key=lambda r: -r["avg_launch_ms"])
-        dominant, other = ranked[0], ranked[1:]
+        # ranked by single KERNELS; the fine level's launch pair as measured inside the steps stays in the list for the cross-check
+        ranked = sorted([third_roof, fd_roof, td_roof] + (split_roofs if split_roofs else [fine_roof]), key=lambda r: -r["avg_launch_ms"])
+        dominant, other = ranked[0], ranked[1:] + ([fine_roof] if split_roofs else [])
         sweeps_per_pair = ITERS * (1 + (rows_step + P_step) / float(pairs))
         res = {
             "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",
