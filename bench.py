@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--maps", choices=["nhwc", "nchw"], default="nhwc",
                     help="memory order of the synthetic backbone maps the two descriptor gathers read: torch.channels_last "
                          "(default) or NCHW-contiguous; same logical tensors, same outputs bit for bit")
+    ap.add_argument("--soak", type=int, default=0, metavar="N",
+                    help="no timing: run N + 1 whole steps on the same inputs and compare every stage's output with the first step's "
+                         "bit for bit (prints the step_determinism object and exits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
@@ -721,6 +724,13 @@ def main():
     cap = batch.Capacities(pairs, h, w, if_local=if_local)
     nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch, channels_last=args.maps == "nhwc")
     n_gpus = dist.get_world_size() if dist is not None else 1
+    if args.soak > 0:
+        rep = step_determinism(batch, nets, cap, wl, n=args.soak + 1)
+        rep["all_zero"] = rep.pop("identical")
+        for k in ("fine_log_plan_problems_differing", "third_level_points_differing", "matches_differing"):
+            rep[k] = {"steps_compared": len(rep[k]), "steps_with_a_difference": int(sum(1 for v in rep[k] if v != 0)), "worst": int(max(rep[k]))}
+        print(json.dumps(rep))
+        return
 
     def barrier():
         if dist is not None:
