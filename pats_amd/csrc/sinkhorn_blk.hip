@@ -47,6 +47,15 @@ struct __attribute__((aligned(16))) BlkLds {
 };
 
 // experiment hooks (libpats_amd_diag<suffix>.so, tools/fine_determinism4.py)
+// Wave priority up for the dependent reduction tail of the row and column phases (DPP / swap chains, reciprocal, the LDS
+// write the other waves wait for at the barrier), back down for the FMA blocks: the waves closest to a barrier get the issue
+// slots.  Measured 5.58 -> 5.50 ms per 20 224 problems for cost + OT, levels 1 / 2 / 3 alike (tools/_prio_ab.sh); no effect
+// on results.  -DPATS_EXPB_NO_PRIO: the A/B partner.
+#ifndef PATS_EXPB_NO_PRIO
+#define BLK_PRIO(n) __builtin_amdgcn_s_setprio((n) ? 1 : 0)
+#else
+#define BLK_PRIO(n) do { } while (0)
+#endif
 #ifdef PATS_EXPB_WSUM
 #define BLK_WSUM(x) wave_sum(x)                 // crossbar all-reduce instead of row_bcast DPP + v_readlane
 #else
@@ -319,11 +328,13 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             for (int r = 0; r < BS; ++r) acc[r] = blk_fma2(f2v{kb[r][6], kb[r][7]}, b67, acc[r]);
 #pragma unroll
             for (int r = 0; r < BS; ++r) part[r] = fmaf(kb[r][8], bl[8], acc[r].x) + acc[r].y;
+            BLK_PRIO(2);
             const float dsum = BLK_WSUM(kdr * b);
             const float s = fmaf(kdc, b_d, row16_reduce9(part, lane));
             a = mul_rcp(mu, s);
             if (rown) lds.va[I * VS + J] = a;
             if (lane == 0) lds.red_r[wave] = dsum;
+            BLK_PRIO(0);
         }
         __syncthreads();                              // a and the dustbin-row partials visible
         {   // ---- b_j = nu_j / sum_i K_ij a_i -----------------------------------------------------
@@ -344,6 +355,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             }
             // over the wave's four DPP rows: permlane32 pairs (0,1)(2,3)(4,5)(6,7), then permlane16 pairs;
             // row rho ends with columns {0,2,1,3}[rho] and that + 4; column 8 is summed in every row
+            BLK_PRIO(2);
             float w0, w1, w2, w3, w4;
             { float x = q01.x, y = q01.y; swap32(x, y); w0 = x + y; }
             { float x = q23.x, y = q23.y; swap32(x, y); w1 = x + y; }
@@ -360,6 +372,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             if (rho == 0) lds.cpart[(BS * J + 8) * 4 + wave] = z2;
             const float dsum = BLK_WSUM(kdc * a);
             if (lane == 0) lds.red_c[wave] = dsum;
+            BLK_PRIO(0);
         }
         __syncthreads();                              // column partials visible
         {

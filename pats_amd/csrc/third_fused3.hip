@@ -43,6 +43,13 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// experiment hook (diagnostic builds): wave priority up for the reduction tail of each half-sweep, as in sinkhorn_blk.hip
+#ifdef PATS_THIRD_PRIO
+#define THIRD_PRIO(n) __builtin_amdgcn_s_setprio((n) ? 1 : 0)
+#else
+#define THIRD_PRIO(n) do { } while (0)
+#endif
+
 constexpr int SST3 = 36;                 // staging row stride (floats): 16-byte aligned rows
 constexpr float GUARD3 = 1073741824.0f;  // 2^30
 __device__ __forceinline__ bool sc_ok3(float x) { return x <= GUARD3 && x > 0.f; }
@@ -485,6 +492,7 @@ third_fused3_kernel(Fused65Args g) {
             } else {
                 dsum = dustbin_sum<DB>(kdrow * b, lds.red, lane);
             }
+            THIRD_PRIO(1);
             const float s = fmaf(kdcol, b64, reduce8_perm(rp, OpSum()));
             float rs = __builtin_amdgcn_rcpf(s), rd = __builtin_amdgcn_rcpf(fmaf(kcorner, b64, dsum));
 #ifdef PATS_EXP_RCP_NOPS
@@ -492,6 +500,7 @@ third_fused3_kernel(Fused65Args g) {
 #endif
             a = mu * rs;
             a64 = mu64 * rd;
+            THIRD_PRIO(0);
         }
         {   // b_j = nu_j / sum_i K_ij a_i
             float dsum = 0.f;
@@ -512,6 +521,7 @@ third_fused3_kernel(Fused65Args g) {
                 for (int cp = 0; cp < 4; ++cp) q[cp] = __builtin_elementwise_fma(Pb[sp][cp], ap[sp].yx, q[cp]);
             }
             if (DB != 5) dsum = dustbin_sum<DB>(kdcol * a, lds.red + 4, lane);
+            THIRD_PRIO(1);
             const float t = fmaf(kdrow, a64, CR ? reduce8_strided_lds(q, lds.stage, I, J)
                                                 : reduce8_strided_pk(q[0], q[1], q[2], q[3], lane));
             float rt = __builtin_amdgcn_rcpf(t), rd = __builtin_amdgcn_rcpf(fmaf(kcorner, a64, dsum));
@@ -521,6 +531,7 @@ third_fused3_kernel(Fused65Args g) {
             b = nu * rt;
             b64 = nu64 * rd;
             lds.vb[colj] = b;
+            THIRD_PRIO(0);
         }
 #ifdef PATS_DIAG
         if (g.fingerprint && ((it + 1) & it) == 0 && it < 64) {
