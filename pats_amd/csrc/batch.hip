@@ -66,7 +66,7 @@ chunk_plan_kernel(ChunkRowsArgs g) {
         int base = carry;
         for (int k = 0; k < wave; ++k) base += wsum[k];
         if (q < N) sc[q] = base + incl;
-        __syncthreads();
+        wg_sync_global();                  // thread 0 reads every wave's part of sc back from global memory below
         if (t == 255) carry = base + incl;
         __syncthreads();
     }

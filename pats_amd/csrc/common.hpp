@@ -158,6 +158,15 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
+// Barrier for data that crosses waves of a workgroup through GLOBAL memory (written before, read by another wave after):
+// hipcc's workgroup-scope release omits the vmcnt wait on gfx950 (same reasoning as the LDS wait asm_pass.py restores -
+// operations of one CU execute in order), and round 3 showed what that reasoning is worth on MI355X for LDS.  Explicit here;
+// asm_pass.py does not add vmcnt waits globally (software-pipelined kernels keep loads in flight across barriers on purpose).
+__device__ __forceinline__ void wg_sync_global() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 inline hipStream_t as_stream(pats_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // memset as a kernel of this library (host.cpp): the throughput path's steps then consist of pats:: kernels only, and a
