@@ -185,8 +185,11 @@ __device__ __forceinline__ void fine_cost_block(const float* __restrict__ A, con
 
 // MODE 0: log_mu / log_nu given (a6)      MODE 2: ns given, log_optimal_transport2 marginals (a5)
 // FUSED: Zin unused, the scores come from the descriptor blocks d0, d1 [batch, D, 145] (see fine_cost_block)
+#ifndef PATS_BLK_WAVES
+#define PATS_BLK_WAVES 3         // workgroups per CU the register budget is cut for (diagnostic builds: 4 = 128 VGPRs, 25 of them spilled)
+#endif
 template <int MODE, bool FUSED = false>
-__global__ void __launch_bounds__(256, FUSED ? 2 : 3)
+__global__ void __launch_bounds__(256, FUSED ? 2 : PATS_BLK_WAVES)
 sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ log_mu_in,
                        const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                        const float* __restrict__ one, int iters, float bias_k, float* __restrict__ out,
