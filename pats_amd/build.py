@@ -30,51 +30,19 @@ def hipcc():
     return exe
 
 
-def llvm_tool(name):
-    for d in (os.path.join(os.path.dirname(os.path.realpath(hipcc())), "..", "lib", "llvm", "bin"), "/opt/rocm/lib/llvm/bin"):
-        exe = os.path.join(d, name)
-        if os.path.exists(exe):
-            return exe
-    raise RuntimeError("%s not found next to hipcc - libpats_amd.so cannot be built" % name)
-
-
 def compile_tu(spath, obj, extra=(), verbose=False):
-    """One translation unit -> host object with the gfx950 code object embedded, in hipcc's own steps, with the device
-    ASSEMBLY passed through pats_amd/asm_pass.py in between (the LDS wait hipcc leaves out in front of some barriers: see
-    that file): device compile to .s -> fix-ups -> assemble -> link the code object -> bundle -> host compile embedding it."""
-    from . import asm_pass
-    stem = obj[:-2]
-    flags = FLAGS[:-2] + list(extra) + FLAGS[-2:]
-
-    def run(cmd):
-        if verbose:
-            print(" ".join(cmd))
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-        if p.returncode != 0:
-            sys.stderr.write(p.stdout.decode())
-            raise RuntimeError("build step failed on %s: %s" % (os.path.basename(spath), " ".join(cmd[:3])))
-        return p.stdout.decode()
-
-    asm = stem + ".gfx950.s"
-    run([hipcc()] + flags + ["-S", "--offload-device-only", spath, "-o", asm])
-    with open(asm) as f:
-        # PATS_BUILD_TRANS_FENCE / PATS_BUILD_NO_BARRIER_WAIT: experiment switches for A/B builds of the diagnostic library
-        text, fences = asm_pass.fence_asm(f.read(), trans="PATS_BUILD_TRANS_FENCE" in os.environ,
-                                          barriers="PATS_BUILD_NO_BARRIER_WAIT" not in os.environ)
-    with open(asm, "w") as f:
-        f.write(text)
-    run([llvm_tool("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", stem + ".gfx950.o"])
-    run([llvm_tool("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", stem + ".hsaco", stem + ".gfx950.o"])
-    run([llvm_tool("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
-         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + stem + ".hsaco",
-         "-output=" + stem + ".hipfb"])
-    out = run([hipcc()] + flags + ["-c", spath, "--offload-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb",
-                                   "-o", obj])
+    """One translation unit -> host object with the gfx950 code object embedded: plain `hipcc -c`.  (Round 3 split hipcc's
+    steps to patch `s_waitcnt lgkmcnt(0)` into the device assembly in front of every barrier; since round 4 the wait is in the
+    source - `wg_barrier()` of csrc/common.hpp - and tools/check_code_objects.py checks the built library for it.)"""
+    cmd = [hipcc()] + FLAGS[:-2] + list(extra) + FLAGS[-2:] + ["-c", spath, "-o", obj]
     if verbose:
-        print("%s: %d assembly fix-ups" % (os.path.basename(spath), fences))
-        if out:
-            print(out)
-    return fences
+        print(" ".join(cmd))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout.decode())
+        raise RuntimeError("hipcc failed on %s" % os.path.basename(spath))
+    if verbose and p.stdout:
+        print(p.stdout.decode())
 
 
 def compile_many(jobs, verbose=False):
@@ -89,8 +57,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pats_amd.h"),
-                                                                os.path.join(HERE, "asm_pass.py")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "pats_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -126,14 +93,12 @@ def build(force=False, verbose=False):
         spath = os.path.join(CSRC, src)
         # every object depends on every header (a struct shared through a .hpp must never be seen in two layouts)
         headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + \
-                  [os.path.join(HERE, "..", "include", "pats_amd.h"), os.path.join(HERE, "asm_pass.py")]
+                  [os.path.join(HERE, "..", "include", "pats_amd.h")]
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
                 and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in headers)):
             continue
         jobs.append((spath, obj, EXTRA_FLAGS.get(src, [])))
-    fences = compile_many(jobs, verbose)
-    if verbose and jobs:
-        print("assembly fix-ups (barrier waits): %d" % sum(fences))
+    compile_many(jobs, verbose)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     subprocess.check_call(cmd)
     return LIB

@@ -86,7 +86,7 @@ attention_kernel(AttnArgs g) {
             if (row < R) slab[row * g.mp + 32 * tj + li] = div_invariant(acc[r], g.sq, g.rsq);      // `/ dim**.5`
         }
     }
-    __syncthreads();
+    wg_barrier();
 
     // ---- 2. softmax over the keys, one wave per row ------------------------------------------------
     for (int row = wave; row < R; row += 4) {
@@ -112,7 +112,7 @@ attention_kernel(AttnArgs g) {
             if (pr && j < g.m) pr[j] = p;
         }
     }
-    __syncthreads();
+    wg_barrier();
 
     // ---- 3. out^T[d][i] = sum_j V[d][j] P[i][j] -------------------------------------------------------
     const int dt = (g.dim + 31) / 32;
@@ -236,7 +236,7 @@ attention65_kernel(AttnArgs g) {
         if (lk == 0) { lds.p64[2 * li] = x0 * inv; lds.p64[2 * li + 1] = x1 * inv; }
         if (lane == 0) lds.p64[64] = xc * inv;
     }
-    __syncthreads();                                               // vt and p64 visible (single wave: ordering only)
+    wg_barrier();                                               // vt and p64 visible (single wave: ordering only)
     // ---- out^T = V P^T -------------------------------------------------------------------------------------
     f32x16 o0, o1;                                                 // queries 2 li (o0) and 2 li + 1 (o1); rows = channels
 #pragma unroll

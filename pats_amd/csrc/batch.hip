@@ -56,19 +56,19 @@ chunk_plan_kernel(ChunkRowsArgs g) {
     const uint8_t* f = g.ifn1 + p * N;
     int32_t* sc = g.sum_cycle + p * N;
     if (t == 0) carry = 0;
-    __syncthreads();
+    wg_barrier();
     for (int q0 = 0; q0 < N; q0 += 256) {
         const int q = q0 + t;
         const int keep = (q < N) ? (f[q] == 0) : 0;
         const int incl = wave_incl_scan_i(keep, lane);
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+        wg_barrier();
         int base = carry;
         for (int k = 0; k < wave; ++k) base += wsum[k];
         if (q < N) sc[q] = base + incl;
-        wg_sync_global();                  // thread 0 reads every wave's part of sc back from global memory below
+        wg_barrier_global();                  // thread 0 reads every wave's part of sc back from global memory below
         if (t == 255) carry = base + incl;
-        __syncthreads();
+        wg_barrier();
     }
     if (t != 0) return;
     const int row = 2 * (g.h + 1);
@@ -99,22 +99,22 @@ chunk_prefix_kernel(ChunkRowsArgs g) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t n = (int64_t)g.Cmax * g.pairs;
     if (t == 0) carry = 0;
-    __syncthreads();
+    wg_barrier();
     for (int64_t i0 = 0; i0 < n; i0 += 256) {
         const int64_t i = i0 + t;
         const int v = i < n ? g.counts[i] : 0;
         const int incl = wave_incl_scan_i(v, lane);
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+        wg_barrier();
         int64_t base = carry;
         for (int k = 0; k < wave; ++k) base += wsum[k];
         if (i < n) {
             g.pair_base[i] = base + incl - v;
             if (i % g.pairs == 0) g.chunk_base[i / g.pairs] = base + incl - v;
         }
-        __syncthreads();
+        wg_barrier();
         if (t == 255) carry = base + incl;
-        __syncthreads();
+        wg_barrier();
     }
     if (t == 0) {
         g.chunk_base[g.Cmax] = carry;

@@ -158,13 +158,45 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
-// Barrier for data that crosses waves of a workgroup through GLOBAL memory (written before, read by another wave after):
-// hipcc's workgroup-scope release omits the vmcnt wait on gfx950 (same reasoning as the LDS wait asm_pass.py restores -
-// operations of one CU execute in order), and round 3 showed what that reasoning is worth on MI355X for LDS.  Explicit here;
-// asm_pass.py does not add vmcnt waits globally (software-pipelined kernels keep loads in flight across barriers on purpose).
-__device__ __forceinline__ void wg_sync_global() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+// ---- workgroup barriers ------------------------------------------------------------------------------------------------
+// wg_barrier(): THE barrier of this library - every kernel uses it where CUDA-style code would write __syncthreads().
+// __syncthreads() is `fence release (workgroup); s_barrier; fence acquire (workgroup)`, and hipcc (ROCm 7.2, gfx950) lowers
+// the release WITHOUT `s_waitcnt lgkmcnt(0)` wherever it reasons that the LDS operations of one CU execute in one total
+// order - e.g. at the top of a Sinkhorn sweep loop whose latch ends in this wave's ds_write of the scaling vector.  On MI355X
+// a wave does pass such a barrier with its ds_write still queued, and the waves the barrier releases read the previous
+// sweep's values: 1-9 of 8 192 fine-level problems per launch came back with perturbed duals (profiles/r03_determinism.md).
+// Round 3 patched the wait into the compiler's assembly; since round 4 it is in the SOURCE: the explicit
+// `s_waitcnt lgkmcnt(0)` below (vmcnt 63 / expcnt 7 = "do not wait": software-pipelined kernels keep global loads in flight
+// across barriers on purpose) sits between the release fence and the s_barrier, so plain `hipcc -c` builds every file
+// correctly.  tools/check_code_objects.py still checks the shipped code objects (tests/test_host_abi.py runs it).
+constexpr int WAITCNT_LGKM0 = 0xC07F;      // gfx9 s_waitcnt encoding: vmcnt[3:0|15:14] = 63, expcnt[6:4] = 7, lgkmcnt[11:8] = 0
+__device__ __forceinline__ void wg_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(WAITCNT_LGKM0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// wg_barrier_global(): the same for data that crosses the waves of a workgroup through GLOBAL memory (written before the
+// barrier, read by another wave behind it).  hipcc's workgroup-scope release also omits the vmcnt wait on gfx950 outside
+// threadgroup-split mode (same in-order reasoning); after what that reasoning was worth for LDS it is explicit here.
+// s_waitcnt 0 = vmcnt(0) expcnt(0) lgkmcnt(0).
+__device__ __forceinline__ void wg_barrier_global() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Workgroup-wide OR of a predicate (what __syncthreads_or does, on wg_barrier()).  Called uniformly by all threads.
+__device__ __forceinline__ bool wg_barrier_or(bool pred) {
+    __shared__ int wg_or_slot;
+    if (threadIdx.x == 0) wg_or_slot = 0;
+    wg_barrier();
+    if (__builtin_amdgcn_ballot_w64(pred) != 0ull && (threadIdx.x & 63) == 0) wg_or_slot = 1;     // same value from every writer
+    wg_barrier();
+    const bool any = wg_or_slot != 0;
+    wg_barrier();                                       // the slot is free for the next call
+    return any;
 }
 
 inline hipStream_t as_stream(pats_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

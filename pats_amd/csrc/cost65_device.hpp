@@ -83,14 +83,14 @@ __device__ __forceinline__ void cost65_accumulate(const float* __restrict__ A, c
     auto k0_of = [&](int blk) { return (blk < nblk ? blk : 0) * 2 * KB; };   // wrap: harmless reloads at the end
     Blk r0, r1, r2, r3;
     load_blk(k0_of(0), r0); load_blk(k0_of(1), r1); load_blk(k0_of(2), r2);
-    __syncthreads();                                     // eA / eB visible
+    wg_barrier();                                     // eA / eB visible
     for (int blk = 0; blk < nblk; blk += 4) {
         load_blk(k0_of(blk + 3), r3); compute_blk(k0_of(blk + 0), r0);
         load_blk(k0_of(blk + 4), r0); compute_blk(k0_of(blk + 1), r1);
         load_blk(k0_of(blk + 5), r1); compute_blk(k0_of(blk + 2), r2);
         load_blk(k0_of(blk + 6), r2); compute_blk(k0_of(blk + 3), r3);
     }
-    __syncthreads();                                     // done with eA / eB: the caller may reuse the LDS
+    wg_barrier();                                     // done with eA / eB: the caller may reuse the LDS
     o.er0 = er0 + __shfl_xor(er0, 32); o.er1 = er1 + __shfl_xor(er1, 32);
     o.ec0 = ec0 + __shfl_xor(ec0, 32); o.ec1 = ec1 + __shfl_xor(ec1, 32);
     o.cn = cn + __shfl_xor(cn, 32);
@@ -163,7 +163,7 @@ __device__ __forceinline__ void cost65_accumulate_f16x2(const float* __restrict_
         eA[k] = a0; eB[k] = b0;
         eA[k1] = a1; eB[k1] = b1;
     }
-    __syncthreads();                                     // eA / eB visible
+    wg_barrier();                                     // eA / eB visible
     for (int s = 0; s < nstep; ++s) {
         const int k0 = 16 * s;
         h2v ah[2][4], al[2][4], bh[2][4], bl[2][4];              // [column parity][pair of channels]
@@ -214,7 +214,7 @@ __device__ __forceinline__ void cost65_accumulate_f16x2(const float* __restrict_
         asm volatile("" :: "v"(Aeh), "v"(Ael), "v"(Aoh), "v"(Aol), "v"(Beh), "v"(Bel), "v"(Boh), "v"(Bol));
         __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                                     // done with eA / eB: the caller may reuse the LDS
+    wg_barrier();                                     // done with eA / eB: the caller may reuse the LDS
     o.er0 = er0 + __shfl_xor(er0, 32); o.er1 = er1 + __shfl_xor(er1, 32);
     o.ec0 = ec0 + __shfl_xor(ec0, 32); o.ec1 = ec1 + __shfl_xor(ec1, 32);
     o.cn = cn + __shfl_xor(cn, 32);

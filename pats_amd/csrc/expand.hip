@@ -112,7 +112,7 @@ expand_kernel(ExpandArgs a) {
     }
     // the sentinel slot: every strip index is in [0, wh - 1] or is S = wh + 1 = N, which reads the appended 1e-14 (:1205,1208)
     if (t == 0) { prow[N] = ZERO_F; popp[N] = ZERO_F; }           // (shared dustbin rows: several groups write the same value)
-    __syncthreads();     // every thread gets here (idle groups shadow the last row)
+    wg_barrier();     // every thread gets here (idle groups shadow the last row)
 
     const int width = a.h > a.w ? a.h : a.w;
     const int height = (a.h * a.w) / width;

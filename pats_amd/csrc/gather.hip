@@ -240,7 +240,7 @@ third_desc_nhwc_kernel(const float* __restrict__ ff0, const float* __restrict__ 
         tile[(lane + 64) * NT + 16 * wave + j] = v1[j];
     }
     if (t < C) tile[t * NT + 64] = rb;                                                                      // :145-146
-    __syncthreads();
+    wg_barrier();
     float* o = (side ? out1 : out0) + p * C * NT;
 #pragma unroll
     for (int r = 0; r < 33; ++r) {
@@ -284,11 +284,11 @@ __device__ __forceinline__ void fine_tile_pass(const float* __restrict__ img, in
         }
     }
     if (t < 64) tile[t * NP + 144] = dust;
-    __syncthreads();
+    wg_barrier();
     const f4* src = reinterpret_cast<const f4*>(tile);
     f4* dst = reinterpret_cast<f4*>(o);
     for (int e = t; e < 64 * NP / 4; e += 256) dst[e] = src[e];
-    __syncthreads();
+    wg_barrier();
 }
 
 __global__ void __launch_bounds__(256)

@@ -230,7 +230,7 @@ conv_lean_kernel(ConvArgs g) {
         const int nchunk = (K + 15) / 16;
         fetch(0);
         stash(0);
-        __syncthreads();
+        wg_barrier();
         for (int c = 0; c < nchunk; ++c) {
             const int buf = c & 1;
             if (c + 1 < nchunk) fetch((c + 1) * 16);
@@ -254,7 +254,7 @@ conv_lean_kernel(ConvArgs g) {
             for (int tj = 0; tj < NT; ++tj) asm volatile("" :: "v"(bh[tj]), "v"(bl[tj]));
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < nchunk) stash(buf ^ 1);
-            __syncthreads();
+            wg_barrier();
         }
     };
     pass(0, g.x0, g.K0, g.in_scale, g.in_shift);
@@ -369,9 +369,9 @@ conv_ws_kernel(ConvArgs g, int row_tiles) {
     const int64_t nsteps = (tiles_j + step - 1) / step;
     unsigned pcur = tile_off(min(first, tiles_j - 1));
     fetch(pcur, 0, R[0]); fetch(pcur, 1, R[1]); fetch(pcur, 2, R[2]);
-    __syncthreads();                                 // the weights
+    wg_barrier();                                 // the weights
     stash(0, 0, R[0]);
-    __syncthreads();
+    wg_barrier();
     for (int64_t it = 0; it < nsteps; ++it) {
         const int64_t ct = first + it * step;
         const bool live = ct < tiles_j;
@@ -410,7 +410,7 @@ conv_ws_kernel(ConvArgs g, int row_tiles) {
             __builtin_amdgcn_sched_barrier(0);
             // the next chunk of the stream (chunk c + 1, or chunk 0 of the next tile) into the other LDS buffer
             stash(buf ^ 1, (c + 1) % WS_NCH, R[(u + 1) % 4]);
-            __syncthreads();
+            wg_barrier();
         }
         if (live) {
 #pragma unroll
@@ -465,7 +465,7 @@ bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, doub
         q += __shfl_xor(q, o);
     }
     if (lane == 0) { s1[wave] = a; s2[wave] = q; }
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) {
         part[((int64_t)c * BN_SPLITS + split) * 2 + 0] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
         part[((int64_t)c * BN_SPLITS + split) * 2 + 1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);

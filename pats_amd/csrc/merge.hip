@@ -41,7 +41,7 @@ scan_flags_kernel(const uint8_t* __restrict__ flags, int64_t n, int32_t* __restr
     }
     const int incl = wave_incl_scan(c, lane);
     if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
+    wg_barrier();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += wsum[w];
     int run = base + incl - c;
@@ -59,18 +59,18 @@ scan_tiles_kernel(int32_t* __restrict__ tile_base, int tiles, int64_t* __restric
     __shared__ int carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) carry = 0;
-    __syncthreads();
+    wg_barrier();
     for (int b0 = 0; b0 < tiles; b0 += 1024) {
         const int v = (b0 + t < tiles) ? tile_base[b0 + t] : 0;
         const int incl = wave_incl_scan(v, lane);
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+        wg_barrier();
         int base = carry;
         for (int w = 0; w < wave; ++w) base += wsum[w];
         if (b0 + t < tiles) tile_base[b0 + t] = base + incl - v;
-        __syncthreads();
+        wg_barrier();
         if (t == 1023) carry = base + incl;
-        __syncthreads();
+        wg_barrier();
     }
     if (t == 0 && total) *total = carry;
 }

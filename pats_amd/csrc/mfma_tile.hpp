@@ -102,7 +102,7 @@ __device__ __forceinline__ void tile_f32(Src& src, LdsF32& lds, f32x16 (&acc)[7]
     const int nchunk = (K + KC - 1) / KC;
     src.fetch_f32(0, ra, rb);
     stash(0);
-    __syncthreads();
+    wg_barrier();
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) src.fetch_f32((c + 1) * KC, ra, rb);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void tile_f32(Src& src, LdsF32& lds, f32x16 (&acc)[7]
             }
         }
         if (c + 1 < nchunk) stash(buf ^ 1);        // last read in chunk c - 1; every wave is past that barrier
-        __syncthreads();
+        wg_barrier();
     }
 }
 
@@ -201,13 +201,13 @@ __device__ __forceinline__ void split_accumulate(Src& src, LdsSplit& lds, f32x16
     float r[SQ][4];
     src.fetch_split(0, r);
     stash(0, r);
-    __syncthreads();
+    wg_barrier();
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) src.fetch_split((c + 1) * SKC, r);
         mfma_chunk(buf);
         if (c + 1 < nchunk) stash(buf ^ 1, r);       // last read in chunk c - 1; every wave is past that barrier
-        __syncthreads();
+        wg_barrier();
     }
 }
 
@@ -232,7 +232,7 @@ __device__ __forceinline__ bool split_finite(const Src& src, const f32x16 (&acc)
         scan(acc[5], 4, wave);
         if (wave == 0) scan(acc[6], 4, 4);
     }
-    return !__syncthreads_or(bad);
+    return !wg_barrier_or(bad);
 }
 
 // Two channel-major operands with caller-defined column offsets: element (channel k, tile column c) of side A is

@@ -26,7 +26,7 @@ imgs_bounds_block(const float* __restrict__ x_scale, const float* __restrict__ y
     const float ps = 32.0f, margin = 128.0f;
     const float board1 = (float)(32 * height - 1), board3 = (float)(32 * width);   // :1351
     if (tid == 0) base_s = 0;
-    __syncthreads();
+    wg_barrier();
     for (int k0 = 0; k0 < Np; k0 += 1024) {
         const int k = k0 + tid;
         int flag = 0;
@@ -56,7 +56,7 @@ imgs_bounds_block(const float* __restrict__ x_scale, const float* __restrict__ y
         const unsigned long long mask = __ballot(flag);
         const int before = __popcll(mask & ((1ull << lane) - 1ull));
         if (lane == 0) wave_tot[wave] = __popcll(mask);
-        __syncthreads();
+        wg_barrier();
         int wbase = base_s;
         for (int q = 0; q < wave; ++q) wbase += wave_tot[q];
         if (flag) {
@@ -64,13 +64,13 @@ imgs_bounds_block(const float* __restrict__ x_scale, const float* __restrict__ y
             bound5[o + 0] = l0; bound5[o + 1] = l1; bound5[o + 2] = l2; bound5[o + 3] = l3;
             bound5[o + 4] = (int64_t)img * 10000 + k;                      // :1374-1377
         }
-        __syncthreads();
+        wg_barrier();
         if (tid == 0) {
             int tot = 0;
             for (int q = 0; q < 16; ++q) tot += wave_tot[q];
             base_s += tot;
         }
-        __syncthreads();
+        wg_barrier();
     }
     if (tid == 0 && K_out) *K_out = base_s;
 }
@@ -102,15 +102,15 @@ imgs_bounds_batch_kernel(const float* __restrict__ x_scale, const float* __restr
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) cnt += __shfl_xor(cnt, o);
     if ((tid & 63) == 0) part[tid >> 6] = cnt;
-    __syncthreads();
+    wg_barrier();
     if (tid == 0) {
         int64_t o = 0;
         for (int q = 0; q < 16; ++q) o += part[q];
         off_s = o;
     }
-    __syncthreads();
+    wg_barrier();
     const int64_t off = off_s;
-    __syncthreads();
+    wg_barrier();
     const int64_t i = img;
     imgs_bounds_block(x_scale + i * Np, y_scale + i * Np, average_point + i * Np * 2, ifn + i * Np, Np, height, width,
                       img, bound5 + off * 5, K_img + i, xsn + i * Np * 2, ysn + i * Np * 2, avn + i * Np * 2);

@@ -70,7 +70,7 @@ scale_head_kernel(const float* __restrict__ x, int C, int ld, int h, int w, cons
                     }
         }
         if (wv == 0 && t < HEADS * 9) sm[t * row + hw] = 0.f;
-        __syncthreads();
+        wg_barrier();
     }
     for (int p = t; p < hw; p += SH_THREADS) {
         const int py = p / w, px = p - py * w;

@@ -41,7 +41,7 @@ ot_prep_kernel(const float* __restrict__ ns, int ns_len, int M, int N, float ms_
     for (int j = threadIdx.x; j < ns_len; j += 256) acc += nsb[j];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    wg_barrier();
     const float ns_sum = (red[0] + red[1]) + (red[2] + red[3]);
     const float ms = ms_base * (one ? *one : 1.0f);       // modules.py:150 / :169
     const float norm = -logf(ms + ns_sum);                // modules.py:157 / :176
@@ -208,7 +208,7 @@ sinkhorn65_kernel(Ot65Args g) {
         lmu = norm;
         lmu64 = logf(ns_sum) + norm;
     }
-    __syncthreads();
+    wg_barrier();
     const float* T = lds.tile;
     const float corner_z = T[TILE - 1];
 
@@ -222,13 +222,13 @@ sinkhorn65_kernel(Ot65Args g) {
         for (int j = 0; j < NB; ++j) r = fmaxf(r, T[lane * NT + j]);      // stride 65: conflict-free
         const float r64 = fmaxf(wave_max(T[NB * NT + lane]), corner_z);
         lds.bc0[lane] = r;
-        __syncthreads();
+        wg_barrier();
         float c = T[NB * NT + lane] - r64;
 #pragma unroll
         for (int i = 0; i < NB; ++i) c = fmaxf(c, T[i * NT + lane] - lds.bc0[i]);
         const float c64 = fmaxf(wave_max(T[lane * NT + NB] - r), corner_z - r64);
         lds.bc1[lane] = c;
-        __syncthreads();
+        wg_barrier();
         // ---- K in both orientations (identical op order => kr/kc hold bitwise-equal entries) ----
         float kr[NB], kc[NB];
 #pragma unroll
@@ -241,14 +241,14 @@ sinkhorn65_kernel(Ot65Args g) {
         const float mu = expf(lmu), mu64 = expf(lmu64), nu = expf(lnu), nu64 = expf(lnu64);
         float a = 0.f, a64 = 0.f, b = expf(c), b64 = expf(c64);
         for (int it = 0; it < iters; ++it) {
-            __syncthreads();
+            wg_barrier();
             lds.bc1[lane] = b;
-            __syncthreads();
+            wg_barrier();
             a = mu * fast_rcp(fmaf(kr64, b64, dot64(kr, lds.bc1)));
             a64 = mu64 * fast_rcp(fmaf(kcorner, b64, wave_sum(kc64 * b)));
-            __syncthreads();
+            wg_barrier();
             lds.bc0[lane] = a;
-            __syncthreads();
+            wg_barrier();
             b = nu * fast_rcp(fmaf(kc64, a64, dot64(kc, lds.bc0)));
             b64 = nu64 * fast_rcp(fmaf(kcorner, a64, wave_sum(kr64 * a)));
         }
@@ -276,9 +276,9 @@ sinkhorn65_kernel(Ot65Args g) {
         u = u64 = v = v64 = 0.f;
         for (int it = 0; it < iters; ++it) {
             // u = log_mu - lse_j(Z + v)
-            __syncthreads();
+            wg_barrier();
             lds.bc1[lane] = v;
-            __syncthreads();
+            wg_barrier();
             {
                 float m = zr64 + v64;
 #pragma unroll
@@ -294,9 +294,9 @@ sinkhorn65_kernel(Ot65Args g) {
                 u64 = lmu64 - lse_finish(s2, mI2);
             }
             // v = log_nu - lse_i(Z + u)
-            __syncthreads();
+            wg_barrier();
             lds.bc0[lane] = u;
-            __syncthreads();
+            wg_barrier();
             {
                 float m = zc64 + u64;
 #pragma unroll
@@ -315,9 +315,9 @@ sinkhorn65_kernel(Ot65Args g) {
     }
 
     // ---- Z + u + v - norm (+ the caller's dustbin bias) from the original Z -----------------------
-    __syncthreads();
+    wg_barrier();
     lds.bc0[lane] = u;
-    __syncthreads();
+    wg_barrier();
     const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
     float* Tw = lds.tile;
     if (EPI == 0) {
@@ -344,11 +344,11 @@ sinkhorn65_kernel(Ot65Args g) {
         if (bias_k > 0.f) { cc += lb; rr += lb; }
         float q = ((corner_z + u64) + v64) - norm;
         if (bias_k > 0.f) { q += lb; q += lb; }
-        __syncthreads();
+        wg_barrier();
         Tw[lane * NT + NB] = cc;
         Tw[NB * NT + lane] = rr;
         if (lane == 0) Tw[TILE - 1] = q;
-        __syncthreads();
+        wg_barrier();
         if (g.out) {
             float* Op = g.out + p * TILE;
 #pragma unroll 11
@@ -371,7 +371,7 @@ cost65_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D,
     const int64_t p = blockIdx.x;
     if (p >= P) return;
     cost65_to_tile<F16>(d0 + p * (int64_t)D * NT, d1 + p * (int64_t)D * NT, D, tile, lane);
-    __syncthreads();
+    wg_barrier();
     float* Op = out + p * TILE;
 #pragma unroll 11
     for (int k = 0; k < 66; ++k) Op[k * 64 + lane] = tile[k * 64 + lane];
@@ -411,10 +411,12 @@ __device__ __forceinline__ float dotN(const float (&k)[(N_ + 3) & ~3], const flo
 
 template <int N_, int MODE>
 __global__ void __launch_bounds__(384)
-sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __restrict__ log_mu_in,
+sinkhorn_rc_kernel(const float* Zin, int64_t P, const float* __restrict__ log_mu_in,
                    const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                    const float* __restrict__ one, int iters, float bias_k, int linear,
-                   float* __restrict__ out, unsigned long long* fallbacks, const int* __restrict__ only_if) {
+                   float* out, unsigned long long* fallbacks, const int* __restrict__ only_if) {
+    // Zin and out are NOT __restrict__: the fused fine-level redo (launch_fine145_fused) solves in place, Zin == out.  The
+    // whole matrix is staged in LDS before the first store and Zin is not read again.
     __shared__ __attribute__((aligned(16))) WgLds<N_> lds;     // 85 KB at N = 145 (static: no opt-in)
     if (only_if) {                                  // re-solve pass after sinkhorn_blk145_kernel: flagged problems only
         if (only_if[blockIdx.x] == 0) return;
@@ -439,14 +441,14 @@ sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __rest
         const float nsj = (!colw && t < N_ - 1) ? ns[p * (N_ - 1) + t] : 0.f;
         const float part = wave_sum(nsj);
         if (lane == 0) lds.red[wave] = part;
-        __syncthreads();
+        wg_barrier();
         const float ns_sum = (lds.red[0] + lds.red[1]) + lds.red[2];
         const float ms = (float)(N_ - 1) * (one ? *one : 1.0f);
         norm = -logf(ms + ns_sum);
         if (colw) lmarg = (tl < N_ - 1 ? logf(ns[p * (N_ - 1) + tt]) : logf(ms)) + norm;
         else lmarg = (tl < N_ - 1 ? 0.f : logf(ns_sum)) + norm;
     }
-    __syncthreads();
+    wg_barrier();
     const float* T = lds.tile;
     float dual = 0.f;                   // u_i in row waves, v_j in column waves
     bool solved = (iters == 0);
@@ -459,13 +461,13 @@ sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __rest
             for (int j = 0; j < N_; ++j) stab = fmaxf(stab, T[tt * N_ + j]);     // stride N_ (odd): conflict-free
             if (act) lds.bc0[tl] = stab;
         }
-        __syncthreads();
+        wg_barrier();
         if (colw) {
 #pragma unroll 5
             for (int i = 0; i < N_; ++i) stab = fmaxf(stab, T[i * N_ + tt] - lds.bc0[i]);
             if (act) lds.bc1[tl] = stab;
         }
-        __syncthreads();
+        wg_barrier();
         float kk[NP];
         // built in chunks of 8 with a compiler barrier between them: a free-running full unroll
         // keeps hundreds of LDS reads in flight and the allocator answers by spilling K entries
@@ -491,30 +493,30 @@ sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __rest
         for (int q = N_; q < NP; ++q) kk[q] = 0.f;
         const float marg = expf(lmarg);
         float sc = colw ? expf(stab) : 1.f;        // b starts at exp(c_j); a is computed first
-        __syncthreads();                           // everyone is done reading the stabilisers
+        wg_barrier();                           // everyone is done reading the stabilisers
         if (colw && act) lds.bc1[tl] = sc;
         for (int it = 0; it < iters; ++it) {
-            __syncthreads();                       // b visible
+            wg_barrier();                       // b visible
             if (!colw) {
                 sc = marg * fast_rcp(dotN<N_>(kk, lds.bc1));
                 if (act) lds.bc0[tl] = sc;
             }
-            __syncthreads();                       // a visible
+            wg_barrier();                       // a visible
             if (colw) {
                 sc = marg * fast_rcp(dotN<N_>(kk, lds.bc0));
                 if (act) lds.bc1[tl] = sc;
             }
         }
         const bool ok_wave = __all(!act || scaling_ok(sc));
-        __syncthreads();
+        wg_barrier();
         if (lane == 0) lds.red[wave] = ok_wave ? 1.f : 0.f;
-        __syncthreads();
+        wg_barrier();
         const float okp = (lds.red[0] * lds.red[1] * lds.red[2]) * (lds.red[3] * lds.red[4] * lds.red[5]);
         if (okp > 0.5f) {
             dual = logf(sc) - stab;
             solved = true;
         }
-        __syncthreads();
+        wg_barrier();
     }
 
     if (!solved) {      // workgroup-uniform: max-subtracted log-sum-exp sweeps on Z itself.
@@ -528,7 +530,7 @@ sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __rest
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {          // h = 0: u from v (row waves); h = 1: v from u
-                __syncthreads();
+                wg_barrier();
                 if ((h == 1) == colw) {
                     const float* other = h == 0 ? lds.bc1 : lds.bc0;
                     float m = -INFINITY;
@@ -548,9 +550,9 @@ sinkhorn_rc_kernel(const float* __restrict__ Zin, int64_t P, const float* __rest
     }
 
     // ---- epilogue: ((Z + u) + v) - norm (+ bias) from the LDS copy of Z, coalesced ---------------
-    __syncthreads();
+    wg_barrier();
     if (act) (colw ? lds.bc1 : lds.bc0)[tl] = dual;
-    __syncthreads();
+    wg_barrier();
     const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
     float* Op = out + p * NN;
     for (int k = t; k < NN; k += TH) {
@@ -624,8 +626,7 @@ __global__ void sinkhorn_wg_kernel(SrcView src, int M, int N, const float* __res
     }
     for (int i = tid; i < M; i += nthr) u[i] = 0.f;
     for (int j = tid; j < N; j += nthr) v[j] = 0.f;
-    __threadfence_block();
-    __syncthreads();
+    wg_barrier_global();     // Zw / Zt went to GLOBAL memory from all waves and are read back wave-per-row below
 
     const float* lmu = log_mu + (int64_t)b * M;
     const float* lnu = log_nu + (int64_t)b * N;
@@ -634,12 +635,12 @@ __global__ void sinkhorn_wg_kernel(SrcView src, int M, int N, const float* __res
             const float l = wave_lse(Zr + (int64_t)i * N, v, N, lane);
             if (lane == 0) u[i] = lmu[i] - l;
         }
-        __syncthreads();
+        wg_barrier();
         for (int j = wave; j < N; j += nwave) {
             const float l = wave_lse(Zt + (int64_t)j * M, u, M, lane);
             if (lane == 0) v[j] = lnu[j] - l;
         }
-        __syncthreads();
+        wg_barrier();
     }
     const float norm = norm_in ? norm_in[b] : 0.f;
     const float lb = bias_k > 0.f ? logf(bias_k) : 0.f;
@@ -764,7 +765,7 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
             if (s_ * NW < M) m = fmaxf(m, (wave + NW * s_ < M) ? KREF(s_, c) - RS(s_) : -INFINITY);
         part[0][wave][lane + 64 * c] = m;
     }
-    __syncthreads();
+    wg_barrier();
     float bsc[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -798,7 +799,7 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
         mured[i] = (RSum::slot_of(i, grp) < RPW && row < M) ? expf(lmu[row]) : 0.f;
         ared[i] = 0.f;
     }
-    __syncthreads();        // part[0] is free again
+    wg_barrier();        // part[0] is free again
 
     for (int it = 0; it < iters; ++it) {
         // ---- a_i = mu_i / sum_j K_ij b_j ----------------------------------------------------------
@@ -825,7 +826,7 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
         float (*pb)[CW] = part[it & 1];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) pb[wave][lane + 64 * c] = t[c];
-        __syncthreads();
+        wg_barrier();
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             float tot = 0.f;
@@ -845,9 +846,9 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
         ok = ok && (!(sl < RPW && wave + NW * sl < M) || scaling_ok(ared[i]));
     }
     const bool okw = __all(ok);
-    __syncthreads();
+    wg_barrier();
     if (lane == 0) ok_s[wave] = okw ? 1 : 0;
-    __syncthreads();
+    wg_barrier();
     bool all_ok = iters > 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) all_ok = all_ok && ok_s[w] != 0;

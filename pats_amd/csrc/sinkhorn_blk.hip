@@ -145,7 +145,7 @@ __device__ __forceinline__ void fine_cost_block(const float* __restrict__ A, con
     zcorner = 0.f;
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
-        __syncthreads();                                  // the band buffer (b == 0: the cost build's staging area) is free
+        wg_barrier();                                  // the band buffer (b == 0: the cost build's staging area) is free
         if (b < 4) {
             if (wave == b) {
 #pragma unroll
@@ -162,7 +162,7 @@ __device__ __forceinline__ void fine_cost_block(const float* __restrict__ A, con
                 for (int r = 0; r < 16; ++r) fl.band[((r & 3) + 8 * (r >> 2) + 4 * lk) * BAND_LD + 128 + li] = scaled(acc[6][r]);
             }
         }
-        __syncthreads();
+        wg_barrier();
 #pragma unroll
         for (int r = 0; r < BS; ++r) {
             const int row = BS * I + r;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void fine_cost_block(const float* __restrict__ A, con
             zcorner = fl.band[(NB - 128) * BAND_LD + NB];
         }
     }
-    __syncthreads();
+    wg_barrier();
 }
 
 }  // namespace
@@ -244,7 +244,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     } else {
         const float part = wave_sum_uniform(t < NB ? ns[p * NB + t] : 0.f);
         if (lane == 0) lds.misc[wave] = part;
-        __syncthreads();
+        wg_barrier();
         const float ns_sum = (lds.misc[0] + lds.misc[1]) + (lds.misc[2] + lds.misc[3]);
         const float ms = (float)NB * (one ? *one : 1.0f);
         norm = uni(-logf(ms + ns_sum));
@@ -275,7 +275,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
         const float wm = wave_max(zdr);
         if (lane == 0) lds.misc[4 + wave] = wm;
         if (rown) lds.va[I * VS + J] = r_own;
-        __syncthreads();
+        wg_barrier();
         r_d = uni(fmaxf(fmaxf(fmaxf(lds.misc[4], lds.misc[5]), fmaxf(lds.misc[6], lds.misc[7])), zcorner));
         load9(&lds.va[I * VS], rloc);
         // columns: partial maxima of (Z - r) over this lane's 9 rows, reduced over the 16 values of I via LDS
@@ -287,7 +287,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             lds.tmp[(BS * J + c) * 17 + I] = x;
         }
         const float wd = wave_max(rown ? zdc - r_own : -INFINITY);
-        __syncthreads();
+        wg_barrier();
         if (lane == 0) lds.misc[wave] = wd;
         float x = -INFINITY;
         if (cown) {
@@ -297,7 +297,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             lds.vb[J * VS + I] = x;
         }
         c_own = x;
-        __syncthreads();
+        wg_barrier();
         c_d = uni(fmaxf(fmaxf(fmaxf(lds.misc[0], lds.misc[1]), fmaxf(lds.misc[2], lds.misc[3])), zcorner - r_d));
         load9(&lds.vb[J * VS], cloc);
     }
@@ -311,11 +311,11 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     const float kcorner = uni(fast_exp2(((zcorner - r_d) - c_d) * LOG2E));
     const float mu = expf(lmu), nu = expf(lnu), mu_d = uni(expf(lmu_d)), nu_d = uni(expf(lnu_d));
     float a = 0.f, b = cown ? expf(c_own) : 0.f, a_d = 0.f, b_d = uni(expf(c_d));
-    __syncthreads();                                  // everyone has read the stabilisers
+    wg_barrier();                                  // everyone has read the stabilisers
     if (cown) lds.vb[J * VS + I] = b;
 
     for (int it = 0; it < iters; ++it) {
-        __syncthreads();                              // b visible
+        wg_barrier();                              // b visible
         {   // ---- a_i = mu_i / sum_j K_ij b_j -----------------------------------------------------
             float bl[BS], part[BS];
             load9(&lds.vb[J * VS], bl);
@@ -339,7 +339,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             if (lane == 0) lds.red_r[wave] = dsum;
             BLK_PRIO(0);
         }
-        __syncthreads();                              // a and the dustbin-row partials visible
+        wg_barrier();                              // a and the dustbin-row partials visible
         {   // ---- b_j = nu_j / sum_i K_ij a_i -----------------------------------------------------
             const f4v dr = *reinterpret_cast<const f4v*>(lds.red_r);
             a_d = mul_rcp(mu_d, fmaf(kcorner, b_d, (dr.x + dr.y) + (dr.z + dr.w)));
@@ -377,7 +377,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
             if (lane == 0) lds.red_c[wave] = dsum;
             BLK_PRIO(0);
         }
-        __syncthreads();                              // column partials visible
+        wg_barrier();                              // column partials visible
         {
             const f4v dc = *reinterpret_cast<const f4v*>(lds.red_c);
             b_d = mul_rcp(nu_d, fmaf(kcorner, a_d, (dc.x + dc.y) + (dc.z + dc.w)));
@@ -391,9 +391,9 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     // ---- guard: every scaling finite, positive, <= 2^30 ---------------------------------------------------
     const bool okl = (!rown || ok_scale(a)) && (!cown || ok_scale(b)) && ok_scale(a_d) && ok_scale(b_d);
     const bool okw = __all(okl);
-    __syncthreads();
+    wg_barrier();
     if (lane == 0) lds.misc[wave] = okw ? 1.f : 0.f;
-    __syncthreads();
+    wg_barrier();
     if ((lds.misc[0] * lds.misc[1]) * (lds.misc[2] * lds.misc[3]) < 0.5f) {
         if (t == 0) fail[p] = 1;
         if constexpr (FUSED) {
@@ -415,7 +415,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
     const float u_d = uni(logf(a_d) - r_d), v_d = uni(logf(b_d) - c_d);
     if (rown) lds.va[I * VS + J] = logf(a) - r_own;
     if (cown) lds.vb[J * VS + I] = logf(b) - c_own;
-    __syncthreads();
+    wg_barrier();
     float ul[BS], vl[BS];
     load9(&lds.va[I * VS], ul);
     load9(&lds.vb[J * VS], vl);
@@ -463,10 +463,10 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
         // est_position's if_nomatching2 = (scores.max(1).indices == 144), second_layer.py:243,248: the dustbin row
         // strictly above every real row of the column (first index wins ties); partial maxima cross the 16 lanes
         // that share J through LDS, as for the stabilisers
-        __syncthreads();
+        wg_barrier();
 #pragma unroll
         for (int c = 0; c < BS; ++c) lds.tmp[(BS * J + c) * 17 + I] = cm[c];
-        __syncthreads();
+        wg_barrier();
         if (cown) {
             float x = lds.tmp[colj * 17];
 #pragma unroll

@@ -40,9 +40,9 @@ constexpr int SW = ST / 64;  // waves
 template <class Op>
 __device__ __forceinline__ float block_allreduce(float v, Op op, float* scratch) {
     v = wave_allreduce(v, op);
-    __syncthreads();
+    wg_barrier();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
+    wg_barrier();
     float r = scratch[0];
 #pragma unroll
     for (int w = 1; w < SW; ++w) r = op(r, scratch[w]);
@@ -112,7 +112,7 @@ stream_colreduce_kernel(const float* __restrict__ partial, int nblk, int N,
         }
     }
     sm[wave][lane] = acc;
-    __syncthreads();
+    wg_barrier();
     if (wave == 0 && j < N) {
         float t = sm[0][lane];
 #pragma unroll
@@ -175,7 +175,7 @@ stream_sweep_kernel(const float* __restrict__ K, int M, int N, const float* __re
         p = wave_sum(p);
         if (lane == 0) red[wave][k] = p;
     }
-    __syncthreads();
+    wg_barrier();
     if (t < RB) {
         const int i = blk * RB + t;
         float s = 0.f;
@@ -185,7 +185,7 @@ stream_sweep_kernel(const float* __restrict__ K, int M, int N, const float* __re
         a_s[t] = a;
         if (i < M) avec[(int64_t)b * M + i] = a;
     }
-    __syncthreads();
+    wg_barrier();
     // column partials of this row block, K still in registers
     float* pb = partial + ((int64_t)b * nblk + blk) * N;
 #pragma unroll

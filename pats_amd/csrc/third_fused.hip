@@ -81,11 +81,11 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
             for (int tile = 0; tile < 4; ++tile) {
                 const int ti = tile >> 1, tj = tile & 1;
                 const f32x16& acc = tile == 0 ? c.c00 : tile == 1 ? c.c01 : tile == 2 ? c.c10 : c.c11;
-                __syncthreads();
+                wg_barrier();
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     lds.stage[((r & 3) + 8 * (r >> 2) + 4 * lk) * SST + li] = cost65_scale(acc[r], sq);
-                __syncthreads();
+                wg_barrier();
                 // element (rc, li) of this tile is matrix (2 rc + ti, 2 li + tj): this lane's block needs
                 // rc = 4I + k, li = 4J + m  ->  local (2k + ti, 2m + tj)
 #pragma unroll
@@ -104,7 +104,7 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
                 lds.ecol[2 * li + 1] = cost65_scale(c.ec1, sq);
             }
             zcorner = cost65_scale(c.cn, sq);
-            __syncthreads();
+            wg_barrier();
             zdrow = lds.erow[colj];          // Z[64][8J+I]
             zdcol = lds.ecol[lane];          // Z[8I+J][64]
         }
@@ -122,9 +122,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
             }
             const float r_own = fmaxf(reduce8_consecutive(part, OpMax(), lane), zdcol);
             const float r64 = uni(fmaxf(wave_max(zdrow), zcorner));
-            __syncthreads();
+            wg_barrier();
             lds.va[lane] = r_own;
-            __syncthreads();
+            wg_barrier();
             float rloc[8];
             {
                 const f4v v0 = *reinterpret_cast<const f4v*>(&lds.va[8 * I]), v1 = *reinterpret_cast<const f4v*>(&lds.va[8 * I + 4]);
@@ -140,9 +140,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
             }
             const float c_own = fmaxf(reduce8_strided(part, OpMax(), lane), zdrow - r64);
             const float c64 = uni(fmaxf(wave_max(zdcol - r_own), zcorner - r64));
-            __syncthreads();
+            wg_barrier();
             lds.vb[colj] = c_own;
-            __syncthreads();
+            wg_barrier();
             float cloc[8];
             {
                 const f4v v0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), v1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
@@ -158,10 +158,10 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
             const float kcorner = fast_exp2(((zcorner - r64) - c64) * LOG2E);
             const float mu = uni(expf(lmu)), mu64 = uni(expf(lmu64)), nu = expf(lnu), nu64 = uni(expf(lnu64));
             float a = 0.f, a64 = 0.f, b = expf(c_own), b64 = expf(c64);
-            __syncthreads();
+            wg_barrier();
             lds.vb[colj] = b;
             for (int it = 0; it < g.iters; ++it) {
-                __syncthreads();                                 // b visible
+                wg_barrier();                                 // b visible
                 {   // a_i = mu_i / sum_j K_ij b_j
                     const f4v b0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), b1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
                     // eight independent accumulator pairs advance together (column pair outer, row
@@ -192,7 +192,7 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
                     a64 = mu64 * __builtin_amdgcn_rcpf(fmaf(kcorner, b64, dsum));
                     lds.va[lane] = a;
                 }
-                __syncthreads();                                 // a visible
+                wg_barrier();                                 // a visible
                 {   // b_j = nu_j / sum_i K_ij a_i
                     const f4v a0 = *reinterpret_cast<const f4v*>(&lds.va[8 * I]), a1 = *reinterpret_cast<const f4v*>(&lds.va[8 * I + 4]);
                     const float al[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -231,9 +231,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
         for (int it = 0; it < g.iters; ++it) {
             float part[8], loc[8], mloc[8];
             // u = log_mu - lse_j(Z + v)
-            __syncthreads();
+            wg_barrier();
             lds.vb[colj] = v;
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int c = 0; c < 8; ++c) loc[c] = lds.vb[8 * J + c];
 #pragma unroll
@@ -246,9 +246,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
             float m = fmaxf(reduce8_consecutive(part, OpMax(), lane), zdcol + v64);
             if (m == -INFINITY || m == INFINITY) m = 0.f;
             const float mI = ceilf(m * LOG2E);
-            __syncthreads();
+            wg_barrier();
             lds.va[lane] = mI;
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int r = 0; r < 8; ++r) mloc[r] = lds.va[8 * I + r];
 #pragma unroll
@@ -269,9 +269,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
                 u64 = lmu64 - lse_fin(s2, mI2);
             }
             // v = log_nu - lse_i(Z + u)
-            __syncthreads();
+            wg_barrier();
             lds.va[lane] = u;
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int r = 0; r < 8; ++r) loc[r] = lds.va[8 * I + r];
 #pragma unroll
@@ -284,9 +284,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
             float mc = fmaxf(reduce8_strided(part, OpMax(), lane), zdrow + u64);
             if (mc == -INFINITY || mc == INFINITY) mc = 0.f;
             const float mIc = ceilf(mc * LOG2E);
-            __syncthreads();
+            wg_barrier();
             lds.vb[colj] = mIc;
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int c = 0; c < 8; ++c) mloc[c] = lds.vb[8 * J + c];
 #pragma unroll
@@ -313,9 +313,9 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
 
     // ---- the 16 centre rows of the plan exp(Z + u + v - norm) -> LDS, then Compute_result --------
     // centre row q = 4 (qy - 2) + (qx - 2) is matrix row 8 qy + qx: block row I = qy, local row qx.
-    __syncthreads();
+    wg_barrier();
     if (linear_done) { lds.va[lane] = sc_r; lds.vb[colj] = sc_c; } else { lds.va[lane] = dual_r; lds.vb[colj] = dual_c; }
-    __syncthreads();
+    wg_barrier();
     float* rows16 = lds.stage;              // [16][66]
     if (I >= 2 && I <= 5) {
         float cl[8];
@@ -339,7 +339,7 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
                                               : expf(((zdcol + dual_r) + dual_c64) - norm);
         }
     }
-    __syncthreads();
+    wg_barrier();
     // scale_x == NULL: scale_x = scale_y = sqrt(ns + 1e-8) (third_layer.py:153-154) is formed in the kernel
     const bool area = g.scale_x == nullptr;
     compute_result_problem(rows16, 0, p, (area ? g.ns : g.scale_x) + p * 64, (area ? g.ns : g.scale_y) + p * 64,
@@ -370,7 +370,7 @@ third_fused_kernel(Fused65Args g) {
     while (todo) {
         const int k = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        __syncthreads();
+        wg_barrier();
         third_v2_problem(g, base + k, lds, lane);
     }
 }

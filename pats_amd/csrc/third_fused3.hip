@@ -92,7 +92,7 @@ __device__ __forceinline__ float wave_sum_lds(float v, float* slot, int lane) {
     v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_f<DPP_ROW_MIRROR>(v);
     slot[lane >> 4] = v;
-    __syncthreads();
+    wg_barrier();
     const f4v r = *reinterpret_cast<const f4v*>(slot);
     return (r.x + r.y) + (r.z + r.w);
 }
@@ -127,7 +127,7 @@ __device__ __forceinline__ float reduce8_strided_lds(const f2v (&q)[4], float* T
         w[(2 * cp) * 8] = q[cp].x;
         w[(2 * cp + 1) * 8] = q[cp].y;
     }
-    __syncthreads();
+    wg_barrier();
     const float* r = T + J * 72 + I * 8;
     const f4v u = *reinterpret_cast<const f4v*>(r), v = *reinterpret_cast<const f4v*>(r + 4);
     return ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
@@ -260,7 +260,7 @@ third_fused3_kernel(Fused65Args g) {
     if (g.lds_poison_on) {
         unsigned* w = reinterpret_cast<unsigned*>(&lds);
         for (unsigned k = lane; k < sizeof(Blk3Lds) / 4; k += 64) w[k] = g.lds_poison;
-        __syncthreads();
+        wg_barrier();
     }
 #endif
     const int colj = 8 * J + I;              // the column this lane owns in the column half-sweep
@@ -301,14 +301,14 @@ third_fused3_kernel(Fused65Args g) {
         for (int tj = 0; tj < 2; ++tj) {
             const f32x16& even = tj == 0 ? c.c00 : c.c01;        // tile (ti, tj): element [r] <-> matrix (2 rc + ti, 2 li + tj)
             const f32x16& odd = tj == 0 ? c.c10 : c.c11;
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rc = (r & 3) + 8 * (r >> 2) + 4 * lk;
                 lds.stage[(2 * rc) * SST3 + li] = cost65_scale(even[r], sq);
                 lds.stage[(2 * rc + 1) * SST3 + li] = cost65_scale(odd[r], sq);
             }
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const f4v v = *reinterpret_cast<const f4v*>(&lds.stage[roff[s]]);    // k[s][2m + tj], m = 0..3
@@ -328,14 +328,14 @@ third_fused3_kernel(Fused65Args g) {
             lds.ecol[2 * li + 1] = cost65_scale(c.ec1, sq);
         }
         zcorner = cost65_scale(c.cn, sq);
-        __syncthreads();
+        wg_barrier();
         zdrow = lds.erow[colj];          // Z[64][8J+I]
         zdcol = lds.ecol[lane];          // Z[8I+J][64]
         if (DB == 4) {
             const f4v e0 = *reinterpret_cast<const f4v*>(&lds.erow[8 * J]), e1 = *reinterpret_cast<const f4v*>(&lds.erow[8 * J + 4]);
             zr8[0] = e0.x; zr8[1] = e0.y; zr8[2] = e0.z; zr8[3] = e0.w; zr8[4] = e1.x; zr8[5] = e1.y; zr8[6] = e1.z; zr8[7] = e1.w;
         }
-        __syncthreads();
+        wg_barrier();
         lds.erow[lane] = sx_lane;                        // the epilogue's target scales wait in the freed edge buffers
         lds.ecol[lane] = sy_lane;
     }
@@ -405,9 +405,9 @@ third_fused3_kernel(Fused65Args g) {
     const float cpart[8] = {cm[0].x, cm[0].y, cm[1].x, cm[1].y, cm[2].x, cm[2].y, cm[3].x, cm[3].y};
     const float c_own = fmaxf(reduce8_strided(cpart, OpMax(), lane), zdrow - r64);
     const float c64 = uni3(fmaxf(wave_max(zdcol - r_own), zcorner - r64));
-    __syncthreads();
+    wg_barrier();
     lds.vb[colj] = c_own;
-    __syncthreads();
+    wg_barrier();
     {
         const f4v v0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), v1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
         const float cl[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -450,10 +450,10 @@ third_fused3_kernel(Fused65Args g) {
 #ifdef PATS_DIAG
     unsigned trace_bits[7] = {0, 0, 0, 0, 0, 0, 0};      // (a, b) fingerprints after sweeps 1, 2, 4, 8, 16, 32, 64
 #endif
-    __syncthreads();
+    wg_barrier();
     lds.vb[colj] = b;
     for (int it = 0; it < g.iters; ++it) {
-        __syncthreads();                                 // b visible
+        wg_barrier();                                 // b visible
         {   // a_i = mu_i / sum_j K_ij b_j
             const f4v b0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), b1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
 #ifdef PATS_EXP_LGKM0
@@ -556,7 +556,7 @@ third_fused3_kernel(Fused65Args g) {
     // ---- plan rows of block rows 2..5 -> LDS [(I-2)*8 + local row][RS3], then Compute_result ------------
     // centre row q = 4 (qy - 2) + (qx - 2) is matrix row 8 qy + qx: block row qy, local row qx in 2..5.  A lane
     // cannot tell statically which of its register rows those are, so block rows 2..5 store all eight.
-    __syncthreads();                                     // b of the last sweep visible
+    wg_barrier();                                     // b of the last sweep visible
     float* rows = lds.stage;
     const float en = expf(-norm);
     if (I >= 2 && I <= 5) {
@@ -579,12 +579,12 @@ third_fused3_kernel(Fused65Args g) {
         }
         rows[((I - 2) * 8 + J) * RS3 + 64] = (kdcol * (a * en)) * b64;     // dustbin entry of the row this lane owns
     }
-    __syncthreads();
+    wg_barrier();
     if (DB == 8) { if (lane == 0) g.cr.ifm[p * 16] = 0; return; }      // timing ablation only: no Compute_result
     compute_result16(rows, lds.erow, lds.ecol, p, (float)g.p_s[p * 2], (float)g.p_s[p * 2 + 1], (float)g.p_t[p * 2],
                      (float)g.p_t[p * 2 + 1], g.outdoor, g.cr, lane);
 #ifdef PATS_DIAG
-    __syncthreads();
+    wg_barrier();
     if (lane == 0 && g.fingerprint) {
         g.cr.label[(p * 16) * 2 + 1] = __builtin_bit_cast(float, (score_bits & 0x007fffffu) | 0x3f800000u);
         g.cr.label[(p * 16 + 1) * 2 + 1] = __builtin_bit_cast(float, (k_bits & 0x007fffffu) | 0x3f800000u);
