@@ -65,9 +65,15 @@ def parse():
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="strong-scaling mode (configs[3]: 4000 YFCC pairs): this many pairs in all, split over the ranks by "
                          "shard.my_pairs; every rank walks its share in steps of --pairs (the last one partly filled)")
-    ap.add_argument("--maps", choices=["nhwc", "nchw"], default="nhwc",
-                    help="memory order of the synthetic backbone maps the two descriptor gathers read: torch.channels_last "
-                         "(default) or NCHW-contiguous; same logical tensors, same outputs bit for bit")
+    ap.add_argument("--maps", choices=["nhwc", "nchw"], default="nchw",
+                    help="memory order of the synthetic backbone maps the two descriptor gathers read in the HEADLINE steps: "
+                         "nchw (default) = NCHW-contiguous, what the unchanged reference's backbones emit (second_layer.py:66-69, "
+                         "third_layer.py:113-117); nhwc = torch.channels_last, what they emit after ops.prepare_backbones(model).  Same "
+                         "logical tensors, same outputs bit for bit.  The other layout is timed in the same run as a secondary "
+                         "(value_nchw / value_nhwc) unless --no-secondary")
+    ap.add_argument("--rows-cap", choices=["worst", "dry-run"], default="worst",
+                    help="row capacity of the fine level's table: worst = pairs * (N + (Cmax - 1) w), what a caller that knows nothing about "
+                         "its data allocates (default); dry-run = a dry run of the coarse stage on the step's own pairs + 1 %% (round 3)")
     ap.add_argument("--soak", type=int, default=0, metavar="N",
                     help="no timing: run N + 1 whole steps on the same inputs and compare every stage's output with the first step's "
                          "bit for bit (prints the step_determinism object and exits)")
@@ -112,7 +118,7 @@ class BenchNets:
     level, its dustbin features, and one scale-head row per third-level problem slot.  Inside the step the callbacks only
     run the path's own gathers (a15: ops.fine_descriptors, a16: ops.third_descriptors); GNN + final_proj = identity."""
 
-    def __init__(self, ops, dev, gen, cap, h, w, batch=None, channels_last=True):
+    def __init__(self, ops, dev, gen, cap, h, w, batch=None, channels_last=True, rows_cap_policy="worst"):
         self.ops = ops
         self.channels_last = cl = bool(channels_last)
         pairs, N = cap.pairs, h * w
@@ -124,10 +130,11 @@ class BenchNets:
         self.alpha = torch.tensor(0.0, device=dev)
         img = torch.randint(0, 256, (2, pairs, 32 * h, 32 * w, 3), device=dev, generator=gen).float()
         self.lefts, self.rights = img[0].contiguous(), (0.5 * img[1] + 0.5 * torch.roll(img[1], 1, dims=2)).contiguous()
-        # capacity planning, outside the timed region (the one host read of the set-up): a dry run of the coarse stage tells
-        # how many rows the fine level's table holds for THESE pairs; the row capacity becomes that + 1 % (a batch that
-        # outgrew it would raise when its matches are fetched) instead of the worst case N + (Cmax - 1) w per pair
-        if batch is not None:
+        # row capacity: the worst case N + (Cmax - 1) w per pair by default (the fine level's launches cover the capacity; rows
+        # past the device-side total are skipped by every kernel).  --rows-cap dry-run (round 3): a dry run of the coarse stage
+        # tells how many rows the table holds for THESE pairs and the capacity becomes that + 1 % - the benchmark peeking at its
+        # data, kept as an option only
+        if batch is not None and rows_cap_policy == "dry-run":
             total = int(batch.coarse_stage(self.lefts, self.rights, self, cap, ITERS, fine_inputs="rows_only")["rows"].chunk_base[-1].item())
             cap.rows_cap = min(cap.rows_cap, (int(total * 1.01) + 63) // 64 * 64)
         self.cap = cap
@@ -158,6 +165,20 @@ class BenchNets:
         self.t0 = [torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev) for _ in range(2)]
         self.t1 = [torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev) for _ in range(2)]
 
+    def set_layout(self, channels_last):
+        """Re-lay the five backbone maps (same logical tensors) in the other memory order, one tensor at a time."""
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        for name in ("m0", "m1", "m2", "ff0", "ff1"):
+            t = getattr(self, name)
+            setattr(self, name, None)
+            t2 = t.contiguous(memory_format=fmt)
+            del t
+            setattr(self, name, t2)
+            assert t2.is_contiguous(memory_format=fmt)
+        self.channels_last = bool(channels_last)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
     def resident_bytes(self):
         flat = []
         for v in vars(self).values():
@@ -179,7 +200,8 @@ class BenchNets:
         desc = self.desc[self.fine_calls & 1]
         self.fine_calls += 1
         e = self._timed("fine_desc")
-        self.ops.fine_descriptors([self.m0, self.m1, self.m2], self.title, self.rubbish, out=desc)            # a15
+        self.ops.fine_descriptors([self.m0, self.m1, self.m2], self.title, self.rubbish, out=desc,
+                                  count=rows.chunk_base[-1:])                                                 # a15
         if e is not None:
             e.record()
         return desc[0], desc[1], self.sx, self.sy, self.ns2
@@ -206,7 +228,42 @@ def _tensors(obj):
             yield from _tensors(getattr(obj, k, None))
 
 
-def run_steps(batch, nets, cap, wl, ev, n, streams):
+class StepWatch:
+    """Every step's counters (table status, third-level problem count P, match count M) come back to the host INSIDE the timed
+    region - asynchronously into pinned memory, checked one step behind, so the steps still queue ahead of the GPU - and a
+    capacity overflow in ANY step raises (batch.split_by_pair checks only the step it is handed)."""
+
+    def __init__(self, cap, depth=2):
+        self.cap, self.q, self.depth = cap, [], depth
+        self.pool = [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(2, dtype=torch.int64).pin_memory())
+                     for _ in range(depth + 1)]             # plain D2H copies: no kernel outside pats:: enters the steps
+        self.steps = 0
+
+    def push(self, out):
+        buf = self.pool[self.steps % len(self.pool)]
+        buf[0].copy_(out["status"], non_blocking=True)
+        buf[1][0:1].copy_(out["P"], non_blocking=True)
+        buf[1][1:2].copy_(out["M"], non_blocking=True)
+        e = torch.cuda.Event()
+        e.record()
+        self.q.append((e, buf))
+        self.steps += 1
+        while len(self.q) > self.depth:
+            self._check(*self.q.pop(0))
+
+    def _check(self, e, buf):
+        e.synchronize()
+        status, (P, M) = int(buf[0][0]), (int(v) for v in buf[1].tolist())
+        if status or P > self.cap.P_cap:
+            raise RuntimeError("bench: a step overflowed a capacity (status %d, P %d of %d)" % (status, P, self.cap.P_cap))
+        self.last = (status, P, M)
+
+    def drain(self):
+        while self.q:
+            self._check(*self.q.pop(0))
+
+
+def run_steps(batch, nets, cap, wl, ev, n, streams, watch=None):
     """n complete steps (batches).  streams = None: the stages of a batch one after the other on the current stream.
     streams = (sG, sS): two HIP streams with DISJOINT compute-unit masks (ops.masked_stream) -
         sG  the HBM-bound stages: coarse level + chunk rows + crops + fine descriptor gather of batch i, third-level window
@@ -225,6 +282,10 @@ def run_steps(batch, nets, cap, wl, ev, n, streams):
             co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
             fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
             out = batch.third_stage(fs, nets, cap, events=ev, **kw)
+            if watch is not None:
+                watch.push(out)
+        if watch is not None:
+            watch.drain()
         return out
     sG, sS = streams
     cur = torch.cuda.current_stream()
@@ -497,16 +558,18 @@ def cpu_baseline(ops, batch, dev, nets, cap, wl, out):
     log_mu = torch.cat([norm.expand(b, m), tns.sum(dim=2).log() + norm], dim=1)
     torch_cpu_sinkhorn(coup, log_mu, log_nu, ITERS)
     tt1 = time.perf_counter() - t0
-    n2 = min(B0, 96)
+    # the WHOLE pair, measured (no sampling): every fine problem, every third-level problem the merge left, in the batch
+    # sizes the reference issues them in (one chunk of <= 2w rows at a time; the third level chunk by chunk: ~300 problems)
     t0 = time.perf_counter()
-    torch_cpu_cost_ot2(torch.from_numpy(f0[:n2]), torch.from_numpy(f1[:n2]), torch.from_numpy((sx * sy)[:n2]), ITERS)
-    tt2 = (time.perf_counter() - t0) / max(n2, 1)
-    n3 = min(P0, 1024)
+    for o in range(0, B0, 40):
+        torch_cpu_cost_ot2(torch.from_numpy(f0[o:o + 40]), torch.from_numpy(f1[o:o + 40]), torch.from_numpy((sx * sy)[o:o + 40]), ITERS)
+    tt2 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    if n3:
-        torch_cpu_cost_ot2(torch.from_numpy(t3a[:n3]), torch.from_numpy(t3b[:n3]), torch.from_numpy(sc3[:n3]), ITERS)
-    tt3 = (time.perf_counter() - t0) / max(n3, 1)
-    torch_pair = tt1 + tt2 * B0 + tt3 * P0
+    step3 = max(1, -(-P0 // max(nchunks, 1)))
+    for o in range(0, P0, step3):
+        torch_cpu_cost_ot2(torch.from_numpy(t3a[o:o + step3]), torch.from_numpy(t3b[o:o + step3]), torch.from_numpy(sc3[o:o + step3]), ITERS)
+    tt3 = time.perf_counter() - t0
+    torch_pair = tt1 + tt2 + tt3
     return {"value": 1.0 / per_pair, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": "oracle/pats_oracle.c (OpenMP over problems) on ONE WHOLE PAIR, measured: pair 0 of a step - L1 %dx%d "
                       "(%.3fs), its %d fine problems (%.3fs), the merges of its %d chunks (%.3fs), its %d third-level problems "
@@ -514,10 +577,11 @@ def cpu_baseline(ops, batch, dev, nets, cap, wl, out):
                                                                   P0, times["L3"], times["result"]),
             "seconds_per_pair": per_pair,
             "torch_cpu": {"value": 1.0 / torch_pair, "unit": "pairs/s", "cores": cores,
-                          "sample": "torch transcription of the reference's CPU arithmetic (einsum cost builds + modules.py:137-182 "
-                                    "logsumexp sweeps; no expansion / merge), %d torch threads: L1 in full (%.3fs), %d of the pair's %d "
-                                    "fine problems (%.4fs each), %d of its %d third-level problems (%.5fs each), scaled to the pair"
-                                    % (cores, tt1, n2, B0, tt2, n3, P0, tt3)},
+                          "sample": "measured on ONE WHOLE PAIR (no sampling): torch transcription of the reference's CPU arithmetic (einsum "
+                                    "cost builds + modules.py:137-182 logsumexp sweeps; no expansion / merge), %d torch threads: L1 "
+                                    "(%.3fs), all %d fine problems in chunks of 40 (%.3fs), all %d third-level problems in %d chunks (%.3fs)"
+                                    % (cores, tt1, B0, tt2, P0, max(nchunks, 1), tt3),
+                          "seconds_per_pair": torch_pair},
             "parity_sample": parity}
 
 
@@ -722,7 +786,10 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(synth.SEED + rank)
     cap = batch.Capacities(pairs, h, w, if_local=if_local)
-    nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch, channels_last=args.maps == "nhwc")
+    t_setup = time.perf_counter()
+    nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch, channels_last=args.maps == "nhwc", rows_cap_policy=args.rows_cap)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
     n_gpus = dist.get_world_size() if dist is not None else 1
     if args.soak > 0:
         rep = step_determinism(batch, nets, cap, wl, n=args.soak + 1)
@@ -753,11 +820,12 @@ def main():
     run_steps(batch, nets, cap, wl, None, args.warmup, streams)
     ev = {}
     nets.ev = ev
+    watch = StepWatch(cap) if streams is None else None
     barrier()
     ops.sinkhorn_fallbacks(reset=True)
     ops.profile_marker(1)                                # kernel traces are cut to the steps between the two markers
     t0 = time.perf_counter()
-    out = run_steps(batch, nets, cap, wl, ev, steps, streams)
+    out = run_steps(batch, nets, cap, wl, ev, steps, streams, watch)
     barrier()
     dt = time.perf_counter() - t0
     ops.profile_marker(2)
@@ -788,11 +856,11 @@ def main():
         assert len(got) == len(gathered) or args.total_pairs > 0, "gather_matches lost a pair"
         matches_per_pair = float(np.mean([g_[0].shape[0] for g_ in got])) if got else 0.0
         gather_bytes = sum(g_[0].shape[0] for g_ in got) * 16
-    rank_ms = [rank_ms_per_step]
+    rank_ms, rank_setup = [rank_ms_per_step], [setup_s]
     if dist is not None:
-        tl = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(n_gpus)]
-        dist.all_gather(tl, torch.tensor([rank_ms_per_step], device=dev, dtype=torch.float64))
-        rank_ms = [float(x.item()) for x in tl]
+        tl = [torch.zeros(2, device=dev, dtype=torch.float64) for _ in range(n_gpus)]
+        dist.all_gather(tl, torch.tensor([rank_ms_per_step, setup_s], device=dev, dtype=torch.float64))
+        rank_ms, rank_setup = [float(x[0].item()) for x in tl], [float(x[1].item()) for x in tl]
 
     res, other = None, []
     if out is not None:
@@ -953,22 +1021,43 @@ def main():
                              % (rows_step, rows_step / float(pairs), cap.rows_cap, cap.Cmax),
                        "L3": "%d x [128,65]^2 -> 65x65 per step, decided by the merge (%.1f per pair; capacity %d)"
                              % (P_step, P_step / float(pairs), cap.P_cap),
-                       "map_layout": "torch.channels_last (logical [B,C,H,W], memory [B,H,W,C]) for the five backbone maps the gathers read"
-                                     if nets.channels_last else "NCHW-contiguous backbone maps",
+                       "map_layout": ("torch.channels_last (logical [B,C,H,W], memory [B,H,W,C]) for the five backbone maps the gathers read: "
+                                      "what the reference's backbones emit after ops.prepare_backbones(model) (value_nhwc)"
+                                      if nets.channels_last else
+                                      "NCHW-contiguous backbone maps: what the UNCHANGED reference's backbones emit (second_layer.py:66-69, "
+                                      "third_layer.py:113-117); value = value_nchw.  value_nhwc = the same steps on torch.channels_last maps"),
+                       "rows_cap": "%s (%d rows; %d in use - the fine level's launches take the count from the device and skip the rest)"
+                                   % ("worst case pairs * (N + (Cmax - 1) w)" if args.rows_cap == "worst" else "dry run of the step's own pairs + 1 %",
+                                      cap.rows_cap, rows_step),
+                       "result_handover": "every step's status / P / M counters are copied to pinned host memory inside the timed region "
+                                          "and checked one step behind (an overflow in any step raises); the per-pair split of the matches "
+                                          "(batch.split_by_pair) and their gather to rank 0 run once, after the clock",
+                       "setup_s": setup_s,
                        "resident_synthetic_GB": nets.resident_bytes() / 1e9, "sinkhorn_iters": ITERS,
                        "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
                                       "after the timed region (%s)" % (n_gpus, backend if dist is not None else "single process")},
             "ot_iters_per_sec": value * sweeps_per_pair,
             "guard_fallbacks_per_step": fallbacks / max(1, steps),
             "gather_ms": gather_ms, "matches_per_pair": matches_per_pair,
-            "rank_ms_per_step": rank_ms,
+            "rank_ms_per_step": rank_ms, "rank_setup_s": rank_setup,
             "roofline": dominant,
         }
     if rank == 0:
         assert res is not None, "rank 0 owns no pair"
         if n_gpus > 1:
             res["gather_bytes"] = gather_bytes
+        res["value_" + args.maps] = value
         if not args.no_secondary and n_gpus == 1:
+            # the same steps on the same logical maps in the OTHER memory order (re-laid in place, one tensor at a time)
+            other_maps = "nhwc" if args.maps == "nchw" else "nchw"
+            nets.set_layout(other_maps == "nhwc")
+            run_steps(batch, nets, cap, wl, None, 1, None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(batch, nets, cap, wl, None, steps, None, StepWatch(cap))
+            torch.cuda.synchronize()
+            res["value_" + other_maps] = pairs * steps / (time.perf_counter() - t1)
+            nets.set_layout(args.maps == "nhwc")
             res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
             res["step_determinism"] = step_determinism(batch, nets, cap, wl)

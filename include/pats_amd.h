@@ -43,7 +43,7 @@ const char* pats_version(void);
  * `row_nomatch` to pats_iterative_expand_f32 under the same symbol: a caller built against the older header would pass
  * its stream where the new pointer goes).  A C consumer checks `pats_abi_version() == PATS_ABI_VERSION` once after
  * loading the library; pats_amd/_lib.py does.  New arguments now come with new entry points instead. */
-#define PATS_ABI_VERSION 4
+#define PATS_ABI_VERSION 5
 int pats_abi_version(void);
 const char* pats_last_error(void);
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
@@ -125,6 +125,15 @@ int pats_cost_ot_flags_f32(const float* d0, const float* d1, int64_t batch, int 
                            float* Z, uint8_t* col_nomatch, void* workspace, size_t workspace_bytes,
                            pats_stream_t stream);
 
+/* The fine level launched over a CAPACITY of batch_cap problems with the number in use on the device (throughput mode:
+ * batch_dev = the row table's total, &chunk_base[Cmax] of pats_chunk_rows_device): workgroups of problems >= *batch_dev return
+ * at once - no cost build, no solve, no log-domain redo; their rows of Z / col_nomatch are left untouched.  variant 2,
+ * n = m = 145 only; everything else as pats_cost_ot_flags_f32 (workspace sized for batch_cap).  ABI 5. */
+int pats_cost_ot_flags_counted_f32(const float* d0, const float* d1, int64_t batch_cap, const int64_t* batch_dev,
+                                   int D, int n, int m, int variant, const float* scalar, const float* ns, int iters,
+                                   float bias_k, float* Z, uint8_t* col_nomatch, void* workspace,
+                                   size_t workspace_bytes, pats_stream_t stream);
+
 /* ---- a7: post-OT reductions ----------------------------------------------------------------
  * colmass: out[b,j] = sqrtf(sum_{i<M-1} expf(Z[b,i,j]) + 1e-8f), j < N-1   first_layer.py:117-118
  * bias   : Z[:,:,-1] += logf(k); Z[:,-1,:] += logf(k) in place              second_layer.py:107-112
@@ -160,6 +169,14 @@ int pats_iterative_expand_f32(const float* P, int input_is_log, int64_t batch, i
                               float lower_bound, int iter_num, float* whole_cost, float* core_cost,
                               float* average_point, float* x_scale, float* y_scale, int64_t* bound,
                               uint8_t* row_nomatch, pats_stream_t stream);
+
+/* The same over a capacity of batch_cap problems, *batch_dev of them in use (device-side count); the outputs of the others are
+ * left untouched.  ABI 5. */
+int pats_iterative_expand_counted_f32(const float* P, int input_is_log, int64_t batch_cap, const int64_t* batch_dev,
+                                      int M, int N, const float* scalex, const float* scaley, int lim3, int h, int w,
+                                      float lower_bound, int iter_num, float* whole_cost, float* core_cost,
+                                      float* average_point, float* x_scale, float* y_scale, int64_t* bound,
+                                      uint8_t* row_nomatch, pats_stream_t stream);
 
 /* ---- a12: split_patches(sum_cycle, height, width, max_once_used)  utils/utils.py:152-181 ----
  * HOST function on a host copy of the int32 cumsum (the reference syncs per comparison; here the
@@ -247,6 +264,12 @@ int pats_compute_result_ws_f32(const float* scores, int input_is_log, int64_t P,
 int pats_fine_descriptors_f32(const float* feat0, const float* feat1, const float* feat2,
                               const float* title, const float* rubbish, int64_t B, float* desc,
                               pats_stream_t stream);
+
+/* a15 over a capacity of B_cap rows, *B_dev of them in use (device-side count; the desc blocks of the others are left
+ * untouched); channels_last != 0: the maps are torch.channels_last as for pats_fine_descriptors_nhwc_f32.  ABI 5. */
+int pats_fine_descriptors_counted_f32(const float* feat0, const float* feat1, const float* feat2,
+                                      const float* title, const float* rubbish, int64_t B_cap,
+                                      const int64_t* B_dev, int channels_last, float* desc, pats_stream_t stream);
 
 /* ---- a16: third-level 8x8 window gather  models/third_layer.py:121-146 -----------------------
  * feat_f0, feat_f1 [B,128,52,52]; mkpts0_c, mkpts1_c [P,2] float (x, y) coarse points in crop
@@ -448,6 +471,21 @@ int pats_attentional_propagation_f32(const float* x, const float* source, int64_
                                      int n, int m, const pats_propagation_weights* weights, int bn_train,
                                      float bn_eps, const float* residual, float* out, void* workspace,
                                      size_t workspace_bytes, pats_stream_t stream);
+
+/* The same layer with the weights additionally PACKED for the matrix pipe (ABI 5): pats_propagation_pack_f32 splits every
+ * Conv1d matrix into fp16 hi + lo halves in MFMA fragment order (q / k / v rows and the merge's columns permuted to head-major)
+ * once per layer into a caller-owned, 16-byte aligned device buffer of pats_propagation_packed_bytes(C, heads) bytes (0 = no
+ * packed form for this shape).  With it, at the third level's shape (C = 128, 4 heads, n = m = 65) the layer runs as ONE kernel
+ * that keeps a problem's activations in LDS from the descriptors to the output (csrc/gnn_fused.hip; bn_train != 0: one kernel
+ * up to the hidden tensor, then the batch-statistics passes and the last convolution); other shapes, PATS_GNN_FUSED=0 and
+ * launches in which an activation left the fp16 range of the split operands take the composition above (same workspace). */
+size_t pats_propagation_packed_bytes(int C, int heads);
+int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
+                              pats_stream_t stream);
+int pats_attentional_propagation_packed_f32(const float* x, const float* source, int64_t batch, int C, int heads,
+                                            int n, int m, const pats_propagation_weights* w, const void* packed,
+                                            int bn_train, float bn_eps, const float* residual, float* out,
+                                            void* workspace, size_t workspace_bytes, pats_stream_t stream);
 
 /* ---- the descriptor heads either side of the GNN: Conv1d(kernel_size=1) and BatchNorm1d + ReLU -------------------
  * Replaces nn.Conv1d(k=1) wherever the path uses it alone - `final_proj` right before the cost build

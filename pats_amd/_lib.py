@@ -17,7 +17,7 @@ if os.environ.get("PATS_AMD_DIAG_LIB", "") not in ("", "0"):
 c_void_p, c_int, c_i64, c_f, c_size = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                        ctypes.c_size_t)
 
-ABI_VERSION = 4      # include/pats_amd.h PATS_ABI_VERSION
+ABI_VERSION = 5      # include/pats_amd.h PATS_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol include/pats_amd.h declares
 SIGNATURES = {
@@ -42,6 +42,13 @@ SIGNATURES = {
                                  c_void_p, c_int, c_f, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_cost_ot_flags_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_cost_ot_flags_counted_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                               c_void_p, c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_iterative_expand_counted_f32": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                                  c_int, c_int, c_f, c_int, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pats_fine_descriptors_counted_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int,
+                                                  c_void_p, c_void_p]),
     "pats_log_optimal_transport2_flags_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int,
                                                       c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_colmass_flags_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -115,6 +122,10 @@ SIGNATURES = {
     "pats_attentional_propagation_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "pats_attentional_propagation_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_f,
                                                  c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_propagation_packed_bytes": (c_size, [c_int, c_int]),
+    "pats_propagation_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size, c_void_p]),
+    "pats_attentional_propagation_packed_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                        c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_conv1x1_workspace_bytes": (c_size, []),
     "pats_conv1x1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size, c_void_p]),

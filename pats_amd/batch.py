@@ -19,9 +19,10 @@ merge's `scores_back` (pats.py:32,37), so with 288 GB of HBM every stage becomes
 
 Sizes are capacities fixed on the host (`Capacities`); the counts the reference reads back (matched patches K, rows B,
 third-level problems P, matches M) stay on the device and come back WITH the results: `status` / `P` / `M` are read by
-the caller when it fetches the matches.  Rows of the table that no chunk uses (padding) run through the fine level on
-whatever the network callback left there and are masked at the merge; rows that are left without a cell are not
-compacted (pats.py:40-52) - they emit nothing, exactly as in pipeline.forward_path.
+the caller when it fetches the matches.  Rows of the table that no chunk uses (padding past the device-side total
+`rows.chunk_base[-1]`) are SKIPPED by the fine level's launches (cost build, OT, expansion take the count from the device;
+a network callback may do the same with ops.fine_descriptors(count=...)) and are "no match" at the merge; rows that are left
+without a cell are not compacted (pats.py:40-52) - they emit nothing, exactly as in pipeline.forward_path.
 
 Network callbacks (`nets`, the out-of-scope backbones + heads; GPU float32 tensors, no host read required of them):
   nets.coarse(lefts, rights) -> mdesc0 [pairs,D,N], mdesc1 [pairs,D,N], scale [pairs,1,N], alpha
@@ -69,8 +70,7 @@ def _one(device):
 def _round4(x, clamp96):
     """third_layer.py:122 / :126-128: round(x / 4).long() * 4 (targets clamped to [0, 96] first)."""
     if clamp96:
-        x = torch.where(x >= 96, torch.tensor(96.0, device=x.device), x)
-        x = torch.where(x <= 0, torch.tensor(0.0, device=x.device), x)
+        x = torch.clamp(x, 0.0, 96.0)           # == the reference's two torch.where; python scalars: no H2D copy per call
     return torch.round(x / 4.0).long() * 4
 
 
@@ -116,10 +116,12 @@ def fine_solve_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, 
     f0, f1, sx, sy = fine[:4]
     ns2 = fine[4] if len(fine) > 4 else (sx * sy).contiguous()
     e = _timed(events, "fine")
-    Z2, cflag2 = ops.cost_ot(f0, f1, 2, _one(f0.device), ns2, iters, bias_k=2.0 if if_outdoor else 3.0, return_flags=True)
+    live = rows.chunk_base[-1:]                 # rows in use, on the device: the launches cover rows_cap, padding rows are skipped
+    Z2, cflag2 = ops.cost_ot(f0, f1, 2, _one(f0.device), ns2, iters, bias_k=2.0 if if_outdoor else 3.0, return_flags=True,
+                             count=live)
     if e is not None:
         e.record()
-    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
+    trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2, count=live)
     merged = ops.merge_patches_batch(merge_new, rows, trust2, (H, W), ifn_L2)
     mk0, mk1, b_ids, P = ops.third_inputs(merged, pts2, capacity=cap.P_cap, sync=False)
     return {"co": co, "merged": merged, "pts2": pts2, "P": P, "mk0": mk0, "mk1": mk1, "b_ids": b_ids,

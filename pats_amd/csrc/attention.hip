@@ -34,12 +34,14 @@ struct AttnArgs {
     int rows;                             // query rows per workgroup: 32, or 16 / 8 / 4 when m is too large for a 32-row slab
     float sq, rsq;                        // dim**.5 and its reciprocal
     float* out; float* prob;
+    const int* gate;                      // optional: the launch is a no-op unless *gate != 0 (fallback behind the fused GNN layer)
 };
 }  // namespace
 
 __global__ void __launch_bounds__(256)
 attention_kernel(AttnArgs g) {
     extern __shared__ __attribute__((aligned(16))) float slab[];          // [rows][mp], then 4 x [32][VST]
+    if (g.gate && *g.gate == 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
     // beyond 1024 keys a 32-row slab no longer fits the CU's LDS: the workgroup then takes 16 / 8 / 4 query rows (the MFMA
@@ -172,6 +174,7 @@ struct Attn65Lds {
 __global__ void __launch_bounds__(64, 2)
 attention65_kernel(AttnArgs g) {
     __shared__ Attn65Lds lds;
+    if (g.gate && *g.gate == 0) return;
     const int lane = threadIdx.x, li = lane & 31, lk = lane >> 5;
     const int64_t bh = blockIdx.x, bi = bh / g.heads;
     const int h = (int)(bh - bi * g.heads);
@@ -279,9 +282,19 @@ attention65_kernel(AttnArgs g) {
 
 using namespace pats;
 
+namespace pats {
+int launch_attention(const float* query, const float* key, const float* value, int64_t batch, int dim, int heads, int n, int m,
+                     float* out, float* prob, pats_stream_t stream, const int* gate);
+}
+
 extern "C" int pats_attention_f32(const float* query, const float* key, const float* value, int64_t batch,
                                   int dim, int heads, int n, int m, float* out, float* prob,
                                   pats_stream_t stream) {
+    return launch_attention(query, key, value, batch, dim, heads, n, m, out, prob, stream, nullptr);
+}
+
+int pats::launch_attention(const float* query, const float* key, const float* value, int64_t batch, int dim, int heads, int n,
+                           int m, float* out, float* prob, pats_stream_t stream, const int* gate) {
     PATS_REQUIRE(batch >= 0 && dim > 0 && heads > 0 && n > 0 && m > 0, "attention: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(query && key && value && out, "attention: null pointer");
@@ -289,7 +302,7 @@ extern "C" int pats_attention_f32(const float* query, const float* key, const fl
     static const bool general_only = getenv("PATS_ATTN_GENERAL") != nullptr;     // A/B switch for benchmarking
     if (n == 65 && m == 65 && dim == 32 && !prob && !general_only) {            // the third-level shape
         PATS_REQUIRE(batch * heads < (1ll << 31), "attention: grid too large (split the batch)");
-        AttnArgs g{query, key, value, dim, heads, n, m, 0, 32, sq0, 1.0f / sq0, out, nullptr};
+        AttnArgs g{query, key, value, dim, heads, n, m, 0, 32, sq0, 1.0f / sq0, out, nullptr, gate};
         hipLaunchKernelGGL(attention65_kernel, dim3((unsigned)(batch * heads)), dim3(64), 0, as_stream(stream), g);
         return check_launch("attention65_kernel");
     }
@@ -312,7 +325,7 @@ extern "C" int pats_attention_f32(const float* query, const float* key, const fl
         hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return check_launch("attention (LDS opt-in)");
     const float sq = (float)sqrt((double)dim);
-    AttnArgs g{query, key, value, dim, heads, n, m, mp, rows, sq, 1.0f / sq, out, prob};
+    AttnArgs g{query, key, value, dim, heads, n, m, mp, rows, sq, 1.0f / sq, out, prob, gate};
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), g);
     return check_launch("attention_kernel");
 }

@@ -34,12 +34,13 @@ struct CostCols {
 template <bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D, int n, int m,
-                 float rsqrtD, float sqrtD, float* __restrict__ out) {
+                 float rsqrtD, float sqrtD, float* __restrict__ out, const int64_t* __restrict__ live) {
     __shared__ mt::Lds lds;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int tiles_j = (m + mt::CT - 1) / mt::CT, tiles = tiles_j * ((n + mt::CT - 1) / mt::CT);
     const int64_t b = blockIdx.x / tiles;
+    if (live && b >= *live) return;            // counted launch (throughput mode): problems past the device-side count
     const int tt = (int)(blockIdx.x - b * tiles);
     const int i0 = (tt / tiles_j) * mt::CT, j0 = (tt % tiles_j) * mt::CT;
     const CostCols cols{n, m, i0, j0};
@@ -72,8 +73,19 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
 namespace pats { int launch_cost65(const float*, const float*, int, int64_t, float*, hipStream_t); }
 using namespace pats;
 
+namespace pats {
+int launch_cost(const float* d0, const float* d1, int64_t batch, int D, int n, int m, float* out, pats_stream_t stream,
+                const int64_t* live);
+}
+
 extern "C" int pats_cost_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
                              float* out, pats_stream_t stream) {
+    return launch_cost(d0, d1, batch, D, n, m, out, stream, nullptr);
+}
+
+// live: optional device-side problem count (<= batch) - the MFMA-tile kernel's workgroups past it return at once
+int pats::launch_cost(const float* d0, const float* d1, int64_t batch, int D, int n, int m, float* out, pats_stream_t stream,
+                      const int64_t* live) {
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(d0 && d1 && out, "cost: null pointer");
@@ -85,8 +97,8 @@ extern "C" int pats_cost_f32(const float* d0, const float* d1, int64_t batch, in
     const float sq = (float)sqrt((double)D);
     const dim3 grid((unsigned)(tiles * batch)), block(256);
     if (fp32_only)
-        hipLaunchKernelGGL(cost_mfma_kernel<false>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out);
+        hipLaunchKernelGGL(cost_mfma_kernel<false>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out, live);
     else
-        hipLaunchKernelGGL(cost_mfma_kernel<true>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out);
+        hipLaunchKernelGGL(cost_mfma_kernel<true>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out, live);
     return check_launch("cost_mfma_kernel");
 }

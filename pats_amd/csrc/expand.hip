@@ -35,6 +35,7 @@ struct ExpandArgs {
     float *whole_cost, *core_cost, *average_point, *x_scale, *y_scale;
     int64_t* bound;
     uint8_t* row_nomatch;     // optional: scores.max(2).indices == N - 1 of the INPUT values (first_layer.py:162-164)
+    const int64_t* live;      // optional: device-side batch count (counted launch); rows of problems >= *live are skipped
 };
 
 __device__ __forceinline__ float range_val(int d, int k) { return k <= d ? (float)k : 1e7f; }
@@ -55,9 +56,15 @@ expand_kernel(ExpandArgs a) {
     const int t = threadIdx.x & 15, slot = threadIdx.x >> 4;      // lane in group, group in workgroup
     const int ROWS_PER_WG = blockDim.x >> 4;                      // 16 (256 threads) or 4 for wide rows
     const int M = a.M, N = a.N, m = M - 1, n = N - 1;
+    int64_t rows_total = a.rows_total;
+    if (a.live) {                                                 // counted launch: the rows of the first *live problems
+        const int64_t lv = *a.live * m;
+        rows_total = lv < rows_total ? lv : rows_total;
+        if ((int64_t)blockIdx.x * ROWS_PER_WG >= rows_total) return;      // workgroup-uniform
+    }
     const int64_t gr_raw = (int64_t)blockIdx.x * ROWS_PER_WG + slot;
-    const bool active = gr_raw < a.rows_total;
-    const int64_t gr = active ? gr_raw : a.rows_total - 1;       // idle groups shadow the last row
+    const bool active = gr_raw < rows_total;
+    const int64_t gr = active ? gr_raw : rows_total - 1;         // idle groups shadow the last row
     const int64_t b = gr / m;
     const int r = (int)(gr - b * m);
     const int ld = N + 3;
@@ -76,14 +83,14 @@ expand_kernel(ExpandArgs a) {
     // (when m >= rows per workgroup), so the whole workgroup stages those two rows ONCE (the first version had every
     // 16-lane group exponentiate its own copy: 16 x N exps per workgroup instead of 2 x N).
     const int64_t g0 = (int64_t)blockIdx.x * ROWS_PER_WG;
-    const int64_t glast = min(g0 + ROWS_PER_WG - 1, a.rows_total - 1);
+    const int64_t glast = min(g0 + ROWS_PER_WG - 1, rows_total - 1);
     const int64_t b0 = g0 / m;
     const bool shared_opp = glast / m - b0 <= 1;                  // workgroup-uniform
     if (shared_opp) {
         popp = sm + (size_t)ROWS_PER_WG * ld + (size_t)(b - b0) * ld;
         for (int e = threadIdx.x; e < 2 * N; e += blockDim.x) {
             const int which = e >= N, j = e - which * N;
-            const int64_t bb = min(b0 + which, (int64_t)(a.rows_total - 1) / m);
+            const int64_t bb = min(b0 + which, (int64_t)(rows_total - 1) / m);
             const float o = a.P[bb * (int64_t)M * N + (int64_t)(M - 1) * N + j];
             sm[(size_t)ROWS_PER_WG * ld + (size_t)which * ld + j] = a.input_is_log ? expf(o) : o;
         }
@@ -289,12 +296,36 @@ expand_kernel(ExpandArgs a) {
 
 using namespace pats;
 
+static int expand_impl(const float* P, int input_is_log, int64_t batch, int M, int N, const float* scalex, const float* scaley,
+                       int lim3, int h, int w, float lower_bound, int iter_num, float* whole_cost, float* core_cost,
+                       float* average_point, float* x_scale, float* y_scale, int64_t* bound, uint8_t* row_nomatch,
+                       const int64_t* live, pats_stream_t stream);
+
 extern "C" int pats_iterative_expand_f32(const float* P, int input_is_log, int64_t batch, int M,
                                          int N, const float* scalex, const float* scaley, int lim3,
                                          int h, int w, float lower_bound, int iter_num,
                                          float* whole_cost, float* core_cost, float* average_point,
                                          float* x_scale, float* y_scale, int64_t* bound,
                                          uint8_t* row_nomatch, pats_stream_t stream) {
+    return expand_impl(P, input_is_log, batch, M, N, scalex, scaley, lim3, h, w, lower_bound, iter_num, whole_cost, core_cost,
+                       average_point, x_scale, y_scale, bound, row_nomatch, nullptr, stream);
+}
+
+// launched over a capacity of batch_cap problems, *batch_dev of them in use (throughput mode); outputs of the others untouched
+extern "C" int pats_iterative_expand_counted_f32(const float* P, int input_is_log, int64_t batch_cap, const int64_t* batch_dev,
+                                                 int M, int N, const float* scalex, const float* scaley, int lim3, int h, int w,
+                                                 float lower_bound, int iter_num, float* whole_cost, float* core_cost,
+                                                 float* average_point, float* x_scale, float* y_scale, int64_t* bound,
+                                                 uint8_t* row_nomatch, pats_stream_t stream) {
+    PATS_REQUIRE(batch_dev, "iterative_expand_counted: null count");
+    return expand_impl(P, input_is_log, batch_cap, M, N, scalex, scaley, lim3, h, w, lower_bound, iter_num, whole_cost, core_cost,
+                       average_point, x_scale, y_scale, bound, row_nomatch, batch_dev, stream);
+}
+
+static int expand_impl(const float* P, int input_is_log, int64_t batch, int M, int N, const float* scalex, const float* scaley,
+                       int lim3, int h, int w, float lower_bound, int iter_num, float* whole_cost, float* core_cost,
+                       float* average_point, float* x_scale, float* y_scale, int64_t* bound, uint8_t* row_nomatch,
+                       const int64_t* live, pats_stream_t stream) {
     PATS_REQUIRE(batch >= 0 && M > 1 && N > 1 && h > 0 && w > 0 && lim3 > 0 && iter_num >= 1,
                  "iterative_expand: bad argument");
     PATS_REQUIRE(h * w == N - 1, "iterative_expand: grid %dx%d does not match %d target columns", h,
@@ -303,7 +334,7 @@ extern "C" int pats_iterative_expand_f32(const float* P, int input_is_log, int64
     PATS_REQUIRE(P && scalex && scaley && whole_cost && core_cost && average_point && x_scale &&
                      y_scale && bound, "iterative_expand: null pointer");
     ExpandArgs a{P, input_is_log, batch * (int64_t)(M - 1), M, N, scalex, scaley, lim3, h, w,
-                 lower_bound, iter_num, whole_cost, core_cost, average_point, x_scale, y_scale, bound, row_nomatch};
+                 lower_bound, iter_num, whole_cost, core_cost, average_point, x_scale, y_scale, bound, row_nomatch, live};
     int rows_per_wg = 16;
     size_t lds = 2 * (size_t)rows_per_wg * (size_t)(N + 3) * sizeof(float);
     if (lds > 48 * 1024) {

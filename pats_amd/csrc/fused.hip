@@ -16,7 +16,13 @@ int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_n
 
 namespace pats {
 int launch_fine145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
-                         float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied);
+                         float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied,
+                         const int64_t* live);
+int launch_cost(const float* d0, const float* d1, int64_t batch, int D, int n, int m, float* out, pats_stream_t stream,
+                const int64_t* live);
+int ot2_flags_live(const float* scores, int64_t batch, int m, int n, const float* one, const float* ns, int iters, float bias_k,
+                   float* Z, uint8_t* col_nomatch, void* workspace, size_t workspace_bytes, pats_stream_t stream,
+                   const int64_t* live);
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -31,7 +37,7 @@ extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int 
 
 static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, int n, int m, int variant,
                         const float* scalar, const float* ns, int iters, float bias_k, float* Z, uint8_t* col_nomatch,
-                        void* workspace, size_t workspace_bytes, pats_stream_t stream);
+                        void* workspace, size_t workspace_bytes, pats_stream_t stream, const int64_t* live = nullptr);
 
 extern "C" int pats_cost_ot_f32(const float* d0, const float* d1, int64_t batch, int D, int n, int m,
                                 int variant, const float* scalar, const float* ns, int iters,
@@ -52,9 +58,22 @@ extern "C" int pats_cost_ot_flags_f32(const float* d0, const float* d1, int64_t 
                         workspace_bytes, stream);
 }
 
+// The fine level of a batch whose row count lives on the device (throughput mode: the row table's total, pats_chunk_rows_device):
+// launched over the capacity `batch_cap`, the workgroups of problems >= *batch_dev return at once - no cost build, no solve, no
+// log-domain redo; their Z / col_nomatch rows are left untouched.
+extern "C" int pats_cost_ot_flags_counted_f32(const float* d0, const float* d1, int64_t batch_cap, const int64_t* batch_dev,
+                                              int D, int n, int m, int variant, const float* scalar, const float* ns, int iters,
+                                              float bias_k, float* Z, uint8_t* col_nomatch, void* workspace,
+                                              size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(variant == 2 && n == 145 && m == 145, "cost_ot_flags_counted: the fine level only (variant 2, 145 x 145)");
+    PATS_REQUIRE(batch_dev, "cost_ot_flags_counted: null count");
+    return cost_ot_impl(d0, d1, batch_cap, D, n, m, variant, scalar, ns, iters, bias_k, Z, col_nomatch, workspace,
+                        workspace_bytes, stream, batch_dev);
+}
+
 static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, int n, int m, int variant,
                         const float* scalar, const float* ns, int iters, float bias_k, float* Z, uint8_t* col_nomatch,
-                        void* workspace, size_t workspace_bytes, pats_stream_t stream) {
+                        void* workspace, size_t workspace_bytes, pats_stream_t stream, const int64_t* live) {
     PATS_REQUIRE(variant == 1 || variant == 2, "cost_ot: variant must be 1 or 2");
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost_ot: bad shape");
     if (batch == 0) return PATS_OK;
@@ -75,10 +94,10 @@ static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, 
         PATS_REQUIRE(d0 && d1 && ns && Z, "cost_ot: null pointer");
         bool applied = false;
         int rc = launch_fine145_fused(d0, d1, D, batch, ns, scalar, iters, bias_k, Z, (int*)ws2, col_nomatch, (hipStream_t)stream,
-                                      &applied);
+                                      &applied, live);
         if (rc || applied) return rc;
     }
-    int rc = pats_cost_f32(d0, d1, batch, D, n, m, scores, stream);
+    int rc = launch_cost(d0, d1, batch, D, n, m, scores, stream, live);
     if (rc) return rc;
     if (variant == 1) {
         PATS_REQUIRE(scalar, "cost_ot: alpha pointer required for variant 1");
@@ -86,6 +105,5 @@ static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, 
         return pats_log_optimal_transport_f32(scores, batch, n, m, scalar, ns, iters, Z, ws2,
                                               workspace_bytes - off, stream);
     }
-    return pats_log_optimal_transport2_flags_f32(scores, batch, n, m, scalar, ns, iters, bias_k, Z, col_nomatch, ws2,
-                                                 workspace_bytes - off, stream);
+    return ot2_flags_live(scores, batch, n, m, scalar, ns, iters, bias_k, Z, col_nomatch, ws2, workspace_bytes - off, stream, live);
 }

@@ -23,9 +23,11 @@ namespace pats {
 __global__ void __launch_bounds__(256)
 fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                  const float* __restrict__ f2, const float* __restrict__ title,
-                 const float* __restrict__ rubbish, int64_t B, float* __restrict__ desc) {
+                 const float* __restrict__ rubbish, int64_t B, float* __restrict__ desc,
+                 const int64_t* __restrict__ B_live) {
     const int64_t n = blockIdx.x;              // s * B + b : index into the stacked maps
     const int64_t b = n % B;
+    if (B_live && b >= *B_live) return;        // counted launch: rows past the device-side total are padding
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* o = desc + n * 264 * 145;
     int pt[3], off0[3], off1[3];
@@ -294,11 +296,13 @@ __device__ __forceinline__ void fine_tile_pass(const float* __restrict__ img, in
 __global__ void __launch_bounds__(256)
 fine_desc_nhwc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                       const float* __restrict__ f2, const float* __restrict__ title,
-                      const float* __restrict__ rubbish, int64_t B, float* __restrict__ desc) {
+                      const float* __restrict__ rubbish, int64_t B, float* __restrict__ desc,
+                      const int64_t* __restrict__ B_live) {
     constexpr int NP = 145;
     __shared__ __attribute__((aligned(16))) float tile[64 * NP];
     const int64_t n = blockIdx.x;              // s * B + b : index into the stacked maps
     const int64_t b = n % B;
+    if (B_live && b >= *B_live) return;        // counted launch: rows past the device-side total are padding
     const int t = threadIdx.x;
     float* o = desc + n * 264 * NP;
     const float* rub = rubbish + b * 264;
@@ -326,7 +330,27 @@ extern "C" int pats_fine_descriptors_f32(const float* feat0, const float* feat1,
     if (B == 0) return PATS_OK;
     PATS_REQUIRE(feat0 && feat1 && feat2 && title && rubbish && desc, "fine_descriptors: null pointer");
     hipLaunchKernelGGL(fine_desc_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, as_stream(stream), feat0, feat1,
-                       feat2, title, rubbish, B, desc);
+                       feat2, title, rubbish, B, desc, (const int64_t*)nullptr);
+    return check_launch("fine_desc_kernel");
+}
+
+// a15 launched over a CAPACITY of B_cap rows with the number of rows in use on the device (throughput mode: the fine level's
+// row table): workgroups of rows >= *B_dev return at once, their desc blocks are left untouched.
+extern "C" int pats_fine_descriptors_counted_f32(const float* feat0, const float* feat1, const float* feat2,
+                                                 const float* title, const float* rubbish, int64_t B_cap,
+                                                 const int64_t* B_dev, int channels_last, float* desc, pats_stream_t stream) {
+    PATS_REQUIRE(B_cap >= 0, "fine_descriptors_counted: bad shape");
+    if (B_cap == 0) return PATS_OK;
+    PATS_REQUIRE(B_dev && feat0 && feat1 && feat2 && title && rubbish && desc, "fine_descriptors_counted: null pointer");
+    if (channels_last) {
+        PATS_REQUIRE(((uintptr_t)feat0 | (uintptr_t)feat1 | (uintptr_t)feat2 | (uintptr_t)desc) % 16 == 0,
+                     "fine_descriptors_counted: channels-last maps and desc must be 16-byte aligned");
+        hipLaunchKernelGGL(fine_desc_nhwc_kernel, dim3((unsigned)(2 * B_cap)), dim3(256), 0, as_stream(stream), feat0, feat1,
+                           feat2, title, rubbish, B_cap, desc, B_dev);
+        return check_launch("fine_desc_nhwc_kernel");
+    }
+    hipLaunchKernelGGL(fine_desc_kernel, dim3((unsigned)(2 * B_cap)), dim3(256), 0, as_stream(stream), feat0, feat1,
+                       feat2, title, rubbish, B_cap, desc, B_dev);
     return check_launch("fine_desc_kernel");
 }
 
@@ -367,7 +391,7 @@ extern "C" int pats_fine_descriptors_nhwc_f32(const float* feat0, const float* f
     PATS_REQUIRE(((uintptr_t)feat0 | (uintptr_t)feat1 | (uintptr_t)feat2 | (uintptr_t)desc) % 16 == 0,
                  "fine_descriptors_nhwc: maps and desc must be 16-byte aligned");
     hipLaunchKernelGGL(fine_desc_nhwc_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, as_stream(stream), feat0, feat1,
-                       feat2, title, rubbish, B, desc);
+                       feat2, title, rubbish, B, desc, (const int64_t*)nullptr);
     return check_launch("fine_desc_nhwc_kernel");
 }
 

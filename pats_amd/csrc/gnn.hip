@@ -40,6 +40,8 @@ struct ConvArgs {
     int tile_rows;             // output rows per workgroup: 160, or 128 when M is a multiple of 128 (no fifth tile row)
     int* redo;                 // conv_lean_kernel: set to 1 by a workgroup whose outputs came out non-finite;
                                // conv1x1_kernel: if non-null, the whole launch is a no-op unless *redo != 0
+    const int* gate;           // optional: every kernel of the launch is a no-op unless *gate != 0 (the composition as the
+                               // fallback behind the fused layer of gnn_fused.hip)
 };
 
 // column addressing for mfma_tile.hpp's CmSrc: A = transposed weights at output rows i0.. (clamped), B = activations at
@@ -63,6 +65,7 @@ template <bool SPLIT, bool ROW4>
 __global__ void __launch_bounds__(256, 2)
 conv1x1_kernel(ConvArgs g) {
     __shared__ mt::Lds lds;
+    if (g.gate && *g.gate == 0) return;
     if (g.redo && *g.redo == 0) return;              // the second, normally empty, launch behind conv_lean_kernel
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
@@ -131,6 +134,7 @@ __global__ void __launch_bounds__(256, NT == 2 ? 4 : 3)
 conv_lean_kernel(ConvArgs g) {
     constexpr int LC = 32 * NT, NB = NT / 2;         // columns per workgroup, activation items per thread
     __shared__ LeanLds<NT> lds;
+    if (g.gate && *g.gate == 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, kg = lane >> 5;
     // (an XCD-aware tile order - each XCD a contiguous run of column tiles, so that the two halves of a 128-byte line
@@ -299,6 +303,7 @@ __global__ void __launch_bounds__(1024)
 conv_ws_kernel(ConvArgs g, int row_tiles) {
     constexpr int WS_KQ = 4 * WS_NCH;                // channel quads
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_raw[];
+    if (g.gate && *g.gate == 0) return;
     uint2* la = reinterpret_cast<uint2*>(ws_raw);                    // [hi | lo][WS_KQ][LR]
     uint2* lb_all = la + (size_t)2 * WS_KQ * LR;                     // [group][buffer][hi | lo][4][WS_LC]
     const int t = threadIdx.x, grp = __builtin_amdgcn_readfirstlane(t >> 8), tt = t & 255;
@@ -447,8 +452,10 @@ conv_ws_kernel(ConvArgs g, int row_tiles) {
 constexpr int BN_SPLITS = 64;
 
 __global__ void __launch_bounds__(256)
-bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, double* __restrict__ part) {
+bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, double* __restrict__ part,
+                  const int* __restrict__ gate = nullptr) {
     __shared__ double s1[4], s2[4];
+    if (gate && *gate == 0) return;
     const int c = blockIdx.x, split = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a = 0.0, q = 0.0;
     for (int64_t b = (int64_t)split * 4 + wave; b < batch; b += 4 * BN_SPLITS) {
@@ -474,9 +481,10 @@ bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, doub
 
 __global__ void __launch_bounds__(64)
 bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const float* __restrict__ gamma,
-                 const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+                 const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                 const int* __restrict__ gate = nullptr) {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+    if (c >= C || (gate && *gate == 0)) return;
     double a = 0.0, q = 0.0;
     for (int s_ = 0; s_ < BN_SPLITS; ++s_) {
         a += part[((int64_t)c * BN_SPLITS + s_) * 2 + 0];
@@ -491,8 +499,9 @@ bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const fl
 }
 
 // `redo`: one int of workspace, zero on entry (conv_lean_kernel raises it; see there).  null -> conv1x1_kernel only.
-static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st) {
+static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr) {
     ConvArgs g = g0;
+    g.gate = gate;
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
     static const bool no_lean = [] { const char* e = getenv("PATS_CONV_LEAN"); return e && atoi(e) == 0; }();    // A/B switch
     PATS_REQUIRE(g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
@@ -572,13 +581,46 @@ extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, in
     const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
     // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each; BN partial sums
     return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float)) +
-           al256((size_t)2 * C * pats::BN_SPLITS * 2 * sizeof(double)) + 256 /* six redo flags */;
+           al256((size_t)2 * C * pats::BN_SPLITS * 2 * sizeof(double)) + 256 /* seven redo flags + the fused layer's flag */;
 }
+
+namespace pats {
+int launch_attention(const float* query, const float* key, const float* value, int64_t batch, int dim, int heads, int n, int m,
+                     float* out, float* prob, pats_stream_t stream, const int* gate);                     // attention.hip
+int fused_layer_supported(int C, int heads, int n, int m);                                                // gnn_fused.hip
+int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
+                       int bn_train, const float* residual, float* out, float* hid, int* flag, hipStream_t st);
+}
+
+static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
+                            const pats_propagation_weights* w, int bn_train, float bn_eps, const float* residual, float* out,
+                            void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed);
 
 extern "C" int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
                                                 int n, int m, const pats_propagation_weights* w, int bn_train,
                                                 float bn_eps, const float* residual, float* out, void* workspace,
                                                 size_t workspace_bytes, pats_stream_t stream) {
+    return propagation_impl(x, source, batch, C, heads, n, m, w, bn_train, bn_eps, residual, out, workspace, workspace_bytes, stream,
+                            nullptr);
+}
+
+// The same layer with the weights additionally handed over PACKED (pats_propagation_pack_f32, once per layer): at the third
+// level's shape (C = 128, 4 heads, n = m = 65) the whole layer then runs as ONE kernel (gnn_fused.hip; on batch statistics: one
+// kernel up to the hidden tensor, then the statistics passes and the last convolution of the composition).  Any other shape, or
+// PATS_GNN_FUSED=0, takes the composition; so does - gated on a device-side flag, its kernels return at once otherwise - a
+// launch in which the fused kernel met a non-finite value (an activation beyond the fp16 range of its split operands).
+extern "C" int pats_attentional_propagation_packed_f32(const float* x, const float* source, int64_t batch, int C, int heads,
+                                                       int n, int m, const pats_propagation_weights* w, const void* packed,
+                                                       int bn_train, float bn_eps, const float* residual, float* out,
+                                                       void* workspace, size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(packed, "attentional_propagation_packed: null packed weights");
+    return propagation_impl(x, source, batch, C, heads, n, m, w, bn_train, bn_eps, residual, out, workspace, workspace_bytes, stream,
+                            packed);
+}
+
+static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
+                            const pats_propagation_weights* w, int bn_train, float bn_eps, const float* residual, float* out,
+                            void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed) {
     PATS_REQUIRE(batch >= 0 && C > 0 && heads > 0 && n > 0 && m > 0 && (C % heads) == 0,
                  "attentional_propagation: bad shape");
     PATS_REQUIRE((C % 8) == 0, "attentional_propagation: feature_dim must be a multiple of 8 (operand slabs of 8 channels)");
@@ -601,30 +643,50 @@ extern "C" int pats_attentional_propagation_f32(const float* x, const float* sou
     float* bsh = (float*)p; p += al256((size_t)2 * C * sizeof(float));
     double* bpart = (double*)p; p += al256((size_t)2 * C * BN_SPLITS * 2 * sizeof(double));
     int* redo = (int*)p;
-    if (hipMemsetAsync(redo, 0, 6 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
+    if (hipMemsetAsync(redo, 0, 8 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
     int rc;
+    const int* gate = nullptr;
+    if (packed && fused_layer_supported(C, heads, n, m)) {
+        // residual == out would be read-after-write across waves of the fused kernel's epilogue only per element: allowed
+        int* flag = redo + 7;
+        rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, st);
+        if (rc == PATS_OK) {
+            if (bn_train) {      // the fused kernel stopped behind mlp[0]: statistics of the hidden tensor, then mlp[1..3]
+                hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)(2 * C), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart,
+                                   (const int*)nullptr);
+                hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, bpart, batch * (int64_t)n,
+                                   2 * C, w->bn_a, w->bn_b, bn_eps, bsc, bsh, (const int*)nullptr);
+                if ((rc = check_launch("bn_stats kernels"))) return rc;
+                if ((rc = launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, bsc, bsh, w->b2, residual, out}, redo + 6, st)))
+                    return rc;
+            }
+            gate = flag;         // the composition below runs only if the fused kernel raised it
+        } else if (rc != PATS_ERR_UNSUPPORTED) {
+            return rc;
+        }
+    }
     // projections (modules.py:101-102)
-    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, redo + 0, st))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, redo + 0, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st, gate))) return rc;
     // attention core (:103): the [b, C, n] projections ARE the [b, dim, heads, n] views
-    if ((rc = pats_attention_f32(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream))) return rc;
+    if ((rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, gate))) return rc;
     // merge (:104)
-    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st, gate))) return rc;
     // mlp[0] on cat([x, message]) without the cat (:116, MLP :64)
-    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, redo + 4, st))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, redo + 4, st, gate))) return rc;
     // mlp[1] BatchNorm1d: eval -> the caller's folded running statistics (bn_a = scale, bn_b = shift);
     //                      train -> batch statistics with bn_a = gamma, bn_b = beta
     const float *sc = w->bn_a, *sh = w->bn_b;
     if (bn_train) {
-        hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)(2 * C), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart);
+        hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)(2 * C), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart, gate);
         hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, bpart, batch * (int64_t)n, 2 * C,
-                           w->bn_a, w->bn_b, bn_eps, bsc, bsh);
+                           w->bn_a, w->bn_b, bn_eps, bsc, bsh, gate);
         if ((rc = check_launch("bn_stats kernels"))) return rc;
         sc = bsc; sh = bsh;
     }
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
-    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st);
+    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st, gate);
 }
 
 // ---- the building blocks on their own: Conv1d(kernel_size = 1) and the BatchNorm1d + ReLU that follows it in MLP ------

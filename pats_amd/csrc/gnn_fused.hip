@@ -1,0 +1,476 @@
+// AttentionalPropagation (models/modules.py:107-117) at the third level's shape - x, source [b,128,65], 4 heads - as ONE kernel:
+// a problem's activations never leave the CU between the two descriptor blocks coming in and the layer's output going out.
+//
+//   message = merge(attention(proj_q(x), proj_k(source), proj_v(source)))           MultiHeadedAttention.forward :100-105
+//   hidden  = Conv1d(256,256)(cat([x, message]))                                    AttentionalPropagation.forward :114-117, MLP :57-69
+//   out     = [residual +] Conv1d(256,128)(relu(bn(hidden)))                        (AttentionalGNN.forward :131-133)
+//
+// The composition of csrc/gnn.hip runs this as seven launches with every intermediate tensor going through HBM (about 800 KB
+// of traffic per 65-token problem for 100 KB of input + output: the layer was HBM-bound in aggregate, 5.7 ms per 25 920
+// problems).  Here one 512-thread workgroup owns a problem at a time (persistent grid, one workgroup per CU):
+//
+//   * activations live in LDS pre-split for the fp16 matrix pipe: x * 2^6 = hi + lo (both fp16, round to nearest: 22 mantissa
+//     bits), in MFMA FRAGMENT ORDER ("TF layout": per 32-channel k-step and 16-token tile, lane (k / 8, token) holds its 8
+//     consecutive channels as one 16-byte read - directly the B operand of v_mfma_f32_16x16x32_f16, and equally the A operand
+//     of the transposed product).  A [128 x 65] tensor takes 33 280 bytes: four k-steps x (hi, lo) x (four full tiles + token
+//     64 alone; the lanes of the fifth tile all read token 64, their columns are never stored).
+//   * every Conv1d is the three-pass contraction of the cost build (lo.hi + hi.lo + hi.hi, fp32 accumulation) with the WEIGHTS
+//     as the A operand, pre-split and pre-tiled once per layer by gnn_pack_kernel (640 KB, L2-resident, streamed by every
+//     workgroup: one 16-byte load per lane and fragment).  Wave w owns output rows 16 w.. (mlp[0]: two row tiles) and walks
+//     the five token tiles; its epilogue (bias, BatchNorm affine + ReLU, re-split) writes the next stage's operand in place.
+//   * heads: the reference views the projections as [b, dim, heads, n] (channel = d * 4 + h).  The packed q / k / v weights
+//     have their output rows permuted to head-major (h * 32 + d), the merge its input columns: a head is then exactly one
+//     k-step of the TF layout.
+//   * attention per (head, 16-query tile): S^T = K^T Q (keys as rows: the softmax over the keys is in-lane + two lane
+//     exchanges), exp, and the accumulator registers of two key tiles ARE the B operand of out = V P^T (key slot 8 q + e of a
+//     k-step = key 4 q + e of the even tile, e < 4, or of the odd tile) - the A operand V comes from a token-major copy
+//     ("TT layout") that the v projection produces directly by running transposed (activations as A, weights as B).
+//   * BatchNorm in eval mode (folded running statistics: the outdoor configuration, pats.py:112-116) -> the whole layer in this
+//     kernel.  On batch statistics (indoor: pats.py:117-118 leaves the third layer in train mode) the kernel stops behind
+//     mlp[0] and writes the hidden tensor; the statistics kernels and the last convolution of gnn.hip finish the layer.
+//
+// LDS: x | source -> q -> attention output -> hidden[0:128] | k -> message | v^T -> hidden[128:256] = 134 656 bytes.
+// Range: |activation| < 1023 (the hi half overflows beyond, as in the cost build).  A non-finite output raises *flag and the
+// host entry then runs the composition of gnn.hip behind it, gated on that flag (its kernels return at once otherwise).
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace pats {
+
+namespace {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int GC = 128, GN = 65, GD = 32;
+constexpr float PRE = 64.0f, UNS = 1.0f / 4096.0f;
+constexpr int TF_BLK = 4 * 1024 + 64;             // bytes of one (k-step, hi | lo) block
+constexpr int TF_BYTES = 4 * 2 * TF_BLK;          // [128 x 65] tensor: 33 280
+constexpr int TT_ROW = 68;                        // tokens per channel row of the token-major copy (65 + zero padding)
+constexpr int TT_PLANE = GC * TT_ROW * 2;         // bytes of its hi (or lo) plane
+constexpr int OFF_X = 0, OFF_S = TF_BYTES, OFF_K = 2 * TF_BYTES, OFF_V = 3 * TF_BYTES;
+constexpr int FUSED_LDS = 3 * TF_BYTES + 2 * TT_PLANE;        // 134 656
+
+// packed weights (units of h8v = 16 bytes): fragment (row tile mt, k-step ks) = [hi | lo][64 lanes]
+constexpr int FR = 2 * 64;
+constexpr int PW_Q = 0, PW_K = PW_Q + 8 * 4 * FR, PW_V = PW_K + 8 * 4 * FR, PW_M = PW_V + 8 * 4 * FR, PW_1 = PW_M + 8 * 4 * FR,
+              PW_2 = PW_1 + 16 * 8 * FR, PW_END = PW_2 + 8 * 8 * FR;
+// biases behind them (floats): bq', bk', bv' (head-major), bm, b1 [256], b2
+constexpr int PB_Q = 0, PB_K = 128, PB_V = 256, PB_M = 384, PB_1 = 512, PB_2 = 768, PB_END = 896;
+
+struct FusedArgs {
+    const float* x;
+    const float* source;
+    const float* residual;     // or null
+    float* out;                // [b,128,65]            (eval)
+    float* hid;                // [b,256,65] pre-BN     (train)
+    const h8v* pw;
+    const float* pb;
+    const float* bn_a;         // eval: folded scale / shift [256]
+    const float* bn_b;
+    int64_t batch;
+    int* flag;
+};
+
+__device__ __forceinline__ int tf_tile_off(int nt, int lane) {      // byte offset of this lane's 16-byte fragment piece in a block
+    return nt < 4 ? nt * 1024 + lane * 16 : 4096 + (lane >> 4) * 16;
+}
+
+__device__ __forceinline__ void split4(const f4v v, h4v& hi, h4v& lo) {
+    const f4v s = v * PRE;
+    hi = __builtin_convertvector(s, h4v);
+    lo = __builtin_convertvector(s - __builtin_convertvector(hi, f4v), h4v);
+}
+
+// rows 16 mt + 4 q' + r (r = 0..3) of token 16 nt + j -> the TF tensor at dst
+__device__ __forceinline__ void store_tf(char* dst, int mt, int nt, const f4v v, int lane) {
+    const int qp = lane >> 4, j = lane & 15;
+    if (nt == 4 && j != 0) return;
+    h4v hi, lo;
+    split4(v, hi, lo);
+    const int kq = 2 * (mt & 1) + (qp >> 1);
+    const int off = ((mt >> 1) * 2) * TF_BLK + (nt < 4 ? nt * 1024 + (kq * 16 + j) * 16 : 4096 + kq * 16) + (qp & 1) * 8;
+    *reinterpret_cast<h4v*>(dst + off) = hi;
+    *reinterpret_cast<h4v*>(dst + off + TF_BLK) = lo;
+}
+
+// [128][65] fp32 in global memory -> TF tensor: item (channel group of 8, token); consecutive lanes = consecutive tokens
+__device__ __forceinline__ void load_tf(const float* __restrict__ src, char* dst, int t) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int i = t + 512 * it;
+        if (i < 16 * GN) {
+            const int cg = i / GN, tok = i - cg * GN;
+            const float* p = src + (cg * 8) * GN + tok;
+            f4v a = {p[0], p[GN], p[2 * GN], p[3 * GN]}, b = {p[4 * GN], p[5 * GN], p[6 * GN], p[7 * GN]};
+            h4v ah, al, bh, bl;
+            split4(a, ah, al);
+            split4(b, bh, bl);
+            const int tile = tok >> 4, j = tok & 15, kq = cg & 3;
+            const int off = ((cg >> 2) * 2) * TF_BLK + (tile < 4 ? tile * 1024 + (kq * 16 + j) * 16 : 4096 + kq * 16);
+            *reinterpret_cast<h8v*>(dst + off) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
+            *reinterpret_cast<h8v*>(dst + off + TF_BLK) = h8v{al.x, al.y, al.z, al.w, bl.x, bl.y, bl.z, bl.w};
+        }
+    }
+}
+
+__device__ __forceinline__ f4v mfma3(const h8v ah, const h8v al, const h8v bh, const h8v bl, f4v c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);       // small terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+
+// acc[m][nt] += W[row tile mts[m]] . src over KS k-steps (k-steps 0..3 from src0, 4..7 from src1); weights = A operand
+template <int KS, int MT>
+__device__ __forceinline__ void gemm_w(const h8v* __restrict__ W, const int (&mts)[MT], const char* src0, const char* src1,
+                                       int lane, f4v (&acc)[MT][5]) {
+    h8v a[2][MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        a[0][m][0] = W[(mts[m] * KS) * FR + lane];
+        a[0][m][1] = W[(mts[m] * KS) * FR + 64 + lane];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                a[(ks + 1) & 1][m][0] = W[(mts[m] * KS + ks + 1) * FR + lane];
+                a[(ks + 1) & 1][m][1] = W[(mts[m] * KS + ks + 1) * FR + 64 + lane];
+            }
+        }
+        const char* blk = (ks < 4 ? src0 : src1) + ((ks & 3) * 2) * TF_BLK;
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            const h8v bh = *reinterpret_cast<const h8v*>(blk + tf_tile_off(nt, lane));
+            const h8v bl = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(nt, lane));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][nt] = mfma3(a[ks & 1][m][0], a[ks & 1][m][1], bh, bl, acc[m][nt]);
+        }
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void zero_acc(f4v (&acc)[MT][5]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
+}
+
+__device__ __forceinline__ f4v load4(const float* p) { return f4v{p[0], p[1], p[2], p[3]}; }
+
+}  // namespace
+
+// weights of one layer -> fragment order, split, head permutation.  One thread per (fragment, lane).
+__global__ void __launch_bounds__(256)
+gnn_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __restrict__ pb) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid < PB_END) {                       // biases (q / k / v in head-major order)
+        const int i = gid & 127, pi = (i & 31) * 4 + (i >> 5);
+        float v;
+        if (gid < PB_K) v = w.bq[pi];
+        else if (gid < PB_V) v = w.bk[pi];
+        else if (gid < PB_M) v = w.bv[pi];
+        else if (gid < PB_1) v = w.bm[i];
+        else if (gid < PB_2) v = w.b1[gid - PB_1];
+        else v = w.b2[i];
+        pb[gid] = v;
+    }
+    const int lane = gid & 63, f = gid >> 6;                   // fragment index over all matrices
+    if (f >= PW_END / FR) return;
+    const float* wt;
+    int K, M, mt, ks, mode;                                    // mode 1: permute output rows, 2: permute input channels
+    int base;
+    if (f < 4 * 32) { const int mat = f >> 5; wt = mat == 0 ? w.wq_t : mat == 1 ? w.wk_t : mat == 2 ? w.wv_t : w.wm_t;
+                      K = 128; M = 128; mt = (f & 31) >> 2; ks = f & 3; mode = mat == 3 ? 2 : 1; base = mat * 32 * FR; }
+    else if (f < 4 * 32 + 128) { const int g = f - 128; wt = w.w1_t; K = 256; M = 256; mt = g >> 3; ks = g & 7; mode = 0; base = PW_1; }
+    else { const int g = f - 256; wt = w.w2_t; K = 256; M = 128; mt = g >> 3; ks = g & 7; mode = 0; base = PW_2; }
+    (void)K;
+    int row = mt * 16 + (lane & 15);
+    if (mode == 1) row = (row & 31) * 4 + (row >> 5);
+    h8v hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int k = ks * 32 + 8 * (lane >> 4) + e;
+        if (mode == 2) k = (k & 31) * 4 + (k >> 5);
+        const float s = wt[(int64_t)k * M + row] * PRE;
+        const _Float16 h = (_Float16)s;
+        hi[e] = h;
+        lo[e] = (_Float16)(s - (float)h);
+    }
+    const int KSm = f < 128 ? 4 : 8, fl = f < 128 ? (f & 31) : (f < 256 ? f - 128 : f - 256);
+    (void)KSm;
+    pw[base + fl * FR + lane] = hi;
+    pw[base + fl * FR + 64 + lane] = lo;
+}
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(512, 1)
+gnn_layer_fused_kernel(FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int qp = lane >> 4, j = lane & 15;
+    const float* pb = g.pb;
+    bool bad = false;
+    for (int64_t b = blockIdx.x; b < g.batch; b += gridDim.x) {
+        load_tf(g.x + b * (GC * GN), lds + OFF_X, t);
+        load_tf(g.source + b * (GC * GN), lds + OFF_S, t);
+        wg_barrier();
+        // ---- k = Wk' source (TF), v^T = source^T Wv'^T (token-major) -----------------------------------------------
+        {
+            f4v acc[1][5];
+            zero_acc(acc);
+            const int mts[1] = {wave};
+            gemm_w<4, 1>(g.pw + PW_K, mts, lds + OFF_S, nullptr, lane, acc);
+            const f4v bias = load4(pb + PB_K + 16 * wave + 4 * qp);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acc[0][nt] * UNS + bias, lane);
+        }
+        {
+            f4v acc[5];
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) acc[tt] = f4v{0.f, 0.f, 0.f, 0.f};
+            const h8v* W = g.pw + PW_V + (wave * 4) * FR;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h8v wh = W[ks * FR + lane], wl = W[ks * FR + 64 + lane];
+                const char* blk = lds + OFF_S + (ks * 2) * TF_BLK;
+#pragma unroll
+                for (int tt = 0; tt < 5; ++tt) {
+                    const h8v sh = *reinterpret_cast<const h8v*>(blk + tf_tile_off(tt, lane));
+                    const h8v sl = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(tt, lane));
+                    acc[tt] = mfma3(sh, sl, wh, wl, acc[tt]);           // rows = tokens 16 tt + 4 q' + r, column = channel 16 w + j
+                }
+            }
+            const float bias = pb[PB_V + 16 * wave + j];
+            char* vrow = lds + OFF_V + ((16 * wave + j) * TT_ROW) * 2;
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) {
+                f4v v = acc[tt] * UNS + bias;
+                if (tt == 4) { v.y = 0.f; v.z = 0.f; v.w = 0.f; }       // tokens 65..67: zero padding (rows 1.. alias token 64)
+                if (tt < 4 || qp == 0) {
+                    h4v hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<h4v*>(vrow + (16 * tt + 4 * qp) * 2) = hi;
+                    *reinterpret_cast<h4v*>(vrow + TT_PLANE + (16 * tt + 4 * qp) * 2) = lo;
+                }
+            }
+        }
+        wg_barrier();
+        // ---- q = Wq' x, into the slot source leaves ------------------------------------------------------------------
+        {
+            f4v acc[1][5];
+            zero_acc(acc);
+            const int mts[1] = {wave};
+            gemm_w<4, 1>(g.pw + PW_Q, mts, lds + OFF_X, nullptr, lane, acc);
+            const f4v bias = load4(pb + PB_Q + 16 * wave + 4 * qp);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_S, wave, nt, acc[0][nt] * UNS + bias, lane);
+        }
+        wg_barrier();
+        // ---- attention: unit = (head, 16-query tile); its output replaces its own q tile -----------------------------
+        for (int u = wave; u < 20; u += 8) {
+            const int h = u / 5, qt = u - 5 * h;
+            const char* qblk = lds + OFF_S + (h * 2) * TF_BLK;
+            const char* kblk = lds + OFF_K + (h * 2) * TF_BLK;
+            const h8v qh = *reinterpret_cast<const h8v*>(qblk + tf_tile_off(qt, lane));
+            const h8v ql = *reinterpret_cast<const h8v*>(qblk + TF_BLK + tf_tile_off(qt, lane));
+            f4v st[5];
+            const float sq = 5.656854249492381f, rsq = 1.0f / 5.656854249492381f;        // dim ** .5, dim = 32
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                const h8v kh = *reinterpret_cast<const h8v*>(kblk + tf_tile_off(kt, lane));
+                const h8v kl = *reinterpret_cast<const h8v*>(kblk + TF_BLK + tf_tile_off(kt, lane));
+                f4v s = mfma3(kh, kl, qh, ql, f4v{0.f, 0.f, 0.f, 0.f});                 // rows = keys 16 kt + 4 q' + r, column = query
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = div_invariant(s[r] * UNS, sq, rsq);
+                    if (kt == 4 && (qp != 0 || r != 0)) v = -INFINITY;                  // keys 65..: not there
+                    s[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+                st[kt] = s;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float den = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2((st[kt][r] - mx) * LOG2E);
+                    st[kt][r] = p;
+                    den += p;
+                }
+            den += __shfl_xor(den, 16);
+            den += __shfl_xor(den, 32);
+            const float inv = 1.0f / den;
+            // B operands of out = V P^T: k-step kk = key tiles 2 kk (slots e < 4) and 2 kk + 1 (e >= 4)
+            h8v ph[3], pl[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                h4v h0, l0, h1 = {0, 0, 0, 0}, l1 = {0, 0, 0, 0};
+                split4(st[2 * kk], h0, l0);
+                if (kk < 2) split4(st[2 * kk + 1], h1, l1);
+                ph[kk] = h8v{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                pl[kk] = h8v{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* vrow = lds + OFF_V + ((h * 32 + dt * 16 + j) * TT_ROW) * 2;      // A: channel j of the tile, key slots
+                f4v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    h4v a0h = {0, 0, 0, 0}, a0l = {0, 0, 0, 0}, a1h = {0, 0, 0, 0}, a1l = {0, 0, 0, 0};
+                    if (kk < 2 || qp == 0) {
+                        a0h = *reinterpret_cast<const h4v*>(vrow + (32 * kk + 4 * qp) * 2);
+                        a0l = *reinterpret_cast<const h4v*>(vrow + TT_PLANE + (32 * kk + 4 * qp) * 2);
+                    }
+                    if (kk < 2) {
+                        a1h = *reinterpret_cast<const h4v*>(vrow + (32 * kk + 16 + 4 * qp) * 2);
+                        a1l = *reinterpret_cast<const h4v*>(vrow + TT_PLANE + (32 * kk + 16 + 4 * qp) * 2);
+                    }
+                    const h8v vh = {a0h.x, a0h.y, a0h.z, a0h.w, a1h.x, a1h.y, a1h.z, a1h.w};
+                    const h8v vl = {a0l.x, a0l.y, a0l.z, a0l.w, a1l.x, a1l.y, a1l.z, a1l.w};
+                    o = mfma3(vh, vl, ph[kk], pl[kk], o);                                  // rows = channels, column = query
+                }
+                store_tf(lds + OFF_S, 2 * h + dt, qt, o * (UNS * inv), lane);
+            }
+        }
+        wg_barrier();
+        // ---- message = Wm' attention + bm, into the slot k leaves --------------------------------------------------------
+        {
+            f4v acc[1][5];
+            zero_acc(acc);
+            const int mts[1] = {wave};
+            gemm_w<4, 1>(g.pw + PW_M, mts, lds + OFF_S, nullptr, lane, acc);
+            const f4v bias = load4(pb + PB_M + 16 * wave + 4 * qp);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acc[0][nt] * UNS + bias, lane);
+        }
+        wg_barrier();
+        // ---- hidden = W1 (x | message) + b1: row tiles w (-> slot of q) and w + 8 (-> slot of v) -------------------------------
+        {
+            f4v acc[2][5];
+            zero_acc(acc);
+            const int mts[2] = {wave, wave + 8};
+            gemm_w<8, 2>(g.pw + PW_1, mts, lds + OFF_X, lds + OFF_K, lane, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int ch = 16 * mts[m] + 4 * qp;
+                const f4v bias = load4(pb + PB_1 + ch);
+                if (TRAIN) {
+                    float* H = g.hid + (b * 256 + ch) * GN;
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) {
+                        const f4v v = acc[m][nt] * UNS + bias;
+                        if (nt < 4 || j == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                H[r * GN + 16 * nt + j] = v[r];
+                                bad |= !(fabsf(v[r]) <= 3.0e38f);
+                            }
+                        }
+                    }
+                } else {
+                    const f4v sc = load4(g.bn_a + ch), sh = load4(g.bn_b + ch);
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) {
+                        f4v v = (acc[m][nt] * UNS + bias) * sc + sh;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];        // ReLU that keeps NaN
+                        store_tf(lds + (m == 0 ? OFF_S : OFF_V), wave, nt, v, lane);
+                    }
+                }
+            }
+        }
+        wg_barrier();
+        if (!TRAIN) {
+            // ---- out = W2 relu(bn(hidden)) + b2 [+ residual] -----------------------------------------------------------
+            f4v acc[1][5];
+            zero_acc(acc);
+            const int mts[1] = {wave};
+            gemm_w<8, 1>(g.pw + PW_2, mts, lds + OFF_S, lds + OFF_V, lane, acc);
+            const int ch = 16 * wave + 4 * qp;
+            const f4v bias = load4(pb + PB_2 + ch);
+            float* O = g.out + (b * GC + ch) * GN;
+            const float* R = g.residual ? g.residual + (b * GC + ch) * GN : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                if (nt < 4 || j == 0) {
+                    const f4v v = acc[0][nt] * UNS + bias;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float o = v[r];
+                        if (R) o = R[r * GN + 16 * nt + j] + o;
+                        O[r * GN + 16 * nt + j] = o;
+                        bad |= !(fabsf(o) <= 3.0e38f);
+                    }
+                }
+            }
+            wg_barrier();                        // the hidden tensor has been read: the next problem may land
+        }
+    }
+    if (bad) atomicOr(g.flag, 1);
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+int fused_layer_supported(int C, int heads, int n, int m) {
+    static const bool off = [] { const char* e = getenv("PATS_GNN_FUSED"); return e && atoi(e) == 0; }();
+    return !off && C == GC && heads == 4 && n == GN && m == GN;
+}
+
+}  // namespace pats
+
+using namespace pats;
+
+extern "C" size_t pats_propagation_packed_bytes(int C, int heads) {
+    return (C == GC && heads == 4) ? (size_t)PW_END * sizeof(h8v) + (size_t)PB_END * sizeof(float) : 0;
+}
+
+extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
+                                         pats_stream_t stream) {
+    PATS_REQUIRE(C == GC && heads == 4, "propagation_pack: the fused layer exists for C = 128, 4 heads (the third level)");
+    PATS_REQUIRE(w && packed && packed_bytes >= pats_propagation_packed_bytes(C, heads), "propagation_pack: null pointer / buffer too small");
+    PATS_REQUIRE(w->wq_t && w->bq && w->wk_t && w->bk && w->wv_t && w->bv && w->wm_t && w->bm && w->w1_t && w->b1 && w->w2_t && w->b2,
+                 "propagation_pack: null weight pointer");
+    PATS_REQUIRE(((uintptr_t)packed & 15) == 0, "propagation_pack: the buffer must be 16-byte aligned");
+    h8v* pw = (h8v*)packed;
+    float* pb = (float*)(pw + PW_END);
+    const int threads = (PW_END / FR) * 64;
+    hipLaunchKernelGGL(gnn_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), *w, pw, pb);
+    return check_launch("gnn_pack_kernel");
+}
+
+namespace pats {
+// The layer (eval: whole; train: up to the hidden tensor) for batch problems.  flag: one int, zero on entry.
+int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
+                       int bn_train, const float* residual, float* out, float* hid, int* flag, hipStream_t st) {
+    struct PerDevice { int state = 0; int n_cu = 256; };
+    static PerDevice per_dev[64];
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = 0; }
+    PerDevice& pd = per_dev[dev_id];
+    if (pd.state == 0) {
+        const bool ok = hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        int v = 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) (void)hipGetLastError();
+        pd.n_cu = v > 0 ? v : 256;
+        pd.state = ok ? 1 : -1;
+    }
+    if (pd.state != 1) return PATS_ERR_UNSUPPORTED;
+    const h8v* pw = (const h8v*)packed;
+    FusedArgs g{x, source, residual, out, hid, pw, (const float*)(pw + PW_END), bn_a, bn_b, batch, flag};
+    const unsigned grid = (unsigned)std::min<int64_t>(batch, pd.n_cu);
+    if (bn_train) hipLaunchKernelGGL(gnn_layer_fused_kernel<true>, dim3(grid), dim3(512), FUSED_LDS, st, g);
+    else hipLaunchKernelGGL(gnn_layer_fused_kernel<false>, dim3(grid), dim3(512), FUSED_LDS, st, g);
+    return check_launch("gnn_layer_fused_kernel");
+}
+}  // namespace pats

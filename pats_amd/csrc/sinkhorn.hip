@@ -414,10 +414,12 @@ __global__ void __launch_bounds__(384)
 sinkhorn_rc_kernel(const float* Zin, int64_t P, const float* __restrict__ log_mu_in,
                    const float* __restrict__ log_nu_in, const float* __restrict__ ns,
                    const float* __restrict__ one, int iters, float bias_k, int linear,
-                   float* out, unsigned long long* fallbacks, const int* __restrict__ only_if) {
+                   float* out, unsigned long long* fallbacks, const int* __restrict__ only_if,
+                   const int64_t* __restrict__ live = nullptr) {
     // Zin and out are NOT __restrict__: the fused fine-level redo (launch_fine145_fused) solves in place, Zin == out.  The
     // whole matrix is staged in LDS before the first store and Zin is not read again.
     __shared__ __attribute__((aligned(16))) WgLds<N_> lds;     // 85 KB at N = 145 (static: no opt-in)
+    if (live && (int64_t)blockIdx.x >= *live) return;          // counted launch: a padding row
     if (only_if) {                                  // re-solve pass after sinkhorn_blk145_kernel: flagged problems only
         if (only_if[blockIdx.x] == 0) return;
         if (threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1ull);
@@ -962,7 +964,7 @@ static inline int use_linear() { return sinkhorn_mode() != PATS_SINKHORN_LOG; }
 namespace pats {
 int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                   const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
-                  uint8_t* col_nomatch, hipStream_t st);     // sinkhorn_blk.hip
+                  uint8_t* col_nomatch, hipStream_t st, const int64_t* live = nullptr);     // sinkhorn_blk.hip
 int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_nomatch, const int* only_if,
                      hipStream_t st);                       // post.hip
 }
@@ -973,21 +975,21 @@ int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_n
 // does everything, as before.
 static int launch_fine145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                           const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
-                          hipStream_t st, uint8_t* col_nomatch = nullptr) {
+                          hipStream_t st, uint8_t* col_nomatch = nullptr, const int64_t* live = nullptr) {
     static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;      // A/B switch for benchmarking
     const bool blk = use_linear() && iters > 0 && fail && !v1_only;
     if (blk) {
-        int rc = launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st);
+        int rc = launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st, live);
         if (rc) return rc;
     }
     if (mode == 0)
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, log_mu,
                            log_nu, nullptr, nullptr, iters, 0.f, blk ? 0 : (int)use_linear(), out,
-                           fallback_counter(), blk ? fail : nullptr);
+                           fallback_counter(), blk ? fail : nullptr, live);
     else
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, nullptr,
                            nullptr, ns, one, iters, bias_k, blk ? 0 : (int)use_linear(), out, fallback_counter(),
-                           blk ? fail : nullptr);
+                           blk ? fail : nullptr, live);
     int rc = check_launch("sinkhorn_rc_kernel<145>");
     // column flags of the problems the log-domain kernel (re-)solved: all of them without the block kernel
     if (!rc && col_nomatch) rc = launch_col_flags(out, batch, NF, NF, col_nomatch, blk ? fail : nullptr, st);
@@ -1000,17 +1002,18 @@ static int launch_fine145(int mode, const float* Z, int64_t batch, const float* 
 namespace pats {
 bool fine_fused();       // host.cpp
 int launch_blk145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
-                        float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st);
+                        float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, const int64_t* live);
 int launch_fine145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
-                         float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied) {
+                         float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied,
+                         const int64_t* live) {
     static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;
     *applied = fine_fused() && use_linear() && iters > 0 && fail && !v1_only && D > 0;       // pats_set_fine_fused / PATS_FINE_FUSED
     if (!*applied) return PATS_OK;
-    int rc = launch_blk145_fused(d0, d1, D, batch, ns, one, iters, bias_k, out, fail, col_nomatch, st);
+    int rc = launch_blk145_fused(d0, d1, D, batch, ns, one, iters, bias_k, out, fail, col_nomatch, st, live);
     if (rc) return rc;
     hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, (const float*)out, batch,
                        (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, 0, out, fallback_counter(),
-                       (const int*)fail);
+                       (const int*)fail, live);
     rc = check_launch("sinkhorn_rc_kernel<145>(redo)");
     if (!rc && col_nomatch) rc = launch_col_flags(out, batch, NF, NF, col_nomatch, fail, st);
     return rc;
@@ -1101,7 +1104,16 @@ extern "C" int pats_log_optimal_transport_f32(const float* scores, int64_t batch
 
 static int ot2_impl(const float* scores, int64_t batch, int m, int n, const float* one, const float* ns, int iters,
                     float bias_k, float* Z, void* workspace, size_t workspace_bytes, pats_stream_t stream,
-                    uint8_t* col_nomatch);
+                    uint8_t* col_nomatch, const int64_t* live = nullptr);
+
+// log_optimal_transport2 + column flags over a capacity of `batch` 145 x 145 problems, *live of them in use (fused.hip)
+namespace pats {
+int ot2_flags_live(const float* scores, int64_t batch, int m, int n, const float* one, const float* ns, int iters, float bias_k,
+                   float* Z, uint8_t* col_nomatch, void* workspace, size_t workspace_bytes, pats_stream_t stream,
+                   const int64_t* live) {
+    return ot2_impl(scores, batch, m, n, one, ns, iters, bias_k, Z, workspace, workspace_bytes, stream, col_nomatch, live);
+}
+}  // namespace pats
 
 extern "C" int pats_log_optimal_transport2_f32(const float* scores, int64_t batch, int m, int n,
                                                const float* one, const float* ns, int iters,
@@ -1119,7 +1131,8 @@ extern "C" int pats_log_optimal_transport2_flags_f32(const float* scores, int64_
 
 static int ot2_impl(const float* scores, int64_t batch, int m, int n, const float* one, const float* ns, int iters,
                     float bias_k, float* Z, void* workspace, size_t workspace_bytes, pats_stream_t stream,
-                    uint8_t* col_nomatch) {
+                    uint8_t* col_nomatch, const int64_t* live) {
+    PATS_REQUIRE(!live || (m == NF && n == NF), "log_optimal_transport2: a device-side count is taken for 145 x 145 problems only");
     PATS_REQUIRE(batch >= 0 && m > 1 && n > 1 && iters >= 0, "log_optimal_transport2: bad shape");
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(scores && ns && Z, "log_optimal_transport2: null pointer");
@@ -1136,7 +1149,7 @@ static int ot2_impl(const float* scores, int64_t batch, int m, int n, const floa
     }
     if (m == NF && n == NF) {
         int* fail = (workspace && workspace_bytes >= pats_ot2_workspace_bytes(batch, m, n)) ? (int*)workspace : nullptr;
-        return launch_fine145(2, scores, batch, nullptr, nullptr, ns, one, iters, bias_k, Z, fail, st, col_nomatch);
+        return launch_fine145(2, scores, batch, nullptr, nullptr, ns, one, iters, bias_k, Z, fail, st, col_nomatch, live);
     }
     PATS_REQUIRE(workspace && workspace_bytes >= pats_ot2_workspace_bytes(batch, m, n),
                  "log_optimal_transport2: workspace too small");   // shapes without a resident kernel

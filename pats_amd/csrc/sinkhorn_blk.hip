@@ -195,10 +195,14 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
                        const float* __restrict__ one, int iters, float bias_k, float* __restrict__ out,
                        int* __restrict__ fail, uint8_t* __restrict__ col_nomatch,
                        const float* __restrict__ d0 = nullptr, const float* __restrict__ d1 = nullptr, int D = 0,
-                       float rsqrtD = 0.f, float sqrtD = 0.f) {
+                       float rsqrtD = 0.f, float sqrtD = 0.f, const int64_t* __restrict__ live = nullptr) {
     __shared__ BlkLds lds;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, J = t & 15, I = t >> 4, rho = lane >> 4;
     const int64_t p = blockIdx.x;
+    if (live && p >= *live) {                  // counted launch: a padding row - no solve, and no redo behind it either
+        if (t == 0 && fail) fail[p] = 0;
+        return;
+    }
     const float* Zp = Zin + p * (N_ * N_);
     const bool rown = J < BS, cown = I < BS;          // owns a row entry a_(9I+J) / a column entry b_(9J+I)
     const int rowi = BS * I + (rown ? J : 0), colj = BS * J + (cown ? I : 0);
@@ -484,7 +488,7 @@ sinkhorn_blk145_kernel(const float* __restrict__ Zin, const float* __restrict__ 
 // fail must hold `batch` ints
 int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                   const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
-                  uint8_t* col_nomatch, hipStream_t st) {
+                  uint8_t* col_nomatch, hipStream_t st, const int64_t* live) {
     // libpats_amd_diag.so only: dynamic LDS the kernel never touches lowers the occupancy (13.7 KB per workgroup: three per
     // CU by registers; + 41 KB = the cost build's staging area -> two) - what the sweeps would cost inside a kernel that
     // also holds the cost build's LDS and registers ("fine-level fusion")
@@ -494,20 +498,22 @@ int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, 
 #endif
     if (mode == 0)
         hipLaunchKernelGGL((sinkhorn_blk145_kernel<0>), dim3((unsigned)batch), dim3(256), pad, st, Z, log_mu, log_nu,
-                           (const float*)nullptr, (const float*)nullptr, iters, 0.f, out, fail, col_nomatch);
+                           (const float*)nullptr, (const float*)nullptr, iters, 0.f, out, fail, col_nomatch,
+                           (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, live);
     else
         hipLaunchKernelGGL((sinkhorn_blk145_kernel<2>), dim3((unsigned)batch), dim3(256), pad, st, Z,
-                           (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch);
+                           (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch,
+                           (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, live);
     return check_launch("sinkhorn_blk145_kernel");
 }
 
 // the fused fine-level step: descriptors [batch, D, 145] x 2 -> log-plan, log_optimal_transport2 marginals (MODE 2)
 int launch_blk145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
-                        float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st) {
+                        float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, const int64_t* live) {
     const float sq = (float)sqrt((double)D);
     hipLaunchKernelGGL((sinkhorn_blk145_kernel<2, true>), dim3((unsigned)batch), dim3(256), 0, st, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, out, fail, col_nomatch, d0, d1, D,
-                       1.0f / sq, sq);
+                       1.0f / sq, sq, live);
     return check_launch("sinkhorn_blk145_kernel<2, fused>");
 }
 

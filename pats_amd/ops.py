@@ -167,10 +167,12 @@ def log_optimal_transport2(scores, one, ns, iters: int, bias_k: float = 0.0):
     return Z
 
 
-def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0, return_flags=False):
+def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0, return_flags=False, count=None):
     """descriptors -> log-plan (cost build + OT on one stream, score matrix never returned).
     return_flags (variant 2): also est_position's if_nomatching2 [b, m-1] (bool) from the OT epilogue ->
-    (Z, col_nomatch); hand it to est_position_second(col_nomatch=...)."""
+    (Z, col_nomatch); hand it to est_position_second(col_nomatch=...).
+    count (fine level, with return_flags): DEVICE int64 [1] - the tensors are a capacity, only the first `count` problems are
+    solved (the rows of the others are left as allocated)."""
     d0, d1 = _dev(mdesc0, "mdesc0"), _dev(mdesc1, "mdesc1")
     b, D, n = d0.shape
     m = d1.shape[2]
@@ -184,10 +186,18 @@ def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0
         if variant != 2:
             raise RuntimeError("cost_ot: return_flags needs variant 2 (the coarse level gets them from colmass_sqrt)")
         flags = torch.empty((b, m - 1), dtype=torch.bool, device=d0.device)
+        if count is not None:
+            cnt = _dev(count, "count", torch.int64)
+            _check(_L().pats_cost_ot_flags_counted_f32(_ptr(d0), _ptr(d1), b, _ptr(cnt), D, n, m, int(variant), _ptr(s), _ptr(ns),
+                                                       int(iters), float(bias_k), _ptr(Z), _ptr(flags.view(torch.uint8)), _ptr(ws),
+                                                       nb, _stream()), "cost_ot")
+            return Z, flags
         _check(_L().pats_cost_ot_flags_f32(_ptr(d0), _ptr(d1), b, D, n, m, int(variant), _ptr(s), _ptr(ns), int(iters),
                                            float(bias_k), _ptr(Z), _ptr(flags.view(torch.uint8)), _ptr(ws), nb, _stream()),
                "cost_ot")
         return Z, flags
+    if count is not None:
+        raise RuntimeError("cost_ot: count needs return_flags=True (the fine level's counted launch)")
     _check(_L().pats_cost_ot_f32(_ptr(d0), _ptr(d1), b, D, n, m, int(variant), _ptr(s), _ptr(ns),
                                  int(iters), float(bias_k), _ptr(Z), _ptr(ws), nb, _stream()), "cost_ot")
     return Z
@@ -278,7 +288,7 @@ def _grid_of(positions, ranges):
 
 def Iterative_expand_matrix(scores_in, scalex, scaley, limitation, ranges, positions,
                             lower_bound=1e-3, upper_bound=1e7, iter_num=15, width=20, height=15,
-                            type="distance", input_is_log=False, row_nomatch=None):
+                            type="distance", input_is_log=False, row_nomatch=None, count=None):
     """utils/utils.py:1179-1297.  Returns (whole_cost, core_cost, average_point, x_scale, y_scale,
     bound) with the reference's shapes/dtypes.  `width`/`height`/`upper_bound`/`type` are accepted
     and ignored exactly as the reference ignores them (it re-derives width/height at :1181)."""
@@ -303,15 +313,21 @@ def Iterative_expand_matrix(scores_in, scalex, scaley, limitation, ranges, posit
     xs = torch.empty((b, m), dtype=torch.float32, device=dev)
     ys = torch.empty((b, m), dtype=torch.float32, device=dev)
     bound = torch.empty((b, m, 4), dtype=torch.int64, device=dev)
+    rn = _ptr(row_nomatch.view(torch.uint8)) if row_nomatch is not None else _ptr(None)
+    if count is not None:           # not in the reference's signature: a device-side batch count (throughput mode)
+        _check(_L().pats_iterative_expand_counted_f32(_ptr(P), int(bool(input_is_log)), b, _ptr(_dev(count, "count", torch.int64)),
+                                                      M, N, _ptr(sx), _ptr(sy), lim3, h, w, float(lower_bound), int(iter_num),
+                                                      _ptr(whole), _ptr(core), _ptr(avg), _ptr(xs), _ptr(ys), _ptr(bound), rn,
+                                                      _stream()), "Iterative_expand_matrix")
+        return whole, core, avg, xs, ys, bound
     _check(_L().pats_iterative_expand_f32(_ptr(P), int(bool(input_is_log)), b, M, N, _ptr(sx), _ptr(sy),
                                           lim3, h, w, float(lower_bound), int(iter_num), _ptr(whole),
-                                          _ptr(core), _ptr(avg), _ptr(xs), _ptr(ys), _ptr(bound),
-                                          _ptr(row_nomatch.view(torch.uint8)) if row_nomatch is not None else _ptr(None),
+                                          _ptr(core), _ptr(avg), _ptr(xs), _ptr(ys), _ptr(bound), rn,
                                           _stream()), "Iterative_expand_matrix")
     return whole, core, avg, xs, ys, bound
 
 
-def _est_position(scores, scale_x, scale_y, H, W, patch_scale, iter_num, lower_bound, col_nomatch=None):
+def _est_position(scores, scale_x, scale_y, H, W, patch_scale, iter_num, lower_bound, col_nomatch=None, count=None):
     """est_position (first_layer.py:159-178 / second_layer.py:240-259) without a separate argmax pass: the row flag
     `scores.max(2).indices[:, :-1] == h*w` comes out of the expansion kernel (which holds every row anyway), the
     column flag from the caller (OT epilogue / colmass pass) or, failing that, from one pass over the columns."""
@@ -326,7 +342,7 @@ def _est_position(scores, scale_x, scale_y, H, W, patch_scale, iter_num, lower_b
     limitation1 = [0, h, 0, w]
     trust_score, _, average_point1, x_scale, y_scale, _ = Iterative_expand_matrix(
         scores, scale_x.reshape(b, -1, 1), scale_y.reshape(b, -1, 1), limitation1, ranges1, positions1,
-        height=h, width=w, iter_num=iter_num, lower_bound=lower_bound, input_is_log=True, row_nomatch=if_nomatching1)
+        height=h, width=w, iter_num=iter_num, lower_bound=lower_bound, input_is_log=True, row_nomatch=if_nomatching1, count=count)
     return trust_score, average_point1, x_scale, y_scale, if_nomatching1, col_nomatch
 
 
@@ -338,11 +354,11 @@ def est_position_first(scores, scale_src, image_shape, patch_scale, col_nomatch=
     return _est_position(scores, scale_src, scale_src, H, W, patch_scale, 15, 1e-5, col_nomatch)
 
 
-def est_position_second(scores, scale_x, scale_y, image_shape, patch_scale, col_nomatch=None):
+def est_position_second(scores, scale_x, scale_y, image_shape, patch_scale, col_nomatch=None, count=None):
     """SecondLayer.est_position (second_layer.py:240-259).  col_nomatch: if_nomatching2 from
-    cost_ot(..., return_flags=True)."""
+    cost_ot(..., return_flags=True).  count: device-side batch count (throughput mode), as for cost_ot."""
     H, W = image_shape
-    return _est_position(scores, scale_x, scale_y, H, W, patch_scale, 8, 1e-3, col_nomatch)
+    return _est_position(scores, scale_x, scale_y, H, W, patch_scale, 8, 1e-3, col_nomatch, count)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -564,7 +580,7 @@ def third_level(feat_f0_unfold, feat_f1_unfold, scale, mkpts0_c, mkpts1_c, outdo
     return (m0, m1, label, ifm.bool(), Z) if return_plan else (m0, m1, label, ifm.bool())
 
 
-def fine_descriptors(desc0_, title, rubbish, out=None):
+def fine_descriptors(desc0_, title, rubbish, out=None, count=None):
     """second_layer.py:71-86: desc0_ = the three maps of ResNet2.forward2 on the stacked crops
     ([2B,64,48,48], [2B,64,24,24], [2B,128,12,12]); title [B,8] = compress_1(desc_l); rubbish [B,264]
     = compress_2(desc_l).  Returns desc [2,B,264,145] (desc[0], desc[1] feed the GNN).
@@ -582,6 +598,11 @@ def fine_descriptors(desc0_, title, rubbish, out=None):
     desc = torch.empty((2, B, 264, 145), dtype=torch.float32, device=f0.device) if out is None else _dev(out, "out")
     if tuple(desc.shape) != (2, B, 264, 145) or (out is not None and desc.data_ptr() != out.data_ptr()):
         raise RuntimeError("fine_descriptors: out must be a contiguous [2,B,264,145] tensor")
+    if count is not None:      # device-side row count: the tensors are a capacity (throughput mode)
+        _check(_L().pats_fine_descriptors_counted_f32(_ptr(f0), _ptr(f1), _ptr(f2), _ptr(ti), _ptr(ru), B,
+                                                      _ptr(_dev(count, "count", torch.int64)), int(bool(nhwc)), _ptr(desc),
+                                                      _stream()), "fine_descriptors")
+        return desc
     fn = _L().pats_fine_descriptors_nhwc_f32 if nhwc else _L().pats_fine_descriptors_f32
     _check(fn(_ptr(f0), _ptr(f1), _ptr(f2), _ptr(ti), _ptr(ru), B, _ptr(desc), _stream()), "fine_descriptors")
     return desc
@@ -969,6 +990,7 @@ class PropagationParams:
             w = get(name)
             return w.reshape(w.shape[0], -1).t().contiguous()
         self.eps = float(eps)
+        self._packed = {}
         self.C = get("attn.merge.bias").shape[0]
         self.t = {"wq_t": mat_t("attn.proj.0.weight"), "bq": get("attn.proj.0.bias").contiguous(),
                   "wk_t": mat_t("attn.proj.1.weight"), "bk": get("attn.proj.1.bias").contiguous(),
@@ -980,6 +1002,21 @@ class PropagationParams:
         scale = gamma / torch.sqrt(get("mlp.1.running_var") + self.eps)
         self.bn = {False: (scale.contiguous(), (beta - get("mlp.1.running_mean") * scale).contiguous()),   # eval: folded
                    True: (gamma.contiguous(), beta.contiguous())}                                       # train: gamma / beta
+
+    def packed(self, heads=4):
+        """The Conv1d matrices split into fp16 hi + lo halves in MFMA fragment order (pats_propagation_pack_f32), made once and
+        kept beside the weights; None for a shape without a fused layer."""
+        key = int(heads)
+        if key not in self._packed:
+            nb = _L().pats_propagation_packed_bytes(self.C, key)
+            buf = None
+            if nb:
+                buf = torch.empty((nb,), dtype=torch.uint8, device=self.t["wq_t"].device)
+                w = self.struct(False)
+                with torch.cuda.device(buf.device):
+                    _check(_L().pats_propagation_pack_f32(ctypes.byref(w), self.C, key, _ptr(buf), nb, _stream()), "propagation_pack")
+            self._packed[key] = buf
+        return self._packed[key]
 
     def struct(self, bn_train):
         a, b = self.bn[bool(bn_train)]
@@ -1005,6 +1042,12 @@ def attentional_propagation(x, source, params, heads=4, bn_train=False, residual
     nb = _L().pats_attentional_propagation_workspace_bytes(b, C, n, m)
     ws = _workspace(nb, x.device)
     w = params.struct(bn_train)
+    pk = params.packed(heads) if (n == 65 and m == 65) else None      # the third level's shape: one fused kernel (gnn_fused.hip)
+    if pk is not None:
+        _check(_L().pats_attentional_propagation_packed_f32(_ptr(x), _ptr(source), b, C, int(heads), n, m, ctypes.byref(w), _ptr(pk),
+                                                            int(bool(bn_train)), float(params.eps), _ptr(res), _ptr(out), _ptr(ws),
+                                                            nb, _stream()), "attentional_propagation")
+        return out
     _check(_L().pats_attentional_propagation_f32(_ptr(x), _ptr(source), b, C, int(heads), n, m, ctypes.byref(w),
                                                  int(bool(bn_train)), float(params.eps), _ptr(res), _ptr(out), _ptr(ws), nb,
                                                  _stream()), "attentional_propagation")

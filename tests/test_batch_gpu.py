@@ -247,3 +247,51 @@ def test_batched_merge_and_result_against_the_single_chunk_ops(new):
     assert m == wl.shape[0] > 1000
     assert torch.equal(ml[:m], wl) and torch.equal(mr[:m], wr)
     assert bool((mrow[:m] >= 0).all()) and bool((mrow[:m] < total).all())
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_counted_fine_level_launches_skip_the_padding_rows(layout):
+    """The fine level over a CAPACITY with the row count on the device (pats_cost_ot_flags_counted_f32,
+    pats_iterative_expand_counted_f32, pats_fine_descriptors_counted_f32): the first `count` rows equal the plain launch
+    over exactly those rows bit for bit; rows past the count keep what the buffers held (nothing is computed for them -
+    NaN-filled padding descriptors trip no guard and cause no log-domain redo)."""
+    from pats_amd import ops
+    cap, live = 37, 23
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(synth.SEED + 77)
+    maps = [torch.randn(sh, device="cuda", generator=gen) for sh in ((2 * cap, 64, 48, 48), (2 * cap, 64, 24, 24), (2 * cap, 128, 12, 12))]
+    if layout == "channels_last":
+        maps = [m.contiguous(memory_format=torch.channels_last) for m in maps]
+    title, rub = torch.randn((cap, 8), device="cuda", generator=gen), torch.randn((cap, 264), device="cuda", generator=gen)
+    cnt = torch.tensor([live], dtype=torch.int64, device="cuda")
+    full = ops.fine_descriptors(maps, title, rub)
+    out = torch.full((2, cap, 264, 145), float("nan"), device="cuda")
+    ops.fine_descriptors(maps, title, rub, out=out, count=cnt)
+    assert torch.equal(out[:, :live], full[:, :live]) and bool(torch.isnan(out[:, live:]).all())
+
+    # descriptors with structure (a match per row), padding rows NaN
+    base = torch.randn((cap, 264, 145), device="cuda", generator=gen)
+    d0 = (3.0 * (base + 0.3 * torch.randn((cap, 264, 145), device="cuda", generator=gen))).contiguous()
+    d1 = (3.0 * (base + 0.3 * torch.randn((cap, 264, 145), device="cuda", generator=gen))).contiguous()
+    d0[live:], d1[live:] = float("nan"), float("nan")
+    sx = torch.exp(0.3 * torch.randn((cap, 1, 144), device="cuda", generator=gen))
+    sy = torch.exp(0.3 * torch.randn((cap, 1, 144), device="cuda", generator=gen))
+    ns = (sx * sy).contiguous()
+    one = torch.tensor(1.0, device="cuda")
+    ops.sinkhorn_fallbacks(reset=True)
+    Zr, fr = ops.cost_ot(d0[:live].contiguous(), d1[:live].contiguous(), 2, one, ns[:live].contiguous(), 100, bias_k=2.0, return_flags=True)
+    assert ops.sinkhorn_fallbacks(reset=True) == 0
+    Zc, fc = ops.cost_ot(d0, d1, 2, one, ns, 100, bias_k=2.0, return_flags=True, count=cnt)
+    assert ops.sinkhorn_fallbacks(reset=True) == 0, "a padding row reached the log-domain redo"
+    assert torch.equal(Zc[:live], Zr) and torch.equal(fc[:live], fr)
+    er = ops.est_position_second(Zr, sx[:live].contiguous(), sy[:live].contiguous(), [96, 96], 8, col_nomatch=fr)
+    Zc[live:] = float("nan")
+    ec = ops.est_position_second(Zc, sx, sy, [96, 96], 8, col_nomatch=fc, count=cnt)
+    for a, b in zip(ec, er):
+        assert torch.equal(a[:live], b)
+    # count = 0 and count > capacity are both legal
+    ops.cost_ot(d0, d1, 2, one, ns, 100, bias_k=2.0, return_flags=True, count=torch.zeros(1, dtype=torch.int64, device="cuda"))
+    Zb, _ = ops.cost_ot(d0[:live].contiguous(), d1[:live].contiguous(), 2, one, ns[:live].contiguous(), 100, bias_k=2.0,
+                        return_flags=True, count=torch.tensor([10 ** 6], dtype=torch.int64, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.equal(Zb, Zr)

@@ -2,8 +2,8 @@
 
 (1) The fine-level Sinkhorn kernels (test_fine_level_solve_...): hipcc left `s_waitcnt lgkmcnt(0)` out in front of the
 barrier at the top of their sweep loops, a wave passed the barrier with its ds_write of the scaling vector still queued,
-and 1-9 of 8 192 problems per launch ended with perturbed duals (round 3, pats_amd/asm_pass.py; the build inserts the
-wait, tests/test_host_abi.py checks the shipped code).  A 388-problem parity sample sees that once in ten runs; 8 192
+and 1-9 of 8 192 problems per launch ended with perturbed duals (round 3; since round 4 the wait is in the source - wg_barrier() of
+csrc/common.hpp - and tests/test_host_abi.py checks the shipped code).  A 388-problem parity sample sees that once in ten runs; 8 192
 problems x several launches see it every time.
 
 (2) The three kernels that carry the MFMA operand write-after-read workaround
@@ -40,66 +40,93 @@ def _desc_pair(shape, gen, drop=0.12):
     return d0.contiguous(), d1.contiguous()
 
 
-def _preheat(seconds=0.6):
-    """Sustained heavy work (fp32 matmuls) so that the GPU has left its low-power state: see the docstring below."""
-    import time
-    x = torch.randn((8192, 8192), device="cuda")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(8):
-            x = (x @ x) * 1e-4
-        torch.cuda.synchronize()
+THIRD_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(repo)r)
+from pats_amd import ops, synth
+P = 414720
+gen = torch.Generator(device="cuda"); gen.manual_seed(synth.SEED + 300)
+shape = (P, 128, 65)
+base = torch.randn(shape, device="cuda", generator=gen)
+d0 = 3.0 * (base + 0.3 * torch.randn(shape, device="cuda", generator=gen))
+d1 = 3.0 * (base + 0.3 * torch.randn(shape, device="cuda", generator=gen))
+gone = torch.rand((P, 1, 65), device="cuda", generator=gen) < 0.12
+d0 = torch.where(gone, 3.12 * torch.randn(shape, device="cuda", generator=gen), d0)
+d0[:, :, -1] *= 0.5; d1[:, :, -1] *= 0.5
+del base, gone
+sc = torch.exp(torch.sigmoid(0.3 * torch.randn((P, 1, 64), device="cuda", generator=gen)) * synth.LN256 - synth.LN256 / 2)
+p_s = torch.randint(1, 23, (P, 2), device="cuda", generator=gen) * 4
+p_t = torch.randint(0, 25, (P, 2), device="cuda", generator=gen) * 4
+runs = [ops.third_level(d0.contiguous(), d1.contiguous(), sc, p_s, p_t, outdoor=True) for _ in range(4)]   # launch 0 is the process's first
+torch.cuda.synchronize()
+touched, worst = [], 0.0
+for r in runs[1:]:
+    d = (r[1] - runs[0][1]).abs()
+    touched.append(int((d.reshape(P, -1).max(dim=1).values > 0).sum()))
+    worst = max(worst, float(d.max()))
+    for a, b in ((runs[0][0], r[0]), (runs[0][2], r[2]), (runs[0][3], r[3])):
+        assert torch.equal(a, b), "index outputs differ between two launches"
+print("TOUCHED", touched, "WORST", worst)
+"""
 
 
-def test_third_level_414720_problems_three_launches_identical(ops, oracle):
-    """ops.third_level (third_fused3_kernel: in-wave fp16-split cost build, 3 waves per SIMD) at the 414 720 problems of
-    a 16-pair launch: launches on the same inputs are bit-identical, and the first 4 096 problems match the oracle.
+def _third_level_child(variant):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("PATS_THIRD_VARIANT", None)
+    if variant:
+        env["PATS_THIRD_VARIANT"] = variant
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", THIRD_CHILD % {"repo": repo}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("TOUCHED")][-1]
+    touched = eval(line.split("WORST")[0].replace("TOUCHED", ""))
+    return touched, float(line.split("WORST")[1])
 
-    What round 3 measured with tools/third_determinism.py (profiles/r03_third_determinism.md): once the GPU is out of
-    its low-power state, 100 of 100 launches are bit-identical.  The FIRST heavy launch after the device sat idle can
-    differ from them in 0-6 of the 414 720 problems by <= 1e-4 px (the gate is 2.4e-3 px): the score matrix and the
-    kernel matrix of those problems are bit-identical (diagnostic fingerprints), the scalings leave the common
-    trajectory somewhere between sweep 16 and sweep 64 and the remaining sweeps pull them back.  Tiny launches of the
-    same kernel or of other kernels beforehand do not remove it, half a second of matmuls does (8 of 8 runs clean
-    against 23 of 24 affected); the fp32-MFMA build of the same kernel never showed it (32 runs), nor does anything
-    depend on LDS or allocator contents, v_permlane*_swap / v_rcp wait states or the order of LDS returns (all tried).
-    So this test (a) asserts bit-identity where the kernel is the only variable - after a pre-heat - and (b) measures
-    the launch made BEFORE the pre-heat against them and bounds it at the parity gate instead of hiding it."""
-    P = 414720
+
+def test_third_level_414720_problems_identical_from_the_first_launch_of_a_process(ops, oracle):
+    """ops.third_level (third_fused3_kernel, 3 waves per SIMD) at the 414 720 problems of a 16-pair launch, in a FRESH process
+    with no pre-heat: launches 0..3 on the same inputs are bit-identical - launch 0 included.
+
+    History.  Round 3 found that the first full-size launch of the fp16-split instantiation in a process differs from every
+    later launch in 0-6 problems (<= 1e-4 px; scores and kernel matrix identical, the scalings leave the common trajectory
+    between sweep 16 and 64) and called it a power-state transient.  Round 4 measured that explanation away
+    (profiles/r04_third_first_launch.md): launches after 30 / 100 s of idle are clean, a warm-up on other memory removes it,
+    touching the inputs or pre-heating with matmuls does not, the stagger of the first wave front is irrelevant, the affected
+    problems sit at two instants of that first launch.  No cause was found, so the DEFAULT became the instantiation that has
+    never shown it (fp32-MFMA cost build, same sweep loop: 0 of 41 fresh processes) and this test holds it to the contract;
+    the fp16-split build (8 % faster) is the opt-in PATS_THIRD_VARIANT=1350, bounded by the next test."""
+    touched, worst = _third_level_child(None)
+    assert touched == [0, 0, 0] and worst == 0.0, (touched, worst)
+    # and the values are the right ones: the first 4 096 problems against the oracle (this process, default build)
+    P, n = 8192, 4096
     gen = torch.Generator(device="cuda")
     gen.manual_seed(synth.SEED + 300)
     d0, d1 = _desc_pair((P, 128, 65), gen)
     sc = torch.exp(torch.sigmoid(0.3 * torch.randn((P, 1, 64), device="cuda", generator=gen)) * synth.LN256 - synth.LN256 / 2)
     p_s = torch.randint(1, 23, (P, 2), device="cuda", generator=gen) * 4
     p_t = torch.randint(0, 25, (P, 2), device="cuda", generator=gen) * 4
-    ops.sinkhorn_fallbacks(reset=True)
-    first = ops.third_level(d0, d1, sc, p_s, p_t, outdoor=True)          # whatever state the GPU is in
-    torch.cuda.synchronize()
-    _preheat()
-    runs = [ops.third_level(d0, d1, sc, p_s, p_t, outdoor=True) for _ in range(3)]
-    torch.cuda.synchronize()
-    for r in runs[1:]:
-        for a, b, name in zip(runs[0], r, ("mkpts0_f", "mkpts1_f", "label", "if_matching1")):
-            diff = int((a != b).sum())
-            assert diff == 0, "%s differs between two launches on the same inputs in %d entries" % (name, diff)
-    # the launch before the pre-heat: indices identical, target points within the gate, a handful of problems at most
-    assert torch.equal(first[0], runs[0][0]) and torch.equal(first[2], runs[0][2]) and torch.equal(first[3], runs[0][3])
-    d = (first[1] - runs[0][1]).abs()
-    touched = int((d.reshape(P, -1).max(dim=1).values > 0).sum())
-    print("launch before the pre-heat: %d of %d problems differ, max |d mkpts1_f| = %.2e px" % (touched, P, float(d.max())))
-    assert touched <= 64 and float(d.max()) <= 1e-3
-    n = 4096
+    m0, m1, label, ifm = ops.third_level(d0, d1, sc, p_s, p_t, outdoor=True)
     S = oracle.cost(d0[:n].cpu().numpy(), d1[:n].cpu().numpy())
     scn = sc[:n].cpu().numpy()
     Zr = oracle.log_optimal_transport2(S, 1.0, scn, 100)
     sq = np.sqrt(scn + np.float32(1e-8)).astype(np.float32)
     r0, r1, _, rlabel, rifm = oracle.compute_result(np.exp(Zr), sq, sq, p_s[:n].cpu().numpy(), p_t[:n].cpu().numpy(), True)
-    m0, m1, label, ifm = runs[0]
     assert np.array_equal(label[:n * 16].cpu().numpy(), rlabel)
     assert np.array_equal(ifm[:n].cpu().numpy().astype(bool), rifm.astype(bool))
     assert np.array_equal(m0[:n].cpu().numpy(), r0)
     assert np.abs(m1[:n].cpu().numpy() - r1).max() <= 3e-4 * 8
+
+
+def test_third_level_fp16_split_build_is_bounded_on_its_first_launch():
+    """The opt-in build (PATS_THIRD_VARIANT=1350): launches 1.. are bit-identical to each other; the process's first
+    full-size launch may differ from them in a handful of problems, far inside the parity gate (2.4e-3 px)."""
+    touched, worst = _third_level_child("1350")
+    assert len(set(touched)) == 1, "launches 1..3 differ from each other: %s" % touched       # same set missing from launch 0 only
+    print("fp16-split build, launch 0 against launches 1..3: %d of 414720 problems differ, max %.2e px" % (touched[0], worst))
+    assert touched[0] <= 64 and worst <= 1e-3
 
 
 def test_cost_20736_fine_problems_three_launches_identical(ops, oracle):

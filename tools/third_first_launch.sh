@@ -1,0 +1,18 @@
+#!/bin/bash
+# Experiment matrix for tools/third_first_launch.py (one fresh process per line); output -> gpurun_out/third_first_launch.log
+out=gpurun_out/third_first_launch.log
+mkdir -p gpurun_out; : > $out
+run() { echo "=== $*" >> $out; env "$@" timeout 300 python tools/third_first_launch.py 2>&1 | grep -v amdgpu.ids >> $out; }
+python -c "import torch" 2>/dev/null
+for i in 1 2 3 4; do run SMI=1; done
+for i in 1 2 3; do run SYNC_FIRST=1 HOST_QUIET=1; done
+for i in 1 2; do run IDLE=30 SMI=1; done
+for k in vec copy matmul same; do for i in 1 2 3; do run PREHEAT=$k:0.6; done; done
+for i in 1 2; do run MATMUL_CHECK=1; done
+for i in 1 2 3; do run PATS_THIRD_VARIANT=300; done
+for i in 1 2 3; do run P=110136 L=6; done
+echo "=== rocm-smi --setperflevel high" >> $out
+rocm-smi --setperflevel high >> $out 2>&1
+for i in 1 2 3 4; do run SMI=1 PERF=high; done
+rocm-smi --setperflevel auto >> $out 2>&1
+tail -5 $out
