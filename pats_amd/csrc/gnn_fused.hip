@@ -96,18 +96,32 @@ __device__ __forceinline__ void store_tf(char* dst, int mt, int nt, const f4v v,
     *reinterpret_cast<h4v*>(dst + off + TF_BLK) = lo;
 }
 
-// [128][65] fp32 in global memory -> TF tensor: item (channel group of 8, token); consecutive lanes = consecutive tokens
-__device__ __forceinline__ void load_tf(const float* __restrict__ src, char* dst, int t) {
+// [128][65] fp32 in global memory -> registers -> TF tensor.  Item = (channel group of 8, token): tokens 0..63 are 16 x 64 items
+// = two per thread (consecutive lanes = consecutive tokens: 256-byte runs per load instruction), token 64 one more item for
+// threads 0..15.  The loads of problem p + 1 are issued right after problem p has been written to LDS and land under its compute.
+struct InRegs { f4v a[3], b[3]; };
+
+__device__ __forceinline__ void load_in(const float* __restrict__ src, int t, InRegs& q) {
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
-        const int i = t + 512 * it;
-        if (i < 16 * GN) {
-            const int cg = i / GN, tok = i - cg * GN;
-            const float* p = src + (cg * 8) * GN + tok;
-            f4v a = {p[0], p[GN], p[2 * GN], p[3 * GN]}, b = {p[4 * GN], p[5 * GN], p[6 * GN], p[7 * GN]};
+        const bool live = it < 2 || t < 16;
+        const int cg = it < 2 ? (t + 512 * it) >> 6 : (t & 15), tok = it < 2 ? (t & 63) : 64;
+        const float* p = src + (cg * 8) * GN + tok;
+        if (live) {
+            q.a[it] = f4v{p[0], p[GN], p[2 * GN], p[3 * GN]};
+            q.b[it] = f4v{p[4 * GN], p[5 * GN], p[6 * GN], p[7 * GN]};
+        }
+    }
+}
+
+__device__ __forceinline__ void store_in(const InRegs& q, char* dst, int t) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        if (it < 2 || t < 16) {
+            const int cg = it < 2 ? (t + 512 * it) >> 6 : (t & 15), tok = it < 2 ? (t & 63) : 64;
             h4v ah, al, bh, bl;
-            split4(a, ah, al);
-            split4(b, bh, bl);
+            split4(q.a[it], ah, al);
+            split4(q.b[it], bh, bl);
             const int tile = tok >> 4, j = tok & 15, kq = cg & 3;
             const int off = ((cg >> 2) * 2) * TF_BLK + (tile < 4 ? tile * 1024 + (kq * 16 + j) * 16 : 4096 + kq * 16);
             *reinterpret_cast<h8v*>(dst + off) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
@@ -123,33 +137,69 @@ __device__ __forceinline__ f4v mfma3(const h8v ah, const h8v al, const h8v bh, c
     return c;
 }
 
-// acc[m][nt] += W[row tile mts[m]] . src over KS k-steps (k-steps 0..3 from src0, 4..7 from src1); weights = A operand
+// Weight fragments of a stage: a ring of four k-steps per row tile (hi, lo), loaded AHEAD - the first four k-steps of stage
+// s + 1 are issued before the epilogue and the barrier of stage s, so that their L2 round trip (the weights are streamed by
+// every workgroup, 640 KB per problem) runs under them; the counters of the first version showed the waves waiting 73 % of
+// their cycles with the matrix pipe 21 % busy: the one-k-step-ahead fetch of 240 MFMA cycles did not cover the latency.
+// (depth 4 for one row tile per wave, 2 for two: a k-step of two row tiles is 30 MFMAs per wave, twice the cover)
+// A fragment's address is wave-uniform + lane * 16: the uniform part is forced into SGPRs (readfirstlane), so that a load is
+// `global_load_dwordx4 v, v_lane, s[base] offset:0 | 1024`.  Left to itself the compiler kept one 64-bit VECTOR address per
+// load, spilled them, and every reload put an s_waitcnt vmcnt(0) in front of the next weight load - no prefetch at all.
+typedef const __attribute__((address_space(1))) h8v* gptr_h8;        // explicitly GLOBAL: the integer round trip below would otherwise
+                                                                     // leave a generic pointer and flat_load (which also counts on lgkmcnt)
+__device__ __forceinline__ gptr_h8 uniform_ptr(const h8v* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gptr_h8)(((uint64_t)hi << 32) | lo);
+}
+template <int MT>
+struct WRing {
+    static constexpr int D = MT == 1 ? 4 : 2;
+    h8v a[D][MT][2];
+};
+
+template <int KS, int MT>
+__device__ __forceinline__ void ring_fill(const h8v* __restrict__ W, const int (&mts)[MT], int lane, WRing<MT>& r) {
+#pragma unroll
+    for (int ks = 0; ks < WRing<MT>::D; ++ks)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            gptr_h8 Wf = uniform_ptr(W + (mts[m] * KS + ks) * FR);
+            r.a[ks][m][0] = Wf[lane];
+            r.a[ks][m][1] = Wf[64 + lane];
+        }
+}
+
+// acc[m][nt] += W[row tile mts[m]] . src over KS k-steps (k-steps 0..3 from src0, 4..7 from src1); weights = A operand,
+// the ring holds k-steps 0..D-1 on entry
 template <int KS, int MT>
 __device__ __forceinline__ void gemm_w(const h8v* __restrict__ W, const int (&mts)[MT], const char* src0, const char* src1,
-                                       int lane, f4v (&acc)[MT][5]) {
-    h8v a[2][MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        a[0][m][0] = W[(mts[m] * KS) * FR + lane];
-        a[0][m][1] = W[(mts[m] * KS) * FR + 64 + lane];
-    }
+                                       int lane, f4v (&acc)[MT][5], WRing<MT>& r) {
+    constexpr int D = WRing<MT>::D;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                a[(ks + 1) & 1][m][0] = W[(mts[m] * KS + ks + 1) * FR + lane];
-                a[(ks + 1) & 1][m][1] = W[(mts[m] * KS + ks + 1) * FR + 64 + lane];
-            }
-        }
         const char* blk = (ks < 4 ? src0 : src1) + ((ks & 3) * 2) * TF_BLK;
+        h8v ah[MT], al[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ah[m] = r.a[ks % D][m][0]; al[m] = r.a[ks % D][m][1]; }
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) {
             const h8v bh = *reinterpret_cast<const h8v*>(blk + tf_tile_off(nt, lane));
             const h8v bl = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(nt, lane));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][nt] = mfma3(a[ks & 1][m][0], a[ks & 1][m][1], bh, bl, acc[m][nt]);
+            for (int m = 0; m < MT; ++m) acc[m][nt] = mfma3(ah[m], al[m], bh, bl, acc[m][nt]);
         }
+        if (ks + D < KS) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                gptr_h8 Wf = uniform_ptr(W + (mts[m] * KS + ks + D) * FR);
+                r.a[ks % D][m][0] = Wf[lane];
+                r.a[ks % D][m][1] = Wf[64 + lane];
+            }
+        }
+        // a k-step is a closed unit for the scheduler: left alone it hoists the LDS reads of many k-steps ahead of their MFMAs
+        // and spills (222 VGPRs in the first version of this loop)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -215,17 +265,28 @@ gnn_layer_fused_kernel(FusedArgs g) {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int qp = lane >> 4, j = lane & 15;
     const float* pb = g.pb;
+    const int mt1[1] = {wave};
+    const int mt2[2] = {wave, wave + 8};
     bool bad = false;
-    for (int64_t b = blockIdx.x; b < g.batch; b += gridDim.x) {
-        load_tf(g.x + b * (GC * GN), lds + OFF_X, t);
-        load_tf(g.source + b * (GC * GN), lds + OFF_S, t);
+    int64_t b = blockIdx.x;
+    InRegs xin, sin;
+    if (b < g.batch) {
+        load_in(g.x + b * (GC * GN), t, xin);
+        load_in(g.source + b * (GC * GN), t, sin);
+    }
+    WRing<1> rk;
+    ring_fill<4, 1>(g.pw + PW_K, mt1, lane, rk);
+    for (; b < g.batch; b += gridDim.x) {
+        store_in(xin, lds + OFF_X, t);           // loaded under the previous problem's last stage (48 registers: holding them
+        store_in(sin, lds + OFF_S, t);           // through the whole problem made the mlp[0] stage spill)
         wg_barrier();
         // ---- k = Wk' source (TF), v^T = source^T Wv'^T (token-major) -----------------------------------------------
+        WRing<1> rv, rq, rm;
         {
             f4v acc[1][5];
             zero_acc(acc);
-            const int mts[1] = {wave};
-            gemm_w<4, 1>(g.pw + PW_K, mts, lds + OFF_S, nullptr, lane, acc);
+            gemm_w<4, 1>(g.pw + PW_K, mt1, lds + OFF_S, nullptr, lane, acc, rk);
+            ring_fill<4, 1>(g.pw + PW_V, mt1, lane, rv);
             const f4v bias = load4(pb + PB_K + 16 * wave + 4 * qp);
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acc[0][nt] * UNS + bias, lane);
@@ -234,10 +295,9 @@ gnn_layer_fused_kernel(FusedArgs g) {
             f4v acc[5];
 #pragma unroll
             for (int tt = 0; tt < 5; ++tt) acc[tt] = f4v{0.f, 0.f, 0.f, 0.f};
-            const h8v* W = g.pw + PW_V + (wave * 4) * FR;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const h8v wh = W[ks * FR + lane], wl = W[ks * FR + 64 + lane];
+                const h8v wh = rv.a[ks][0][0], wl = rv.a[ks][0][1];
                 const char* blk = lds + OFF_S + (ks * 2) * TF_BLK;
 #pragma unroll
                 for (int tt = 0; tt < 5; ++tt) {
@@ -246,6 +306,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
                     acc[tt] = mfma3(sh, sl, wh, wl, acc[tt]);           // rows = tokens 16 tt + 4 q' + r, column = channel 16 w + j
                 }
             }
+            ring_fill<4, 1>(g.pw + PW_Q, mt1, lane, rq);
             const float bias = pb[PB_V + 16 * wave + j];
             char* vrow = lds + OFF_V + ((16 * wave + j) * TT_ROW) * 2;
 #pragma unroll
@@ -265,8 +326,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
         {
             f4v acc[1][5];
             zero_acc(acc);
-            const int mts[1] = {wave};
-            gemm_w<4, 1>(g.pw + PW_Q, mts, lds + OFF_X, nullptr, lane, acc);
+            gemm_w<4, 1>(g.pw + PW_Q, mt1, lds + OFF_X, nullptr, lane, acc, rq);
             const f4v bias = load4(pb + PB_Q + 16 * wave + 4 * qp);
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_S, wave, nt, acc[0][nt] * UNS + bias, lane);
@@ -342,27 +402,45 @@ gnn_layer_fused_kernel(FusedArgs g) {
                 store_tf(lds + OFF_S, 2 * h + dt, qt, o * (UNS * inv), lane);
             }
         }
+        ring_fill<4, 1>(g.pw + PW_M, mt1, lane, rm);              // under the barrier wait
         wg_barrier();
         // ---- message = Wm' attention + bm, into the slot k leaves --------------------------------------------------------
+        WRing<2> r1;
         {
             f4v acc[1][5];
             zero_acc(acc);
-            const int mts[1] = {wave};
-            gemm_w<4, 1>(g.pw + PW_M, mts, lds + OFF_S, nullptr, lane, acc);
+            gemm_w<4, 1>(g.pw + PW_M, mt1, lds + OFF_S, nullptr, lane, acc, rm);
+            ring_fill<8, 2>(g.pw + PW_1, mt2, lane, r1);
             const f4v bias = load4(pb + PB_M + 16 * wave + 4 * qp);
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acc[0][nt] * UNS + bias, lane);
         }
         wg_barrier();
         // ---- hidden = W1 (x | message) + b1: row tiles w (-> slot of q) and w + 8 (-> slot of v) -------------------------------
+        WRing<1> r2;
+        f4v res[5];
         {
             f4v acc[2][5];
             zero_acc(acc);
-            const int mts[2] = {wave, wave + 8};
-            gemm_w<8, 2>(g.pw + PW_1, mts, lds + OFF_X, lds + OFF_K, lane, acc);
+            gemm_w<8, 2>(g.pw + PW_1, mt2, lds + OFF_X, lds + OFF_K, lane, acc, r1);
+            if (!TRAIN) {
+                ring_fill<8, 1>(g.pw + PW_2, mt1, lane, r2);
+                if (g.residual) {                                  // the residual rows of this lane's outputs, ahead of mlp[3]
+                    const float* R = g.residual + (b * GC + 16 * wave + 4 * qp) * GN;
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt)
+                        if (nt < 4 || j == 0) res[nt] = f4v{R[16 * nt + j], R[GN + 16 * nt + j], R[2 * GN + 16 * nt + j], R[3 * GN + 16 * nt + j]};
+                }
+            } else {
+                ring_fill<4, 1>(g.pw + PW_K, mt1, lane, rk);       // the next problem's first stage
+                if (b + gridDim.x < g.batch) {                     // and its descriptors: in flight under this epilogue
+                    load_in(g.x + (b + gridDim.x) * (GC * GN), t, xin);
+                    load_in(g.source + (b + gridDim.x) * (GC * GN), t, sin);
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const int ch = 16 * mts[m] + 4 * qp;
+                const int ch = 16 * mt2[m] + 4 * qp;
                 const f4v bias = load4(pb + PB_1 + ch);
                 if (TRAIN) {
                     float* H = g.hid + (b * 256 + ch) * GN;
@@ -392,14 +470,17 @@ gnn_layer_fused_kernel(FusedArgs g) {
         wg_barrier();
         if (!TRAIN) {
             // ---- out = W2 relu(bn(hidden)) + b2 [+ residual] -----------------------------------------------------------
+            if (b + gridDim.x < g.batch) {       // the next problem's descriptors: in flight under this stage
+                load_in(g.x + (b + gridDim.x) * (GC * GN), t, xin);
+                load_in(g.source + (b + gridDim.x) * (GC * GN), t, sin);
+            }
             f4v acc[1][5];
             zero_acc(acc);
-            const int mts[1] = {wave};
-            gemm_w<8, 1>(g.pw + PW_2, mts, lds + OFF_S, lds + OFF_V, lane, acc);
+            gemm_w<8, 1>(g.pw + PW_2, mt1, lds + OFF_S, lds + OFF_V, lane, acc, r2);
+            ring_fill<4, 1>(g.pw + PW_K, mt1, lane, rk);           // the next problem's first stage
             const int ch = 16 * wave + 4 * qp;
             const f4v bias = load4(pb + PB_2 + ch);
             float* O = g.out + (b * GC + ch) * GN;
-            const float* R = g.residual ? g.residual + (b * GC + ch) * GN : nullptr;
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
                 if (nt < 4 || j == 0) {
@@ -407,7 +488,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float o = v[r];
-                        if (R) o = R[r * GN + 16 * nt + j] + o;
+                        if (g.residual) o = res[nt][r] + o;
                         O[r * GN + 16 * nt + j] = o;
                         bad |= !(fabsf(o) <= 3.0e38f);
                     }
