@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--soak", type=int, default=0, metavar="N",
                     help="no timing: run N + 1 whole steps on the same inputs and compare every stage's output with the first step's "
                          "bit for bit (prints the step_determinism object and exits)")
+    ap.add_argument("--wild", type=float, default=0.0, metavar="FRAC",
+                    help="diagnostic: scale the backbone maps of this fraction of the fine rows by 32 (scores x 1024) before the timed steps - "
+                         "the guard-trip leg as the whole run, for kernel traces; not a bench line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
@@ -630,6 +633,47 @@ def secondary_rooflines(ops, dev):
     return res
 
 
+def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
+    """SURVEY 8f rank 4 beside the headline, NOT in it: the AttentionalGNN stacks that sit between each level's gather and its
+    cost build (first_layer.py:102, second_layer.py:89, third_layer.py:148), random weights, timed at the step's own problem
+    counts - one AttentionalPropagation per level (both descriptor sides), scaled by the reference's layer counts (18 / 18 / 10).
+    Third level: the fused kernel of csrc/gnn_fused.hip (BatchNorm as PATS.eval() leaves it: running statistics outdoors, batch
+    statistics indoors, pats.py:112-118); fine and coarse level: the seven-launch composition of csrc/gnn.hip."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4242)
+
+    def layer_ms(C, b, n, train, chunk):
+        P = ops.PropagationParams(synth.gnn_params(seed=9, C=C))
+        bb = min(b, chunk)
+        x = torch.randn((bb, C, n), device=dev, generator=gen)
+        s_ = torch.randn((bb, C, n), device=dev, generator=gen)
+        ms = timed(lambda: ops.attentional_propagation(x, s_, P, bn_train=train, residual=x), reps=3, warm=1)
+        del x, s_
+        torch.cuda.empty_cache()
+        return ms * b / float(bb), bb
+    t3, b3 = layer_ms(128, P_step, 65, not outdoor, 131072)
+    t2, b2 = layer_ms(264, rows_step, 145, False, 4096)
+    t1, b1 = layer_ms(448, pairs, 300, False, 64)
+    per_step = {"coarse": 2 * 18 * t1, "fine": 2 * 18 * t2, "third": 2 * 10 * t3}
+    total = sum(per_step.values())
+    flops3 = 2.0 * 65 * (4 * 128 * 128 + 256 * 256 + 256 * 128) + 4 * 2 * (2.0 * 65 * 65 * 32)
+    by3 = 3.0 * 128 * 65 * 4 + 128 * 65 * 4
+    roof = {"kernel": "gnn_layer_fused_kernel (AttentionalPropagation at [128,65], %d problems per launch%s)"
+                      % (b3, "" if outdoor else "; batch statistics: up to the hidden tensor, + statistics passes + last convolution"),
+            "bound": "mfma", "achieved": 3.0 * flops3 * b3 / (t3 * b3 / P_step * 1e-3) / 1e12, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "ms_per_launch": t3 * b3 / P_step, "algorithmic_tflops": flops3 * b3 / (t3 * b3 / P_step * 1e-3) / 1e12,
+            "hbm_frac": by3 * b3 / (t3 * b3 / P_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "the whole layer in one kernel, activations LDS-resident in MFMA fragment order; priced like the cost build: fp32 "
+                    "operands as fp16 hi + lo, three exact-product passes = 3 x the algorithmic flops against the dense fp16 matrix peak "
+                    "(token padding 80 / 65 not counted); hbm_frac = x + source + residual in, out (4 x 33 KB per problem) against 8 TB/s"}
+    roof["frac"] = roof["achieved"] / F16_PEAK_TFLOPS
+    return {"ms_per_step": per_step, "layers": {"coarse": 18, "fine": 18, "third": 10},
+            "sample": {"third": "%d of %d problems" % (b3, P_step), "fine": "%d of %d rows" % (b2, rows_step), "coarse": "%d of %d pairs" % (b1, pairs)},
+            "pairs_per_s_with_gnn": pairs / ((ms_per_step + total) * 1e-3),
+            "note": "headline step + the three GNN stacks on random weights, added as sequential stream time (every kernel fills the "
+                    "GPU on its own); backbones, KeypointEncoder, final_proj and scale heads not included"}, roof
+
+
 def gather_layout_ab(ops, dev, cap, P_step, rows=2048):
     """The two descriptor gathers on the SAME logical maps in both memory orders (a sample of `rows` fine rows and the
     matching share of third-level points, times scaled to the step's launch sizes): outputs compared bit for bit."""
@@ -817,6 +861,15 @@ def main():
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         k = min(max(args.overlap, 1), 7)
         streams = (ops.masked_stream([c for c in range(n_cu) if c // 32 < k]), ops.masked_stream([c for c in range(n_cu) if c // 32 >= k]))
+    if args.wild > 0.0:
+        gw = torch.Generator(device=dev)
+        gw.manual_seed(12345)
+        pick = torch.nonzero(torch.rand((cap.rows_cap,), device=dev, generator=gw) < args.wild).flatten()
+        both = torch.cat([pick, pick + cap.rows_cap])
+        for t_ in (nets.m0, nets.m1, nets.m2):
+            t_[both] *= 32.0
+        nets.ff0[pick] *= 32.0
+        nets.ff1[pick] *= 32.0
     run_steps(batch, nets, cap, wl, None, args.warmup, streams)
     ev = {}
     nets.ev = ev
@@ -1058,7 +1111,9 @@ def main():
             torch.cuda.synchronize()
             res["value_" + other_maps] = pairs * steps / (time.perf_counter() - t1)
             nets.set_layout(args.maps == "nhwc")
-            res["roofline_secondary"] = other + secondary_rooflines(ops, dev)
+            gnn, gnn_roof = gnn_secondary(ops, dev, pairs, rows_step, P_step, 1e3 * dt / max(steps, 1), wl["outdoor"])
+            res["gnn"] = gnn
+            res["roofline_secondary"] = other + [gnn_roof] + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
             res["step_determinism"] = step_determinism(batch, nets, cap, wl)
             res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)

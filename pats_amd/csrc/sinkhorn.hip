@@ -497,16 +497,56 @@ sinkhorn_rc_kernel(const float* Zin, int64_t P, const float* __restrict__ log_mu
         float sc = colw ? expf(stab) : 1.f;        // b starts at exp(c_j); a is computed first
         wg_barrier();                           // everyone is done reading the stabilisers
         if (colw && act) lds.bc1[tl] = sc;
+        // linear == 2 (the re-solve behind sinkhorn_blk145_kernel): STABILISED linear sweeps.  A scaling that drifts out of
+        // [2^-20, 2^20] is absorbed into its stabiliser - r_i <- r_i - ln a_i, c_j <- c_j - ln b_j, a = b = 1 - and K is rebuilt
+        // from the scores in LDS with the new stabilisers (exact exponents, nothing that was flushed stays flushed): the same
+        // iterate as the reference's log-sum-exp form for any score range a sweep does not carry past fp32 in one step, at the
+        // linear kernel's speed.  Round 3 sent these problems through the log-domain sweeps below, which read Z from LDS four
+        // times per element and sweep with one or two waves per SIMD: 13 us per problem, 26 ms for the 2 000 wild problems of a
+        // step with 10 % of its rows scaled by 32 (profiles/r04_wild10_step_kernel_stats.md).
+        const bool absorb = linear == 2;
+        if (absorb && t < 6) lds.red[t] = 0.f;
         for (int it = 0; it < iters; ++it) {
-            wg_barrier();                       // b visible
+            wg_barrier();                       // b visible (and the drift flags of the previous sweep)
+            if (absorb && it > 0 && ((lds.red[0] + lds.red[1] + lds.red[2]) + (lds.red[3] + lds.red[4] + lds.red[5])) > 0.5f) {
+                // workgroup-uniform branch: every wave re-bases its stabilisers and rebuilds its part of K
+                const float lg = logf(sc);
+                if (act && lg == lg && fabsf(lg) < 3.0e38f) { stab -= lg; sc = 1.f; }     // a dead scaling (0, inf, NaN) is left to the guard
+                wg_barrier();                   // every wave has read the flags and the old b
+                if (act) (colw ? lds.bc1 : lds.bc0)[tl] = stab;
+                if (t < 6) lds.red[t] = 0.f;
+                wg_barrier();
+                if (!colw) {
+#pragma unroll
+                    for (int j0 = 0; j0 < N_; j0 += 8) {
+#pragma unroll
+                        for (int j = j0; j < j0 + 8 && j < N_; ++j)
+                            kk[j] = fast_exp2(((T[tt * N_ + j] - stab) - lds.bc1[j]) * LOG2E);
+                        asm volatile("" ::: "memory");
+                    }
+                } else {
+#pragma unroll
+                    for (int i0 = 0; i0 < N_; i0 += 8) {
+#pragma unroll
+                        for (int i = i0; i < i0 + 8 && i < N_; ++i)
+                            kk[i] = fast_exp2(((T[i * N_ + tt] - lds.bc0[i]) - stab) * LOG2E);
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                wg_barrier();                   // everyone is done reading the stabilisers
+                if (colw && act) lds.bc1[tl] = sc;
+                wg_barrier();                   // b visible
+            }
             if (!colw) {
                 sc = marg * fast_rcp(dotN<N_>(kk, lds.bc1));
                 if (act) lds.bc0[tl] = sc;
+                if (absorb && __any(act && !(sc <= 1048576.f && sc >= 9.5367431640625e-07f)) && lane == 0) lds.red[wave] = 1.f;
             }
             wg_barrier();                       // a visible
             if (colw) {
                 sc = marg * fast_rcp(dotN<N_>(kk, lds.bc0));
                 if (act) lds.bc1[tl] = sc;
+                if (absorb && __any(act && !(sc <= 1048576.f && sc >= 9.5367431640625e-07f)) && lane == 0) lds.red[wave] = 1.f;
             }
         }
         const bool ok_wave = __all(!act || scaling_ok(sc));
@@ -522,7 +562,7 @@ sinkhorn_rc_kernel(const float* Zin, int64_t P, const float* __restrict__ log_mu
     }
 
     if (!solved) {      // workgroup-uniform: max-subtracted log-sum-exp sweeps on Z itself.
-        if (linear && t == 0 && fallbacks) atomicAdd(fallbacks, 1ull);
+        if (linear == 1 && t == 0 && fallbacks) atomicAdd(fallbacks, 1ull);      // (a re-solve pass has counted its problem on entry)
         // Rare path (guard tripped, or PATS_SINKHORN_LOG): Z is read from the LDS tile each time
         // rather than held in registers, so it does not raise the kernel's VGPR budget.
         const int zstride = colw ? N_ : 1;
@@ -960,6 +1000,13 @@ using namespace pats;
 constexpr int NF = 145;   // fine level (12 x 12 + dustbin)
 static inline bool resident_shape(int M, int N) { return (M == NT && N == NT) || (M == NF && N == NF); }
 static inline int use_linear() { return sinkhorn_mode() != PATS_SINKHORN_LOG; }
+// how sinkhorn_rc_kernel re-solves the problems the block kernel flagged: 2 = stabilised linear sweeps (absorption; a problem
+// that still leaves the guard ends in the log-sum-exp sweeps inside the same launch), 0 = log-sum-exp sweeps at once (round 3;
+// PATS_FINE_REDO_LOG=1)
+static inline int redo_mode() {
+    static const int m = getenv("PATS_FINE_REDO_LOG") ? 0 : 2;
+    return m;
+}
 
 namespace pats {
 int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
@@ -984,11 +1031,11 @@ static int launch_fine145(int mode, const float* Z, int64_t batch, const float* 
     }
     if (mode == 0)
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 0>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, log_mu,
-                           log_nu, nullptr, nullptr, iters, 0.f, blk ? 0 : (int)use_linear(), out,
+                           log_nu, nullptr, nullptr, iters, 0.f, blk ? redo_mode() : (int)use_linear(), out,
                            fallback_counter(), blk ? fail : nullptr, live);
     else
         hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, Z, batch, nullptr,
-                           nullptr, ns, one, iters, bias_k, blk ? 0 : (int)use_linear(), out, fallback_counter(),
+                           nullptr, ns, one, iters, bias_k, blk ? redo_mode() : (int)use_linear(), out, fallback_counter(),
                            blk ? fail : nullptr, live);
     int rc = check_launch("sinkhorn_rc_kernel<145>");
     // column flags of the problems the log-domain kernel (re-)solved: all of them without the block kernel
@@ -1012,7 +1059,7 @@ int launch_fine145_fused(const float* d0, const float* d1, int D, int64_t batch,
     int rc = launch_blk145_fused(d0, d1, D, batch, ns, one, iters, bias_k, out, fail, col_nomatch, st, live);
     if (rc) return rc;
     hipLaunchKernelGGL((sinkhorn_rc_kernel<NF, 2>), dim3((unsigned)batch), dim3(384), 0, st, (const float*)out, batch,
-                       (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, 0, out, fallback_counter(),
+                       (const float*)nullptr, (const float*)nullptr, ns, one, iters, bias_k, redo_mode(), out, fallback_counter(),
                        (const int*)fail, live);
     rc = check_launch("sinkhorn_rc_kernel<145>(redo)");
     if (!rc && col_nomatch) rc = launch_col_flags(out, batch, NF, NF, col_nomatch, fail, st);

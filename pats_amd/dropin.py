@@ -125,6 +125,26 @@ def _methods(ops):
             "models.modules#gnn": ("AttentionalGNN", {"forward": gnn_forward})}
 
 
+def prepare_backbones(model, names=("descriptor_extract", "backbone", "compress", "compress_1", "compress_2")):
+    """Optional, beside install(): switch the convolution stacks whose OUTPUTS the two descriptor gathers read -
+    `SecondLayer.descriptor_extract` (second_layer.py:69: the three ResNet2.forward2 maps of a15) and
+    `ThirdLayer.descriptor_extract` / `.backbone` (third_layer.py:113-117: the half-resolution maps of a16) - to
+    torch.channels_last parameters.  PyTorch then picks channels-last for the convolutions' outputs as well (with MIOpen:
+    PYTORCH_MIOPEN_SUGGEST_NHWC=1 in the environment), the logical shapes stay [B,C,H,W], and ops.fine_descriptors /
+    ops.third_descriptors take their channels-last kernels (same bits; 4.0 + 3.0 instead of 6.4 + 8.0 ms per 48-pair step:
+    a pixel's channels are one contiguous run).  The unchanged reference emits NCHW maps, which is what bench.py's headline
+    runs on; this is the one-line opt-in behind `value_nhwc`.  Returns the sub-modules it converted."""
+    import torch
+    done = []
+    for mod in model.modules():
+        for n in names:
+            sub = getattr(mod, n, None)
+            if isinstance(sub, torch.nn.Module) and sub not in done:
+                sub.to(memory_format=torch.channels_last)
+                done.append(sub)
+    return done
+
+
 def install(import_reference=False):
     """Rebinds the names listed in the module docstring; returns the list of "module.name" it touched.
     Idempotent (a second call first undoes the first).  Needs the HIP library: pats_amd.ops raises if
