@@ -930,15 +930,15 @@ def main():
         # HBM traffic per launch from rocprofv3 PMC passes over this same step (tools/pmc_step.sh -> profiles/r03_pmc_step.json:
         # FETCH_SIZE and WRITE_SIZE in separate runs, calibrated on the cost build's known byte count in the same run)
         pmc, pmc_src = {}, None
-        pmc_path = os.path.join(REPO, "profiles", "r03_pmc_step.json")
+        pmc_path = os.path.join(REPO, "profiles", "r04_pmc_step_%s.json" % args.maps)
         if os.path.exists(pmc_path):
             pj = json.load(open(pmc_path))
             if int(pj.get("rows_cap", -1)) == cap.rows_cap and args.workload == "megadepth":
                 pmc = pj["kernels"]
-                pmc_src = "profiles/r03_pmc_step.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over bench.py), factors " \
+                pmc_src = "profiles/r04_pmc_step_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over bench.py), factors " \
                           "from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the third-level " \
                           "kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
-                          % (pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
+                          % (args.maps, pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
 
         def traffic_of(prefix):
             hit = [v for k, v in pmc.items() if k.startswith(prefix)]
@@ -955,7 +955,7 @@ def main():
                               "two allowed rooflines but not the limiter: the sweeps are fp32 VALU work (valu_frac = sweep FMA flops / "
                               "157.3 TF/s vector peak)"}
         # fine level: descriptors in, log-plan out
-        f_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * cap.rows_cap
+        f_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * rows_step
         f_ach = f_by / (fine_ms * 1e-3) / 1e9
         f_parts = [traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145_kernel")[0]]
         f_traffic = float(sum(f_parts)) if all(v is not None for v in f_parts) else None
@@ -964,56 +964,39 @@ def main():
                      "traffic": f_traffic, "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145_kernel: includes the "
                      "score matrix written by the first and read by the second)", "traffic_source": pmc_src if f_traffic is not None else None,
                      "algorithmic_bytes_per_launch": f_by, "avg_launch_ms": fine_ms, "launches": int(len(ev["fine"])),
-                     "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
+                     "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * rows_step / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
                      "note": "descriptors in (2 x 264 x 145 fp32), log-plan out (145 x 145 fp32) per problem; the 100 sweeps run on the "
                              "register-resident blocks (VALU-bound)"}
-        # The fine level is TWO kernels inside one C call (pats_cost_ot_flags_f32): the contract's roofline is per kernel, so each is
-        # timed on its own after the timed steps - same descriptors, same launch sizes, HIP events around ops.cost and around
-        # ops.log_optimal_transport2 on its output (their sum must reproduce the pair's in-step time; both are reported)
+        # The fine level is TWO kernels inside one C call (pats_cost_ot_flags_counted_f32): the contract's roofline is per kernel,
+        # so the call records an event between its two launches (ops.set_cost_ot_mid_event, armed by batch.fine_solve_stage) and
+        # both are timed INSIDE the timed steps (round 3 re-timed them on their own afterwards: 3.39 against 3.80 ms in the trace)
         fine_split = None
-        try:
-            dsc = nets.desc[(nets.fine_calls - 1) & 1]
-            one_t = torch.ones(1, device=dev)
-
-            def _ev_time(fn, reps=5):
-                fn()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / reps
-            S_buf = ops.cost(dsc[0], dsc[1])
-            c_ms = _ev_time(lambda: ops.cost(dsc[0], dsc[1]))
-            s_ms = _ev_time(lambda: ops.log_optimal_transport2(S_buf, one_t, nets.ns2, ITERS, bias_k=2.0 if wl["outdoor"] else 3.0))
-            del S_buf
+        if ev.get("fine_mid") and len(ev["fine_mid"]) == len(ev["fine"]):
+            c_ms = float(np.mean([a.elapsed_time(m_) for (a, _), m_ in zip(ev["fine"], ev["fine_mid"])]))
+            s_ms = float(np.mean([m_.elapsed_time(b_) for (_, b_), m_ in zip(ev["fine"], ev["fine_mid"])]))
             fine_split = (c_ms, s_ms)
-        except RuntimeError:
-            pass
         split_roofs = []
         if fine_split is not None:
             c_ms, s_ms = fine_split
-            c_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * cap.rows_cap
-            s_by = (2.0 * 145 * 145 * 4 + 144 * 4) * cap.rows_cap
+            c_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * rows_step
+            s_by = (2.0 * 145 * 145 * 4 + 144 * 4) * rows_step
             c_tr = traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0]
             s_tr = traffic_of("pats::sinkhorn_blk145_kernel")[0]
             split_roofs = [
-                {"bound": "hbm", "kernel": "sinkhorn_blk145_kernel<2> (fine-level OT: %d x 145x145, 100 sweeps)" % cap.rows_cap,
+                {"bound": "hbm", "kernel": "sinkhorn_blk145_kernel<2> (fine-level OT: %d x 145x145 in use of a capacity of %d, 100 sweeps)" % (rows_step, cap.rows_cap),
                  "achieved": s_by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "traffic": s_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if s_tr is not None else None,
-                 "algorithmic_bytes_per_launch": s_by, "avg_launch_ms": s_ms, "launches": 5,
-                 "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * cap.rows_cap / (s_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
-                 "timed": "on its own after the timed steps (one C call holds both fine-level kernels); in-step pair %.3f ms" % fine_ms,
+                 "algorithmic_bytes_per_launch": s_by, "avg_launch_ms": s_ms, "launches": int(len(ev["fine"])),
+                 "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * rows_step / (s_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
+                 "timed": "inside the timed steps (event recorded between the two launches of the one C call); in-step pair %.3f ms" % fine_ms,
                  "note": "scores in, log-plan out (2 x 145 x 145 fp32 per problem); HBM is the nearer allowed roofline but not the limiter: "
                          "100 sweeps on register-resident 9x9 blocks, VALU issue (valu_frac = sweep FMA flops / 157.3 TF/s; 203 "
                          "instructions per wave and sweep, 85 of them packed FMAs)"},
-                {"bound": "hbm", "kernel": "cost_mfma_kernel<true> (fine-level cost build: %d x [264,145]^2)" % cap.rows_cap,
+                {"bound": "hbm", "kernel": "cost_mfma_kernel<true> (fine-level cost build: %d x [264,145]^2 in use of a capacity of %d)" % (rows_step, cap.rows_cap),
                  "achieved": c_by / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_by / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "traffic": c_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if c_tr is not None else None,
-                 "algorithmic_bytes_per_launch": c_by, "avg_launch_ms": c_ms, "launches": 5,
-                 "timed": "on its own after the timed steps; in-step pair %.3f ms" % fine_ms,
+                 "algorithmic_bytes_per_launch": c_by, "avg_launch_ms": c_ms, "launches": int(len(ev["fine"])),
+                 "timed": "inside the timed steps; in-step pair %.3f ms" % fine_ms,
                  "note": "both descriptor blocks in, the score matrix out: a streaming kernel (the fp16-split MFMA passes hide under the "
                          "descriptor stream)"}]
         # the two descriptor gathers (a15 / a16): HBM-bound copies with index arithmetic
@@ -1022,11 +1005,11 @@ def main():
         # a15, algorithmic bytes per stacked image: every sampled input element once (64 ch x 144 points x 4 pooled taps on the
         # two high-resolution maps, 128 ch x 144 on the third, title + dustbin features) and the [264,145] block out
         FD_BYTES = (2 * 64 * 144 * 4 + 128 * 144 + 8 + 264) * 4 + 264 * 145 * 4
-        fd_by = float(FD_BYTES) * 2 * cap.rows_cap
+        fd_by = float(FD_BYTES) * 2 * rows_step
         cl = nets.channels_last
         fd_name, td_name = ("fine_desc_nhwc_kernel", "third_desc_nhwc_kernel") if cl else ("fine_desc_kernel", "third_desc_kernel")
         fd_roof = {"bound": "hbm", "kernel": "%s (a15: fine descriptor sampling, %d stacked crops, %s maps)"
-                                             % (fd_name, 2 * cap.rows_cap, "channels-last" if cl else "NCHW"),
+                                             % (fd_name, 2 * rows_step, "channels-last" if cl else "NCHW"),
                    "achieved": fd_by / (fd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": fd_by / (fd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + fd_name + " ")[0],
                    "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": fd_by,
@@ -1090,6 +1073,7 @@ def main():
                        "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "
                                       "after the timed region (%s)" % (n_gpus, backend if dist is not None else "single process")},
             "ot_iters_per_sec": value * sweeps_per_pair,
+            "rows_in_use_per_step": rows_step, "rows_cap": cap.rows_cap, "third_problems_per_step": P_step,
             "guard_fallbacks_per_step": fallbacks / max(1, steps),
             "gather_ms": gather_ms, "matches_per_pair": matches_per_pair,
             "rank_ms_per_step": rank_ms, "rank_setup_s": rank_setup,

@@ -125,6 +125,10 @@ int pats_cost_ot_flags_f32(const float* d0, const float* d1, int64_t batch, int 
                            float* Z, uint8_t* col_nomatch, void* workspace, size_t workspace_bytes,
                            pats_stream_t stream);
 
+/* Measurement hook: `event` (a hipEvent_t, or NULL) is recorded once, by the next two-kernel pats_cost_ot*_f32 call of the calling
+ * thread, between its cost-build launch and its Sinkhorn launch (bench.py times the two kernels inside its steps with it).  ABI 5. */
+int pats_set_cost_ot_mid_event(void* event);
+
 /* The fine level launched over a CAPACITY of batch_cap problems with the number in use on the device (throughput mode:
  * batch_dev = the row table's total, &chunk_base[Cmax] of pats_chunk_rows_device): workgroups of problems >= *batch_dev return
  * at once - no cost build, no solve, no log-domain redo; their rows of Z / col_nomatch are left untouched.  variant 2,

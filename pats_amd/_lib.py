@@ -42,6 +42,7 @@ SIGNATURES = {
                                  c_void_p, c_int, c_f, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_cost_ot_flags_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_set_cost_ot_mid_event": (c_int, [c_void_p]),
     "pats_cost_ot_flags_counted_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_iterative_expand_counted_f32": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,

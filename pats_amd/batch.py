@@ -116,6 +116,11 @@ def fine_solve_stage(co, nets, cap, if_outdoor=True, merge_new=True, iters=100, 
     f0, f1, sx, sy = fine[:4]
     ns2 = fine[4] if len(fine) > 4 else (sx * sy).contiguous()
     e = _timed(events, "fine")
+    if events is not None:                      # the boundary between the pair's two kernels, recorded inside the C call
+        em = torch.cuda.Event(enable_timing=True)
+        em.record()
+        events.setdefault("fine_mid", []).append(em)
+        ops.set_cost_ot_mid_event(em)
     live = rows.chunk_base[-1:]                 # rows in use, on the device: the launches cover rows_cap, padding rows are skipped
     Z2, cflag2 = ops.cost_ot(f0, f1, 2, _one(f0.device), ns2, iters, bias_k=2.0 if if_outdoor else 3.0, return_flags=True,
                              count=live)

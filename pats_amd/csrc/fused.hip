@@ -27,6 +27,14 @@ int ot2_flags_live(const float* scores, int64_t batch, int m, int n, const float
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Measurement hook (bench.py): an event the next cost_ot call of THIS THREAD records between its two launches (cost build |
+// Sinkhorn), so that the two kernels of the one C call can be timed inside a step instead of on their own afterwards.
+static thread_local hipEvent_t g_mid_event = nullptr;
+extern "C" int pats_set_cost_ot_mid_event(void* event) {
+    g_mid_event = (hipEvent_t)event;
+    return PATS_OK;
+}
+
 extern "C" size_t pats_cost_ot_workspace_bytes(int64_t batch, int D, int n, int m, int variant) {
     (void)D;
     if (variant == 2 && n == 65 && m == 65 && (D % 32) == 0 && D <= 512) return 0;
@@ -99,6 +107,11 @@ static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, 
     }
     int rc = launch_cost(d0, d1, batch, D, n, m, scores, stream, live);
     if (rc) return rc;
+    if (g_mid_event) {
+        const hipEvent_t ev = g_mid_event;
+        g_mid_event = nullptr;                       // one call, one record
+        if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess) return check_launch("cost_ot mid event");
+    }
     if (variant == 1) {
         PATS_REQUIRE(scalar, "cost_ot: alpha pointer required for variant 1");
         PATS_REQUIRE(bias_k == 0.f, "cost_ot: bias only applies to variant 2");

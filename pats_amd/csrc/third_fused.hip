@@ -347,8 +347,12 @@ __device__ __forceinline__ void third_v2_problem(const Fused65Args& g, const int
                            g.outdoor, g.cr, lane, 66, area);
 }
 
-// direct mode: one workgroup per problem.  scan mode (g.scan): workgroup w looks at problems 64w .. 64w+63 and
-// re-solves those whose if_matching1 slot carries THIRD_REDO (left there by third_fused3_kernel's guard).
+// direct mode: one workgroup per problem.  scan mode (g.scan): the W workgroups of the launch share the problems INTERLEAVED -
+// workgroup w looks at w, w + W, w + 2 W, ... (64 candidates per ballot) and re-solves those whose if_matching1 slot carries
+// THIRD_REDO (left there by third_fused3_kernel's guard).  Flagged problems come in runs (the points of one wild fine row are
+// consecutive): with contiguous blocks of 64 per workgroup - round 3 - one wave re-solved a whole run serially while the rest
+// of the GPU idled (9.1 ms per step for 8 000 flagged problems, profiles/r04_wild10_step_kernel_stats.md); interleaved, a
+// run of 64 goes to 64 different waves.
 __global__ void __launch_bounds__(64, 3)
 third_fused_kernel(Fused65Args g) {
     __shared__ BlkLds lds;
@@ -364,14 +368,17 @@ third_fused_kernel(Fused65Args g) {
         third_v2_problem(g, p, lds, lane);
         return;
     }
-    const int64_t base = (int64_t)blockIdx.x * 64;
-    const bool redo = base + lane < live_problems(g) && g.cr.ifm[(base + lane) * 16] == THIRD_REDO;
-    unsigned long long todo = __ballot(redo);
-    while (todo) {
-        const int k = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        wg_barrier();
-        third_v2_problem(g, base + k, lds, lane);
+    const int64_t W = gridDim.x, live = live_problems(g);
+    for (int64_t first = blockIdx.x; first < live; first += 64 * W) {
+        const int64_t cand = first + (int64_t)lane * W;
+        const bool redo = cand < live && g.cr.ifm[cand * 16] == THIRD_REDO;
+        unsigned long long todo = __ballot(redo);
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            wg_barrier();
+            third_v2_problem(g, first + (int64_t)k * W, lds, lane);
+        }
     }
 }
 
@@ -389,7 +396,8 @@ int launch_third_fused(const Fused65Args& g0, hipStream_t st) {
         if (rc) return rc;
         g.linear = 0;
         g.scan = 1;
-        hipLaunchKernelGGL(third_fused_kernel, dim3((unsigned)ceil_div(g.P, 64)), dim3(64), 0, st, g);
+        const int64_t waves = g.P < 6144 ? g.P : 6144;            // two rounds of the 3 072 wave slots: flagged runs spread out
+        hipLaunchKernelGGL(third_fused_kernel, dim3((unsigned)(waves > 0 ? waves : 1)), dim3(64), 0, st, g);
         return check_launch("third_fused_kernel(scan)");
     }
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);

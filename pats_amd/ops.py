@@ -167,6 +167,13 @@ def log_optimal_transport2(scores, one, ns, iters: int, bias_k: float = 0.0):
     return Z
 
 
+def set_cost_ot_mid_event(event):
+    """Measurement hook: the next two-kernel cost_ot call records `event` (a torch.cuda.Event that has been recorded once, so
+    that its handle exists; None clears) between its cost-build launch and its Sinkhorn launch."""
+    h = None if event is None else ctypes.c_void_p(event.cuda_event)
+    _check(_L().pats_set_cost_ot_mid_event(h), "set_cost_ot_mid_event")
+
+
 def cost_ot(mdesc0, mdesc1, variant, scalar, ns, iters: int, bias_k: float = 0.0, return_flags=False, count=None):
     """descriptors -> log-plan (cost build + OT on one stream, score matrix never returned).
     return_flags (variant 2): also est_position's if_nomatching2 [b, m-1] (bool) from the OT epilogue ->

@@ -3,7 +3,7 @@
 WRITE_SIZE in separate passes, no trace domains beside them; FETCH_SIZE calibrated on a kernel of known byte count in
 the same run, because other access widths than 16 B / lane are uncalibrated on gfx950).
 
-usage: pmc_step.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> [rows_cap] > profiles/r03_pmc_step.json
+usage: pmc_step.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <bench.py's JSON line of one pass> > profiles/r04_pmc_step_<layout>.json
 Both passes ran `bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline` (tools/pmc_step.sh)."""
 import collections
 import csv
@@ -30,7 +30,9 @@ def main():
     write, _ = load(sys.argv[2], "WRITE_SIZE")
     # the fine level's cost build is the cost_mfma_kernel launch with the largest grid: one 256-thread workgroup per row
     grids = [k[1] for k in fetch if k[0].startswith("pats::cost_mfma_kernel")]
-    rows_cap = max(grids) // 256 if grids else int(sys.argv[3])
+    bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    rows_cap = max(grids) // 256 if grids else int(bench["rows_cap"])
+    rows_live = int(bench["rows_in_use_per_step"])      # the launches cover rows_cap, workgroups past the device-side count return
     # rocprofv3 reports both counters in KB
     KB = 1024.0
     # calibrator: the fine-level cost build reads exactly 2 x 264 x 145 fp32 per problem (8-byte lane loads, coalesced)
@@ -42,7 +44,7 @@ def main():
     f_fac = w_fac = None
     if cal_key:
         k = cal_key[0]
-        known_r, known_w = 2.0 * 264 * 145 * 4 * rows_cap, 145.0 * 145 * 4 * rows_cap
+        known_r, known_w = 2.0 * 264 * 145 * 4 * rows_live, 145.0 * 145 * 4 * rows_live
         f_fac, w_fac = known_r / (fetch[k] * KB), known_w / (write[k] * KB)
         out["calibration"] = {"kernel": k[0], "grid": k[1], "known_read_bytes": known_r, "FETCH_SIZE_raw_bytes": fetch[k] * KB,
                               "fetch_factor": f_fac, "known_write_bytes": known_w, "WRITE_SIZE_raw_bytes": write[k] * KB,
@@ -56,6 +58,7 @@ def main():
     # known byte count, same run): x1.381 (profiles/r02_pmc_third.json)
     override = {"pats::third_fused3_kernel": 1.381}
     out["rows_cap"] = rows_cap
+    out["rows_in_use"] = rows_live
     ks = {}
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         if not k[0].startswith("pats::"):
