@@ -46,10 +46,10 @@ struct __attribute__((aligned(16))) BlkLds {
     float tmp[NB * 17];          // one-time: partial maxima for the stabilisers
 };
 
-// experiment hooks (libpats_amd_diag<suffix>.so, tools/fine_determinism4.py)
+// experiment hooks (libpats_amd_diag<suffix>.so, tools/fine_determinism.py)
 // Wave priority up for the dependent reduction tail of the row and column phases (DPP / swap chains, reciprocal, the LDS
 // write the other waves wait for at the barrier), back down for the FMA blocks: the waves closest to a barrier get the issue
-// slots.  Measured 5.58 -> 5.50 ms per 20 224 problems for cost + OT, levels 1 / 2 / 3 alike (tools/_prio_ab.sh); no effect
+// slots.  Measured 5.58 -> 5.50 ms per 20 224 problems for cost + OT, levels 1 / 2 / 3 alike; no effect
 // on results.  -DPATS_EXPB_NO_PRIO: the A/B partner.
 #ifndef PATS_EXPB_NO_PRIO
 #define BLK_PRIO(n) __builtin_amdgcn_s_setprio((n) ? 1 : 0)

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""How do the path's two kinds of kernels scale with the number of compute units they may use?  An HBM-bound gather
-(ops.fine_descriptors) and a VALU-bound solver (ops.third_level) on streams masked to every k-th CU, alone and together."""
+"""Gather (HBM-bound) and solver (VALU-bound) under complementary CU masks, alone and together."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,30 +14,29 @@ desc = torch.empty((2, R, 264, 145), device=dev)
 d0 = torch.randn((P, 128, 65), device=dev, generator=g); d1 = d0 + 0.3 * torch.randn((P, 128, 65), device=dev, generator=g)
 sc = torch.exp(torch.sigmoid(0.3 * torch.randn((P, 1, 64), device=dev, generator=g)) * synth.LN256 - synth.LN256 / 2)
 ps = torch.randint(1, 23, (P, 2), device=dev) * 4; pt = torch.randint(0, 25, (P, 2), device=dev) * 4
-
 def gather(): ops.fine_descriptors([m0, m1, m2], title, rub, out=desc)
 def solve(): ops.third_level(d0, d1, sc, ps, pt)
-
 def timed(fn, stream, reps=6):
     with torch.cuda.stream(stream):
-        fn(); torch.cuda.synchronize()
+        fn(); fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps): fn()
         torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / reps
-
 full = torch.cuda.Stream()
-print("all 256 CUs: gather %.2f ms, solver %.2f ms" % (timed(gather, full), timed(solve, full)))
-for num, den in ((1, 4), (1, 3), (1, 2), (2, 3), (3, 4)):
-    cus_g = [c for c in range(256) if (c * num) % den < num] if False else [c for c in range(256) if (c % den) < num]
-    cus_s = [c for c in range(256) if c not in set(cus_g)]
-    sg, ss = ops.masked_stream(cus_g), ops.masked_stream(cus_s)
+timed(solve, full)
+tg0, ts0 = timed(gather, full), timed(solve, full)
+print("all CUs: gather %.2f ms, solver %.2f ms, sum %.2f" % (tg0, ts0, tg0 + ts0))
+for name, sel in (("k<2", lambda c: c // 32 < 2), ("k<3", lambda c: c // 32 < 3), ("k<4", lambda c: c // 32 < 4), ("k<5", lambda c: c // 32 < 5),
+                  ("k in 0,2,4", lambda c: (c // 32) in (0, 2, 4)), ("k<3 (as G), swap", lambda c: c // 32 >= 5)):
+    cg = [c for c in range(256) if sel(c)]; cs = [c for c in range(256) if not sel(c)]
+    sg, ss = ops.masked_stream(cg), ops.masked_stream(cs)
     tg, ts = timed(gather, sg), timed(solve, ss)
-    # together: both streams busy at once
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(6):
         with torch.cuda.stream(sg): gather()
         with torch.cuda.stream(ss): solve()
     torch.cuda.synchronize()
     both = 1e3 * (time.perf_counter() - t0) / 6
-    print("gather on %3d CUs %.2f ms | solver on %3d CUs %.2f ms | both at once %.2f ms per (gather + solve)" % (len(cus_g), tg, len(cus_s), ts, both))
+    print("%-8s gather on %3d CUs %.2f ms (x%.2f) | solver on %3d CUs %.2f ms (x%.2f) | both at once %.2f ms (serial on all CUs: %.2f)"
+          % (name, len(cg), tg, tg / tg0, len(cs), ts, ts / ts0, both, tg0 + ts0))

@@ -30,6 +30,8 @@ What each fixture pins (reference file:line):
   attention.npz    attention(query, key, value) of the GNN layers (models/modules.py:84-88)
   third_desc_ring.npz  the a16 gather for source points on the border ring of the cell grid: windows that wrap
                    in the flattened NHWC view, the dustbin index that reads the next patch (third_layer.py:127,141-144)
+  dropin_gnn.npz   AttentionalGNN (3 layers) / AttentionalPropagation / KeypointEncoder instances of the reference in eval and
+                   train mode and after two parameter changes (models/modules.py:70-134): the drop-in test's expected values
   result.npz / result_mixed.npz   third-level inputs, result scatter and get_result
                    (pats.py:53-78, utils/utils.py:189-213); _mixed flips left_choice per row
 """
@@ -601,6 +603,50 @@ def gen_heads(R):
     save("heads.npz", **arrs)
 
 
+def gen_dropin(R):
+    """What tests/test_gpu_parity.py::test_dropin_runs_a_gnn_module_on_the_hip_kernels compares against: the REFERENCE's own
+    AttentionalGNN / AttentionalPropagation / KeypointEncoder instances (models/modules.py:70-134), parameters from
+    pats_amd.synth, forward in eval and train mode, and after the two parameter changes the drop-in's caches must follow
+    (a checkpoint loaded later; an in-place update).  Outputs sampled (8192 entries) with their sums: data only."""
+    C, names = 128, ["self", "cross", "self"]
+    gnn = R.M.AttentionalGNN(C, names)
+    ps = [synth.gnn_params(seed=synth.SEED + 120 + i, C=C) for i in range(3)]
+    other = [synth.gnn_params(seed=synth.SEED + 130 + i, C=C) for i in range(3)]
+
+    def load(plist):
+        for lyr, p_ in zip(gnn.layers, plist):
+            lyr.load_state_dict({k: T(v) for k, v in p_.items()}, strict=False)
+    a = synth.gnn_inputs(seed=synth.SEED + 125, b=6, C=C, n=65)
+    d0, d1 = T(a["x"]), T(a["source"])
+    rng = np.random.default_rng(93)
+    idx = sample_idx(rng, d0.shape, 8192)
+    arrs = {"idx": idx}
+
+    def put(tag, y0, y1):
+        arrs.update({tag + "_d0": y0.reshape(-1)[T(idx)], tag + "_d1": y1.reshape(-1)[T(idx)],
+                     tag + "_sum": torch.stack([y0.double().sum(), y1.double().sum()])})
+    with torch.no_grad():
+        load(ps)
+        put("eval", *gnn.eval()(d0, d1))
+        one = gnn.layers[0].eval()(d0, d1)
+        arrs.update(one=one.reshape(-1)[T(idx)], one_sum=one.double().sum())
+        put("train", *gnn.train()(d0, d1))
+        load(other)                                                   # "a checkpoint loaded after the first forward"
+        put("load", *gnn.eval()(d0, d1))
+        gnn.layers[1].attn.merge.weight.mul_(1.5)                     # "an in-place optimiser-style update"
+        put("step", *gnn.eval()(d0, d1))
+    kp = synth.kenc_params(seed=synth.SEED + 140, feature_dim=C)
+    kenc = R.M.KeypointEncoder(C, [32, 64, 128, 256, 512])
+    kpts = T(synth.grid_kpts(8, 8))
+    for mode in ("eval", "train"):
+        kenc.load_state_dict({k: T(v) for k, v in kp.items()}, strict=False)
+        kenc.train(mode == "train")
+        with torch.no_grad():
+            arrs["kenc_" + mode] = kenc(kpts)
+    arrs["in_checksum"] = synth.checksum(a["x"], a["source"], ps[0]["mlp.0.weight"], other[2]["mlp.3.weight"], kp["encoder.0.weight"])
+    save("dropin_gnn.npz", **arrs)
+
+
 def gen_roofline(R):
     """BASELINE.json configs[4] through the reference itself: cost einsum at [1,448,4096]^2, then
     log_optimal_transport on 4097x4097 with 200 iterations (modules.py:145-162; ~10 s on 8 cores).  Stored:
@@ -635,6 +681,9 @@ def main():
     if only == ["heads"]:
         gen_heads(R)
         return
+    if only == ["dropin"]:                                        # round 4: the drop-in test's fixture
+        gen_dropin(R)
+        return
     if only == ["ring"]:                                          # round 3: the a16 gather on the border ring of the cell grid
         gen_third_desc(R, "third_desc_ring.npz", synth.third_maps_ring())
         return
@@ -662,6 +711,7 @@ def main():
     gen_attention(R)
     gen_gnn(R)
     gen_heads(R)
+    gen_dropin(R)
     gen_pipeline(R, "pipeline_outdoor.npz", synth.SEED + 40, 5, 6, True, True, True)
     gen_pipeline(R, "pipeline_indoor.npz", synth.SEED + 41, 4, 5, False, False, False)
     gen_pipeline(R, "pipeline_640x480_outdoor.npz", synth.SEED + 50, 15, 20, True, True, True)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Experiment matrix for tools/third_first_launch.py (one fresh process per line); output -> gpurun_out/third_first_launch.log
+# (round 4 ran it in two halves: profiles/r04_third_first_launch_1.log / _2.log)
 out=gpurun_out/third_first_launch.log
 mkdir -p gpurun_out; : > $out
 run() { echo "=== $*" >> $out; env "$@" timeout 300 python tools/third_first_launch.py 2>&1 | grep -v amdgpu.ids >> $out; }
@@ -15,4 +16,13 @@ echo "=== rocm-smi --setperflevel high" >> $out
 rocm-smi --setperflevel high >> $out 2>&1
 for i in 1 2 3 4; do run SMI=1 PERF=high; done
 rocm-smi --setperflevel auto >> $out 2>&1
+# second matrix (memory-translation theory, one warm-up launch, stagger, longer idle)
+for i in 1 2 3 4; do run PREHEAT=touch:2; done
+for i in 1 2 3 4; do run PREHEAT=other:0.6; done
+for i in 1 2 3 4; do run PREHEAT=same1:0; done
+for i in 1 2 3; do run PATS_STAGGER=0; done
+for i in 1 2 3; do run PATS_STAGGER=5; done
+for i in 1 2; do run IDLE=100; done
+for i in 1 2 3 4 5 6; do run PATS_THIRD_VARIANT=300; done
+grep RESULT $out
 tail -5 $out
