@@ -1411,8 +1411,8 @@ def test_dropin_runs_a_gnn_module_on_the_hip_kernels(ops):
     other = [synth.gnn_params(seed=synth.SEED + 130 + i, C=C) for i in range(3)]
     a = synth.gnn_inputs(seed=synth.SEED + 125, b=6, C=C, n=65)
     kp = synth.kenc_params(seed=synth.SEED + 140, feature_dim=C)
-    assert np.array_equal(g["in_checksum"], synth.checksum(a["x"], a["source"], ps[0]["mlp.0.weight"], other[2]["mlp.3.weight"],
-                                                           kp["encoder.0.weight"]))
+    assert synth.checksum(a["x"], a["source"], ps[0]["mlp.0.weight"], other[2]["mlp.3.weight"], kp["encoder.0.weight"]) == \
+        pytest.approx(float(g["in_checksum"]), rel=1e-9)
     saved = {n: sys.modules.get(n) for n in ("models", "models.modules")}
     mod = types.ModuleType("models.modules")
     mod.AttentionalPropagation, mod.AttentionalGNN, mod.KeypointEncoder = AttentionalPropagation, AttentionalGNN, KeypointEncoder
