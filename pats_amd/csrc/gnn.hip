@@ -482,13 +482,13 @@ bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, doub
 __global__ void __launch_bounds__(64)
 bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const float* __restrict__ gamma,
                  const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
-                 const int* __restrict__ gate = nullptr) {
+                 const int* __restrict__ gate = nullptr, int splits = BN_SPLITS) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C || (gate && *gate == 0)) return;
     double a = 0.0, q = 0.0;
-    for (int s_ = 0; s_ < BN_SPLITS; ++s_) {
-        a += part[((int64_t)c * BN_SPLITS + s_) * 2 + 0];
-        q += part[((int64_t)c * BN_SPLITS + s_) * 2 + 1];
+    for (int s_ = 0; s_ < splits; ++s_) {
+        a += part[((int64_t)c * splits + s_) * 2 + 0];
+        q += part[((int64_t)c * splits + s_) * 2 + 1];
     }
     const double mean = a / (double)total;
     double var = q / (double)total - mean * mean;
@@ -580,8 +580,9 @@ extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, in
     if (batch < 0 || C <= 0 || n <= 0 || m <= 0) return 0;
     const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
     // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each; BN partial sums
+    // (BatchNorm partial sums: BN_SPLITS per channel for the composition, one per workgroup of the fused kernel's grid - at most 512)
     return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float)) +
-           al256((size_t)2 * C * pats::BN_SPLITS * 2 * sizeof(double)) + 256 /* seven redo flags + the fused layer's flag */;
+           al256((size_t)2 * C * 512 * 2 * sizeof(double)) + 256 /* seven redo flags + the fused layer's flag */;
 }
 
 namespace pats {
@@ -589,7 +590,10 @@ int launch_attention(const float* query, const float* key, const float* value, i
                      float* out, float* prob, pats_stream_t stream, const int* gate);                     // attention.hip
 int fused_layer_supported(int C, int heads, int n, int m);                                                // gnn_fused.hip
 int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
-                       int bn_train, const float* residual, float* out, float* hid, int* flag, hipStream_t st);
+                       int bn_train, const float* residual, float* out, float* hid, int* flag, double* bn_part, int* splits_out,
+                       hipStream_t st);
+int launch_gnn_tail(const float* hid, int64_t batch, const void* packed, const float* scale, const float* shift, const float* residual,
+                    float* out, int* flag, hipStream_t st);
 }
 
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
@@ -641,7 +645,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     float* hid = (float*)p; p += al256((size_t)batch * 2 * C * n * sizeof(float));
     float* bsc = (float*)p; p += al256((size_t)2 * C * sizeof(float));
     float* bsh = (float*)p; p += al256((size_t)2 * C * sizeof(float));
-    double* bpart = (double*)p; p += al256((size_t)2 * C * BN_SPLITS * 2 * sizeof(double));
+    double* bpart = (double*)p; p += al256((size_t)2 * C * 512 * 2 * sizeof(double));
     int* redo = (int*)p;
     if (hipMemsetAsync(redo, 0, 8 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
     int rc;
@@ -649,16 +653,15 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     if (packed && fused_layer_supported(C, heads, n, m)) {
         // residual == out would be read-after-write across waves of the fused kernel's epilogue only per element: allowed
         int* flag = redo + 7;
-        rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, st);
+        int splits = 0;
+        rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, bpart, &splits, st);
         if (rc == PATS_OK) {
-            if (bn_train) {      // the fused kernel stopped behind mlp[0]: statistics of the hidden tensor, then mlp[1..3]
-                hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)(2 * C), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart,
-                                   (const int*)nullptr);
+            if (bn_train) {      // the fused kernel stopped behind mlp[0] and left per-workgroup partial sums of the hidden tensor:
+                                 // scale / shift from them, then mlp[1..3] from the hidden tensor in one kernel
                 hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, bpart, batch * (int64_t)n,
-                                   2 * C, w->bn_a, w->bn_b, bn_eps, bsc, bsh, (const int*)nullptr);
-                if ((rc = check_launch("bn_stats kernels"))) return rc;
-                if ((rc = launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, bsc, bsh, w->b2, residual, out}, redo + 6, st)))
-                    return rc;
+                                   2 * C, w->bn_a, w->bn_b, bn_eps, bsc, bsh, (const int*)nullptr, splits);
+                if ((rc = check_launch("bn_finish_kernel"))) return rc;
+                if ((rc = launch_gnn_tail(hid, batch, packed, bsc, bsh, residual, out, flag, st))) return rc;
             }
             gate = flag;         // the composition below runs only if the fused kernel raised it
         } else if (rc != PATS_ERR_UNSUPPORTED) {

@@ -44,7 +44,7 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int GC = 128, GN = 65, GD = 32;
+constexpr int GC = 128, GN = 65;
 constexpr float PRE = 64.0f, UNS = 1.0f / 4096.0f;
 constexpr int TF_BLK = 4 * 1024 + 64;             // bytes of one (k-step, hi | lo) block
 constexpr int TF_BYTES = 4 * 2 * TF_BLK;          // [128 x 65] tensor: 33 280
@@ -52,6 +52,7 @@ constexpr int TT_ROW = 68;                        // tokens per channel row of t
 constexpr int TT_PLANE = GC * TT_ROW * 2;         // bytes of its hi (or lo) plane
 constexpr int OFF_X = 0, OFF_S = TF_BYTES, OFF_K = 2 * TF_BYTES, OFF_V = 3 * TF_BYTES;
 constexpr int FUSED_LDS = 3 * TF_BYTES + 2 * TT_PLANE;        // 134 656
+constexpr int FUSED_MAX_GRID = 512;                           // workgroups of the persistent grid = partial-sum slots per channel
 
 // packed weights (units of h8v = 16 bytes): fragment (row tile mt, k-step ks) = [hi | lo][64 lanes]
 constexpr int FR = 2 * 64;
@@ -72,6 +73,7 @@ struct FusedArgs {
     const float* bn_b;
     int64_t batch;
     int* flag;
+    double* bn_part;           // train: per-workgroup partial sums of the hidden tensor, [256][gridDim.x][2] (sum, sum of squares)
 };
 
 __device__ __forceinline__ int tf_tile_off(int nt, int lane) {      // byte offset of this lane's 16-byte fragment piece in a block
@@ -268,6 +270,15 @@ gnn_layer_fused_kernel(FusedArgs g) {
     const int mt1[1] = {wave};
     const int mt2[2] = {wave, wave + 8};
     bool bad = false;
+    // TRAIN: this lane's share of the batch statistics of the hidden tensor (mlp[1] = BatchNorm1d on batch statistics): per
+    // problem the fp32 sums over a channel's 65 tokens (fixed order: in-lane over the token tiles, then a 16-lane butterfly), across
+    // the workgroup's problems in double.  Every workgroup writes its partials, bn_finish_kernel adds them in index order:
+    // the result does not depend on scheduling.
+    double st1[2][4], st2[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st1[m][r] = 0.0; st2[m][r] = 0.0; }
     int64_t b = blockIdx.x;
     InRegs xin, sin;
     if (b < g.batch) {
@@ -444,16 +455,27 @@ gnn_layer_fused_kernel(FusedArgs g) {
                 const f4v bias = load4(pb + PB_1 + ch);
                 if (TRAIN) {
                     float* H = g.hid + (b * 256 + ch) * GN;
+                    f4v p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int nt = 0; nt < 5; ++nt) {
                         const f4v v = acc[m][nt] * UNS + bias;
                         if (nt < 4 || j == 0) {
+                            p1 = p1 + v;
+                            p2 = p2 + v * v;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 H[r * GN + 16 * nt + j] = v[r];
                                 bad |= !(fabsf(v[r]) <= 3.0e38f);
                             }
                         }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a1 = p1[r], a2 = p2[r];
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }     // the 16 lanes of the row tile's token axis
+                        st1[m][r] += (double)a1;
+                        st2[m][r] += (double)a2;
                     }
                 } else {
                     const f4v sc = load4(g.bn_a + ch), sh = load4(g.bn_b + ch);
@@ -498,7 +520,82 @@ gnn_layer_fused_kernel(FusedArgs g) {
         }
     }
     if (bad) atomicOr(g.flag, 1);
+    if (TRAIN && j == 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * mt2[m] + 4 * qp + r;
+                g.bn_part[((int64_t)ch * gridDim.x + blockIdx.x) * 2 + 0] = st1[m][r];
+                g.bn_part[((int64_t)ch * gridDim.x + blockIdx.x) * 2 + 1] = st2[m][r];
+            }
+    }
 }
+
+// ---- the layer's tail on batch statistics: out = W2 relu(hidden * scale + shift) + b2 [+ residual] from the hidden tensor the
+// kernel above wrote (TRAIN) and the scale / shift bn_finish_kernel made of its partial sums.  One problem per workgroup pass:
+// hidden [256][65] fp32 -> affine + ReLU -> split -> TF layout (two 128-channel tensors) -> the mlp[3] stage of the fused
+// kernel.  66.5 KB of LDS: two workgroups per CU.
+__global__ void __launch_bounds__(512, 4)          // four waves per SIMD = two 8-wave workgroups per CU: 128 registers
+gnn_tail_kernel(FusedArgs g, const float* __restrict__ scale, const float* __restrict__ shift) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int qp = lane >> 4, j = lane & 15;
+    const int mt1[1] = {wave};
+    bool bad = false;
+    for (int64_t b = blockIdx.x; b < g.batch; b += gridDim.x) {
+        WRing<1> r2;
+        ring_fill<8, 1>(g.pw + PW_2, mt1, lane, r2);
+        const float* H = g.hid + b * (256 * GN);
+        // items (channel group of 8, token): 32 x 64 = four per thread, token 64: threads 0..31
+        auto item = [&](int cg, int tok) {
+            const float* p = H + (cg * 8) * GN + tok;
+            const f4v sc0 = load4(scale + cg * 8), sc1 = load4(scale + cg * 8 + 4), sh0 = load4(shift + cg * 8), sh1 = load4(shift + cg * 8 + 4);
+            f4v a = f4v{p[0], p[GN], p[2 * GN], p[3 * GN]} * sc0 + sh0, c = f4v{p[4 * GN], p[5 * GN], p[6 * GN], p[7 * GN]} * sc1 + sh1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = a[r] < 0.f ? 0.f : a[r]; c[r] = c[r] < 0.f ? 0.f : c[r]; }
+            h4v ah, al, ch_, cl;
+            split4(a, ah, al);
+            split4(c, ch_, cl);
+            const int tile = tok >> 4, jj = tok & 15, kq = cg & 3;
+            char* dst = lds + (cg >> 4) * TF_BYTES;
+            const int off = (((cg & 15) >> 2) * 2) * TF_BLK + (tile < 4 ? tile * 1024 + (kq * 16 + jj) * 16 : 4096 + kq * 16);
+            *reinterpret_cast<h8v*>(dst + off) = h8v{ah.x, ah.y, ah.z, ah.w, ch_.x, ch_.y, ch_.z, ch_.w};
+            *reinterpret_cast<h8v*>(dst + off + TF_BLK) = h8v{al.x, al.y, al.z, al.w, cl.x, cl.y, cl.z, cl.w};
+        };
+#pragma unroll 2
+        for (int it = 0; it < 4; ++it) item((t + 512 * it) >> 6, t & 63);
+        if (t < 32) item(t, 64);
+        wg_barrier();
+        f4v acc[1][5];
+        zero_acc(acc);
+        gemm_w<8, 1>(g.pw + PW_2, mt1, lds, lds + TF_BYTES, lane, acc, r2);
+        const int ch = 16 * wave + 4 * qp;
+        const f4v bias = load4(g.pb + PB_2 + ch);
+        float* O = g.out + (b * GC + ch) * GN;
+        const float* R = g.residual ? g.residual + (b * GC + ch) * GN : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            if (nt < 4 || j == 0) {
+                const f4v v = acc[0][nt] * UNS + bias;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float o = v[r];
+                    if (R) o = R[r * GN + 16 * nt + j] + o;
+                    O[r * GN + 16 * nt + j] = o;
+                    bad |= !(fabsf(o) <= 3.0e38f);
+                }
+            }
+        }
+        wg_barrier();
+    }
+    if (bad) atomicOr(g.flag, 1);
+}
+
+// Measured and not kept (round 4): the same layer with SIXTEEN waves per workgroup (four per SIMD, 128 registers each; the
+// 128-row stages split their token tiles between two waves per row tile, mlp[0] one wave per row tile, the attention's twenty
+// units in two rounds instead of three): 3.62 against 2.95 ms per 25 920 problems - 81-111 spilled registers at the 128 budget
+// and the row tiles' weight fragments streamed twice.
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 int fused_layer_supported(int C, int heads, int n, int m) {
@@ -531,14 +628,16 @@ extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int 
 namespace pats {
 // The layer (eval: whole; train: up to the hidden tensor) for batch problems.  flag: one int, zero on entry.
 int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
-                       int bn_train, const float* residual, float* out, float* hid, int* flag, hipStream_t st) {
+                       int bn_train, const float* residual, float* out, float* hid, int* flag, double* bn_part, int* splits_out,
+                       hipStream_t st) {
     struct PerDevice { int state = 0; int n_cu = 256; };
     static PerDevice per_dev[64];
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = 0; }
     PerDevice& pd = per_dev[dev_id];
     if (pd.state == 0) {
-        const bool ok = hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
+        const bool ok = hipFuncSetAttribute((const void*)gnn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TF_BYTES) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
                         hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         int v = 256;
@@ -548,10 +647,24 @@ int launch_fused_layer(const float* x, const float* source, int64_t batch, const
     }
     if (pd.state != 1) return PATS_ERR_UNSUPPORTED;
     const h8v* pw = (const h8v*)packed;
-    FusedArgs g{x, source, residual, out, hid, pw, (const float*)(pw + PW_END), bn_a, bn_b, batch, flag};
-    const unsigned grid = (unsigned)std::min<int64_t>(batch, pd.n_cu);
+    FusedArgs g{x, source, residual, out, hid, pw, (const float*)(pw + PW_END), bn_a, bn_b, batch, flag, bn_part};
+    const unsigned grid = (unsigned)std::min<int64_t>(batch, std::min(pd.n_cu, FUSED_MAX_GRID));
+    if (splits_out) *splits_out = (int)grid;
     if (bn_train) hipLaunchKernelGGL(gnn_layer_fused_kernel<true>, dim3(grid), dim3(512), FUSED_LDS, st, g);
     else hipLaunchKernelGGL(gnn_layer_fused_kernel<false>, dim3(grid), dim3(512), FUSED_LDS, st, g);
     return check_launch("gnn_layer_fused_kernel");
+}
+
+// mlp[1..3] of the layer on batch statistics, from the hidden tensor (see gnn_tail_kernel)
+int launch_gnn_tail(const float* hid, int64_t batch, const void* packed, const float* scale, const float* shift, const float* residual,
+                    float* out, int* flag, hipStream_t st) {
+    int dev_id = 0, n_cu = 256;
+    if (hipGetDevice(&dev_id) != hipSuccess) { (void)hipGetLastError(); dev_id = 0; }
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n_cu <= 0) { (void)hipGetLastError(); n_cu = 256; }
+    const h8v* pw = (const h8v*)packed;
+    FusedArgs g{nullptr, nullptr, residual, out, const_cast<float*>(hid), pw, (const float*)(pw + PW_END), nullptr, nullptr, batch, flag, nullptr};
+    const unsigned grid = (unsigned)std::min<int64_t>(batch, 2 * (int64_t)n_cu);
+    hipLaunchKernelGGL(gnn_tail_kernel, dim3(grid), dim3(512), 2 * TF_BYTES, st, g, scale, shift);
+    return check_launch("gnn_tail_kernel");
 }
 }  // namespace pats

@@ -2,7 +2,8 @@
 """Static check of the SHIPPED gfx950 code (the code objects bundled in libpats_amd.so).
 
 Rule (enforced, exit status 1): every `s_barrier` has `s_waitcnt ... lgkmcnt(0)` in front of it in its basic block with no
-LDS / scalar-memory / flat operation in between.  `wg_barrier()` of pats_amd/csrc/common.hpp puts the wait there in the
+LDS-memory / scalar-memory / flat operation in between (ds_bpermute / ds_permute / ds_swizzle - lane exchanges on the LDS
+crossbar that touch no LDS memory - may sit behind the wait).  `wg_barrier()` of pats_amd/csrc/common.hpp puts the wait there in the
 SOURCE (round 4; round 3 patched it into the compiler's assembly): `__syncthreads()` compiled by hipcc (ROCm 7.2) lacks it in
 front of some barriers - e.g. at the top of a sweep loop whose latch ends in a ds_write - and on MI355X the waves released by
 the barrier then read LDS the late wave has not written yet: the run-to-run differences of the fine-level Sinkhorn solve
@@ -27,6 +28,9 @@ def disassemble(path):
 
 LGKM = re.compile(r"^(ds_|s_load|s_buffer_load|s_scratch_load|s_store|s_buffer_store|s_atomic|s_buffer_atomic|s_dcache|s_memtime|"
                   r"s_memrealtime|s_sendmsg|flat_|s_gl1_inv|s_atc_probe)")
+
+
+CROSSBAR = re.compile(r"^(ds_bpermute_b32|ds_permute_b32|ds_swizzle_b32)$")
 
 
 def scan_lines(lines):
@@ -56,6 +60,9 @@ def scan_lines(lines):
                 if qm == "s_waitcnt" and "lgkmcnt(0)" in q:
                     covered = True
                     break
+                if CROSSBAR.match(qm):
+                    continue          # lane exchanges on the LDS crossbar: on the LGKM counter, but no LDS MEMORY is touched -
+                                      # nothing another wave could read stale; the scheduler may place them behind the wait
                 if LGKM.match(qm) or qm.startswith("s_cbranch") or qm in ("s_branch", "s_setpc_b64", "s_swappc_b64"):
                     why = q
                     break
