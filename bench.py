@@ -238,7 +238,8 @@ class StepWatch:
 
     def __init__(self, cap, depth=2):
         self.cap, self.q, self.depth = cap, [], depth
-        self.pool = [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(2, dtype=torch.int64).pin_memory())
+        self.pool = [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(2, dtype=torch.int64).pin_memory(),
+                      torch.empty(cap.pairs + 1, dtype=torch.int64).pin_memory())
                      for _ in range(depth + 1)]             # plain D2H copies: no kernel outside pats:: enters the steps
         self.steps = 0
 
@@ -247,6 +248,8 @@ class StepWatch:
         buf[0].copy_(out["status"], non_blocking=True)
         buf[1][0:1].copy_(out["P"], non_blocking=True)
         buf[1][1:2].copy_(out["M"], non_blocking=True)
+        if "by_pair" in out:
+            buf[2].copy_(out["by_pair"][2], non_blocking=True)        # where every pair's matches start
         e = torch.cuda.Event()
         e.record()
         self.q.append((e, buf))
@@ -259,6 +262,9 @@ class StepWatch:
         status, (P, M) = int(buf[0][0]), (int(v) for v in buf[1].tolist())
         if status or P > self.cap.P_cap:
             raise RuntimeError("bench: a step overflowed a capacity (status %d, P %d of %d)" % (status, P, self.cap.P_cap))
+        off = buf[2].tolist()
+        if off[-1] not in (0, M) or any(b_ < a_ for a_, b_ in zip(off, off[1:])):
+            raise RuntimeError("bench: the per-pair offsets of a step do not add up to its match count")
         self.last = (status, P, M)
 
     def drain(self):
@@ -285,6 +291,7 @@ def run_steps(batch, nets, cap, wl, ev, n, streams, watch=None):
             co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
             fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
             out = batch.third_stage(fs, nets, cap, events=ev, **kw)
+            batch.group_by_pair(out, cap)                 # the hand-over: every pair's match list contiguous, offsets on the device
             if watch is not None:
                 watch.push(out)
         if watch is not None:
@@ -1065,9 +1072,11 @@ def main():
                        "rows_cap": "%s (%d rows; %d in use - the fine level's launches take the count from the device and skip the rest)"
                                    % ("worst case pairs * (N + (Cmax - 1) w)" if args.rows_cap == "worst" else "dry run of the step's own pairs + 1 %",
                                       cap.rows_cap, rows_step),
-                       "result_handover": "every step's status / P / M counters are copied to pinned host memory inside the timed region "
-                                          "and checked one step behind (an overflow in any step raises); the per-pair split of the matches "
-                                          "(batch.split_by_pair) and their gather to rank 0 run once, after the clock",
+                       "result_handover": "inside the timed region, every step: the matches are regrouped by pair on the device "
+                                          "(pats_matches_by_pair_f32: each pair's list contiguous, in the reference's order) and the step's "
+                                          "status / P / M counters + per-pair offsets go to pinned host memory, checked one step behind (an "
+                                          "overflow in any step raises).  The match coordinates themselves stay in HBM; their gather to rank 0 "
+                                          "runs once, after the clock",
                        "setup_s": setup_s,
                        "resident_synthetic_GB": nets.resident_bytes() / 1e9, "sinkhorn_iters": ITERS,
                        "parallelism": "pairs sharded over %d rank(s), no data-path collective; matches gathered to rank 0 "

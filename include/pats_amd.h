@@ -439,6 +439,17 @@ int pats_get_result_chunks_f32(int Cmax, int64_t pairs, const uint8_t* masks, co
                                int64_t capacity, int64_t* count, void* workspace, size_t workspace_bytes,
                                pats_stream_t stream);
 
+/* The matches of a batch grouped BY PAIR on the device (ABI 5; throughput mode's hand-over, no reference counterpart: the
+ * reference runs one pair at a time).  Input = what pats_get_result_chunks_f32 wrote (matches in (chunk, pair, patch, sub-cell)
+ * order, match_row, the count *M_dev) + the row table's row_cell / chunk_base; output = the same matches with every pair's list
+ * contiguous and in the reference's order (its chunks one after the other), pair_off [pairs + 1] int64: pair p owns rows
+ * [pair_off[p], pair_off[p + 1]) of out_l / out_r.  No host read. */
+size_t pats_matches_by_pair_workspace_bytes(int Cmax, int64_t pairs);
+int pats_matches_by_pair_f32(const float* matches_l, const float* matches_r, const int32_t* match_row, const int64_t* M_dev,
+                             const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
+                             float* out_l, float* out_r, int64_t* pair_off, void* workspace, size_t workspace_bytes,
+                             pats_stream_t stream);
+
 /* attention(query, key, value) of the GNN layers (reference models/modules.py:84-88; the core of
  * MultiHeadedAttention.forward :100-105): scores = q^T k / dim**.5 per (batch, head), softmax over the
  * keys, out = prob v.  query [batch,dim,heads,n], key / value [batch,dim,heads,m] (the view

@@ -183,6 +183,13 @@ def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, ite
     return fine_third_stage(co, nets, cap, if_outdoor, merge_new, iters, events)
 
 
+def group_by_pair(out, cap, buffers=None):
+    """Device side of the hand-over: the batch's matches regrouped by pair (ops.matches_by_pair), no host read.  Adds
+    `by_pair` = (matches_l, matches_r, pair_off) to the result; a caller in a loop passes `buffers` to reuse the outputs."""
+    out["by_pair"] = ops.matches_by_pair(out["rows"], out["matches_l"], out["matches_r"], out["match_row"], out["M"], out=buffers)
+    return out["by_pair"]
+
+
 def split_by_pair(out, cap):
     """Host side, AFTER the step: per-pair (matches_l, matches_r) lists from a forward_pairs result, in the reference's
     order.  Reads the counts back (the one synchronisation of a batch) and raises on a capacity overflow."""
@@ -193,13 +200,6 @@ def split_by_pair(out, cap):
         raise RuntimeError("pats_amd.batch: the row table overflowed rows_cap = %d" % cap.rows_cap)
     if P > cap.P_cap:
         raise RuntimeError("pats_amd.batch: %d third-level problems exceed P_cap = %d" % (P, cap.P_cap))
-    rows = out["rows"]
-    pair = torch.div(rows.row_cell[out["match_row"][:M].long()], cap.N, rounding_mode="floor")
-    order = torch.argsort(pair, stable=True)
-    counts = torch.bincount(pair, minlength=cap.pairs).cpu().tolist()
-    ml, mr = out["matches_l"][:M][order], out["matches_r"][:M][order]
-    res, o = [], 0
-    for c in counts:
-        res.append((ml[o:o + c], mr[o:o + c]))
-        o += c
-    return res
+    ml, mr, off = out["by_pair"] if "by_pair" in out else group_by_pair(out, cap)
+    o = off.cpu().tolist()
+    return [(ml[o[p]:o[p + 1]], mr[o[p]:o[p + 1]]) for p in range(cap.pairs)]

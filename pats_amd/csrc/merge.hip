@@ -466,6 +466,86 @@ extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, 
     return check_launch("merge_patches_batch");
 }
 
+// ---- matches of a batch, grouped by pair (throughput mode's hand-over: what batch.split_by_pair did with argsort + bincount) ----
+// pats_get_result_chunks_f32 emits the matches in (chunk, pair, patch, sub-cell) order: the matches of one (chunk, pair) are a
+// contiguous run, a pair's list in the reference's order is the concatenation of its runs over the chunks.  Three small launches:
+// run boundaries (one thread per match looks at its neighbour), destination offsets (one workgroup, pairs x Cmax entries), copy.
+namespace pats {
+struct ByPairArgs {
+    const float* ml; const float* mr; const int32_t* match_row; const int64_t* M; const int32_t* row_cell; const int64_t* chunk_base;
+    int Cmax; int64_t pairs; int N;
+    float* out_l; float* out_r; int64_t* pair_off; int64_t* seg_lo; int64_t* seg_hi; int64_t* seg_dst;
+};
+__device__ __forceinline__ int64_t bypair_key(const ByPairArgs& g, int64_t i) {
+    const int64_t row = g.match_row[i];
+    int c = 0;
+    for (int k = 1; k < g.Cmax; ++k) c += (row >= g.chunk_base[k]) ? 1 : 0;            // chunk blocks are ascending
+    return (int64_t)c * g.pairs + g.row_cell[row] / g.N;
+}
+__global__ void __launch_bounds__(256) bypair_runs_kernel(ByPairArgs g) {
+    const int64_t M = *g.M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = bypair_key(g, i);
+        if (i == 0 || bypair_key(g, i - 1) != k) g.seg_lo[k] = i;
+        if (i == M - 1 || bypair_key(g, i + 1) != k) g.seg_hi[k] = i + 1;
+    }
+}
+__global__ void __launch_bounds__(256) bypair_offsets_kernel(ByPairArgs g) {              // one workgroup; thread p walks pair p's chunks
+    __shared__ int64_t total[1024];
+    const int64_t P = g.pairs;
+    for (int64_t p0 = 0; p0 < P; p0 += 1024) {                                            // (pairs per batch: tens)
+        for (int64_t p = p0 + threadIdx.x; p < P && p < p0 + 1024; p += 256) {
+            int64_t t = 0;
+            for (int c = 0; c < g.Cmax; ++c) t += g.seg_hi[c * P + p] - g.seg_lo[c * P + p];
+            total[p - p0] = t;
+        }
+        wg_barrier();
+        if (threadIdx.x == 0) {
+            int64_t run = p0 == 0 ? 0 : g.pair_off[p0];
+            for (int64_t p = p0; p < P && p < p0 + 1024; ++p) { g.pair_off[p] = run; run += total[p - p0]; }
+            g.pair_off[P < p0 + 1024 ? P : p0 + 1024] = run;
+        }
+        wg_barrier();
+    }
+    for (int64_t p = threadIdx.x; p < P; p += 256) {
+        int64_t run = g.pair_off[p];
+        for (int c = 0; c < g.Cmax; ++c) { g.seg_dst[c * P + p] = run; run += g.seg_hi[c * P + p] - g.seg_lo[c * P + p]; }
+    }
+}
+__global__ void __launch_bounds__(256) bypair_copy_kernel(ByPairArgs g) {
+    const int64_t M = *g.M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = bypair_key(g, i), d = g.seg_dst[k] + (i - g.seg_lo[k]);
+        reinterpret_cast<float2*>(g.out_l)[d] = reinterpret_cast<const float2*>(g.ml)[i];
+        reinterpret_cast<float2*>(g.out_r)[d] = reinterpret_cast<const float2*>(g.mr)[i];
+    }
+}
+}  // namespace pats
+
+extern "C" size_t pats_matches_by_pair_workspace_bytes(int Cmax, int64_t pairs) {
+    return Cmax > 0 && pairs > 0 ? (size_t)3 * Cmax * pairs * sizeof(int64_t) : 0;
+}
+
+extern "C" int pats_matches_by_pair_f32(const float* matches_l, const float* matches_r, const int32_t* match_row, const int64_t* M_dev,
+                                        const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
+                                        float* out_l, float* out_r, int64_t* pair_off, void* workspace, size_t workspace_bytes,
+                                        pats_stream_t stream) {
+    PATS_REQUIRE(Cmax >= 1 && pairs >= 1 && N >= 1, "matches_by_pair: bad shape");
+    PATS_REQUIRE(matches_l && matches_r && match_row && M_dev && row_cell && chunk_base && out_l && out_r && pair_off,
+                 "matches_by_pair: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_matches_by_pair_workspace_bytes(Cmax, pairs), "matches_by_pair: workspace too small");
+    hipStream_t st = as_stream(stream);
+    int64_t* ws = reinterpret_cast<int64_t*>(workspace);
+    const int64_t nseg = (int64_t)Cmax * pairs;
+    if (fill_bytes(ws, 0, sizeof(int64_t) * (size_t)(2 * nseg), st)) return PATS_ERR_LAUNCH;        // runs without matches: lo = hi = 0
+    ByPairArgs g{matches_l, matches_r, match_row, M_dev, row_cell, chunk_base, Cmax, pairs, N, out_l, out_r, pair_off, ws, ws + nseg,
+                 ws + 2 * nseg};
+    hipLaunchKernelGGL(bypair_runs_kernel, dim3(2048), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(bypair_offsets_kernel, dim3(1), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(bypair_copy_kernel, dim3(2048), dim3(256), 0, st, g);
+    return check_launch("matches_by_pair kernels");
+}
+
 extern "C" size_t pats_compact_workspace_bytes(int64_t n) { return n < 0 ? 0 : scan_bytes(n) + 64; }
 
 extern "C" int pats_third_inputs_f32(const uint8_t* if_nomatching, const float* pts, int64_t B, float* mkpts0,

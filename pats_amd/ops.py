@@ -936,6 +936,22 @@ def get_result_chunks(rows, if_nomatching16, pts_new, pts16, scales, patch_size=
     return ml, mr, mrow, cnt
 
 
+def matches_by_pair(rows, matches_l, matches_r, match_row, M, out=None):
+    """The matches of a batch (get_result_chunks) grouped by pair ON THE DEVICE: (matches_l, matches_r) with every pair's
+    list contiguous in the reference's order, and pair_off [pairs + 1] int64 (pair p = rows pair_off[p] .. pair_off[p + 1]).
+    What batch.split_by_pair reads back is then only pair_off.  out: optional (out_l, out_r, pair_off) to write into."""
+    dev = matches_l.device
+    if out is None:
+        out = (torch.empty_like(matches_l), torch.empty_like(matches_r), torch.empty((rows.pairs + 1,), dtype=torch.int64, device=dev))
+    ol, orr, off = out
+    nws = _L().pats_matches_by_pair_workspace_bytes(rows.Cmax, rows.pairs)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_matches_by_pair_f32(_ptr(matches_l), _ptr(matches_r), _ptr(match_row), _ptr(M), _ptr(rows.row_cell),
+                                         _ptr(rows.chunk_base), rows.Cmax, rows.pairs, rows.h * rows.w, _ptr(ol), _ptr(orr), _ptr(off),
+                                         _ptr(ws), nws, _stream()), "matches_by_pair")
+    return ol, orr, off
+
+
 def masked_stream(cus):
     """A torch stream (torch.cuda.ExternalStream over a HIP stream of this library) whose kernels may only run on the
     compute units listed in `cus` (indices 0..255 on MI355X) - see pats_stream_create_cu_mask.  The stream lives as long as

@@ -295,3 +295,28 @@ def test_counted_fine_level_launches_skip_the_padding_rows(layout):
                         return_flags=True, count=torch.tensor([10 ** 6], dtype=torch.int64, device="cuda"))
     torch.cuda.synchronize()
     assert torch.equal(Zb, Zr)
+
+
+def test_matches_grouped_by_pair_on_the_device_equal_the_stable_argsort():
+    """pats_matches_by_pair_f32 (run boundaries, offsets, copy - no host read) against the round-3 hand-over: stable argsort of
+    the matches' pair index + bincount, on a batch of three different pairs with a pair that matches nothing in one chunk."""
+    from pats_amd import batch, ops
+    h, w = 15, 20
+    nets = [synth.SynthNets(seed=s, h=h, w=w) for s in (synth.SEED + 40, synth.SEED + 1040, synth.SEED + 2040)]
+    imgs = [n.images() for n in nets]
+    lefts = cu(np.concatenate([i[0] for i in imgs]))
+    rights = cu(np.concatenate([i[1] for i in imgs]))
+    cap = batch.Capacities(3, h, w, if_local=True)
+    out = batch.forward_pairs(lefts, rights, _BatchNets(nets), cap, if_outdoor=True, merge_new=True)
+    M = int(out["M"].item())
+    rows = out["rows"]
+    pair = torch.div(rows.row_cell[out["match_row"][:M].long()], cap.N, rounding_mode="floor")
+    order = torch.argsort(pair, stable=True)
+    want_l, want_r = out["matches_l"][:M][order], out["matches_r"][:M][order]
+    counts = torch.bincount(pair, minlength=cap.pairs)
+    ml, mr, off = batch.group_by_pair(out, cap)
+    torch.cuda.synchronize()
+    assert off.cpu().tolist() == [0] + torch.cumsum(counts, 0).cpu().tolist()
+    assert M > 0 and torch.equal(ml[:M], want_l) and torch.equal(mr[:M], want_r)
+    per_pair = batch.split_by_pair(out, cap)
+    assert [int(a.shape[0]) for a, _ in per_pair] == counts.cpu().tolist()

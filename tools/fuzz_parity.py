@@ -4,7 +4,7 @@
 Draws random shapes / seeds for every op of the path and compares the C-ABI result with
 oracle/pats_oracle.c under the gates of tests/test_gpu_parity.py.  Prints one line per failing case
 (op, seed, shape) and a summary; exit code 1 if anything failed.
-usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops scale,conv,attention,sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
+usage: fuzz_parity.py [--seconds 120] [--seed 0] [--ops gnn,scale,conv,attention,sinkhorn,ot,ot2,cost,expand,resize,merge,result,third]
 """
 import argparse
 import os
@@ -87,15 +87,23 @@ def op_ot2(rng):
     m, n = rand_shape(rng)
     m, n = max(m, 3), max(n, 3)
     b = int(rng.integers(1, 6))
-    S = (rng.standard_normal((b, m, n)) * rng.choice([0.5, 3.0])).astype(np.float32)
+    # now and then a WILD problem (round 4): score ranges of tens to hundreds of nats send the scalings out of the guard band
+    # and the problem through its re-solve (145 x 145: stabilised linear sweeps with absorption; else log-sum-exp sweeps)
+    wild = rng.random() < 0.25
+    amp = float(rng.choice([15.0, 40.0, 90.0])) if wild else float(rng.choice([0.5, 3.0]))
+    S = (rng.standard_normal((b, m, n)) * amp).astype(np.float32)
     ns = np.exp(rng.uniform(-2.7, 2.7, (b, 1, n - 1))).astype(np.float32)
     k = float(rng.choice([0.0, 2.0, 3.0]))
     got = ops.log_optimal_transport2(cu(S), 1.0, cu(ns), 100, bias_k=k).cpu().numpy()
     want = oracle.log_optimal_transport2(S, 1.0, ns, 100)
     if k:
         want = oracle.dustbin_bias(want, k)
-    mass_close(got, want)
-    return "b=%d %dx%d bias=%g" % (b, m, n, k)
+    if wild:          # the gate of tests/test_gpu_parity.py::test_wide_dynamic_range...: log-plan entries to fp32 resolution of |Z|
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, want, atol=2e-5 * max(50.0, 5.0 * amp), rtol=2e-5)
+    else:
+        mass_close(got, want)
+    return "b=%d %dx%d bias=%g amp=%g" % (b, m, n, k, amp)
 
 
 def op_cost(rng):
@@ -322,7 +330,38 @@ def op_scale(rng):
     return "b=%d C=%d %dx%d ld=%d heads=%d amp=%g" % (b, C, h, w, ld, heads, amp)
 
 
-OPS = {"scale": op_scale, "conv": op_conv, "attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
+def op_gnn(rng):
+    """AttentionalPropagation (modules.py:107-117): the fused kernel at the third level's shape (C = 128, 65 tokens: eval /
+    batch-statistics BatchNorm, with / without the residual, weight and activation magnitudes over three decades, now and then
+    an activation beyond the fp16 range -> the gated composition) and the composition at other shapes."""
+    from pats_amd import synth
+    fused = rng.integers(0, 4) != 0
+    if fused:
+        C, n, m, b = 128, 65, 65, int(rng.integers(1, 24))
+    else:
+        C = int(rng.choice([8, 32, 64, 128, 264]))
+        n, m, b = int(rng.integers(1, 150)), int(rng.integers(1, 150)), int(rng.integers(1, 5))
+    params = synth.gnn_params(seed=int(rng.integers(0, 1 << 30)), C=C)
+    wamp = float(rng.choice([0.1, 1.0, 3.0]))
+    for k in list(params):
+        if k.endswith("weight") and params[k].ndim == 3:
+            params[k] = (params[k] * wamp).astype(np.float32)
+    amp = float(rng.choice([0.1, 1.0, 5.0]))
+    x = (amp * rng.standard_normal((b, C, n))).astype(np.float32)
+    src = (amp * rng.standard_normal((b, C, m))).astype(np.float32)
+    spike = fused and rng.integers(0, 12) == 0
+    if spike:
+        x[int(rng.integers(0, b)), int(rng.integers(0, C)), int(rng.integers(0, n))] = 2500.0
+    train = bool(rng.integers(0, 2)) and b * n >= 8
+    res = bool(rng.integers(0, 2))
+    y = ops.attentional_propagation(cu(x), cu(src), ops.PropagationParams(params), bn_train=train, residual=cu(x) if res else None).cpu().numpy()
+    want = oracle.attentional_propagation(x, src, params, bn_train=train, residual=x if res else None)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(y, want, atol=(3e-5 if not spike else 2e-3) * scale, rtol=3e-4)
+    return "C=%d b=%d n=%d m=%d train=%d res=%d wamp=%g amp=%g spike=%d" % (C, b, n, m, train, res, wamp, amp, spike)
+
+
+OPS = {"gnn": op_gnn, "scale": op_scale, "conv": op_conv, "attention": op_attention, "sinkhorn": op_sinkhorn, "ot": op_ot, "ot2": op_ot2, "cost": op_cost, "expand": op_expand,
        "resize": op_resize, "merge": op_merge, "result": op_result, "third": op_third}
 
 
