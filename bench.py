@@ -730,15 +730,16 @@ def gather_layout_ab(ops, dev, cap, P_step, rows=2048):
 
 def step_determinism(batch, nets, cap, wl, n=4):
     """The bench's steps all run on the same resident inputs: n more of them, every stage's output compared bit for bit with
-    the first one's (the fine-level log-plans, the third-level points, the matches).  Before the round-3 barrier fix
-    (pats_amd/asm_pass.py) the fine level differed in ~10 of 20 224 problems in every step."""
+    the first one's (the fine-level log-plans of the rows in use, the third-level points, the matches).  Before the round-3
+    barrier fix (now wg_barrier() in csrc/common.hpp) the fine level differed in ~10 of 20 224 problems in every step."""
     kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
     ref, rep = None, {"steps": n, "fine_log_plan_problems_differing": [], "third_level_points_differing": [],
                       "matches_differing": [], "match_count_equal": True}
     for k in range(n):
         out = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, **kw)
         M = int(out["M"].item())
-        cur = {"Z2": out["stages"]["Z2"].clone(), "m1f": out["stages"]["m1f"].clone(), "ml": out["matches_l"][:M].clone(),
+        live = int(out["rows"].chunk_base[-1].item())         # rows in use: padding rows past it are skipped by the launches
+        cur = {"Z2": out["stages"]["Z2"][:live].clone(), "m1f": out["stages"]["m1f"].clone(), "ml": out["matches_l"][:M].clone(),
                "mr": out["matches_r"][:M].clone(), "M": M, "P": int(out["P"].item())}
         if ref is None:
             ref = cur
