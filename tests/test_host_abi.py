@@ -106,14 +106,15 @@ def test_split_patches_through_ops_cpu_tensor(lib):
 
 
 def test_production_library_carries_no_diagnostic_kernels(lib):
-    """The sweep-loop variants and the timing ablations of the third-level kernel ("wrong results by design") are
-    compiled under -DPATS_DIAG into libpats_amd_diag.so only; the production library holds the default instantiation and
-    its fp32-MFMA partner and refuses every other PATS_THIRD_VARIANT."""
+    """The sweep-loop variants, the timing ablations ("wrong results by design") and - since round 4 - the fp16-split cost
+    build of the third-level kernel (its first full-size launch in a process is not bit-reproducible) are compiled under
+    -DPATS_DIAG into libpats_amd_diag.so only; the production library holds ONE instantiation (fp32-MFMA cost build) and
+    refuses every other PATS_THIRD_VARIANT."""
     import subprocess
     from pats_amd import _lib
     syms = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     inst = sorted(set(re.findall(r"third_fused3_kernel<[^>]*>", syms)))
-    assert inst == ["third_fused3_kernel<3, 0, 0, 0>", "third_fused3_kernel<3, 0, 5, 1>"], inst
+    assert inst == ["third_fused3_kernel<3, 0, 0, 0>"], inst       # the one instantiation that is reproducible from launch 0
     assert "libpats_amd.so" in _lib.LIB_PATH and "diag" not in os.path.basename(_lib.LIB_PATH)
 
 

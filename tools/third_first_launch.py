@@ -13,7 +13,10 @@ call; the scenario comes from the environment:
                     other (the kernel on COPIES of the inputs) | touch (<s> passes of a.sum() over every input)
   MATMUL_CHECK=1    additionally: is hipBLASLt's own first heavy launch reproducible?  (x @ x) repeated, first result against later
   SMI=1             print sclk / power from sysfs right before and after launch 0
-  P=<n>             problems per launch (default 414720)        PATS_THIRD_VARIANT=300 selects the fp32-MFMA build"""
+  P=<n>             problems per launch (default 414720)
+The kernel under study is the fp16-split instantiation (PATS_THIRD_VARIANT=1350), which since round 4 exists in the diagnostic
+library only: build it with `python -m pats_amd.build --diag` and run with PATS_AMD_DIAG_LIB=1 PATS_THIRD_VARIANT=1350 (the
+round-4 logs were taken while it was still the production default); PATS_THIRD_VARIANT=300 = the production build."""
 import glob
 import os
 import sys

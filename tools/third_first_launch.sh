@@ -3,6 +3,9 @@
 # (round 4 ran it in two halves: profiles/r04_third_first_launch_1.log / _2.log)
 out=gpurun_out/third_first_launch.log
 mkdir -p gpurun_out; : > $out
+# (the fp16-split build lives in the diagnostic library since round 4)
+python -m pats_amd.build --diag > /dev/null 2>&1
+export PATS_AMD_DIAG_LIB=1 PATS_THIRD_VARIANT=1350
 run() { echo "=== $*" >> $out; env "$@" timeout 300 python tools/third_first_launch.py 2>&1 | grep -v amdgpu.ids >> $out; }
 python -c "import torch" 2>/dev/null
 for i in 1 2 3 4; do run SMI=1; done
