@@ -202,3 +202,35 @@ def test_fine_level_solve_8192_problems_six_launches_identical(ops, oracle, mode
         got = outs[0][:n].cpu().numpy().astype(np.float64)
         # the mass gate of tests/test_gpu_parity.py: 1e-4 absolute, 5e-6 relative where masses exceed 1 (the dustbin corner, ~137 here)
         np.testing.assert_allclose(np.exp(got), np.exp(want.astype(np.float64)), atol=1e-4, rtol=5e-6)
+
+
+GNN_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(repo)r)
+from pats_amd import ops, synth
+b = 25920
+P = ops.PropagationParams(synth.gnn_params(seed=3, C=128))
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+x = torch.randn((b, 128, 65), device="cuda", generator=g); s = torch.randn((b, 128, 65), device="cuda", generator=g)
+for train in (False, True):
+    runs = [ops.attentional_propagation(x, s, P, bn_train=train, residual=x) for _ in range(4)]      # launch 0 = the process's first
+    torch.cuda.synchronize()
+    print("DIFF", train, [int((r != runs[0]).flatten(1).any(1).sum()) for r in runs[1:]])
+"""
+
+
+def test_fused_gnn_layer_25920_problems_identical_from_the_first_launch_of_a_process():
+    """The fused AttentionalPropagation kernel (csrc/gnn_fused.hip: fp16-split MFMA contractions beside VALU re-splits and an
+    in-register softmax, two waves per SIMD) at the 25 920 problems of one pair, eval and batch-statistics BatchNorm, in a FRESH
+    process with no pre-heat: four launches on the same inputs are bit-identical, the first included - the property the
+    fp16-split third-level build did not have (profiles/r04_third_first_launch.md)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", GNN_CHILD % {"repo": repo}], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIFF")]
+    assert len(lines) == 2
+    for ln in lines:
+        assert ln.endswith("[0, 0, 0]"), ln

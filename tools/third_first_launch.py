@@ -10,7 +10,8 @@ call; the scenario comes from the environment:
   IDLE=<s>          after launch 2: sleep <s> seconds, launch again, twice (does a long idle re-create the effect?)
   PREHEAT=<kind>:<s>  before launch 0, <s> seconds of: matmul (8192^3 fp32) | vec (elementwise fp32 fma chain, no matrix pipe) |
                     copy (HBM copies) | same (the third-level kernel itself on the same inputs) | same1 (one such launch) |
-                    other (the kernel on COPIES of the inputs) | touch (<s> passes of a.sum() over every input)
+                    other (the kernel on COPIES of the inputs) | touch (<s> passes of a.sum() over every input) |
+                    outbufs (tensors of the output shapes written and freed <s> times: the allocator hands launch 0 used blocks)
   MATMUL_CHECK=1    additionally: is hipBLASLt's own first heavy launch reproducible?  (x @ x) repeated, first result against later
   SMI=1             print sclk / power from sysfs right before and after launch 0
   P=<n>             problems per launch (default 414720)
@@ -100,6 +101,12 @@ def preheat(kind, seconds, args):
             ops.third_level(*cp, outdoor=True)
             torch.cuda.synchronize()
         del cp
+    elif kind == "outbufs":        # tensors of exactly the OUTPUT shapes written and freed: launch 0's outputs land in used blocks
+        for _ in range(max(1, int(seconds))):
+            o = [torch.zeros((P, 16, 2), device="cuda"), torch.zeros((P, 16, 2), device="cuda"), torch.zeros((P * 16, 2), device="cuda"),
+                 torch.zeros((P, 16), dtype=torch.uint8, device="cuda")]
+            torch.cuda.synchronize()
+            del o
     elif kind == "touch":          # every byte of the inputs read once by another kernel (address translations, no compute)
         for _ in range(max(1, int(seconds))):
             for a in args:

@@ -29,3 +29,5 @@ for i in 1 2; do run IDLE=100; done
 for i in 1 2 3 4 5 6; do run PATS_THIRD_VARIANT=300; done
 grep RESULT $out
 tail -5 $out
+# third matrix: does it matter whether launch 0's OUTPUTS land in memory this process has written before?  (no: 2 of 6)
+for i in 1 2 3 4 5 6; do run PREHEAT=outbufs:1; done
