@@ -60,7 +60,7 @@ struct OpMax {
 // mis-folds the pair when it can see through it - op(r[0], r[1]) came out as op(r[0], r[0]) (a wave sum returned 4 x the row
 // total on hardware) - so the second operand and both results pass through empty asm to stay opaque.
 // -DPATS_NO_PERMLANE_SWAP: the same exchanges on the LDS crossbar (ds_bpermute_b32 / ds_swizzle_b32; every lane hands its
-// partner the one value the partner wants) - the A/B partner used while hunting the round-3 barrier bug (asm_pass.py).
+// partner the one value the partner wants) - the A/B partner used while hunting the round-3 barrier bug (profiles/r03_determinism.md).
 #ifndef PATS_NO_PERMLANE_SWAP
 __device__ __forceinline__ void lane_swap32(unsigned& a, unsigned& b) {
     asm volatile("" : "+v"(b));

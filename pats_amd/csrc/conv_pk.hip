@@ -1,0 +1,315 @@
+// Conv1d(kernel_size = 1) of the GNN layers with PACKED weights (round 4): y[b] = W . x[b] (+ bias, + residual) over the flattened
+// (batch, token) axis, W handed over pre-split (fp16 hi + lo of 2^6 w) in MFMA fragment order (pats_propagation_pack_f32, once per
+// layer).
+//
+// Why beside conv_lean_kernel (gnn.hip): at the fine level's shape (264 / 528 channels, 145 tokens) that kernel spends two thirds of
+// its loads re-fetching the fp32 weights for every 64-column tile, splits them again each time and keeps one 16-channel chunk of
+// operands in flight per workgroup (matrix pipe ~10 % busy, a third of the HBM rate).  Here
+//   * a 512-thread workgroup owns 64 columns x up to 272 output rows (wave w: row tiles w, w + 8 of 16 rows each, all four
+//     16-column tiles; a 17th row tile - 264 rows are 16 tiles and a half - has its four column tiles on waves 0..3);
+//   * the activations of its 64 columns are staged WHOLE, up to 288 channels at a time (one "pass": 72 KB of LDS, split into fp16
+//     hi + lo in MFMA fragment order on the way, the BatchNorm affine + ReLU of the producing layer applied there, (x | message)
+//     read from two tensors without a cat): every load of a pass is in flight at once, and the k loop behind it has no barrier;
+//   * the weights are the A operand straight from L2 into registers - one 16-byte load per lane and fragment, a ring of two
+//     32-channel k-steps, no LDS staging, no VALU split (the fused layer's scheme, csrc/gnn_fused.hip);
+//   * two workgroups share a CU (128 registers, 2 x 72 KB): one loads or stores while the other multiplies;
+//   * the result leaves through LDS: rows of 64 consecutive columns per wave store instead of the MFMA layout's 16;
+//   * v_mfma_f32_16x16x32_f16, three exact-product passes, fp32 accumulation - the contraction of the cost build.
+// Range: |activation| < 1023; a non-finite output raises *redo and conv1x1_kernel (fp32 redo inside), queued behind by launch_conv,
+// recomputes the product - the protocol of conv_lean_kernel.
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace pats {
+
+namespace {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) h8v* gptr_h8;
+
+constexpr float PRE = 64.0f, UNS = 1.0f / 4096.0f;
+constexpr int FR = 2 * 64;                 // h8v per fragment (hi | lo)
+constexpr int PK_NT = 4, PK_NC = 16 * PK_NT;      // 16-column tiles per workgroup: 64 columns
+constexpr int PK_KS_BYTES = 2 * PK_NT * 1024;     // one k-step of activations in LDS: (hi | lo) x 4 tiles x 64 lanes x 16 B
+constexpr int PK_KP = 288, PK_KSPP = PK_KP / 32;  // channels / k-steps of a pass at most
+constexpr int PK_OSTRIDE = PK_NC + 4;             // floats per output row in the epilogue's LDS tile (4 rows apart = 16 banks apart)
+constexpr int PK_ROWS = 17 * 16;
+constexpr int PK_LDS = PK_ROWS * PK_OSTRIDE * 4;  // 73 984 B >= PK_KSPP * PK_KS_BYTES = 73 728
+static_assert(PK_LDS >= PK_KSPP * PK_KS_BYTES, "the output tile overlays the activation stage");
+
+struct PkGeom { int npass, Kp, kspp; };
+// K channels in passes of at most 288, every pass a whole number of 8-channel groups and of (zero-padded) 32-channel k-steps
+inline PkGeom pk_geom(int K) {
+    PkGeom q;
+    q.npass = (K + PK_KP - 1) / PK_KP;
+    q.Kp = (((K + q.npass - 1) / q.npass) + 7) & ~7;
+    q.kspp = (q.Kp + 31) / 32;
+    return q;
+}
+
+struct PkArgs {
+    const h8v* pw;             // [row tiles][passes][k-steps of a pass][hi | lo][64]
+    const float* x0;           // [batch, K0, n]
+    const float* x1;           // [batch, K1, n] or null
+    int K0, K1, M, n, npass, Kp, kspp, mtiles, tpg, groups;   // tpg: row tiles per row group
+    int64_t cols;              // batch * n
+    const float* in_scale;     // [K0 + K1] or null: x <- max(0, x * scale + shift) while staging
+    const float* in_shift;
+    const float* bias;
+    const float* residual;
+    float* y;
+    int* redo;
+    const int* gate;
+};
+
+__device__ __forceinline__ gptr_h8 uniform_ptr(const h8v* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gptr_h8)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void split4(const f4v v, h4v& hi, h4v& lo) {
+    const f4v s = v * PRE;
+    hi = __builtin_convertvector(s, h4v);
+    lo = __builtin_convertvector(s - __builtin_convertvector(hi, f4v), h4v);
+}
+
+}  // namespace
+
+// weights [K][M] (transposed, as the C-ABI takes them) -> fragments; rows >= M and channels past a pass / past K are zero
+__global__ void __launch_bounds__(256)
+conv_pack_kernel(const float* __restrict__ wt, int K, int M, int npass, int Kp, int kspp, int mtiles, h8v* __restrict__ pw) {
+    const int gid = blockIdx.x * 256 + threadIdx.x, lane = gid & 63, f = gid >> 6;
+    if (f >= mtiles * npass * kspp) return;
+    const int mt = f / (npass * kspp), r = f - mt * (npass * kspp), ps = r / kspp, ks = r - ps * kspp;
+    const int row = mt * 16 + (lane & 15);
+    h8v hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kin = ks * 32 + 8 * (lane >> 4) + e, k = ps * Kp + kin;
+        const float s = (row < M && kin < Kp && k < K) ? wt[(int64_t)k * M + row] * PRE : 0.f;
+        const _Float16 h = (_Float16)s;
+        hi[e] = h;
+        lo[e] = (_Float16)(s - (float)h);
+    }
+    pw[f * FR + lane] = hi;
+    pw[f * FR + 64 + lane] = lo;
+}
+
+// MT: rounds of eight row tiles (wave w: local tiles w, w + 8); SH: one more row tile (local index 8 MT) whose four column tiles
+// go to waves 0..3 - a third round for wave 0 alone would idle the other seven
+template <int MT, bool SH>
+__global__ void __launch_bounds__(512, 4)
+conv_pk_kernel(PkArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (g.gate && *g.gate == 0) return;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int qp = lane >> 4, j = lane & 15;
+    // row groups of one column tile are neighbours in the launch order (they read the same activations)
+    const int grp = blockIdx.x % g.groups;
+    const int64_t j0 = (int64_t)(blockIdx.x / g.groups) * PK_NC;
+    const int mt0 = grp * g.tpg, mt_end = min(g.mtiles, mt0 + g.tpg);
+    const int n = g.n, KSPP = g.kspp, Kt = g.K0 + g.K1;
+    int mts[MT];
+    bool has[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { mts[m] = mt0 + wave + 8 * m; has[m] = mts[m] < mt_end; mts[m] = min(mts[m], mt_end - 1); }
+    // (a row tile this wave does not have is computed on a clamped index and not stored: no branch inside the k loop)
+    const int mt_sh = min(mt0 + 8 * MT, mt_end - 1), nt_sh = min(wave, PK_NT - 1);
+    const bool has_sh = SH && mt0 + 8 * MT < mt_end && wave < PK_NT;
+
+    // this lane's column while staging and storing: flattened (problem, token); one past the end repeats the last and is not stored
+    const int64_t cglob = min(j0 + lane, g.cols - 1);
+    const unsigned cb = (unsigned)(cglob / n), ctk = (unsigned)(cglob - (int64_t)cb * n);
+    const float* base0 = g.x0 + (int64_t)cb * g.K0 * n + ctk;
+    const float* base1 = g.K1 > 0 ? g.x1 + (int64_t)cb * g.K1 * n + ctk : base0;
+    const int soff = (lane >> 4) * 1024 + (lane & 15) * 16;    // + k-step * 8192 + (group & 3) * 256 (+ 4096 for the lo plane)
+
+    f4v acc[MT][PK_NT], accs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < PK_NT; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
+
+    for (int ps = 0; ps < g.npass; ++ps) {
+        // ---- stage the pass: wave w takes the 8-channel groups w, w + 8, .. (a group = one 256-byte row of 64 columns per channel) --
+        if (ps > 0) wg_barrier();                               // the previous pass has been read
+        const int cbase = ps * g.Kp, cend = min(Kt, cbase + g.Kp), ngroups = KSPP * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            constexpr int R0[2] = {0, 3}, R1[2] = {3, 5};
+            f4v ra[3], rb[3];
+#pragma unroll
+            for (int i = R0[half]; i < R1[half]; ++i) {
+                const int cg = wave + 8 * i, ch = cbase + cg * 8;       // wave-uniform
+                ra[i - R0[half]] = rb[i - R0[half]] = f4v{0.f, 0.f, 0.f, 0.f};
+                if (cg < ngroups && ch < cend) {
+                    const float* p = ch >= g.K0 ? base1 + (int64_t)(ch - g.K0) * n : base0 + (int64_t)ch * n;
+                    ra[i - R0[half]] = f4v{p[0], p[n], p[2 * n], p[3 * n]};
+                    rb[i - R0[half]] = f4v{p[4 * n], p[5 * n], p[6 * n], p[7 * n]};
+                }
+            }
+#pragma unroll
+            for (int i = R0[half]; i < R1[half]; ++i) {
+                const int cg = wave + 8 * i, ch = cbase + cg * 8;
+                if (cg < ngroups) {
+                    f4v a = ra[i - R0[half]], b = rb[i - R0[half]];
+                    if (g.in_scale && ch < cend) {
+                        const float* sc = g.in_scale + ch;
+                        const float* sh = g.in_shift + ch;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = fmaxf(fmaf(a[e], sc[e], sh[e]), 0.f);
+                            b[e] = fmaxf(fmaf(b[e], sc[4 + e], sh[4 + e]), 0.f);
+                        }
+                    }
+                    h4v ah, al, bh, bl;
+                    split4(a, ah, al);
+                    split4(b, bh, bl);
+                    char* d = lds + (cg >> 2) * PK_KS_BYTES + (cg & 3) * 256 + soff;
+                    *reinterpret_cast<h8v*>(d) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
+                    *reinterpret_cast<h8v*>(d + PK_NT * 1024) = h8v{al.x, al.y, al.z, al.w, bl.x, bl.y, bl.z, bl.w};
+                }
+            }
+        }
+        wg_barrier();
+
+        // ---- the k loop of the pass: no barrier; weight fragments in a ring of two k-steps, straight from L2 ------------------------
+        h8v wa[2][MT][2], was[2][2];
+#define PK_WLOAD(ks_, slot_)                                                                                     \
+    {                                                                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                         \
+            gptr_h8 Wf = uniform_ptr(g.pw + (((int64_t)mts[m] * g.npass + ps) * KSPP + (ks_)) * FR);             \
+            wa[slot_][m][0] = Wf[lane];                                                                          \
+            wa[slot_][m][1] = Wf[64 + lane];                                                                     \
+        }                                                                                                        \
+        if (SH) {                                                                                                \
+            gptr_h8 Wf = uniform_ptr(g.pw + (((int64_t)mt_sh * g.npass + ps) * KSPP + (ks_)) * FR);              \
+            was[slot_][0] = Wf[lane];                                                                            \
+            was[slot_][1] = Wf[64 + lane];                                                                       \
+        }                                                                                                        \
+    }
+        PK_WLOAD(0, 0);
+        if (KSPP > 1) PK_WLOAD(1, 1);
+        for (int ks0 = 0; ks0 < KSPP; ks0 += 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ks = ks0 + s;
+                if (ks >= KSPP) break;
+                const char* blk = lds + ks * PK_KS_BYTES;
+#pragma unroll
+                for (int nt = 0; nt < PK_NT; ++nt) {
+                    const h8v bh = *reinterpret_cast<const h8v*>(blk + nt * 1024 + lane * 16);
+                    const h8v bl = *reinterpret_cast<const h8v*>(blk + PK_NT * 1024 + nt * 1024 + lane * 16);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        f4v c = acc[m][nt];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][m][1], bh, c, 0, 0, 0);       // small terms first
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][m][0], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][m][0], bh, c, 0, 0, 0);
+                        acc[m][nt] = c;
+                    }
+                }
+                if (SH) {                                       // the shared row tile: this wave's one column tile of it
+                    const h8v bh = *reinterpret_cast<const h8v*>(blk + nt_sh * 1024 + lane * 16);
+                    const h8v bl = *reinterpret_cast<const h8v*>(blk + PK_NT * 1024 + nt_sh * 1024 + lane * 16);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(was[s][1], bh, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(was[s][0], bl, accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(was[s][0], bh, accs, 0, 0, 0);
+                }
+                if (ks + 2 < KSPP) PK_WLOAD(ks + 2, s);         // the ring slot just used
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef PK_WLOAD
+    }
+
+    // ---- epilogue: the tile through LDS (row-major, 64 columns + 4 of padding), then whole rows per wave ----------------------------
+    wg_barrier();
+    float* ot = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (!has[m]) continue;
+        const int rl = 16 * (wave + 8 * m) + 4 * qp;
+#pragma unroll
+        for (int nt = 0; nt < PK_NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[(rl + r) * PK_OSTRIDE + 16 * nt + j] = acc[m][nt][r] * UNS;
+    }
+    if (SH && has_sh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[(16 * 8 * MT + 4 * qp + r) * PK_OSTRIDE + 16 * wave + j] = accs[r] * UNS;
+    }
+    wg_barrier();
+    const int rows = min(16 * (mt_end - mt0), g.M - 16 * mt0);
+    const bool colok = j0 + lane < g.cols;
+    bool bad = false;
+    for (int rl = wave; rl < rows; rl += 8) {
+        const int row = 16 * mt0 + rl;
+        float v = ot[rl * PK_OSTRIDE + lane];
+        bad |= colok && !(fabsf(v) <= 3.0e38f);
+        if (g.bias) v += g.bias[row];
+        const int64_t o = ((int64_t)cb * g.M + row) * n + ctk;
+        if (colok) {
+            if (g.residual) v = g.residual[o] + v;
+            g.y[o] = v;
+        }
+    }
+    if (__any(bad) && lane == 0 && g.redo) atomicOr(g.redo, 1);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+size_t conv_packed_bytes(int K, int M) {
+    const PkGeom q = pk_geom(K);
+    return (size_t)((M + 15) / 16) * q.npass * q.kspp * FR * sizeof(h8v);
+}
+
+int launch_conv_pack(const float* wt, int K, int M, void* packed, hipStream_t st) {
+    const PkGeom q = pk_geom(K);
+    const int mtiles = (M + 15) / 16;
+    const int threads = mtiles * q.npass * q.kspp * 64;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, wt, K, M, q.npass, q.Kp, q.kspp, mtiles,
+                       (h8v*)packed);
+    return check_launch("conv_pack_kernel");
+}
+
+// 1 if this device grants the kernel its 72 KB of dynamic LDS (asked once per device)
+static bool conv_pk_ready() {
+    static int state[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+    if (state[dev] == 0) {
+        const bool ok = hipFuncSetAttribute((const void*)conv_pk_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)conv_pk_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)conv_pk_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_LDS) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1;
+}
+
+// y = W . (x0 | x1) with packed W; K0, K1 multiples of 8.  redo: as conv_lean_kernel (the caller queues conv1x1_kernel behind).
+// PATS_ERR_UNSUPPORTED: the device refused the LDS - the caller takes the unpacked kernels.
+int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0, int K1, int M, int n, int64_t cols,
+                   const float* in_scale, const float* in_shift, const float* bias, const float* residual, float* y, int* redo,
+                   const int* gate, hipStream_t st) {
+    if (!conv_pk_ready()) return PATS_ERR_UNSUPPORTED;
+    const PkGeom q = pk_geom(K0 + K1);
+    const int mtiles = (M + 15) / 16;
+    // row groups of at most 17 tiles, evenly: 264 rows -> one group of 16 + the shared 17th; 528 -> 17 + 16; 128 -> 8
+    const int groups = (mtiles + 16) / 17, tpg = (mtiles + groups - 1) / groups;
+    PkArgs g{(const h8v*)packed, x0, x1, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, in_scale, in_shift, bias, residual, y, redo, gate};
+    const int64_t wgs = ((cols + PK_NC - 1) / PK_NC) * groups;
+    PATS_REQUIRE(wgs < (1ll << 31), "conv_pk: grid too large (split the batch)");
+    const dim3 grid((unsigned)wgs), block(512);
+    // (10..16 tiles take the 17-tile instantiation too: without the shared tile the same loop spills 29 registers at the 128 cap)
+    if (tpg <= 8) hipLaunchKernelGGL((conv_pk_kernel<1, false>), grid, block, PK_LDS, st, g);
+    else if (tpg == 9) hipLaunchKernelGGL((conv_pk_kernel<1, true>), grid, block, PK_LDS, st, g);
+    else hipLaunchKernelGGL((conv_pk_kernel<2, true>), grid, block, PK_LDS, st, g);
+    return check_launch("conv_pk_kernel");
+}
+
+}  // namespace pats

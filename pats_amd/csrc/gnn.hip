@@ -499,7 +499,14 @@ bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const fl
 }
 
 // `redo`: one int of workspace, zero on entry (conv_lean_kernel raises it; see there).  null -> conv1x1_kernel only.
-static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr) {
+int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0, int K1, int M, int n, int64_t cols,
+                   const float* in_scale, const float* in_shift, const float* bias, const float* residual, float* y, int* redo,
+                   const int* gate, hipStream_t st);                                                        // conv_pk.hip
+size_t conv_packed_bytes(int K, int M);
+size_t packed_fused_bytes(int C, int heads);                                                                // gnn_fused.hip
+
+// pk: this matrix packed for conv_pk_kernel (pats_propagation_pack_f32) or null
+static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr, const void* pk = nullptr) {
     ConvArgs g = g0;
     g.gate = gate;
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
@@ -531,6 +538,20 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int*
         pd.state = ok ? 1 : -1;
     }
     const bool ws_lds_ok = pd.state == 1;
+    static const bool no_pk = [] { const char* e = getenv("PATS_CONV_PK"); return e && atoi(e) == 0; }();         // A/B switch
+    if (pk && lean && !no_pk) {
+        int rc = launch_conv_pk(pk, g.x0, g.x1, g.K0, g.K1, g.M, g.n, g.cols, g.in_scale, g.in_shift, g.bias, g.residual, g.y, redo, gate, st);
+        if (rc == PATS_ERR_UNSUPPORTED) return launch_conv(g0, redo, st, gate, nullptr);
+        if (rc) return rc;
+        g.redo = redo;
+        const bool r128 = g.M <= 128 || g.M % 128 == 0;
+        g.tile_rows = r128 ? 128 : mt::CT;
+        const int64_t tl = (int64_t)((g.M + g.tile_rows - 1) / g.tile_rows) * ((g.cols + mt::CT - 1) / mt::CT);
+        PATS_REQUIRE(tl < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
+        if (r128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), dim3((unsigned)tl), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((conv1x1_kernel<true, true>), dim3((unsigned)tl), dim3(256), 0, st, g);
+        return check_launch("conv1x1_kernel");
+    }
     const bool ws = lean && ws_mode != 0 && ws_lds_ok && ((Kt == 128 && !two) || (Kt == 256 && (!two || g.K0 == 128))) &&
                     g.cols * (int64_t)std::max(g.K0, 1) < (1ll << 31) && (g.cols >= 64 * 4096 || ws_mode == 2);
     if (ws) {
@@ -668,16 +689,26 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
             return rc;
         }
     }
+    // the six matrices packed for conv_pk_kernel (behind the fused layer's section); the gated fallback composition keeps
+    // the unpacked kernels
+    const char* pk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (packed && !gate) {
+        const char* q0 = (const char*)packed + packed_fused_bytes(C, heads);
+        const size_t cc = conv_packed_bytes(C, C);
+        for (int i = 0; i < 4; ++i) pk[i] = q0 + i * cc;
+        pk[4] = q0 + 4 * cc;
+        pk[5] = pk[4] + conv_packed_bytes(2 * C, 2 * C);
+    }
     // projections (modules.py:101-102)
-    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, redo + 0, st, gate))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st, gate))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, redo + 0, st, gate, pk[0]))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st, gate, pk[1]))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st, gate, pk[2]))) return rc;
     // attention core (:103): the [b, C, n] projections ARE the [b, dim, heads, n] views
     if ((rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, gate))) return rc;
     // merge (:104)
-    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st, gate, pk[3]))) return rc;
     // mlp[0] on cat([x, message]) without the cat (:116, MLP :64)
-    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, redo + 4, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, redo + 4, st, gate, pk[4]))) return rc;
     // mlp[1] BatchNorm1d: eval -> the caller's folded running statistics (bn_a = scale, bn_b = shift);
     //                      train -> batch statistics with bn_a = gamma, bn_b = beta
     const float *sc = w->bn_a, *sh = w->bn_b;
@@ -689,7 +720,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         sc = bsc; sh = bsh;
     }
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
-    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st, gate);
+    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st, gate, pk[5]);
 }
 
 // ---- the building blocks on their own: Conv1d(kernel_size = 1) and the BatchNorm1d + ReLU that follows it in MLP ------

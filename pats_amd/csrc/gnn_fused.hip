@@ -607,22 +607,45 @@ int fused_layer_supported(int C, int heads, int n, int m) {
 
 using namespace pats;
 
+// The packed buffer: [ the fused layer's section (only C = 128, 4 heads) | the six matrices for conv_pk_kernel, any C ]
+namespace pats {
+size_t packed_fused_bytes(int C, int heads) {
+    return (C == GC && heads == 4) ? (((size_t)PW_END * sizeof(h8v) + (size_t)PB_END * sizeof(float) + 255) & ~(size_t)255) : 0;
+}
+size_t conv_packed_bytes(int K, int M);                                                                     // conv_pk.hip
+int launch_conv_pack(const float* wt, int K, int M, void* packed, hipStream_t st);
+}
+
 extern "C" size_t pats_propagation_packed_bytes(int C, int heads) {
-    return (C == GC && heads == 4) ? (size_t)PW_END * sizeof(h8v) + (size_t)PB_END * sizeof(float) : 0;
+    if (C <= 0 || heads <= 0 || (C % 8) != 0 || (C % heads) != 0) return 0;
+    return packed_fused_bytes(C, heads) + 4 * conv_packed_bytes(C, C) + conv_packed_bytes(2 * C, 2 * C) + conv_packed_bytes(2 * C, C);
 }
 
 extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
                                          pats_stream_t stream) {
-    PATS_REQUIRE(C == GC && heads == 4, "propagation_pack: the fused layer exists for C = 128, 4 heads (the third level)");
+    PATS_REQUIRE(C > 0 && heads > 0 && (C % 8) == 0 && (C % heads) == 0, "propagation_pack: bad shape");
     PATS_REQUIRE(w && packed && packed_bytes >= pats_propagation_packed_bytes(C, heads), "propagation_pack: null pointer / buffer too small");
     PATS_REQUIRE(w->wq_t && w->bq && w->wk_t && w->bk && w->wv_t && w->bv && w->wm_t && w->bm && w->w1_t && w->b1 && w->w2_t && w->b2,
                  "propagation_pack: null weight pointer");
     PATS_REQUIRE(((uintptr_t)packed & 15) == 0, "propagation_pack: the buffer must be 16-byte aligned");
-    h8v* pw = (h8v*)packed;
-    float* pb = (float*)(pw + PW_END);
-    const int threads = (PW_END / FR) * 64;
-    hipLaunchKernelGGL(gnn_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), *w, pw, pb);
-    return check_launch("gnn_pack_kernel");
+    hipStream_t st = as_stream(stream);
+    if (packed_fused_bytes(C, heads)) {
+        h8v* pw = (h8v*)packed;
+        float* pb = (float*)(pw + PW_END);
+        const int threads = (PW_END / FR) * 64;
+        hipLaunchKernelGGL(gnn_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *w, pw, pb);
+        int rc = check_launch("gnn_pack_kernel");
+        if (rc) return rc;
+    }
+    char* p = (char*)packed + packed_fused_bytes(C, heads);
+    const float* mats[6] = {w->wq_t, w->wk_t, w->wv_t, w->wm_t, w->w1_t, w->w2_t};
+    const int Ks[6] = {C, C, C, C, 2 * C, 2 * C}, Ms[6] = {C, C, C, C, 2 * C, C};
+    for (int i = 0; i < 6; ++i) {
+        int rc = launch_conv_pack(mats[i], Ks[i], Ms[i], p, st);
+        if (rc) return rc;
+        p += conv_packed_bytes(Ks[i], Ms[i]);
+    }
+    return PATS_OK;
 }
 
 namespace pats {

@@ -1028,7 +1028,7 @@ class PropagationParams:
 
     def packed(self, heads=4):
         """The Conv1d matrices split into fp16 hi + lo halves in MFMA fragment order (pats_propagation_pack_f32), made once and
-        kept beside the weights; None for a shape without a fused layer."""
+        kept beside the weights; None if the library has no packed form for this shape."""
         key = int(heads)
         if key not in self._packed:
             nb = _L().pats_propagation_packed_bytes(self.C, key)
@@ -1065,7 +1065,7 @@ def attentional_propagation(x, source, params, heads=4, bn_train=False, residual
     nb = _L().pats_attentional_propagation_workspace_bytes(b, C, n, m)
     ws = _workspace(nb, x.device)
     w = params.struct(bn_train)
-    pk = params.packed(heads) if (n == 65 and m == 65) else None      # the third level's shape: one fused kernel (gnn_fused.hip)
+    pk = params.packed(heads)      # the third level's shape: one fused kernel (gnn_fused.hip); any other: packed-weights convolutions
     if pk is not None:
         _check(_L().pats_attentional_propagation_packed_f32(_ptr(x), _ptr(source), b, C, int(heads), n, m, ctypes.byref(w), _ptr(pk),
                                                             int(bool(bn_train)), float(params.eps), _ptr(res), _ptr(out), _ptr(ws),
