@@ -609,6 +609,8 @@ extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, in
 namespace pats {
 int launch_attention(const float* query, const float* key, const float* value, int64_t batch, int dim, int heads, int n, int m,
                      float* out, float* prob, pats_stream_t stream, const int* gate);                     // attention.hip
+int launch_attention145(const float* query, const float* key, const float* value, int64_t batch, int dim, int heads, int n, int m,
+                        float* out, int* flag, const int* gate, hipStream_t st);                          // attention145.hip
 int fused_layer_supported(int C, int heads, int n, int m);                                                // gnn_fused.hip
 int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
                        int bn_train, const float* residual, float* out, float* hid, int* flag, double* bn_part, int* splits_out,
@@ -704,7 +706,11 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st, gate, pk[1]))) return rc;
     if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st, gate, pk[2]))) return rc;
     // attention core (:103): the [b, C, n] projections ARE the [b, dim, heads, n] views
-    if ((rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, gate))) return rc;
+    // at the fine level's shape: the fp16-split kernel with the scores in registers (attention145.hip), the general kernel queued
+    // behind it as its redo (a no-op unless an output came out non-finite)
+    rc = gate ? PATS_ERR_UNSUPPORTED : launch_attention145(q, k, v, batch, C / heads, heads, n, m, att, redo + 6, nullptr, st);
+    if (rc != PATS_OK && rc != PATS_ERR_UNSUPPORTED) return rc;
+    if ((rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, rc == PATS_OK ? redo + 6 : gate))) return rc;
     // merge (:104)
     if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st, gate, pk[3]))) return rc;
     // mlp[0] on cat([x, message]) without the cat (:116, MLP :64)
