@@ -645,7 +645,8 @@ def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
     cost build (first_layer.py:102, second_layer.py:89, third_layer.py:148), random weights, timed at the step's own problem
     counts - one AttentionalPropagation per level (both descriptor sides), scaled by the reference's layer counts (18 / 18 / 10).
     Third level: the fused kernel of csrc/gnn_fused.hip (BatchNorm as PATS.eval() leaves it: running statistics outdoors, batch
-    statistics indoors, pats.py:112-118); fine and coarse level: the seven-launch composition of csrc/gnn.hip."""
+    statistics indoors, pats.py:112-118); fine and coarse level: six packed-weights convolutions (csrc/conv_pk.hip) around the
+    attention core (fine: csrc/attention145.hip, scores in registers; coarse: the general kernel)."""
     gen = torch.Generator(device=dev)
     gen.manual_seed(4242)
 
@@ -674,6 +675,17 @@ def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
                     "operands as fp16 hi + lo, three exact-product passes = 3 x the algorithmic flops against the dense fp16 matrix peak "
                     "(token padding 80 / 65 not counted); hbm_frac = x + source + residual in, out (4 x 33 KB per problem) against 8 TB/s"}
     roof["frac"] = roof["achieved"] / F16_PEAK_TFLOPS
+    flops2 = 2.0 * 145 * (4 * 264 * 264 + 528 * 528 + 528 * 264) + 4 * 2 * (2.0 * 145 * 145 * 66)
+    by2 = 264 * 145 * 4.0 * (2 + 6 + 4 + 2 + 3 + 4 + 3)       # x, source in; q k v written and read; attention out, message and the
+                                                                # hidden tensor (2 C) written and read; x read again (mlp[0], residual); out
+    fine = {"kernel": "conv_pk_kernel x 6 + attention145_kernel (AttentionalPropagation at [264,145], %d problems per launch)" % b2,
+            "bound": "mfma", "achieved": 3.0 * flops2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e12, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "ms_per_launch": t2 * b2 / rows_step, "algorithmic_tflops": flops2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e12,
+            "hbm_frac": by2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "seven launches, every intermediate tensor through HBM (24 tensor passes of 153 KB per problem: the layer is nearer "
+                    "its HBM bound than its matrix bound); same pricing as the fused layer"}
+    fine["frac"] = fine["achieved"] / F16_PEAK_TFLOPS
+    roof["fine_level_layer"] = fine
     return {"ms_per_step": per_step, "layers": {"coarse": 18, "fine": 18, "third": 10},
             "sample": {"third": "%d of %d problems" % (b3, P_step), "fine": "%d of %d rows" % (b2, rows_step), "coarse": "%d of %d pairs" % (b1, pairs)},
             "pairs_per_s_with_gnn": pairs / ((ms_per_step + total) * 1e-3),

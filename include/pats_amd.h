@@ -488,12 +488,18 @@ int pats_attentional_propagation_f32(const float* x, const float* source, int64_
                                      size_t workspace_bytes, pats_stream_t stream);
 
 /* The same layer with the weights additionally PACKED for the matrix pipe (ABI 5): pats_propagation_pack_f32 splits every
- * Conv1d matrix into fp16 hi + lo halves in MFMA fragment order (q / k / v rows and the merge's columns permuted to head-major)
- * once per layer into a caller-owned, 16-byte aligned device buffer of pats_propagation_packed_bytes(C, heads) bytes (0 = no
- * packed form for this shape).  With it, at the third level's shape (C = 128, 4 heads, n = m = 65) the layer runs as ONE kernel
- * that keeps a problem's activations in LDS from the descriptors to the output (csrc/gnn_fused.hip; bn_train != 0: one kernel
- * up to the hidden tensor, then the batch-statistics passes and the last convolution); other shapes, PATS_GNN_FUSED=0 and
- * launches in which an activation left the fp16 range of the split operands take the composition above (same workspace). */
+ * Conv1d matrix into fp16 hi + lo halves in MFMA fragment order once per layer into a caller-owned, 16-byte aligned device
+ * buffer of pats_propagation_packed_bytes(C, heads) bytes (C % 8 == 0, C % heads == 0; 0 = no packed form for this shape).
+ * With it
+ *  - at the third level's shape (C = 128, 4 heads, n = m = 65) the layer runs as ONE kernel that keeps a problem's activations in
+ *    LDS from the descriptors to the output (csrc/gnn_fused.hip; q / k / v rows and the merge's columns permuted to head-major;
+ *    bn_train != 0: one kernel up to the hidden tensor, then the batch-statistics passes and the last convolution);
+ *  - at every other shape the six convolutions stream the packed weights from L2 straight into the matrix pipe
+ *    (csrc/conv_pk.hip: 64 columns x up to 288 input channels staged whole in LDS per workgroup) and, between 97 and 160 tokens
+ *    with 33 .. 80 channels per head (the fine level: [264, 145], 4 heads), the attention core keeps its scores in registers
+ *    from the first product to the second (csrc/attention145.hip).
+ * PATS_GNN_FUSED=0 / PATS_CONV_PK=0 / PATS_ATTN145=0 and launches in which an activation left the fp16 range of the split
+ * operands take the composition above (same workspace; device-side flags, no host read). */
 size_t pats_propagation_packed_bytes(int C, int heads);
 int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
                               pats_stream_t stream);

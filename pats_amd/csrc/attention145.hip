@@ -40,6 +40,7 @@ static_assert(A_LDS >= 2 * A_DT * A_KK * A_FRAG && A_LDS >= 16 * A_DT * A_OSTR *
 struct A145Args {
     const float* q; const float* k; const float* v; float* out;
     int dim, heads, n, m;
+    int64_t items, per_xcd;                // (problem, head) pairs, and how many each of the 8 XCDs takes
     float c;                               // 2^-12 / sqrt(dim) * log2(e): accumulator -> exponent of 2
     int* flag;                             // raised if an output is not finite
     const int* gate;                       // optional: no-op unless *gate != 0
@@ -71,8 +72,12 @@ attention145_kernel(A145Args g) {
     if (g.gate && *g.gate == 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int qp = lane >> 4, j = lane & 15;
-    const int64_t bi = blockIdx.x / g.heads;
-    const int h = (int)(blockIdx.x - bi * g.heads);
+    // workgroup i runs on XCD i % 8: every XCD takes one contiguous range of (problem, head) - the heads of a problem interleave
+    // their 145-float rows, i.e. share 128-byte lines
+    const int64_t lid = (int64_t)(blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+    if (lid >= g.items) return;
+    const int64_t bi = lid / g.heads;
+    const int h = (int)(lid - bi * g.heads);
     const int n = g.n, m = g.m, dim = g.dim;
     const int rsn = g.heads * n, rsm = g.heads * m;                       // channel strides
     const float* Q = g.q + (bi * dim * g.heads + h) * (int64_t)n;
@@ -235,7 +240,7 @@ int launch_attention145(const float* query, const float* key, const float* value
                         float* out, int* flag, const int* gate, hipStream_t st) {
     static const bool off = [] { const char* e = getenv("PATS_ATTN145"); return e && atoi(e) == 0; }();     // A/B switch
     if (off || n > 16 * A_T || m > 16 * A_T || n <= 96 || m <= 96 || dim > 16 * A_DT || dim <= 32 || !flag) return PATS_ERR_UNSUPPORTED;
-    if (batch * heads >= (1ll << 31)) return PATS_ERR_UNSUPPORTED;
+    if (batch * heads + 8 >= (1ll << 31)) return PATS_ERR_UNSUPPORTED;
     static int state[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
@@ -245,8 +250,9 @@ int launch_attention145(const float* query, const float* key, const float* value
         state[dev] = ok ? 1 : -1;
     }
     if (state[dev] != 1) return PATS_ERR_UNSUPPORTED;
-    A145Args g{query, key, value, out, dim, heads, n, m, (float)((double)UNS / sqrt((double)dim) * 1.4426950408889634), flag, gate};
-    hipLaunchKernelGGL(attention145_kernel, dim3((unsigned)(batch * heads)), dim3(640), A_LDS, st, g);
+    const int64_t items = batch * heads, per_xcd = (items + 7) / 8;
+    A145Args g{query, key, value, out, dim, heads, n, m, items, per_xcd, (float)((double)UNS / sqrt((double)dim) * 1.4426950408889634), flag, gate};
+    hipLaunchKernelGGL(attention145_kernel, dim3((unsigned)(8 * per_xcd)), dim3(640), A_LDS, st, g);
     return check_launch("attention145_kernel");
 }
 

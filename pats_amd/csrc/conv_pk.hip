@@ -35,10 +35,10 @@ constexpr int FR = 2 * 64;                 // h8v per fragment (hi | lo)
 constexpr int PK_NT = 4, PK_NC = 16 * PK_NT;      // 16-column tiles per workgroup: 64 columns
 constexpr int PK_KS_BYTES = 2 * PK_NT * 1024;     // one k-step of activations in LDS: (hi | lo) x 4 tiles x 64 lanes x 16 B
 constexpr int PK_KP = 288, PK_KSPP = PK_KP / 32;  // channels / k-steps of a pass at most
-constexpr int PK_OSTRIDE = PK_NC + 4;             // floats per output row in the epilogue's LDS tile (4 rows apart = 16 banks apart)
 constexpr int PK_ROWS = 17 * 16;
-constexpr int PK_LDS = PK_ROWS * PK_OSTRIDE * 4;  // 73 984 B >= PK_KSPP * PK_KS_BYTES = 73 728
-static_assert(PK_LDS >= PK_KSPP * PK_KS_BYTES, "the output tile overlays the activation stage");
+constexpr int PK_OSTRIDE = PK_ROWS + 4;           // floats per COLUMN of the epilogue's LDS tile
+constexpr int PK_LDS = PK_KSPP * PK_KS_BYTES;     // 73 728 B; the output tile (64 x 276 x 4 = 70 656) overlays the activation stage
+static_assert(PK_LDS >= PK_NC * PK_OSTRIDE * 4, "the output tile overlays the activation stage");
 
 struct PkGeom { int npass, Kp, kspp; };
 // K channels in passes of at most 288, every pass a whole number of 8-channel groups and of (zero-padded) 32-channel k-steps
@@ -56,6 +56,7 @@ struct PkArgs {
     const float* x1;           // [batch, K1, n] or null
     int K0, K1, M, n, npass, Kp, kspp, mtiles, tpg, groups;   // tpg: row tiles per row group
     int64_t cols;              // batch * n
+    int64_t wgs, per_xcd;      // logical workgroups, and how many of them each of the 8 XCDs takes
     const float* in_scale;     // [K0 + K1] or null: x <- max(0, x * scale + shift) while staging
     const float* in_shift;
     const float* bias;
@@ -108,9 +109,13 @@ conv_pk_kernel(PkArgs g) {
     if (g.gate && *g.gate == 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int qp = lane >> 4, j = lane & 15;
-    // row groups of one column tile are neighbours in the launch order (they read the same activations)
-    const int grp = blockIdx.x % g.groups;
-    const int64_t j0 = (int64_t)(blockIdx.x / g.groups) * PK_NC;
+    // Workgroup i runs on XCD i % 8, each with its own L2: the logical tiles are dealt out so that every XCD walks ONE contiguous
+    // range of columns (neighbouring tiles share the 128-byte lines their 145-float rows straddle; the row groups of one column
+    // tile - neighbours in that order - read the same activations)
+    const int64_t lid = (int64_t)(blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+    if (lid >= g.wgs) return;
+    const int grp = (int)(lid % g.groups);
+    const int64_t j0 = (lid / g.groups) * PK_NC;
     const int mt0 = grp * g.tpg, mt_end = min(g.mtiles, mt0 + g.tpg);
     const int n = g.n, KSPP = g.kspp, Kt = g.K0 + g.K1;
     int mts[MT];
@@ -128,6 +133,12 @@ conv_pk_kernel(PkArgs g) {
     const float* base1 = g.K1 > 0 ? g.x1 + (int64_t)cb * g.K1 * n + ctk : base0;
     const int soff = (lane >> 4) * 1024 + (lane & 15) * 16;    // + k-step * 8192 + (group & 3) * 256 (+ 4096 for the lo plane)
 
+    // the epilogue: wave w stores the row quads w, w + 8, ..; lane l keeps the bias of row (l & 3) of its (l >> 2)-th quad - one load
+    // up here, not one (and its latency) per row down there
+    const int rows = min(16 * (mt_end - mt0), g.M - 16 * mt0);
+    const int myrow = 4 * (wave + 8 * (lane >> 2)) + (lane & 3);
+    const float bias_l = (g.bias && myrow < rows) ? g.bias[16 * mt0 + myrow] : 0.f;
+
     f4v acc[MT][PK_NT], accs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -136,27 +147,42 @@ conv_pk_kernel(PkArgs g) {
 
     for (int ps = 0; ps < g.npass; ++ps) {
         // ---- stage the pass: wave w takes the 8-channel groups w, w + 8, .. (a group = one 256-byte row of 64 columns per channel) --
+        // ---- the k loop of the pass: no barrier; weight fragments in a ring of two k-steps, straight from L2 ------------------------
+        h8v wa[2][MT][2], was[2][2];
+        was[0][0] = was[0][1] = was[1][0] = was[1][1] = h8v{0, 0, 0, 0, 0, 0, 0, 0};
+#define PK_WLOAD(ks_, slot_)                                                                                     \
+    {                                                                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                         \
+            gptr_h8 Wf = uniform_ptr(g.pw + (((int64_t)mts[m] * g.npass + ps) * KSPP + (ks_)) * FR);             \
+            wa[slot_][m][0] = Wf[lane];                                                                          \
+            wa[slot_][m][1] = Wf[64 + lane];                                                                     \
+        }                                                                                                        \
+        if (SH && wave < PK_NT) {                                                                                \
+            gptr_h8 Wf = uniform_ptr(g.pw + (((int64_t)mt_sh * g.npass + ps) * KSPP + (ks_)) * FR);              \
+            was[slot_][0] = Wf[lane];                                                                            \
+            was[slot_][1] = Wf[64 + lane];                                                                       \
+        }                                                                                                        \
+    }
         if (ps > 0) wg_barrier();                               // the previous pass has been read
         const int cbase = ps * g.Kp, cend = min(Kt, cbase + g.Kp), ngroups = KSPP * 4;
+        {
+            constexpr int NR = (PK_KSPP * 4 + 7) / 8;           // rounds of eight groups: every load of the pass is in flight at once
+            f4v ra[NR], rb[NR];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            constexpr int R0[2] = {0, 3}, R1[2] = {3, 5};
-            f4v ra[3], rb[3];
-#pragma unroll
-            for (int i = R0[half]; i < R1[half]; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int cg = wave + 8 * i, ch = cbase + cg * 8;       // wave-uniform
-                ra[i - R0[half]] = rb[i - R0[half]] = f4v{0.f, 0.f, 0.f, 0.f};
+                ra[i] = rb[i] = f4v{0.f, 0.f, 0.f, 0.f};
                 if (cg < ngroups && ch < cend) {
                     const float* p = ch >= g.K0 ? base1 + (int64_t)(ch - g.K0) * n : base0 + (int64_t)ch * n;
-                    ra[i - R0[half]] = f4v{p[0], p[n], p[2 * n], p[3 * n]};
-                    rb[i - R0[half]] = f4v{p[4 * n], p[5 * n], p[6 * n], p[7 * n]};
+                    ra[i] = f4v{p[0], p[n], p[2 * n], p[3 * n]};
+                    rb[i] = f4v{p[4 * n], p[5 * n], p[6 * n], p[7 * n]};
                 }
             }
 #pragma unroll
-            for (int i = R0[half]; i < R1[half]; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int cg = wave + 8 * i, ch = cbase + cg * 8;
                 if (cg < ngroups) {
-                    f4v a = ra[i - R0[half]], b = rb[i - R0[half]];
+                    f4v a = ra[i], b = rb[i];
                     if (g.in_scale && ch < cend) {
                         const float* sc = g.in_scale + ch;
                         const float* sh = g.in_shift + ch;
@@ -177,21 +203,6 @@ conv_pk_kernel(PkArgs g) {
         }
         wg_barrier();
 
-        // ---- the k loop of the pass: no barrier; weight fragments in a ring of two k-steps, straight from L2 ------------------------
-        h8v wa[2][MT][2], was[2][2];
-#define PK_WLOAD(ks_, slot_)                                                                                     \
-    {                                                                                                            \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                         \
-            gptr_h8 Wf = uniform_ptr(g.pw + (((int64_t)mts[m] * g.npass + ps) * KSPP + (ks_)) * FR);             \
-            wa[slot_][m][0] = Wf[lane];                                                                          \
-            wa[slot_][m][1] = Wf[64 + lane];                                                                     \
-        }                                                                                                        \
-        if (SH) {                                                                                                \
-            gptr_h8 Wf = uniform_ptr(g.pw + (((int64_t)mt_sh * g.npass + ps) * KSPP + (ks_)) * FR);              \
-            was[slot_][0] = Wf[lane];                                                                            \
-            was[slot_][1] = Wf[64 + lane];                                                                       \
-        }                                                                                                        \
-    }
         PK_WLOAD(0, 0);
         if (KSPP > 1) PK_WLOAD(1, 1);
         for (int ks0 = 0; ks0 < KSPP; ks0 += 2) {
@@ -213,7 +224,7 @@ conv_pk_kernel(PkArgs g) {
                         acc[m][nt] = c;
                     }
                 }
-                if (SH) {                                       // the shared row tile: this wave's one column tile of it
+                if (SH && wave < PK_NT) {                       // the shared row tile: this wave's one column tile of it
                     const h8v bh = *reinterpret_cast<const h8v*>(blk + nt_sh * 1024 + lane * 16);
                     const h8v bl = *reinterpret_cast<const h8v*>(blk + PK_NT * 1024 + nt_sh * 1024 + lane * 16);
                     accs = __builtin_amdgcn_mfma_f32_16x16x32_f16(was[s][1], bh, accs, 0, 0, 0);
@@ -227,7 +238,9 @@ conv_pk_kernel(PkArgs g) {
 #undef PK_WLOAD
     }
 
-    // ---- epilogue: the tile through LDS (row-major, 64 columns + 4 of padding), then whole rows per wave ----------------------------
+    // ---- epilogue: the tile through LDS, COLUMN-major ([column][row], 276 floats apart: an accumulator's four rows are one 16-byte
+    // write, a lane's four rows of its column one 16-byte read; 276 = 20 mod 64 spreads 16 lanes over all banks), then whole rows of
+    // 64 columns per wave store ------------------------------------------------------------------------------------------------
     wg_barrier();
     float* ot = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -235,27 +248,24 @@ conv_pk_kernel(PkArgs g) {
         if (!has[m]) continue;
         const int rl = 16 * (wave + 8 * m) + 4 * qp;
 #pragma unroll
-        for (int nt = 0; nt < PK_NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ot[(rl + r) * PK_OSTRIDE + 16 * nt + j] = acc[m][nt][r] * UNS;
+        for (int nt = 0; nt < PK_NT; ++nt) *reinterpret_cast<f4v*>(ot + (16 * nt + j) * PK_OSTRIDE + rl) = acc[m][nt] * UNS;
     }
-    if (SH && has_sh) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ot[(16 * 8 * MT + 4 * qp + r) * PK_OSTRIDE + 16 * wave + j] = accs[r] * UNS;
-    }
+    if (SH && has_sh) *reinterpret_cast<f4v*>(ot + (16 * wave + j) * PK_OSTRIDE + 16 * 8 * MT + 4 * qp) = accs * UNS;
     wg_barrier();
-    const int rows = min(16 * (mt_end - mt0), g.M - 16 * mt0);
     const bool colok = j0 + lane < g.cols;
+    const int64_t obase = ((int64_t)cb * g.M + 16 * mt0) * n + ctk;
     bool bad = false;
-    for (int rl = wave; rl < rows; rl += 8) {
-        const int row = 16 * mt0 + rl;
-        float v = ot[rl * PK_OSTRIDE + lane];
-        bad |= colok && !(fabsf(v) <= 3.0e38f);
-        if (g.bias) v += g.bias[row];
-        const int64_t o = ((int64_t)cb * g.M + row) * n + ctk;
-        if (colok) {
-            if (g.residual) v = g.residual[o] + v;
-            g.y[o] = v;
+    for (int i = 0; 4 * (wave + 8 * i) < rows; ++i) {
+        const int r0 = 4 * (wave + 8 * i);
+        const f4v v = *reinterpret_cast<const f4v*>(ot + lane * PK_OSTRIDE + r0);
+        float res[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) res[u] = (g.residual && colok && r0 + u < rows) ? g.residual[obase + (int64_t)(r0 + u) * n] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bad |= colok && r0 + u < rows && !(fabsf(v[u]) <= 3.0e38f);
+            const float y = res[u] + (v[u] + __shfl(bias_l, 4 * i + u));
+            if (colok && r0 + u < rows) g.y[obase + (int64_t)(r0 + u) * n] = y;
         }
     }
     if (__any(bad) && lane == 0 && g.redo) atomicOr(g.redo, 1);
@@ -301,10 +311,10 @@ int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0,
     const int mtiles = (M + 15) / 16;
     // row groups of at most 17 tiles, evenly: 264 rows -> one group of 16 + the shared 17th; 528 -> 17 + 16; 128 -> 8
     const int groups = (mtiles + 16) / 17, tpg = (mtiles + groups - 1) / groups;
-    PkArgs g{(const h8v*)packed, x0, x1, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, in_scale, in_shift, bias, residual, y, redo, gate};
-    const int64_t wgs = ((cols + PK_NC - 1) / PK_NC) * groups;
-    PATS_REQUIRE(wgs < (1ll << 31), "conv_pk: grid too large (split the batch)");
-    const dim3 grid((unsigned)wgs), block(512);
+    const int64_t wgs = ((cols + PK_NC - 1) / PK_NC) * groups, per_xcd = (wgs + 7) / 8;
+    PATS_REQUIRE(8 * per_xcd < (1ll << 31), "conv_pk: grid too large (split the batch)");
+    PkArgs g{(const h8v*)packed, x0, x1, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, wgs, per_xcd, in_scale, in_shift, bias, residual, y, redo, gate};
+    const dim3 grid((unsigned)(8 * per_xcd)), block(512);
     // (10..16 tiles take the 17-tile instantiation too: without the shared tile the same loop spills 29 registers at the 128 cap)
     if (tpg <= 8) hipLaunchKernelGGL((conv_pk_kernel<1, false>), grid, block, PK_LDS, st, g);
     else if (tpg == 9) hipLaunchKernelGGL((conv_pk_kernel<1, true>), grid, block, PK_LDS, st, g);

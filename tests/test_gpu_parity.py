@@ -1323,10 +1323,13 @@ def test_conv1d_edge_cases(ops, oracle):
     np.testing.assert_allclose(t.cpu().numpy(), bet - mean * gam / np.sqrt(var + 1e-5), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("C,b,n,m", [(8, 37, 3, 5), (24, 9, 70, 33), (72, 4, 161, 20), (136, 3, 65, 65)])
+@pytest.mark.parametrize("C,b,n,m", [(8, 37, 3, 5), (24, 9, 70, 33), (72, 4, 161, 20), (136, 3, 65, 65), (160, 3, 100, 160), (320, 2, 160, 97),
+                                     (296, 2, 129, 145)])
 def test_attentional_propagation_small_widths_against_oracle(ops, oracle, C, b, n, m):
     """Single-chunk and ragged reductions (K = 8 .. 272, the two-pass reduction of the MLP's first product with a
-    zero-filled tail in each pass), column tiles that cover many problems, train and eval BatchNorm, residual."""
+    zero-filled tail in each pass), column tiles that cover many problems, train and eval BatchNorm, residual.  The last three
+    are attention145_kernel's corners (40 / 80 / 74 channels per head, 97 .. 160 tokens, n != m) and, for the packed-weights
+    convolutions, 10 / 20 / 19 row tiles and reductions of 160 .. 640 channels in one to three passes."""
     params = synth.gnn_params(seed=100 + C, C=C)
     inp = synth.gnn_inputs(seed=200 + C, b=b, C=C, n=n, m=m)
     P = ops.PropagationParams(params)
@@ -1335,6 +1338,19 @@ def test_attentional_propagation_small_widths_against_oracle(ops, oracle, C, b, 
         y = ops.attentional_propagation(x, s, P, bn_train=train, residual=x).cpu().numpy()
         want = oracle.attentional_propagation(inp["x"], inp["source"], params, bn_train=train, residual=inp["x"])
         np.testing.assert_allclose(y, want, atol=1e-4, rtol=2e-4)
+
+
+def test_fine_level_layer_operands_beyond_the_fp16_range(ops, oracle):
+    """The fine level's shape runs conv_pk_kernel and attention145_kernel (fp16-split operands, no fp32 path inside): spikes in the
+    descriptors make their outputs non-finite, they raise their flags, and the fp32-capable kernels queued behind redo the launch."""
+    params = synth.gnn_params(seed=21, C=264)
+    inp = synth.gnn_inputs(seed=22, b=3, C=264, n=145)
+    inp["x"][1, 100, 77] = 70000.0                 # beyond fp16 even before the 2^6 prescale: q overflows, then the attention's operands
+    inp["source"][2, 5, 144] = -2500.0
+    y = ops.attentional_propagation(cu(inp["x"]), cu(inp["source"]), ops.PropagationParams(params), residual=cu(inp["x"])).cpu().numpy()
+    want = oracle.attentional_propagation(inp["x"], inp["source"], params, residual=inp["x"])
+    assert np.isfinite(y).all()
+    np.testing.assert_allclose(y, want, atol=2e-2, rtol=5e-4)          # outputs reach 1e4 next to the spikes
 
 
 def test_attentional_propagation_operands_beyond_the_fp16_range(ops, oracle):
