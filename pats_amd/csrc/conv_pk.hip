@@ -15,6 +15,12 @@
 //   * two workgroups share a CU (128 registers, 2 x 72 KB): one loads or stores while the other multiplies;
 //   * the result leaves through LDS: rows of 64 consecutive columns per wave store instead of the MFMA layout's 16;
 //   * v_mfma_f32_16x16x32_f16, three exact-product passes, fp32 accumulation - the contraction of the cost build.
+// Measured and not kept (round 4): 16-byte lane loads of four consecutive columns turned in LDS or by 4 x 4 DPP transposes (rows of
+// 145 floats: three quads in four are misaligned and pass the address unit no faster than four dwords - 510 / 680 us against 400
+// per [264 -> 264] product); a persistent grid that fetches the next tile under the epilogue (vmcnt is in order: the stash's wait for
+// those loads waits for the epilogue's stores too - 470 us).  Timeline of a workgroup (s_memrealtime, mean of 9 280): 5.5 us issuing its
+// 40 dword loads per lane, 1.8 stash, 6.3 k loop (two workgroups share the matrix pipe), 3.3 at barriers, 2.5 epilogue: the vector
+// memory pipe (activations in and out at 4 bytes a lane, 360 KB of weights per tile) is what bounds it, not HBM and not the MFMAs.
 // Range: |activation| < 1023; a non-finite output raises *redo and conv1x1_kernel (fp32 redo inside), queued behind by launch_conv,
 // recomputes the product - the protocol of conv_lean_kernel.
 #include "common.hpp"
@@ -28,6 +34,7 @@ namespace {
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef const __attribute__((address_space(1))) h8v* gptr_h8;
 
 constexpr float PRE = 64.0f, UNS = 1.0f / 4096.0f;
@@ -112,10 +119,11 @@ conv_pk_kernel(PkArgs g) {
     // Workgroup i runs on XCD i % 8, each with its own L2: the logical tiles are dealt out so that every XCD walks ONE contiguous
     // range of columns (neighbouring tiles share the 128-byte lines their 145-float rows straddle; the row groups of one column
     // tile - neighbours in that order - read the same activations)
-    const int64_t lid = (int64_t)(blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
-    if (lid >= g.wgs) return;
-    const int grp = (int)(lid % g.groups);
-    const int64_t j0 = (lid / g.groups) * PK_NC;
+    // (32-bit throughout: launch_conv_pk requires 8 * per_xcd and the column count below 2^31)
+    const unsigned lid = (blockIdx.x & 7u) * (unsigned)g.per_xcd + (blockIdx.x >> 3);
+    if (lid >= (unsigned)g.wgs) return;
+    const int grp = (int)(lid % (unsigned)g.groups);
+    const unsigned j0 = (lid / (unsigned)g.groups) * PK_NC;
     const int mt0 = grp * g.tpg, mt_end = min(g.mtiles, mt0 + g.tpg);
     const int n = g.n, KSPP = g.kspp, Kt = g.K0 + g.K1;
     int mts[MT];
@@ -127,23 +135,28 @@ conv_pk_kernel(PkArgs g) {
     const bool has_sh = SH && mt0 + 8 * MT < mt_end && wave < PK_NT;
 
     // this lane's column while staging and storing: flattened (problem, token); one past the end repeats the last and is not stored
-    const int64_t cglob = min(j0 + lane, g.cols - 1);
-    const unsigned cb = (unsigned)(cglob / n), ctk = (unsigned)(cglob - (int64_t)cb * n);
+    const unsigned cglob = min(j0 + lane, (unsigned)g.cols - 1u);
+    const unsigned cb = cglob / (unsigned)n, ctk = cglob - cb * (unsigned)n;
     const float* base0 = g.x0 + (int64_t)cb * g.K0 * n + ctk;
     const float* base1 = g.K1 > 0 ? g.x1 + (int64_t)cb * g.K1 * n + ctk : base0;
     const int soff = (lane >> 4) * 1024 + (lane & 15) * 16;    // + k-step * 8192 + (group & 3) * 256 (+ 4096 for the lo plane)
 
-    // the epilogue: wave w stores the row quads w, w + 8, ..; lane l keeps the bias of row (l & 3) of its (l >> 2)-th quad - one load
-    // up here, not one (and its latency) per row down there
+    // The accumulators start at 2^12 bias (exact): the bias costs no load, no exchange and no latency in the epilogue.  Lane (q', j)
+    // holds rows 16 tile + 4 q' .. + 3 (M is a multiple of 8: all four exist or none)
     const int rows = min(16 * (mt_end - mt0), g.M - 16 * mt0);
-    const int myrow = 4 * (wave + 8 * (lane >> 2)) + (lane & 3);
-    const float bias_l = (g.bias && myrow < rows) ? g.bias[16 * mt0 + myrow] : 0.f;
-
-    f4v acc[MT][PK_NT], accs = {0.f, 0.f, 0.f, 0.f};
+    auto bias4 = [&](int mt) {
+        const int row = 16 * mt + 4 * qp;
+        if (!g.bias || row >= g.M) return f4v{0.f, 0.f, 0.f, 0.f};
+        const f4u b = *reinterpret_cast<const f4u*>(g.bias + row);
+        return f4v{b.x, b.y, b.z, b.w} * (1.0f / UNS);
+    };
+    f4v acc[MT][PK_NT], accs = bias4(mt_sh);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+        const f4v b = bias4(mts[m]);
 #pragma unroll
-        for (int nt = 0; nt < PK_NT; ++nt) acc[m][nt] = f4v{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < PK_NT; ++nt) acc[m][nt] = b;
+    }
 
     for (int ps = 0; ps < g.npass; ++ps) {
         // ---- stage the pass: wave w takes the 8-channel groups w, w + 8, .. (a group = one 256-byte row of 64 columns per channel) --
@@ -252,20 +265,45 @@ conv_pk_kernel(PkArgs g) {
     }
     if (SH && has_sh) *reinterpret_cast<f4v*>(ot + (16 * wave + j) * PK_OSTRIDE + 16 * 8 * MT + 4 * qp) = accs * UNS;
     wg_barrier();
-    const bool colok = j0 + lane < g.cols;
-    const int64_t obase = ((int64_t)cb * g.M + 16 * mt0) * n + ctk;
+    // wave w stores the row quads w, w + 8, ..: all its LDS reads (and residual loads) first, then the stores - no round trip per row.
+    // Addresses: a wave-uniform row base + one 32-bit lane offset (the lane's problem relative to the tile's first, its token).
+    const bool colok = j0 + lane < (unsigned)g.cols;
+    const unsigned b0 = j0 / (unsigned)n;                                       // wave-uniform
+    const unsigned ovoff = ((cb - b0) * (unsigned)g.M * (unsigned)n + ctk) * 4u;
+    const int64_t obase = ((int64_t)b0 * g.M + 16 * mt0) * n;                   // wave-uniform
+    constexpr int NQ = (PK_ROWS / 4 + 7) / 8;
+    f4v v[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int rc = min(4 * (wave + 8 * i), rows - 4);
+        v[i] = *reinterpret_cast<const f4v*>(ot + lane * PK_OSTRIDE + rc);
+    }
     bool bad = false;
-    for (int i = 0; 4 * (wave + 8 * i) < rows; ++i) {
+    if (g.residual) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int rc = min(4 * (wave + 8 * i), rows - 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bad |= !(fabsf(v[i][u]) <= 3.0e38f);
+                const float r = colok ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.residual + obase + (int64_t)(rc + u) * n) + ovoff) : 0.f;
+                v[i][u] = r + v[i][u];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bad |= !(fabsf(v[i][u]) <= 3.0e38f);
+    }
+    bad &= colok;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
         const int r0 = 4 * (wave + 8 * i);
-        const f4v v = *reinterpret_cast<const f4v*>(ot + lane * PK_OSTRIDE + r0);
-        float res[4];
+        if (r0 < rows && colok) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) res[u] = (g.residual && colok && r0 + u < rows) ? g.residual[obase + (int64_t)(r0 + u) * n] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            bad |= colok && r0 + u < rows && !(fabsf(v[u]) <= 3.0e38f);
-            const float y = res[u] + (v[u] + __shfl(bias_l, 4 * i + u));
-            if (colok && r0 + u < rows) g.y[obase + (int64_t)(r0 + u) * n] = y;
+            for (int u = 0; u < 4; ++u)
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(g.y + obase + (int64_t)(r0 + u) * n) + ovoff) = v[i][u];
         }
     }
     if (__any(bad) && lane == 0 && g.redo) atomicOr(g.redo, 1);
