@@ -242,27 +242,13 @@ __device__ __forceinline__ unsigned wave_xor_bits(unsigned v) {
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 #endif
 
-template <int WAVES, int CR, int DB, int CF = 0>
-__global__ void __launch_bounds__(64, WAVES)
-third_fused3_kernel(Fused65Args g) {
-    __shared__ Blk3Lds lds;
-    const int lane = threadIdx.x, I = lane >> 3, J = lane & 7;
-    const int64_t p = blockIdx.x;
-    if (p >= live_problems(g)) return;
-    // de-phase the first wave-front (see sinkhorn65_kernel)
-    if (g.stagger > 0 && blockIdx.x < 8192u) {
-        const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
-        for (unsigned q = 0; q < slots * (unsigned)g.stagger; ++q) __builtin_amdgcn_s_sleep(127);
-    }
-#ifdef PATS_DIAG
-    // diagnostic library only: every LDS word starts as a caller-chosen bit pattern - a result that changes with the
-    // pattern has read LDS it never wrote (tools/third_determinism.py LDSPOISON=1)
-    if (g.lds_poison_on) {
-        unsigned* w = reinterpret_cast<unsigned*>(&lds);
-        for (unsigned k = lane; k < sizeof(Blk3Lds) / 4; k += 64) w[k] = g.lds_poison;
-        wg_barrier();
-    }
-#endif
+// One problem, one wave.  ST = 1 (round 4): the STABILISED solve for the problems the plain one flagged - after every sweep a scaling
+// that has drifted out of [2^-20, 2^20] is absorbed into the kernel matrix (K_ij <- a_i K_ij b_j, a = b = 1: the plan K a b is
+// unchanged, the iterate is the same Sinkhorn iterate) and the sweeps go on; only a scaling that leaves fp32 within ONE sweep
+// (-inf scores, ranges beyond 2^127) still goes to the log-sum-exp kernel.  A problem that never drifts runs bit-identically to ST = 0.
+template <int CR, int DB, int CF, int ST>
+__device__ __forceinline__ void third3_problem(const Fused65Args& g, const int64_t p, Blk3Lds& lds, const int lane) {
+    const int I = lane >> 3, J = lane & 7;
     const int colj = 8 * J + I;              // the column this lane owns in the column half-sweep
     // ---- marginals of log_optimal_transport2 (modules.py:169-179); wave-uniform values in SGPRs -------
     // The loads are issued here, ahead of the descriptor stream, and first used after the cost build: one memory
@@ -280,7 +266,7 @@ third_fused3_kernel(Fused65Args g) {
     float zdrow, zdcol, zcorner;
     float zr8[8];                            // DB == 4: Z[64][8J .. 8J+7]
     f2v kdr[4];                              // DB == 4: the same as K, in column pairs
-    {
+    auto build_scores = [&]() {              // (ST: called again whenever the stabilisers move)
         Cost65Acc c;
         if (DB == 9) {      // timing ablation only: no cost build (results are garbage)
             for (int r = 0; r < 16; ++r) { c.c00[r] = (float)(lane + r) * 0.01f; c.c01[r] = -c.c00[r]; c.c10[r] = c.c00[r] * 0.5f; c.c11[r] = 0.25f; }
@@ -338,7 +324,8 @@ third_fused3_kernel(Fused65Args g) {
         wg_barrier();
         lds.erow[lane] = sx_lane;                        // the epilogue's target scales wait in the freed edge buffers
         lds.ecol[lane] = sy_lane;
-    }
+    };
+    build_scores();
 
 #ifdef PATS_DIAG
     // diagnostic library only: a bit-exact fingerprint (xor of the fp32 bit patterns) of the score matrix this wave built,
@@ -405,30 +392,37 @@ third_fused3_kernel(Fused65Args g) {
     const float cpart[8] = {cm[0].x, cm[0].y, cm[1].x, cm[1].y, cm[2].x, cm[2].y, cm[3].x, cm[3].y};
     const float c_own = fmaxf(reduce8_strided(cpart, OpMax(), lane), zdrow - r64);
     const float c64 = uni3(fmaxf(wave_max(zdcol - r_own), zcorner - r64));
-    wg_barrier();
-    lds.vb[colj] = c_own;
-    wg_barrier();
-    {
+    float kdcol, kdrow, kcorner;             // K[8I+J][64], K[64][8J+I], K[64][64]
+    // K = exp(Z - r - c) from the scores in Pa / Pb and the edge scores, in place; rs / r64s / cs / c64s: this lane's row, the dustbin
+    // row, this lane's column, the dustbin column
+    auto exp_kernel = [&](const float rs, const float r64s, const float cs, const float c64s) {
+        float rr[8];
+        gather_rows(rs, rr);
+        wg_barrier();
+        lds.vb[colj] = cs;
+        wg_barrier();
         const f4v v0 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J]), v1 = *reinterpret_cast<const f4v*>(&lds.vb[8 * J + 4]);
         const float cl[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
             for (int cp = 0; cp < 4; ++cp) {
-                const float r0 = rl[2 * sp], r1 = rl[2 * sp + 1], c0 = cl[2 * cp], c1 = cl[2 * cp + 1];
+                const float r0 = rr[2 * sp], r1 = rr[2 * sp + 1], c0 = cl[2 * cp], c1 = cl[2 * cp + 1];
                 Pa[sp][cp] = f2v{fast_exp2(((Pa[sp][cp].x - r0) - c0) * LOG2E), fast_exp2(((Pa[sp][cp].y - r1) - c1) * LOG2E)};
                 Pb[sp][cp] = f2v{fast_exp2(((Pb[sp][cp].x - r1) - c0) * LOG2E), fast_exp2(((Pb[sp][cp].y - r0) - c1) * LOG2E)};
             }
         if (DB == 4) {
 #pragma unroll
             for (int cp = 0; cp < 4; ++cp)
-                kdr[cp] = f2v{fast_exp2(((zr8[2 * cp] - r64) - cl[2 * cp]) * LOG2E),
-                              fast_exp2(((zr8[2 * cp + 1] - r64) - cl[2 * cp + 1]) * LOG2E)};
+                kdr[cp] = f2v{fast_exp2(((zr8[2 * cp] - r64s) - cl[2 * cp]) * LOG2E),
+                              fast_exp2(((zr8[2 * cp + 1] - r64s) - cl[2 * cp + 1]) * LOG2E)};
         }
-    }
-    const float kdcol = fast_exp2(((zdcol - r_own) - c64) * LOG2E);     // K[8I+J][64]
-    const float kdrow = fast_exp2(((zdrow - r64) - c_own) * LOG2E);     // K[64][8J+I]
-    const float kcorner = uni3(fast_exp2(((zcorner - r64) - c64) * LOG2E));
+        kdcol = fast_exp2(((zdcol - rs) - c64s) * LOG2E);
+        kdrow = fast_exp2(((zdrow - r64s) - cs) * LOG2E);
+        kcorner = uni3(fast_exp2(((zcorner - r64s) - c64s) * LOG2E));
+    };
+    exp_kernel(r_own, r64, c_own, c64);
+    float r_t = r_own, r64_t = r64, c_t = c_own, c64_t = c64;      // ST: the stabilisers as they move
     const float ns_sum = uni3(wave_sum(ns_lane));
     const float ms = uni3(64.0f * one_v);
     const float norm = uni3(-logf(ms + ns_sum));
@@ -533,6 +527,22 @@ third_fused3_kernel(Fused65Args g) {
             lds.vb[colj] = b;
             THIRD_PRIO(0);
         }
+        if (ST) {
+            auto band = [](float x) { return x >= 9.5367431640625e-07f && x <= 1048576.0f; };       // [2^-20, 2^20]
+            auto fin = [](float x) { return x > 0.f && x <= 3.0e38f; };
+            if (!(__all(band(a) && band(b)) && band(a64) && band(b64))) {          // wave-uniform
+                if (!(__all(fin(a) && fin(b)) && fin(a64) && fin(b64))) return;     // out of fp32 in one sweep: the log-sum-exp kernel
+                // absorb: the scalings go into the stabilisers (logs) and K is built again from the scores - exact exponents; a
+                // product a_i K_ij b_j would keep the entries the first K lost below 2^-126 lost, and those are the ones that carry
+                // the plan once a b has grown by 2^100
+                r_t -= logf(a); r64_t -= logf(a64); c_t -= logf(b); c64_t -= logf(b64);
+                build_scores();
+                exp_kernel(r_t, r64_t, c_t, c64_t);
+                a = 1.f; a64 = 1.f; b = 1.f; b64 = 1.f;
+                wg_barrier();                         // every lane has read the old b
+                lds.vb[colj] = 1.f;
+            }
+        }
 #ifdef PATS_DIAG
         if (g.fingerprint && ((it + 1) & it) == 0 && it < 64) {
             const unsigned f = wave_xor_bits(fbits(a) ^ (fbits(b) * 3u) ^ (fbits(a64) * 5u) ^ (fbits(b64) * 7u));
@@ -545,8 +555,9 @@ third_fused3_kernel(Fused65Args g) {
     const unsigned ab_bits = wave_xor_bits(fbits(a) ^ (fbits(b) * 3u) ^ (fbits(a64) * 5u) ^ (fbits(b64) * 7u));
 #endif
     if (!(__all(sc_ok3(a) && sc_ok3(b)) && sc_ok3(a64) && sc_ok3(b64))) {
-        // guard tripped: third_fused_kernel (log-sum-exp sweeps) redoes this problem in scan mode
-        if (lane == 0) {
+        // guard tripped: the stabilised instantiation of this solve, then third_fused_kernel (log-sum-exp sweeps), redo this problem
+        // in scan mode (ST: the sentinel is already there and the trip already counted)
+        if (!ST && lane == 0) {
             g.cr.ifm[p * 16] = THIRD_REDO;
             if (g.fallbacks) atomicAdd(g.fallbacks, 1ull);
         }
@@ -594,6 +605,50 @@ third_fused3_kernel(Fused65Args g) {
             g.cr.label[(p * 16 + 3 + k) * 2 + 1] = __builtin_bit_cast(float, (trace_bits[k] & 0x007fffffu) | 0x3f800000u);
     }
 #endif
+}
+
+template <int WAVES, int CR, int DB, int CF = 0>
+__global__ void __launch_bounds__(64, WAVES)
+third_fused3_kernel(Fused65Args g) {
+    __shared__ Blk3Lds lds;
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    if (p >= live_problems(g)) return;
+    // de-phase the first wave-front (see sinkhorn65_kernel)
+    if (g.stagger > 0 && blockIdx.x < 8192u) {
+        const unsigned slots = (blockIdx.x * 2654435761u) >> 29;
+        for (unsigned q = 0; q < slots * (unsigned)g.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+    }
+#ifdef PATS_DIAG
+    // diagnostic library only: every LDS word starts as a caller-chosen bit pattern - a result that changes with the
+    // pattern has read LDS it never wrote (tools/third_determinism.py LDSPOISON=1)
+    if (g.lds_poison_on) {
+        unsigned* w = reinterpret_cast<unsigned*>(&lds);
+        for (unsigned k = lane; k < sizeof(Blk3Lds) / 4; k += 64) w[k] = g.lds_poison;
+        wg_barrier();
+    }
+#endif
+    third3_problem<CR, DB, CF, 0>(g, p, lds, lane);
+}
+
+// The stabilised solve over the problems the launch above flagged: the W workgroups share the problems interleaved, as
+// third_fused_kernel's scan mode does (third_fused.hip) - which runs behind this one for what is still flagged.
+__global__ void __launch_bounds__(64, 2)
+third_fused3_stab_kernel(Fused65Args g) {
+    __shared__ Blk3Lds lds;
+    const int lane = threadIdx.x;
+    const int64_t W = gridDim.x, live = live_problems(g);
+    for (int64_t first = blockIdx.x; first < live; first += 64 * W) {
+        const int64_t cand = first + (int64_t)lane * W;
+        const bool redo = cand < live && g.cr.ifm[cand * 16] == THIRD_REDO;
+        unsigned long long todo = __ballot(redo);
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            wg_barrier();
+            third3_problem<0, 0, 0, 1>(g, first + (int64_t)k * W, lds, lane);
+        }
+    }
 }
 
 int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
@@ -660,7 +715,15 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
         default:  hipLaunchKernelGGL((third_fused3_kernel<3, 0, 5, 1>), grid, block, lds_pad, st, g); break;
     }
 #endif
-    return check_launch("third_fused3_kernel");
+    int rc = check_launch("third_fused3_kernel");
+    if (rc) return rc;
+    static const bool no_stab = [] { const char* e = getenv("PATS_THIRD_STAB"); return e && atoi(e) == 0; }();      // A/B switch
+    if (!no_stab && g.iters > 0) {
+        const int64_t waves = g.P < 6144 ? g.P : 6144;            // two rounds of the 3 072 wave slots: flagged runs spread out
+        hipLaunchKernelGGL(third_fused3_stab_kernel, dim3((unsigned)(waves > 0 ? waves : 1)), dim3(64), 0, st, g);
+        rc = check_launch("third_fused3_stab_kernel");
+    }
+    return rc;
 }
 
 }  // namespace pats

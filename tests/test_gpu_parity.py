@@ -1024,6 +1024,56 @@ def test_third_level_guard_trips_are_resolved_by_the_scan_kernel(ops, oracle, si
     assert np.isfinite(m1.cpu().numpy()).all()
 
 
+STAB_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %(repo)r)
+from pats_amd import ops, synth
+P = 600
+inp = synth.third_inputs(seed=synth.SEED + 64, P=P)
+d0, d1 = inp["d0"].copy(), inp["d1"].copy()
+rng = np.random.default_rng(5)
+wild = rng.choice(P, 200, replace=False)
+amp = rng.choice([3.0, 5.0, 9.0, 14.0], size=200).astype(np.float32)
+d0[wild] *= amp[:, None, None]; d1[wild] *= amp[:, None, None]
+ops.sinkhorn_fallbacks(reset=True)
+cu = lambda a: torch.from_numpy(a).cuda()
+m0, m1, label, ifm = ops.third_level(cu(d0), cu(d1), cu(inp["scale"]), cu(inp["p_s"]), cu(inp["p_t"]), outdoor=True)
+np.savez(sys.argv[1], m0=m0.cpu().numpy(), m1=m1.cpu().numpy(), label=label.cpu().numpy(), ifm=ifm.cpu().numpy(), wild=wild,
+         trips=np.int64(ops.sinkhorn_fallbacks(reset=True)))
+"""
+
+
+def test_stabilised_third_level_resolve_agrees_with_the_log_domain_one(tmp_path):
+    """Problems the plain linear solve flags are re-solved by its stabilised instantiation (third_fused3_stab_kernel: scalings
+    absorbed into the kernel matrix when they drift) and only what that cannot hold by the log-sum-exp kernel.  Two processes on
+    the same inputs - PATS_THIRD_STAB=0 takes every flagged problem to the log-sum-exp kernel as before round 4: same flags and
+    labels wherever the plan is not a near-tie, the same points within the parity gate, tame problems bit-identical."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for stab in ("1", "0"):
+        out = str(tmp_path / ("third_stab%s.npz" % stab))
+        env = dict(os.environ, PATS_THIRD_STAB=stab)
+        r = subprocess.run([sys.executable, "-c", STAB_CHILD % {"repo": repo}, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert int(a["trips"]) == int(b["trips"]) and int(a["trips"]) >= 20           # the same problems leave the band in both
+    assert set(np.unique(a["ifm"].astype(np.uint8))) <= {0, 1}                    # no sentinel left behind
+    P = a["m0"].shape[0] // 16 if a["m0"].ndim == 2 else 600
+    tame = np.setdiff1d(np.arange(600), a["wild"])
+    for k in ("m0", "m1", "label", "ifm"):
+        x, y = a[k].reshape(600, 16, -1), b[k].reshape(600, 16, -1)
+        assert np.array_equal(x[tame], y[tame]), k
+    assert np.array_equal(a["m0"], b["m0"])
+    same_flag = a["ifm"].reshape(600, 16) == b["ifm"].reshape(600, 16)
+    assert same_flag.mean() > 0.995                                                # a flag may flip only on a near-tie
+    both = same_flag & (a["ifm"].reshape(600, 16) == 0)
+    d = np.abs(a["m1"].reshape(600, 16, 2) - b["m1"].reshape(600, 16, 2)).max(-1)
+    assert d[both].max() <= 3e-4 * 8, d[both].max()
+    assert np.isfinite(a["m1"]).all()
+
+
 # ---- AttentionalPropagation / AttentionalGNN around the attention core (section 8f rank 4) -------------------
 GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
 
