@@ -21,8 +21,8 @@
 // those loads waits for the epilogue's stores too - 470 us).  Timeline of a workgroup (s_memrealtime, mean of 9 280): 5.5 us issuing its
 // 40 dword loads per lane, 1.8 stash, 6.3 k loop (two workgroups share the matrix pipe), 3.3 at barriers, 2.5 epilogue: the vector
 // memory pipe (activations in and out at 4 bytes a lane, 360 KB of weights per tile) is what bounds it, not HBM and not the MFMAs.
-// Range: |activation| < 1023; a non-finite output raises *redo and conv1x1_kernel (fp32 redo inside), queued behind by launch_conv,
-// recomputes the product - the protocol of conv_lean_kernel.
+// Range: |activation| < 1023; a non-finite output raises *redo - the layer's one flag: the round-2 composition queued behind the
+// layer, gated on it, recomputes the whole layer (gnn.hip, propagation_impl).
 #include "common.hpp"
 
 #include <cstdlib>
@@ -61,6 +61,8 @@ struct PkArgs {
     const h8v* pw;             // [row tiles][passes][k-steps of a pass][hi | lo][64]
     const float* x0;           // [batch, K0, n]
     const float* x1;           // [batch, K1, n] or null
+    int layout;                // bit 0 / 1: x0 / x1 channel-BLOCKED, bit 2: y channel-blocked - [batch, C / 8, n, 8]: a token's eight
+                               // channels are 32 contiguous bytes (the layer's own intermediate tensors; 16-byte accesses both ways)
     int K0, K1, M, n, npass, Kp, kspp, mtiles, tpg, groups;   // tpg: row tiles per row group
     int64_t cols;              // batch * n
     int64_t wgs, per_xcd;      // logical workgroups, and how many of them each of the 8 XCDs takes
@@ -186,9 +188,17 @@ conv_pk_kernel(PkArgs g) {
                 const int cg = wave + 8 * i, ch = cbase + cg * 8;       // wave-uniform
                 ra[i] = rb[i] = f4v{0.f, 0.f, 0.f, 0.f};
                 if (cg < ngroups && ch < cend) {
-                    const float* p = ch >= g.K0 ? base1 + (int64_t)(ch - g.K0) * n : base0 + (int64_t)ch * n;
-                    ra[i] = f4v{p[0], p[n], p[2 * n], p[3 * n]};
-                    rb[i] = f4v{p[4 * n], p[5 * n], p[6 * n], p[7 * n]};
+                    const bool second = ch >= g.K0;             // (K0, K1 multiples of 8: a group never straddles the sources)
+                    if (g.layout & (second ? 2 : 1)) {          // blocked source: the group is 32 contiguous bytes of this lane's token
+                        const int64_t Ks8 = (second ? g.K1 : g.K0) >> 3, c8 = (second ? ch - g.K0 : ch) >> 3;
+                        const float* p = (second ? g.x1 : g.x0) + (((int64_t)cb * Ks8 + c8) * n + ctk) * 8;
+                        ra[i] = *reinterpret_cast<const f4v*>(p);
+                        rb[i] = *reinterpret_cast<const f4v*>(p + 4);
+                    } else {
+                        const float* p = second ? base1 + (int64_t)(ch - g.K0) * n : base0 + (int64_t)ch * n;
+                        ra[i] = f4v{p[0], p[n], p[2 * n], p[3 * n]};
+                        rb[i] = f4v{p[4 * n], p[5 * n], p[6 * n], p[7 * n]};
+                    }
                 }
             }
 #pragma unroll
@@ -268,6 +278,34 @@ conv_pk_kernel(PkArgs g) {
     // wave w stores the row quads w, w + 8, ..: all its LDS reads (and residual loads) first, then the stores - no round trip per row.
     // Addresses: a wave-uniform row base + one 32-bit lane offset (the lane's problem relative to the tile's first, its token).
     const bool colok = j0 + lane < (unsigned)g.cols;
+    if (g.layout & 4) {
+        // blocked output (no residual in this mode): wave w stores the 8-row blocks w, w + 8, .. - two 16-byte reads of its column,
+        // two 16-byte stores (32 contiguous bytes per token, 2 KB per wave)
+        constexpr int NB = (PK_ROWS / 8 + 7) / 8;
+        f4v va[NB], vb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int rc = min(8 * (wave + 8 * i), rows - 8);
+            va[i] = *reinterpret_cast<const f4v*>(ot + lane * PK_OSTRIDE + rc);
+            vb[i] = *reinterpret_cast<const f4v*>(ot + lane * PK_OSTRIDE + rc + 4);
+        }
+        bool badb = false;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) badb |= !(fabsf(va[i][u]) <= 3.0e38f) || !(fabsf(vb[i][u]) <= 3.0e38f);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r0 = 8 * (wave + 8 * i);
+            if (r0 < rows && colok) {
+                float* yb = g.y + (((int64_t)cb * (g.M >> 3) + ((16 * mt0 + r0) >> 3)) * n + ctk) * 8;
+                *reinterpret_cast<f4v*>(yb) = va[i];
+                *reinterpret_cast<f4v*>(yb + 4) = vb[i];
+            }
+        }
+        if (__any(badb && colok) && lane == 0 && g.redo) atomicOr(g.redo, 1);
+        return;
+    }
     const unsigned b0 = j0 / (unsigned)n;                                       // wave-uniform
     const unsigned ovoff = ((cb - b0) * (unsigned)g.M * (unsigned)n + ctk) * 4u;
     const int64_t obase = ((int64_t)b0 * g.M + 16 * mt0) * n;                   // wave-uniform
@@ -325,7 +363,7 @@ int launch_conv_pack(const float* wt, int K, int M, void* packed, hipStream_t st
 }
 
 // 1 if this device grants the kernel its 72 KB of dynamic LDS (asked once per device)
-static bool conv_pk_ready() {
+bool conv_pk_ready() {
     static int state[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
@@ -343,15 +381,16 @@ static bool conv_pk_ready() {
 // PATS_ERR_UNSUPPORTED: the device refused the LDS - the caller takes the unpacked kernels.
 int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0, int K1, int M, int n, int64_t cols,
                    const float* in_scale, const float* in_shift, const float* bias, const float* residual, float* y, int* redo,
-                   const int* gate, hipStream_t st) {
+                   const int* gate, hipStream_t st, int layout) {
     if (!conv_pk_ready()) return PATS_ERR_UNSUPPORTED;
+    PATS_REQUIRE(!((layout & 4) && residual), "conv_pk: no residual with a blocked output");
     const PkGeom q = pk_geom(K0 + K1);
     const int mtiles = (M + 15) / 16;
     // row groups of at most 17 tiles, evenly: 264 rows -> one group of 16 + the shared 17th; 528 -> 17 + 16; 128 -> 8
     const int groups = (mtiles + 16) / 17, tpg = (mtiles + groups - 1) / groups;
     const int64_t wgs = ((cols + PK_NC - 1) / PK_NC) * groups, per_xcd = (wgs + 7) / 8;
     PATS_REQUIRE(8 * per_xcd < (1ll << 31), "conv_pk: grid too large (split the batch)");
-    PkArgs g{(const h8v*)packed, x0, x1, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, wgs, per_xcd, in_scale, in_shift, bias, residual, y, redo, gate};
+    PkArgs g{(const h8v*)packed, x0, x1, layout, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, wgs, per_xcd, in_scale, in_shift, bias, residual, y, redo, gate};
     const dim3 grid((unsigned)(8 * per_xcd)), block(512);
     // (10..16 tiles take the 17-tile instantiation too: without the shared tile the same loop spills 29 registers at the 128 cap)
     if (tpg <= 8) hipLaunchKernelGGL((conv_pk_kernel<1, false>), grid, block, PK_LDS, st, g);

@@ -479,6 +479,38 @@ bn_partial_kernel(const float* __restrict__ h, int64_t batch, int C, int n, doub
     }
 }
 
+// The same partial sums over a channel-BLOCKED tensor [batch, C / 8, n, 8] (the hidden tensor between the packed-weights
+// convolutions, csrc/conv_pk.hip): grid (C / 8, BN_SPLITS); a batch's block is n x 8 contiguous floats, thread t walks the elements
+// t, t + 256, .. - always channel t & 7 - and the eight lanes' classes are folded with a fixed butterfly.
+__global__ void __launch_bounds__(256)
+bn_partial_blocked_kernel(const float* __restrict__ h, int64_t batch, int C, int n, double* __restrict__ part,
+                          const int* __restrict__ gate = nullptr) {
+    __shared__ double s1[4][8], s2[4][8];
+    if (gate && *gate == 0) return;
+    const int cb = blockIdx.x, split = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0.0, q = 0.0;
+    for (int64_t b = (int64_t)split * 4 + wave; b < batch; b += 4 * BN_SPLITS) {
+        const float* blk = h + (b * (C >> 3) + cb) * (int64_t)n * 8;
+        for (int t = lane; t < n * 8; t += 64) {
+            const double x = (double)blk[t];
+            a += x;
+            q += x * x;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) {         // fixed butterfly order over the lanes of one channel (lane & 7)
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+    }
+    if (lane < 8) { s1[wave][lane] = a; s2[wave][lane] = q; }
+    wg_barrier();
+    if (threadIdx.x < 8) {
+        const int c = cb * 8 + threadIdx.x, e = threadIdx.x;
+        part[((int64_t)c * BN_SPLITS + split) * 2 + 0] = (s1[0][e] + s1[1][e]) + (s1[2][e] + s1[3][e]);
+        part[((int64_t)c * BN_SPLITS + split) * 2 + 1] = (s2[0][e] + s2[1][e]) + (s2[2][e] + s2[3][e]);
+    }
+}
+
 __global__ void __launch_bounds__(64)
 bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const float* __restrict__ gamma,
                  const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
@@ -501,12 +533,12 @@ bn_finish_kernel(const double* __restrict__ part, int64_t total, int C, const fl
 // `redo`: one int of workspace, zero on entry (conv_lean_kernel raises it; see there).  null -> conv1x1_kernel only.
 int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0, int K1, int M, int n, int64_t cols,
                    const float* in_scale, const float* in_shift, const float* bias, const float* residual, float* y, int* redo,
-                   const int* gate, hipStream_t st);                                                        // conv_pk.hip
+                   const int* gate, hipStream_t st, int layout);                                            // conv_pk.hip
+bool conv_pk_ready();
 size_t conv_packed_bytes(int K, int M);
 size_t packed_fused_bytes(int C, int heads);                                                                // gnn_fused.hip
 
-// pk: this matrix packed for conv_pk_kernel (pats_propagation_pack_f32) or null
-static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr, const void* pk = nullptr) {
+static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr) {
     ConvArgs g = g0;
     g.gate = gate;
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
@@ -538,20 +570,6 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int*
         pd.state = ok ? 1 : -1;
     }
     const bool ws_lds_ok = pd.state == 1;
-    static const bool no_pk = [] { const char* e = getenv("PATS_CONV_PK"); return e && atoi(e) == 0; }();         // A/B switch
-    if (pk && lean && !no_pk) {
-        int rc = launch_conv_pk(pk, g.x0, g.x1, g.K0, g.K1, g.M, g.n, g.cols, g.in_scale, g.in_shift, g.bias, g.residual, g.y, redo, gate, st);
-        if (rc == PATS_ERR_UNSUPPORTED) return launch_conv(g0, redo, st, gate, nullptr);
-        if (rc) return rc;
-        g.redo = redo;
-        const bool r128 = g.M <= 128 || g.M % 128 == 0;
-        g.tile_rows = r128 ? 128 : mt::CT;
-        const int64_t tl = (int64_t)((g.M + g.tile_rows - 1) / g.tile_rows) * ((g.cols + mt::CT - 1) / mt::CT);
-        PATS_REQUIRE(tl < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
-        if (r128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), dim3((unsigned)tl), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((conv1x1_kernel<true, true>), dim3((unsigned)tl), dim3(256), 0, st, g);
-        return check_launch("conv1x1_kernel");
-    }
     const bool ws = lean && ws_mode != 0 && ws_lds_ok && ((Kt == 128 && !two) || (Kt == 256 && (!two || g.K0 == 128))) &&
                     g.cols * (int64_t)std::max(g.K0, 1) < (1ll << 31) && (g.cols >= 64 * 4096 || ws_mode == 2);
     if (ws) {
@@ -691,30 +709,51 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
             return rc;
         }
     }
-    // the six matrices packed for conv_pk_kernel (behind the fused layer's section); the gated fallback composition keeps
-    // the unpacked kernels
-    const char* pk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (packed && !gate) {
+    // Packed weights at any other shape (round 4): six conv_pk_kernel launches around the attention core, the message and the hidden
+    // tensor - the layer's own intermediates - channel-BLOCKED ([batch, C / 8, n, 8]: 16-byte accesses both ways).  No fp32 path in
+    // these kernels: a non-finite output anywhere raises ONE flag, and the round-2 composition below - gated on it, its kernels
+    // return at once otherwise - redoes the layer.  (residual == out: the redo would read what the first attempt wrote.)
+    static const bool no_pk = [] { const char* e = getenv("PATS_CONV_PK"); return e && atoi(e) == 0; }();         // A/B switch
+    static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
+    if (packed && !gate && !no_pk && !fp32_only && !(residual && residual == out) && conv_pk_ready() && batch * (int64_t)std::max(n, m) < (1ll << 31)) {
+        int* flag = redo + 7;
         const char* q0 = (const char*)packed + packed_fused_bytes(C, heads);
         const size_t cc = conv_packed_bytes(C, C);
-        for (int i = 0; i < 4; ++i) pk[i] = q0 + i * cc;
-        pk[4] = q0 + 4 * cc;
-        pk[5] = pk[4] + conv_packed_bytes(2 * C, 2 * C);
+        const char* pk4 = q0 + 4 * cc;
+        const char* pk5 = pk4 + conv_packed_bytes(2 * C, 2 * C);
+        if ((rc = launch_conv_pk(q0, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q, flag, nullptr, st, 0))) return rc;
+        if ((rc = launch_conv_pk(q0 + cc, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k, flag, nullptr, st, 0))) return rc;
+        if ((rc = launch_conv_pk(q0 + 2 * cc, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v, flag, nullptr, st, 0))) return rc;
+        // the attention core: at the fine level's shape with its scores in registers (attention145.hip), else the general kernel
+        rc = launch_attention145(q, k, v, batch, C / heads, heads, n, m, att, flag, nullptr, st);
+        if (rc == PATS_ERR_UNSUPPORTED) rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, nullptr);
+        if (rc) return rc;
+        if ((rc = launch_conv_pk(q0 + 3 * cc, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg, flag, nullptr, st, 4))) return rc;
+        if ((rc = launch_conv_pk(pk4, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid, flag, nullptr, st, 2 | 4))) return rc;
+        const float *sc = w->bn_a, *sh = w->bn_b;
+        if (bn_train) {
+            hipLaunchKernelGGL(bn_partial_blocked_kernel, dim3((unsigned)(2 * C / 8), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart,
+                               (const int*)nullptr);
+            hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, bpart, batch * (int64_t)n, 2 * C,
+                               w->bn_a, w->bn_b, bn_eps, bsc, bsh, (const int*)nullptr);
+            if ((rc = check_launch("bn_stats kernels"))) return rc;
+            sc = bsc; sh = bsh;
+        }
+        if ((rc = launch_conv_pk(pk5, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out, flag, nullptr, st, 1))) return rc;
+        gate = flag;             // the composition below runs only if one of the kernels above raised it
     }
+    // (as the gated fallback behind the fused layer / the packed-weights kernels: conv1x1_kernel alone - it has the fp32 redo inside -
+    //  i.e. nine empty launches per layer instead of fifteen)
     // projections (modules.py:101-102)
-    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, redo + 0, st, gate, pk[0]))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, redo + 1, st, gate, pk[1]))) return rc;
-    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, redo + 2, st, gate, pk[2]))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wq_t, x, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bq, nullptr, q}, gate ? nullptr : redo + 0, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wk_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bk, nullptr, k}, gate ? nullptr : redo + 1, st, gate))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wv_t, source, nullptr, C, 0, C, m, batch * m, nullptr, nullptr, w->bv, nullptr, v}, gate ? nullptr : redo + 2, st, gate))) return rc;
     // attention core (:103): the [b, C, n] projections ARE the [b, dim, heads, n] views
-    // at the fine level's shape: the fp16-split kernel with the scores in registers (attention145.hip), the general kernel queued
-    // behind it as its redo (a no-op unless an output came out non-finite)
-    rc = gate ? PATS_ERR_UNSUPPORTED : launch_attention145(q, k, v, batch, C / heads, heads, n, m, att, redo + 6, nullptr, st);
-    if (rc != PATS_OK && rc != PATS_ERR_UNSUPPORTED) return rc;
-    if ((rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, rc == PATS_OK ? redo + 6 : gate))) return rc;
+    if ((rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, gate))) return rc;
     // merge (:104)
-    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, redo + 3, st, gate, pk[3]))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->wm_t, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg}, gate ? nullptr : redo + 3, st, gate))) return rc;
     // mlp[0] on cat([x, message]) without the cat (:116, MLP :64)
-    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, redo + 4, st, gate, pk[4]))) return rc;
+    if ((rc = launch_conv(ConvArgs{w->w1_t, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid}, gate ? nullptr : redo + 4, st, gate))) return rc;
     // mlp[1] BatchNorm1d: eval -> the caller's folded running statistics (bn_a = scale, bn_b = shift);
     //                      train -> batch statistics with bn_a = gamma, bn_b = beta
     const float *sc = w->bn_a, *sh = w->bn_b;
@@ -726,7 +765,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         sc = bsc; sh = bsh;
     }
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
-    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, redo + 5, st, gate, pk[5]);
+    return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, gate ? nullptr : redo + 5, st, gate);
 }
 
 // ---- the building blocks on their own: Conv1d(kernel_size = 1) and the BatchNorm1d + ReLU that follows it in MLP ------
