@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 evidence run (on the GPU box, through gpurun): bench line, step-only kernel tables in both map layouts, the other
-# workloads, the fused GNN layer's trace and counters.  Writes gpurun_out/r04_*; the PMC / SQ passes have their own scripts
+# workloads, the fused GNN layer's trace and counters, the fine-level layer's trace and counters, the 10 %-wild step.  Writes gpurun_out/r04_*; the PMC / SQ passes have their own scripts
 # (tools/pmc_step.sh, tools/pmc_sq.sh, tools/fetch_patterns.sh).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -16,6 +16,9 @@ done
 bash $R/tools/pmc_gnn.sh > /dev/null 2>&1
 BN=train bash -c "cd /tmp; rm -rf /tmp/ktGt; BN=train rocprofv3 --kernel-trace --stats -d /tmp/ktGt -- python $R/tools/pmc_gnn.py > /dev/null 2>&1; python $R/tools/rocpd_stats.py \$(find /tmp/ktGt -name '*.db' | head -1) 'tools/pmc_gnn.py BN=train: 4 x ops.attentional_propagation(25 920 x [128,65], BatchNorm on batch statistics, residual)' > $O/r04_gnn_layer_train_kernel_stats.md 2>&1"
 python $R/tools/bench_gnn.py > $O/r04_gnn_layer.jsonl 2>/dev/null
+bash $R/tools/gnn_fine_trace.sh > /dev/null 2>&1
+bash $R/tools/pmc_gnn_fine.sh > /dev/null 2>&1
+bash $R/tools/step_profile.sh r04_wild10 --wild 0.1 > /dev/null 2>&1
 python - <<PY
 import json
 d = json.load(open("$O/r04_z_bench.json"))
