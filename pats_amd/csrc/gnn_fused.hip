@@ -174,22 +174,37 @@ __device__ __forceinline__ void ring_fill(const h8v* __restrict__ W, const int (
 
 // acc[m][nt] += W[row tile mts[m]] . src over KS k-steps (k-steps 0..3 from src0, 4..7 from src1); weights = A operand,
 // the ring holds k-steps 0..D-1 on entry
-template <int KS, int MT>
+template <int KS, int MT, bool PIPE = (MT == 1)>
 __device__ __forceinline__ void gemm_w(const h8v* __restrict__ W, const int (&mts)[MT], const char* src0, const char* src1,
                                        int lane, f4v (&acc)[MT][5], WRing<MT>& r) {
     constexpr int D = WRing<MT>::D;
+    // PIPE: the activations' fragments (B operand) of k-step ks + 1 are read from LDS while the MFMAs of k-step ks run - two
+    // register sets.  (With the reads and their MFMAs in one scheduling unit every k-step begins with an LDS round trip, two waves
+    // per SIMD: the one-row-tile stages ran 5-15 % longer, profiles/r04_gnn_fused_timeline.txt.)  Off where the registers are
+    // needed: two row tiles per wave - 30 MFMAs per k-step cover the round trip better anyway - and the last stage, which holds
+    // the next problem's inputs.
+    constexpr int NB = PIPE ? 2 : 1;
+    h8v bq[NB][5][2];
+    auto bload = [&](int ks, int buf) {
+        const char* blk = (ks < 4 ? src0 : src1) + ((ks & 3) * 2) * TF_BLK;
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            bq[buf][nt][0] = *reinterpret_cast<const h8v*>(blk + tf_tile_off(nt, lane));
+            bq[buf][nt][1] = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(nt, lane));
+        }
+    };
+    if (NB == 2) bload(0, 0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const char* blk = (ks < 4 ? src0 : src1) + ((ks & 3) * 2) * TF_BLK;
+        if (NB == 2) { if (ks + 1 < KS) bload(ks + 1, (ks + 1) & 1); }
+        else bload(ks, 0);
         h8v ah[MT], al[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) { ah[m] = r.a[ks % D][m][0]; al[m] = r.a[ks % D][m][1]; }
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) {
-            const h8v bh = *reinterpret_cast<const h8v*>(blk + tf_tile_off(nt, lane));
-            const h8v bl = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(nt, lane));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][nt] = mfma3(ah[m], al[m], bh, bl, acc[m][nt]);
+            for (int m = 0; m < MT; ++m) acc[m][nt] = mfma3(ah[m], al[m], bq[ks & (NB - 1)][nt][0], bq[ks & (NB - 1)][nt][1], acc[m][nt]);
         }
         if (ks + D < KS) {
 #pragma unroll
@@ -293,29 +308,39 @@ gnn_layer_fused_kernel(FusedArgs g) {
         wg_barrier();
         // ---- k = Wk' source (TF), v^T = source^T Wv'^T (token-major) -----------------------------------------------
         WRing<1> rv, rq, rm;
+        ring_fill<4, 1>(g.pw + PW_V, mt1, lane, rv);
         {
-            f4v acc[1][5];
-            zero_acc(acc);
-            gemm_w<4, 1>(g.pw + PW_K, mt1, lds + OFF_S, nullptr, lane, acc, rk);
-            ring_fill<4, 1>(g.pw + PW_V, mt1, lane, rv);
-            const f4v bias = load4(pb + PB_K + 16 * wave + 4 * qp);
+            // ONE loop for both products: a fragment of source read from LDS is the B operand of k's row tile (weights x source) and
+            // the A operand of v's channel tile (source^T x weights^T) - the two layouts coincide - so v costs no LDS read of its own
+            // (k, v + barrier 4.55 -> 3.7 us per problem)
+            f4v acck[5], acc[5];
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acc[0][nt] * UNS + bias, lane);
-        }
-        {
-            f4v acc[5];
-#pragma unroll
-            for (int tt = 0; tt < 5; ++tt) acc[tt] = f4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h8v wh = rv.a[ks][0][0], wl = rv.a[ks][0][1];
+            for (int tt = 0; tt < 5; ++tt) { acck[tt] = f4v{0.f, 0.f, 0.f, 0.f}; acc[tt] = f4v{0.f, 0.f, 0.f, 0.f}; }
+            h8v bq[2][5][2];
+            auto bload = [&](int ks, int buf) {
                 const char* blk = lds + OFF_S + (ks * 2) * TF_BLK;
 #pragma unroll
-                for (int tt = 0; tt < 5; ++tt) {
-                    const h8v sh = *reinterpret_cast<const h8v*>(blk + tf_tile_off(tt, lane));
-                    const h8v sl = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(tt, lane));
-                    acc[tt] = mfma3(sh, sl, wh, wl, acc[tt]);           // rows = tokens 16 tt + 4 q' + r, column = channel 16 w + j
+                for (int nt = 0; nt < 5; ++nt) {
+                    bq[buf][nt][0] = *reinterpret_cast<const h8v*>(blk + tf_tile_off(nt, lane));
+                    bq[buf][nt][1] = *reinterpret_cast<const h8v*>(blk + TF_BLK + tf_tile_off(nt, lane));
                 }
+            };
+            bload(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) bload(ks + 1, (ks + 1) & 1);
+                const h8v kh = rk.a[ks][0][0], kl = rk.a[ks][0][1], wh = rv.a[ks][0][0], wl = rv.a[ks][0][1];
+#pragma unroll
+                for (int tt = 0; tt < 5; ++tt) {
+                    acck[tt] = mfma3(kh, kl, bq[ks & 1][tt][0], bq[ks & 1][tt][1], acck[tt]);
+                    acc[tt] = mfma3(bq[ks & 1][tt][0], bq[ks & 1][tt][1], wh, wl, acc[tt]);   // rows = tokens 16 tt + 4 q' + r, column = channel 16 w + j
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const f4v bias = load4(pb + PB_K + 16 * wave + 4 * qp);
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acck[nt] * UNS + bias, lane);
             }
             ring_fill<4, 1>(g.pw + PW_Q, mt1, lane, rq);
             const float bias = pb[PB_V + 16 * wave + j];
@@ -498,7 +523,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
             }
             f4v acc[1][5];
             zero_acc(acc);
-            gemm_w<8, 1>(g.pw + PW_2, mt1, lds + OFF_S, lds + OFF_V, lane, acc, r2);
+            gemm_w<8, 1, false>(g.pw + PW_2, mt1, lds + OFF_S, lds + OFF_V, lane, acc, r2);
             ring_fill<4, 1>(g.pw + PW_K, mt1, lane, rk);           // the next problem's first stage
             const int ch = 16 * wave + 4 * qp;
             const f4v bias = load4(pb + PB_2 + ch);
@@ -569,7 +594,7 @@ gnn_tail_kernel(FusedArgs g, const float* __restrict__ scale, const float* __res
         wg_barrier();
         f4v acc[1][5];
         zero_acc(acc);
-        gemm_w<8, 1>(g.pw + PW_2, mt1, lds, lds + TF_BYTES, lane, acc, r2);
+        gemm_w<8, 1, false>(g.pw + PW_2, mt1, lds, lds + TF_BYTES, lane, acc, r2);
         const int ch = 16 * wave + 4 * qp;
         const f4v bias = load4(g.pb + PB_2 + ch);
         float* O = g.out + (b * GC + ch) * GN;
