@@ -18,14 +18,23 @@
 // Measured and not kept (round 4): 16-byte lane loads of four consecutive columns turned in LDS or by 4 x 4 DPP transposes (rows of
 // 145 floats: three quads in four are misaligned and pass the address unit no faster than four dwords - 510 / 680 us against 400
 // per [264 -> 264] product); a persistent grid that fetches the next tile under the epilogue (vmcnt is in order: the stash's wait for
-// those loads waits for the epilogue's stores too - 470 us).  Timeline of a workgroup (s_memrealtime, mean of 9 280): 5.5 us issuing its
+// those loads waits for the epilogue's stores too - 470 us); LOADER waves (one persistent 768-thread workgroup per CU, waves 8..11 fill
+// the other of two 72 KB stages with the next tile - 72 dword loads a lane in flight - while waves 0..7 multiply and store from
+// registers, one barrier per tile: 590-600 us, the same as ONE conv_pk workgroup per CU - four loader waves do not keep the vector
+// memory pipe as full as the eight of a second workgroup do, and the register stores of 16 columns a row are slower than the
+// LDS-turned rows of 64).  Timeline of a workgroup (s_memrealtime, mean of 9 280): 5.5 us issuing its
 // 40 dword loads per lane, 1.8 stash, 6.3 k loop (two workgroups share the matrix pipe), 3.3 at barriers, 2.5 epilogue: the vector
 // memory pipe (activations in and out at 4 bytes a lane, 360 KB of weights per tile) is what bounds it, not HBM and not the MFMAs.
 // Range: |activation| < 1023; a non-finite output raises *redo - the layer's one flag: the round-2 composition queued behind the
 // layer, gated on it, recomputes the whole layer (gnn.hip, propagation_impl).
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
+#ifdef PATS_DIAG
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace pats {
 
@@ -73,7 +82,18 @@ struct PkArgs {
     float* y;
     int* redo;
     const int* gate;
+#ifdef PATS_DIAG
+    int* tl;                   // diagnostic library: nine ints per workgroup - the phase durations of its thread 0 (10 ns units)
+#endif
 };
+
+// Diagnostic library only (python -m pats_amd.build --diag, PATS_AMD_DIAG_LIB=1, PATS_PK_TL=1): s_memrealtime stamps at the phase
+// boundaries of a workgroup; launch_conv_pk prints their means (tools/conv_pk_timeline.sh -> profiles/r04_gnn_fine_timeline.txt)
+#ifdef PATS_DIAG
+#define PK_TS(k) { __builtin_amdgcn_sched_barrier(0); T##k = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PK_TS(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ gptr_h8 uniform_ptr(const h8v* p) {
     const uint64_t v = (uint64_t)p;
@@ -117,6 +137,10 @@ conv_pk_kernel(PkArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (g.gate && *g.gate == 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef PATS_DIAG
+    long long T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0, T7 = 0, T8 = 0;
+#endif
+    PK_TS(0);
     const int qp = lane >> 4, j = lane & 15;
     // Workgroup i runs on XCD i % 8, each with its own L2: the logical tiles are dealt out so that every XCD walks ONE contiguous
     // range of columns (neighbouring tiles share the 128-byte lines their 145-float rows straddle; the row groups of one column
@@ -201,6 +225,7 @@ conv_pk_kernel(PkArgs g) {
                     }
                 }
             }
+            if (ps == 0) PK_TS(1);
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const int cg = wave + 8 * i, ch = cbase + cg * 8;
@@ -224,7 +249,9 @@ conv_pk_kernel(PkArgs g) {
                 }
             }
         }
+        if (ps == 0) PK_TS(2);
         wg_barrier();
+        if (ps == 0) PK_TS(3);
 
         PK_WLOAD(0, 0);
         if (KSPP > 1) PK_WLOAD(1, 1);
@@ -260,11 +287,13 @@ conv_pk_kernel(PkArgs g) {
         }
 #undef PK_WLOAD
     }
+    PK_TS(4);
 
     // ---- epilogue: the tile through LDS, COLUMN-major ([column][row], 276 floats apart: an accumulator's four rows are one 16-byte
     // write, a lane's four rows of its column one 16-byte read; 276 = 20 mod 64 spreads 16 lanes over all banks), then whole rows of
     // 64 columns per wave store ------------------------------------------------------------------------------------------------
     wg_barrier();
+    PK_TS(5);
     float* ot = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -275,6 +304,7 @@ conv_pk_kernel(PkArgs g) {
     }
     if (SH && has_sh) *reinterpret_cast<f4v*>(ot + (16 * wave + j) * PK_OSTRIDE + 16 * 8 * MT + 4 * qp) = accs * UNS;
     wg_barrier();
+    PK_TS(6);
     // wave w stores the row quads w, w + 8, ..: all its LDS reads (and residual loads) first, then the stores - no round trip per row.
     // Addresses: a wave-uniform row base + one 32-bit lane offset (the lane's problem relative to the tile's first, its token).
     const bool colok = j0 + lane < (unsigned)g.cols;
@@ -316,6 +346,7 @@ conv_pk_kernel(PkArgs g) {
         const int rc = min(4 * (wave + 8 * i), rows - 4);
         v[i] = *reinterpret_cast<const f4v*>(ot + lane * PK_OSTRIDE + rc);
     }
+    PK_TS(7);
     bool bad = false;
     if (g.residual) {
 #pragma unroll
@@ -344,6 +375,14 @@ conv_pk_kernel(PkArgs g) {
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(g.y + obase + (int64_t)(r0 + u) * n) + ovoff) = v[i][u];
         }
     }
+#ifdef PATS_DIAG
+    PK_TS(8);
+    if (g.tl && t == 0) {
+        int* o = g.tl + (size_t)lid * 9;
+        o[0] = (int)(T1 - T0); o[1] = (int)(T2 - T1); o[2] = (int)(T3 - T2); o[3] = (int)(T4 - T3); o[4] = (int)(T5 - T4);
+        o[5] = (int)(T6 - T5); o[6] = (int)(T7 - T6); o[7] = (int)(T8 - T7); o[8] = (int)(T0 & 0x7fffffff);
+    }
+#endif
     if (__any(bad) && lane == 0 && g.redo) atomicOr(g.redo, 1);
 }
 
@@ -391,11 +430,34 @@ int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0,
     const int64_t wgs = ((cols + PK_NC - 1) / PK_NC) * groups, per_xcd = (wgs + 7) / 8;
     PATS_REQUIRE(8 * per_xcd < (1ll << 31), "conv_pk: grid too large (split the batch)");
     PkArgs g{(const h8v*)packed, x0, x1, layout, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, wgs, per_xcd, in_scale, in_shift, bias, residual, y, redo, gate};
+#ifdef PATS_DIAG
+    g.tl = nullptr;
+    if (getenv("PATS_PK_TL") && !(layout & 4)) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * 9 * 4); (void)hipMemset(g.tl, 0, (size_t)wgs * 9 * 4); }
+#endif
     const dim3 grid((unsigned)(8 * per_xcd)), block(512);
     // (10..16 tiles take the 17-tile instantiation too: without the shared tile the same loop spills 29 registers at the 128 cap)
     if (tpg <= 8) hipLaunchKernelGGL((conv_pk_kernel<1, false>), grid, block, PK_LDS, st, g);
     else if (tpg == 9) hipLaunchKernelGGL((conv_pk_kernel<1, true>), grid, block, PK_LDS, st, g);
     else hipLaunchKernelGGL((conv_pk_kernel<2, true>), grid, block, PK_LDS, st, g);
+#ifdef PATS_DIAG
+    if (g.tl) {
+        (void)hipStreamSynchronize(st);
+        std::vector<int> h((size_t)wgs * 9);
+        (void)hipMemcpy(h.data(), g.tl, h.size() * 4, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        long long tmin = 1ll << 62, tmax = 0;
+        for (int64_t w = 0; w < wgs; ++w) {
+            for (int q8 = 0; q8 < 8; ++q8) sum[q8] += h[w * 9 + q8];
+            tmin = std::min<long long>(tmin, h[w * 9 + 8]);
+            tmax = std::max<long long>(tmax, h[w * 9 + 8]);
+        }
+        fprintf(stderr, "conv_pk timeline (K=%d M=%d, %lld workgroups, mean per workgroup, us): start->loads issued %.2f, ->stashed %.2f, ->barrier %.2f, "
+                        "->k loops %.2f, ->barrier %.2f, ->tile in LDS + barrier %.2f, ->read back %.2f, ->stores issued %.2f; first to last start %.1f us\n",
+                K0 + K1, M, (long long)wgs, sum[0] / wgs / 100, sum[1] / wgs / 100, sum[2] / wgs / 100, sum[3] / wgs / 100, sum[4] / wgs / 100,
+                sum[5] / wgs / 100, sum[6] / wgs / 100, sum[7] / wgs / 100, (tmax - tmin) / 100.0);
+        (void)hipFree(g.tl);
+    }
+#endif
     return check_launch("conv_pk_kernel");
 }
 
