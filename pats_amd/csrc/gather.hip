@@ -13,13 +13,36 @@
 // by consecutive lanes; source windows are short contiguous runs of a feature-map row (L2-resident).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace pats {
+
+// Cache policy of the gathers' accesses (round 4).  tools/granule_probe.hip -> profiles/r04_granule_probe.txt: the memory side always
+// moves whole 128-byte lines (32 bytes of every 128 cost what the whole line costs: the NCHW kernels' over-fetch is the layout's),
+// and NON-TEMPORAL loads of data used once stream 9 % faster than plain ones (6.28 against 5.74 TB/s dense).  In the kernels
+// (tools/gather_nt_ab.sh -> profiles/r04_gather_nt_ab.txt, inside the bench's steps): the CHANNELS-LAST kernels, whose outputs leave
+// as whole lines of a linear 16-byte stream, gain 6 % / 9 % from non-temporal STORES (4.10 -> 3.85, 2.94 -> 2.67 ms; non-temporal
+// loads alone change nothing there); the NCHW kernels LOSE with either - their taps re-visit lines through the L1 the policy
+// bypasses (6.2 -> 6.7, 4.9 -> 6.8 ms with such loads) and their 4-byte stores into rows of 145 / 65 floats end lines partially
+// (-> 7.3, 8.0 ms with such stores).  POL bit 0: map reads non-temporal; bit 1: output stores non-temporal.  Defaults: 0 on NCHW
+// maps, 3 on channels-last maps; PATS_GATHER_NT = 0..3 overrides both (read once per process).
+template <int POL, typename T>
+__device__ __forceinline__ T ldm(const T* p) {
+    if (POL & 1) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <int POL, typename T>
+__device__ __forceinline__ void stm(T* p, T v) {
+    if (POL & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 // ---- fine level ------------------------------------------------------------------------------
 // One 256-thread workgroup per stacked image n = s * B + b (left crops first).  Wave w takes channels w, w + 4, ...;
 // a lane owns the points l, l + 64, l + 128 (< 145) of every channel it visits, so the source offsets of the three maps are
 // computed ONCE per lane (no division in the channel loop) and a channel's 145 outputs leave as three coalesced stores.
 // The channel loop is split by source (title / map 0 / map 1 / map 2): wave-uniform, branch-free bodies.
+template <int POL>
 __global__ void __launch_bounds__(256)
 fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                  const float* __restrict__ f2, const float* __restrict__ title,
@@ -44,9 +67,9 @@ fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
     const bool dust = lane == 16;                              // group 2 of lane 16 is point 144: the dustbin feature column
     auto put = [&](int ch, float v0, float v1, float v2) {
         float* row = o + ch * 145;
-        row[lane] = v0;
-        row[lane + 64] = v1;
-        if (live[2]) row[lane + 128] = dust ? rubbish[b * 264 + ch] : v2;           // second_layer.py:83,85
+        stm<POL>(row + lane, v0);
+        stm<POL>(row + lane + 64, v1);
+        if (live[2]) stm<POL>(row + lane + 128, dust ? rubbish[b * 264 + ch] : v2);           // second_layer.py:83,85
     };
     for (int ch = wave; ch < 8; ch += 4) {                     // the 8-channel "title"                         :82,84
         const float v = title[b * 8 + ch];
@@ -59,7 +82,7 @@ fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const float* q = m + off0[g];
-            v[g] = (((q[0] + q[1]) + q[48]) + q[49]) / 4.0f;
+            v[g] = (((ldm<POL>(q) + ldm<POL>(q + 1)) + ldm<POL>(q + 48)) + ldm<POL>(q + 49)) / 4.0f;
         }
         put(ch, v[0], v[1], v[2]);
     }
@@ -70,14 +93,14 @@ fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const float* q = m + off1[g];
-            v[g] = (((q[0] + q[1]) + q[24]) + q[25]) / 4.0f;
+            v[g] = (((ldm<POL>(q) + ldm<POL>(q + 1)) + ldm<POL>(q + 24)) + ldm<POL>(q + 25)) / 4.0f;
         }
         put(ch, v[0], v[1], v[2]);
     }
 #pragma unroll 4
     for (int ch = 136 + wave; ch < 264; ch += 4) {             // map 2: [.,128,12,12], no pooling, sample (r, c)
         const float* m = f2 + (n * 128 + (ch - 136)) * 144;
-        put(ch, m[pt[0]], m[pt[1]], m[pt[2]]);
+        put(ch, ldm<POL>(m + pt[0]), ldm<POL>(m + pt[1]), ldm<POL>(m + pt[2]));
     }
 }
 
@@ -89,6 +112,7 @@ __device__ __forceinline__ long long round_half_even_div(float x, float d) {
 // one workgroup (256 threads = 4 waves) per point; wave w handles channels 32w .. 32w+31, eight at a time (sixteen
 // window loads in flight, then sixteen stores); lane = window cell.  The dustbin feature column is written once per wave
 // by 32 lanes (one channel each) instead of by lane 0 inside the channel loop.
+template <int POL>
 __global__ void __launch_bounds__(256)
 third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
                   const float* __restrict__ mk0, const float* __restrict__ mk1,
@@ -148,14 +172,14 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
         float a[8], c[8], ke[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            a[k] = src0[(int64_t)(c0 + k) * (M * M)];
-            c[k] = src1[(int64_t)(c0 + k) * (M * M)];
+            a[k] = ldm<POL>(src0 + (int64_t)(c0 + k) * (M * M));
+            c[k] = ldm<POL>(src1 + (int64_t)(c0 + k) * (M * M));
             ke[k] = kenc[(c0 + k) * 64 + lane];                                  // + self.kenc(kpts)   :139-140
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            o0[(c0 + k) * 65 + lane] = a[k] + ke[k];
-            o1[(c0 + k) * 65 + lane] = c[k] + ke[k];
+            stm<POL>(o0 + (c0 + k) * 65 + lane, a[k] + ke[k]);
+            stm<POL>(o1 + (c0 + k) * 65 + lane, c[k] + ke[k]);
         }
     }
     if (lane < 32) {
@@ -179,6 +203,7 @@ third_desc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
 // operation order per element as the NCHW kernels: bit-identical outputs (tests/test_gpu_parity.py).
 
 // one workgroup per (point, side): 64 pixels x 128 channels = 32 KB in, [128, 65] out
+template <int POL>
 __global__ void __launch_bounds__(256)
 third_desc_nhwc_kernel(const float* __restrict__ ff0, const float* __restrict__ ff1,
                        const float* __restrict__ mk0, const float* __restrict__ mk1,
@@ -226,8 +251,8 @@ third_desc_nhwc_kernel(const float* __restrict__ ff0, const float* __restrict__ 
         long long i = i00 + (2 * wave + (j >> 3)) * M + (j & 7);
         i = i < 0 ? 0 : (i > lim ? lim : i);          // memory safety (torch.gather would raise out of range)
         const float* src = ff + i * C;
-        v0[j] = src[lane];
-        v1[j] = src[lane + 64];
+        v0[j] = ldm<POL>(src + lane);
+        v1[j] = ldm<POL>(src + lane + 64);
     }
     // + self.kenc(kpts) rides on the way out: element e = c * 65 + n of the output takes kenc[c, n]       :139-140
     float ke[33];
@@ -247,14 +272,14 @@ third_desc_nhwc_kernel(const float* __restrict__ ff0, const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 33; ++r) {
         const int e = t + 256 * r, c = e / NT, n = e - c * NT;
-        if (e < C * NT) o[e] = n < 64 ? tile[e] + ke[r] : tile[e];
+        if (e < C * NT) stm<POL>(o + e, n < 64 ? tile[e] + ke[r] : tile[e]);
     }
 }
 
 // one workgroup per stacked image; the 264 output channels leave in four 64-channel tiles (map 0, map 1, the two halves of
 // map 2), each gathered with 16-byte loads - lane = (node % 4, four channels) - pooled in registers, turned in LDS and
 // copied out as float4.  `cpp` = channels per pixel of the map, `ch0` = first of the 64 channels this pass takes.
-template <int TAPS>
+template <int TAPS, int POL>
 __device__ __forceinline__ void fine_tile_pass(const float* __restrict__ img, int cpp, int ch0, int rowpix, int step, int first,
                                                float* tile, float* __restrict__ o, const float* __restrict__ rub, int t) {
     constexpr int NP = 145;
@@ -272,7 +297,7 @@ __device__ __forceinline__ void fine_tile_pass(const float* __restrict__ img, in
             const float* px = img + ((step * r + first) * rowpix + step * c + first) * cpp + ch0 + 4 * cg;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap)
-                q[g][tap] = *reinterpret_cast<const f4*>(px + ((tap >> 1) * rowpix + (tap & 1)) * cpp);
+                q[g][tap] = ldm<POL>(reinterpret_cast<const f4*>(px + ((tap >> 1) * rowpix + (tap & 1)) * cpp));
         }
 #pragma unroll
         for (int g = 0; g < GR; ++g) {
@@ -289,10 +314,11 @@ __device__ __forceinline__ void fine_tile_pass(const float* __restrict__ img, in
     wg_barrier();
     const f4* src = reinterpret_cast<const f4*>(tile);
     f4* dst = reinterpret_cast<f4*>(o);
-    for (int e = t; e < 64 * NP / 4; e += 256) dst[e] = src[e];
+    for (int e = t; e < 64 * NP / 4; e += 256) stm<POL>(dst + e, src[e]);
     wg_barrier();
 }
 
+template <int POL>
 __global__ void __launch_bounds__(256)
 fine_desc_nhwc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                       const float* __restrict__ f2, const float* __restrict__ title,
@@ -311,13 +337,26 @@ fine_desc_nhwc_kernel(const float* __restrict__ f0, const float* __restrict__ f1
         o[e] = p == 144 ? rub[ch] : title[b * 8 + ch];
     }
     // map 0 [.,48,48,64]: avgpool(2,1,1) -> 49x49, sample (4r+2, 4c+2) = mean of pixels (4r+1.., 4c+1..)
-    fine_tile_pass<4>(f0 + n * 48 * 48 * 64, 64, 0, 48, 4, 1, tile, o + 8 * NP, rub + 8, t);
+    fine_tile_pass<4, POL>(f0 + n * 48 * 48 * 64, 64, 0, 48, 4, 1, tile, o + 8 * NP, rub + 8, t);
     // map 1 [.,24,24,64]: avgpool -> 25x25, sample (2r+1, 2c+1) = mean of pixels (2r.., 2c..)
-    fine_tile_pass<4>(f1 + n * 24 * 24 * 64, 64, 0, 24, 2, 0, tile, o + 72 * NP, rub + 72, t);
+    fine_tile_pass<4, POL>(f1 + n * 24 * 24 * 64, 64, 0, 24, 2, 0, tile, o + 72 * NP, rub + 72, t);
     // map 2 [.,12,12,128]: no pooling, sample (r, c)
-    fine_tile_pass<1>(f2 + n * 144 * 128, 128, 0, 12, 1, 0, tile, o + 136 * NP, rub + 136, t);
-    fine_tile_pass<1>(f2 + n * 144 * 128, 128, 64, 12, 1, 0, tile, o + 200 * NP, rub + 200, t);
+    fine_tile_pass<1, POL>(f2 + n * 144 * 128, 128, 0, 12, 1, 0, tile, o + 136 * NP, rub + 136, t);
+    fine_tile_pass<1, POL>(f2 + n * 144 * 128, 128, 64, 12, 1, 0, tile, o + 200 * NP, rub + 200, t);
 }
+
+// PATS_GATHER_NT = 0..3 (see ldm / stm above), read once per process; without it 0 on NCHW maps, 3 on channels-last maps
+static int gather_policy(bool channels_last) {
+    static const int pol = [] { const char* e = getenv("PATS_GATHER_NT"); return e ? (atoi(e) & 3) : -1; }();
+    return pol >= 0 ? pol : (channels_last ? 3 : 0);
+}
+#define GATHER_LAUNCH(KERNEL, NHWC, grid, ...)                                                                                \
+    switch (gather_policy(NHWC)) {                                                                                           \
+        case 0: hipLaunchKernelGGL((KERNEL<0>), grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break;                  \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break;                  \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break;                  \
+        default: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break;                 \
+    }
 
 }  // namespace pats
 
@@ -329,7 +368,7 @@ extern "C" int pats_fine_descriptors_f32(const float* feat0, const float* feat1,
     PATS_REQUIRE(B >= 0, "fine_descriptors: bad shape");
     if (B == 0) return PATS_OK;
     PATS_REQUIRE(feat0 && feat1 && feat2 && title && rubbish && desc, "fine_descriptors: null pointer");
-    hipLaunchKernelGGL(fine_desc_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, as_stream(stream), feat0, feat1,
+    GATHER_LAUNCH(fine_desc_kernel, false, dim3((unsigned)(2 * B)), feat0, feat1,
                        feat2, title, rubbish, B, desc, (const int64_t*)nullptr);
     return check_launch("fine_desc_kernel");
 }
@@ -345,11 +384,11 @@ extern "C" int pats_fine_descriptors_counted_f32(const float* feat0, const float
     if (channels_last) {
         PATS_REQUIRE(((uintptr_t)feat0 | (uintptr_t)feat1 | (uintptr_t)feat2 | (uintptr_t)desc) % 16 == 0,
                      "fine_descriptors_counted: channels-last maps and desc must be 16-byte aligned");
-        hipLaunchKernelGGL(fine_desc_nhwc_kernel, dim3((unsigned)(2 * B_cap)), dim3(256), 0, as_stream(stream), feat0, feat1,
+        GATHER_LAUNCH(fine_desc_nhwc_kernel, true, dim3((unsigned)(2 * B_cap)), feat0, feat1,
                            feat2, title, rubbish, B_cap, desc, B_dev);
         return check_launch("fine_desc_nhwc_kernel");
     }
-    hipLaunchKernelGGL(fine_desc_kernel, dim3((unsigned)(2 * B_cap)), dim3(256), 0, as_stream(stream), feat0, feat1,
+    GATHER_LAUNCH(fine_desc_kernel, false, dim3((unsigned)(2 * B_cap)), feat0, feat1,
                        feat2, title, rubbish, B_cap, desc, B_dev);
     return check_launch("fine_desc_kernel");
 }
@@ -363,7 +402,7 @@ extern "C" int pats_third_descriptors_f32(const float* feat_f0, const float* fea
     if (P == 0) return PATS_OK;
     PATS_REQUIRE(feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
                  "third_descriptors: null pointer");
-    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)((P + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
+    GATHER_LAUNCH(third_desc_kernel, false, dim3((unsigned)((P + 7) / 8 * 8)), feat_f0, feat_f1,
                        mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P, B, out0, out1, p_s_out, p_t_out, (const int64_t*)nullptr);
     return check_launch("third_desc_kernel");
 }
@@ -377,7 +416,7 @@ extern "C" int pats_third_descriptors_counted_f32(const float* feat_f0, const fl
     if (P_cap == 0) return PATS_OK;
     PATS_REQUIRE(P_dev && feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
                  "third_descriptors_counted: null pointer");
-    hipLaunchKernelGGL(third_desc_kernel, dim3((unsigned)((P_cap + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), feat_f0, feat_f1,
+    GATHER_LAUNCH(third_desc_kernel, false, dim3((unsigned)((P_cap + 7) / 8 * 8)), feat_f0, feat_f1,
                        mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P_cap, B, out0, out1, p_s_out, p_t_out, P_dev);
     return check_launch("third_desc_kernel");
 }
@@ -390,7 +429,7 @@ extern "C" int pats_fine_descriptors_nhwc_f32(const float* feat0, const float* f
     PATS_REQUIRE(feat0 && feat1 && feat2 && title && rubbish && desc, "fine_descriptors_nhwc: null pointer");
     PATS_REQUIRE(((uintptr_t)feat0 | (uintptr_t)feat1 | (uintptr_t)feat2 | (uintptr_t)desc) % 16 == 0,
                  "fine_descriptors_nhwc: maps and desc must be 16-byte aligned");
-    hipLaunchKernelGGL(fine_desc_nhwc_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, as_stream(stream), feat0, feat1,
+    GATHER_LAUNCH(fine_desc_nhwc_kernel, true, dim3((unsigned)(2 * B)), feat0, feat1,
                        feat2, title, rubbish, B, desc, (const int64_t*)nullptr);
     return check_launch("fine_desc_nhwc_kernel");
 }
@@ -404,7 +443,7 @@ extern "C" int pats_third_descriptors_nhwc_f32(const float* feat_f0, const float
     if (P_cap == 0) return PATS_OK;
     PATS_REQUIRE(feat_f0 && feat_f1 && mkpts0_c && mkpts1_c && b_ids && kenc && rubbish && out0 && out1,
                  "third_descriptors_nhwc: null pointer");
-    hipLaunchKernelGGL(third_desc_nhwc_kernel, dim3((unsigned)((P_cap + 7) / 8 * 16)), dim3(256), 0, as_stream(stream), feat_f0,
+    GATHER_LAUNCH(third_desc_nhwc_kernel, true, dim3((unsigned)((P_cap + 7) / 8 * 16)), feat_f0,
                        feat_f1, mkpts0_c, mkpts1_c, b_ids, kenc, rubbish, P_cap, B, out0, out1, p_s_out, p_t_out, P_dev);
     return check_launch("third_desc_nhwc_kernel");
 }

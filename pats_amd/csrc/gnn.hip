@@ -537,6 +537,8 @@ int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0,
 bool conv_pk_ready();
 size_t conv_packed_bytes(int K, int M);
 size_t packed_fused_bytes(int C, int heads);                                                                // gnn_fused.hip
+bool gnn_fold_enabled();                                                                                    // (merge folded into mlp[0])
+const float* packed_folded_bias(const void* packed, int C, int heads);
 
 static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr) {
     ConvArgs g = g0;
@@ -728,8 +730,13 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         rc = launch_attention145(q, k, v, batch, C / heads, heads, n, m, att, flag, nullptr, st);
         if (rc == PATS_ERR_UNSUPPORTED) rc = launch_attention(q, k, v, batch, C / heads, heads, n, m, att, nullptr, stream, nullptr);
         if (rc) return rc;
-        if ((rc = launch_conv_pk(q0 + 3 * cc, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg, flag, nullptr, st, 4))) return rc;
-        if ((rc = launch_conv_pk(pk4, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid, flag, nullptr, st, 2 | 4))) return rc;
+        if (gnn_fold_enabled()) {
+            // the merge is folded into mlp[0]'s packed weights and bias (gnn_fold_kernel): hidden = W1x x + (W1m Wm) att + b1'
+            if ((rc = launch_conv_pk(pk4, x, att, C, C, 2 * C, n, batch * n, nullptr, nullptr, packed_folded_bias(packed, C, heads), nullptr, hid, flag, nullptr, st, 4))) return rc;
+        } else {
+            if ((rc = launch_conv_pk(q0 + 3 * cc, att, nullptr, C, 0, C, n, batch * n, nullptr, nullptr, w->bm, nullptr, msg, flag, nullptr, st, 4))) return rc;
+            if ((rc = launch_conv_pk(pk4, x, msg, C, C, 2 * C, n, batch * n, nullptr, nullptr, w->b1, nullptr, hid, flag, nullptr, st, 2 | 4))) return rc;
+        }
         const float *sc = w->bn_a, *sh = w->bn_b;
         if (bn_train) {
             hipLaunchKernelGGL(bn_partial_blocked_kernel, dim3((unsigned)(2 * C / 8), BN_SPLITS), dim3(256), 0, st, hid, batch, 2 * C, n, bpart,

@@ -232,9 +232,35 @@ __device__ __forceinline__ f4v load4(const float* p) { return f4v{p[0], p[1], p[
 
 }  // namespace
 
-// weights of one layer -> fragment order, split, head permutation.  One thread per (fragment, lane).
+// ---- merge folded into mlp[0] at pack time (round 4) ----------------------------------------------------------------------------
+// modules.py:104,116: message = Wm att + bm is consumed by ONE product, hidden = W1 (x | message) + b1.  With W1 = (W1x | W1m):
+//     hidden = W1x x + (W1m Wm) att + (W1m bm + b1)
+// so the layer needs no merge product at all once W1m Wm [2C x C] and the bias are formed - once per layer, here, in double, rounded
+// once to fp32 (the folded matrix then goes through the same split as every weight).  One Conv1d, its launch and two tensor passes
+// less per layer (the fused kernel: one stage and one barrier less); the result differs from the two-step form by fp32 rounding
+// only (1e-7 relative per term: the goldens' tolerance is 2e-4).  PATS_GNN_FOLD=0 (read once per process) keeps the two products.
+// w1f_t: [2C in][2C out] like w1_t - rows 0..C-1 = W1x, rows C.. = the folded matrix by attention channel; b1f [2C].
 __global__ void __launch_bounds__(256)
-gnn_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __restrict__ pb) {
+gnn_fold_kernel(pats_propagation_weights w, int C, float* __restrict__ w1f_t, float* __restrict__ b1f) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, M = 2 * C;
+    if (gid < M) {                                             // b1f[o] = b1[o] + sum_c W1[o][C + c] bm[c]
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) s += (double)w.w1_t[(int64_t)(C + c) * M + gid] * (double)w.bm[c];
+        b1f[gid] = (float)((double)w.b1[gid] + s);
+    }
+    if (gid >= M * M) return;
+    const int k = (int)(gid / M), o = (int)(gid - (int64_t)k * M);
+    if (k < C) { w1f_t[gid] = w.w1_t[gid]; return; }
+    const int i = k - C;                                       // attention channel: sum_c Wm[c][i] W1[o][C + c]
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += (double)w.wm_t[(int64_t)i * C + c] * (double)w.w1_t[(int64_t)(C + c) * M + o];
+    w1f_t[gid] = (float)s;
+}
+
+// weights of one layer -> fragment order, split, head permutation.  One thread per (fragment, lane).
+// fold: w.w1_t / w.b1 are the folded ones and mlp[0]'s second operand is the ATTENTION slot, whose channels are head-major.
+__global__ void __launch_bounds__(256)
+gnn_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __restrict__ pb, int fold) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid < PB_END) {                       // biases (q / k / v in head-major order)
         const int i = gid & 127, pi = (i & 31) * 4 + (i >> 5);
@@ -254,7 +280,7 @@ gnn_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __restr
     int base;
     if (f < 4 * 32) { const int mat = f >> 5; wt = mat == 0 ? w.wq_t : mat == 1 ? w.wk_t : mat == 2 ? w.wv_t : w.wm_t;
                       K = 128; M = 128; mt = (f & 31) >> 2; ks = f & 3; mode = mat == 3 ? 2 : 1; base = mat * 32 * FR; }
-    else if (f < 4 * 32 + 128) { const int g = f - 128; wt = w.w1_t; K = 256; M = 256; mt = g >> 3; ks = g & 7; mode = 0; base = PW_1; }
+    else if (f < 4 * 32 + 128) { const int g = f - 128; wt = w.w1_t; K = 256; M = 256; mt = g >> 3; ks = g & 7; mode = fold ? 3 : 0; base = PW_1; }
     else { const int g = f - 256; wt = w.w2_t; K = 256; M = 128; mt = g >> 3; ks = g & 7; mode = 0; base = PW_2; }
     (void)K;
     int row = mt * 16 + (lane & 15);
@@ -264,6 +290,7 @@ gnn_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __restr
     for (int e = 0; e < 8; ++e) {
         int k = ks * 32 + 8 * (lane >> 4) + e;
         if (mode == 2) k = (k & 31) * 4 + (k >> 5);
+        if (mode == 3 && k >= 128) k = 128 + ((k - 128) & 31) * 4 + ((k - 128) >> 5);
         const float s = wt[(int64_t)k * M + row] * PRE;
         const _Float16 h = (_Float16)s;
         hi[e] = h;
@@ -275,7 +302,7 @@ gnn_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __restr
     pw[base + fl * FR + 64 + lane] = lo;
 }
 
-template <bool TRAIN>
+template <bool TRAIN, bool FOLD>
 __global__ void __launch_bounds__(512, 1)
 gnn_layer_fused_kernel(FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -438,11 +465,15 @@ gnn_layer_fused_kernel(FusedArgs g) {
                 store_tf(lds + OFF_S, 2 * h + dt, qt, o * (UNS * inv), lane);
             }
         }
-        ring_fill<4, 1>(g.pw + PW_M, mt1, lane, rm);              // under the barrier wait
-        wg_barrier();
-        // ---- message = Wm' attention + bm, into the slot k leaves --------------------------------------------------------
         WRing<2> r1;
-        {
+        if (FOLD) {
+            // (the merge is folded into mlp[0]'s weights, gnn_fold_kernel: no message stage)
+            ring_fill<8, 2>(g.pw + PW_1, mt2, lane, r1);          // under the barrier wait
+            wg_barrier();
+        } else {
+            ring_fill<4, 1>(g.pw + PW_M, mt1, lane, rm);          // under the barrier wait
+            wg_barrier();
+            // ---- message = Wm' attention + bm, into the slot k leaves ----------------------------------------------------
             f4v acc[1][5];
             zero_acc(acc);
             gemm_w<4, 1>(g.pw + PW_M, mt1, lds + OFF_S, nullptr, lane, acc, rm);
@@ -450,15 +481,17 @@ gnn_layer_fused_kernel(FusedArgs g) {
             const f4v bias = load4(pb + PB_M + 16 * wave + 4 * qp);
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acc[0][nt] * UNS + bias, lane);
+            wg_barrier();
         }
-        wg_barrier();
-        // ---- hidden = W1 (x | message) + b1: row tiles w (-> slot of q) and w + 8 (-> slot of v) -------------------------------
+        // ---- hidden = W1 (x | message) + b1: row tiles w and w + 8.  FOLD: (x | attention) with the folded weights; the attention
+        //      slot (q's) is still being read while the first waves finish, so hidden[0:128] goes to the slot k left, not to q's ------
+        constexpr int OFF_H0 = FOLD ? OFF_K : OFF_S;
         WRing<1> r2;
         f4v res[5];
         {
             f4v acc[2][5];
             zero_acc(acc);
-            gemm_w<8, 2>(g.pw + PW_1, mt2, lds + OFF_X, lds + OFF_K, lane, acc, r1);
+            gemm_w<8, 2>(g.pw + PW_1, mt2, lds + OFF_X, lds + (FOLD ? OFF_S : OFF_K), lane, acc, r1);
             if (!TRAIN) {
                 ring_fill<8, 1>(g.pw + PW_2, mt1, lane, r2);
                 if (g.residual) {                                  // the residual rows of this lane's outputs, ahead of mlp[3]
@@ -509,7 +542,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
                         f4v v = (acc[m][nt] * UNS + bias) * sc + sh;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];        // ReLU that keeps NaN
-                        store_tf(lds + (m == 0 ? OFF_S : OFF_V), wave, nt, v, lane);
+                        store_tf(lds + (m == 0 ? OFF_H0 : OFF_V), wave, nt, v, lane);
                     }
                 }
             }
@@ -523,7 +556,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
             }
             f4v acc[1][5];
             zero_acc(acc);
-            gemm_w<8, 1, false>(g.pw + PW_2, mt1, lds + OFF_S, lds + OFF_V, lane, acc, r2);
+            gemm_w<8, 1, false>(g.pw + PW_2, mt1, lds + OFF_H0, lds + OFF_V, lane, acc, r2);
             ring_fill<4, 1>(g.pw + PW_K, mt1, lane, rk);           // the next problem's first stage
             const int ch = 16 * wave + 4 * qp;
             const f4v bias = load4(pb + PB_2 + ch);
@@ -639,11 +672,23 @@ size_t packed_fused_bytes(int C, int heads) {
 }
 size_t conv_packed_bytes(int K, int M);                                                                     // conv_pk.hip
 int launch_conv_pack(const float* wt, int K, int M, void* packed, hipStream_t st);
+// merge folded into mlp[0] (gnn_fold_kernel): on unless PATS_GNN_FOLD=0; the same answer at pack time and at run time
+bool gnn_fold_enabled() {
+    static const bool on = [] { const char* e = getenv("PATS_GNN_FOLD"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+static size_t packed_matrices_bytes(int C, int heads) {
+    return packed_fused_bytes(C, heads) + 4 * conv_packed_bytes(C, C) + conv_packed_bytes(2 * C, 2 * C) + conv_packed_bytes(2 * C, C);
+}
+// behind the packed matrices: the folded fp32 weights [2C][2C] and bias [2C] (the bias is read at run time)
+const float* packed_folded_bias(const void* packed, int C, int heads) {
+    return (const float*)((const char*)packed + packed_matrices_bytes(C, heads)) + (size_t)4 * C * C;
+}
 }
 
 extern "C" size_t pats_propagation_packed_bytes(int C, int heads) {
     if (C <= 0 || heads <= 0 || (C % 8) != 0 || (C % heads) != 0) return 0;
-    return packed_fused_bytes(C, heads) + 4 * conv_packed_bytes(C, C) + conv_packed_bytes(2 * C, 2 * C) + conv_packed_bytes(2 * C, C);
+    return packed_matrices_bytes(C, heads) + ((size_t)4 * C * C + 2 * C) * sizeof(float);
 }
 
 extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
@@ -654,11 +699,23 @@ extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int 
                  "propagation_pack: null weight pointer");
     PATS_REQUIRE(((uintptr_t)packed & 15) == 0, "propagation_pack: the buffer must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
+    pats_propagation_weights wf = *w;
+    const bool fold = gnn_fold_enabled();
+    if (fold) {
+        float* w1f = (float*)((char*)packed + packed_matrices_bytes(C, heads));
+        float* b1f = w1f + (size_t)4 * C * C;
+        hipLaunchKernelGGL(gnn_fold_kernel, dim3((unsigned)(((int64_t)4 * C * C + 255) / 256)), dim3(256), 0, st, *w, C, w1f, b1f);
+        int rc = check_launch("gnn_fold_kernel");
+        if (rc) return rc;
+        wf.w1_t = w1f;
+        wf.b1 = b1f;
+    }
+    w = &wf;
     if (packed_fused_bytes(C, heads)) {
         h8v* pw = (h8v*)packed;
         float* pb = (float*)(pw + PW_END);
         const int threads = (PW_END / FR) * 64;
-        hipLaunchKernelGGL(gnn_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *w, pw, pb);
+        hipLaunchKernelGGL(gnn_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *w, pw, pb, fold ? 1 : 0);
         int rc = check_launch("gnn_pack_kernel");
         if (rc) return rc;
     }
@@ -685,8 +742,10 @@ int launch_fused_layer(const float* x, const float* source, int64_t batch, const
     PerDevice& pd = per_dev[dev_id];
     if (pd.state == 0) {
         const bool ok = hipFuncSetAttribute((const void*)gnn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TF_BYTES) == hipSuccess &&
-                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
-                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
+                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_layer_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         int v = 256;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) (void)hipGetLastError();
@@ -698,8 +757,11 @@ int launch_fused_layer(const float* x, const float* source, int64_t batch, const
     FusedArgs g{x, source, residual, out, hid, pw, (const float*)(pw + PW_END), bn_a, bn_b, batch, flag, bn_part};
     const unsigned grid = (unsigned)std::min<int64_t>(batch, std::min(pd.n_cu, FUSED_MAX_GRID));
     if (splits_out) *splits_out = (int)grid;
-    if (bn_train) hipLaunchKernelGGL(gnn_layer_fused_kernel<true>, dim3(grid), dim3(512), FUSED_LDS, st, g);
-    else hipLaunchKernelGGL(gnn_layer_fused_kernel<false>, dim3(grid), dim3(512), FUSED_LDS, st, g);
+    const bool fold = gnn_fold_enabled();
+    if (bn_train && fold) hipLaunchKernelGGL((gnn_layer_fused_kernel<true, true>), dim3(grid), dim3(512), FUSED_LDS, st, g);
+    else if (bn_train) hipLaunchKernelGGL((gnn_layer_fused_kernel<true, false>), dim3(grid), dim3(512), FUSED_LDS, st, g);
+    else if (fold) hipLaunchKernelGGL((gnn_layer_fused_kernel<false, true>), dim3(grid), dim3(512), FUSED_LDS, st, g);
+    else hipLaunchKernelGGL((gnn_layer_fused_kernel<false, false>), dim3(grid), dim3(512), FUSED_LDS, st, g);
     return check_launch("gnn_layer_fused_kernel");
 }
 

@@ -11,6 +11,12 @@
 // stores); source taps of one output row fall in at most two source rows, served by L1/L2.
 #include "common.hpp"
 
+#include <cstdlib>
+
+#ifndef PATS_CROPS_NT_DEFAULT
+#define PATS_CROPS_NT_DEFAULT 1
+#endif
+
 namespace pats {
 
 // ---- bounds + ordered compaction of the matched patches --------------------------------------
@@ -118,6 +124,7 @@ imgs_bounds_batch_kernel(const float* __restrict__ x_scale, const float* __restr
 }
 
 // ---- left crops: 96x96 windows on the fixed grid of the 32-px zero-padded left image ---------
+template <bool NT>
 __global__ void __launch_bounds__(288)
 left_crops_kernel(const float* __restrict__ left_all, int n_img, int H, int W, const int64_t* __restrict__ bound5,
                   int width, float* __restrict__ out, const int64_t* __restrict__ K_dev) {
@@ -152,7 +159,8 @@ left_crops_kernel(const float* __restrict__ left_all, int n_img, int H, int W, c
                 }
             }
         }
-        *reinterpret_cast<f4s*>(o + y * 288 + 4 * j) = v;
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4s*>(o + y * 288 + 4 * j));
+        else *reinterpret_cast<f4s*>(o + y * 288 + 4 * j) = v;
     }
 }
 
@@ -221,6 +229,7 @@ resize_chw_kernel(const float* __restrict__ input, int n_img, int C, int Hp, int
 
 // HWC unpadded source [n_img,H,W,3] with a virtual zero margin, HWC output [K,96,96,3]:
 // fuses F.pad (utils.py:1352), the NCHW permute and the caller's permute(0,2,3,1) (utils.py:1385)
+template <bool NT>
 __global__ void __launch_bounds__(256)
 resize_hwc_kernel(const float* __restrict__ right, int n_img, int H, int W, int margin,
                   const int64_t* __restrict__ bound, float* __restrict__ out,
@@ -255,11 +264,21 @@ resize_hwc_kernel(const float* __restrict__ right, int n_img, int H, int W, int 
         const Tap ty = make_tap(sh, oy, ih), tx = make_tap(sw, ox, iw);
         const int y = y0 + ty.i1, x = x0 + tx.i1;
         const Px p00 = at(y, x), p01 = at(y, x + tx.ip), p10 = at(y + ty.ip, x), p11 = at(y + ty.ip, x + tx.ip);
-        float* d = o + oy * 288 + 3 * ox;
-        d[0] = ty.l0 * (tx.l0 * p00.r + tx.l1 * p01.r) + ty.l1 * (tx.l0 * p10.r + tx.l1 * p11.r);
-        d[1] = ty.l0 * (tx.l0 * p00.g + tx.l1 * p01.g) + ty.l1 * (tx.l0 * p10.g + tx.l1 * p11.g);
-        d[2] = ty.l0 * (tx.l0 * p00.b + tx.l1 * p01.b) + ty.l1 * (tx.l0 * p10.b + tx.l1 * p11.b);
+        typedef float f3a __attribute__((ext_vector_type(3), aligned(4)));
+        const f3a d = {ty.l0 * (tx.l0 * p00.r + tx.l1 * p01.r) + ty.l1 * (tx.l0 * p10.r + tx.l1 * p11.r),
+                       ty.l0 * (tx.l0 * p00.g + tx.l1 * p01.g) + ty.l1 * (tx.l0 * p10.g + tx.l1 * p11.g),
+                       ty.l0 * (tx.l0 * p00.b + tx.l1 * p01.b) + ty.l1 * (tx.l0 * p10.b + tx.l1 * p11.b)};
+        f3a* dp = reinterpret_cast<f3a*>(o + oy * 288 + 3 * ox);       // one 12-byte store: a wave's 64 pixels are 768 contiguous bytes
+        if (NT) __builtin_nontemporal_store(d, dp);
+        else *dp = d;
     }
+}
+
+// the crops are written once and read by another kernel much later (2.3 GB per side and step): non-temporal stores of whole
+// lines (see gather.hip).  PATS_CROPS_NT = 0 / 1, read once per process.
+static bool crops_nt() {
+    static const bool nt = [] { const char* e = getenv("PATS_CROPS_NT"); return e ? atoi(e) != 0 : PATS_CROPS_NT_DEFAULT != 0; }();
+    return nt;
 }
 
 }  // namespace pats
@@ -285,8 +304,10 @@ extern "C" int pats_left_crops_f32(const float* left, int n_img, int H, int W, c
     PATS_REQUIRE(K >= 0 && n_img > 0 && H > 0 && W > 0 && height > 0 && width > 0, "left_crops: bad shape");
     if (K == 0) return PATS_OK;
     PATS_REQUIRE(left && bound5 && out, "left_crops: null pointer");
-    hipLaunchKernelGGL(left_crops_kernel, dim3((unsigned)K, 12), dim3(288), 0, as_stream(stream),
-                       left, n_img, H, W, bound5, width, out, (const int64_t*)nullptr);
+    if (crops_nt()) hipLaunchKernelGGL(left_crops_kernel<true>, dim3((unsigned)K, 12), dim3(288), 0, as_stream(stream),
+                                       left, n_img, H, W, bound5, width, out, (const int64_t*)nullptr);
+    else hipLaunchKernelGGL(left_crops_kernel<false>, dim3((unsigned)K, 12), dim3(288), 0, as_stream(stream),
+                            left, n_img, H, W, bound5, width, out, (const int64_t*)nullptr);
     return check_launch("left_crops_kernel");
 }
 
@@ -310,8 +331,10 @@ extern "C" int pats_left_crops_counted_f32(const float* left, int n_img, int H, 
     PATS_REQUIRE(K_cap >= 0 && n_img > 0 && H > 0 && W > 0 && height > 0 && width > 0, "left_crops_counted: bad shape");
     if (K_cap == 0) return PATS_OK;
     PATS_REQUIRE(left && bound5 && out && K_dev, "left_crops_counted: null pointer");
-    hipLaunchKernelGGL(left_crops_kernel, dim3((unsigned)K_cap, 12), dim3(288), 0, as_stream(stream),
-                       left, n_img, H, W, bound5, width, out, K_dev);
+    if (crops_nt()) hipLaunchKernelGGL(left_crops_kernel<true>, dim3((unsigned)K_cap, 12), dim3(288), 0, as_stream(stream),
+                                       left, n_img, H, W, bound5, width, out, K_dev);
+    else hipLaunchKernelGGL(left_crops_kernel<false>, dim3((unsigned)K_cap, 12), dim3(288), 0, as_stream(stream),
+                            left, n_img, H, W, bound5, width, out, K_dev);
     return check_launch("left_crops_kernel");
 }
 
@@ -333,8 +356,10 @@ extern "C" int pats_tensor_resize_hwc_f32(const float* right, int n_img, int H, 
     PATS_REQUIRE(K >= 0 && n_img > 0 && H > 0 && W > 0 && margin >= 0, "tensor_resize_hwc: bad shape");
     if (K == 0) return PATS_OK;
     PATS_REQUIRE(right && bound && out, "tensor_resize_hwc: null pointer");
-    hipLaunchKernelGGL(resize_hwc_kernel, dim3((unsigned)K, 4), dim3(256), 0, as_stream(stream), right,
-                       n_img, H, W, margin, bound, out, status, (const int64_t*)nullptr);
+    if (crops_nt()) hipLaunchKernelGGL(resize_hwc_kernel<true>, dim3((unsigned)K, 4), dim3(256), 0, as_stream(stream), right,
+                                       n_img, H, W, margin, bound, out, status, (const int64_t*)nullptr);
+    else hipLaunchKernelGGL(resize_hwc_kernel<false>, dim3((unsigned)K, 4), dim3(256), 0, as_stream(stream), right,
+                            n_img, H, W, margin, bound, out, status, (const int64_t*)nullptr);
     return check_launch("resize_hwc_kernel");
 }
 
@@ -344,7 +369,9 @@ extern "C" int pats_tensor_resize_hwc_counted_f32(const float* right, int n_img,
     PATS_REQUIRE(K_cap >= 0 && n_img > 0 && H > 0 && W > 0 && margin >= 0, "tensor_resize_hwc_counted: bad shape");
     if (K_cap == 0) return PATS_OK;
     PATS_REQUIRE(right && bound && out && K_dev, "tensor_resize_hwc_counted: null pointer");
-    hipLaunchKernelGGL(resize_hwc_kernel, dim3((unsigned)K_cap, 4), dim3(256), 0, as_stream(stream), right,
-                       n_img, H, W, margin, bound, out, status, K_dev);
+    if (crops_nt()) hipLaunchKernelGGL(resize_hwc_kernel<true>, dim3((unsigned)K_cap, 4), dim3(256), 0, as_stream(stream), right,
+                                       n_img, H, W, margin, bound, out, status, K_dev);
+    else hipLaunchKernelGGL(resize_hwc_kernel<false>, dim3((unsigned)K_cap, 4), dim3(256), 0, as_stream(stream), right,
+                            n_img, H, W, margin, bound, out, status, K_dev);
     return check_launch("resize_hwc_kernel");
 }
