@@ -21,7 +21,10 @@ namespace pats {
 namespace {
 
 // column addressing for mfma_tile.hpp's CmSrc: A = d0 [D][n] at columns i0.., B = d1 [D][m] at columns j0.. (clamped)
-struct CostCols {
+// STREAM: the main loop's operand loads non-temporal (an experiment switch, PATS_COST_NT: see launch_cost)
+template <bool STREAM>
+struct CostColsT {
+    static constexpr bool stream = STREAM;
     int n, m, i0, j0;
     __device__ __forceinline__ int64_t a_off(int c) const { return min(i0 + c, n - 1); }
     __device__ __forceinline__ int64_t b_off(int c) const { return min(j0 + c, m - 1); }
@@ -31,7 +34,7 @@ struct CostCols {
 
 }  // namespace
 
-template <bool SPLIT>
+template <bool SPLIT, bool STREAM = false>
 __global__ void __launch_bounds__(256, 2)
 cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D, int n, int m,
                  float rsqrtD, float sqrtD, float* __restrict__ out, const int64_t* __restrict__ live) {
@@ -43,6 +46,7 @@ cost_mfma_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int
     if (live && b >= *live) return;            // counted launch (throughput mode): problems past the device-side count
     const int tt = (int)(blockIdx.x - b * tiles);
     const int i0 = (tt / tiles_j) * mt::CT, j0 = (tt % tiles_j) * mt::CT;
+    typedef CostColsT<STREAM> CostCols;
     const CostCols cols{n, m, i0, j0};
     mt::CmSrc<CostCols> src(d0 + b * (int64_t)D * n, n, d1 + b * (int64_t)D * m, m, D, cols, t);
     float* O = out + b * (int64_t)n * m;
@@ -96,8 +100,11 @@ int pats::launch_cost(const float* d0, const float* d1, int64_t batch, int D, in
     static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
     const float sq = (float)sqrt((double)D);
     const dim3 grid((unsigned)(tiles * batch)), block(256);
+    static const bool nt = [] { const char* e = getenv("PATS_COST_NT"); return e && atoi(e) != 0; }();
     if (fp32_only)
         hipLaunchKernelGGL(cost_mfma_kernel<false>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out, live);
+    else if (nt)
+        hipLaunchKernelGGL((cost_mfma_kernel<true, true>), grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out, live);
     else
         hipLaunchKernelGGL(cost_mfma_kernel<true>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out, live);
     return check_launch("cost_mfma_kernel");

@@ -48,6 +48,7 @@ struct ConvArgs {
 // flattened (batch, token) columns j0..: tile column c -> element offset of channel 0 in a [batch, Kc, n] tensor.  The
 // decomposition is 32-bit (launch_conv requires batch * n < 2^31) and done once per item, not per chunk.
 struct ConvCols {
+    static constexpr bool stream = false;
     int i0, M, n, Kc;          // Kc: channels of THIS activation tensor (its batch stride is Kc * n)
     int64_t j0, cols;
     __device__ __forceinline__ int64_t a_off(int c) const { return min(i0 + c, M - 1); }

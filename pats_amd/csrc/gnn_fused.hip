@@ -51,7 +51,6 @@ constexpr int TF_BYTES = 4 * 2 * TF_BLK;          // [128 x 65] tensor: 33 280
 constexpr int TT_ROW = 68;                        // tokens per channel row of the token-major copy (65 + zero padding)
 constexpr int TT_PLANE = GC * TT_ROW * 2;         // bytes of its hi (or lo) plane
 constexpr int OFF_X = 0, OFF_S = TF_BYTES, OFF_K = 2 * TF_BYTES, OFF_V = 3 * TF_BYTES;
-constexpr int FUSED_LDS = 3 * TF_BYTES + 2 * TT_PLANE;        // 134 656
 constexpr int FUSED_MAX_GRID = 512;                           // workgroups of the persistent grid = partial-sum slots per channel
 
 // packed weights (units of h8v = 16 bytes): fragment (row tile mt, k-step ks) = [hi | lo][64 lanes]
@@ -60,6 +59,7 @@ constexpr int PW_Q = 0, PW_K = PW_Q + 8 * 4 * FR, PW_V = PW_K + 8 * 4 * FR, PW_M
               PW_2 = PW_1 + 16 * 8 * FR, PW_END = PW_2 + 8 * 8 * FR;
 // biases behind them (floats): bq', bk', bv' (head-major), bm, b1 [256], b2
 constexpr int PB_Q = 0, PB_K = 128, PB_V = 256, PB_M = 384, PB_1 = 512, PB_2 = 768, PB_END = 896;
+constexpr int FUSED_LDS = 3 * TF_BYTES + 2 * TT_PLANE;        // 134 656
 
 struct FusedArgs {
     const float* x;
@@ -86,12 +86,22 @@ __device__ __forceinline__ void split4(const f4v v, h4v& hi, h4v& lo) {
     lo = __builtin_convertvector(s - __builtin_convertvector(hi, f4v), h4v);
 }
 
-// rows 16 mt + 4 q' + r (r = 0..3) of token 16 nt + j -> the TF tensor at dst
+// the same for a value that already carries the factor PRE (the epilogues fold it - a power of two - into their one fma)
+__device__ __forceinline__ void split4_pre(const f4v s, h4v& hi, h4v& lo) {
+    hi = __builtin_convertvector(s, h4v);
+    lo = __builtin_convertvector(s - __builtin_convertvector(hi, f4v), h4v);
+}
+__device__ __forceinline__ f4v fma4(const f4v a, const f4v b, const f4v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f4v bcast4(float x) { return f4v{x, x, x, x}; }
+
+// rows 16 mt + 4 q' + r (r = 0..3) of token 16 nt + j -> the TF tensor at dst.  PRESCALED: v = PRE x the value
+template <bool PRESCALED = false>
 __device__ __forceinline__ void store_tf(char* dst, int mt, int nt, const f4v v, int lane) {
     const int qp = lane >> 4, j = lane & 15;
     if (nt == 4 && j != 0) return;
     h4v hi, lo;
-    split4(v, hi, lo);
+    if (PRESCALED) split4_pre(v, hi, lo);
+    else split4(v, hi, lo);
     const int kq = 2 * (mt & 1) + (qp >> 1);
     const int off = ((mt >> 1) * 2) * TF_BLK + (nt < 4 ? nt * 1024 + (kq * 16 + j) * 16 : 4096 + kq * 16) + (qp & 1) * 8;
     *reinterpret_cast<h4v*>(dst + off) = hi;
@@ -365,20 +375,21 @@ gnn_layer_fused_kernel(FusedArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             {
-                const f4v bias = load4(pb + PB_K + 16 * wave + 4 * qp);
+                // (acc UNS + bias) PRE in one fma: the same bits as mul, add, mul - the two factors are powers of two
+                const f4v bias = load4(pb + PB_K + 16 * wave + 4 * qp) * PRE;
 #pragma unroll
-                for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_K, wave, nt, acck[nt] * UNS + bias, lane);
+                for (int nt = 0; nt < 5; ++nt) store_tf<true>(lds + OFF_K, wave, nt, fma4(acck[nt], bcast4(UNS * PRE), bias), lane);
             }
             ring_fill<4, 1>(g.pw + PW_Q, mt1, lane, rq);
-            const float bias = pb[PB_V + 16 * wave + j];
+            const float bias = pb[PB_V + 16 * wave + j] * PRE;
             char* vrow = lds + OFF_V + ((16 * wave + j) * TT_ROW) * 2;
 #pragma unroll
             for (int tt = 0; tt < 5; ++tt) {
-                f4v v = acc[tt] * UNS + bias;
+                f4v v = fma4(acc[tt], bcast4(UNS * PRE), bcast4(bias));
                 if (tt == 4) { v.y = 0.f; v.z = 0.f; v.w = 0.f; }       // tokens 65..67: zero padding (rows 1.. alias token 64)
                 if (tt < 4 || qp == 0) {
                     h4v hi, lo;
-                    split4(v, hi, lo);
+                    split4_pre(v, hi, lo);
                     *reinterpret_cast<h4v*>(vrow + (16 * tt + 4 * qp) * 2) = hi;
                     *reinterpret_cast<h4v*>(vrow + TT_PLANE + (16 * tt + 4 * qp) * 2) = lo;
                 }
@@ -390,9 +401,9 @@ gnn_layer_fused_kernel(FusedArgs g) {
             f4v acc[1][5];
             zero_acc(acc);
             gemm_w<4, 1>(g.pw + PW_Q, mt1, lds + OFF_X, nullptr, lane, acc, rq);
-            const f4v bias = load4(pb + PB_Q + 16 * wave + 4 * qp);
+            const f4v bias = load4(pb + PB_Q + 16 * wave + 4 * qp) * PRE;
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) store_tf(lds + OFF_S, wave, nt, acc[0][nt] * UNS + bias, lane);
+            for (int nt = 0; nt < 5; ++nt) store_tf<true>(lds + OFF_S, wave, nt, fma4(acc[0][nt], bcast4(UNS * PRE), bias), lane);
         }
         wg_barrier();
         // ---- attention: unit = (head, 16-query tile); its output replaces its own q tile -----------------------------
@@ -462,7 +473,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
                     const h8v vl = {a0l.x, a0l.y, a0l.z, a0l.w, a1l.x, a1l.y, a1l.z, a1l.w};
                     o = mfma3(vh, vl, ph[kk], pl[kk], o);                                  // rows = channels, column = query
                 }
-                store_tf(lds + OFF_S, 2 * h + dt, qt, o * (UNS * inv), lane);
+                store_tf<true>(lds + OFF_S, 2 * h + dt, qt, o * (UNS * PRE * inv), lane);
             }
         }
         WRing<2> r1;
@@ -516,7 +527,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
                     f4v p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int nt = 0; nt < 5; ++nt) {
-                        const f4v v = acc[m][nt] * UNS + bias;
+                        const f4v v = fma4(acc[m][nt], bcast4(UNS), bias);            // = acc UNS + bias bit for bit (UNS is a power of two)
                         if (nt < 4 || j == 0) {
                             p1 = p1 + v;
                             p2 = p2 + v * v;
@@ -536,13 +547,16 @@ gnn_layer_fused_kernel(FusedArgs g) {
                         st2[m][r] += (double)a2;
                     }
                 } else {
+                    // bias, BatchNorm affine and the split's factor in ONE fma per value: ((acc UNS + bias) sc + sh) PRE =
+                    // acc (sc UNS PRE) + (bias sc + sh) PRE (mul, add, mul, add, mul before: -ffp-contract=off; the ReLU commutes with PRE)
                     const f4v sc = load4(g.bn_a + ch), sh = load4(g.bn_b + ch);
+                    const f4v scl = sc * (UNS * PRE), shf = (bias * sc + sh) * PRE;
 #pragma unroll
                     for (int nt = 0; nt < 5; ++nt) {
-                        f4v v = (acc[m][nt] * UNS + bias) * sc + sh;
+                        f4v v = fma4(acc[m][nt], scl, shf);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];        // ReLU that keeps NaN
-                        store_tf(lds + (m == 0 ? OFF_H0 : OFF_V), wave, nt, v, lane);
+                        store_tf<true>(lds + (m == 0 ? OFF_H0 : OFF_V), wave, nt, v, lane);
                     }
                 }
             }
@@ -564,7 +578,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) {
                 if (nt < 4 || j == 0) {
-                    const f4v v = acc[0][nt] * UNS + bias;
+                    const f4v v = fma4(acc[0][nt], bcast4(UNS), bias);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float o = v[r];
@@ -635,7 +649,7 @@ gnn_tail_kernel(FusedArgs g, const float* __restrict__ scale, const float* __res
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt) {
             if (nt < 4 || j == 0) {
-                const f4v v = acc[0][nt] * UNS + bias;
+                const f4v v = fma4(acc[0][nt], bcast4(UNS), bias);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float o = v[r];

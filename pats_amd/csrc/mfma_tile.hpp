@@ -291,7 +291,7 @@ struct CmSrc {
 #pragma unroll
             for (int q = 0; q < SQ; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[q][e] = p[q][e * ld[q]];
+                for (int e = 0; e < 4; ++e) r[q][e] = Cols::stream ? __builtin_nontemporal_load(p[q] + e * ld[q]) : p[q][e * ld[q]];
         } else {
 #pragma unroll
             for (int q = 0; q < SQ; ++q)

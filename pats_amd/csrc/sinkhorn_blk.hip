@@ -116,6 +116,7 @@ __device__ __forceinline__ float row16_max(float v) {
 // this variant is built for two workgroups per CU (256 VGPRs): tools/fine_fusion_probe.py measured the sweeps of the
 // unfused kernel at that occupancy within 1-3 % of three workgroups per CU.
 struct FineCols {
+    static constexpr bool stream = false;
     __device__ __forceinline__ int64_t a_off(int c) const { return c < N_ ? c : N_ - 1; }
     __device__ __forceinline__ int64_t b_off(int c) const { return c < N_ ? c : N_ - 1; }
     __device__ __forceinline__ bool row_stored(int r) const { return r < N_; }

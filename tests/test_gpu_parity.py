@@ -1349,6 +1349,44 @@ print("OK")
         assert np.array_equal(res["2"][k], res["0"][k]), k          # same split, same MFMA order: the same bits
 
 
+def test_merge_folded_into_mlp0_against_the_two_product_form(ops, oracle):
+    """Round 4: pats_propagation_pack_f32 folds the merge Conv1d into mlp[0] (W1m Wm and W1m bm + b1 formed once per layer in
+    double, csrc/gnn_fused.hip gnn_fold_kernel); PATS_GNN_FOLD=0 keeps modules.py:104,116 as two products.  Both forms against
+    the oracle (which runs the two products), and against each other at fp32 rounding level - third-level shape (fused kernel,
+    eval and batch statistics), fine-level shape (conv_pk path) and a small ragged one.  Subprocesses: the switch is read once."""
+    import subprocess
+    import tempfile
+    code = r'''
+import sys, os, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+from pats_amd import ops, synth
+import pats_oracle as oracle
+cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+out = {}
+for tag, C, b, n in (("third", 128, 9, 65), ("fine", 264, 5, 145), ("small", 64, 3, 37)):
+    p = synth.gnn_params(seed=11 + C, C=C); i = synth.gnn_inputs(seed=12 + C, b=b, C=C, n=n)
+    P = ops.PropagationParams(p)
+    for train in (False, True):
+        y = ops.attentional_propagation(cu(i["x"]), cu(i["source"]), P, bn_train=train, residual=cu(i["x"])).cpu().numpy()
+        want = oracle.attentional_propagation(i["x"], i["source"], p, bn_train=train, residual=i["x"])
+        np.testing.assert_allclose(y, want, atol=1e-4, rtol=2e-4)
+        out["%%s%%d" %% (tag, train)] = y
+np.savez(sys.argv[1], **out)
+print("OK")
+''' % (REPO, REPO)
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("1", "0"):
+            path = os.path.join(d, "o%s.npz" % mode)
+            p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, PATS_GNN_FOLD=mode), capture_output=True,
+                               text=True, timeout=900)
+            assert p.returncode == 0 and "OK" in p.stdout, mode + ": " + p.stdout[-500:] + p.stderr[-2000:]
+            res[mode] = dict(np.load(path))
+    for k in res["1"]:
+        assert not np.array_equal(res["1"][k], res["0"][k]), k         # the switch took effect: a different rounding somewhere
+        np.testing.assert_allclose(res["1"][k], res["0"][k], atol=2e-5, rtol=2e-5, err_msg=k)
+
+
 def test_conv1d_edge_cases(ops, oracle):
     rng = np.random.default_rng(4)
     # no bias, ragged channel counts (K = 5 is padded to 8 inside), residual, folded input affine + ReLU
