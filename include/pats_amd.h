@@ -498,6 +498,11 @@ int pats_attentional_propagation_f32(const float* x, const float* source, int64_
  *    (csrc/conv_pk.hip: 64 columns x up to 288 input channels staged whole in LDS per workgroup) and, between 97 and 160 tokens
  *    with 33 .. 80 channels per head (the fine level: [264, 145], 4 heads), the attention core keeps its scores in registers
  *    from the first product to the second (csrc/attention145.hip).
+ * The packing also FOLDS the merge Conv1d into mlp[0] (modules.py:104,116: message = Wm att + bm has one consumer, hidden = W1
+ * (x | message) + b1 = W1x x + (W1m Wm) att + (W1m bm + b1)): W1m Wm and the bias are formed once, in double, and kept - as fp32
+ * [2C][2C] + [2C] - at the end of the packed buffer; the packed layer runs five products instead of six and differs from the
+ * two-product form by fp32 rounding only (PATS_GNN_FOLD=0, read at pack time and at run time, keeps the merge as its own product).
+ * The weights must not change between the packing and the calls that use it.
  * PATS_GNN_FUSED=0 / PATS_CONV_PK=0 / PATS_ATTN145=0 and launches in which an activation left the fp16 range of the split
  * operands take the composition above (same workspace; device-side flags, no host read). */
 size_t pats_propagation_packed_bytes(int C, int heads);
