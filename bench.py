@@ -835,7 +835,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # PATS_BENCH_FORCE_DIST=1 (a test knob): initialise the process group under a launcher even with ONE rank, so that a 1-GPU box
+    # runs every collective of the multi-rank path (barrier, all_reduce, all_gather, shard.gather_matches) over RCCL itself
+    if world > 1 or (os.environ.get("PATS_BENCH_FORCE_DIST") and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -1103,7 +1105,7 @@ def main():
         }
     if rank == 0:
         assert res is not None, "rank 0 owns no pair"
-        if n_gpus > 1:
+        if dist is not None:
             res["gather_bytes"] = gather_bytes
         res["value_" + args.maps] = value
         if not args.no_secondary and n_gpus == 1:

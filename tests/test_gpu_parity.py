@@ -960,6 +960,30 @@ def test_bench_spawns_its_own_ranks(ops, sinkhorn_mode):
     assert two["matches_per_pair"] > 1000
 
 
+def test_bench_under_a_launcher_over_rccl_with_one_rank(ops, sinkhorn_mode):
+    """The driver's multi-GPU command line (`python -m torch.distributed.run ... bench.py --gpus N`) with N = 1 and
+    PATS_BENCH_FORCE_DIST=1: the process group is initialised over RCCL (backend "nccl") on this one GPU and every collective of
+    the N > 1 path runs on it - barrier, all_reduce(MAX), all_gather, shard.gather_matches (all_gather_into_tensor / gather).  A
+    1-GPU box cannot host two RCCL ranks; this is as much of the real transport as it can exercise."""
+    import json
+    import subprocess
+    if sinkhorn_mode != "kernel":
+        pytest.skip("once is enough")
+    env = dict(os.environ, PATS_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PATS_BENCH_BACKEND", "PATS_BENCH_SHARE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", "2",
+           "--no-cpu-baseline", "--no-secondary"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["matches_per_pair"] > 1000 and d["gather_bytes"] > 0
+    assert "nccl" in json.dumps(d), "the line should name the backend the gather ran on"
+
+
 def test_flags_from_the_ot_epilogue_and_the_expansion(ops, oracle):
     """est_position's two flag vectors without an argmax pass (first_layer.py:162-167, second_layer.py:243-248):
     if_nomatching2 from the 145 x 145 Sinkhorn epilogue (or the colmass pass), if_nomatching1 from the expansion
