@@ -1014,6 +1014,10 @@ int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, 
                   uint8_t* col_nomatch, hipStream_t st, const int64_t* live = nullptr);     // sinkhorn_blk.hip
 int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_nomatch, const int* only_if,
                      hipStream_t st);                       // post.hip
+bool fine_w2_enabled();                                     // sinkhorn_blk2w.hip: the two-wave form of the same kernel
+int launch_blk145_w2(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu, const float* ns,
+                     const float* one, int iters, float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st,
+                     const int64_t* live);
 }
 
 // 145 x 145: the register-block kernel solves in the linear domain and flags the problems whose
@@ -1026,7 +1030,8 @@ static int launch_fine145(int mode, const float* Z, int64_t batch, const float* 
     static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;      // A/B switch for benchmarking
     const bool blk = use_linear() && iters > 0 && fail && !v1_only;
     if (blk) {
-        int rc = launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st, live);
+        int rc = fine_w2_enabled() ? launch_blk145_w2(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st, live)
+                                   : launch_blk145(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st, live);
         if (rc) return rc;
     }
     if (mode == 0)

@@ -1683,41 +1683,79 @@ print("OK", d, trips)
         assert p.returncode != 0 and "libpats_amd_diag.so" in p.stderr, variant
 
 
+FUSED_FINE_CHILD = r"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, %(repo)r)
+from pats_amd import ops
+cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+forced_log = os.environ.get("PATS_TEST_SINKHORN_MODE") == "log"
+if forced_log:
+    ops.set_sinkhorn_mode("log")
+bitwise = os.environ.get("PATS_FINE_W2") == "0" or forced_log
+rng = np.random.default_rng(31)
+B, D = 300, 264
+base = rng.standard_normal((B, D, 145)).astype(np.float32)
+d0 = (3.0 * (base + 0.3 * rng.standard_normal((B, D, 145)))).astype(np.float32)
+d1 = (3.0 * (base + 0.3 * rng.standard_normal((B, D, 145)))).astype(np.float32)
+d0[:, :, -1] *= 0.5
+d1[:, :, -1] *= 0.5
+wild = [7, 150, 299]
+d0[wild] *= 12.0                                          # scores x 144: far outside the linear-domain guard band
+d1[wild] *= 12.0
+ns = np.exp(0.3 * rng.standard_normal((B, 1, 144))).astype(np.float32)
+ops.sinkhorn_fallbacks(reset=True)
+prev = ops.set_fine_fused(True)
+
+def same(a, b, what):
+    if bitwise:
+        assert torch.equal(a, b), what + ": differ in %%d problems" %% int((a != b).flatten(1).any(1).sum())
+    else:       # the two-wave kernel sums in another order: the mass gate of the parity tests
+        ea, eb = torch.exp(a.double()), torch.exp(b.double())
+        assert torch.allclose(ea, eb, atol=1e-4, rtol=5e-6), what + ": %%g" %% float((ea - eb).abs().max())
+
+for bias in (2.0, 0.0):
+    Zf, flags = ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=bias, return_flags=True)
+    trips = ops.sinkhorn_fallbacks(reset=True)
+    S = ops.cost(cu(d0), cu(d1))
+    Zu = ops.log_optimal_transport2(S, 1.0, cu(ns), 100, bias_k=bias)
+    ops.sinkhorn_fallbacks(reset=True)
+    if not forced_log:
+        assert trips >= len(wild)                       # (the forced log domain has no guard to trip)
+    same(Zf, Zu, "fused and two-kernel log-plans")
+    want_flags = Zf[:, -1, :-1] > Zf[:, :-1, :-1].max(1).values          # second_layer.py:243,248
+    assert torch.equal(flags, want_flags)
+    assert torch.equal(ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=bias), Zf)      # without the flags
+    ops.set_fine_fused(False)
+    Z2, flags2 = ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=bias, return_flags=True)      # the default path
+    ops.set_fine_fused(True)
+    same(Z2, Zf, "default path and fused kernel")
+    assert torch.equal(flags2, Z2[:, -1, :-1] > Z2[:, :-1, :-1].max(1).values)               # every plan's flags are its own
+    if bitwise:
+        assert torch.equal(flags2, flags)
+    else:
+        assert float((flags2 != flags).float().mean()) < 1e-4                                 # a flag may flip only on a near-tie
+ops.set_fine_fused(prev)
+sys.path.insert(0, os.path.join(%(repo)r, "oracle"))
+import pats_oracle as oracle
+n = 6
+want = oracle.log_optimal_transport2(oracle.cost(d0[:n], d1[:n]), 1.0, ns[:n], 100)
+np.testing.assert_allclose(np.exp(Zf[:n].cpu().numpy().astype(np.float64)), np.exp(want.astype(np.float64)), atol=1e-4, rtol=5e-6)
+np.testing.assert_allclose(np.exp(Z2[:n].cpu().numpy().astype(np.float64)), np.exp(want.astype(np.float64)), atol=1e-4, rtol=5e-6)
+print("OK")
+"""
+
+
 def test_fused_fine_level_cost_ot_is_the_two_kernel_path_bit_for_bit(ops, oracle, sinkhorn_mode):
     """ops.cost_ot at 145 x 145 (the fused kernel: MFMA cost tile -> register blocks through an LDS band buffer -> sweeps ->
-    epilogue, scores never in HBM) against ops.cost + ops.log_optimal_transport2 on the same descriptors: every bit of the
-    log-plan and the column flags, with problems that leave the guard band (the fused kernel hands their raw scores to the
-    log-domain kernel in place), and a slice against the oracle."""
-    rng = np.random.default_rng(31)
-    B, D = 300, 264
-    base = rng.standard_normal((B, D, 145)).astype(np.float32)
-    d0 = (3.0 * (base + 0.3 * rng.standard_normal((B, D, 145)))).astype(np.float32)
-    d1 = (3.0 * (base + 0.3 * rng.standard_normal((B, D, 145)))).astype(np.float32)
-    d0[:, :, -1] *= 0.5
-    d1[:, :, -1] *= 0.5
-    wild = [7, 150, 299]
-    d0[wild] *= 12.0                                          # scores x 144: far outside the linear-domain guard band
-    d1[wild] *= 12.0
-    ns = np.exp(0.3 * rng.standard_normal((B, 1, 144))).astype(np.float32)
-    ops.sinkhorn_fallbacks(reset=True)
-    prev = ops.set_fine_fused(True)
-    for bias in (2.0, 0.0):
-        Zf, flags = ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=bias, return_flags=True)
-        trips = ops.sinkhorn_fallbacks(reset=True)
-        S = ops.cost(cu(d0), cu(d1))
-        Zu = ops.log_optimal_transport2(S, 1.0, cu(ns), 100, bias_k=bias)
-        ops.sinkhorn_fallbacks(reset=True)
-        if sinkhorn_mode == "kernel":
-            assert trips >= len(wild)                       # (the forced log domain has no guard to trip)
-        assert torch.equal(Zf, Zu), "fused and two-kernel log-plans differ in %d problems" % int((Zf != Zu).flatten(1).any(1).sum())
-        want_flags = Zf[:, -1, :-1] > Zf[:, :-1, :-1].max(1).values          # second_layer.py:243,248
-        assert torch.equal(flags, want_flags)
-        assert torch.equal(ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=bias), Zf)      # without the flags
-        ops.set_fine_fused(False)
-        Z2, flags2 = ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=bias, return_flags=True)      # the default path
-        ops.set_fine_fused(True)
-        assert torch.equal(Z2, Zf) and torch.equal(flags2, flags)
-    ops.set_fine_fused(prev)
-    n = 6
-    want = oracle.log_optimal_transport2(oracle.cost(d0[:n], d1[:n]), 1.0, ns[:n], 100)
-    np.testing.assert_allclose(np.exp(Zf[:n].cpu().numpy().astype(np.float64)), np.exp(want.astype(np.float64)), atol=1e-4, rtol=5e-6)
+    epilogue, scores never in HBM) against ops.cost + ops.log_optimal_transport2 on the same descriptors, with problems that leave
+    the guard band (the fused kernel hands their raw scores to the log-domain kernel in place).  Every bit of the log-plan and the
+    column flags against the FOUR-wave kernel it shares its sweep loop with (PATS_FINE_W2=0: a child process, the switch is read
+    once), and under the mass gate against the two-wave kernel that is the default since round 4 (another summation order)."""
+    import subprocess
+    env = dict(os.environ)
+    if sinkhorn_mode != "kernel":
+        env["PATS_TEST_SINKHORN_MODE"] = "log"
+    for w2 in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", FUSED_FINE_CHILD % {"repo": REPO}], env=dict(env, PATS_FINE_W2=w2), capture_output=True,
+                           text=True, timeout=900)
+        assert p.returncode == 0 and "OK" in p.stdout, "PATS_FINE_W2=" + w2 + ": " + p.stdout[-500:] + p.stderr[-2500:]
