@@ -979,11 +979,11 @@ def main():
         # fine level: descriptors in, log-plan out
         f_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * rows_step
         f_ach = f_by / (fine_ms * 1e-3) / 1e9
-        f_parts = [traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145_kernel")[0]]
+        f_parts = [traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145")[0]]
         f_traffic = float(sum(f_parts)) if all(v is not None for v in f_parts) else None
-        fine_roof = {"bound": "hbm", "kernel": "fine-level launch pair as timed inside the steps: cost_mfma_kernel + sinkhorn_blk145_kernel (%d x 145x145 = the row capacity, %d rows in use)"
+        fine_roof = {"bound": "hbm", "kernel": "fine-level launch pair as timed inside the steps: cost_mfma_kernel + sinkhorn_blk145[w2]_kernel (%d x 145x145 = the row capacity, %d rows in use)"
                      % (cap.rows_cap, rows_step), "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_ach / HBM_PEAK_GBS,
-                     "traffic": f_traffic, "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145_kernel: includes the "
+                     "traffic": f_traffic, "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145[w2]_kernel: includes the "
                      "score matrix written by the first and read by the second)", "traffic_source": pmc_src if f_traffic is not None else None,
                      "algorithmic_bytes_per_launch": f_by, "avg_launch_ms": fine_ms, "launches": int(len(ev["fine"])),
                      "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * rows_step / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
@@ -998,22 +998,27 @@ def main():
             s_ms = float(np.mean([m_.elapsed_time(b_) for (_, b_), m_ in zip(ev["fine"], ev["fine_mid"])]))
             fine_split = (c_ms, s_ms)
         split_roofs = []
+        w2 = os.environ.get("PATS_FINE_W2", "1") != "0"
+        fine_kernel = "sinkhorn_blk145w2_kernel<2>" if w2 else "sinkhorn_blk145_kernel<2>"
         if fine_split is not None:
             c_ms, s_ms = fine_split
             c_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * rows_step
             s_by = (2.0 * 145 * 145 * 4 + 144 * 4) * rows_step
             c_tr = traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0]
-            s_tr = traffic_of("pats::sinkhorn_blk145_kernel")[0]
+            s_tr = traffic_of("pats::sinkhorn_blk145")[0]
             split_roofs = [
-                {"bound": "hbm", "kernel": "sinkhorn_blk145_kernel<2> (fine-level OT: %d x 145x145 in use of a capacity of %d, 100 sweeps)" % (rows_step, cap.rows_cap),
+                {"bound": "hbm", "kernel": "%s (fine-level OT: %%d x 145x145 in use of a capacity of %%d, 100 sweeps)" % fine_kernel % (rows_step, cap.rows_cap),
                  "achieved": s_by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "traffic": s_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if s_tr is not None else None,
                  "algorithmic_bytes_per_launch": s_by, "avg_launch_ms": s_ms, "launches": int(len(ev["fine"])),
                  "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * rows_step / (s_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
                  "timed": "inside the timed steps (event recorded between the two launches of the one C call); in-step pair %.3f ms" % fine_ms,
                  "note": "scores in, log-plan out (2 x 145 x 145 fp32 per problem); HBM is the nearer allowed roofline but not the limiter: "
-                         "100 sweeps on register-resident 9x9 blocks, VALU issue (valu_frac = sweep FMA flops / 157.3 TF/s; 203 "
-                         "instructions per wave and sweep, 85 of them packed FMAs)"},
+                         "100 sweeps on register-resident blocks, VALU issue (valu_frac = sweep FMA flops / 157.3 TF/s).  "
+                         + ("Two waves per problem, 9 x 18 blocks: 295 VALU instructions per wave and sweep, 164 of them packed FMAs, "
+                            "one barrier; VALU 73 % busy at two waves per SIMD" if w2 else
+                            "Four waves per problem, 9 x 9 blocks (PATS_FINE_W2=0): 208 VALU instructions per wave and sweep, 75 of them "
+                            "packed, three barriers; VALU 95 % busy")},
                 {"bound": "hbm", "kernel": "cost_mfma_kernel<true> (fine-level cost build: %d x [264,145]^2 in use of a capacity of %d)" % (rows_step, cap.rows_cap),
                  "achieved": c_by / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_by / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "traffic": c_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if c_tr is not None else None,
