@@ -1411,6 +1411,80 @@ print("OK")
         np.testing.assert_allclose(res["1"][k], res["0"][k], atol=2e-5, rtol=2e-5, err_msg=k)
 
 
+W2_CHILD = r"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, %(repo)r)
+from pats_amd import ops
+cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+rng = np.random.default_rng(91)
+B = 256
+out = {}
+# (a) log_optimal_transport2: tame scores, three biases, 1 / 3 / 100 sweeps; a few problems far outside the guard band and one
+#     with -inf entries (both leave through the fail flag and the re-solve)
+S = (2.0 * rng.standard_normal((B, 145, 145))).astype(np.float32)
+S[5] *= 70.0
+S[77] *= 90.0
+S[130, 3, 40:60] = -np.inf
+ns = np.exp(0.4 * rng.standard_normal((B, 1, 144))).astype(np.float32)
+ops.sinkhorn_fallbacks(reset=True)
+for bias in (0.0, 2.0, 3.0):
+    for iters in (1, 3, 100):
+        out["ot2_b%%g_i%%d" %% (bias, iters)] = ops.log_optimal_transport2(cu(S), 1.0, cu(ns), iters, bias_k=bias).cpu().numpy()
+out["trips"] = np.array([ops.sinkhorn_fallbacks(reset=True)])
+# (b) given marginals (log_sinkhorn_iterations): random positive marginals of equal mass
+mu = rng.uniform(0.2, 2.0, (B, 145)); nu = rng.uniform(0.2, 2.0, (B, 145))
+mu /= mu.sum(1, keepdims=True); nu /= nu.sum(1, keepdims=True)
+out["given"] = ops.log_sinkhorn_iterations(cu(S[:64]), cu(np.log(mu[:64]).astype(np.float32)), cu(np.log(nu[:64]).astype(np.float32)), 100).cpu().numpy()
+# (c) cost + OT with the column flags, over a capacity with the count on the device (padding rows untouched)
+base = rng.standard_normal((B, 264, 145)).astype(np.float32)
+d0 = (3.0 * (base + 0.3 * rng.standard_normal((B, 264, 145)))).astype(np.float32)
+d1 = (3.0 * (base + 0.3 * rng.standard_normal((B, 264, 145)))).astype(np.float32)
+Z, fl = ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=2.0, return_flags=True)
+out["cost_ot"] = Z.cpu().numpy(); out["flags"] = fl.cpu().numpy()
+cnt = torch.tensor([200], device="cuda", dtype=torch.int64)
+Zc, fc = ops.cost_ot(cu(d0), cu(d1), 2, 1.0, cu(ns), 100, bias_k=2.0, return_flags=True, count=cnt)
+assert torch.equal(Zc[:200], Z[:200]) and torch.equal(fc[:200], fl[:200])
+assert torch.equal(fl, Z[:, -1, :-1] > Z[:, :-1, :-1].max(1).values)          # second_layer.py:243,248 on the plan's own values
+np.savez(sys.argv[1], **out)
+print("OK")
+"""
+
+
+def test_two_wave_fine_solver_against_the_four_wave_one(ops, oracle, sinkhorn_mode):
+    """csrc/sinkhorn_blk2w.hip (two waves per 145 x 145 problem, the default) against csrc/sinkhorn_blk.hip (four waves,
+    PATS_FINE_W2=0) in two child processes: log_optimal_transport2 at three biases and 1 / 3 / 100 sweeps (after ONE sweep a
+    wrong hand-over shows at once: the bug this kernel once had was invisible after 100), given marginals, guard trips and -inf
+    entries, cost + OT with column flags over a counted capacity.  Plans under the mass gate of the parity tests, the same
+    problems re-solved, flags equal up to near-ties."""
+    import subprocess
+    import tempfile
+    if sinkhorn_mode != "kernel":
+        pytest.skip("the forced log domain runs neither kernel")
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for w2 in ("0", "1"):
+            path = os.path.join(d, "w%s.npz" % w2)
+            p = subprocess.run([sys.executable, "-c", W2_CHILD % {"repo": REPO}, path], env=dict(os.environ, PATS_FINE_W2=w2),
+                               capture_output=True, text=True, timeout=900)
+            assert p.returncode == 0 and "OK" in p.stdout, "PATS_FINE_W2=" + w2 + ": " + p.stdout[-500:] + p.stderr[-2500:]
+            res[w2] = dict(np.load(path))
+    assert int(res["0"]["trips"][0]) == int(res["1"]["trips"][0]) >= 6              # the same problems leave the guard band (two, at 100 sweeps, per bias)
+    for k in res["0"]:
+        if k in ("trips", "flags"):
+            continue
+        a, b = res["0"][k].astype(np.float64), res["1"][k].astype(np.float64)
+        assert np.array_equal(np.isneginf(a), np.isneginf(b)), k
+        fin = np.isfinite(a)
+        np.testing.assert_allclose(np.exp(b[fin]), np.exp(a[fin]), atol=1e-4, rtol=5e-6, err_msg=k)
+    assert float((res["0"]["flags"] != res["1"]["flags"]).mean()) < 1e-4             # a flag may flip only on a near-tie
+    # and one slice against the oracle
+    rng = np.random.default_rng(91)
+    S = (2.0 * rng.standard_normal((256, 145, 145))).astype(np.float32)
+    ns = np.exp(0.4 * rng.standard_normal((256, 1, 144))).astype(np.float32)
+    want = oracle.log_optimal_transport2(S[:4], 1.0, ns[:4], 3)
+    np.testing.assert_allclose(np.exp(res["1"]["ot2_b0_i3"][:4].astype(np.float64)), np.exp(want.astype(np.float64)), atol=1e-4, rtol=5e-6)
+
+
 def test_conv1d_edge_cases(ops, oracle):
     rng = np.random.default_rng(4)
     # no bias, ragged channel counts (K = 5 is padded to 8 inside), residual, folded input affine + ReLU
