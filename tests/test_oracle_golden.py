@@ -343,6 +343,26 @@ def test_attentional_propagation_against_the_reference_class(oracle, case):
         np.testing.assert_allclose(y.astype(np.float64).sum((1, 2)), g["%s_sum%d" % (mode, case)], atol=2e-2, rtol=1e-4)
 
 
+def test_merge_folded_into_mlp0_is_the_same_layer(oracle):
+    """The identity behind pats_propagation_pack_f32's fold (csrc/gnn_fused.hip gnn_fold_kernel): modules.py:104,116
+    mlp[0](cat([x, merge(att)])) = W1x x + (W1m Wm) att + (W1m bm + b1).  A layer whose merge is the identity and whose mlp[0]
+    carries the folded matrix and bias must reproduce the oracle's layer to double-rounding level - on the CPU, no kernel involved."""
+    C = 64
+    p = synth.gnn_params(seed=synth.SEED + 71, C=C)
+    inp = synth.gnn_inputs(seed=synth.SEED + 81, b=2, C=C, n=37, m=53)
+    W1 = p["mlp.0.weight"][:, :, 0].astype(np.float64)
+    Wm, bm = p["attn.merge.weight"][:, :, 0].astype(np.float64), p["attn.merge.bias"].astype(np.float64)
+    q = dict(p)
+    q["attn.merge.weight"] = np.eye(C, dtype=np.float32)[:, :, None]
+    q["attn.merge.bias"] = np.zeros(C, np.float32)
+    q["mlp.0.weight"] = np.concatenate([W1[:, :C], W1[:, C:] @ Wm], 1).astype(np.float32)[:, :, None]
+    q["mlp.0.bias"] = (p["mlp.0.bias"].astype(np.float64) + W1[:, C:] @ bm).astype(np.float32)
+    for train in (False, True):
+        want = oracle.attentional_propagation(inp["x"], inp["source"], p, bn_train=train)
+        got = oracle.attentional_propagation(inp["x"], inp["source"], q, bn_train=train)
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=2e-5)
+
+
 def test_attentional_gnn_two_layers(oracle):
     g = golden("gnn_layer.npz")
     ps = [synth.gnn_params(seed=synth.SEED + 90 + i, C=128) for i in range(2)]
