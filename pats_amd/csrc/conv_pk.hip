@@ -27,7 +27,8 @@
 // the loaders' global loads 352, without the stores 368, without either 256, and without the MFMAs no faster at all - the 256 us that
 // remain are the WEIGHT STREAM: 360 KB of fragments per 64-column tile through the CU's vector L1 at ~24 bytes a clock (7.1 us a tile),
 // which is also conv_pk_kernel's own skeleton (251 us).  Overlapping activations with MFMAs cannot go below it; halving it takes
-// weights that stay on the CU (a weights-stationary tile: 128 output rows x 264 channels = 135 KB of LDS) or 128-column tiles.  Timeline of a workgroup (s_memrealtime, mean of 9 280): 5.5 us issuing its
+// weights that stay on the CU (a weights-stationary tile: 128 output rows x 264 channels = 135 KB of LDS) or 128-column tiles.
+// (Non-temporal weight loads - past the L1 - cost 45 %: 395 -> 570 us; the two workgroups of a CU share half of that stream in it.)  Timeline of a workgroup (s_memrealtime, mean of 9 280): 5.5 us issuing its
 // 40 dword loads per lane, 1.8 stash, 6.3 k loop (two workgroups share the matrix pipe), 3.3 at barriers, 2.5 epilogue: the vector
 // memory pipe (activations in and out at 4 bytes a lane, 360 KB of weights per tile) is what bounds it, not HBM and not the MFMAs.
 // Range: |activation| < 1023; a non-finite output raises *redo - the layer's one flag: the round-2 composition queued behind the
