@@ -963,7 +963,9 @@ def main():
                           % (args.maps, pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
 
         def traffic_of(prefix):
-            hit = [v for k, v in pmc.items() if k.startswith(prefix)]
+            # (kernel names in the PMC file carry their template arguments - `fine_desc_kernel<0> grid=..` -: match with and without them)
+            import re
+            hit = [v for k, v in pmc.items() if k.startswith(prefix) or re.sub(r"<[^<>]*>", "", k).startswith(prefix)]
             return (float(max(hit, key=lambda v: v["hbm_bytes"])["hbm_bytes"]), pmc_src) if hit else (None, None)
         traffic, traffic_src = traffic_of("pats::third_fused3_kernel")
         third_roof = {"bound": "hbm", "kernel": "third_fused3_kernel (fused third level, %d problems per launch over a capacity of %d)"
@@ -979,7 +981,7 @@ def main():
         # fine level: descriptors in, log-plan out
         f_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * rows_step
         f_ach = f_by / (fine_ms * 1e-3) / 1e9
-        f_parts = [traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145")[0]]
+        f_parts = [traffic_of("pats::cost_mfma_kernel grid=%d" % (cap.rows_cap * 256))[0], traffic_of("pats::sinkhorn_blk145")[0]]
         f_traffic = float(sum(f_parts)) if all(v is not None for v in f_parts) else None
         fine_roof = {"bound": "hbm", "kernel": "fine-level launch pair as timed inside the steps: cost_mfma_kernel + sinkhorn_blk145[w2]_kernel (%d x 145x145 = the row capacity, %d rows in use)"
                      % (cap.rows_cap, rows_step), "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_ach / HBM_PEAK_GBS,
@@ -1004,7 +1006,7 @@ def main():
             c_ms, s_ms = fine_split
             c_by = (2.0 * 264 * 145 * 4 + 145 * 145 * 4) * rows_step
             s_by = (2.0 * 145 * 145 * 4 + 144 * 4) * rows_step
-            c_tr = traffic_of("pats::cost_mfma_kernel<true> grid=%d" % (cap.rows_cap * 256))[0]
+            c_tr = traffic_of("pats::cost_mfma_kernel grid=%d" % (cap.rows_cap * 256))[0]
             s_tr = traffic_of("pats::sinkhorn_blk145")[0]
             split_roofs = [
                 {"bound": "hbm", "kernel": "%s (fine-level OT: %%d x 145x145 in use of a capacity of %%d, 100 sweeps)" % fine_kernel % (rows_step, cap.rows_cap),
