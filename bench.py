@@ -1120,9 +1120,10 @@ def main():
             other_maps = "nhwc" if args.maps == "nchw" else "nchw"
             nets.set_layout(other_maps == "nhwc")
             run_steps(batch, nets, cap, wl, None, 1, None)
-            torch.cuda.synchronize()
+            watch2 = StepWatch(cap)                      # (its pinned buffers before the clock, as in the headline leg: nine
+            torch.cuda.synchronize()                     #  hipHostMalloc calls once cost 2 s inside this leg on one box)
             t1 = time.perf_counter()
-            run_steps(batch, nets, cap, wl, None, steps, None, StepWatch(cap))
+            run_steps(batch, nets, cap, wl, None, steps, None, watch2)
             torch.cuda.synchronize()
             res["value_" + other_maps] = pairs * steps / (time.perf_counter() - t1)
             nets.set_layout(args.maps == "nhwc")
