@@ -82,6 +82,10 @@ extern "C" int pats_cost_ot_flags_counted_f32(const float* d0, const float* d1, 
 static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, int n, int m, int variant,
                         const float* scalar, const float* ns, int iters, float bias_k, float* Z, uint8_t* col_nomatch,
                         void* workspace, size_t workspace_bytes, pats_stream_t stream, const int64_t* live) {
+    // the handle is consumed by THIS call whatever path it takes (fused kernel, 65-wide kernel, an error): left armed it would be
+    // recorded by a later, unrelated call - by then possibly destroyed (round-4 advice)
+    const hipEvent_t mid_event = g_mid_event;
+    g_mid_event = nullptr;
     PATS_REQUIRE(variant == 1 || variant == 2, "cost_ot: variant must be 1 or 2");
     PATS_REQUIRE(batch >= 0 && D > 0 && n > 0 && m > 0, "cost_ot: bad shape");
     if (batch == 0) return PATS_OK;
@@ -107,11 +111,7 @@ static int cost_ot_impl(const float* d0, const float* d1, int64_t batch, int D, 
     }
     int rc = launch_cost(d0, d1, batch, D, n, m, scores, stream, live);
     if (rc) return rc;
-    if (g_mid_event) {
-        const hipEvent_t ev = g_mid_event;
-        g_mid_event = nullptr;                       // one call, one record
-        if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess) return check_launch("cost_ot mid event");
-    }
+    if (mid_event && hipEventRecord(mid_event, (hipStream_t)stream) != hipSuccess) return check_launch("cost_ot mid event");
     if (variant == 1) {
         PATS_REQUIRE(scalar, "cost_ot: alpha pointer required for variant 1");
         PATS_REQUIRE(bias_k == 0.f, "cost_ot: bias only applies to variant 2");

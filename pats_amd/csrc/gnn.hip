@@ -694,8 +694,9 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     if (hipMemsetAsync(redo, 0, 8 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
     int rc;
     const int* gate = nullptr;
-    if (packed && fused_layer_supported(C, heads, n, m)) {
-        // residual == out would be read-after-write across waves of the fused kernel's epilogue only per element: allowed
+    if (packed && fused_layer_supported(C, heads, n, m) && !(residual && residual == out)) {
+        // residual == out is excluded (round-4 advice): the kernel itself reads and writes each element once, but the gated redo
+        // behind it would read the residual the first attempt has already overwritten - such a call takes the composition alone
         int* flag = redo + 7;
         int splits = 0;
         rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, bpart, &splits, st);

@@ -491,8 +491,10 @@ __global__ void __launch_bounds__(256) bypair_runs_kernel(ByPairArgs g) {
     }
 }
 __global__ void __launch_bounds__(256) bypair_offsets_kernel(ByPairArgs g) {              // one workgroup; thread p walks pair p's chunks
-    __shared__ int64_t total[1024];
+    __shared__ int64_t total[1024];          // in: a pair's match count; after thread 0's scan: its offset (the hand-over between the
+    __shared__ int64_t carry;                // waves stays in LDS - pair_off in global memory is an OUTPUT here, never read back)
     const int64_t P = g.pairs;
+    if (threadIdx.x == 0) carry = 0;
     for (int64_t p0 = 0; p0 < P; p0 += 1024) {                                            // (pairs per batch: tens)
         for (int64_t p = p0 + threadIdx.x; p < P && p < p0 + 1024; p += 256) {
             int64_t t = 0;
@@ -501,15 +503,17 @@ __global__ void __launch_bounds__(256) bypair_offsets_kernel(ByPairArgs g) {    
         }
         wg_barrier();
         if (threadIdx.x == 0) {
-            int64_t run = p0 == 0 ? 0 : g.pair_off[p0];
-            for (int64_t p = p0; p < P && p < p0 + 1024; ++p) { g.pair_off[p] = run; run += total[p - p0]; }
+            int64_t run = carry;
+            for (int64_t p = p0; p < P && p < p0 + 1024; ++p) { const int64_t t = total[p - p0]; total[p - p0] = run; g.pair_off[p] = run; run += t; }
             g.pair_off[P < p0 + 1024 ? P : p0 + 1024] = run;
+            carry = run;
         }
         wg_barrier();
-    }
-    for (int64_t p = threadIdx.x; p < P; p += 256) {
-        int64_t run = g.pair_off[p];
-        for (int c = 0; c < g.Cmax; ++c) { g.seg_dst[c * P + p] = run; run += g.seg_hi[c * P + p] - g.seg_lo[c * P + p]; }
+        for (int64_t p = p0 + threadIdx.x; p < P && p < p0 + 1024; p += 256) {
+            int64_t run = total[p - p0];
+            for (int c = 0; c < g.Cmax; ++c) { g.seg_dst[c * P + p] = run; run += g.seg_hi[c * P + p] - g.seg_lo[c * P + p]; }
+        }
+        wg_barrier();
     }
 }
 __global__ void __launch_bounds__(256) bypair_copy_kernel(ByPairArgs g) {

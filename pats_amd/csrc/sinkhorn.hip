@@ -400,7 +400,7 @@ template <int N_>
 struct __attribute__((aligned(16))) WgLds {
     float bc0[(N_ + 7) & ~3];       // r, then a (and u for the epilogue)
     float bc1[(N_ + 7) & ~3];       // c, then b (and v)
-    float red[8];
+    float red[12];                  // six per-wave slots x 2: the stabilised re-solve's drift flags alternate halves by sweep parity
     float tile[N_ * N_];
 };
 
@@ -505,16 +505,23 @@ sinkhorn_rc_kernel(const float* Zin, int64_t P, const float* __restrict__ log_mu
         // times per element and sweep with one or two waves per SIMD: 13 us per problem, 26 ms for the 2 000 wild problems of a
         // step with 10 % of its rows scaled by 32 (profiles/r04_wild10_step_kernel_stats.md).
         const bool absorb = linear == 2;
-        if (absorb && t < 6) lds.red[t] = 0.f;
+        if (absorb && t < 12) lds.red[t] = 0.f;
         for (int it = 0; it < iters; ++it) {
             wg_barrier();                       // b visible (and the drift flags of the previous sweep)
-            if (absorb && it > 0 && ((lds.red[0] + lds.red[1] + lds.red[2]) + (lds.red[3] + lds.red[4] + lds.red[5])) > 0.5f) {
+            // The flags of sweep it live in half (it & 1): this sweep READS the other half (written during sweep it - 1, complete
+            // behind the barrier above) and WRITES its own, which every wave first clears for itself - so a fast wave raising its
+            // flag later in this sweep can never be seen by a slow wave still evaluating the branch below (round-4 advice: with one
+            // set of flags the two could disagree, and the branch holds barriers).
+            const float* frd = lds.red + ((it + 1) & 1) * 6;
+            float* fwr = lds.red + (it & 1) * 6;
+            const bool drifted = absorb && it > 0 && ((frd[0] + frd[1] + frd[2]) + (frd[3] + frd[4] + frd[5])) > 0.5f;
+            if (absorb && lane == 0) fwr[wave] = 0.f;
+            if (drifted) {
                 // workgroup-uniform branch: every wave re-bases its stabilisers and rebuilds its part of K
                 const float lg = logf(sc);
                 if (act && lg == lg && fabsf(lg) < 3.0e38f) { stab -= lg; sc = 1.f; }     // a dead scaling (0, inf, NaN) is left to the guard
-                wg_barrier();                   // every wave has read the flags and the old b
+                wg_barrier();                   // every wave has read the old b
                 if (act) (colw ? lds.bc1 : lds.bc0)[tl] = stab;
-                if (t < 6) lds.red[t] = 0.f;
                 wg_barrier();
                 if (!colw) {
 #pragma unroll
@@ -540,13 +547,13 @@ sinkhorn_rc_kernel(const float* Zin, int64_t P, const float* __restrict__ log_mu
             if (!colw) {
                 sc = marg * fast_rcp(dotN<N_>(kk, lds.bc1));
                 if (act) lds.bc0[tl] = sc;
-                if (absorb && __any(act && !(sc <= 1048576.f && sc >= 9.5367431640625e-07f)) && lane == 0) lds.red[wave] = 1.f;
+                if (absorb && __any(act && !(sc <= 1048576.f && sc >= 9.5367431640625e-07f)) && lane == 0) fwr[wave] = 1.f;
             }
             wg_barrier();                       // a visible
             if (colw) {
                 sc = marg * fast_rcp(dotN<N_>(kk, lds.bc0));
                 if (act) lds.bc1[tl] = sc;
-                if (absorb && __any(act && !(sc <= 1048576.f && sc >= 9.5367431640625e-07f)) && lane == 0) lds.red[wave] = 1.f;
+                if (absorb && __any(act && !(sc <= 1048576.f && sc >= 9.5367431640625e-07f)) && lane == 0) fwr[wave] = 1.f;
             }
         }
         const bool ok_wave = __all(!act || scaling_ok(sc));
