@@ -1099,10 +1099,11 @@ def test_stabilised_third_level_resolve_agrees_with_the_log_domain_one(tmp_path)
 
 
 # ---- AttentionalPropagation / AttentionalGNN around the attention core (section 8f rank 4) -------------------
-GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
+GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53),
+             dict(C=264, b=5, n=145, m=145), dict(C=448, b=2, n=300, m=300)]      # 3, 4: the fine and the coarse level's production shapes
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
 def test_attentional_propagation_golden(ops, oracle, case):
     """modules.py:107-117 against the reference's own AttentionalPropagation (eval mode and train mode = BatchNorm on
     batch statistics, which is what the third layer runs under PATS.eval) and against the oracle."""
@@ -1141,6 +1142,20 @@ def test_attentional_gnn_and_edge_shapes(ops, oracle):
     np.testing.assert_allclose(y, oracle.attentional_propagation(i["x"], i["source"], p, bn_train=True), atol=1e-4, rtol=2e-4)
     with pytest.raises(RuntimeError):
         ops.attentional_propagation(cu(i["x"]), cu(i["source"][:, :100]), ops.PropagationParams(p))
+
+
+def test_attentional_gnn_three_layers_at_the_fine_level_shape(ops):
+    """AttentionalGNN(264, [self, cross, self]) against the reference's own class (tests/golden/gnn_layer.npz, gnn264_*): the
+    stack second_layer.py:89 runs, on the packed fine-level layer kernels."""
+    g = golden("gnn_layer.npz")
+    ps = [synth.gnn_params(seed=synth.SEED + 96 + i, C=264) for i in range(3)]
+    a = synth.gnn_inputs(seed=synth.SEED + 99, b=3, C=264, n=145)
+    d0, d1 = ops.attentional_gnn(cu(a["x"]), cu(a["source"]), [ops.PropagationParams(p) for p in ps], ["self", "cross", "self"])
+    d0, d1 = d0.cpu().numpy(), d1.cpu().numpy()
+    np.testing.assert_allclose(d0.reshape(-1)[g["gnn264_idx"]], g["gnn264_d0"], atol=1e-4, rtol=2e-4)
+    np.testing.assert_allclose(d1.reshape(-1)[g["gnn264_idx"]], g["gnn264_d1"], atol=1e-4, rtol=2e-4)
+    np.testing.assert_allclose(d0.astype(np.float64).sum((1, 2)), g["gnn264_sum0"], atol=5e-2, rtol=2e-4)
+    np.testing.assert_allclose(d1.astype(np.float64).sum((1, 2)), g["gnn264_sum1"], atol=5e-2, rtol=2e-4)
 
 
 def test_gnn_ten_layers_with_small_magnitude_weights(ops, oracle):

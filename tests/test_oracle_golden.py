@@ -327,10 +327,11 @@ def test_attention(oracle):
 
 
 # ---- AttentionalPropagation / AttentionalGNN (modules.py:91-134), fixtures from the reference's own classes ----
-GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
+GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53),
+             dict(C=264, b=5, n=145, m=145), dict(C=448, b=2, n=300, m=300)]      # 3, 4: the fine and the coarse level's production shapes
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
 def test_attentional_propagation_against_the_reference_class(oracle, case):
     g = golden("gnn_layer.npz")
     kw = GNN_CASES[case]
@@ -373,6 +374,21 @@ def test_attentional_gnn_two_layers(oracle):
         d0, d1 = (oracle.attentional_propagation(d0, s0, p, residual=d0), oracle.attentional_propagation(d1, s1, p, residual=d1))
     np.testing.assert_allclose(d0.reshape(-1)[g["gnn_idx"]], g["gnn_d0"], atol=5e-5, rtol=1e-4)
     np.testing.assert_allclose(d1.reshape(-1)[g["gnn_idx"]], g["gnn_d1"], atol=5e-5, rtol=1e-4)
+
+
+def test_attentional_gnn_three_layers_at_the_fine_level_shape(oracle):
+    """AttentionalGNN(264, [self, cross, self]) from the reference's class (second_layer.py:44,89 runs 18 such layers)."""
+    g = golden("gnn_layer.npz")
+    ps = [synth.gnn_params(seed=synth.SEED + 96 + i, C=264) for i in range(3)]
+    a = synth.gnn_inputs(seed=synth.SEED + 99, b=3, C=264, n=145)
+    d0, d1 = a["x"], a["source"]
+    for p, name in zip(ps, ["self", "cross", "self"]):
+        s0, s1 = (d1, d0) if name == "cross" else (d0, d1)
+        d0, d1 = (oracle.attentional_propagation(d0, s0, p, residual=d0), oracle.attentional_propagation(d1, s1, p, residual=d1))
+    np.testing.assert_allclose(d0.reshape(-1)[g["gnn264_idx"]], g["gnn264_d0"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(d1.reshape(-1)[g["gnn264_idx"]], g["gnn264_d1"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(d0.astype(np.float64).sum((1, 2)), g["gnn264_sum0"], atol=3e-2, rtol=1e-4)
+    np.testing.assert_allclose(d1.astype(np.float64).sum((1, 2)), g["gnn264_sum1"], atol=3e-2, rtol=1e-4)
 
 
 # ---- the descriptor heads: KeypointEncoder (modules.py:70-82) and final_proj (Conv1d, first_layer.py:34-36,105) ----

@@ -501,7 +501,10 @@ def gen_pipeline(R, name, seed, h, w, if_local, if_outdoor, merge_new):
          matches_r=matches_r)
 
 
-GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53)]
+# cases 3, 4 (round 5): the two PRODUCTION shapes besides the third level's - the fine level (second_layer.py:44,89: 264 channels,
+# 144 cells + dustbin) and the coarse level (first_layer.py:32,101: 448 channels, 15 x 20 cells)
+GNN_CASES = [dict(C=128, b=3, n=65, m=65), dict(C=64, b=2, n=145, m=145), dict(C=32, b=2, n=37, m=53),
+             dict(C=264, b=5, n=145, m=145), dict(C=448, b=2, n=300, m=300)]
 
 
 def gen_gnn(R):
@@ -539,6 +542,20 @@ def gen_gnn(R):
     rng = np.random.default_rng(77)
     i0 = sample_idx(rng, d0.shape, 8192)
     arrs.update(gnn_idx=i0, gnn_d0=d0.reshape(-1)[T(i0)], gnn_d1=d1.reshape(-1)[T(i0)])
+    # three layers at the fine level's shape (self, cross, self), eval mode: the stack second_layer.py:89 runs 18 layers of
+    C = 264
+    gnn = R.M.AttentionalGNN(C, ["self", "cross", "self"])
+    ps = [synth.gnn_params(seed=synth.SEED + 96 + i, C=C) for i in range(3)]
+    for lyr, p in zip(gnn.layers, ps):
+        lyr.load_state_dict({k: T(v) for k, v in p.items()}, strict=False)
+    gnn.eval()
+    a = synth.gnn_inputs(seed=synth.SEED + 99, b=3, C=C, n=145)
+    with torch.no_grad():
+        d0, d1 = gnn(T(a["x"]), T(a["source"]))
+    rng = np.random.default_rng(78)
+    i0 = sample_idx(rng, d0.shape, 8192)
+    arrs.update(gnn264_idx=i0, gnn264_d0=d0.reshape(-1)[T(i0)], gnn264_d1=d1.reshape(-1)[T(i0)],
+                gnn264_sum0=d0.double().sum((1, 2)), gnn264_sum1=d1.double().sum((1, 2)))
     save("gnn_layer.npz", **arrs)
 
 
