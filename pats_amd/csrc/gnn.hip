@@ -618,13 +618,20 @@ using namespace pats;
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+namespace pats {
+int fine_layer_supported(int C, int heads, int n, int m);          // gnn_fine.hip
+size_t fine_scratch_bytes(int64_t P);
+}
+
 extern "C" size_t pats_attentional_propagation_workspace_bytes(int64_t batch, int C, int n, int m) {
     if (batch < 0 || C <= 0 || n <= 0 || m <= 0) return 0;
     const size_t qb = al256((size_t)batch * C * n * sizeof(float)), kb = al256((size_t)batch * C * m * sizeof(float));
     // q, attention output, message [b,C,n]; k, v [b,C,m]; hidden [b,2C,n]; BN scale / shift [2C] each; BN partial sums
     // (BatchNorm partial sums: BN_SPLITS per channel for the composition, one per workgroup of the fused kernel's grid - at most 512)
+    // (+ the fine level's one-kernel layer: its per-workgroup scratch blocks; its descriptor images overlay q / att / msg / k)
+    const size_t fine = pats::fine_layer_supported(C, 4, n, m) ? al256(pats::fine_scratch_bytes(batch)) : 0;
     return 3 * qb + 2 * kb + al256((size_t)batch * 2 * C * n * sizeof(float)) + 2 * al256((size_t)2 * C * sizeof(float)) +
-           al256((size_t)2 * C * 512 * 2 * sizeof(double)) + 256 /* seven redo flags + the fused layer's flag */;
+           al256((size_t)2 * C * 512 * 2 * sizeof(double)) + 256 /* seven redo flags + the fused layer's flag */ + fine;
 }
 
 namespace pats {
@@ -638,6 +645,15 @@ int launch_fused_layer(const float* x, const float* source, int64_t batch, const
                        hipStream_t st);
 int launch_gnn_tail(const float* hid, int64_t batch, const void* packed, const float* scale, const float* shift, const float* residual,
                     float* out, int* flag, hipStream_t st);
+// the fine level's one-kernel layer (gnn_fine.hip)
+int fine_layer_supported(int C, int heads, int n, int m);
+const void* packed_fine_section(const void* packed, int C, int heads);                                   // gnn_fused.hip
+size_t fine_scratch_bytes(int64_t P);
+size_t fine_image_bytes(int64_t P);
+int launch_fine_in(const float* x, int64_t P, float* blk, char* tf, hipStream_t st);
+int launch_fine_out(const float* blk, int64_t P, float* y, hipStream_t st);
+int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const float* blk_res, int64_t P, const void* section,
+                      float* blk_out, char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st);
 }
 
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
@@ -690,11 +706,33 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     float* bsc = (float*)p; p += al256((size_t)2 * C * sizeof(float));
     float* bsh = (float*)p; p += al256((size_t)2 * C * sizeof(float));
     double* bpart = (double*)p; p += al256((size_t)2 * C * 512 * 2 * sizeof(double));
-    int* redo = (int*)p;
+    int* redo = (int*)p; p += 256;
+    char* fine_scratch = p;
     if (hipMemsetAsync(redo, 0, 8 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
     int rc;
     const int* gate = nullptr;
-    if (packed && fused_layer_supported(C, heads, n, m) && !(residual && residual == out)) {
+    if (packed && !bn_train && fine_layer_supported(C, heads, n, m) && gnn_fold_enabled() && !(residual && residual == out)) {
+        // The fine level (round 5, gnn_fine.hip): the whole layer in one kernel on (fp32 blocked, TF image) descriptors.  This
+        // single-layer entry converts on the way in and out (pats_attentional_gnn_packed_f32 keeps a stack in that form); the
+        // images and blocked copies overlay the composition's q / att / msg / k buffers, which only the gated redo would use.
+        int* flag = redo + 7;
+        char* tf_x = (char*)q;
+        char* tf_s = source == x ? tf_x : (char*)att;
+        float* blk_res = residual ? msg : nullptr;
+        float* blk_out = k;
+        if ((rc = launch_fine_in(x, batch, residual == x ? blk_res : nullptr, tf_x, st))) return rc;
+        if (source != x && (rc = launch_fine_in(source, batch, nullptr, tf_s, st))) return rc;
+        if (residual && residual != x && (rc = launch_fine_in(residual, batch, blk_res, nullptr, st))) return rc;
+        rc = launch_fine_layer(tf_x, tf_s, 0, blk_res, batch, packed_fine_section(packed, C, heads), blk_out, nullptr, fine_scratch, flag,
+                               nullptr, st);
+        if (rc == PATS_OK) {
+            if ((rc = launch_fine_out(blk_out, batch, out, st))) return rc;
+            gate = flag;         // the composition below runs only if the kernel raised it
+        } else if (rc != PATS_ERR_UNSUPPORTED) {
+            return rc;
+        }
+    }
+    if (packed && !gate && fused_layer_supported(C, heads, n, m) && !(residual && residual == out)) {
         // residual == out is excluded (round-4 advice): the kernel itself reads and writes each element once, but the gated redo
         // behind it would read the residual the first attempt has already overwritten - such a call takes the composition alone
         int* flag = redo + 7;

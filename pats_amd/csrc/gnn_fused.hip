@@ -698,11 +698,20 @@ static size_t packed_matrices_bytes(int C, int heads) {
 const float* packed_folded_bias(const void* packed, int C, int heads) {
     return (const float*)((const char*)packed + packed_matrices_bytes(C, heads)) + (size_t)4 * C * C;
 }
+// and behind those (round 5): the fine level's one-kernel layer has its own fragment set (gnn_fine.hip; only C = 264, 4 heads)
+size_t packed_fine_bytes(int C, int heads);
+int launch_fine_pack(const pats_propagation_weights& w, void* section, hipStream_t st);
+static size_t packed_fine_offset(int C, int heads) {
+    return (packed_matrices_bytes(C, heads) + ((size_t)4 * C * C + 2 * C) * sizeof(float) + 255) & ~(size_t)255;
+}
+const void* packed_fine_section(const void* packed, int C, int heads) {
+    return packed_fine_bytes(C, heads) ? (const char*)packed + packed_fine_offset(C, heads) : nullptr;
+}
 }
 
 extern "C" size_t pats_propagation_packed_bytes(int C, int heads) {
     if (C <= 0 || heads <= 0 || (C % 8) != 0 || (C % heads) != 0) return 0;
-    return packed_matrices_bytes(C, heads) + ((size_t)4 * C * C + 2 * C) * sizeof(float);
+    return packed_fine_offset(C, heads) + packed_fine_bytes(C, heads);
 }
 
 extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
@@ -725,6 +734,11 @@ extern "C" int pats_propagation_pack_f32(const pats_propagation_weights* w, int 
         wf.b1 = b1f;
     }
     w = &wf;
+    if (fold && packed_fine_bytes(C, heads)) {       // the fine level's fused layer runs on the FOLDED mlp[0] only
+        PATS_REQUIRE(w->bn_a && w->bn_b, "propagation_pack: the fine level's packed layer keeps the BatchNorm scale / shift (eval mode)");
+        int rc = launch_fine_pack(wf, (char*)packed + packed_fine_offset(C, heads), st);
+        if (rc) return rc;
+    }
     if (packed_fused_bytes(C, heads)) {
         h8v* pw = (h8v*)packed;
         float* pb = (float*)(pw + PW_END);
