@@ -37,6 +37,10 @@
 
 #include <algorithm>
 #include <cstdlib>
+#ifdef PATS_DIAG
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace pats {
 
@@ -89,7 +93,20 @@ struct FineArgs {
     int64_t P, shift;
     int* flag;
     const int* gate;           // optional: no-op unless *gate != 0
+    int stagger;               // workgroup i starts ((i >> 3) % 32) * stagger * ~1 us late: de-phases the memory bursts of the stages
+#ifdef PATS_DIAG
+    long long* tl;             // diagnostic library: FT_N accumulated stage durations per workgroup (thread 0, 10 ns units)
+#endif
 };
+
+// Diagnostic library only (python -m pats_amd.build --diag, PATS_AMD_DIAG_LIB=1, PATS_FINE_TL=1): s_memrealtime stamps at the stage
+// boundaries of thread 0, summed over the workgroup's problems; launch_fine_layer prints the means per problem
+constexpr int FT_N = 24;
+#ifdef PATS_DIAG
+#define FT(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_amdgcn_s_memrealtime(); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define FT(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int tf_blk(int ks, int plane) { return ks < 8 ? (2 * ks + plane) * TFB : TF_MAIN + plane * TFR; }
 // byte offset of fragment piece (token tile t, lane) inside a block; ragged k-step: valid for lanes < 16 only
@@ -142,17 +159,28 @@ __device__ __forceinline__ void dma_fill(char* lds_dst, const char* src, int wav
     }
 }
 
-// rows 16 mt + 4 g + r (r = 0..3) of token 16 t + j, value v = PRE x the element -> a TF image at dst (LDS or global)
+// rows 16 mt + 4 g + r (r = 0..3) of token 16 t + j, value v = PRE x the element -> a TF image at dst (global memory).
+// A lane's four values are HALF of a 16-byte piece (lanes g = 2 k, 2 k + 1 share one): the pair exchanges halves through
+// v_permlane16_swap - the even row of 16 lanes ends up with the whole hi piece, the odd row with the whole lo piece - and every lane
+// issues ONE 16-byte store; a wave's store covers whole 256-byte runs.  (The first version stored 8-byte halves: every 128-byte line
+// of an image was written by two instructions with half its bytes enabled - read-for-ownership traffic at the memory side; the
+// output epilogue alone took 20 us of a problem's 230.)  Called by all 64 lanes (the exchange), inactive tiles masked at the store.
 __device__ __forceinline__ void store_tf(char* dst, int mt, int t, const f4v v, int lane) {
     const int g = lane >> 4, j = lane & 15;
-    if (t == 9 && j != 0) return;
-    if (mt == 16 && g >= 2) return;
     h4v hi, lo;
     split4_pre(v, hi, lo);
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v H = __builtin_bit_cast(u2v, hi), L = __builtin_bit_cast(u2v, lo);
+    // lane_swap16(a, b): odd rows of a <-> even rows of b.  Afterwards an even-row lane holds (own hi, partner's hi) = the hi piece,
+    // an odd-row lane (partner's lo, own lo) = the lo piece - both as (H, L)
+    unsigned hx = H.x, hy = H.y, lx = L.x, ly = L.y;
+    lane_swap16(hx, lx);
+    lane_swap16(hy, ly);
+    if (t == 9 && j != 0) return;
+    if (mt == 16 && g >= 2) return;
     const int ks = mt >> 1, kq = mt == 16 ? 0 : 2 * (mt & 1) + (g >> 1);
-    const int off = tf_off(mt == 16, t, kq * 16 + j) + (g & 1) * 8;
-    *reinterpret_cast<h4v*>(dst + tf_blk(ks, 0) + off) = hi;
-    *reinterpret_cast<h4v*>(dst + tf_blk(ks, 1) + off) = lo;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u4v*>(dst + tf_blk(ks, g & 1) + tf_off(mt == 16, t, kq * 16 + j)) = u4v{hx, hy, lx, ly};
 }
 
 // ---- one convolution pass over the nine k-steps of the TF image in LDS -----------------------------------------------------------
@@ -344,6 +372,10 @@ gnn_fine_layer_kernel(FineArgs g) {
     char* scr0 = g.scratch + (size_t)blockIdx.x * SC_BYTES;
     bool bad = false;
     const int lane0 = lane;
+    for (int i = (int)(blockIdx.x >> 3 & 31) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);       // ~1 us a step
+#ifdef PATS_DIAG
+    long long tsum[FT_N] = {0}, tlast = 0, nprob = 0;
+#endif
     for (int64_t p = blockIdx.x; p < g.P; p += gridDim.x) {
         // Everything the epilogues address is invariant over the problem loop (the scratch block, the lane's offsets in a TF image):
         // left alone the compiler hoists several hundred store addresses and fragment bases out of the loop and spills the
@@ -366,11 +398,16 @@ gnn_fine_layer_kernel(FineArgs g) {
         if (ps >= g.P) ps -= g.P;
         const char* img_s = g.tf_s + ps * TF_BYTES;
         f4v acc[2][FNT], accr[2];
+#ifdef PATS_DIAG
+        tlast = __builtin_amdgcn_s_memrealtime();
+#endif
         // ================= source -> k (TF image + packed extras), v^T (A fragments of the second attention product) =================
         dma_fill<TF_BYTES>(lds, img_s, wave, lane);
         wg_barrier_global();
+        FT(0);
         zero_acc(acc, accr);
         conv_pass<false, 9>(pw + FW_K, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(1);
         {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -392,8 +429,10 @@ gnn_fine_layer_kernel(FineArgs g) {
                 }
             }
         }
+        FT(2);
         zero_acc(acc, accr);
         conv_pass<true, 9>(pw + FW_V, 0, 0, lds, wave, lane, acc, accr, vt0, vt1);
+        FT(3);
         {
             // rows = tokens 16 t + 4 g + r, column = channel 16 mt + j: key slots (g, e) of k-step kk = token tiles 2 kk (e < 4), 2 kk + 1
 #pragma unroll
@@ -419,12 +458,15 @@ gnn_fine_layer_kernel(FineArgs g) {
                 }
             }
         }
+        FT(4);
         wg_barrier();                                      // the source image has been read
         // ================= x -> q (TF image + packed extras, B packing (h0 h1 h0 h1 l0 l1 0 0)) ======================================
         dma_fill<TF_BYTES>(lds, img_x, wave, lane);
         wg_barrier_global();
+        FT(5);
         zero_acc(acc, accr);
         conv_pass<false, 9>(pw + FW_Q, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(6);
         {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -445,14 +487,31 @@ gnn_fine_layer_kernel(FineArgs g) {
                 }
             }
         }
+        FT(7);
         wg_barrier_global();                               // q, k, v are in the scratch block; the x image has been read
+        FT(8);
         // ================= attention: unit = (head, 16-query tile); its output replaces its own q tile ===============================
         dma_fill<4 * TFB>(lds + L_KA, scr + SC_K, wave, lane);
         dma_fill<FN * 16>(lds + L_KA + 4 * TFB, scr + SC_KX, wave, lane);
         dma_fill<4 * V_TILE>(lds + L_V, scr + SC_V, wave, lane);
         dma_fill<V_TILE>(lds + L_VX, scr + SC_V + 16 * V_TILE, wave, lane);
+        // this wave's queries of a unit: B operand, two k-steps + the packed extras (every lane reads the piece of its query; lanes
+        // k / 8 > 0 then take zeros).  Loaded one unit AHEAD: the scratch block is an L2 / Infinity-Cache round trip away.
+        struct QF { h8v h0, l0, h1, l1, x; };
+        auto qload = [&](int h, int qt, QF& q) {
+            const int qoff = tf_off(false, qt, lane);
+            const int qtok = qt < 9 ? 16 * qt + j : 144;
+            q.h0 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h, 0) + qoff);
+            q.l0 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h, 1) + qoff);
+            q.h1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 0) + qoff);
+            q.l1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 1) + qoff);
+            q.x = *reinterpret_cast<const h8v*>(scr + SC_QX + (h * FN + qtok) * 16);
+        };
+        QF q;
+        qload(0, wave, q);
         for (int h = 0; h < 4; ++h) {
             wg_barrier_global();                           // k_h, v_h (and the extras tile) have landed
+            FT(9);
             if (h < 3) {
                 char* kn = lds + L_KA + ((h + 1) & 1) * KH_BYTES;
                 dma_fill<4 * TFB>(kn, scr + SC_K + (h + 1) * 4 * TFB, wave, lane);
@@ -460,30 +519,29 @@ gnn_fine_layer_kernel(FineArgs g) {
             }
             const char* kb = lds + L_KA + (h & 1) * KH_BYTES;
             for (int qt = wave; qt < FNT; qt += 8) {
-                // this unit's queries: B operand, two k-steps + the packed extras
-                const int qoff = tf_off(false, qt, lane);
-                const int qtok = qt < 9 ? 16 * qt + j : 144;
-                const h8v qh0 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h, 0) + qoff);
-                const h8v ql0 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h, 1) + qoff);
-                const h8v qh1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 0) + qoff);
-                const h8v ql1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 1) + qoff);
-                h8v qx = zero8();
-                if (gq == 0) qx = *reinterpret_cast<const h8v*>(scr + SC_QX + (h * FN + qtok) * 16);
+                const h8v qx = gq == 0 ? q.x : zero8();
                 f4v st[FNT];
                 const float c = UNS * 0.12309149097933272f * LOG2E;          // accumulator -> exponent of 2: 2^-12 / sqrt(66) * log2(e)
                 float mx = -INFINITY;
+                // the key fragments of tile kt + 1 are read while the MFMAs of tile kt run (two register sets)
+                struct KF { h8v h0, l0, h1, l1, x; };
+                auto kload = [&](int kt, KF& k) {
+                    const int koff = tf_off(false, kt, lane);
+                    k.h0 = *reinterpret_cast<const h8v*>(kb + koff);
+                    k.l0 = *reinterpret_cast<const h8v*>(kb + TFB + koff);
+                    k.h1 = *reinterpret_cast<const h8v*>(kb + 2 * TFB + koff);
+                    k.l1 = *reinterpret_cast<const h8v*>(kb + 3 * TFB + koff);
+                    k.x = *reinterpret_cast<const h8v*>(kb + 4 * TFB + (kt < 9 ? 16 * kt + j : 144) * 16);
+                };
+                KF kf[2];
+                kload(0, kf[0]);
 #pragma unroll
                 for (int kt = 0; kt < FNT; ++kt) {
-                    const int koff = tf_off(false, kt, lane);
-                    const h8v kh0 = *reinterpret_cast<const h8v*>(kb + koff);
-                    const h8v kl0 = *reinterpret_cast<const h8v*>(kb + TFB + koff);
-                    const h8v kh1 = *reinterpret_cast<const h8v*>(kb + 2 * TFB + koff);
-                    const h8v kl1 = *reinterpret_cast<const h8v*>(kb + 3 * TFB + koff);
-                    h8v kx = zero8();
-                    if (gq == 0) kx = *reinterpret_cast<const h8v*>(kb + 4 * TFB + (kt < 9 ? 16 * kt + j : 144) * 16);
-                    f4v s = mfma3(kh0, kl0, qh0, ql0, f4v{0.f, 0.f, 0.f, 0.f});             // rows = keys 16 kt + 4 g + r, column = query
-                    s = mfma3(kh1, kl1, qh1, ql1, s);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kx, qx, s, 0, 0, 0);
+                    if (kt + 1 < FNT) kload(kt + 1, kf[(kt + 1) & 1]);
+                    const KF& k = kf[kt & 1];
+                    f4v s = mfma3(k.h0, k.l0, q.h0, q.l0, f4v{0.f, 0.f, 0.f, 0.f});         // rows = keys 16 kt + 4 g + r, column = query
+                    s = mfma3(k.h1, k.l1, q.h1, q.l1, s);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(gq == 0 ? k.x : zero8(), qx, s, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = s[r] * c;
@@ -494,6 +552,10 @@ gnn_fine_layer_kernel(FineArgs g) {
                     st[kt] = s;
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // the next unit's queries: this wave's second tile of the head (waves 0, 1), else its tile of the next head
+                const int qt_own = qt;
+                if (qt + 8 < FNT) qload(h, qt + 8, q);
+                else if (h < 3) qload(h + 1, wave, q);
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 float den = 0.f;
@@ -518,46 +580,59 @@ gnn_fine_layer_kernel(FineArgs g) {
                     pl[kk] = h8v{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
                 }
                 const float osc = UNS * PRE * inv;
-#pragma unroll
-                for (int dt = 0; dt < 5; ++dt) {
+                h8v vf[2][5][2];
+                auto vload = [&](int dt, h8v (&v)[5][2]) {
                     const char* vb = dt < 4 ? lds + L_V + dt * V_TILE : lds + L_VX;
-                    f4v o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kk = 0; kk < 5; ++kk) {
-                        const h8v vh = *reinterpret_cast<const h8v*>(vb + kk * 2048 + lane * 16);
-                        const h8v vl = *reinterpret_cast<const h8v*>(vb + kk * 2048 + 1024 + lane * 16);
-                        o = mfma3(vh, vl, ph[kk], pl[kk], o);                               // rows = channels, column = query
+                        v[kk][0] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + lane * 16);
+                        v[kk][1] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + 1024 + lane * 16);
                     }
+                };
+                vload(0, vf[0]);
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) {
+                    if (dt + 1 < 5) vload(dt + 1, vf[(dt + 1) & 1]);
+                    f4v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk) o = mfma3(vf[dt & 1][kk][0], vf[dt & 1][kk][1], ph[kk], pl[kk], o);     // rows = channels, column = query
                     __builtin_amdgcn_sched_barrier(0);
                     o = o * osc;
                     if (dt < 4) {
-                        store_tf(scr + SC_Q, 4 * h + dt, qt, o, lane);
-                    } else if (gq == (h >> 1) && (qt < 9 || j == 0)) {
+                        store_tf(scr + SC_Q, 4 * h + dt, qt_own, o, lane);
+                    } else if (gq == (h >> 1) && (qt_own < 9 || j == 0)) {
                         // rows 2 h', 2 h' + 1 of the extras tile are head h's channels 64, 65 -> bytes 4 h .. of the ragged block's piece
                         const float e0 = (h & 1) ? o.z : o.x, e1 = (h & 1) ? o.w : o.y;
                         const _Float16 a0 = (_Float16)e0, a1 = (_Float16)e1;
                         const h2v hi = {a0, a1}, lo = {(_Float16)(e0 - (float)a0), (_Float16)(e1 - (float)a1)};
-                        const int off = tf_off(true, qt, j) + 4 * h;
+                        const int off = tf_off(true, qt_own, j) + 4 * h;
                         *reinterpret_cast<h2v*>(scr + SC_Q + tf_blk(8, 0) + off) = hi;
                         *reinterpret_cast<h2v*>(scr + SC_Q + tf_blk(8, 1) + off) = lo;
                     }
                 }
             }
+            FT(10);
             if (h < 3) {
                 wg_barrier();                              // every wave is done with v_h
+                FT(11);
                 dma_fill<4 * V_TILE>(lds + L_V, scr + SC_V + (h + 1) * 4 * V_TILE, wave, lane);
             }
         }
         wg_barrier_global();                               // the attention output is in the scratch block; the staging area is free
+        FT(11);
         // ================= hidden = relu(bn(W1x x + W1a att + b1')): two halves of 264 rows =========================================
         dma_fill<TF_BYTES>(lds, scr + SC_Q, wave, lane);   // att
         wg_barrier_global();
+        FT(12);
         zero_acc(acc, accr);
         conv_pass<false, 18>(pw + FW_1, 0, 9, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(13);
         wg_barrier();
         dma_fill<TF_BYTES>(lds, img_x, wave, lane);
         wg_barrier_global();
+        FT(14);
         conv_pass<false, 18>(pw + FW_1, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(15);
         auto hidden_out = [&](const f4v (&a)[2][FNT], const f4v (&ar)[2], int hf, char* dst) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -576,27 +651,52 @@ gnn_fine_layer_kernel(FineArgs g) {
             }
         };
         hidden_out(acc, accr, 0, scr + SC_K);
+        FT(16);
         zero_acc(acc, accr);
         conv_pass<false, 18>(pw + FW_1, 17, 0, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(15);
         wg_barrier();
         dma_fill<TF_BYTES>(lds, scr + SC_Q, wave, lane);   // att again
         wg_barrier_global();
+        FT(12);
         conv_pass<false, 18>(pw + FW_1, 17, 9, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(13);
         hidden_out(acc, accr, 1, scr + SC_V);
+        FT(16);
         wg_barrier_global();                               // hidden0 / hidden1 are in the scratch block; att has been read
         // ================= out = W2 hidden + b2 [+ residual] -> fp32 blocked + TF image ==============================================
         dma_fill<TF_BYTES>(lds, scr + SC_K, wave, lane);
         wg_barrier_global();
+        FT(17);
         zero_acc(acc, accr);
         conv_pass<false, 18>(pw + FW_2, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(18);
         wg_barrier();
         dma_fill<TF_BYTES>(lds, scr + SC_V, wave, lane);
         wg_barrier_global();
+        FT(17);
         conv_pass<false, 18>(pw + FW_2, 0, 9, lds, wave, lane, acc, accr, rt0, rt1);
+        FT(18);
         {
             const float* R = g.blk_res ? g.blk_res + p * (33 * FN * 8) : nullptr;
             float* O = g.blk_out + p * (33 * FN * 8);
             char* TO = g.tf_out ? g.tf_out + p * TF_BYTES : nullptr;
+            // every residual piece of this lane FIRST, in one batch (22 dependent load -> add -> store chains, each a trip to HBM,
+            // took 22 us of the 230 a problem cost in the first version)
+            f4v res[3][FNT];
+            if (R) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int mt = m < 2 ? 2 * wave + m : 16, ch = 16 * mt + 4 * gq;
+#pragma unroll
+                    for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
+                        const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
+                        res[m][tt] = f4v{0.f, 0.f, 0.f, 0.f};
+                        if (tok_t < 0 || !(mt < 16 || gq < 2) || (tok_t == 9 && j != 0)) continue;
+                        res[m][tt] = load4(R + ((int64_t)(ch >> 3) * FN + 16 * tok_t + j) * 8 + (ch & 7));
+                    }
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const int mt = m < 2 ? 2 * wave + m : 16, ch = 16 * mt + 4 * gq;
@@ -606,20 +706,33 @@ gnn_fine_layer_kernel(FineArgs g) {
                 for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
                     const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
                     if (tok_t < 0) continue;
-                    if (!rows_ok || (tok_t == 9 && j != 0)) continue;
+                    const bool live = rows_ok && !(tok_t == 9 && j != 0);
                     f4v v = fma4(m < 2 ? acc[m][tt] : accr[tt], bcast4(UNS), bias);
                     const int64_t e = ((int64_t)(ch >> 3) * FN + 16 * tok_t + j) * 8 + (ch & 7);
-                    if (R) v = load4(R + e) + v;
-                    *reinterpret_cast<f4v*>(O + e) = v;
+                    if (R) v = res[m][tt] + v;
+                    if (live) {
+                        *reinterpret_cast<f4v*>(O + e) = v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
-                    if (TO) store_tf(TO, mt, tok_t, v * PRE, lane);
+                        for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
+                    }
+                    if (TO) store_tf(TO, mt, tok_t, v * PRE, lane);           // (every lane: the pieces are paired across lanes)
                 }
             }
         }
+        FT(19);
         wg_barrier();                                      // hidden1 has been read: the next problem's source may land
+        FT(20);
+#ifdef PATS_DIAG
+        ++nprob;
+#endif
     }
     if (bad) atomicOr(g.flag, 1);
+#ifdef PATS_DIAG
+    if (g.tl && t == 0) {
+        for (int k = 0; k < FT_N - 1; ++k) g.tl[(size_t)blockIdx.x * FT_N + k] = tsum[k];
+        g.tl[(size_t)blockIdx.x * FT_N + FT_N - 1] = nprob;
+    }
+#endif
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
@@ -677,8 +790,31 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const f
     const int grid = fine_grid(P);
     if (grid <= 0) return PATS_ERR_UNSUPPORTED;
     const h8v* pw = (const h8v*)section;
-    FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate};
-    hipLaunchKernelGGL(gnn_fine_layer_kernel, dim3((unsigned)std::min(grid, fine_max_grid())), dim3(512), FINE_LDS, st, g);
+    static const int stagger = [] { const char* e = getenv("PATS_FINE_STAGGER"); return e ? atoi(e) : 0; }();
+    FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, stagger};
+    const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
+#ifdef PATS_DIAG
+    g.tl = nullptr;
+    if (getenv("PATS_FINE_TL")) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * FT_N * 8); (void)hipMemset(g.tl, 0, (size_t)wgs * FT_N * 8); }
+#endif
+    hipLaunchKernelGGL(gnn_fine_layer_kernel, dim3(wgs), dim3(512), FINE_LDS, st, g);
+#ifdef PATS_DIAG
+    if (g.tl) {
+        (void)hipStreamSynchronize(st);
+        std::vector<long long> h((size_t)wgs * FT_N);
+        (void)hipMemcpy(h.data(), g.tl, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[FT_N] = {0}, np = 0;
+        for (unsigned w = 0; w < wgs; ++w) { for (int k = 0; k < FT_N - 1; ++k) sum[k] += (double)h[(size_t)w * FT_N + k]; np += (double)h[(size_t)w * FT_N + FT_N - 1]; }
+        static const char* names[FT_N] = {"fill s", "k product", "k epilogue", "v^T product", "v^T epilogue", "barrier + fill x", "q product", "q epilogue",
+            "barrier (q k v visible)", "attention: wait k_h v_h", "attention: units", "attention: barrier after units", "fill att (x2)", "hidden: att part (x2)",
+            "barrier + fill x", "hidden: x part (x2)", "hidden epilogue (x2)", "fill hidden (x2)", "out product (x2)", "out epilogue", "last barrier", "", "", ""};
+        double tot = 0;
+        for (int k = 0; k <= 20; ++k) tot += sum[k];
+        fprintf(stderr, "gnn_fine timeline (%u workgroups, %.0f problems; mean us per problem, thread 0): total %.2f\n", wgs, np, tot / np / 100.0);
+        for (int k = 0; k <= 20; ++k) fprintf(stderr, "  %-34s %7.2f\n", names[k], sum[k] / np / 100.0);
+        (void)hipFree(g.tl);
+    }
+#endif
     return check_launch("gnn_fine_layer_kernel");
 }
 
