@@ -165,22 +165,39 @@ __device__ __forceinline__ void dma_fill(char* lds_dst, const char* src, int wav
 // issues ONE 16-byte store; a wave's store covers whole 256-byte runs.  (The first version stored 8-byte halves: every 128-byte line
 // of an image was written by two instructions with half its bytes enabled - read-for-ownership traffic at the memory side; the
 // output epilogue alone took 20 us of a problem's 230.)  Called by all 64 lanes (the exchange), inactive tiles masked at the store.
-__device__ __forceinline__ void store_tf(char* dst, int mt, int t, const f4v v, int lane) {
+// (addresses: uniform base + per-store scalar constant + one of three 32-bit lane offsets made once per problem - global_store
+//  with an SGPR base; per-store 64-bit vector addresses were what the epilogues spilled and reloaded behind s_waitcnt vmcnt(0))
+struct LaneOff { unsigned tf0, tf1, tf2, blk; };
+__device__ __forceinline__ LaneOff lane_offsets(int lane) {
+    const unsigned g = (unsigned)lane >> 4, j = (unsigned)lane & 15u;
+    LaneOff o;
+    o.tf0 = (g & 1u) * TFB + (g >> 1) * 256u + j * 16u;    // full k-step, token tiles 0..8
+    o.tf1 = (g & 1u) * TFB + (g >> 1) * 16u;               // full k-step, token 144 (lanes j = 0)
+    o.tf2 = (g & 1u) * TFR + j * 16u;                      // ragged k-step (lanes g < 2)
+    o.blk = (((g >> 1) * FN + j) * 8u + (g & 1u) * 4u) * 4u;   // fp32 channel-blocked: rows 16 mt + 4 g.. of token 16 t + j, bytes
+    return o;
+}
+__device__ __forceinline__ void store_tf(char* dst, int mt, int t, const f4v v, int lane, const LaneOff& lo_) {
     const int g = lane >> 4, j = lane & 15;
     h4v hi, lo;
     split4_pre(v, hi, lo);
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    u2v H = __builtin_bit_cast(u2v, hi), L = __builtin_bit_cast(u2v, lo);
+    const u2v H = __builtin_bit_cast(u2v, hi), L = __builtin_bit_cast(u2v, lo);
     // lane_swap16(a, b): odd rows of a <-> even rows of b.  Afterwards an even-row lane holds (own hi, partner's hi) = the hi piece,
     // an odd-row lane (partner's lo, own lo) = the lo piece - both as (H, L)
     unsigned hx = H.x, hy = H.y, lx = L.x, ly = L.y;
     lane_swap16(hx, lx);
     lane_swap16(hy, ly);
-    if (t == 9 && j != 0) return;
-    if (mt == 16 && g >= 2) return;
-    const int ks = mt >> 1, kq = mt == 16 ? 0 : 2 * (mt & 1) + (g >> 1);
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<u4v*>(dst + tf_blk(ks, g & 1) + tf_off(mt == 16, t, kq * 16 + j)) = u4v{hx, hy, lx, ly};
+    const u4v piece = {hx, hy, lx, ly};
+    if (mt < 16) {
+        char* d = dst + (mt >> 1) * (2 * TFB) + (mt & 1) * (t < 9 ? 512 : 32) + (t < 9 ? t * 1024 : 9216);
+        if (t < 9) *reinterpret_cast<u4v*>(d + lo_.tf0) = piece;
+        else if (j == 0) *reinterpret_cast<u4v*>(d + lo_.tf1) = piece;
+    } else {
+        char* d = dst + TF_MAIN + (t < 9 ? t * 256 : 2304);
+        if (g < 2 && (t < 9 || j == 0)) *reinterpret_cast<u4v*>(d + lo_.tf2) = piece;
+    }
 }
 
 // ---- one convolution pass over the nine k-steps of the TF image in LDS -----------------------------------------------------------
@@ -370,7 +387,7 @@ gnn_fine_layer_kernel(FineArgs g) {
     if (g.gate && *g.gate == 0) return;
     const int t = threadIdx.x, lane = t & 63, wave0 = __builtin_amdgcn_readfirstlane(t >> 6);
     char* scr0 = g.scratch + (size_t)blockIdx.x * SC_BYTES;
-    bool bad = false;
+    bool bad = false, first = true;
     const int lane0 = lane;
     for (int i = (int)(blockIdx.x >> 3 & 31) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);       // ~1 us a step
 #ifdef PATS_DIAG
@@ -393,6 +410,7 @@ gnn_fine_layer_kernel(FineArgs g) {
         const int rt0 = wave, rt1 = wave < 2 ? wave + 8 : -1;
         const int vt0 = wave < 5 ? 2 * wave : -1, vt1 = wave < 5 ? 2 * wave + 1 : -1;
         const int gq = lane >> 4, j = lane & 15;
+        const LaneOff lo_ = lane_offsets(lane);
         const char* img_x = g.tf_x + p * TF_BYTES;
         int64_t ps = p + g.shift;
         if (ps >= g.P) ps -= g.P;
@@ -402,7 +420,8 @@ gnn_fine_layer_kernel(FineArgs g) {
         tlast = __builtin_amdgcn_s_memrealtime();
 #endif
         // ================= source -> k (TF image + packed extras), v^T (A fragments of the second attention product) =================
-        dma_fill<TF_BYTES>(lds, img_s, wave, lane);
+        if (first) dma_fill<TF_BYTES>(lds, img_s, wave, lane);      // (later problems: started under the previous output epilogue)
+        first = false;
         wg_barrier_global();
         FT(0);
         zero_acc(acc, accr);
@@ -413,7 +432,7 @@ gnn_fine_layer_kernel(FineArgs g) {
             for (int m = 0; m < 2; ++m) {
                 const f4v bias = load4(pb + FB_K + 16 * (2 * wave + m) + 4 * gq) * PRE;
 #pragma unroll
-                for (int tt = 0; tt < FNT; ++tt) store_tf(scr + SC_K, 2 * wave + m, tt, fma4(acc[m][tt], bcast4(UNS * PRE), bias), lane);
+                for (int tt = 0; tt < FNT; ++tt) store_tf(scr + SC_K, 2 * wave + m, tt, fma4(acc[m][tt], bcast4(UNS * PRE), bias), lane, lo_);
             }
             // extras: rows 256 + 4 g + r = (head 2 g + (r >> 1), channel 64 + (r & 1)); A packing (h0 h1 l0 l1 h0 h1 0 0)
             const f4v bias = load4(pb + FB_K + 256 + 4 * (gq & 1)) * PRE;
@@ -433,6 +452,8 @@ gnn_fine_layer_kernel(FineArgs g) {
         zero_acc(acc, accr);
         conv_pass<true, 9>(pw + FW_V, 0, 0, lds, wave, lane, acc, accr, vt0, vt1);
         FT(3);
+        wg_barrier();                                      // the source image has been read: x lands under the epilogue
+        dma_fill<TF_BYTES>(lds, img_x, wave, lane);
         {
             // rows = tokens 16 t + 4 g + r, column = channel 16 mt + j: key slots (g, e) of k-step kk = token tiles 2 kk (e < 4), 2 kk + 1
 #pragma unroll
@@ -459,20 +480,23 @@ gnn_fine_layer_kernel(FineArgs g) {
             }
         }
         FT(4);
-        wg_barrier();                                      // the source image has been read
         // ================= x -> q (TF image + packed extras, B packing (h0 h1 h0 h1 l0 l1 0 0)) ======================================
-        dma_fill<TF_BYTES>(lds, img_x, wave, lane);
         wg_barrier_global();
         FT(5);
         zero_acc(acc, accr);
         conv_pass<false, 9>(pw + FW_Q, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
         FT(6);
+        wg_barrier();                                      // the x image has been read: k_0, v_0 and the extras tile land under the epilogue
+        dma_fill<4 * TFB>(lds + L_KA, scr + SC_K, wave, lane);       // (k and v have been in the scratch block since the barriers above)
+        dma_fill<FN * 16>(lds + L_KA + 4 * TFB, scr + SC_KX, wave, lane);
+        dma_fill<4 * V_TILE>(lds + L_V, scr + SC_V, wave, lane);
+        dma_fill<V_TILE>(lds + L_VX, scr + SC_V + 16 * V_TILE, wave, lane);
         {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const f4v bias = load4(pb + FB_Q + 16 * (2 * wave + m) + 4 * gq) * PRE;
 #pragma unroll
-                for (int tt = 0; tt < FNT; ++tt) store_tf(scr + SC_Q, 2 * wave + m, tt, fma4(acc[m][tt], bcast4(UNS * PRE), bias), lane);
+                for (int tt = 0; tt < FNT; ++tt) store_tf(scr + SC_Q, 2 * wave + m, tt, fma4(acc[m][tt], bcast4(UNS * PRE), bias), lane, lo_);
             }
             const f4v bias = load4(pb + FB_Q + 256 + 4 * (gq & 1)) * PRE;
 #pragma unroll
@@ -491,10 +515,6 @@ gnn_fine_layer_kernel(FineArgs g) {
         wg_barrier_global();                               // q, k, v are in the scratch block; the x image has been read
         FT(8);
         // ================= attention: unit = (head, 16-query tile); its output replaces its own q tile ===============================
-        dma_fill<4 * TFB>(lds + L_KA, scr + SC_K, wave, lane);
-        dma_fill<FN * 16>(lds + L_KA + 4 * TFB, scr + SC_KX, wave, lane);
-        dma_fill<4 * V_TILE>(lds + L_V, scr + SC_V, wave, lane);
-        dma_fill<V_TILE>(lds + L_VX, scr + SC_V + 16 * V_TILE, wave, lane);
         // this wave's queries of a unit: B operand, two k-steps + the packed extras (every lane reads the piece of its query; lanes
         // k / 8 > 0 then take zeros).  Loaded one unit AHEAD: the scratch block is an L2 / Infinity-Cache round trip away.
         struct QF { h8v h0, l0, h1, l1, x; };
@@ -599,7 +619,7 @@ gnn_fine_layer_kernel(FineArgs g) {
                     __builtin_amdgcn_sched_barrier(0);
                     o = o * osc;
                     if (dt < 4) {
-                        store_tf(scr + SC_Q, 4 * h + dt, qt_own, o, lane);
+                        store_tf(scr + SC_Q, 4 * h + dt, qt_own, o, lane, lo_);
                     } else if (gq == (h >> 1) && (qt_own < 9 || j == 0)) {
                         // rows 2 h', 2 h' + 1 of the extras tile are head h's channels 64, 65 -> bytes 4 h .. of the ragged block's piece
                         const float e0 = (h & 1) ? o.z : o.x, e1 = (h & 1) ? o.w : o.y;
@@ -646,7 +666,7 @@ gnn_fine_layer_kernel(FineArgs g) {
                     f4v v = fma4(m < 2 ? a[m][tt] : ar[tt], scl, shf);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];            // ReLU that keeps NaN
-                    store_tf(dst, mt, tok_t, v, lane);
+                    store_tf(dst, mt, tok_t, v, lane, lo_);
                 }
             }
         };
@@ -661,22 +681,26 @@ gnn_fine_layer_kernel(FineArgs g) {
         FT(12);
         conv_pass<false, 18>(pw + FW_1, 17, 9, lds, wave, lane, acc, accr, rt0, rt1);
         FT(13);
-        hidden_out(acc, accr, 1, scr + SC_V);
+        wg_barrier();                                      // att has been read: hidden[264:528] goes from the accumulators straight into the slot
+        hidden_out(acc, accr, 1, lds);
         FT(16);
-        wg_barrier_global();                               // hidden0 / hidden1 are in the scratch block; att has been read
+        wg_barrier();
         // ================= out = W2 hidden + b2 [+ residual] -> fp32 blocked + TF image ==============================================
-        dma_fill<TF_BYTES>(lds, scr + SC_K, wave, lane);
-        wg_barrier_global();
-        FT(17);
         zero_acc(acc, accr);
-        conv_pass<false, 18>(pw + FW_2, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
+        conv_pass<false, 18>(pw + FW_2, 0, 9, lds, wave, lane, acc, accr, rt0, rt1);      // the second half of the channels first
         FT(18);
         wg_barrier();
-        dma_fill<TF_BYTES>(lds, scr + SC_V, wave, lane);
+        dma_fill<TF_BYTES>(lds, scr + SC_K, wave, lane);   // hidden[0:264] (in the scratch block since the barriers behind its epilogue)
         wg_barrier_global();
         FT(17);
-        conv_pass<false, 18>(pw + FW_2, 0, 9, lds, wave, lane, acc, accr, rt0, rt1);
+        conv_pass<false, 18>(pw + FW_2, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
         FT(18);
+        wg_barrier();                                      // the slot is free: the next problem's source lands under the output epilogue
+        if (p + gridDim.x < g.P) {
+            int64_t pn = p + gridDim.x + g.shift;
+            if (pn >= g.P) pn -= g.P;
+            dma_fill<TF_BYTES>(lds, g.tf_s + pn * TF_BYTES, wave, lane);
+        }
         {
             const float* R = g.blk_res ? g.blk_res + p * (33 * FN * 8) : nullptr;
             float* O = g.blk_out + p * (33 * FN * 8);
@@ -693,7 +717,7 @@ gnn_fine_layer_kernel(FineArgs g) {
                         const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
                         res[m][tt] = f4v{0.f, 0.f, 0.f, 0.f};
                         if (tok_t < 0 || !(mt < 16 || gq < 2) || (tok_t == 9 && j != 0)) continue;
-                        res[m][tt] = load4(R + ((int64_t)(ch >> 3) * FN + 16 * tok_t + j) * 8 + (ch & 7));
+                        res[m][tt] = *reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(R + (2 * mt * FN + 16 * tok_t) * 8) + lo_.blk);
                     }
                 }
             }
@@ -708,20 +732,17 @@ gnn_fine_layer_kernel(FineArgs g) {
                     if (tok_t < 0) continue;
                     const bool live = rows_ok && !(tok_t == 9 && j != 0);
                     f4v v = fma4(m < 2 ? acc[m][tt] : accr[tt], bcast4(UNS), bias);
-                    const int64_t e = ((int64_t)(ch >> 3) * FN + 16 * tok_t + j) * 8 + (ch & 7);
                     if (R) v = res[m][tt] + v;
                     if (live) {
-                        *reinterpret_cast<f4v*>(O + e) = v;
+                        *reinterpret_cast<f4v*>(reinterpret_cast<char*>(O + (2 * mt * FN + 16 * tok_t) * 8) + lo_.blk) = v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
                     }
-                    if (TO) store_tf(TO, mt, tok_t, v * PRE, lane);           // (every lane: the pieces are paired across lanes)
+                    if (TO) store_tf(TO, mt, tok_t, v * PRE, lane, lo_);           // (every lane: the pieces are paired across lanes)
                 }
             }
         }
         FT(19);
-        wg_barrier();                                      // hidden1 has been read: the next problem's source may land
-        FT(20);
 #ifdef PATS_DIAG
         ++nprob;
 #endif
