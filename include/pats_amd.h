@@ -43,7 +43,7 @@ const char* pats_version(void);
  * `row_nomatch` to pats_iterative_expand_f32 under the same symbol: a caller built against the older header would pass
  * its stream where the new pointer goes).  A C consumer checks `pats_abi_version() == PATS_ABI_VERSION` once after
  * loading the library; pats_amd/_lib.py does.  New arguments now come with new entry points instead. */
-#define PATS_ABI_VERSION 5
+#define PATS_ABI_VERSION 6
 int pats_abi_version(void);
 const char* pats_last_error(void);
 /* number of HIP devices visible (0 on a CPU-only box; never fails) */
@@ -512,6 +512,23 @@ int pats_attentional_propagation_packed_f32(const float* x, const float* source,
                                             int n, int m, const pats_propagation_weights* w, const void* packed,
                                             int bn_train, float bn_eps, const float* residual, float* out,
                                             void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
+/* (ABI 6) At the FINE level's shape - C = 264, 4 heads, n = m = 145 (models/second_layer.py:44,89) - and bn_train == 0 the packed
+ * layer is ONE kernel (csrc/gnn_fine.hip): a persistent workgroup per CU owns a problem, the descriptors arrive as pre-split
+ * fragment images by LDS DMA, every product's output lives in the accumulators, q / k / v / attention / hidden stay in a
+ * per-workgroup scratch block.  The BatchNorm scale / shift applied there are the ones in `w` AT PACK TIME (eval mode).
+ * pats_attentional_propagation_packed_f32 converts a layer's [batch, C, n] tensors on the way in and out;
+ * pats_attentional_gnn_packed_f32 is AttentionalGNN.forward (models/modules.py:127-134: `layers` propagations on both descriptor
+ * sets, cross[l] != 0 = 'cross', the residual of :133 included) with the descriptors kept in the kernel's own form between the
+ * layers.  weights[l] / packed[l]: the layer's weights and its pats_propagation_pack_f32 buffer.  Returns PATS_ERR_UNSUPPORTED
+ * (nothing launched) at any other shape - run the layers one by one then.  A launch that meets a non-finite value raises a
+ * device-side flag; the per-layer compositions queued behind, gated on it, redo the stack (no host read).  PATS_GNN_FINE=0
+ * switches the kernel off (both entry points take the round-4 kernels). */
+size_t pats_attentional_gnn_packed_workspace_bytes(int64_t batch, int C, int heads, int n);
+int pats_attentional_gnn_packed_f32(const float* desc0, const float* desc1, int64_t batch, int C, int heads, int n, int layers,
+                                    const pats_propagation_weights* const* weights, const void* const* packed,
+                                    const int* cross, float bn_eps, float* out0, float* out1, void* workspace,
+                                    size_t workspace_bytes, pats_stream_t stream);
 
 /* ---- the descriptor heads either side of the GNN: Conv1d(kernel_size=1) and BatchNorm1d + ReLU -------------------
  * Replaces nn.Conv1d(k=1) wherever the path uses it alone - `final_proj` right before the cost build

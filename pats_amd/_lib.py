@@ -17,7 +17,7 @@ if os.environ.get("PATS_AMD_DIAG_LIB", "") not in ("", "0"):
 c_void_p, c_int, c_i64, c_f, c_size = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                        ctypes.c_size_t)
 
-ABI_VERSION = 5      # include/pats_amd.h PATS_ABI_VERSION
+ABI_VERSION = 6      # include/pats_amd.h PATS_ABI_VERSION
 
 # name -> (restype, argtypes); must list every symbol include/pats_amd.h declares
 SIGNATURES = {
@@ -127,6 +127,9 @@ SIGNATURES = {
     "pats_propagation_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size, c_void_p]),
     "pats_attentional_propagation_packed_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                                         c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_attentional_gnn_packed_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "pats_attentional_gnn_packed_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_f,
+                                                c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_matches_by_pair_workspace_bytes": (c_size, [c_int, c_i64]),
     "pats_matches_by_pair_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),

@@ -658,7 +658,8 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const f
 
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
                             const pats_propagation_weights* w, int bn_train, float bn_eps, const float* residual, float* out,
-                            void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed);
+                            void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed,
+                            const int* ext_gate = nullptr);
 
 extern "C" int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
                                                 int n, int m, const pats_propagation_weights* w, int bn_train,
@@ -684,7 +685,10 @@ extern "C" int pats_attentional_propagation_packed_f32(const float* x, const flo
 
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
                             const pats_propagation_weights* w, int bn_train, float bn_eps, const float* residual, float* out,
-                            void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed) {
+                            void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed,
+                            const int* ext_gate) {
+    // ext_gate: run ONLY the round-2 composition, every kernel of it gated on *ext_gate (the redo chain behind a fused stack,
+    // pats_attentional_gnn_packed_f32): no-ops unless that flag is raised
     PATS_REQUIRE(batch >= 0 && C > 0 && heads > 0 && n > 0 && m > 0 && (C % heads) == 0,
                  "attentional_propagation: bad shape");
     PATS_REQUIRE((C % 8) == 0, "attentional_propagation: feature_dim must be a multiple of 8 (operand slabs of 8 channels)");
@@ -710,7 +714,8 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     char* fine_scratch = p;
     if (hipMemsetAsync(redo, 0, 8 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
     int rc;
-    const int* gate = nullptr;
+    const int* gate = ext_gate;
+    if (ext_gate) packed = nullptr;
     if (packed && !bn_train && fine_layer_supported(C, heads, n, m) && gnn_fold_enabled() && !(residual && residual == out)) {
         // The fine level (round 5, gnn_fine.hip): the whole layer in one kernel on (fp32 blocked, TF image) descriptors.  This
         // single-layer entry converts on the way in and out (pats_attentional_gnn_packed_f32 keeps a stack in that form); the
@@ -813,6 +818,82 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     }
     // mlp[2] ReLU + mlp[3] Conv1d(2C, C), BN affine + ReLU applied while staging; optional residual (desc + delta, :133)
     return launch_conv(ConvArgs{w->w2_t, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out}, gate ? nullptr : redo + 5, st, gate);
+}
+
+// ---- AttentionalGNN.forward (modules.py:127-134) at the fine level's shape, descriptors kept in the one-kernel layer's own form ----
+// (round 5) desc0, desc1 [batch, 264, 145] -> one array of P = 2 batch problems as (fp32 channel-blocked, TF image), `layers` launches
+// of gnn_fine_layer_kernel (a layer updates BOTH descriptor sets: problem p < batch is desc0[p], p >= batch desc1[p - batch]; a
+// 'cross' layer reads the source image (p + batch) % P, a 'self' layer its own), back to [batch, 264, 145].  Between the layers
+// nothing but the two forms travels: no conversion, no q / k / v / message / hidden tensor in HBM.  Eval-mode BatchNorm only (the
+// scale / shift given at pack time).  If any layer meets a non-finite value (an activation beyond the fp16 range of the split
+// operands) a device flag is raised and the chain of per-layer compositions queued behind - every kernel gated on that flag -
+// recomputes the whole stack from the inputs.
+namespace pats {
+__global__ void __launch_bounds__(256) gated_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4, const int* __restrict__ gate) {
+    if (*gate == 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+size_t fine_blocked_bytes(int64_t P);
+}
+extern "C" size_t pats_attentional_gnn_packed_workspace_bytes(int64_t batch, int C, int heads, int n) {
+    if (batch <= 0 || !fine_layer_supported(C, heads, n, n)) return 0;
+    const int64_t P = 2 * batch;
+    const size_t fused = 2 * al256(fine_image_bytes(P)) + 2 * al256(fine_blocked_bytes(P));
+    const size_t redo = 4 * al256((size_t)batch * C * n * sizeof(float)) + al256(pats_attentional_propagation_workspace_bytes(batch, C, n, n));
+    return std::max(fused, redo) + al256(fine_scratch_bytes(P)) + 256;
+}
+extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* desc1, int64_t batch, int C, int heads, int n, int layers,
+                                               const pats_propagation_weights* const* weights, const void* const* packed,
+                                               const int* cross, float bn_eps, float* out0, float* out1, void* workspace,
+                                               size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(batch >= 0 && layers >= 0, "attentional_gnn_packed: bad shape");
+    if (!fine_layer_supported(C, heads, n, n) || !gnn_fold_enabled()) return PATS_ERR_UNSUPPORTED;
+    if (batch == 0) return PATS_OK;
+    PATS_REQUIRE(desc0 && desc1 && out0 && out1 && (layers == 0 || (weights && packed && cross)), "attentional_gnn_packed: null pointer");
+    PATS_REQUIRE(workspace && workspace_bytes >= pats_attentional_gnn_packed_workspace_bytes(batch, C, heads, n), "attentional_gnn_packed: workspace too small");
+    for (int l = 0; l < layers; ++l) PATS_REQUIRE(weights[l] && packed[l], "attentional_gnn_packed: null layer");
+    hipStream_t st = as_stream(stream);
+    const int64_t P = 2 * batch;
+    const size_t elems = (size_t)batch * C * n;
+    char* p = (char*)workspace;
+    const size_t fused = 2 * al256(fine_image_bytes(P)) + 2 * al256(fine_blocked_bytes(P));
+    const size_t redo_b = 4 * al256(elems * sizeof(float)) + al256(pats_attentional_propagation_workspace_bytes(batch, C, n, n));
+    char* tf[2] = {p, p + al256(fine_image_bytes(P))};
+    float* blk[2] = {(float*)(p + 2 * al256(fine_image_bytes(P))), (float*)(p + 2 * al256(fine_image_bytes(P)) + al256(fine_blocked_bytes(P)))};
+    char* scratch = p + std::max(fused, redo_b);
+    int* flag = (int*)(scratch + al256(fine_scratch_bytes(P)));
+    if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return check_launch("attentional_gnn_packed memset");
+    int rc;
+    // in: the two descriptor sets into one array of problems
+    if ((rc = launch_fine_in(desc0, batch, blk[0], tf[0], st))) return rc;
+    if ((rc = launch_fine_in(desc1, batch, blk[0] + elems, tf[0] + fine_image_bytes(batch), st))) return rc;
+    int cur = 0;
+    for (int l = 0; l < layers; ++l) {
+        rc = launch_fine_layer(tf[cur], tf[cur], cross[l] ? batch : 0, blk[cur], P, packed_fine_section(packed[l], C, heads), blk[1 - cur],
+                               tf[1 - cur], scratch, flag, nullptr, st);
+        if (rc) return rc;           // (PATS_ERR_UNSUPPORTED: the LDS attribute was refused - the caller takes the per-layer path)
+        cur = 1 - cur;
+    }
+    if ((rc = launch_fine_out(blk[cur], batch, out0, st))) return rc;
+    if ((rc = launch_fine_out(blk[cur] + elems, batch, out1, st))) return rc;
+    // the redo chain (no-ops unless the flag is up): the layers one by one on the round-2 composition, from the inputs
+    float* d[2][2] = {{(float*)p, (float*)(p + al256(elems * sizeof(float)))},
+                      {(float*)(p + 2 * al256(elems * sizeof(float))), (float*)(p + 3 * al256(elems * sizeof(float)))}};
+    void* cws = p + 4 * al256(elems * sizeof(float));
+    const size_t cws_b = pats_attentional_propagation_workspace_bytes(batch, C, n, n);
+    const float *c0 = desc0, *c1 = desc1;
+    for (int l = 0; l < layers; ++l) {
+        float *n0 = d[l & 1][0], *n1 = d[l & 1][1];
+        const float *s0 = cross[l] ? c1 : c0, *s1 = cross[l] ? c0 : c1;
+        if ((rc = propagation_impl(c0, s0, batch, C, heads, n, n, weights[l], 0, bn_eps, c0, n0, cws, cws_b, stream, nullptr, flag))) return rc;
+        if ((rc = propagation_impl(c1, s1, batch, C, heads, n, n, weights[l], 0, bn_eps, c1, n1, cws, cws_b, stream, nullptr, flag))) return rc;
+        c0 = n0; c1 = n1;
+    }
+    const int64_t n4 = (int64_t)(elems / 4);
+    const unsigned cg = (unsigned)std::min<int64_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(gated_copy_kernel, dim3(cg), dim3(256), 0, st, (const float4*)c0, (float4*)out0, n4, (const int*)flag);
+    hipLaunchKernelGGL(gated_copy_kernel, dim3(cg), dim3(256), 0, st, (const float4*)c1, (float4*)out1, n4, (const int*)flag);
+    return check_launch("gated_copy_kernel");
 }
 
 // ---- the building blocks on their own: Conv1d(kernel_size = 1) and the BatchNorm1d + ReLU that follows it in MLP ------

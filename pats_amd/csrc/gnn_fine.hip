@@ -811,7 +811,11 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const f
     const int grid = fine_grid(P);
     if (grid <= 0) return PATS_ERR_UNSUPPORTED;
     const h8v* pw = (const h8v*)section;
-    static const int stagger = [] { const char* e = getenv("PATS_FINE_STAGGER"); return e ? atoi(e) : 0; }();
+    // De-phasing: a layer's far-memory traffic comes in bursts (image fills, epilogues) that every workgroup of a lockstep grid
+    // issues at the same instants; workgroup i starts ((i >> 3) % 32) x 4 us late, which spreads them over a problem's period
+    // (4 096 problems: 4.86 -> 4.57 ms with the conversions).  Only where a workgroup has enough problems to pay for the ramp.
+    static const int stagger_env = [] { const char* e = getenv("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
+    const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)grid ? 4 : 0);
     FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, stagger};
     const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
 #ifdef PATS_DIAG

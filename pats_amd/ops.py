@@ -1077,8 +1077,48 @@ def attentional_propagation(x, source, params, heads=4, bn_train=False, residual
     return out
 
 
+UNSUPPORTED = 2            # include/pats_amd.h PATS_ERR_UNSUPPORTED
+GNN_STACK_ROWS = 4096     # rows of a descriptor set per pats_attentional_gnn_packed_f32 call (its workspace is ~1.2 MB a row)
+
+
+def _gnn_packed_stack(desc0, desc1, layers, names, heads):
+    """The whole stack in the fine level's one-kernel form (csrc/gnn_fine.hip), or None if the library has no such form for
+    this shape (anything but [b, 264, 145], 4 heads)."""
+    b, C, n = desc0.shape
+    if tuple(desc1.shape) != (b, C, n) or b == 0 or not _L().pats_attentional_gnn_packed_workspace_bytes(1, C, int(heads), n):
+        return None
+    packed = [p.packed(heads) for p in layers]
+    if any(pk is None for pk in packed) or any(p.C != C for p in layers):
+        return None
+    L = len(layers)
+    structs = [p.struct(False) for p in layers]
+    w_arr = (ctypes.c_void_p * max(L, 1))(*[ctypes.addressof(w) for w in structs])
+    pk_arr = (ctypes.c_void_p * max(L, 1))(*[pk.data_ptr() for pk in packed])
+    cross = (ctypes.c_int * max(L, 1))(*[1 if nm == "cross" else 0 for nm in names])
+    out0, out1 = torch.empty_like(desc0), torch.empty_like(desc1)
+    for lo in range(0, b, GNN_STACK_ROWS):
+        hi = min(b, lo + GNN_STACK_ROWS)
+        nb = _L().pats_attentional_gnn_packed_workspace_bytes(hi - lo, C, int(heads), n)
+        ws = _workspace(nb, desc0.device)
+        rc = _L().pats_attentional_gnn_packed_f32(_ptr(desc0[lo:hi]), _ptr(desc1[lo:hi]), hi - lo, C, int(heads), n, L, w_arr, pk_arr, cross,
+                                                  float(layers[0].eps) if L else 1e-5, _ptr(out0[lo:hi]), _ptr(out1[lo:hi]), _ptr(ws), nb,
+                                                  _stream())
+        if rc == UNSUPPORTED:
+            return None
+        _check(rc, "attentional_gnn_packed")
+    return out0, out1
+
+
 def attentional_gnn(desc0, desc1, layers, names, heads=4, bn_train=False):
-    """AttentionalGNN.forward (modules.py:127-134): layers = [PropagationParams, ...], names = ['self', 'cross', ...]."""
+    """AttentionalGNN.forward (modules.py:127-134): layers = [PropagationParams, ...], names = ['self', 'cross', ...].
+    At the fine level's shape ([b, 264, 145], eval-mode BatchNorm) the whole stack runs in the one-kernel layer's own descriptor
+    form (pats_attentional_gnn_packed_f32); any other shape: layer by layer."""
+    layers, names = list(layers), list(names)
+    if not bn_train and len(layers) == len(names):
+        desc0, desc1 = _dev(desc0, "desc0"), _dev(desc1, "desc1")
+        got = _gnn_packed_stack(desc0, desc1, layers, names, heads)
+        if got is not None:
+            return got
     for p, name in zip(layers, names):
         src0, src1 = (desc1, desc0) if name == "cross" else (desc0, desc1)
         n0 = attentional_propagation(desc0, src0, p, heads, bn_train, residual=desc0)

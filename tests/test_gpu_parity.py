@@ -1848,3 +1848,56 @@ def test_fused_fine_level_cost_ot_is_the_two_kernel_path_bit_for_bit(ops, oracle
         p = subprocess.run([sys.executable, "-c", FUSED_FINE_CHILD % {"repo": REPO}], env=dict(env, PATS_FINE_W2=w2), capture_output=True,
                            text=True, timeout=900)
         assert p.returncode == 0 and "OK" in p.stdout, "PATS_FINE_W2=" + w2 + ": " + p.stdout[-500:] + p.stderr[-2500:]
+
+
+# ---- the fine level's one-kernel layer and stack (csrc/gnn_fine.hip, round 5) -----------------------------------------------------
+def test_fine_level_gnn_stack_matches_the_layer_by_layer_path(ops, oracle):
+    """pats_attentional_gnn_packed_f32 (descriptors kept as (blocked fp32, fragment image) between the layers) against the same
+    layers run one by one through pats_attentional_propagation_packed_f32, and against the oracle: four layers, self / cross, more
+    problems than workgroups (every scratch block and the LDS slot are reused), odd batch."""
+    C, n, b = 264, 145, 301
+    ps = [synth.gnn_params(seed=300 + i, C=C) for i in range(4)]
+    names = ["self", "cross", "cross", "self"]
+    P = [ops.PropagationParams(p) for p in ps]
+    a = synth.gnn_inputs(seed=310, b=b, C=C, n=n)
+    d0, d1 = cu(a["x"]), cu(a["source"])
+    s0, s1 = ops.attentional_gnn(d0, d1, P, names)
+    assert torch.equal(d0, cu(a["x"])) and torch.equal(d1, cu(a["source"]))                    # inputs are borrowed
+    l0, l1 = d0, d1
+    for p, name in zip(P, names):
+        x0, x1 = (l1, l0) if name == "cross" else (l0, l1)
+        l0, l1 = ops.attentional_propagation(l0, x0, p, residual=l0), ops.attentional_propagation(l1, x1, p, residual=l1)
+    # the stack rounds nothing the single layer does not; the only difference is the order of the two halves of mlp[3]'s sum
+    np.testing.assert_allclose(s0.cpu().numpy(), l0.cpu().numpy(), atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(s1.cpu().numpy(), l1.cpu().numpy(), atol=2e-5, rtol=2e-5)
+    # the first 3 problems of each set against the oracle's four layers
+    r0, r1 = a["x"][:3], a["source"][:3]
+    full0, full1 = a["x"], a["source"]
+    # (cross layers couple row i of one set with row i of the other only: three rows suffice)
+    for p, name in zip(ps, names):
+        y0, y1 = (r1, r0) if name == "cross" else (r0, r1)
+        r0, r1 = (oracle.attentional_propagation(r0, y0, p, residual=r0), oracle.attentional_propagation(r1, y1, p, residual=r1))
+    np.testing.assert_allclose(s0[:3].cpu().numpy(), r0, atol=1e-4, rtol=2e-4)
+    np.testing.assert_allclose(s1[:3].cpu().numpy(), r1, atol=1e-4, rtol=2e-4)
+    # launch-to-launch identical
+    t0, t1 = ops.attentional_gnn(d0, d1, P, names)
+    assert torch.equal(s0, t0) and torch.equal(s1, t1)
+
+
+def test_fine_level_gnn_stack_beyond_the_fp16_range(ops, oracle):
+    """An activation beyond +-1023 overflows the hi half of the split operands: the one-kernel layer raises its flag and the gated
+    per-layer compositions queued behind the stack redo it from the inputs (fp32 MFMA inside conv1x1_kernel) - no host read."""
+    C, n, b = 264, 145, 4
+    ps = [synth.gnn_params(seed=320 + i, C=C) for i in range(2)]
+    a = synth.gnn_inputs(seed=330, b=b, C=C, n=n)
+    x, s = a["x"].copy(), a["source"].copy()
+    x[1, 7, 33] = 3.0e4                                                                           # one wild descriptor entry
+    d0, d1 = ops.attentional_gnn(cu(x), cu(s), [ops.PropagationParams(p) for p in ps], ["self", "cross"])
+    r0, r1 = x, s
+    for p, name in zip(ps, ["self", "cross"]):
+        y0, y1 = (r1, r0) if name == "cross" else (r0, r1)
+        r0, r1 = (oracle.attentional_propagation(r0, y0, p, residual=r0), oracle.attentional_propagation(r1, y1, p, residual=r1))
+    assert np.isfinite(d0.cpu().numpy()).all()
+    np.testing.assert_allclose(d0.cpu().numpy(), r0, atol=2e-2, rtol=2e-4)                        # (outputs of magnitude 3e4 in row 1)
+    np.testing.assert_allclose(d1.cpu().numpy(), r1, atol=2e-2, rtol=2e-4)
+    np.testing.assert_allclose(d0.cpu().numpy()[[0, 2, 3]], r0[[0, 2, 3]], atol=1e-4, rtol=2e-4)
