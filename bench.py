@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--wild", type=float, default=0.0, metavar="FRAC",
                     help="diagnostic: scale the backbone maps of this fraction of the fine rows by 32 (scores x 1024) before the timed steps - "
                          "the guard-trip leg as the whole run, for kernel traces; not a bench line")
+    ap.add_argument("--with-gnn", action="store_true",
+                    help="time whole steps WITH the layers' heads inside (GnnNets: KeypointEncoder, the 18 / 18 / 10-layer GNN stacks, "
+                         "final_proj, scale heads on random weights) and print that report instead of the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
@@ -218,6 +221,135 @@ class BenchNets:
         if e is not None:
             e.record()
         return t0, t1, self.scale3, ps, pt
+
+
+class GnnNets:
+    """BenchNets with the HEADS inside the step (round-4 verdict item 3): what the three layers run between their backbone and their
+    optimal-transport problem - KeypointEncoder, the 18 / 18 / 10-layer AttentionalGNN stacks (first_layer.py:100-102,
+    second_layer.py:89, third_layer.py:146-148), final_proj, the scale heads - on random weights, as callbacks of
+    pats_amd.batch.forward_pairs.  The backbones stay what BenchNets holds (synthetic maps, resident).  Weights: the reference's
+    initialisation (synth.gnn_params / kenc_params) with the LAST Conv1d of every MLP scaled by 0.02, final_proj orthogonal and
+    the scale heads' stencils small: the residual stacks then perturb the synthetic descriptors instead of scrambling them, so the
+    optimal-transport problems behind them keep the headline's match structure and the step's counts (rows, P, M) stay comparable -
+    the arithmetic per layer does not depend on the values.  Every launch that runs over a capacity takes its count from the device
+    (rows: chunk_base[-1]; third-level problems: P)."""
+
+    def __init__(self, base, ops, dev, h, w):
+        from pats_amd import heads
+        self.base, self.ops, self.h, self.w = base, ops, h, w
+        self.lefts, self.rights = base.lefts, base.rights
+        g = torch.Generator(device=dev)
+        g.manual_seed(99)
+
+        def gnn(C, layers, seed):
+            out = []
+            for i in range(layers):
+                p = synth.gnn_params(seed=seed + i, C=C)
+                p["mlp.3.weight"] = (0.02 * p["mlp.3.weight"]).astype(np.float32)
+                out.append(ops.PropagationParams(p, device=dev))
+            return out
+
+        def kenc(dim, seed):
+            p = synth.kenc_params(seed=seed, feature_dim=dim)
+            last = max(int(k.split(".")[1]) for k in p if k.endswith(".weight") and p[k].ndim == 3)
+            p["encoder.%d.weight" % last] = (0.02 * p["encoder.%d.weight" % last]).astype(np.float32)
+            return ops.MLPParams(p, device=dev, prefix="encoder.")
+
+        def ortho(C):
+            q, _ = torch.linalg.qr(torch.randn((C, C), device=dev, generator=g))
+            return q.contiguous().reshape(C, C, 1), torch.zeros((C,), device=dev)
+
+        def stencil(C):
+            return (0.002 * torch.randn((1, C, 3, 3), device=dev, generator=g)).contiguous(), torch.zeros((1,), device=dev)
+        self.names18, self.names10 = ["self", "cross"] * 9, ["self", "cross"] * 5
+        self.coarse_heads = heads.CoarseHeads(kenc(448, 501), gnn(448, 18, 510), self.names18, ortho(448), stencil(448), bin_score=0.0)
+        self.gnn2, self.proj2 = gnn(264, 18, 540), ortho(264)
+        self.sx2, self.sy2 = stencil(264), stencil(264)
+        self.kenc3, self.gnn3, self.scale3 = kenc(128, 502), gnn(128, 10, 570), stencil(128)
+        R, Pc = base.cap.rows_cap, base.cap.P_cap
+        # outputs of the stacks over the capacities, resident (rows past the device-side counts are never written: zeros)
+        self.g2 = (torch.zeros((R, 264, 145), device=dev), torch.zeros((R, 264, 145), device=dev))
+        self.g3 = (torch.zeros((Pc, 128, 65), device=dev), torch.zeros((Pc, 128, 65), device=dev))
+        for t in base.desc + base.t0 + base.t1:
+            t.zero_()                                       # the gathers' padding rows: zeros, not whatever torch.empty left
+        self.ev = None
+
+    def _timed(self, tag):
+        if self.ev is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.ev.setdefault(tag, []).append((e0, e1))
+        e0.record()
+        return e1
+
+    def coarse(self, lefts, rights):
+        b = self.base
+        e = self._timed("coarse_heads")
+        pairs = b.d0.shape[0]
+        out = self.coarse_heads(b.d0.reshape(pairs, 448, self.h, self.w), b.d1.reshape(pairs, 448, self.h, self.w))
+        if e is not None:
+            e.record()
+        return out
+
+    def fine(self, rows, new_left, new_right):
+        b, ops = self.base, self.ops
+        live = rows.chunk_base[-1:]
+        desc = b.fine(rows, new_left, new_right)                                                     # a15 (counted)
+        e = self._timed("fine_gnn")
+        d0, d1 = ops.attentional_gnn(desc[0], desc[1], self.gnn2, self.names18, count=live, out=self.g2)     # second_layer.py:89
+        if e is not None:
+            e.record()
+        e = self._timed("fine_proj_scale")
+        m0, m1 = ops.conv1d(d0, *self.proj2), ops.conv1d(d1, *self.proj2)                             # :91
+        _, (sx, sy) = ops.scale_head(m1, 12, 12, [self.sx2[0], self.sy2[0]], [self.sx2[1], self.sy2[1]], return_heads=True)   # :92-97
+        if e is not None:
+            e.record()
+        return m0, m1, sx.contiguous(), sy.contiguous()
+
+    def third(self, rows, mk0, mk1, b_ids, P_dev):
+        b, ops = self.base, self.ops
+        from pats_amd import heads
+        k3 = ops.keypoint_encoder(heads.grid_kpts(8, 8, mk0.device), self.kenc3)                    # third_layer.py:132-140
+        kk = b.third_calls & 1
+        b.third_calls += 1
+        t0, t1, ps, pt = ops.third_descriptors(b.ff0, b.ff1, mk0, mk1, b_ids, k3.reshape(128, 64), b.rubbish3, count=P_dev,
+                                               out=(b.t0[kk], b.t1[kk]))                             # a16
+        e = self._timed("third_gnn")
+        f0, f1 = ops.attentional_gnn(t0, t1, self.gnn3, self.names10, count=P_dev, out=self.g3)      # :146-148
+        if e is not None:
+            e.record()
+        scale = ops.scale_head(f1, 8, 8, [self.scale3[0]], [self.scale3[1]])                         # :151-152
+        return f0, f1, scale, ps, pt
+
+
+def with_gnn_leg(ops, batch, dev, base, cap, wl, h, w, steps, warm=1):
+    """`steps` whole steps with the heads inside (GnnNets), timed like the headline's: barrier, wall clock, markers for a kernel trace."""
+    nets = GnnNets(base, ops, dev, h, w)
+    run_steps(batch, nets, cap, wl, None, warm, None)
+    torch.cuda.synchronize()
+    ev = {}
+    nets.ev = ev
+    watch = StepWatch(cap)
+    torch.cuda.synchronize()
+    ops.profile_marker(1)
+    t0 = time.perf_counter()
+    out = run_steps(batch, nets, cap, wl, None, steps, None, watch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.profile_marker(2)
+    nets.ev = None
+    mean = lambda tag: float(np.mean([a.elapsed_time(b_) for a, b_ in ev[tag]])) if tag in ev else None
+    rep = {"pairs_per_s_with_gnn_measured": cap.pairs * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "ms_in_step": {"coarse_heads (KeypointEncoder + 18 layers + final_proj + scale head)": mean("coarse_heads"),
+                          "fine_gnn (18 layers, both descriptor sets, every row in use)": mean("fine_gnn"),
+                          "fine_proj_scale (final_proj x 2 + two scale heads)": mean("fine_proj_scale"),
+                          "third_gnn (10 layers, both sets, every problem in use)": mean("third_gnn")},
+           "rows_in_use": int(out["rows"].chunk_base[-1].item()), "third_problems": int(out["P"].item()), "matches": int(out["M"].item()),
+           "note": "the headline step with the layers' heads as callbacks of batch.forward_pairs (bench.py::GnnNets): random weights, "
+                   "backbones synthetic and resident; launches over capacities take their counts from the device"}
+    del nets
+    torch.cuda.empty_cache()
+    return rep
 
 
 def _tensors(obj):
@@ -857,6 +989,9 @@ def main():
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
     n_gpus = dist.get_world_size() if dist is not None else 1
+    if args.with_gnn:
+        print(json.dumps(with_gnn_leg(ops, batch, dev, nets, cap, wl, h, w, max(1, args.steps), warm=max(1, args.warmup))))
+        return
     if args.soak > 0:
         rep = step_determinism(batch, nets, cap, wl, n=args.soak + 1)
         rep["all_zero"] = rep.pop("identical")
@@ -1129,6 +1264,7 @@ def main():
             nets.set_layout(args.maps == "nhwc")
             gnn, gnn_roof = gnn_secondary(ops, dev, pairs, rows_step, P_step, 1e3 * dt / max(steps, 1), wl["outdoor"])
             res["gnn"] = gnn
+            res["gnn"]["measured"] = with_gnn_leg(ops, batch, dev, nets, cap, wl, h, w, 2)
             res["roofline_secondary"] = other + [gnn_roof] + secondary_rooflines(ops, dev)
             res["guard_trips"] = guard_trip_sweep(ops, batch, nets, cap, wl)
             res["step_determinism"] = step_determinism(batch, nets, cap, wl)

@@ -523,12 +523,22 @@ int pats_attentional_propagation_packed_f32(const float* x, const float* source,
  * layers.  weights[l] / packed[l]: the layer's weights and its pats_propagation_pack_f32 buffer.  Returns PATS_ERR_UNSUPPORTED
  * (nothing launched) at any other shape - run the layers one by one then.  A launch that meets a non-finite value raises a
  * device-side flag; the per-layer compositions queued behind, gated on it, redo the stack (no host read).  PATS_GNN_FINE=0
- * switches the kernel off (both entry points take the round-4 kernels). */
+ * switches the kernel off (both entry points take the round-4 kernels).
+ * live (may be NULL): a device-side row count - throughput mode's row total; rows >= clamp(*live - live_off, 0, batch) of both
+ * descriptor sets are not processed (their output rows hold whatever the conversion of the inputs left there).
+ * pats_attentional_propagation_packed_counted_f32: one packed layer over a capacity with such a count (honoured by the one-kernel
+ * layers at the third and the fine level's shapes in eval mode; ignored otherwise). */
 size_t pats_attentional_gnn_packed_workspace_bytes(int64_t batch, int C, int heads, int n);
-int pats_attentional_gnn_packed_f32(const float* desc0, const float* desc1, int64_t batch, int C, int heads, int n, int layers,
+int pats_attentional_gnn_packed_f32(const float* desc0, const float* desc1, int64_t batch, const int64_t* live, int64_t live_off,
+                                    int C, int heads, int n, int layers,
                                     const pats_propagation_weights* const* weights, const void* const* packed,
                                     const int* cross, float bn_eps, float* out0, float* out1, void* workspace,
                                     size_t workspace_bytes, pats_stream_t stream);
+int pats_attentional_propagation_packed_counted_f32(const float* x, const float* source, int64_t batch, const int64_t* live,
+                                                    int64_t live_off, int C, int heads, int n, int m,
+                                                    const pats_propagation_weights* w, const void* packed, int bn_train,
+                                                    float bn_eps, const float* residual, float* out, void* workspace,
+                                                    size_t workspace_bytes, pats_stream_t stream);
 
 /* ---- the descriptor heads either side of the GNN: Conv1d(kernel_size=1) and BatchNorm1d + ReLU -------------------
  * Replaces nn.Conv1d(k=1) wherever the path uses it alone - `final_proj` right before the cost build

@@ -128,8 +128,11 @@ SIGNATURES = {
     "pats_attentional_propagation_packed_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                                         c_int, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_attentional_gnn_packed_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
-    "pats_attentional_gnn_packed_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_f,
-                                                c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_attentional_gnn_packed_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                c_void_p, c_f, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_attentional_propagation_packed_counted_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int,
+                                                                c_void_p, c_void_p, c_int, c_f, c_void_p, c_void_p, c_void_p, c_size,
+                                                                c_void_p]),
     "pats_matches_by_pair_workspace_bytes": (c_size, [c_int, c_i64]),
     "pats_matches_by_pair_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),

@@ -642,7 +642,7 @@ int launch_attention145(const float* query, const float* key, const float* value
 int fused_layer_supported(int C, int heads, int n, int m);                                                // gnn_fused.hip
 int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
                        int bn_train, const float* residual, float* out, float* hid, int* flag, double* bn_part, int* splits_out,
-                       hipStream_t st);
+                       hipStream_t st, const int64_t* live = nullptr, int64_t live_off = 0);
 int launch_gnn_tail(const float* hid, int64_t batch, const void* packed, const float* scale, const float* shift, const float* residual,
                     float* out, int* flag, hipStream_t st);
 // the fine level's one-kernel layer (gnn_fine.hip)
@@ -651,15 +651,16 @@ const void* packed_fine_section(const void* packed, int C, int heads);          
 size_t fine_scratch_bytes(int64_t P);
 size_t fine_image_bytes(int64_t P);
 int launch_fine_in(const float* x, int64_t P, float* blk, char* tf, hipStream_t st);
-int launch_fine_out(const float* blk, int64_t P, float* y, hipStream_t st);
+int launch_fine_out(const float* blk, int64_t P, float* y, hipStream_t st, const int64_t* live = nullptr, int64_t live_off = 0);
 int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const float* blk_res, int64_t P, const void* section,
-                      float* blk_out, char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st);
+                      float* blk_out, char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
+                      const int64_t* live, int64_t live_off);
 }
 
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
                             const pats_propagation_weights* w, int bn_train, float bn_eps, const float* residual, float* out,
                             void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed,
-                            const int* ext_gate = nullptr);
+                            const int* ext_gate = nullptr, const int64_t* live = nullptr, int64_t live_off = 0);
 
 extern "C" int pats_attentional_propagation_f32(const float* x, const float* source, int64_t batch, int C, int heads,
                                                 int n, int m, const pats_propagation_weights* w, int bn_train,
@@ -683,10 +684,23 @@ extern "C" int pats_attentional_propagation_packed_f32(const float* x, const flo
                             packed);
 }
 
+// The packed layer over a CAPACITY with the problem count on the device (throughput mode: the third level's P, the fine level's row
+// total): problems >= clamp(*live - live_off, 0, batch) are skipped by the one-kernel layers (third and fine level's shapes, eval
+// mode); their output rows are left untouched.  Any other shape / bn_train: the count is ignored, every problem is computed.
+extern "C" int pats_attentional_propagation_packed_counted_f32(const float* x, const float* source, int64_t batch, const int64_t* live,
+                                                               int64_t live_off, int C, int heads, int n, int m,
+                                                               const pats_propagation_weights* w, const void* packed, int bn_train,
+                                                               float bn_eps, const float* residual, float* out, void* workspace,
+                                                               size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(packed, "attentional_propagation_packed_counted: null packed weights");
+    return propagation_impl(x, source, batch, C, heads, n, m, w, bn_train, bn_eps, residual, out, workspace, workspace_bytes, stream,
+                            packed, nullptr, live, live_off);
+}
+
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
                             const pats_propagation_weights* w, int bn_train, float bn_eps, const float* residual, float* out,
                             void* workspace, size_t workspace_bytes, pats_stream_t stream, const void* packed,
-                            const int* ext_gate) {
+                            const int* ext_gate, const int64_t* live, int64_t live_off) {
     // ext_gate: run ONLY the round-2 composition, every kernel of it gated on *ext_gate (the redo chain behind a fused stack,
     // pats_attentional_gnn_packed_f32): no-ops unless that flag is raised
     PATS_REQUIRE(batch >= 0 && C > 0 && heads > 0 && n > 0 && m > 0 && (C % heads) == 0,
@@ -729,9 +743,9 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         if (source != x && (rc = launch_fine_in(source, batch, nullptr, tf_s, st))) return rc;
         if (residual && residual != x && (rc = launch_fine_in(residual, batch, blk_res, nullptr, st))) return rc;
         rc = launch_fine_layer(tf_x, tf_s, 0, blk_res, batch, packed_fine_section(packed, C, heads), blk_out, nullptr, fine_scratch, flag,
-                               nullptr, st);
+                               nullptr, st, 1, live, live_off);
         if (rc == PATS_OK) {
-            if ((rc = launch_fine_out(blk_out, batch, out, st))) return rc;
+            if ((rc = launch_fine_out(blk_out, batch, out, st, live, live_off))) return rc;
             gate = flag;         // the composition below runs only if the kernel raised it
         } else if (rc != PATS_ERR_UNSUPPORTED) {
             return rc;
@@ -742,7 +756,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         // behind it would read the residual the first attempt has already overwritten - such a call takes the composition alone
         int* flag = redo + 7;
         int splits = 0;
-        rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, bpart, &splits, st);
+        rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, bpart, &splits, st, live, live_off);
         if (rc == PATS_OK) {
             if (bn_train) {      // the fused kernel stopped behind mlp[0] and left per-workgroup partial sums of the hidden tensor:
                                  // scale / shift from them, then mlp[1..3] from the hidden tensor in one kernel
@@ -842,7 +856,8 @@ extern "C" size_t pats_attentional_gnn_packed_workspace_bytes(int64_t batch, int
     const size_t redo = 4 * al256((size_t)batch * C * n * sizeof(float)) + al256(pats_attentional_propagation_workspace_bytes(batch, C, n, n));
     return std::max(fused, redo) + al256(fine_scratch_bytes(P)) + 256;
 }
-extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* desc1, int64_t batch, int C, int heads, int n, int layers,
+extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* desc1, int64_t batch, const int64_t* live, int64_t live_off,
+                                               int C, int heads, int n, int layers,
                                                const pats_propagation_weights* const* weights, const void* const* packed,
                                                const int* cross, float bn_eps, float* out0, float* out1, void* workspace,
                                                size_t workspace_bytes, pats_stream_t stream) {
@@ -870,12 +885,12 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     int cur = 0;
     for (int l = 0; l < layers; ++l) {
         rc = launch_fine_layer(tf[cur], tf[cur], cross[l] ? batch : 0, blk[cur], P, packed_fine_section(packed[l], C, heads), blk[1 - cur],
-                               tf[1 - cur], scratch, flag, nullptr, st);
+                               tf[1 - cur], scratch, flag, nullptr, st, 2, live, live_off);
         if (rc) return rc;           // (PATS_ERR_UNSUPPORTED: the LDS attribute was refused - the caller takes the per-layer path)
         cur = 1 - cur;
     }
-    if ((rc = launch_fine_out(blk[cur], batch, out0, st))) return rc;
-    if ((rc = launch_fine_out(blk[cur] + elems, batch, out1, st))) return rc;
+    if ((rc = launch_fine_out(blk[cur], batch, out0, st, live, live_off))) return rc;
+    if ((rc = launch_fine_out(blk[cur] + elems, batch, out1, st, live, live_off))) return rc;
     // the redo chain (no-ops unless the flag is up): the layers one by one on the round-2 composition, from the inputs
     float* d[2][2] = {{(float*)p, (float*)(p + al256(elems * sizeof(float)))},
                       {(float*)(p + 2 * al256(elems * sizeof(float))), (float*)(p + 3 * al256(elems * sizeof(float)))}};

@@ -93,6 +93,9 @@ struct FineArgs {
     int64_t P, shift;
     int* flag;
     const int* gate;           // optional: no-op unless *gate != 0
+    const int64_t* live;       // optional device-side ROW count: of every descriptor set (`sets` of them, `half` rows each: P = sets * half)
+    int64_t live_off, half;    // only rows < clamp(*live - live_off, 0, half) are problems
+    int sets;
     int stagger;               // workgroup i starts ((i >> 3) % 32) * stagger * ~1 us late: de-phases the memory bursts of the stages
 #ifdef PATS_DIAG
     long long* tl;             // diagnostic library: FT_N accumulated stage durations per workgroup (thread 0, 10 ns units)
@@ -365,16 +368,18 @@ gnn_fine_in_kernel(const float* __restrict__ x, int64_t P, float* __restrict__ b
 }
 
 __global__ void __launch_bounds__(256)
-gnn_fine_out_kernel(const float* __restrict__ blk, int64_t P, float* __restrict__ y, const int* __restrict__ gate_skip) {
-    // gate_skip: the layer's flag - when it is raised the composition behind writes y itself, this copy must not overwrite it later;
-    // (it runs BEFORE the composition in stream order, so it may simply run - kept for symmetry: unused)
-    (void)gate_skip;
+gnn_fine_out_kernel(const float* __restrict__ blk, int64_t P, float* __restrict__ y, const int64_t* __restrict__ live, int64_t live_off) {
+    // rows past the device-side count (no layer computed them): zeros, so that whatever runs over the capacity next reads finite values
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= P * 33 * FN) return;
     const int64_t p = gid / (33 * FN);
     const int r = (int)(gid - p * (33 * FN)), cg = r / FN, tok = r - cg * FN;
-    const float* s = blk + ((p * 33 + cg) * FN + tok) * 8;
-    const f4v a = load4(s), b = load4(s + 4);
+    f4v a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (!live || p < *live - live_off) {
+        const float* s = blk + ((p * 33 + cg) * FN + tok) * 8;
+        a = load4(s);
+        b = load4(s + 4);
+    }
     float* d = y + (p * FC + cg * 8) * FN + tok;
     d[0] = a.x; d[FN] = a.y; d[2 * FN] = a.z; d[3 * FN] = a.w;
     d[4 * FN] = b.x; d[5 * FN] = b.y; d[6 * FN] = b.z; d[7 * FN] = b.w;
@@ -393,7 +398,11 @@ gnn_fine_layer_kernel(FineArgs g) {
 #ifdef PATS_DIAG
     long long tsum[FT_N] = {0}, tlast = 0, nprob = 0;
 #endif
-    for (int64_t p = blockIdx.x; p < g.P; p += gridDim.x) {
+    int64_t L = g.half;                                   // live rows per descriptor set
+    if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
+    const int64_t NQ = L * g.sets;                         // live problems: q -> problem (q / L) * half + q % L
+    for (int64_t q_ = blockIdx.x; q_ < NQ; q_ += gridDim.x) {
+        const int64_t p = q_ < L ? q_ : g.half + (q_ - L);
         // Everything the epilogues address is invariant over the problem loop (the scratch block, the lane's offsets in a TF image):
         // left alone the compiler hoists several hundred store addresses and fragment bases out of the loop and spills the
         // accumulators around them (672 spilled VGPRs in the first build).  An opaque copy of the lane index per problem ...
@@ -696,8 +705,9 @@ gnn_fine_layer_kernel(FineArgs g) {
         conv_pass<false, 18>(pw + FW_2, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
         FT(18);
         wg_barrier();                                      // the slot is free: the next problem's source lands under the output epilogue
-        if (p + gridDim.x < g.P) {
-            int64_t pn = p + gridDim.x + g.shift;
+        if (q_ + gridDim.x < NQ) {
+            const int64_t qn = q_ + gridDim.x;
+            int64_t pn = (qn < L ? qn : g.half + (qn - L)) + g.shift;
             if (pn >= g.P) pn -= g.P;
             dma_fill<TF_BYTES>(lds, g.tf_s + pn * TF_BYTES, wave, lane);
         }
@@ -800,14 +810,16 @@ int launch_fine_in(const float* x, int64_t P, float* blk, char* tf, hipStream_t 
     hipLaunchKernelGGL(gnn_fine_in_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, P, blk, tf);
     return check_launch("gnn_fine_in_kernel");
 }
-int launch_fine_out(const float* blk, int64_t P, float* y, hipStream_t st) {
+int launch_fine_out(const float* blk, int64_t P, float* y, hipStream_t st, const int64_t* live, int64_t live_off) {
     const int64_t items = P * 33 * FN;
-    hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, blk, P, y, (const int*)nullptr);
+    hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, blk, P, y, live, live_off);
     return check_launch("gnn_fine_out_kernel");
 }
 // one layer over P problems: image p of tf_x with source image (p + shift) % P of tf_s
+// sets descriptor sets of P / sets rows each; live (optional): device-side row count of a set, minus live_off
 int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const float* blk_res, int64_t P, const void* section,
-                      float* blk_out, char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st) {
+                      float* blk_out, char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
+                      const int64_t* live, int64_t live_off) {
     const int grid = fine_grid(P);
     if (grid <= 0) return PATS_ERR_UNSUPPORTED;
     const h8v* pw = (const h8v*)section;
@@ -816,7 +828,7 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const f
     // (4 096 problems: 4.86 -> 4.57 ms with the conversions).  Only where a workgroup has enough problems to pay for the ramp.
     static const int stagger_env = [] { const char* e = getenv("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
     const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)grid ? 4 : 0);
-    FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, stagger};
+    FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off, P / sets, sets, stagger};
     const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
 #ifdef PATS_DIAG
     g.tl = nullptr;

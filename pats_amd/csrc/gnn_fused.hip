@@ -74,6 +74,8 @@ struct FusedArgs {
     int64_t batch;
     int* flag;
     double* bn_part;           // train: per-workgroup partial sums of the hidden tensor, [256][gridDim.x][2] (sum, sum of squares)
+    const int64_t* live;       // optional device-side problem count (eval mode): problems >= clamp(*live - live_off, 0, batch) are skipped
+    int64_t live_off;
 };
 
 __device__ __forceinline__ int tf_tile_off(int nt, int lane) {      // byte offset of this lane's 16-byte fragment piece in a block
@@ -332,6 +334,7 @@ gnn_layer_fused_kernel(FusedArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { st1[m][r] = 0.0; st2[m][r] = 0.0; }
     int64_t b = blockIdx.x;
+    if (g.live) { const int64_t l_ = *g.live - g.live_off; g.batch = l_ < 0 ? 0 : (l_ < g.batch ? l_ : g.batch); }
     InRegs xin, sin;
     if (b < g.batch) {
         load_in(g.x + b * (GC * GN), t, xin);
@@ -762,7 +765,7 @@ namespace pats {
 // The layer (eval: whole; train: up to the hidden tensor) for batch problems.  flag: one int, zero on entry.
 int launch_fused_layer(const float* x, const float* source, int64_t batch, const void* packed, const float* bn_a, const float* bn_b,
                        int bn_train, const float* residual, float* out, float* hid, int* flag, double* bn_part, int* splits_out,
-                       hipStream_t st) {
+                       hipStream_t st, const int64_t* live, int64_t live_off) {
     struct PerDevice { int state = 0; int n_cu = 256; };
     static PerDevice per_dev[64];
     int dev_id = 0;
@@ -782,7 +785,7 @@ int launch_fused_layer(const float* x, const float* source, int64_t batch, const
     }
     if (pd.state != 1) return PATS_ERR_UNSUPPORTED;
     const h8v* pw = (const h8v*)packed;
-    FusedArgs g{x, source, residual, out, hid, pw, (const float*)(pw + PW_END), bn_a, bn_b, batch, flag, bn_part};
+    FusedArgs g{x, source, residual, out, hid, pw, (const float*)(pw + PW_END), bn_a, bn_b, batch, flag, bn_part, bn_train ? nullptr : live, live_off};
     const unsigned grid = (unsigned)std::min<int64_t>(batch, std::min(pd.n_cu, FUSED_MAX_GRID));
     if (splits_out) *splits_out = (int)grid;
     const bool fold = gnn_fold_enabled();
@@ -800,7 +803,7 @@ int launch_gnn_tail(const float* hid, int64_t batch, const void* packed, const f
     if (hipGetDevice(&dev_id) != hipSuccess) { (void)hipGetLastError(); dev_id = 0; }
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n_cu <= 0) { (void)hipGetLastError(); n_cu = 256; }
     const h8v* pw = (const h8v*)packed;
-    FusedArgs g{nullptr, nullptr, residual, out, const_cast<float*>(hid), pw, (const float*)(pw + PW_END), nullptr, nullptr, batch, flag, nullptr};
+    FusedArgs g{nullptr, nullptr, residual, out, const_cast<float*>(hid), pw, (const float*)(pw + PW_END), nullptr, nullptr, batch, flag, nullptr, nullptr, 0};
     const unsigned grid = (unsigned)std::min<int64_t>(batch, 2 * (int64_t)n_cu);
     hipLaunchKernelGGL(gnn_tail_kernel, dim3(grid), dim3(512), 2 * TF_BYTES, st, g, scale, shift);
     return check_launch("gnn_tail_kernel");

@@ -1050,7 +1050,7 @@ class PropagationParams:
         return w
 
 
-def attentional_propagation(x, source, params, heads=4, bn_train=False, residual=None):
+def attentional_propagation(x, source, params, heads=4, bn_train=False, residual=None, count=None, out=None, count_off=0):
     """AttentionalPropagation.forward(x, source) (modules.py:114-117) -> delta [b,C,n]; with `residual` (= x in
     AttentionalGNN.forward, :131-133) the sum residual + delta.  bn_train: BatchNorm on batch statistics - what the
     third layer's GNN does under PATS.eval() (pats.py:112-120).  Six GEMM launches + the attention kernel."""
@@ -1061,11 +1061,21 @@ def attentional_propagation(x, source, params, heads=4, bn_train=False, residual
         raise RuntimeError("attentional_propagation: x %s / source %s / weights C=%d do not match"
                            % (tuple(x.shape), tuple(source.shape), params.C))
     res = _dev(residual, "residual") if residual is not None else None
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif tuple(out.shape) != tuple(x.shape) or not out.is_contiguous() or out.dtype != torch.float32 or not out.is_cuda:
+        raise RuntimeError("attentional_propagation: out must be a contiguous float32 GPU tensor shaped like x")
     nb = _L().pats_attentional_propagation_workspace_bytes(b, C, n, m)
     ws = _workspace(nb, x.device)
     w = params.struct(bn_train)
     pk = params.packed(heads)      # the third level's shape: one fused kernel (gnn_fused.hip); any other: packed-weights convolutions
+    if pk is not None and count is not None:
+        _check(_L().pats_attentional_propagation_packed_counted_f32(_ptr(x), _ptr(source), b, _ptr(_dev(count, "count", torch.int64)),
+                                                                    int(count_off), C,
+                                                                    int(heads), n, m, ctypes.byref(w), _ptr(pk), int(bool(bn_train)),
+                                                                    float(params.eps), _ptr(res), _ptr(out), _ptr(ws), nb, _stream()),
+               "attentional_propagation")
+        return out
     if pk is not None:
         _check(_L().pats_attentional_propagation_packed_f32(_ptr(x), _ptr(source), b, C, int(heads), n, m, ctypes.byref(w), _ptr(pk),
                                                             int(bool(bn_train)), float(params.eps), _ptr(res), _ptr(out), _ptr(ws),
@@ -1081,7 +1091,7 @@ UNSUPPORTED = 2            # include/pats_amd.h PATS_ERR_UNSUPPORTED
 GNN_STACK_ROWS = 4096     # rows of a descriptor set per pats_attentional_gnn_packed_f32 call (its workspace is ~1.2 MB a row)
 
 
-def _gnn_packed_stack(desc0, desc1, layers, names, heads):
+def _gnn_packed_stack(desc0, desc1, layers, names, heads, count=None, out=None):
     """The whole stack in the fine level's one-kernel form (csrc/gnn_fine.hip), or None if the library has no such form for
     this shape (anything but [b, 264, 145], 4 heads)."""
     b, C, n = desc0.shape
@@ -1095,12 +1105,13 @@ def _gnn_packed_stack(desc0, desc1, layers, names, heads):
     w_arr = (ctypes.c_void_p * max(L, 1))(*[ctypes.addressof(w) for w in structs])
     pk_arr = (ctypes.c_void_p * max(L, 1))(*[pk.data_ptr() for pk in packed])
     cross = (ctypes.c_int * max(L, 1))(*[1 if nm == "cross" else 0 for nm in names])
-    out0, out1 = torch.empty_like(desc0), torch.empty_like(desc1)
+    out0, out1 = out if out is not None else (torch.empty_like(desc0), torch.empty_like(desc1))
     for lo in range(0, b, GNN_STACK_ROWS):
         hi = min(b, lo + GNN_STACK_ROWS)
         nb = _L().pats_attentional_gnn_packed_workspace_bytes(hi - lo, C, int(heads), n)
         ws = _workspace(nb, desc0.device)
-        rc = _L().pats_attentional_gnn_packed_f32(_ptr(desc0[lo:hi]), _ptr(desc1[lo:hi]), hi - lo, C, int(heads), n, L, w_arr, pk_arr, cross,
+        rc = _L().pats_attentional_gnn_packed_f32(_ptr(desc0[lo:hi]), _ptr(desc1[lo:hi]), hi - lo, _ptr(count), lo, C, int(heads), n, L, w_arr,
+                                                  pk_arr, cross,
                                                   float(layers[0].eps) if L else 1e-5, _ptr(out0[lo:hi]), _ptr(out1[lo:hi]), _ptr(ws), nb,
                                                   _stream())
         if rc == UNSUPPORTED:
@@ -1109,22 +1120,52 @@ def _gnn_packed_stack(desc0, desc1, layers, names, heads):
     return out0, out1
 
 
-def attentional_gnn(desc0, desc1, layers, names, heads=4, bn_train=False):
+GNN_LAYER_ROWS = 32768    # rows per pass of the layer-by-layer path over a big batch (a layer's workspace is ~7 tensors)
+
+
+def attentional_gnn(desc0, desc1, layers, names, heads=4, bn_train=False, count=None, out=None):
     """AttentionalGNN.forward (modules.py:127-134): layers = [PropagationParams, ...], names = ['self', 'cross', ...].
     At the fine level's shape ([b, 264, 145], eval-mode BatchNorm) the whole stack runs in the one-kernel layer's own descriptor
-    form (pats_attentional_gnn_packed_f32); any other shape: layer by layer."""
+    form (pats_attentional_gnn_packed_f32); any other shape: layer by layer (eval mode: in blocks of GNN_LAYER_ROWS rows - rows are
+    independent problems, a cross layer couples row i of one set with row i of the other only).
+    count: optional device int64 [1] - only rows < count are problems (throughput mode: the launches cover a capacity); honoured
+    by the one-kernel layers (fine and third level's shapes, eval mode), rows past it are zeros (fine) / left untouched (third).
+    out: optional (out0, out1), contiguous float32 GPU tensors shaped like the inputs."""
     layers, names = list(layers), list(names)
+    desc0, desc1 = _dev(desc0, "desc0"), _dev(desc1, "desc1")
+    if out is not None and (len(out) != 2 or any(tuple(o.shape) != tuple(desc0.shape) or not o.is_contiguous() for o in out)):
+        raise RuntimeError("attentional_gnn: out must be two contiguous tensors shaped like the descriptors")
+    if count is not None:
+        count = _dev(count, "count", torch.int64)
     if not bn_train and len(layers) == len(names):
-        desc0, desc1 = _dev(desc0, "desc0"), _dev(desc1, "desc1")
-        got = _gnn_packed_stack(desc0, desc1, layers, names, heads)
+        got = _gnn_packed_stack(desc0, desc1, layers, names, heads, count, out)
         if got is not None:
             return got
-    for p, name in zip(layers, names):
-        src0, src1 = (desc1, desc0) if name == "cross" else (desc0, desc1)
-        n0 = attentional_propagation(desc0, src0, p, heads, bn_train, residual=desc0)
-        n1 = attentional_propagation(desc1, src1, p, heads, bn_train, residual=desc1)
-        desc0, desc1 = n0, n1
-    return desc0, desc1
+    b = desc0.shape[0]
+    if len(layers) == 0:
+        if out is not None:
+            out[0].copy_(desc0)
+            out[1].copy_(desc1)
+            return out[0], out[1]
+        return desc0, desc1
+    # batch statistics couple all rows of a launch: no blocking there
+    step = b if (bn_train or b <= GNN_LAYER_ROWS) else GNN_LAYER_ROWS
+    if step == b and out is None:
+        res = None
+    else:
+        res = out if out is not None else (torch.empty_like(desc0), torch.empty_like(desc1))
+    for lo in range(0, max(b, 1), max(step, 1)):
+        hi = min(b, lo + step)
+        c0, c1 = desc0[lo:hi], desc1[lo:hi]
+        for li, (p, name) in enumerate(zip(layers, names)):
+            src0, src1 = (c1, c0) if name == "cross" else (c0, c1)
+            last = li == len(layers) - 1 and res is not None
+            n0 = attentional_propagation(c0, src0, p, heads, bn_train, residual=c0, count=count, count_off=lo, out=res[0][lo:hi] if last else None)
+            n1 = attentional_propagation(c1, src1, p, heads, bn_train, residual=c1, count=count, count_off=lo, out=res[1][lo:hi] if last else None)
+            c0, c1 = n0, n1
+        if res is None:
+            return c0, c1
+    return res[0], res[1]
 
 
 # ------------------------------------------------------------------------------------------------
