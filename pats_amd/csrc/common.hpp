@@ -187,6 +187,17 @@ __device__ __forceinline__ void wg_barrier_global() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// wave_lds_sync(): between a wave's LDS writes and the reads of them by OTHER lanes of the SAME wave where no wg_barrier() stands in
+// between.  The hardware runs a wave's LDS operations in order, but to the compiler a lane's load does not depend on another lane's
+// store - in sinkhorn_blk145w2_kernel it hoisted such a read above the store (round 4: seven lanes in eight multiplied with the
+// previous sweep's value).  Wavefront-scope release / acquire fences order the two; no instruction is emitted.
+// tools/wave_lds_order_repro.hip is the pattern on its own; tools/lds_handover_audit.py lists the candidate sites of a tree.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Workgroup-wide OR of a predicate (what __syncthreads_or does, on wg_barrier()).  Called uniformly by all threads.
 __device__ __forceinline__ bool wg_barrier_or(bool pred) {
     __shared__ int wg_or_slot;

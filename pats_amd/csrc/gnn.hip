@@ -726,7 +726,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     double* bpart = (double*)p; p += al256((size_t)2 * C * 512 * 2 * sizeof(double));
     int* redo = (int*)p; p += 256;
     char* fine_scratch = p;
-    if (hipMemsetAsync(redo, 0, 8 * sizeof(int), st) != hipSuccess) return check_launch("attentional_propagation memset");
+    if (fill_bytes(redo, 0, 8 * sizeof(int), st)) return PATS_ERR_LAUNCH;      // (a pats:: kernel: the steps hold no runtime fill)
     int rc;
     const int* gate = ext_gate;
     if (ext_gate) packed = nullptr;
@@ -877,7 +877,7 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     float* blk[2] = {(float*)(p + 2 * al256(fine_image_bytes(P))), (float*)(p + 2 * al256(fine_image_bytes(P)) + al256(fine_blocked_bytes(P)))};
     char* scratch = p + std::max(fused, redo_b);
     int* flag = (int*)(scratch + al256(fine_scratch_bytes(P)));
-    if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return check_launch("attentional_gnn_packed memset");
+    if (fill_bytes(flag, 0, sizeof(int), st)) return PATS_ERR_LAUNCH;
     int rc;
     // in: the two descriptor sets into one array of problems
     if ((rc = launch_fine_in(desc0, batch, blk[0], tf[0], st))) return rc;
@@ -926,7 +926,7 @@ extern "C" int pats_conv1x1_f32(const float* w_t, const float* bias, const float
     PATS_REQUIRE(workspace && workspace_bytes >= pats_conv1x1_workspace_bytes(), "conv1x1: workspace too small");
     hipStream_t st = as_stream(stream);
     int* redo = (int*)workspace;
-    if (hipMemsetAsync(redo, 0, sizeof(int), st) != hipSuccess) return check_launch("conv1x1 memset");
+    if (fill_bytes(redo, 0, sizeof(int), st)) return PATS_ERR_LAUNCH;
     return launch_conv(ConvArgs{w_t, x, nullptr, K, 0, M, n, batch * n, in_scale, in_shift, bias, residual, y}, redo, st);
 }
 

@@ -804,7 +804,9 @@ sinkhorn_cu_kernel(SrcView src, int M, int N, const float* __restrict__ log_mu,
             if ((lane & 15) == 0 && RSum::slot_of(i, grp) < RPW) rsave[wave][RSum::slot_of(i, grp)] = rred[i];
     }
     // ---- c_j = max_i (Z_ij - r_i): per-wave partial, then across waves through LDS ---------------
-    // (same wave wrote rsave: LDS operations of one wave complete in order)
+    // (same wave wrote rsave: LDS operations of one wave complete in order - and wave_lds_sync() tells the compiler, to which the
+    //  reads below do not depend on another lane's store; round 5 audit, tools/lds_handover_audit.py)
+    wave_lds_sync();
 #define RS(s_) (rsave[wave][s_])
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {

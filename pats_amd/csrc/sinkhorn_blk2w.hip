@@ -38,14 +38,7 @@ __device__ __forceinline__ float uni(float x) {
 }
 __device__ __forceinline__ float mul_rcp(float num, float den) { return num * __builtin_amdgcn_rcpf(den); }
 
-// Between a wave's LDS writes and the reads by OTHER lanes of the same wave: the hardware runs a wave's LDS operations in order, but
-// to the compiler a lane's load does not depend on another lane's store - it hoisted the read of a[9 I + 8] above the (J = 0 only)
-// store of it, and seven lanes in eight multiplied with the previous sweep's value.  Wavefront-scope fences order the two.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// (wave_lds_sync(): common.hpp - every intra-wave hand-over of this kernel sits behind it)
 
 // wave priority up from the end of a half-sweep's FMA block to the hand-over of its result (reduction chain, reciprocal, LDS write,
 // barrier, the other half's start): the wave nearest to the hand-over gets the issue slots (as in sinkhorn_blk.hip).  PATS_W2_NO_PRIO: A/B
