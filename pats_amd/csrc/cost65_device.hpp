@@ -189,6 +189,11 @@ __device__ __forceinline__ void cost65_accumulate_f16x2(const float* __restrict_
         const h8v Boh = pack8(bh[1][0], bh[1][1], bh[1][2], bh[1][3]), Bol = pack8(bl[1][0], bl[1][1], bl[1][2], bl[1][3]);
         load_blk(s + 1 < nstep ? k0 + 16 : 0, q);        // wrap: a harmless reload at the end
         __builtin_amdgcn_sched_barrier(0);               // all eight operands complete before the first MFMA issues
+#ifdef PATS_EXP_PREFENCE                                 // (round-5 experiment, diagnostic builds: the fence on BOTH sides of the block)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        asm volatile("" :: "v"(Aeh), "v"(Ael), "v"(Aoh), "v"(Aol), "v"(Beh), "v"(Bel), "v"(Boh), "v"(Bol));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // small terms first, so that the dominant hi.hi product is added last to each accumulator
         c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ael, Beh, c00, 0, 0, 0);
         c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ael, Boh, c01, 0, 0, 0);

@@ -727,3 +727,38 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
 }
 
 }  // namespace pats
+
+#ifdef PATS_DIAG
+// Diagnostic library only (round 5, the first-launch divergence of the fp16-split instantiation): overwrite EVERY vector register
+// (v1..v255, a0..a255: a wave here owns its SIMD's whole register file) and the whole LDS of every CU with a bit pattern, so that the
+// next kernel starts from known leftovers - zeros, or a NaN pattern that exposes a read of an uninitialised register / LDS word.
+namespace pats {
+#define PR8(p, n) p #n "0\n" p #n "1\n" p #n "2\n" p #n "3\n" p #n "4\n" p #n "5\n" p #n "6\n" p #n "7\n" p #n "8\n" p #n "9\n"
+__global__ void __launch_bounds__(64, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) diag_poison_kernel(unsigned pat, int lds_words) {
+    extern __shared__ unsigned pz[];
+    for (int i = threadIdx.x; i < lds_words; i += 64) pz[i] = pat;
+    asm volatile(
+        "v_mov_b32 v1, %0\n v_mov_b32 v2, %0\n v_mov_b32 v3, %0\n v_mov_b32 v4, %0\n v_mov_b32 v5, %0\n v_mov_b32 v6, %0\n v_mov_b32 v7, %0\n v_mov_b32 v8, %0\n v_mov_b32 v9, %0\n"
+#define VM(n) "v_mov_b32 v" #n ", %0\n"
+#define VM10(t) VM(t##0) VM(t##1) VM(t##2) VM(t##3) VM(t##4) VM(t##5) VM(t##6) VM(t##7) VM(t##8) VM(t##9)
+        VM10(1) VM10(2) VM10(3) VM10(4) VM10(5) VM10(6) VM10(7) VM10(8) VM10(9) VM10(10) VM10(11) VM10(12) VM10(13) VM10(14) VM10(15) VM10(16) VM10(17)
+        VM10(18) VM10(19) VM10(20) VM10(21) VM10(22) VM10(23) VM10(24) VM(250) VM(251) VM(252) VM(253) VM(254) VM(255)
+#define AM(n) "v_accvgpr_write_b32 a" #n ", %0\n"
+#define AM10(t) AM(t##0) AM(t##1) AM(t##2) AM(t##3) AM(t##4) AM(t##5) AM(t##6) AM(t##7) AM(t##8) AM(t##9)
+        AM(0) AM(1) AM(2) AM(3) AM(4) AM(5) AM(6) AM(7) AM(8) AM(9)
+        AM10(1) AM10(2) AM10(3) AM10(4) AM10(5) AM10(6) AM10(7) AM10(8) AM10(9) AM10(10) AM10(11) AM10(12) AM10(13) AM10(14) AM10(15) AM10(16) AM10(17)
+        AM10(18) AM10(19) AM10(20) AM10(21) AM10(22) AM10(23) AM10(24) AM(250) AM(251) AM(252) AM(253) AM(254) AM(255)
+        :: "s"(pat)
+        : "v1","v2","v3","v4","v5","v6","v7","v8","v9","v250","v251","v252","v253","v254","v255","a0","a250","a251","a252","a253","a254","a255","a255",
+          "v10","v20","v30","v40","v50","v60","v70","v80","v90","v100","v110","v120","v130","v140","v150","v160","v170","v180","v190","v200","v210","v220","v230","v240","v249",
+          "a10","a20","a30","a40","a50","a60","a70","a80","a90","a100","a110","a120","a130","a140","a150","a160","a170","a180","a190","a200","a210","a220","a230","a240","a249");
+}
+}  // namespace pats
+extern "C" int pats_diag_poison(unsigned pattern, pats_stream_t stream) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)pats::diag_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    // 256 CUs x 4 SIMDs, several rounds: every SIMD's register file and every CU's LDS is written at least once
+    hipLaunchKernelGGL(pats::diag_poison_kernel, dim3(256 * 4 * 4), dim3(64), 160 * 1024 - 64, pats::as_stream(stream), pattern, (160 * 1024 - 64) / 4);
+    return pats::check_launch("diag_poison_kernel");
+}
+#endif

@@ -14,6 +14,10 @@ call; the scenario comes from the environment:
                     outbufs (tensors of the output shapes written and freed <s> times: the allocator hands launch 0 used blocks)
   MATMUL_CHECK=1    additionally: is hipBLASLt's own first heavy launch reproducible?  (x @ x) repeated, first result against later
   SMI=1             print sclk / power from sysfs right before and after launch 0
+  POISON=<hex>[:k]  (round 5, diagnostic library) before launch 0 - and again before launch k (default 2) - overwrite every vector
+                    register, accumulation register and LDS word of the chip with the 32-bit pattern (pats_diag_poison): 0 = start
+                    from clean leftovers; 7fc00000 = a quiet NaN in whatever the kernel reads before writing it.  If launch 0's
+                    divergence goes away with 0, or a LATER launch diverges behind a NaN poison, the kernel consumes leftovers.
   P=<n>             problems per launch (default 414720)
 The kernel under study is the fp16-split instantiation (PATS_THIRD_VARIANT=1350), which since round 4 exists in the diagnostic
 library only: build it with `python -m pats_amd.build --diag` and run with PATS_AMD_DIAG_LIB=1 PATS_THIRD_VARIANT=1350 (the
@@ -139,8 +143,20 @@ def main():
     if os.environ.get("SMI"):
         torch.cuda.synchronize()
         smi("before launch 0")
+    poison = None
+    if os.environ.get("POISON"):
+        import ctypes
+        from pats_amd import _lib
+        spec = os.environ["POISON"].split(":")
+        poison = (int(spec[0], 16), int(spec[1]) if len(spec) > 1 else 2)
+        lib = ctypes.CDLL(_lib.LIB_PATH)
+        lib.pats_diag_poison.restype = ctypes.c_int
+        lib.pats_diag_poison.argtypes = [ctypes.c_uint, ctypes.c_void_p]
+        do_poison = lambda: lib.pats_diag_poison(ctypes.c_uint(poison[0]), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     runs = []
     for i in range(L):
+        if poison is not None and i in (0, poison[1]):
+            assert do_poison() == 0
         runs.append(ops.third_level(*args, outdoor=True))
         if quiet or (i == 0 and os.environ.get("SMI")):
             torch.cuda.synchronize()
@@ -167,7 +183,7 @@ def main():
                   (i, n, d, ["%.3f" % (k / P) for k in idx[:8]]), flush=True)
     print("RESULT variant=%s scenario=%s differing-from-launch-1 per launch = %s" %
           (os.environ.get("PATS_THIRD_VARIANT", "default"),
-           ",".join("%s=%s" % (k, os.environ[k]) for k in ("SYNC_FIRST", "HOST_QUIET", "IDLE", "PREHEAT", "P") if k in os.environ) or "plain",
+           ",".join("%s=%s" % (k, os.environ[k]) for k in ("SYNC_FIRST", "HOST_QUIET", "IDLE", "PREHEAT", "POISON", "P") if k in os.environ) or "plain",
            counts), flush=True)
 
 
