@@ -10,9 +10,10 @@ LIB = os.path.join(HERE, "libpats_amd.so")
 # diagnostic twin: the same objects, third_fused3.hip compiled with -DPATS_DIAG (every sweep-loop variant and the timing
 # ablations whose results are wrong by design).  Built on request only (`--diag`); never loaded unless PATS_AMD_DIAG_LIB=1.
 LIB_DIAG = os.path.join(HERE, "libpats_amd_diag.so")
-DIAG_SOURCES = {"third_fused3.hip": ["-DPATS_DIAG=1"], "sinkhorn_blk.hip": ["-DPATS_DIAG=1"], "conv_pk.hip": ["-DPATS_DIAG=1"], "gnn_fine.hip": ["-DPATS_DIAG=1"]}
+DIAG_SOURCES = None      # every source, each with -DPATS_DIAG=1 (set below SOURCES): diag_env() (csrc/common.hpp) is live in that library only
 SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "sinkhorn_blk2w.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip", "attention145.hip", "gnn.hip", "gnn_fused.hip", "gnn_fine.hip", "conv_pk.hip",
            "fused.hip", "scale_head.hip", "batch.hip"]
+DIAG_SOURCES = {src: ["-DPATS_DIAG=1"] for src in SOURCES}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 # third_fused.hip runs at the 168-VGPR edge (three waves per SIMD).  The SLP vectoriser pairs the

@@ -299,7 +299,7 @@ int pats::launch_attention(const float* query, const float* key, const float* va
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(query && key && value && out, "attention: null pointer");
     const float sq0 = (float)sqrt((double)dim);
-    static const bool general_only = getenv("PATS_ATTN_GENERAL") != nullptr;     // A/B switch for benchmarking
+    static const bool general_only = diag_env("PATS_ATTN_GENERAL") != nullptr;     // A/B switch for benchmarking
     if (n == 65 && m == 65 && dim == 32 && !prob && !general_only) {            // the third-level shape
         PATS_REQUIRE(batch * heads < (1ll << 31), "attention: grid too large (split the batch)");
         AttnArgs g{query, key, value, dim, heads, n, m, 0, 32, sq0, 1.0f / sq0, out, nullptr, gate};

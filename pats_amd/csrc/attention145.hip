@@ -238,7 +238,7 @@ attention145_kernel(A145Args g) {
 // flag: one int, zero on entry; the caller queues the general kernel behind, gated on it.
 int launch_attention145(const float* query, const float* key, const float* value, int64_t batch, int dim, int heads, int n, int m,
                         float* out, int* flag, const int* gate, hipStream_t st) {
-    static const bool off = [] { const char* e = getenv("PATS_ATTN145"); return e && atoi(e) == 0; }();     // A/B switch
+    static const bool off = [] { const char* e = diag_env("PATS_ATTN145"); return e && atoi(e) == 0; }();     // A/B switch
     if (off || n > 16 * A_T || m > 16 * A_T || n <= 96 || m <= 96 || dim > 16 * A_DT || dim <= 32 || !flag) return PATS_ERR_UNSUPPORTED;
     if (batch * heads + 8 >= (1ll << 31)) return PATS_ERR_UNSUPPORTED;
     static int state[64] = {0};

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/pats_amd.h"
 
@@ -13,6 +14,20 @@ constexpr int WAVE = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float ZERO_F = 1e-14f;  // the reference's `zero` (utils/utils.py:1201)
+
+// ---- environment switches -----------------------------------------------------------------------------------------------------
+// The PRODUCTION library reads exactly the switches INTEGRATION.md lists (section "Environment switches": each selects a TESTED
+// alternative) - through env_switch().  Everything else - A/B partners of superseded kernel generations, timelines, ablations,
+// occupancy pads - goes through diag_env(), which is a constant nullptr outside -DPATS_DIAG builds (libpats_amd_diag*.so:
+// `python -m pats_amd.build --diag` compiles every file with it).  tests/test_host_abi.py holds the shipped library's strings to
+// that table.
+inline const char* env_switch(const char* name) { return getenv(name); }
+#ifdef PATS_DIAG
+inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
+bool cost_f32_only();      // PATS_COST_F32 (host.cpp): every contraction on the fp32 MFMA (the in-kernel fallback of the fp16 split)
 
 // ---- error plumbing ----------------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -438,7 +438,7 @@ int launch_conv_pk(const void* packed, const float* x0, const float* x1, int K0,
     PkArgs g{(const h8v*)packed, x0, x1, layout, K0, K1, M, n, q.npass, q.Kp, q.kspp, mtiles, tpg, groups, cols, wgs, per_xcd, in_scale, in_shift, bias, residual, y, redo, gate};
 #ifdef PATS_DIAG
     g.tl = nullptr;
-    if (getenv("PATS_PK_TL") && !(layout & 4)) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * 9 * 4); (void)hipMemset(g.tl, 0, (size_t)wgs * 9 * 4); }
+    if (diag_env("PATS_PK_TL") && !(layout & 4)) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * 9 * 4); (void)hipMemset(g.tl, 0, (size_t)wgs * 9 * 4); }
 #endif
     const dim3 grid((unsigned)(8 * per_xcd)), block(512);
     // (10..16 tiles take the 17-tile instantiation too: without the shared tile the same loop spills 29 registers at the 128 cap)

@@ -97,10 +97,10 @@ int pats::launch_cost(const float* d0, const float* d1, int64_t batch, int D, in
         return launch_cost65(d0, d1, D, batch, out, as_stream(stream));
     const int64_t tiles = (int64_t)((n + mt::CT - 1) / mt::CT) * ((m + mt::CT - 1) / mt::CT);
     PATS_REQUIRE(tiles * batch < (1ll << 31), "cost: grid too large (split the call)");
-    static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
+    const bool fp32_only = cost_f32_only();
     const float sq = (float)sqrt((double)D);
     const dim3 grid((unsigned)(tiles * batch)), block(256);
-    static const bool nt = [] { const char* e = getenv("PATS_COST_NT"); return e && atoi(e) != 0; }();
+    static const bool nt = [] { const char* e = diag_env("PATS_COST_NT"); return e && atoi(e) != 0; }();
     if (fp32_only)
         hipLaunchKernelGGL(cost_mfma_kernel<false>, grid, block, 0, as_stream(stream), d0, d1, D, n, m, 1.0f / sq, sq, out, live);
     else if (nt)

@@ -347,7 +347,7 @@ fine_desc_nhwc_kernel(const float* __restrict__ f0, const float* __restrict__ f1
 
 // PATS_GATHER_NT = 0..3 (see ldm / stm above), read once per process; without it 0 on NCHW maps, 3 on channels-last maps
 static int gather_policy(bool channels_last) {
-    static const int pol = [] { const char* e = getenv("PATS_GATHER_NT"); return e ? (atoi(e) & 3) : -1; }();
+    static const int pol = [] { const char* e = env_switch("PATS_GATHER_NT"); return e ? (atoi(e) & 3) : -1; }();
     return pol >= 0 ? pol : (channels_last ? 3 : 0);
 }
 #define GATHER_LAUNCH(KERNEL, NHWC, grid, ...)                                                                                \

@@ -544,13 +544,13 @@ const float* packed_folded_bias(const void* packed, int C, int heads);
 static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int* gate = nullptr) {
     ConvArgs g = g0;
     g.gate = gate;
-    static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
-    static const bool no_lean = [] { const char* e = getenv("PATS_CONV_LEAN"); return e && atoi(e) == 0; }();    // A/B switch
+    const bool fp32_only = cost_f32_only();
+    static const bool no_lean = [] { const char* e = diag_env("PATS_CONV_LEAN"); return e && atoi(e) == 0; }();    // A/B switch
     PATS_REQUIRE(g.cols < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
     const bool lean = redo && !fp32_only && !no_lean && !(g.residual && g.residual == g.y);
     // weights-stationary tile: exactly 128 channels in from one source, at most 128 out, and enough column tiles for a
     // persistent grid of 4 x CUs groups to pay (the third level: 26 325 tiles)
-    static const int ws_mode = [] { const char* e = getenv("PATS_CONV_WS"); return e ? atoi(e) : 1; }();     // A/B switch: 0 off, 2 = also on small grids (tests)
+    static const int ws_mode = [] { const char* e = env_switch("PATS_CONV_WS"); return e ? atoi(e) : 1; }();     // A/B switch: 0 off, 2 = also on small grids (tests)
     const int Kt = g.K0 + g.K1;
     const bool two = g.K1 > 0;
     // the tile needs up to the CU's whole 160 KB of LDS as dynamic shared memory: if the runtime will not grant it, the lean
@@ -589,7 +589,7 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int*
         else if (!two) hipLaunchKernelGGL((conv_ws_kernel<16, false>), dim3((unsigned)grid), dim3(1024), lds, st, g, row_tiles);
         else hipLaunchKernelGGL((conv_ws_kernel<16, true>), dim3((unsigned)grid), dim3(1024), lds, st, g, row_tiles);
     } else if (lean) {
-        static const int nt = getenv("PATS_CONV_NT") ? atoi(getenv("PATS_CONV_NT")) : 2;       // A/B switch: 2 or 4 column tiles
+        static const int nt = diag_env("PATS_CONV_NT") ? atoi(diag_env("PATS_CONV_NT")) : 2;       // A/B switch: 2 or 4 column tiles
         const int lc = 32 * (nt == 4 ? 4 : 2);
         const int64_t lt = (int64_t)((g.M + LR - 1) / LR) * ((g.cols + lc - 1) / lc);
         PATS_REQUIRE(lt < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
@@ -774,8 +774,8 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     // tensor - the layer's own intermediates - channel-BLOCKED ([batch, C / 8, n, 8]: 16-byte accesses both ways).  No fp32 path in
     // these kernels: a non-finite output anywhere raises ONE flag, and the round-2 composition below - gated on it, its kernels
     // return at once otherwise - redoes the layer.  (residual == out: the redo would read what the first attempt wrote.)
-    static const bool no_pk = [] { const char* e = getenv("PATS_CONV_PK"); return e && atoi(e) == 0; }();         // A/B switch
-    static const bool fp32_only = [] { const char* e = getenv("PATS_COST_F32"); return e && atoi(e) != 0; }();
+    static const bool no_pk = [] { const char* e = diag_env("PATS_CONV_PK"); return e && atoi(e) == 0; }();         // A/B switch
+    const bool fp32_only = cost_f32_only();
     if (packed && !gate && !no_pk && !fp32_only && !(residual && residual == out) && conv_pk_ready() && batch * (int64_t)std::max(n, m) < (1ll << 31)) {
         int* flag = redo + 7;
         const char* q0 = (const char*)packed + packed_fused_bytes(C, heads);

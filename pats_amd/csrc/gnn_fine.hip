@@ -768,7 +768,7 @@ gnn_fine_layer_kernel(FineArgs g) {
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 int fine_layer_supported(int C, int heads, int n, int m) {
-    static const bool off = [] { const char* e = getenv("PATS_GNN_FINE"); return e && atoi(e) == 0; }();
+    static const bool off = [] { const char* e = env_switch("PATS_GNN_FINE"); return e && atoi(e) == 0; }();
     return !off && C == FC && heads == 4 && n == FN && m == FN;
 }
 size_t packed_fine_bytes(int C, int heads) {
@@ -826,13 +826,13 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const f
     // De-phasing: a layer's far-memory traffic comes in bursts (image fills, epilogues) that every workgroup of a lockstep grid
     // issues at the same instants; workgroup i starts ((i >> 3) % 32) x 4 us late, which spreads them over a problem's period
     // (4 096 problems: 4.86 -> 4.57 ms with the conversions).  Only where a workgroup has enough problems to pay for the ramp.
-    static const int stagger_env = [] { const char* e = getenv("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
+    static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
     const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)grid ? 4 : 0);
     FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off, P / sets, sets, stagger};
     const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
 #ifdef PATS_DIAG
     g.tl = nullptr;
-    if (getenv("PATS_FINE_TL")) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * FT_N * 8); (void)hipMemset(g.tl, 0, (size_t)wgs * FT_N * 8); }
+    if (diag_env("PATS_FINE_TL")) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * FT_N * 8); (void)hipMemset(g.tl, 0, (size_t)wgs * FT_N * 8); }
 #endif
     hipLaunchKernelGGL(gnn_fine_layer_kernel, dim3(wgs), dim3(512), FINE_LDS, st, g);
 #ifdef PATS_DIAG

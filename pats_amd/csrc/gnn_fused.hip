@@ -674,7 +674,7 @@ gnn_tail_kernel(FusedArgs g, const float* __restrict__ scale, const float* __res
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 int fused_layer_supported(int C, int heads, int n, int m) {
-    static const bool off = [] { const char* e = getenv("PATS_GNN_FUSED"); return e && atoi(e) == 0; }();
+    static const bool off = [] { const char* e = env_switch("PATS_GNN_FUSED"); return e && atoi(e) == 0; }();
     return !off && C == GC && heads == 4 && n == GN && m == GN;
 }
 
@@ -691,7 +691,7 @@ size_t conv_packed_bytes(int K, int M);                                         
 int launch_conv_pack(const float* wt, int K, int M, void* packed, hipStream_t st);
 // merge folded into mlp[0] (gnn_fold_kernel): on unless PATS_GNN_FOLD=0; the same answer at pack time and at run time
 bool gnn_fold_enabled() {
-    static const bool on = [] { const char* e = getenv("PATS_GNN_FOLD"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char* e = env_switch("PATS_GNN_FOLD"); return !(e && atoi(e) == 0); }();
     return on;
 }
 static size_t packed_matrices_bytes(int C, int heads) {

@@ -112,7 +112,8 @@ extern "C" int pats_set_sinkhorn_mode(int mode) {
 
 // fine level (145 x 145, pats_cost_ot_f32 variant 2): 0 = cost_mfma_kernel + sinkhorn_blk145_kernel (default: measured 1 % faster),
 // 1 = the fused kernel (sinkhorn_blk.hip FUSED: no score matrix in HBM, two workgroups per CU).  PATS_FINE_FUSED=1 sets the default.
-static int g_fine_fused = getenv("PATS_FINE_FUSED") && atoi(getenv("PATS_FINE_FUSED")) != 0;
+static int g_fine_fused = env_switch("PATS_FINE_FUSED") && atoi(env_switch("PATS_FINE_FUSED")) != 0;
+namespace pats { bool cost_f32_only() { static const bool on = [] { const char* e = env_switch("PATS_COST_F32"); return e && atoi(e) != 0; }(); return on; } }
 namespace pats { bool fine_fused() { return g_fine_fused != 0; } }
 extern "C" int pats_set_fine_fused(int on) {
     const int prev = g_fine_fused;

@@ -277,7 +277,7 @@ resize_hwc_kernel(const float* __restrict__ right, int n_img, int H, int W, int 
 // the crops are written once and read by another kernel much later (2.3 GB per side and step): non-temporal stores of whole
 // lines (see gather.hip).  PATS_CROPS_NT = 0 / 1, read once per process.
 static bool crops_nt() {
-    static const bool nt = [] { const char* e = getenv("PATS_CROPS_NT"); return e ? atoi(e) != 0 : PATS_CROPS_NT_DEFAULT != 0; }();
+    static const bool nt = [] { const char* e = env_switch("PATS_CROPS_NT"); return e ? atoi(e) != 0 : PATS_CROPS_NT_DEFAULT != 0; }();
     return nt;
 }
 

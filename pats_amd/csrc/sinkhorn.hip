@@ -379,7 +379,7 @@ cost65_kernel(const float* __restrict__ d0, const float* __restrict__ d1, int D,
 }
 
 int launch_cost65(const float* d0, const float* d1, int D, int64_t P, float* out, hipStream_t st) {
-    static const bool f16 = getenv("PATS_COST65_F16") != nullptr;      // diagnostic: the fp16-split contraction of the fused kernel
+    static const bool f16 = diag_env("PATS_COST65_F16") != nullptr;      // diagnostic: the fp16-split contraction of the fused kernel
     if (f16) hipLaunchKernelGGL(cost65_kernel<true>, dim3((unsigned)P), dim3(64), 0, st, d0, d1, D, P, out);
     else hipLaunchKernelGGL(cost65_kernel<false>, dim3((unsigned)P), dim3(64), 0, st, d0, d1, D, P, out);
     return check_launch("cost65_kernel");
@@ -1013,7 +1013,7 @@ static inline int use_linear() { return sinkhorn_mode() != PATS_SINKHORN_LOG; }
 // that still leaves the guard ends in the log-sum-exp sweeps inside the same launch), 0 = log-sum-exp sweeps at once (round 3;
 // PATS_FINE_REDO_LOG=1)
 static inline int redo_mode() {
-    static const int m = getenv("PATS_FINE_REDO_LOG") ? 0 : 2;
+    static const int m = diag_env("PATS_FINE_REDO_LOG") ? 0 : 2;
     return m;
 }
 
@@ -1036,7 +1036,7 @@ int launch_blk145_w2(int mode, const float* Z, int64_t batch, const float* log_m
 static int launch_fine145(int mode, const float* Z, int64_t batch, const float* log_mu, const float* log_nu,
                           const float* ns, const float* one, int iters, float bias_k, float* out, int* fail,
                           hipStream_t st, uint8_t* col_nomatch = nullptr, const int64_t* live = nullptr) {
-    static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;      // A/B switch for benchmarking
+    static const bool v1_only = diag_env("PATS_FINE_V1") != nullptr;      // A/B switch for benchmarking
     const bool blk = use_linear() && iters > 0 && fail && !v1_only;
     if (blk) {
         int rc = fine_w2_enabled() ? launch_blk145_w2(mode, Z, batch, log_mu, log_nu, ns, one, iters, bias_k, out, fail, col_nomatch, st, live)
@@ -1067,7 +1067,7 @@ int launch_blk145_fused(const float* d0, const float* d1, int D, int64_t batch, 
 int launch_fine145_fused(const float* d0, const float* d1, int D, int64_t batch, const float* ns, const float* one, int iters,
                          float bias_k, float* out, int* fail, uint8_t* col_nomatch, hipStream_t st, bool* applied,
                          const int64_t* live) {
-    static const bool v1_only = getenv("PATS_FINE_V1") != nullptr;
+    static const bool v1_only = diag_env("PATS_FINE_V1") != nullptr;
     *applied = fine_fused() && use_linear() && iters > 0 && fail && !v1_only && D > 0;       // pats_set_fine_fused / PATS_FINE_FUSED
     if (!*applied) return PATS_OK;
     int rc = launch_blk145_fused(d0, d1, D, batch, ns, one, iters, bias_k, out, fail, col_nomatch, st, live);
@@ -1266,7 +1266,7 @@ extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int6
     if (P == 0) return PATS_OK;
     PATS_REQUIRE(feat0 && feat1 && scale && scale_x && scale_y && p_s && p_t && mkpts0_f && mkpts1_f &&
                      label && if_matching1, "third_level: null pointer");
-    static const bool v1_only = getenv("PATS_THIRD_V1") != nullptr;     // A/B switch for benchmarking
+    static const bool v1_only = diag_env("PATS_THIRD_V1") != nullptr;     // A/B switch for benchmarking
     if (!Z_out && !v1_only) {      // no plan requested: the 8x8 register-block kernel (third_fused.hip)
         Fused65Args f{feat0, feat1, D, P, scale, nullptr, iters, 1, scale_x, scale_y, p_s, p_t, outdoor,
                       ComputeResultOut{mkpts0_f, mkpts1_f, nullptr, label, if_matching1, nullptr}, 0, nullptr};
@@ -1282,7 +1282,7 @@ extern "C" int pats_third_level_f32(const float* feat0, const float* feat1, int6
     // when the launch is at least ~4 full rounds of the 2048 wave slots (s_sleep(127) ~ 3.4 us)
     // (measured on MI355X: unit 1-3 all give ~-11 %, larger units lose it again)
     if (P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)iters) / 16.0f / 3.4f);
-    if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
+    if (const char* e = diag_env("PATS_STAGGER")) g.stagger = atoi(e);
     hipLaunchKernelGGL((sinkhorn65_kernel<2, 1, 1>), dim3((unsigned)P), dim3(64), 0, as_stream(stream), g);
     return check_launch("sinkhorn65_kernel<2,1,1>");
 }

@@ -495,7 +495,7 @@ int launch_blk145(int mode, const float* Z, int64_t batch, const float* log_mu, 
     // also holds the cost build's LDS and registers ("fine-level fusion")
     unsigned pad = 0;
 #ifdef PATS_DIAG
-    if (const char* e = getenv("PATS_BLK_LDS_PAD")) pad = (unsigned)atoi(e);
+    if (const char* e = diag_env("PATS_BLK_LDS_PAD")) pad = (unsigned)atoi(e);
 #endif
     if (mode == 0)
         hipLaunchKernelGGL((sinkhorn_blk145_kernel<0>), dim3((unsigned)batch), dim3(256), pad, st, Z, log_mu, log_nu,

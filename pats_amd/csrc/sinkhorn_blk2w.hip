@@ -427,7 +427,7 @@ sinkhorn_blk145w2_kernel(const float* __restrict__ Zin, const float* __restrict_
 
 // PATS_FINE_W2 (read once per process): 0 = the four-wave kernel of sinkhorn_blk.hip
 bool fine_w2_enabled() {
-    static const bool on = [] { const char* e = getenv("PATS_FINE_W2"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char* e = env_switch("PATS_FINE_W2"); return !(e && atoi(e) == 0); }();
     return on;
 }
 

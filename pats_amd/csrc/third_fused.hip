@@ -388,7 +388,7 @@ int launch_third_fused(const Fused65Args& g0, hipStream_t st) {
     Fused65Args g = g0;
     g.linear = sinkhorn_mode() != PATS_SINKHORN_LOG;
     g.fallbacks = fallback_counter();
-    static const bool v2_only = getenv("PATS_THIRD_V2") != nullptr;     // A/B switch for benchmarking
+    static const bool v2_only = diag_env("PATS_THIRD_V2") != nullptr;     // A/B switch for benchmarking
     if (g.linear && g.iters > 0 && !v2_only) {
         // linear-domain solve by the third-generation kernel; it flags the problems that leave the guard
         // band, and this file's kernel re-solves exactly those with log-sum-exp sweeps (scan mode)
@@ -401,7 +401,7 @@ int launch_third_fused(const Fused65Args& g0, hipStream_t st) {
         return check_launch("third_fused_kernel(scan)");
     }
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
-    if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
+    if (const char* e = diag_env("PATS_STAGGER")) g.stagger = atoi(e);
     hipLaunchKernelGGL(third_fused_kernel, dim3((unsigned)g.P), dim3(64), 0, st, g);
     return check_launch("third_fused_kernel");
 }

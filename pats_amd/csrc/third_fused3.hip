@@ -656,10 +656,10 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     g.linear = 1;
     g.fallbacks = fallback_counter();
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
-    if (const char* e = getenv("PATS_STAGGER")) g.stagger = atoi(e);
+    if (const char* e = diag_env("PATS_STAGGER")) g.stagger = atoi(e);
 #ifdef PATS_DIAG
-    g.fingerprint = getenv("PATS_THIRD_FINGERPRINT") != nullptr;
-    if (const char* e = getenv("PATS_THIRD_LDS_POISON")) { g.lds_poison_on = 1; g.lds_poison = (unsigned)strtoul(e, nullptr, 0); }
+    g.fingerprint = diag_env("PATS_THIRD_FINGERPRINT") != nullptr;
+    if (const char* e = diag_env("PATS_THIRD_LDS_POISON")) { g.lds_poison_on = 1; g.lds_poison = (unsigned)strtoul(e, nullptr, 0); }
 #endif
     const dim3 grid((unsigned)g.P), block(64);
     // Default since round 4: 300, the fp32-MFMA cost build.  The fp16-split instantiation (1350) is 8 % faster, but the FIRST
@@ -670,7 +670,7 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     // first wave front's phase (any stagger) - but not to a cause, and one of 60 fresh processes had a problem 0.25 px off
     // (the parity gate is 2.4e-3 px).  The contract (bit-identical results from launch 0) decides: the production library
     // holds the fp32-MFMA build ONLY; the fp16-split build lives in libpats_amd_diag.so with the other experiments.
-    static const int variant = getenv("PATS_THIRD_VARIANT") ? atoi(getenv("PATS_THIRD_VARIANT")) : 300;
+    static const int variant = diag_env("PATS_THIRD_VARIANT") ? atoi(diag_env("PATS_THIRD_VARIANT")) : 300;
 #ifndef PATS_DIAG
     // The production library carries exactly ONE instantiation: the fp32-MFMA cost build, reproducible from the first launch of
     // a process.  The fp16-split cost build (1350), every other sweep-loop variant and every timing ablation (builds whose
@@ -681,11 +681,11 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     hipLaunchKernelGGL((third_fused3_kernel<3, 0, 0>), grid, block, 0, st, g);       // fp32 MFMA cost build
 #else
     // last digit (dustbin sums) 6..9 = diagnostic / timing-ablation builds whose RESULTS ARE NOT the solve: never by accident
-    static const bool ablation_ok = getenv("PATS_THIRD_ABLATION") != nullptr;
+    static const bool ablation_ok = diag_env("PATS_THIRD_ABLATION") != nullptr;
     PATS_REQUIRE(ablation_ok || variant % 10 < 6,
                  "PATS_THIRD_VARIANT=%d is a timing ablation (wrong results by design); set PATS_THIRD_ABLATION=1 to run it", variant);
     // experiment: extra dynamic LDS per workgroup lowers the occupancy (12 workgroups per CU at 10 KB; 40 KB -> 4 = one wave per SIMD)
-    const unsigned lds_pad = getenv("PATS_THIRD_LDS_PAD") ? (unsigned)atoi(getenv("PATS_THIRD_LDS_PAD")) : 0u;
+    const unsigned lds_pad = diag_env("PATS_THIRD_LDS_PAD") ? (unsigned)atoi(diag_env("PATS_THIRD_LDS_PAD")) : 0u;
     switch (variant) {          // digits: waves per SIMD, column reduction, dustbin sums
         case 311: hipLaunchKernelGGL((third_fused3_kernel<3, 1, 1>), grid, block, lds_pad, st, g); break;
         case 306: hipLaunchKernelGGL((third_fused3_kernel<3, 0, 6, 0>), grid, block, lds_pad, st, g); break;
@@ -717,7 +717,7 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
 #endif
     int rc = check_launch("third_fused3_kernel");
     if (rc) return rc;
-    static const bool no_stab = [] { const char* e = getenv("PATS_THIRD_STAB"); return e && atoi(e) == 0; }();      // A/B switch
+    static const bool no_stab = [] { const char* e = env_switch("PATS_THIRD_STAB"); return e && atoi(e) == 0; }();      // A/B switch
     if (!no_stab && g.iters > 0) {
         const int64_t waves = g.P < 6144 ? g.P : 6144;            // two rounds of the 3 072 wave slots: flagged runs spread out
         hipLaunchKernelGGL(third_fused3_stab_kernel, dim3((unsigned)(waves > 0 ? waves : 1)), dim3(64), 0, st, g);

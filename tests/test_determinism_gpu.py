@@ -155,23 +155,31 @@ def test_weights_stationary_conv_8192_problems_three_launches_identical(ops, ora
         np.testing.assert_allclose(outs[0][sl].cpu().numpy(), want, atol=5e-5, rtol=2e-4)
 
 
-@pytest.mark.parametrize("mode", ["ot2", "given_marginals", "ot2_log_domain"])
+@pytest.mark.parametrize("mode", ["ot2", "given_marginals", "ot2_four_wave", "ot2_log_domain"])
 def test_fine_level_solve_8192_problems_six_launches_identical(ops, oracle, mode):
-    """ops.log_optimal_transport2 / ops.log_sinkhorn_iterations on 8 192 x 145 x 145 (sinkhorn_blk145_kernel; in the forced
-    log domain sinkhorn_rc_kernel), 100 sweeps: six launches on the same scores are bit-identical, and a slice is held to the
-    oracle.  Before the barrier fix this failed in every run (3-9 problems per pair of launches, |dZ| up to 2e-2)."""
+    """ops.log_optimal_transport2 / ops.log_sinkhorn_iterations on 8 192 x 145 x 145, 100 sweeps: six launches on the same
+    scores are bit-identical, and a slice is held to the oracle.  Both fine-level solvers are pinned while both ship:
+      ot2, given_marginals   sinkhorn_blk145w2_kernel (two waves per problem, csrc/sinkhorn_blk2w.hip: the default since round 4)
+      ot2_four_wave          sinkhorn_blk145_kernel (four waves, csrc/sinkhorn_blk.hip; PATS_FINE_W2=0, read once per process: a child)
+      ot2_log_domain         sinkhorn_rc_kernel in the forced log domain (ops.set_sinkhorn_mode('log'), a child)
+    Before the round-3 barrier fix the four-wave kernel failed this in every run (3-9 problems per pair of launches, |dZ| up to 2e-2)."""
     import os
     import subprocess
     import sys
-    if mode == "ot2_log_domain":            # the mode switch is read once per process: run this case in a child
-        env = dict(os.environ, PATS_SINKHORN="log")
+    if mode in ("ot2_log_domain", "ot2_four_wave"):
+        env = dict(os.environ, PATS_FINE_W2="0") if mode == "ot2_four_wave" else dict(os.environ)
+        n_prob = 8192 if mode == "ot2_four_wave" else 4096
         code = ("import sys, torch; sys.path.insert(0, %r); from pats_amd import ops\n"
+                "%s"
                 "g = torch.Generator(device='cuda'); g.manual_seed(5)\n"
-                "S = 2.0 * torch.randn((4096, 145, 145), device='cuda', generator=g)\n"
-                "ns = torch.exp(0.3 * torch.randn((4096, 1, 144), device='cuda', generator=g))\n"
-                "outs = [ops.log_optimal_transport2(S, 1.0, ns, 100) for _ in range(4)]\n"
+                "S = 2.0 * torch.randn((%d, 145, 145), device='cuda', generator=g)\n"
+                "ns = torch.exp(0.3 * torch.randn((%d, 1, 144), device='cuda', generator=g))\n"
+                "outs = [ops.log_optimal_transport2(S, 1.0, ns, 100) for _ in range(6)]\n"
                 "torch.cuda.synchronize()\n"
-                "assert all(torch.equal(outs[0], o) for o in outs[1:]), 'log-domain launches differ'\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                "assert all(torch.equal(outs[0], o) for o in outs[1:]), 'launches differ'\n"
+                "print('FALLBACKS', ops.sinkhorn_fallbacks(reset=True))\n") % (
+                    os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                    "ops.set_sinkhorn_mode('log')\n" if mode == "ot2_log_domain" else "", n_prob, n_prob)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         return

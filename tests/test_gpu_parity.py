@@ -1764,12 +1764,13 @@ print("OK", d, trips)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, str(variant) + ": " + p.stdout[-500:] + p.stderr[-1500:]
     # every other variant (the fp16-split cost build - not bit-reproducible on its first launch -, sweep-loop experiments,
-    # timing ablations that are wrong by design) is refused by the production library: libpats_amd_diag.so only
-    # (csrc/third_fused3.hip, -DPATS_DIAG)
-    for variant in ("1350", "1300", "1308"):
+    # timing ablations that are wrong by design) exists in libpats_amd_diag.so only (csrc/third_fused3.hip, -DPATS_DIAG).  Since
+    # round 5 the production library does not even READ the variant switch (diag_env() is a constant there): setting it changes
+    # nothing, the one production instantiation runs and passes the same gates
+    for variant in ("1350", "1308"):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PATS_THIRD_VARIANT=variant, PATS_THIRD_ABLATION="1"),
                            capture_output=True, text=True, timeout=600)
-        assert p.returncode != 0 and "libpats_amd_diag.so" in p.stderr, variant
+        assert p.returncode == 0 and "OK" in p.stdout, variant + ": " + p.stdout[-500:] + p.stderr[-1500:]
 
 
 FUSED_FINE_CHILD = r"""

@@ -109,13 +109,41 @@ def test_production_library_carries_no_diagnostic_kernels(lib):
     """The sweep-loop variants, the timing ablations ("wrong results by design") and - since round 4 - the fp16-split cost
     build of the third-level kernel (its first full-size launch in a process is not bit-reproducible) are compiled under
     -DPATS_DIAG into libpats_amd_diag.so only; the production library holds ONE instantiation (fp32-MFMA cost build) and
-    refuses every other PATS_THIRD_VARIANT."""
+    does not read PATS_THIRD_VARIANT at all (round 5: diag_env() is a constant outside -DPATS_DIAG builds)."""
     import subprocess
     from pats_amd import _lib
     syms = subprocess.run(["nm", "-C", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     inst = sorted(set(re.findall(r"third_fused3_kernel<[^>]*>", syms)))
     assert inst == ["third_fused3_kernel<3, 0, 0, 0>"], inst       # the one instantiation that is reproducible from launch 0
     assert "libpats_amd.so" in _lib.LIB_PATH and "diag" not in os.path.basename(_lib.LIB_PATH)
+
+
+def test_production_library_reads_only_the_documented_environment_switches():
+    """Round 5: the shipped library reads an environment variable only through env_switch() (csrc/common.hpp) and every such
+    switch - each selects a TESTED alternative - has a row in INTEGRATION.md's table; the A/B partners of superseded kernel
+    generations, timelines, ablations and occupancy pads go through diag_env(), a constant outside -DPATS_DIAG builds.  Checked
+    on the SOURCE (no getenv outside common.hpp, at most ten switches) and on the BINARY (its PATS_* strings)."""
+    from pats_amd import _lib
+    csrc = os.path.join(REPO, "pats_amd", "csrc")
+    switches = set()
+    for root, _, files in os.walk(csrc):
+        for fn in files:
+            if not fn.endswith((".hip", ".hpp", ".cpp")):
+                continue
+            text = open(os.path.join(root, fn)).read()
+            if fn != "common.hpp":
+                assert not re.search(r"(?<![_a-z])getenv\s*\(", text), "%s calls getenv directly" % fn
+            switches |= set(re.findall(r'env_switch\("(PATS_[A-Z0-9_]+)"\)', text))
+    assert 0 < len(switches) <= 10, sorted(switches)
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    table = doc[doc.index("## 6. Environment switches"):]
+    documented = set(re.findall(r"^\| `(PATS_[A-Z0-9_]+)", table, flags=re.M))
+    assert switches <= documented, "undocumented switches: %s" % sorted(switches - documented)
+    # the binary: every NUL-terminated string that is exactly an environment-variable name
+    blob = open(_lib.LIB_PATH, "rb").read()
+    in_binary = {m.decode() for m in re.findall(rb"(?<=\x00)(PATS_[A-Z0-9_]+)(?=\x00)", blob)}
+    in_binary -= {"PATS_REQUIRE"}
+    assert in_binary <= documented, "the shipped library carries switches INTEGRATION.md does not list: %s" % sorted(in_binary - documented)
 
 
 def _checker():
