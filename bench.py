@@ -83,6 +83,12 @@ def parse():
     ap.add_argument("--with-gnn", action="store_true",
                     help="time whole steps WITH the layers' heads inside (GnnNets: KeypointEncoder, the 18 / 18 / 10-layer GNN stacks, "
                          "final_proj, scale heads on random weights) and print that report instead of the headline line")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="no GPU: print what a --gpus N run would do - every rank's pair share, steps, row / problem capacities, resident "
+                         "bytes and expected set-up time - as one JSON line and exit (the first real 8-GPU run cannot fail on plumbing)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not re-run three steps under rocprofv3 --pmc for roofline.traffic (default: done when rocprofv3 is on PATH, one "
+                         "rank, not --no-secondary; the committed profiles/r*_pmc_step_<layout>.json is the fallback, with its age in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
@@ -941,8 +947,82 @@ def free_port():
     return p
 
 
+def live_pmc(args):
+    """roofline.traffic measured in THIS run (round-4 verdict item 8): bench.py re-invokes itself for three steps under
+    `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes, no trace domains beside them - the
+    micro-architecture guide's recipe) and tools/pmc_step.py turns the two counter dumps into bytes per launch.  None if
+    rocprofv3 is missing, a pass fails or times out - the caller then falls back to the committed file and says how old it is."""
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import pmc_step
+    tmp = tempfile.mkdtemp(prefix="pats_pmc_", dir="/tmp")
+    cmd = [sys.executable, os.path.abspath(__file__), "--maps", args.maps, "--steps", "3", "--warmup", "1", "--no-secondary",
+           "--no-cpu-baseline", "--no-pmc"] + (["--pairs", str(args.pairs)] if args.pairs else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        line = os.path.join(tmp, "bench.json")
+        for counter, sub in (("FETCH_SIZE", "F"), ("WRITE_SIZE", "W")):
+            with open(line if sub == "F" else os.devnull, "w") as fo:
+                r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, sub), "--"] + cmd, cwd="/tmp",
+                                   env=env, stdout=fo, stderr=subprocess.DEVNULL, timeout=300)
+            if r.returncode != 0:
+                return None
+        out = pmc_step.summarise(os.path.join(tmp, "F"), os.path.join(tmp, "W"), line)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        json.dump(out, open(os.path.join(REPO, "gpurun_out", "pmc_step_%s_live.json" % args.maps), "w"), indent=1)
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def plan_only(args):
+    """What `bench.py --gpus N ...` would do, computed on the host alone (the C-ABI library loads without a GPU: the chunk
+    planner is host code).  Resident bytes: BenchNets' tensors by their shapes; set-up time from the rate rank 0 measured
+    (148 GB of synthetic maps in 2.5 s)."""
+    from pats_amd import batch, shard
+    h, w, if_local, outdoor, default_pairs, label = WORKLOADS[args.workload]
+    pairs = args.pairs if args.pairs else default_pairs
+    cap = batch.Capacities(pairs, h, w, if_local=if_local)
+    N, R, Pc = h * w, cap.rows_cap, cap.P_cap
+    f = 4
+    resident = (2 * pairs * 448 * N + pairs * N) * f + 2 * pairs * 32 * h * 32 * w * 3 * f           # coarse descriptors, ns, images
+    resident += 2 * R * (64 * 48 * 48 + 64 * 24 * 24 + 128 * 12 * 12) * f + R * (8 + 264 + 3 * 144) * f   # fine maps, title, rubbish, scales
+    resident += 2 * 2 * R * 264 * 145 * f                                                              # a15 outputs, double-buffered
+    resident += 2 * R * 128 * 52 * 52 * f + R * 128 * 144 * f + Pc * 64 * f + 4 * Pc * 128 * 65 * f    # third-level maps, rubbish, scale, a16 outputs
+    world = max(1, args.gpus)
+    ranks = []
+    for r in range(world):
+        if args.total_pairs > 0:
+            mine = len(shard.my_pairs(args.total_pairs, r, world))
+            steps = shard.steps_for(args.total_pairs, r, world, pairs)
+        else:
+            mine, steps = pairs * args.steps, args.steps
+        ranks.append({"rank": r, "device": "cuda:%d" % r, "pairs": mine, "steps": steps,
+                      "slots_idle_in_last_step": (steps * pairs - mine) if args.total_pairs > 0 else 0})
+    plan = {"plan_only": True, "workload": label, "gpus": world, "scaling": "strong" if args.total_pairs > 0 else "weak",
+            "pairs_per_step_per_rank": pairs, "grid": [h, w], "coarse_problem": "%d x %d" % (N + 1, N + 1),
+            "rows_cap": R, "chunks_max": cap.Cmax, "third_problem_cap": Pc,
+            "resident_synthetic_GB_per_rank": resident / 1e9, "expected_setup_s_per_rank": resident / 59.2e9,
+            "total_pairs": args.total_pairs if args.total_pairs > 0 else pairs * args.steps * world,
+            "launch": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py %s"
+                      % (world, " ".join(a for a in sys.argv[1:] if a != "--plan-only")),
+            "collectives": ["barrier x 2 around the timed region", "all_reduce(MAX) of the elapsed time", "all_gather of (ms_per_step, setup_s)",
+                            "shard.gather_matches after the clock: all_gather of the (pair, K) table + flat [K,4] payload to rank 0"],
+            "ranks": ranks}
+    assert sum(r_["pairs"] for r_ in ranks) == plan["total_pairs"]
+    print(json.dumps(plan))
+
+
 def main():
     args = parse()
+    if args.plan_only:
+        return plan_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU over RCCL
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -1086,16 +1166,27 @@ def main():
         t_valu = float(2.0 * 2.0 * ITERS * 65 * 65 * P_step / (third_ms.mean() * 1e-3) / 1e12)
         # HBM traffic per launch from rocprofv3 PMC passes over this same step (tools/pmc_step.sh -> profiles/r03_pmc_step.json:
         # FETCH_SIZE and WRITE_SIZE in separate runs, calibrated on the cost build's known byte count in the same run)
-        pmc, pmc_src = {}, None
-        pmc_path = os.path.join(REPO, "profiles", "r04_pmc_step_%s.json" % args.maps)
-        if os.path.exists(pmc_path):
-            pj = json.load(open(pmc_path))
-            if int(pj.get("rows_cap", -1)) == cap.rows_cap and args.workload == "megadepth":
-                pmc = pj["kernels"]
-                pmc_src = "profiles/r04_pmc_step_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over bench.py), factors " \
-                          "from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the third-level " \
-                          "kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
-                          % (args.maps, pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
+        pmc, pmc_src, pmc_age = {}, None, None
+        pj, pmc_name = None, None
+        if rank == 0 and n_gpus == 1 and not args.no_pmc and not args.no_secondary and args.workload == "megadepth":
+            pj = live_pmc(args)                          # three steps again under rocprofv3 --pmc (two passes), after the clock
+            pmc_name = "live: bench.py re-ran itself under rocprofv3 in this run"
+        if pj is None:
+            import glob
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_step_%s.json" % args.maps)))
+            if cands:
+                pj, pmc_name = json.load(open(cands[-1])), "profiles/" + os.path.basename(cands[-1])
+        if pj is not None and int(pj.get("rows_cap", -1)) == cap.rows_cap and args.workload == "megadepth":
+            pmc = pj["kernels"]
+            pmc_src = "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over bench.py --steps 3), factors " \
+                      "from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the third-level " \
+                      "kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
+                      % (pmc_name, pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
+            # how old is the figure?  kernel sources whose content differs from what the PMC run measured
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import pmc_step
+            now, then = pmc_step.csrc_sha16(), pj.get("csrc_sha16")
+            pmc_age = {"source": pmc_name, "kernel_sources_changed_since": sorted(k for k in now if then.get(k) != now[k]) if then else "unknown (no hashes in the file)"}
 
         def traffic_of(prefix):
             # (kernel names in the PMC file carry their template arguments - `fine_desc_kernel<0> grid=..` -: match with and without them)
@@ -1105,7 +1196,7 @@ def main():
         traffic, traffic_src = traffic_of("pats::third_fused3_kernel")
         third_roof = {"bound": "hbm", "kernel": "third_fused3_kernel (fused third level, %d problems per launch over a capacity of %d)"
                       % (P_step, cap.P_cap), "achieved": t_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS,
-                      "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                      "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_age": pmc_age,
                       "algorithmic_bytes_per_launch": float(BYTES_PER_PROBLEM * P_step), "avg_launch_ms": float(third_ms.mean()),
                       "launches": int(len(third_ms)), "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
                       "valu_frac": t_valu / F32_PEAK_TFLOPS, "valu_tflops": t_valu,
@@ -1202,6 +1293,7 @@ def main():
         # ranked by single KERNELS; the fine level's launch pair as measured inside the steps stays in the list for the cross-check
         ranked = sorted([third_roof, fd_roof, td_roof] + (split_roofs if split_roofs else [fine_roof]), key=lambda r: -r["avg_launch_ms"])
         dominant, other = ranked[0], ranked[1:] + ([fine_roof] if split_roofs else [])
+        dominant["traffic_age"] = pmc_age                # where roofline.traffic comes from and which kernel sources changed since
         sweeps_per_pair = ITERS * (1 + (rows_step + P_step) / float(pairs))
         res = {
             "metric": "image-pairs/sec (coarse+fine OT) on 640x480 MegaDepth; OT iters/sec per pair",

@@ -96,3 +96,22 @@ def test_collective_device_follows_the_backend_not_the_local_tensors(monkeypatch
     assert shard.collective_device() == torch.device("cuda", 3)
     monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
     assert shard.collective_device() == torch.device("cpu")
+
+
+def test_bench_plan_only_prints_every_ranks_share_without_a_gpu():
+    """`bench.py --gpus 8 --workload yfcc --total-pairs 4000 --plan-only` (BASELINE configs[3], evaluate.py:25-35 sharded over the
+    ranks): no GPU is touched; every rank's pairs / steps add up, capacities and the launcher line are printed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--workload", "yfcc", "--total-pairs", "4000", "--plan-only"],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["plan_only"] and plan["gpus"] == 8 and plan["scaling"] == "strong" and plan["total_pairs"] == 4000
+    assert len(plan["ranks"]) == 8 and sum(x["pairs"] for x in plan["ranks"]) == 4000
+    assert all(x["steps"] == (x["pairs"] + plan["pairs_per_step_per_rank"] - 1) // plan["pairs_per_step_per_rank"] for x in plan["ranks"])
+    assert plan["coarse_problem"] == "769 x 769" and plan["rows_cap"] > 0 and "--nproc-per-node 8" in plan["launch"]
+    assert "--plan-only" not in plan["launch"] and 0 < plan["resident_synthetic_GB_per_rank"] < 288

@@ -8,8 +8,23 @@ Both passes ran `bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline`
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pats_amd", "csrc")
+
+
+def csrc_sha16():
+    """sha256[:16] of every kernel source: bench.py compares them with the tree it runs from, so a traffic figure that is older
+    than the kernels it describes is visible in the bench line (roofline.traffic_age)."""
+    out = {}
+    for root, _, files in os.walk(CSRC):
+        for fn in sorted(files):
+            if fn.endswith((".hip", ".hpp", ".cpp")):
+                out[os.path.relpath(os.path.join(root, fn), CSRC)] = hashlib.sha256(open(os.path.join(root, fn), "rb").read()).hexdigest()[:16]
+    return out
 
 
 def load(d, counter):
@@ -25,12 +40,12 @@ def load(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def main():
-    fetch, nf = load(sys.argv[1], "FETCH_SIZE")
-    write, _ = load(sys.argv[2], "WRITE_SIZE")
+def summarise(fetch_dir, write_dir, bench_line_path):
+    fetch, nf = load(fetch_dir, "FETCH_SIZE")
+    write, _ = load(write_dir, "WRITE_SIZE")
     # the fine level's cost build is the cost_mfma_kernel launch with the largest grid: one 256-thread workgroup per row
     grids = [k[1] for k in fetch if k[0].startswith("pats::cost_mfma_kernel")]
-    bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    bench = json.loads(open(bench_line_path).read().strip().splitlines()[-1])
     rows_cap = max(grids) // 256 if grids else int(bench["rows_cap"])
     rows_live = int(bench["rows_in_use_per_step"])      # the launches cover rows_cap, workgroups past the device-side count return
     # rocprofv3 reports both counters in KB
@@ -69,7 +84,12 @@ def main():
                                 "hbm_read_bytes": r * ff, "hbm_write_bytes": w * (w_fac or 1.0),
                                 "hbm_bytes": r * ff + w * (w_fac or 1.0)}
     out["kernels"] = ks
-    json.dump(out, sys.stdout, indent=1)
+    out["csrc_sha16"] = csrc_sha16()
+    return out
+
+
+def main():
+    json.dump(summarise(sys.argv[1], sys.argv[2], sys.argv[3]), sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
