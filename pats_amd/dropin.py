@@ -145,12 +145,17 @@ def prepare_backbones(model, names=("descriptor_extract", "backbone", "compress"
     return done
 
 
-def install(import_reference=False):
+def install(import_reference=False, model=None):
     """Rebinds the names listed in the module docstring; returns the list of "module.name" it touched.
     Idempotent (a second call first undoes the first).  Needs the HIP library: pats_amd.ops raises if
-    libpats_amd.so is missing - there is no CPU fallback to fall back to."""
+    libpats_amd.so is missing - there is no CPU fallback to fall back to.
+    model: the instantiated PATS (or any module holding the layers) - its gather-feeding backbones are switched to
+    channels_last parameters as well (prepare_backbones: the maps then arrive in the order the gathers read fastest,
+    profiles/r05_backbone_layout.txt); without it the maps stay NCHW and everything still works."""
     if _saved:
         uninstall()
+    if model is not None:
+        prepare_backbones(model)
     from . import ops
     native = _load_native()
     touched = []
