@@ -84,9 +84,8 @@ constexpr int FB_Q = 0, FB_K = 272, FB_V = 544, FB_1 = 816, FB_A = FB_1 + 544, F
 struct FineArgs {
     const char* tf_x;          // [P] TF images of the descriptors
     const char* tf_s;          // [P] TF images of the sources; problem p reads image (p + shift) % P
-    const float* blk_res;      // [P][33][145][8] fp32 or null: added to the output
-    float* blk_out;            // [P][33][145][8]
-    char* tf_out;              // [P] TF images of the output, or null
+    const char* tf_res;        // [P] TF images of the residual or null: added to the output (exact to the 22 bits an image holds)
+    char* tf_out;              // [P] TF images of the output
     const h8v* pw;
     const float* pb;
     char* scratch;             // [gridDim.x][SC_BYTES]
@@ -170,14 +169,13 @@ __device__ __forceinline__ void dma_fill(char* lds_dst, const char* src, int wav
 // output epilogue alone took 20 us of a problem's 230.)  Called by all 64 lanes (the exchange), inactive tiles masked at the store.
 // (addresses: uniform base + per-store scalar constant + one of three 32-bit lane offsets made once per problem - global_store
 //  with an SGPR base; per-store 64-bit vector addresses were what the epilogues spilled and reloaded behind s_waitcnt vmcnt(0))
-struct LaneOff { unsigned tf0, tf1, tf2, blk; };
+struct LaneOff { unsigned tf0, tf1, tf2; };
 __device__ __forceinline__ LaneOff lane_offsets(int lane) {
     const unsigned g = (unsigned)lane >> 4, j = (unsigned)lane & 15u;
     LaneOff o;
     o.tf0 = (g & 1u) * TFB + (g >> 1) * 256u + j * 16u;    // full k-step, token tiles 0..8
     o.tf1 = (g & 1u) * TFB + (g >> 1) * 16u;               // full k-step, token 144 (lanes j = 0)
     o.tf2 = (g & 1u) * TFR + j * 16u;                      // ragged k-step (lanes g < 2)
-    o.blk = (((g >> 1) * FN + j) * 8u + (g & 1u) * 4u) * 4u;   // fp32 channel-blocked: rows 16 mt + 4 g.. of token 16 t + j, bytes
     return o;
 }
 __device__ __forceinline__ void store_tf(char* dst, int mt, int t, const f4v v, int lane, const LaneOff& lo_) {
@@ -201,6 +199,34 @@ __device__ __forceinline__ void store_tf(char* dst, int mt, int t, const f4v v, 
         char* d = dst + TF_MAIN + (t < 9 ? t * 256 : 2304);
         if (g < 2 && (t < 9 || j == 0)) *reinterpret_cast<u4v*>(d + lo_.tf2) = piece;
     }
+}
+
+// the inverse: rows 16 mt + 4 g + r of token 16 t + j from a TF image in global memory.  load_tf_piece() issues the one 16-byte load
+// of a lane (an even-row lane its pair's hi piece, an odd-row lane the lo piece; zeros where the tile has nothing for it);
+// tf_piece_value() - called by all 64 lanes - gives the halves back to their owners and rebuilds (hi + lo) / 2^6.
+typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4v_t load_tf_piece(const char* src, int mt, int t, int lane, const LaneOff& lo_) {
+    const int g = lane >> 4, j = lane & 15;
+    u4v_t p = {0u, 0u, 0u, 0u};
+    if (mt < 16) {
+        const char* d = src + (mt >> 1) * (2 * TFB) + (mt & 1) * (t < 9 ? 512 : 32) + (t < 9 ? t * 1024 : 9216);
+        if (t < 9) p = *reinterpret_cast<const u4v_t*>(d + lo_.tf0);
+        else if (j == 0) p = *reinterpret_cast<const u4v_t*>(d + lo_.tf1);
+    } else {
+        const char* d = src + TF_MAIN + (t < 9 ? t * 256 : 2304);
+        if (g < 2 && (t < 9 || j == 0)) p = *reinterpret_cast<const u4v_t*>(d + lo_.tf2);
+    }
+    return p;
+}
+__device__ __forceinline__ f4v tf_piece_value(const u4v_t p) {
+    // even-row lane: (x, y) = own hi, (z, w) = partner's hi; odd-row lane: (x, y) = partner's lo, (z, w) = own lo.
+    // lane_swap16(a, b): odd rows of a <-> even rows of b  =>  every lane ends with a = own hi, b = own lo
+    unsigned ax = p.x, ay = p.y, bx = p.z, by = p.w;
+    lane_swap16(ax, bx);
+    lane_swap16(ay, by);
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const h4v hi = __builtin_bit_cast(h4v, u2v{ax, ay}), lo = __builtin_bit_cast(h4v, u2v{bx, by});
+    return (__builtin_convertvector(hi, f4v) + __builtin_convertvector(lo, f4v)) * (1.0f / PRE);
 }
 
 // ---- one convolution pass over the nine k-steps of the TF image in LDS -----------------------------------------------------------
@@ -341,48 +367,44 @@ gnn_fine_pack_kernel(pats_propagation_weights w, h8v* __restrict__ pw, float* __
     pw[(size_t)f * FR + 64 + lane] = lo;
 }
 
-// ---- [P][264][145] fp32 -> (fp32 channel-blocked [P][33][145][8], TF image).  One thread per (problem, 8-channel group, token). ----
+// ---- [P][264][145] fp32 -> TF image (and back).  One thread per (problem, 8-channel group, token). -------------------------------
 __global__ void __launch_bounds__(256)
-gnn_fine_in_kernel(const float* __restrict__ x, int64_t P, float* __restrict__ blk, char* __restrict__ tf) {
+gnn_fine_in_kernel(const float* __restrict__ x, int64_t P, char* __restrict__ tf) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= P * 33 * FN) return;
     const int64_t p = gid / (33 * FN);
     const int r = (int)(gid - p * (33 * FN)), cg = r / FN, tok = r - cg * FN;
     const float* src = x + (p * FC + cg * 8) * FN + tok;
     const f4v a = {src[0], src[FN], src[2 * FN], src[3 * FN]}, b = {src[4 * FN], src[5 * FN], src[6 * FN], src[7 * FN]};
-    if (blk) {
-        float* d = blk + ((p * 33 + cg) * FN + tok) * 8;
-        *reinterpret_cast<f4v*>(d) = a;
-        *reinterpret_cast<f4v*>(d + 4) = b;
-    }
-    if (tf) {
-        h4v ah, al, bh, bl;
-        split4_pre(a * PRE, ah, al);
-        split4_pre(b * PRE, bh, bl);
-        const int ks = cg >> 2, kq = cg & 3, t = tok >> 4, j = tok & 15;
-        char* img = tf + p * TF_BYTES;
-        const int off = tf_off(ks == 8, t, kq * 16 + j);
-        *reinterpret_cast<h8v*>(img + tf_blk(ks, 0) + off) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
-        *reinterpret_cast<h8v*>(img + tf_blk(ks, 1) + off) = h8v{al.x, al.y, al.z, al.w, bl.x, bl.y, bl.z, bl.w};
-    }
+    h4v ah, al, bh, bl;
+    split4_pre(a * PRE, ah, al);
+    split4_pre(b * PRE, bh, bl);
+    const int ks = cg >> 2, kq = cg & 3, t = tok >> 4, j = tok & 15;
+    char* img = tf + p * TF_BYTES;
+    const int off = tf_off(ks == 8, t, kq * 16 + j);
+    *reinterpret_cast<h8v*>(img + tf_blk(ks, 0) + off) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
+    *reinterpret_cast<h8v*>(img + tf_blk(ks, 1) + off) = h8v{al.x, al.y, al.z, al.w, bl.x, bl.y, bl.z, bl.w};
 }
 
 __global__ void __launch_bounds__(256)
-gnn_fine_out_kernel(const float* __restrict__ blk, int64_t P, float* __restrict__ y, const int64_t* __restrict__ live, int64_t live_off) {
+gnn_fine_out_kernel(const char* __restrict__ tf, int64_t P, float* __restrict__ y, const int64_t* __restrict__ live, int64_t live_off) {
     // rows past the device-side count (no layer computed them): zeros, so that whatever runs over the capacity next reads finite values
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= P * 33 * FN) return;
     const int64_t p = gid / (33 * FN);
     const int r = (int)(gid - p * (33 * FN)), cg = r / FN, tok = r - cg * FN;
-    f4v a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!live || p < *live - live_off) {
-        const float* s = blk + ((p * 33 + cg) * FN + tok) * 8;
-        a = load4(s);
-        b = load4(s + 4);
+        const int ks = cg >> 2, kq = cg & 3, t = tok >> 4, j = tok & 15;
+        const char* img = tf + p * TF_BYTES;
+        const int off = tf_off(ks == 8, t, kq * 16 + j);
+        const h8v hi = *reinterpret_cast<const h8v*>(img + tf_blk(ks, 0) + off), lo = *reinterpret_cast<const h8v*>(img + tf_blk(ks, 1) + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((float)hi[e] + (float)lo[e]) * (1.0f / PRE);
     }
     float* d = y + (p * FC + cg * 8) * FN + tok;
-    d[0] = a.x; d[FN] = a.y; d[2 * FN] = a.z; d[3 * FN] = a.w;
-    d[4 * FN] = b.x; d[5 * FN] = b.y; d[6 * FN] = b.z; d[7 * FN] = b.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e * FN] = v[e];
 }
 
 // ---- the layer -----------------------------------------------------------------------------------------------------------------
@@ -712,44 +734,41 @@ gnn_fine_layer_kernel(FineArgs g) {
             dma_fill<TF_BYTES>(lds, g.tf_s + pn * TF_BYTES, wave, lane);
         }
         {
-            const float* R = g.blk_res ? g.blk_res + p * (33 * FN * 8) : nullptr;
-            float* O = g.blk_out + p * (33 * FN * 8);
-            char* TO = g.tf_out ? g.tf_out + p * TF_BYTES : nullptr;
-            // every residual piece of this lane FIRST, in one batch (22 dependent load -> add -> store chains, each a trip to HBM,
-            // took 22 us of the 230 a problem cost in the first version)
-            f4v res[3][FNT];
-            if (R) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const int mt = m < 2 ? 2 * wave + m : 16, ch = 16 * mt + 4 * gq;
-#pragma unroll
-                    for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
-                        const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
-                        res[m][tt] = f4v{0.f, 0.f, 0.f, 0.f};
-                        if (tok_t < 0 || !(mt < 16 || gq < 2) || (tok_t == 9 && j != 0)) continue;
-                        res[m][tt] = *reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(R + (2 * mt * FN + 16 * tok_t) * 8) + lo_.blk);
-                    }
-                }
-            }
+            const char* R = g.tf_res ? g.tf_res + p * TF_BYTES : nullptr;
+            char* TO = g.tf_out + p * TF_BYTES;
+            // per row tile: its ten residual pieces in one batch (a load -> add -> store chain per piece would pay a memory round trip
+            // each; all 22 at once is 88 more registers beside the accumulators - the allocator then spills, and a spill reload waits
+            // for every store issued before it).  The residual comes from the descriptor's IMAGE - lines the fills of this problem
+            // just read - and is exact to the 22 bits an image holds.
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const int mt = m < 2 ? 2 * wave + m : 16, ch = 16 * mt + 4 * gq;
                 const f4v bias = load4(pb + FB_2 + ch);
                 const bool rows_ok = mt < 16 || gq < 2;
+                u4v_t res[FNT];
+                if (R) {
+#pragma unroll
+                    for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
+                        const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
+                        res[tt] = u4v_t{0u, 0u, 0u, 0u};
+                        if (tok_t >= 0) res[tt] = load_tf_piece(R, mt, tok_t, lane, lo_);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
                     const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
                     if (tok_t < 0) continue;
                     const bool live = rows_ok && !(tok_t == 9 && j != 0);
                     f4v v = fma4(m < 2 ? acc[m][tt] : accr[tt], bcast4(UNS), bias);
-                    if (R) v = res[m][tt] + v;
+                    if (R) v = tf_piece_value(res[tt]) + v;                  // (every lane: the pieces are paired across lanes)
                     if (live) {
-                        *reinterpret_cast<f4v*>(reinterpret_cast<char*>(O + (2 * mt * FN + 16 * tok_t) * 8) + lo_.blk) = v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
                     }
-                    if (TO) store_tf(TO, mt, tok_t, v * PRE, lane, lo_);           // (every lane: the pieces are paired across lanes)
+                    store_tf(TO, mt, tok_t, v * PRE, lane, lo_);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         FT(19);
@@ -803,22 +822,21 @@ static int fine_grid(int64_t P) {
 int fine_max_grid() { return 512; }                      // scratch blocks a workspace must provide at most (CUs of the device, capped)
 size_t fine_scratch_bytes(int64_t P) { return (size_t)std::min<int64_t>(P, fine_max_grid()) * SC_BYTES; }
 size_t fine_image_bytes(int64_t P) { return (size_t)P * TF_BYTES; }
-size_t fine_blocked_bytes(int64_t P) { return (size_t)P * 33 * FN * 8 * sizeof(float); }
 
-int launch_fine_in(const float* x, int64_t P, float* blk, char* tf, hipStream_t st) {
+int launch_fine_in(const float* x, int64_t P, char* tf, hipStream_t st) {
     const int64_t items = P * 33 * FN;
-    hipLaunchKernelGGL(gnn_fine_in_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, P, blk, tf);
+    hipLaunchKernelGGL(gnn_fine_in_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, P, tf);
     return check_launch("gnn_fine_in_kernel");
 }
-int launch_fine_out(const float* blk, int64_t P, float* y, hipStream_t st, const int64_t* live, int64_t live_off) {
+int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const int64_t* live, int64_t live_off) {
     const int64_t items = P * 33 * FN;
-    hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, blk, P, y, live, live_off);
+    hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, tf, P, y, live, live_off);
     return check_launch("gnn_fine_out_kernel");
 }
 // one layer over P problems: image p of tf_x with source image (p + shift) % P of tf_s
 // sets descriptor sets of P / sets rows each; live (optional): device-side row count of a set, minus live_off
-int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const float* blk_res, int64_t P, const void* section,
-                      float* blk_out, char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
+int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const char* tf_res, int64_t P, const void* section,
+                      char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
                       const int64_t* live, int64_t live_off) {
     const int grid = fine_grid(P);
     if (grid <= 0) return PATS_ERR_UNSUPPORTED;
@@ -828,7 +846,7 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const f
     // (4 096 problems: 4.86 -> 4.57 ms with the conversions).  Only where a workgroup has enough problems to pay for the ramp.
     static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
     const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)grid ? 4 : 0);
-    FineArgs g{tf_x, tf_s, blk_res, blk_out, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off, P / sets, sets, stagger};
+    FineArgs g{tf_x, tf_s, tf_res, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off, P / sets, sets, stagger};
     const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
 #ifdef PATS_DIAG
     g.tl = nullptr;
