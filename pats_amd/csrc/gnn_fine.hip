@@ -18,9 +18,9 @@
 //   * the WEIGHTS are the A operand straight from L2 into a register ring (pre-split fragments, one 16-byte load per lane, packed once
 //     per layer by gnn_fine_pack_kernel): 2.7 MB per problem per CU instead of 5.7, at a quarter of the rate the L2 sustains
 //     (tools/wstream_probe.hip: 115-135 GB/s per CU with every CU streaming).
-//   * descriptors travel BETWEEN layers as (fp32 channel-blocked [33][145][8], TF image): the layer's epilogue writes both, the
-//     next layer DMAs the image and reads the fp32 copy only for the residual - 16-byte accesses everywhere, no 4-byte strided loads
-//     (round 4's limiter).  gnn_fine_in_kernel / gnn_fine_out_kernel convert at the ends of a stack.
+//   * descriptors travel BETWEEN layers as TF images: the layer's epilogue writes one, the next layer DMAs it and rebuilds the
+//     residual from it ((hi + lo) / 2^6: exact to the 22 bits an image holds) - 16-byte accesses everywhere, no 4-byte strided
+//     loads (round 4's limiter).  gnn_fine_in_kernel / gnn_fine_out_kernel convert at the ends of a stack.
 //   * heads: the reference views a projection as [b, 66, 4, n] (channel = d * 4 + h).  q / k / v rows are permuted at pack time to
 //     [head][d < 64] (head h = k-steps 2 h, 2 h + 1 of a TF image) followed by the eight "extra" channels (d = 64, 65 of each head) in
 //     the ragged 17th row tile; the folded mlp[0] matrix has its attention columns in the same order.
@@ -30,7 +30,7 @@
 //     order.  The two extra channels of a head cost ONE more MFMA per key tile instead of a k-step of three: A = (kh0 kh1 kl0 kl1 kh0
 //     kh1 0 0), B = (qh0 qh1 qh0 qh1 ql0 ql1 0 0) gives hi.hi + lo.hi + hi.lo of both channels.
 // Stages per problem: s -> [k, v^T]; x -> [q]; attention; att -> [hidden0 (attention part)]; x -> [hidden0 (x part) -> scratch,
-// hidden1 (x part)]; att -> [hidden1 -> scratch]; hidden0 -> [out (first half)]; hidden1 -> [out + b2 + x -> (fp32, TF image)].
+// hidden1 (x part)]; att -> [hidden1 -> LDS straight from the accumulators -> out (second half)]; hidden0 -> [out + b2 + x -> TF image].
 // BatchNorm in eval mode only (the second layer always is: pats.py:112-114).  Range: |activation| < 1023; a non-finite output raises
 // *flag and the round-2 composition queued behind, gated on it, redoes the layer.
 #include "common.hpp"
