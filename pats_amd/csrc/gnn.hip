@@ -651,9 +651,10 @@ const void* packed_fine_section(const void* packed, int C, int heads);          
 size_t fine_scratch_bytes(int64_t P);
 size_t fine_image_bytes(int64_t P);
 int launch_fine_in(const float* x, int64_t P, char* tf, hipStream_t st);
-int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const int64_t* live = nullptr, int64_t live_off = 0);
-int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const char* tf_res, int64_t P, const void* section,
-                      char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
+int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const int64_t* live = nullptr, int64_t live_off = 0,
+                    const float* add = nullptr);
+int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, int residual, int64_t P, const void* section,
+                      char* tf_out, char* tf_att, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
                       const int64_t* live, int64_t live_off);
 }
 
@@ -737,15 +738,15 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         int* flag = redo + 7;
         char* tf_x = (char*)q;
         char* tf_s = source == x ? tf_x : (char*)att;
-        char* tf_res = !residual ? nullptr : residual == x ? tf_x : residual == source ? tf_s : (char*)msg;
+        char* tf_att = (char*)msg;
         char* tf_out = (char*)k;
         if ((rc = launch_fine_in(x, batch, tf_x, st))) return rc;
         if (source != x && (rc = launch_fine_in(source, batch, tf_s, st))) return rc;
-        if (tf_res == (char*)msg && (rc = launch_fine_in(residual, batch, tf_res, st))) return rc;
-        rc = launch_fine_layer(tf_x, tf_s, 0, tf_res, batch, packed_fine_section(packed, C, heads), tf_out, fine_scratch, flag,
-                               nullptr, st, 1, live, live_off);
+        // the kernels add the layer's own x (what AttentionalGNN.forward does); any other residual is added by the conversion out
+        rc = launch_fine_layer(tf_x, tf_s, 0, residual == x ? 1 : 0, batch, packed_fine_section(packed, C, heads), tf_out, tf_att, fine_scratch,
+                               flag, nullptr, st, 1, live, live_off);
         if (rc == PATS_OK) {
-            if ((rc = launch_fine_out(tf_out, batch, out, st, live, live_off))) return rc;
+            if ((rc = launch_fine_out(tf_out, batch, out, st, live, live_off, residual && residual != x ? residual : nullptr))) return rc;
             gate = flag;         // the composition below runs only if the kernel raised it
         } else if (rc != PATS_ERR_UNSUPPORTED) {
             return rc;
@@ -851,7 +852,7 @@ __global__ void __launch_bounds__(256) gated_copy_kernel(const float4* __restric
 extern "C" size_t pats_attentional_gnn_packed_workspace_bytes(int64_t batch, int C, int heads, int n) {
     if (batch <= 0 || !fine_layer_supported(C, heads, n, n)) return 0;
     const int64_t P = 2 * batch;
-    const size_t fused = 2 * al256(fine_image_bytes(P));
+    const size_t fused = 3 * al256(fine_image_bytes(P));
     const size_t redo = 4 * al256((size_t)batch * C * n * sizeof(float)) + al256(pats_attentional_propagation_workspace_bytes(batch, C, n, n));
     return std::max(fused, redo) + al256(fine_scratch_bytes(P)) + 256;
 }
@@ -870,9 +871,10 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     const int64_t P = 2 * batch;
     const size_t elems = (size_t)batch * C * n;
     char* p = (char*)workspace;
-    const size_t fused = 2 * al256(fine_image_bytes(P));
+    const size_t fused = 3 * al256(fine_image_bytes(P));
     const size_t redo_b = 4 * al256(elems * sizeof(float)) + al256(pats_attentional_propagation_workspace_bytes(batch, C, n, n));
     char* tf[2] = {p, p + al256(fine_image_bytes(P))};
+    char* tf_att = p + 2 * al256(fine_image_bytes(P));
     char* scratch = p + std::max(fused, redo_b);
     int* flag = (int*)(scratch + al256(fine_scratch_bytes(P)));
     if (fill_bytes(flag, 0, sizeof(int), st)) return PATS_ERR_LAUNCH;
@@ -882,7 +884,7 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     if ((rc = launch_fine_in(desc1, batch, tf[0] + fine_image_bytes(batch), st))) return rc;
     int cur = 0;
     for (int l = 0; l < layers; ++l) {
-        rc = launch_fine_layer(tf[cur], tf[cur], cross[l] ? batch : 0, tf[cur], P, packed_fine_section(packed[l], C, heads), tf[1 - cur],
+        rc = launch_fine_layer(tf[cur], tf[cur], cross[l] ? batch : 0, 1, P, packed_fine_section(packed[l], C, heads), tf[1 - cur], tf_att,
                                scratch, flag, nullptr, st, 2, live, live_off);
         if (rc) return rc;           // (PATS_ERR_UNSUPPORTED: the LDS attribute was refused - the caller takes the per-layer path)
         cur = 1 - cur;

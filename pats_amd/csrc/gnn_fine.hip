@@ -85,7 +85,8 @@ struct FineArgs {
     const char* tf_x;          // [P] TF images of the descriptors
     const char* tf_s;          // [P] TF images of the sources; problem p reads image (p + shift) % P
     const char* tf_res;        // [P] TF images of the residual or null: added to the output (exact to the 22 bits an image holds)
-    char* tf_out;              // [P] TF images of the output
+    char* tf_out;              // [P] TF images of the output (FULL)
+    char* tf_att;              // [P] TF images of the attention output (!FULL: the kernel stops behind the attention; gnn_fine_mlp_kernel follows)
     const h8v* pw;
     const float* pb;
     char* scratch;             // [gridDim.x][SC_BYTES]
@@ -387,7 +388,8 @@ gnn_fine_in_kernel(const float* __restrict__ x, int64_t P, char* __restrict__ tf
 }
 
 __global__ void __launch_bounds__(256)
-gnn_fine_out_kernel(const char* __restrict__ tf, int64_t P, float* __restrict__ y, const int64_t* __restrict__ live, int64_t live_off) {
+gnn_fine_out_kernel(const char* __restrict__ tf, int64_t P, float* __restrict__ y, const int64_t* __restrict__ live, int64_t live_off,
+                    const float* __restrict__ add) {
     // rows past the device-side count (no layer computed them): zeros, so that whatever runs over the capacity next reads finite values
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= P * 33 * FN) return;
@@ -403,11 +405,19 @@ gnn_fine_out_kernel(const char* __restrict__ tf, int64_t P, float* __restrict__ 
         for (int e = 0; e < 8; ++e) v[e] = ((float)hi[e] + (float)lo[e]) * (1.0f / PRE);
     }
     float* d = y + (p * FC + cg * 8) * FN + tok;
+    if (add) {                 // a residual that is neither null nor the layer's own x (the single-layer entry): added here, in fp32
+        const float* a_ = add + (p * FC + cg * 8) * FN + tok;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a_[e * FN];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) d[e * FN] = v[e];
 }
 
 // ---- the layer -----------------------------------------------------------------------------------------------------------------
+// FULL: the whole layer per problem (round 5, first form; diagnostic library only since the split below is faster).  !FULL: q / k / v
+// and the attention only - the attention output leaves as a TF image and gnn_fine_mlp_kernel runs the MLP on flattened column tiles.
+template <bool FULL>
 __global__ void __launch_bounds__(512, 1)
 gnn_fine_layer_kernel(FineArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -558,6 +568,7 @@ gnn_fine_layer_kernel(FineArgs g) {
             q.l1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 1) + qoff);
             q.x = *reinterpret_cast<const h8v*>(scr + SC_QX + (h * FN + qtok) * 16);
         };
+        char* att_dst = FULL ? scr + SC_Q : g.tf_att + p * TF_BYTES;
         QF q;
         qload(0, wave, q);
         for (int h = 0; h < 4; ++h) {
@@ -650,15 +661,15 @@ gnn_fine_layer_kernel(FineArgs g) {
                     __builtin_amdgcn_sched_barrier(0);
                     o = o * osc;
                     if (dt < 4) {
-                        store_tf(scr + SC_Q, 4 * h + dt, qt_own, o, lane, lo_);
+                        store_tf(att_dst, 4 * h + dt, qt_own, o, lane, lo_);
                     } else if (gq == (h >> 1) && (qt_own < 9 || j == 0)) {
                         // rows 2 h', 2 h' + 1 of the extras tile are head h's channels 64, 65 -> bytes 4 h .. of the ragged block's piece
                         const float e0 = (h & 1) ? o.z : o.x, e1 = (h & 1) ? o.w : o.y;
                         const _Float16 a0 = (_Float16)e0, a1 = (_Float16)e1;
                         const h2v hi = {a0, a1}, lo = {(_Float16)(e0 - (float)a0), (_Float16)(e1 - (float)a1)};
                         const int off = tf_off(true, qt_own, j) + 4 * h;
-                        *reinterpret_cast<h2v*>(scr + SC_Q + tf_blk(8, 0) + off) = hi;
-                        *reinterpret_cast<h2v*>(scr + SC_Q + tf_blk(8, 1) + off) = lo;
+                        *reinterpret_cast<h2v*>(att_dst + tf_blk(8, 0) + off) = hi;
+                        *reinterpret_cast<h2v*>(att_dst + tf_blk(8, 1) + off) = lo;
                     }
                 }
             }
@@ -671,6 +682,18 @@ gnn_fine_layer_kernel(FineArgs g) {
         }
         wg_barrier_global();                               // the attention output is in the scratch block; the staging area is free
         FT(11);
+        if (!FULL) {                                       // the MLP is gnn_fine_mlp_kernel's: next problem (its source lands now)
+            if (q_ + gridDim.x < NQ) {
+                const int64_t qn = q_ + gridDim.x;
+                int64_t pn = (qn < L ? qn : g.half + (qn - L)) + g.shift;
+                if (pn >= g.P) pn -= g.P;
+                dma_fill<TF_BYTES>(lds, g.tf_s + pn * TF_BYTES, wave, lane);
+            }
+#ifdef PATS_DIAG
+            ++nprob;
+#endif
+            continue;
+        }
         // ================= hidden = relu(bn(W1x x + W1a att + b1')): two halves of 264 rows =========================================
         dma_fill<TF_BYTES>(lds, scr + SC_Q, wave, lane);   // att
         wg_barrier_global();
@@ -785,6 +808,253 @@ gnn_fine_layer_kernel(FineArgs g) {
 #endif
 }
 
+// ---- the MLP half of the layer on FLATTENED column tiles ------------------------------------------------------------------------
+// hidden = relu(bn(W1x x + W1a att + b1')), out = W2 hidden + b2 + x are per-token: a workgroup takes 64 columns of the flattened
+// (problem, token) axis - no token padding (145 = 9 x 16 + 1 costs the per-problem kernel 10 %), and x-tile + att-tile (2 x 66 KB as
+// fragments) sit in LDS TOGETHER, so mlp[0] is one 18-k-step loop whose 528 x 64 output lives in the accumulators (17 tile units a
+// wave), is written - BatchNorm, ReLU, split - over the operands it came from, and feeds mlp[3] from there: the hidden tensor never
+// leaves the CU and x / att are read once.  The residual is rebuilt from the x fragments in LDS before they are overwritten.
+// Operands arrive by gather DMA from the per-problem TF images (a lane's source address is its column's; the 64 pieces of a
+// fragment land contiguously), the output leaves as 16-byte pieces scattered into the per-problem images of the next layer.
+constexpr int MT_HALF = 8 * 8192 + 2 * 1024;          // one operand half-tile: eight full k-steps [plane][4 column tiles][64 x 16 B] + the ragged one
+constexpr int MLP_LDS = 2 * MT_HALF;                  // 135 168
+
+struct MlpArgs {
+    const char* tf_x; const char* tf_att; char* tf_out;
+    const h8v* pw; const float* pb;
+    int64_t P, half; int sets;
+    const int64_t* live; int64_t live_off;
+    int* flag;
+    int residual;              // add x (AttentionalGNN.forward's desc + delta); 0: the delta alone
+    const int* gate;
+};
+
+// byte offset of token t's 16-byte piece (k-group kq) inside a (k-step, plane) block of a per-problem image
+__device__ __forceinline__ int img_tok_off(bool ragged, int t, int kq) {
+    if (!ragged) return t < 144 ? (t >> 4) * 1024 + kq * 256 + (t & 15) * 16 : 9216 + kq * 16;
+    return t < 144 ? (t >> 4) * 256 + (t & 15) * 16 : 2304;
+}
+
+__global__ void __launch_bounds__(512, 1)
+gnn_fine_mlp_kernel(MlpArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (g.gate && *g.gate == 0) return;
+    const int t_ = threadIdx.x, lane0 = t_ & 63, wave0 = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    int64_t L = g.half;
+    if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
+    const int64_t ncol = L * g.sets * FN, ntile = (ncol + 63) >> 6;
+    bool bad = false;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        int lane = lane0, wave = wave0;
+        const h8v* pw = g.pw;
+        const float* pb = g.pb;
+        asm volatile("" : "+v"(lane), "+s"(wave), "+s"(pw), "+s"(pb));       // (as in the layer kernel: nothing hoisted out of the tile loop)
+        const int gq = lane >> 4, j = lane & 15;
+        // this lane's four columns (one per column tile): problem image and token
+        int64_t pbase[4];
+        int tok[4];
+        bool colok[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            int64_t c = tile * 64 + ct * 16 + j;
+            colok[ct] = c < ncol;
+            if (c >= ncol) c = ncol - 1;
+            const int64_t q = c / FN;
+            tok[ct] = (int)(c - q * FN);
+            pbase[ct] = (q < L ? q : g.half + (q - L)) * (int64_t)TF_BYTES;
+        }
+        wg_barrier();                                      // the previous tile's hidden fragments have been read
+        // ---- gather: 2 x 72 fragments, 18 a wave ------------------------------------------------------------------------------------
+#pragma unroll 2
+        for (int i = 0; i < 18; ++i) {
+            const int idx = wave + 8 * i, part = idx >= 72 ? 1 : 0, r = idx - 72 * part;
+            const char* img = part ? g.tf_att : g.tf_x;
+            if (r < 64) {
+                const int ks = r >> 3, plane = (r >> 2) & 1, ct = r & 3;
+                const int64_t pbc = ct == 0 ? pbase[0] : ct == 1 ? pbase[1] : ct == 2 ? pbase[2] : pbase[3];
+                const int tk = ct == 0 ? tok[0] : ct == 1 ? tok[1] : ct == 2 ? tok[2] : tok[3];
+                const char* src = img + pbc + (2 * ks + plane) * TFB + img_tok_off(false, tk, gq);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + ks * 8192 + plane * 4096 + ct * 1024), 16, 0, 0);
+            } else {
+                const int rr = r - 64, plane = rr >> 2, ct = rr & 3;
+                const int64_t pbc = ct == 0 ? pbase[0] : ct == 1 ? pbase[1] : ct == 2 ? pbase[2] : pbase[3];
+                const int tk = ct == 0 ? tok[0] : ct == 1 ? tok[1] : ct == 2 ? tok[2] : tok[3];
+                const char* src = img + pbc + TF_MAIN + plane * TFR + img_tok_off(true, tk, 0);
+                if (lane < 16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + 65536 + plane * 1024 + ct * 256), 16, 0, 0);
+            }
+        }
+        wg_barrier_global();
+        // B fragments of k-step kk (0..8; 8 = ragged) of operand half `part`
+        auto bload = [&](int part, int kk, h8v (&bh)[4], h8v (&bl)[4]) {
+            const char* base = lds + part * MT_HALF;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (kk < 8) {
+                    bh[ct] = *reinterpret_cast<const h8v*>(base + kk * 8192 + ct * 1024 + lane * 16);
+                    bl[ct] = *reinterpret_cast<const h8v*>(base + kk * 8192 + 4096 + ct * 1024 + lane * 16);
+                } else {
+                    const h8v a = *reinterpret_cast<const h8v*>(base + 65536 + ct * 256 + j * 16);
+                    const h8v b = *reinterpret_cast<const h8v*>(base + 65536 + 1024 + ct * 256 + j * 16);
+                    bh[ct] = lane < 16 ? a : zero8();
+                    bl[ct] = lane < 16 ? b : zero8();
+                }
+            }
+        };
+        // ---- mlp[0]: row tiles 2 w, 2 w + 1 of both halves (FW_1 numbering: half 1 starts at tile 17) + one unit of a ragged tile -------
+        const int rag_tile = wave < 4 ? 16 : 33, rag_ct = wave & 3;
+        f4v acc[4][4], accr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+        {
+            h8v a[2][5][2];
+            auto aload5 = [&](int ks, h8v (&r)[5][2]) {
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const int mt = m < 2 ? 2 * wave + m : m < 4 ? 17 + 2 * wave + (m - 2) : rag_tile;
+                    gptr_h8 Wf = uniform_ptr(pw + FW_1 + ((size_t)mt * 18 + ks) * FR);
+                    r[m][0] = Wf[lane];
+                    r[m][1] = Wf[64 + lane];
+                }
+            };
+            aload5(0, a[0]);
+#pragma unroll 1
+            for (int kp = 0; kp < 9; ++kp) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int ks = 2 * kp + e;
+                    if (ks + 1 < 18) aload5(ks + 1, a[1 - e]);
+                    h8v bh[4], bl[4];
+                    bload(ks >= 9 ? 1 : 0, ks >= 9 ? ks - 9 : ks, bh, bl);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m][ct] = mfma3(a[e][m][0], a[e][m][1], bh[ct], bl[ct], acc[m][ct]);
+                        if (ct == rag_ct) accr = mfma3(a[e][4][0], a[e][4][1], bh[ct], bl[ct], accr);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- the residual of this wave's mlp[3] units, from the x fragments still in LDS: rows 16 mt + 4 g.. of its four columns ---------
+        f4v res[2][4], resr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) res[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+        if (g.residual) {
+            auto rd = [&](int mt, int ct) {
+                const char* bx = mt < 16 ? lds + (mt >> 1) * 8192 + ct * 1024 + ((2 * (mt & 1) + (gq >> 1)) * 16 + j) * 16 + (gq & 1) * 8
+                                         : lds + 65536 + ct * 256 + j * 16 + (gq & 1) * 8;
+                const int pl = mt < 16 ? 4096 : 1024;
+                const h4v hi = *reinterpret_cast<const h4v*>(bx), lo = *reinterpret_cast<const h4v*>(bx + pl);
+                return (__builtin_convertvector(hi, f4v) + __builtin_convertvector(lo, f4v)) * (1.0f / PRE);
+            };
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) res[m][ct] = rd(2 * wave + m, ct);
+            if (wave < 4 && gq < 2) resr = rd(16, wave);
+        }
+        wg_barrier();                                      // every wave is done with x | att: hidden takes their place
+        {
+            auto put = [&](int mtl, int hf, int ct, const f4v acc_, bool ragged) {
+                const int ch = hf * 272 + 16 * mtl + 4 * gq;
+                const f4v bias = load4(pb + FB_1 + ch), sc = load4(pb + FB_A + ch), sh = load4(pb + FB_S + ch);
+                f4v v = fma4(acc_, sc * (UNS * PRE), (bias * sc + sh) * PRE);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];                  // ReLU that keeps NaN
+                h4v hi, lo;
+                split4_pre(v, hi, lo);
+                const u2v H = __builtin_bit_cast(u2v, hi), Lo = __builtin_bit_cast(u2v, lo);
+                unsigned hx = H.x, hy = H.y, lx = Lo.x, ly = Lo.y;
+                lane_swap16(hx, lx);
+                lane_swap16(hy, ly);
+                char* d = ragged ? lds + hf * MT_HALF + 65536 + (gq & 1) * 1024 + ct * 256 + j * 16
+                                 : lds + hf * MT_HALF + (mtl >> 1) * 8192 + (gq & 1) * 4096 + ct * 1024 + ((2 * (mtl & 1) + (gq >> 1)) * 16 + j) * 16;
+                if (!ragged || gq < 2) *reinterpret_cast<u4v*>(d) = u4v{hx, hy, lx, ly};
+            };
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) put(2 * wave + (m & 1), m >> 1, ct, acc[m][ct], false);
+            put(16, wave >> 2, rag_ct, accr, true);
+        }
+        wg_barrier();
+        // ---- mlp[3]: row tiles 2 w, 2 w + 1 over the four column tiles + (waves 0..3) column tile w of the ragged 17th ---------------
+        f4v o[2][4], orr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) o[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+        {
+            h8v a[2][3][2];
+            auto aload3 = [&](int ks, h8v (&r)[3][2]) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int mt = m < 2 ? 2 * wave + m : 16;
+                    gptr_h8 Wf = uniform_ptr(pw + FW_2 + ((size_t)mt * 18 + ks) * FR);
+                    r[m][0] = Wf[lane];
+                    r[m][1] = Wf[64 + lane];
+                }
+            };
+            aload3(0, a[0]);
+#pragma unroll 1
+            for (int kp = 0; kp < 9; ++kp) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int ks = 2 * kp + e;
+                    if (ks + 1 < 18) aload3(ks + 1, a[1 - e]);
+                    h8v bh[4], bl[4];
+                    bload(ks >= 9 ? 1 : 0, ks >= 9 ? ks - 9 : ks, bh, bl);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        o[0][ct] = mfma3(a[e][0][0], a[e][0][1], bh[ct], bl[ct], o[0][ct]);
+                        o[1][ct] = mfma3(a[e][1][0], a[e][1][1], bh[ct], bl[ct], o[1][ct]);
+                        if (ct == wave) orr = mfma3(a[e][2][0], a[e][2][1], bh[ct], bl[ct], orr);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- out = . + b2 + x -> the next layer's images (16-byte pieces, lane pairs exchange halves) ---------------------------------
+        {
+            auto emit = [&](int mt, int ct, const f4v acc_, const f4v res_, bool mine) {
+                const f4v bias = load4(pb + FB_2 + 16 * mt + 4 * gq);
+                const f4v v = fma4(acc_, bcast4(UNS), bias) + res_;
+                const int64_t pbc = ct == 0 ? pbase[0] : ct == 1 ? pbase[1] : ct == 2 ? pbase[2] : pbase[3];
+                const int tk = ct == 0 ? tok[0] : ct == 1 ? tok[1] : ct == 2 ? tok[2] : tok[3];
+                const bool ok = (ct == 0 ? colok[0] : ct == 1 ? colok[1] : ct == 2 ? colok[2] : colok[3]) && mine && (mt < 16 || gq < 2);
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
+                }
+                h4v hi, lo;
+                split4_pre(v * PRE, hi, lo);
+                const u2v H = __builtin_bit_cast(u2v, hi), Lo = __builtin_bit_cast(u2v, lo);
+                unsigned hx = H.x, hy = H.y, lx = Lo.x, ly = Lo.y;
+                lane_swap16(hx, lx);
+                lane_swap16(hy, ly);
+                char* d = g.tf_out + pbc + (mt < 16 ? ((mt >> 1) * 2 + (gq & 1)) * TFB + img_tok_off(false, tk, 2 * (mt & 1) + (gq >> 1))
+                                                    : TF_MAIN + (gq & 1) * TFR + img_tok_off(true, tk, 0));
+                if (ok) *reinterpret_cast<u4v*>(d) = u4v{hx, hy, lx, ly};
+            };
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) emit(2 * wave + m, ct, o[m][ct], res[m][ct], true);
+            emit(16, wave & 3, orr, resr, wave < 4);
+        }
+    }
+    if (bad) atomicOr(g.flag, 1);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------
 int fine_layer_supported(int C, int heads, int n, int m) {
     static const bool off = [] { const char* e = env_switch("PATS_GNN_FINE"); return e && atoi(e) == 0; }();
@@ -809,7 +1079,11 @@ static int fine_grid(int64_t P) {
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = 0; }
     PerDevice& pd = per_dev[dev_id];
     if (pd.state == 0) {
-        const bool ok = hipFuncSetAttribute((const void*)gnn_fine_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_LDS) == hipSuccess;
+        bool ok = hipFuncSetAttribute((const void*)gnn_fine_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_LDS) == hipSuccess &&
+                  hipFuncSetAttribute((const void*)gnn_fine_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) == hipSuccess;
+#ifdef PATS_DIAG
+        ok = ok && hipFuncSetAttribute((const void*)gnn_fine_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_LDS) == hipSuccess;
+#endif
         if (!ok) (void)hipGetLastError();
         int v = 256;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) (void)hipGetLastError();
@@ -828,31 +1102,40 @@ int launch_fine_in(const float* x, int64_t P, char* tf, hipStream_t st) {
     hipLaunchKernelGGL(gnn_fine_in_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, P, tf);
     return check_launch("gnn_fine_in_kernel");
 }
-int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const int64_t* live, int64_t live_off) {
+int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const int64_t* live, int64_t live_off, const float* add) {
     const int64_t items = P * 33 * FN;
-    hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, tf, P, y, live, live_off);
+    hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, tf, P, y, live, live_off, add);
     return check_launch("gnn_fine_out_kernel");
 }
 // one layer over P problems: image p of tf_x with source image (p + shift) % P of tf_s
-// sets descriptor sets of P / sets rows each; live (optional): device-side row count of a set, minus live_off
-int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const char* tf_res, int64_t P, const void* section,
-                      char* tf_out, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
+// One layer over P problems (sets descriptor sets of P / sets rows each; live (optional): device-side row count of a set, minus
+// live_off): image p of tf_x with source image (p + shift) % P of tf_s.  Two launches: q / k / v + attention per problem
+// (gnn_fine_layer_kernel<false> -> tf_att), then the MLP on flattened 64-column tiles (gnn_fine_mlp_kernel -> tf_out; residual != 0:
+// + x).  Diagnostic library, PATS_FINE_SPLIT=0: the whole layer per problem in the first kernel (the round's first form).
+int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, int residual, int64_t P, const void* section,
+                      char* tf_out, char* tf_att, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
                       const int64_t* live, int64_t live_off) {
     const int grid = fine_grid(P);
     if (grid <= 0) return PATS_ERR_UNSUPPORTED;
     const h8v* pw = (const h8v*)section;
     // De-phasing: a layer's far-memory traffic comes in bursts (image fills, epilogues) that every workgroup of a lockstep grid
-    // issues at the same instants; workgroup i starts ((i >> 3) % 32) x 4 us late, which spreads them over a problem's period
-    // (4 096 problems: 4.86 -> 4.57 ms with the conversions).  Only where a workgroup has enough problems to pay for the ramp.
+    // issues at the same instants; workgroup i starts ((i >> 3) % 32) x 4 us late, which spreads them over a problem's period.
+    // Only where a workgroup has enough problems to pay for the ramp.
     static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
     const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)grid ? 4 : 0);
-    FineArgs g{tf_x, tf_s, tf_res, tf_out, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off, P / sets, sets, stagger};
+    FineArgs g{tf_x, tf_s, residual ? tf_x : nullptr, tf_out, tf_att, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off,
+               P / sets, sets, stagger};
     const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
+    bool split = true;
 #ifdef PATS_DIAG
+    static const bool whole = [] { const char* e = diag_env("PATS_FINE_SPLIT"); return e && atoi(e) == 0; }();
+    split = !whole;
     g.tl = nullptr;
     if (diag_env("PATS_FINE_TL")) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * FT_N * 8); (void)hipMemset(g.tl, 0, (size_t)wgs * FT_N * 8); }
+    if (!split) hipLaunchKernelGGL(gnn_fine_layer_kernel<true>, dim3(wgs), dim3(512), FINE_LDS, st, g);
+    else
 #endif
-    hipLaunchKernelGGL(gnn_fine_layer_kernel, dim3(wgs), dim3(512), FINE_LDS, st, g);
+    hipLaunchKernelGGL(gnn_fine_layer_kernel<false>, dim3(wgs), dim3(512), FINE_LDS, st, g);
 #ifdef PATS_DIAG
     if (g.tl) {
         (void)hipStreamSynchronize(st);
@@ -860,17 +1143,22 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, const c
         (void)hipMemcpy(h.data(), g.tl, h.size() * 8, hipMemcpyDeviceToHost);
         double sum[FT_N] = {0}, np = 0;
         for (unsigned w = 0; w < wgs; ++w) { for (int k = 0; k < FT_N - 1; ++k) sum[k] += (double)h[(size_t)w * FT_N + k]; np += (double)h[(size_t)w * FT_N + FT_N - 1]; }
-        static const char* names[FT_N] = {"fill s", "k product", "k epilogue", "v^T product", "v^T epilogue", "barrier + fill x", "q product", "q epilogue",
-            "barrier (q k v visible)", "attention: wait k_h v_h", "attention: units", "attention: barrier after units", "fill att (x2)", "hidden: att part (x2)",
-            "barrier + fill x", "hidden: x part (x2)", "hidden epilogue (x2)", "fill hidden (x2)", "out product (x2)", "out epilogue", "last barrier", "", "", ""};
+        static const char* names[FT_N] = {"fill s", "k product", "k epilogue", "v^T product", "v^T epilogue (x fill under it)", "barrier", "q product", "q epilogue (k, v staging under it)",
+            "barrier (q k v visible)", "attention: wait k_h v_h", "attention: units", "attention: barriers", "fill att", "hidden: att part (x2)",
+            "barrier + fill x", "hidden: x part (x2)", "hidden epilogues", "fill hidden0", "out product (x2)", "out epilogue", "", "", "", ""};
         double tot = 0;
         for (int k = 0; k <= 20; ++k) tot += sum[k];
-        fprintf(stderr, "gnn_fine timeline (%u workgroups, %.0f problems; mean us per problem, thread 0): total %.2f\n", wgs, np, tot / np / 100.0);
-        for (int k = 0; k <= 20; ++k) fprintf(stderr, "  %-34s %7.2f\n", names[k], sum[k] / np / 100.0);
+        fprintf(stderr, "gnn_fine timeline, %s (%u workgroups, %.0f problems; mean us per problem, thread 0): total %.2f\n",
+                split ? "first kernel of the split layer" : "whole layer in one kernel", wgs, np, tot / np / 100.0);
+        for (int k = 0; k <= 19; ++k) if (sum[k] > 0) fprintf(stderr, "  %-38s %7.2f\n", names[k], sum[k] / np / 100.0);
         (void)hipFree(g.tl);
     }
 #endif
-    return check_launch("gnn_fine_layer_kernel");
+    int rc = check_launch("gnn_fine_layer_kernel");
+    if (rc || !split) return rc;
+    MlpArgs m{tf_x, tf_att, tf_out, pw, (const float*)(pw + FW_END), P, P / sets, sets, live, live_off, flag, residual, gate};
+    hipLaunchKernelGGL(gnn_fine_mlp_kernel, dim3(wgs), dim3(512), MLP_LDS, st, m);
+    return check_launch("gnn_fine_mlp_kernel");
 }
 
 }  // namespace pats
