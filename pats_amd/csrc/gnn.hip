@@ -654,8 +654,14 @@ int launch_fine_in(const float* x, int64_t P, char* tf, hipStream_t st);
 int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const int64_t* live = nullptr, int64_t live_off = 0,
                     const float* add = nullptr);
 int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, int residual, int64_t P, const void* section,
-                      char* tf_out, char* tf_att, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
+                      char* tf_out, char* tf_att, char* qkv, int* flag, const int* gate, hipStream_t st, int sets,
                       const int64_t* live, int64_t live_off);
+int launch_fine_qkv(const char* tf, int64_t P, const void* section, char* qkv, int want_q, int want_kv, const int* gate, hipStream_t st, int sets,
+                    const int64_t* live, int64_t live_off);
+int launch_fine_attn(const char* qkv, int64_t shift, char* tf_att, int64_t P, const int* gate, hipStream_t st, int sets, const int64_t* live,
+                     int64_t live_off);
+int launch_fine_mlp(const char* tf_x, const char* tf_att, int residual, const void* section, char* tf_out, const void* next_section, char* qkv,
+                    int64_t P, int* flag, const int* gate, hipStream_t st, int sets, const int64_t* live, int64_t live_off);
 }
 
 static int propagation_impl(const float* x, const float* source, int64_t batch, int C, int heads, int n, int m,
@@ -883,10 +889,14 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     if ((rc = launch_fine_in(desc0, batch, tf[0], st))) return rc;
     if ((rc = launch_fine_in(desc1, batch, tf[0] + fine_image_bytes(batch), st))) return rc;
     int cur = 0;
+    // the first layer's projections; every later layer's are made by the MLP launch of the layer before it, from the tile in its LDS
+    if (layers > 0 && (rc = launch_fine_qkv(tf[0], P, packed_fine_section(packed[0], C, heads), scratch, 1, 1, nullptr, st, 2, live, live_off)))
+        return rc;                   // (PATS_ERR_UNSUPPORTED: the LDS attribute was refused - the caller takes the per-layer path)
     for (int l = 0; l < layers; ++l) {
-        rc = launch_fine_layer(tf[cur], tf[cur], cross[l] ? batch : 0, 1, P, packed_fine_section(packed[l], C, heads), tf[1 - cur], tf_att,
-                               scratch, flag, nullptr, st, 2, live, live_off);
-        if (rc) return rc;           // (PATS_ERR_UNSUPPORTED: the LDS attribute was refused - the caller takes the per-layer path)
+        if ((rc = launch_fine_attn(scratch, cross[l] ? batch : 0, tf_att, P, nullptr, st, 2, live, live_off))) return rc;
+        rc = launch_fine_mlp(tf[cur], tf_att, 1, packed_fine_section(packed[l], C, heads), tf[1 - cur],
+                             l + 1 < layers ? packed_fine_section(packed[l + 1], C, heads) : nullptr, scratch, P, flag, nullptr, st, 2, live, live_off);
+        if (rc) return rc;
         cur = 1 - cur;
     }
     if ((rc = launch_fine_out(tf[cur], batch, out0, st, live, live_off))) return rc;

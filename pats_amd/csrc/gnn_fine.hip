@@ -62,18 +62,9 @@ constexpr int TF_BYTES = TF_MAIN + 2 * TFR;   // 153 120
 constexpr int XB = 4 * FN * 16;               // the extra channels of q / k: [head][token] one 16-byte packed piece
 constexpr int V_TILE = 5 * 2 * 1024;          // one 16-channel tile of v as A fragments: [key pair tile kk][hi | lo][64 lanes x 16 B]
 constexpr int V_BYTES = 17 * V_TILE;
-// per-workgroup scratch block (global memory)
-constexpr int SC_Q = 0;                       // q as a TF image; the attention output replaces it in place (main part) / fills its ragged block
-constexpr int SC_QX = SC_Q + TF_BYTES;
-constexpr int SC_K = SC_QX + XB;              // k (TF main part); later hidden[0:264] as a TF image
-constexpr int SC_KX = SC_K + TF_BYTES;
-constexpr int SC_V = SC_KX + XB;              // v^T fragments; later hidden[264:528] as a TF image
-constexpr int SC_BYTES = SC_V + V_BYTES;      // 498 880
 // LDS while the attention runs
 constexpr int KH_BYTES = 4 * TFB + FN * 16;   // one head of k: two k-steps x (hi, lo) + its extras
 constexpr int L_KA = 0, L_V = 2 * KH_BYTES, L_VX = L_V + 4 * V_TILE, L_ATT_END = L_VX + V_TILE;
-constexpr int FINE_LDS = TF_BYTES + 32;
-static_assert(L_ATT_END <= FINE_LDS, "attention staging fits the slot");
 // packed weights (units of h8v): fragment (row tile, k-step) = [hi | lo][64 lanes]
 constexpr int FR = 128;
 constexpr int FW_Q = 0, FW_K = FW_Q + 17 * 9 * FR, FW_V = FW_K + 17 * 9 * FR, FW_1 = FW_V + 17 * 9 * FR, FW_2 = FW_1 + 34 * 18 * FR,
@@ -81,30 +72,9 @@ constexpr int FW_Q = 0, FW_K = FW_Q + 17 * 9 * FR, FW_V = FW_K + 17 * 9 * FR, FW
 // biases behind them (floats): q', k', v' (permuted), b1' (two halves), bn scale, bn shift, b2 - every vector padded to 272
 constexpr int FB_Q = 0, FB_K = 272, FB_V = 544, FB_1 = 816, FB_A = FB_1 + 544, FB_S = FB_A + 544, FB_2 = FB_S + 544, FB_END = FB_2 + 272;
 
-struct FineArgs {
-    const char* tf_x;          // [P] TF images of the descriptors
-    const char* tf_s;          // [P] TF images of the sources; problem p reads image (p + shift) % P
-    const char* tf_res;        // [P] TF images of the residual or null: added to the output (exact to the 22 bits an image holds)
-    char* tf_out;              // [P] TF images of the output (FULL)
-    char* tf_att;              // [P] TF images of the attention output (!FULL: the kernel stops behind the attention; gnn_fine_mlp_kernel follows)
-    const h8v* pw;
-    const float* pb;
-    char* scratch;             // [gridDim.x][SC_BYTES]
-    int64_t P, shift;
-    int* flag;
-    const int* gate;           // optional: no-op unless *gate != 0
-    const int64_t* live;       // optional device-side ROW count: of every descriptor set (`sets` of them, `half` rows each: P = sets * half)
-    int64_t live_off, half;    // only rows < clamp(*live - live_off, 0, half) are problems
-    int sets;
-    int stagger;               // workgroup i starts ((i >> 3) % 32) * stagger * ~1 us late: de-phases the memory bursts of the stages
-#ifdef PATS_DIAG
-    long long* tl;             // diagnostic library: FT_N accumulated stage durations per workgroup (thread 0, 10 ns units)
-#endif
-};
-
 // Diagnostic library only (python -m pats_amd.build --diag, PATS_AMD_DIAG_LIB=1, PATS_FINE_TL=1): s_memrealtime stamps at the stage
 // boundaries of thread 0, summed over the workgroup's problems; launch_fine_layer prints the means per problem
-constexpr int FT_N = 24;
+constexpr int FT_N = 24;          // (diagnostic library)
 #ifdef PATS_DIAG
 #define FT(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_amdgcn_s_memrealtime(); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -200,115 +170,6 @@ __device__ __forceinline__ void store_tf(char* dst, int mt, int t, const f4v v, 
         char* d = dst + TF_MAIN + (t < 9 ? t * 256 : 2304);
         if (g < 2 && (t < 9 || j == 0)) *reinterpret_cast<u4v*>(d + lo_.tf2) = piece;
     }
-}
-
-// the inverse: rows 16 mt + 4 g + r of token 16 t + j from a TF image in global memory.  load_tf_piece() issues the one 16-byte load
-// of a lane (an even-row lane its pair's hi piece, an odd-row lane the lo piece; zeros where the tile has nothing for it);
-// tf_piece_value() - called by all 64 lanes - gives the halves back to their owners and rebuilds (hi + lo) / 2^6.
-typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u4v_t load_tf_piece(const char* src, int mt, int t, int lane, const LaneOff& lo_) {
-    const int g = lane >> 4, j = lane & 15;
-    u4v_t p = {0u, 0u, 0u, 0u};
-    if (mt < 16) {
-        const char* d = src + (mt >> 1) * (2 * TFB) + (mt & 1) * (t < 9 ? 512 : 32) + (t < 9 ? t * 1024 : 9216);
-        if (t < 9) p = *reinterpret_cast<const u4v_t*>(d + lo_.tf0);
-        else if (j == 0) p = *reinterpret_cast<const u4v_t*>(d + lo_.tf1);
-    } else {
-        const char* d = src + TF_MAIN + (t < 9 ? t * 256 : 2304);
-        if (g < 2 && (t < 9 || j == 0)) p = *reinterpret_cast<const u4v_t*>(d + lo_.tf2);
-    }
-    return p;
-}
-__device__ __forceinline__ f4v tf_piece_value(const u4v_t p) {
-    // even-row lane: (x, y) = own hi, (z, w) = partner's hi; odd-row lane: (x, y) = partner's lo, (z, w) = own lo.
-    // lane_swap16(a, b): odd rows of a <-> even rows of b  =>  every lane ends with a = own hi, b = own lo
-    unsigned ax = p.x, ay = p.y, bx = p.z, by = p.w;
-    lane_swap16(ax, bx);
-    lane_swap16(ay, by);
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    const h4v hi = __builtin_bit_cast(h4v, u2v{ax, ay}), lo = __builtin_bit_cast(h4v, u2v{bx, by});
-    return (__builtin_convertvector(hi, f4v) + __builtin_convertvector(lo, f4v)) * (1.0f / PRE);
-}
-
-// ---- one convolution pass over the nine k-steps of the TF image in LDS -----------------------------------------------------------
-// Wave w accumulates row tiles tb + 2 w, tb + 2 w + 1 (acc[m][t], all ten token tiles) and two units (tr, t0), (tr, t1) of the
-// ragged row tile tr = tb + 16 (accr; t1 < 0: none).  TRANS: the activations are the A operand, the weights B (v^T).
-struct ARing { h8v a[2][3][2]; };             // [slot][main 0, main 1, ragged][hi, lo]
-
-template <int KSM>
-__device__ __forceinline__ void aload(const h8v* __restrict__ W, int tb, int wave, int ks, int lane, h8v (&a)[3][2]) {
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        const int mt = m < 2 ? tb + 2 * wave + m : tb + 16;
-        gptr_h8 Wf = uniform_ptr(W + ((size_t)mt * KSM + ks) * FR);
-        a[m][0] = Wf[lane];
-        a[m][1] = Wf[64 + lane];
-    }
-}
-
-template <bool TRANS, bool RAG>
-__device__ __forceinline__ void kstep(const char* slot, int ks, const h8v (&a)[3][2], f4v (&acc)[2][FNT], f4v (&accr)[2], int t0, int t1,
-                                      int lane) {
-    const char* b0 = slot + tf_blk(RAG ? 8 : ks, 0);
-    const char* b1 = slot + tf_blk(RAG ? 8 : ks, 1);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        h8v bh[5], bl[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            // (ragged k-step: every lane reads the piece of lane & 15 - a valid address - and lanes >= 16 then take zeros: selects
-            //  instead of an exec-mask region per load)
-            const int off = tf_off(RAG, 5 * half + i, lane);
-            bh[i] = *reinterpret_cast<const h8v*>(b0 + off);
-            bl[i] = *reinterpret_cast<const h8v*>(b1 + off);
-            if (RAG) {
-                bh[i] = lane < 16 ? bh[i] : zero8();
-                bl[i] = lane < 16 ? bl[i] : zero8();
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int t = 5 * half + i;
-            if (TRANS) {
-                acc[0][t] = mfma3(bh[i], bl[i], a[0][0], a[0][1], acc[0][t]);
-                acc[1][t] = mfma3(bh[i], bl[i], a[1][0], a[1][1], acc[1][t]);
-                if (t == t0) accr[0] = mfma3(bh[i], bl[i], a[2][0], a[2][1], accr[0]);
-                if (t == t1) accr[1] = mfma3(bh[i], bl[i], a[2][0], a[2][1], accr[1]);
-            } else {
-                acc[0][t] = mfma3(a[0][0], a[0][1], bh[i], bl[i], acc[0][t]);
-                acc[1][t] = mfma3(a[1][0], a[1][1], bh[i], bl[i], acc[1][t]);
-                if (t == t0) accr[0] = mfma3(a[2][0], a[2][1], bh[i], bl[i], accr[0]);
-                if (t == t1) accr[1] = mfma3(a[2][0], a[2][1], bh[i], bl[i], accr[1]);
-            }
-        }
-        // a half k-step is a closed unit for the scheduler: left alone it hoists the LDS reads of both halves (and of the next
-        // k-step) above the MFMAs and spills
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <bool TRANS, int KSM>
-__device__ __forceinline__ void conv_pass(const h8v* __restrict__ W, int tb, int ks0, const char* slot, int wave, int lane,
-                                          f4v (&acc)[2][FNT], f4v (&accr)[2], int t0, int t1) {
-    ARing r;
-    aload<KSM>(W, tb, wave, ks0, lane, r.a[0]);
-#pragma unroll 1
-    for (int kp = 0; kp < 4; ++kp) {
-        aload<KSM>(W, tb, wave, ks0 + 2 * kp + 1, lane, r.a[1]);
-        kstep<TRANS, false>(slot, 2 * kp, r.a[0], acc, accr, t0, t1, lane);
-        aload<KSM>(W, tb, wave, ks0 + 2 * kp + 2, lane, r.a[0]);
-        kstep<TRANS, false>(slot, 2 * kp + 1, r.a[1], acc, accr, t0, t1, lane);
-    }
-    kstep<TRANS, true>(slot, 8, r.a[0], acc, accr, t0, t1, lane);
-}
-
-__device__ __forceinline__ void zero_acc(f4v (&acc)[2][FNT], f4v (&accr)[2]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < FNT; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
-    accr[0] = f4v{0.f, 0.f, 0.f, 0.f};
-    accr[1] = f4v{0.f, 0.f, 0.f, 0.f};
 }
 
 // position p of the permuted q / k / v row order (and of the attention channels) -> the reference's channel d * 4 + h
@@ -414,18 +275,543 @@ gnn_fine_out_kernel(const char* __restrict__ tf, int64_t P, float* __restrict__ 
     for (int e = 0; e < 8; ++e) d[e * FN] = v[e];
 }
 
-// ---- the layer -----------------------------------------------------------------------------------------------------------------
-// FULL: the whole layer per problem (round 5, first form; diagnostic library only since the split below is faster).  !FULL: q / k / v
-// and the attention only - the attention output leaves as a TF image and gnn_fine_mlp_kernel runs the MLP on flattened column tiles.
-template <bool FULL>
+// ---- column tiles of the per-token products -------------------------------------------------------------------------------------
+// Everything of the layer except the attention core is per TOKEN: q / k / v = W x, hidden = relu(bn(W1x x + W1a att + b1')),
+// out = W2 hidden + b2 + x.  gnn_fine_tile_kernel runs those on tiles of 64 columns = four 16-token tiles taken from the flattened
+// list of (problem, token tile) pairs, so that no token padding is computed (145 = 9 x 16 + 1 costs a per-problem kernel 10 %):
+//   class F  tiles 0..3 and 4..7 of one problem (two workgroup tiles a problem),
+//   class E  tile 8 of four consecutive problems,
+//   class T  token 144 of 64 consecutive problems (column tile ct, column j = problem 64 n + 16 ct + j).
+// A column tile of classes F / E is a 16-token tile of ONE problem, aligned as the attention kernel's fragments are - which is what
+// lets v leave TRANSPOSED (activations as the A operand) directly as the A fragments of out^T = V P^T.
+// MLP: x-tile + att-tile (2 x 66 KB as B fragments) sit in LDS together; mlp[0] is one 18-k-step loop whose 528 x 64 output lives
+// in the accumulators (17 tile units a wave), is written - BatchNorm, ReLU, split - over the operands it came from and feeds mlp[3]
+// from there: the hidden tensor never leaves the CU.  The residual is rebuilt from the x fragments before they are overwritten.
+// QKV: the projections of the NEXT layer from the tile the MLP has just produced (written to LDS as fragments besides leaving as
+// the next layer's image) - or, QKV alone, of an image tile fetched for it (the first layer of a stack).  q and k leave as TF images
+// + the packed extras, v^T as A fragments, into the per-problem block the attention kernel reads (QKV_BYTES a problem).
+// Operands arrive by gather DMA (a lane's source address is its column's; the 64 pieces of a fragment land contiguously).
+constexpr int MT_HALF = 8 * 8192 + 2 * 1024;          // one operand half-tile: eight full k-steps [plane][4 column tiles][64 x 16 B] + the ragged one
+constexpr int L_PB = 2 * MT_HALF;                     // the layer's bias / BatchNorm vectors (FB_END floats) and the q / k / v biases of the
+constexpr int L_PBQ = L_PB + FB_END * 4;              // projections' layer (FB_1 floats): read by every epilogue - from LDS, not through L2
+constexpr int MLP_LDS = L_PBQ + FB_1 * 4;             // 149 312
+// per-problem block of projections
+constexpr int QO_Q = 0, QO_QX = QO_Q + TF_MAIN, QO_K = QO_QX + XB, QO_KX = QO_K + TF_MAIN, QO_V = QO_KX + XB, QKV_BYTES = QO_V + V_BYTES;
+static_assert(QKV_BYTES % 16 == 0, "16-byte pieces");
+
+struct TileArgs {
+    const char* tf_x;          // [P] TF images: the layer's x (MLP) / the tensor to project (QKV alone)
+    const char* tf_att;        // [P] the attention output (MLP)
+    char* tf_out;              // [P] the layer's output (MLP)
+    char* qkv;                 // [P][QKV_BYTES] projections (QKV)
+    const h8v* pw; const float* pb;          // the layer's packed section (MLP)
+    const h8v* pwq; const float* pbq;        // the section whose q / k / v matrices the QKV phase applies
+    int64_t P, half; int sets;
+    const int64_t* live; int64_t live_off;
+    int* flag;
+    int residual;              // MLP: add x (AttentionalGNN.forward's desc + delta); 0: the delta alone
+    int want_q, want_kv;       // QKV: which of the projections leave
+    const int* gate;
+#ifdef PATS_DIAG
+    long long* tl;
+#endif
+};
+
+// byte offset of token t's 16-byte piece (k-group kq) inside a (k-step, plane) block of a per-problem image
+__device__ __forceinline__ int img_tok_off(bool ragged, int t, int kq) {
+    if (!ragged) return t < 144 ? (t >> 4) * 1024 + kq * 256 + (t & 15) * 16 : 9216 + kq * 16;
+    return t < 144 ? (t >> 4) * 256 + (t & 15) * 16 : 2304;
+}
+
+// B fragment pair of k-step kk (0..8; 8 = ragged) of operand half `part` of the tile in LDS, column tile ct
+__device__ __forceinline__ void bload1(const char* lds, int part, int kk, int ct, int lane, h8v& bh, h8v& bl) {
+    const char* base = lds + part * MT_HALF;
+    if (kk < 8) {
+        bh = *reinterpret_cast<const h8v*>(base + kk * 8192 + ct * 1024 + lane * 16);
+        bl = *reinterpret_cast<const h8v*>(base + kk * 8192 + 4096 + ct * 1024 + lane * 16);
+    } else {
+        const h8v a = *reinterpret_cast<const h8v*>(base + 65536 + ct * 256 + (lane & 15) * 16);
+        const h8v b = *reinterpret_cast<const h8v*>(base + 65536 + 1024 + ct * 256 + (lane & 15) * 16);
+        bh = lane < 16 ? a : zero8();
+        bl = lane < 16 ? b : zero8();
+    }
+}
+
+// The weights are the A operand straight from L2 into a register ring of two k-steps.  On entry slot 0 holds k-step 0 - wload()
+// issued by the caller BEFORE the epilogue of the product in front, so that no product starts with an L2 round trip.  (A ring of
+// three k-steps - 20 KB a wave in flight - changes nothing: the stream is not latency-bound; it costs 40 registers and spills.)
+template <int N>
+__device__ __forceinline__ void wload(const h8v* const (&w)[N], int ks, int lane, h8v (&r)[N][2]) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        gptr_h8 Wf = uniform_ptr(w[m] + (size_t)ks * FR);
+        r[m][0] = Wf[lane];
+        r[m][1] = Wf[64 + lane];
+    }
+}
+#if defined(PATS_DIAG) && defined(PATS_EXP_NOW)      // experiment: no weight stream (k-step 0's fragments for every k-step; wrong results)
+#define WLOAD_IN_LOOP(N, W, ks, lane, r) do { } while (0)
+#define WSLOT(e) 0
+#else
+#define WLOAD_IN_LOOP(N, W, ks, lane, r) wload<N>(W, ks, lane, r)
+#define WSLOT(e) (e)
+#endif
+#if defined(PATS_DIAG) && defined(PATS_EXP_NOB)      // experiment: no B fragments from LDS after the first k-step (wrong results)
+#define BKK(kk) 0
+#else
+#define BKK(kk) (kk)
+#endif
+// five row tiles (w[m]: fragment of k-step 0; k-step ks at + ks * FR) x four column tiles over NKS k-steps; the fifth - a ragged row
+// tile shared by four waves - for column tile rag_ct only
+struct W5 { const h8v* w[5]; };
+template <int NKS>
+__device__ __forceinline__ void prod5(const W5& W, h8v (&a)[2][5][2], const char* lds, int lane, int rag_ct, f4v (&acc)[4][4], f4v& accr) {
+#pragma unroll 1
+    for (int kp = 0; kp < (NKS + 1) / 2; ++kp) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ks = 2 * kp + e;
+            if (ks < NKS) {
+                if (ks + 1 < NKS) WLOAD_IN_LOOP(5, W.w, ks + 1, lane, a[1 - e]);
+                const int part = ks >= 9 ? 1 : 0, kk = BKK(ks >= 9 ? ks - 9 : ks);
+                h8v bh[4], bl[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bload1(lds, part, kk, ct, lane, bh[ct], bl[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m][ct] = mfma3(a[WSLOT(e)][m][0], a[WSLOT(e)][m][1], bh[ct], bl[ct], acc[m][ct]);
+                    if (ct == rag_ct) accr = mfma3(a[WSLOT(e)][4][0], a[WSLOT(e)][4][1], bh[ct], bl[ct], accr);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// three row tiles (the third for column tile rag_ct only; rag_ct < 0: none).  TRANS: the tile's fragments are the A operand, the
+// weights B - the accumulators hold rows = tokens 4 g + r of the column tile, column = channel j of the weight tile
+struct W3 { const h8v* w[3]; };
+template <int NKS, bool TRANS>
+__device__ __forceinline__ void prod3(const W3& W, h8v (&a)[2][3][2], const char* lds, int lane, int rag_ct, f4v (&o)[2][4], f4v& orr) {
+#pragma unroll 1
+    for (int kp = 0; kp < (NKS + 1) / 2; ++kp) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ks = 2 * kp + e;
+            if (ks < NKS) {
+                if (ks + 1 < NKS) WLOAD_IN_LOOP(3, W.w, ks + 1, lane, a[1 - e]);
+                const int part = ks >= 9 ? 1 : 0, kk = BKK(ks >= 9 ? ks - 9 : ks);
+                h8v bh[4], bl[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bload1(lds, part, kk, ct, lane, bh[ct], bl[ct]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const h8v xh = bh[ct], xl = bl[ct];
+                    if (TRANS) {
+                        o[0][ct] = mfma3(xh, xl, a[WSLOT(e)][0][0], a[WSLOT(e)][0][1], o[0][ct]);
+                        o[1][ct] = mfma3(xh, xl, a[WSLOT(e)][1][0], a[WSLOT(e)][1][1], o[1][ct]);
+                        if (ct == rag_ct) orr = mfma3(xh, xl, a[WSLOT(e)][2][0], a[WSLOT(e)][2][1], orr);
+                    } else {
+                        o[0][ct] = mfma3(a[WSLOT(e)][0][0], a[WSLOT(e)][0][1], xh, xl, o[0][ct]);
+                        o[1][ct] = mfma3(a[WSLOT(e)][1][0], a[WSLOT(e)][1][1], xh, xl, o[1][ct]);
+                        if (ct == rag_ct) orr = mfma3(a[WSLOT(e)][2][0], a[WSLOT(e)][2][1], xh, xl, orr);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+// a lane's four values (rows 4 g + r of its column, already x PRE) -> the 16-byte piece its lane pair shares: afterwards an even
+// row of 16 lanes holds the hi piece, an odd row the lo piece (see store_tf)
+__device__ __forceinline__ u4v make_piece(const f4v v) {
+    h4v hi, lo;
+    split4_pre(v, hi, lo);
+    const u2v H = __builtin_bit_cast(u2v, hi), Lo = __builtin_bit_cast(u2v, lo);
+    unsigned hx = H.x, hy = H.y, lx = Lo.x, ly = Lo.y;
+    lane_swap16(hx, lx);
+    lane_swap16(hy, ly);
+    return u4v{hx, hy, lx, ly};
+}
+// where that piece goes: row tile mt of the tile's operand half in LDS (column tile ct) ...
+__device__ __forceinline__ int lds_piece_off(int mt, int ct, int gq, int j) {
+    return mt < 16 ? (mt >> 1) * 8192 + (gq & 1) * 4096 + ct * 1024 + ((2 * (mt & 1) + (gq >> 1)) * 16 + j) * 16
+                   : 65536 + (gq & 1) * 1024 + ct * 256 + j * 16;
+}
+// ... and of a per-problem TF image (token tk)
+__device__ __forceinline__ int img_piece_off(int mt, int tk, int gq) {
+    return mt < 16 ? ((mt >> 1) * 2 + (gq & 1)) * TFB + img_tok_off(false, tk, 2 * (mt & 1) + (gq >> 1))
+                   : TF_MAIN + (gq & 1) * TFR + img_tok_off(true, tk, 0);
+}
+
+#ifdef PATS_DIAG
+#define TT(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_amdgcn_s_memrealtime(); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TT(k) do { } while (0)
+#endif
+
+template <bool MLP, bool QKV>
 __global__ void __launch_bounds__(512, 1)
-gnn_fine_layer_kernel(FineArgs g) {
+gnn_fine_tile_kernel(TileArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (g.gate && *g.gate == 0) return;
-    const int t = threadIdx.x, lane = t & 63, wave0 = __builtin_amdgcn_readfirstlane(t >> 6);
-    char* scr0 = g.scratch + (size_t)blockIdx.x * SC_BYTES;
-    bool bad = false, first = true;
-    const int lane0 = lane;
+    const int t_ = threadIdx.x, lane0 = t_ & 63, wave0 = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    int64_t L = g.half;
+    if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
+    const int64_t NQ = L * g.sets;                         // live problems: index qi -> problem (qi / L) * half + qi % L
+    const int64_t nF = 2 * NQ, nE = (NQ + 3) >> 2, nT = (NQ + 63) >> 6, ntile = nF + nE + nT;
+    bool bad = false;
+#ifdef PATS_DIAG
+    long long tsum[FT_N] = {0}, tlast = 0, nprob = 0;
+#endif
+    const float* pb = reinterpret_cast<const float*>(lds + L_PB);
+    const float* pbq = reinterpret_cast<const float*>(lds + L_PBQ);
+    if (MLP) for (int i = t_; i < FB_END; i += 512) reinterpret_cast<float*>(lds + L_PB)[i] = g.pb[i];
+    if (QKV) for (int i = t_; i < FB_1; i += 512) reinterpret_cast<float*>(lds + L_PBQ)[i] = g.pbq[i];
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        int lane = lane0, wave = wave0;
+        const h8v* pw = g.pw;
+        const h8v* pwq = g.pwq;
+        asm volatile("" : "+v"(lane), "+s"(wave), "+s"(pw), "+s"(pwq));       // (nothing hoisted out of the tile loop: see the attention kernel)
+        const int gq = lane >> 4, j = lane & 15;
+        const int cls = tile < nF ? 0 : tile < nF + nE ? 1 : 2;
+        // this lane's four columns (one per column tile): problem and token
+        int pidx[4], tok[4];
+        bool colok[4];
+        auto column = [&](int64_t tl, int ct, int& pi, int& tk, bool& ok) {
+            int64_t qi;
+            if (cls == 0) { qi = tl >> 1; tk = 64 * (int)(tl & 1) + 16 * ct + j; }
+            else if (cls == 1) { qi = 4 * (tl - nF) + ct; tk = 128 + j; }
+            else { qi = 64 * (tl - nF - nE) + 16 * ct + j; tk = 144; }
+            ok = qi < NQ;
+            if (qi >= NQ) qi = NQ - 1;
+            pi = (int)(qi < L ? qi : g.half + (qi - L));
+        };
+        // the column tile this wave gathers and owns the ragged unit of: w & 3 (computed, not selected out of the arrays above - a
+        // runtime index would put them in scratch memory)
+        const int myct = wave & 3;
+        int my_p, my_t;
+        bool my_ok;
+        auto remap = [&]() {
+            int64_t tl = tile;
+            asm volatile("" : "+s"(tl));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) column(tl, ct, pidx[ct], tok[ct], colok[ct]);
+            column(tl, myct, my_p, my_t, my_ok);
+        };
+        remap();
+#ifdef PATS_DIAG
+        tlast = __builtin_amdgcn_s_memrealtime();
+#endif
+        wg_barrier();                                      // the previous tile's fragments have been read
+        TT(12);
+        // ---- gather: 72 fragments per operand half, 9 (QKV alone) or 18 a wave ------------------------------------------------------
+#pragma unroll 2
+        for (int i = 0; i < (MLP ? 18 : 9); ++i) {
+            const int idx = wave + 8 * i, part = idx >= 72 ? 1 : 0, r = idx - 72 * part;
+            const char* img = part ? g.tf_att : g.tf_x;
+            // (fragment r = (k-step, plane, column tile r & 3): wave w's are all of column tile w & 3)
+            if (r < 64) {
+                const int ks = r >> 3, plane = (r >> 2) & 1;
+                const char* src = img + (int64_t)my_p * TF_BYTES + (2 * ks + plane) * TFB + img_tok_off(false, my_t, gq);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + ks * 8192 + plane * 4096 + myct * 1024), 16, 0, 0);
+            } else {
+                const int plane = (r - 64) >> 2;
+                const char* src = img + (int64_t)my_p * TF_BYTES + TF_MAIN + plane * TFR + img_tok_off(true, my_t, 0);
+                if (lane < 16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + 65536 + plane * 1024 + myct * 256), 16, 0, 0);
+            }
+        }
+        // the weight fragments of the tile's first k-step go out behind the gather (and every later product's before the epilogue
+        // in front of it)
+        const int rag_tile = wave < 4 ? 16 : 33;
+        W5 W0;
+        h8v a5[2][5][2];
+        if (MLP) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const int mt = m < 2 ? 2 * wave + m : m < 4 ? 17 + 2 * wave + (m - 2) : rag_tile;
+                W0.w[m] = (const h8v*)uniform_ptr(pw + FW_1 + (size_t)mt * 18 * FR);
+            }
+        } else {
+            W0.w[0] = (const h8v*)uniform_ptr(pwq + FW_Q + (size_t)(2 * wave) * 9 * FR);
+            W0.w[1] = (const h8v*)uniform_ptr(pwq + FW_Q + (size_t)(2 * wave + 1) * 9 * FR);
+            W0.w[2] = (const h8v*)uniform_ptr(pwq + FW_K + (size_t)(2 * wave) * 9 * FR);
+            W0.w[3] = (const h8v*)uniform_ptr(pwq + FW_K + (size_t)(2 * wave + 1) * 9 * FR);
+            W0.w[4] = (const h8v*)uniform_ptr(pwq + (wave < 4 ? FW_Q : FW_K) + (size_t)16 * 9 * FR);
+        }
+        wload<5>(W0.w, 0, lane, a5[0]);
+        TT(13);
+        wg_barrier_global();
+        TT(0);
+        h8v a3[2][3][2];
+        if (MLP) {
+            // ---- mlp[0]: row tiles 2 w, 2 w + 1 of both halves (FW_1 numbering: half 1 starts at tile 17) + one unit of a ragged tile ----
+            const int rag_ct = wave & 3;
+            f4v acc[4][4], accr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+            prod5<18>(W0, a5, lds, lane, rag_ct, acc, accr);
+            W3 W2;
+            W2.w[0] = (const h8v*)uniform_ptr(pw + FW_2 + (size_t)(2 * wave) * 18 * FR);
+            W2.w[1] = (const h8v*)uniform_ptr(pw + FW_2 + (size_t)(2 * wave + 1) * 18 * FR);
+            W2.w[2] = (const h8v*)uniform_ptr(pw + FW_2 + (size_t)16 * 18 * FR);
+            wload<3>(W2.w, 0, lane, a3[0]);
+            TT(1);
+            // ---- the residual of this wave's mlp[3] units, from the x fragments still in LDS: rows 16 mt + 4 g.. of its four columns ------
+            f4v res[2][4], resr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) res[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+            if (g.residual) {
+                auto rd = [&](int mt, int ct) {
+                    const char* bx = lds + lds_piece_off(mt, ct, 0, j) + (mt < 16 ? (gq >> 1) * 256 : 0) + (gq & 1) * 8;
+                    const int pl = mt < 16 ? 4096 : 1024;
+                    const h4v hi = *reinterpret_cast<const h4v*>(bx), lo = *reinterpret_cast<const h4v*>(bx + pl);
+                    return (__builtin_convertvector(hi, f4v) + __builtin_convertvector(lo, f4v)) * (1.0f / PRE);
+                };
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) res[m][ct] = rd(2 * wave + m, ct);
+                if (wave < 4 && gq < 2) resr = rd(16, wave);
+            }
+            TT(9);
+            wg_barrier();                                  // every wave is done with x | att: hidden takes their place
+            TT(10);
+            {
+                auto put = [&](int mtl, int hf, int ct, const f4v acc_, bool ragged) {
+                    const int ch = hf * 272 + 16 * mtl + 4 * gq;
+                    const f4v bias = load4(pb + FB_1 + ch), sc = load4(pb + FB_A + ch), sh = load4(pb + FB_S + ch);
+                    f4v v = fma4(acc_, sc * (UNS * PRE), (bias * sc + sh) * PRE);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];              // ReLU that keeps NaN
+                    const u4v piece = make_piece(v);
+                    if (!ragged || gq < 2) *reinterpret_cast<u4v*>(lds + hf * MT_HALF + lds_piece_off(mtl, ct, gq, j)) = piece;
+                };
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) put(2 * wave + (m & 1), m >> 1, ct, acc[m][ct], false);
+                put(16, wave >> 2, rag_ct, accr, true);
+            }
+            TT(11);
+            wg_barrier();
+            TT(2);
+            // ---- mlp[3]: row tiles 2 w, 2 w + 1 over the four column tiles + (waves 0..3) column tile w of the ragged 17th -------------
+            f4v o[2][4], orr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) o[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+            prod3<18, false>(W2, a3, lds, lane, wave < 4 ? wave : -1, o, orr);
+            if (QKV) {
+                W0.w[0] = (const h8v*)uniform_ptr(pwq + FW_Q + (size_t)(2 * wave) * 9 * FR);
+                W0.w[1] = (const h8v*)uniform_ptr(pwq + FW_Q + (size_t)(2 * wave + 1) * 9 * FR);
+                W0.w[2] = (const h8v*)uniform_ptr(pwq + FW_K + (size_t)(2 * wave) * 9 * FR);
+                W0.w[3] = (const h8v*)uniform_ptr(pwq + FW_K + (size_t)(2 * wave + 1) * 9 * FR);
+                W0.w[4] = (const h8v*)uniform_ptr(pwq + (wave < 4 ? FW_Q : FW_K) + (size_t)16 * 9 * FR);
+                wload<5>(W0.w, 0, lane, a5[0]);
+            }
+            TT(3);
+            if (QKV) wg_barrier();                         // every wave is done with the hidden fragments: the output tile takes their place
+            // ---- out = . + b2 + x -> the next layer's images (16-byte pieces, lane pairs exchange halves) [-> LDS: the QKV phase's operand] --
+            {
+                auto emit = [&](int mt, int ct, int cp, int ctk, bool cok, const f4v acc_, const f4v res_, bool mine) {
+                    const f4v bias = load4(pb + FB_2 + 16 * mt + 4 * gq);
+                    const f4v v = fma4(acc_, bcast4(UNS), bias) + res_;
+                    const bool ok = cok && mine && (mt < 16 || gq < 2);
+                    if (ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
+                    }
+                    const u4v piece = make_piece(v * PRE);
+                    char* d = g.tf_out + (int64_t)cp * TF_BYTES + img_piece_off(mt, ctk, gq);
+                    if (ok) *reinterpret_cast<u4v*>(d) = piece;
+                    if (QKV && mine && (mt < 16 || gq < 2)) *reinterpret_cast<u4v*>(lds + lds_piece_off(mt, ct, gq, j)) = piece;
+                };
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) emit(2 * wave + m, ct, pidx[ct], tok[ct], colok[ct], o[m][ct], res[m][ct], true);
+                emit(16, myct, my_p, my_t, my_ok, orr, resr, wave < 4);
+            }
+            if (QKV) wg_barrier();
+            TT(4);
+        }
+        if (QKV) {
+            // ---- q, k: row tiles 2 w, 2 w + 1 of each + one unit of a ragged tile (waves 0..3: q's, 4..7: k's) -------------------------------
+            W3 WV;
+            WV.w[0] = (const h8v*)uniform_ptr(pwq + FW_V + (size_t)(2 * wave) * 9 * FR);
+            WV.w[1] = (const h8v*)uniform_ptr(pwq + FW_V + (size_t)(2 * wave + 1) * 9 * FR);
+            WV.w[2] = (const h8v*)uniform_ptr(pwq + FW_V + (size_t)16 * 9 * FR);
+            {
+                const int rag_ct = wave & 3;
+                f4v acc[4][4], accr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+                prod5<9>(W0, a5, lds, lane, rag_ct, acc, accr);
+                wload<3>(WV.w, 0, lane, a3[0]);
+                TT(5);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int mt = 2 * wave + (m & 1);
+                    const f4v bias = load4(pbq + (m < 2 ? FB_Q : FB_K) + 16 * mt + 4 * gq) * PRE;
+                    const bool want = m < 2 ? g.want_q != 0 : g.want_kv != 0;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const u4v piece = make_piece(fma4(acc[m][ct], bcast4(UNS * PRE), bias));
+                        char* d = g.qkv + (int64_t)pidx[ct] * QKV_BYTES + (m < 2 ? QO_Q : QO_K) + img_piece_off(mt, tok[ct], gq);
+                        if (want && colok[ct]) *reinterpret_cast<u4v*>(d) = piece;
+                    }
+                }
+                // extras: rows 256 + 4 g + r = (head 2 g + (r >> 1), channel 64 + (r & 1)); k as the A operand (h0 h1 l0 l1 h0 h1 0 0),
+                // q as B (h0 h1 h0 h1 l0 l1 0 0): ONE more MFMA per key tile gives hi.hi + lo.hi + hi.lo of both channels
+                {
+                    const bool isq = wave < 4;
+                    const f4v bias = load4(pbq + (isq ? FB_Q : FB_K) + 256 + 4 * (gq & 1)) * PRE;
+                    h4v hi, lo;
+                    split4_pre(fma4(accr, bcast4(UNS * PRE), bias), hi, lo);
+                    char* d = g.qkv + (int64_t)my_p * QKV_BYTES + (isq ? QO_QX : QO_KX) + ((2 * gq) * FN + my_t) * 16;
+                    if ((isq ? g.want_q != 0 : g.want_kv != 0) && my_ok && gq < 2) {
+                        if (isq) {
+                            *reinterpret_cast<h8v*>(d) = h8v{hi.x, hi.y, hi.x, hi.y, lo.x, lo.y, 0, 0};
+                            *reinterpret_cast<h8v*>(d + FN * 16) = h8v{hi.z, hi.w, hi.z, hi.w, lo.z, lo.w, 0, 0};
+                        } else {
+                            *reinterpret_cast<h8v*>(d) = h8v{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y, 0, 0};
+                            *reinterpret_cast<h8v*>(d + FN * 16) = h8v{hi.z, hi.w, lo.z, lo.w, hi.z, hi.w, 0, 0};
+                        }
+                    }
+                }
+                TT(6);
+            }
+            // ---- v^T: channel tiles 2 w, 2 w + 1 (+ the ragged 17th for column tile w, waves 0..3); rows = the column tile's tokens ------
+            {
+                f4v o[2][4], orr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) o[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+                prod3<9, true>(WV, a3, lds, lane, wave < 4 ? wave : -1, o, orr);
+                TT(7);
+                if (g.want_kv) {
+                    // A fragment (channel tile mt, key pair tile kk) of a problem: lane (g, j = channel) holds keys 32 kk + 4 g + r (first
+                    // half) and 32 kk + 16 + 4 g + r (second half), hi at +0, lo at +1024
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        if (m == 2 && wave >= 4) break;
+                        const int mt = m < 2 ? 2 * wave + m : 16;
+                        const f4v bias = bcast4(pbq[FB_V + 16 * mt + j] * PRE);
+                        if (cls == 0) {
+                            char* vb = g.qkv + (int64_t)pidx[0] * QKV_BYTES + QO_V + mt * V_TILE + lane * 16;
+                            if (m < 2) {
+#pragma unroll
+                                for (int pp = 0; pp < 2; ++pp) {
+                                    h4v ah, al, bh, bl;
+                                    split4_pre(fma4(o[m][2 * pp], bcast4(UNS * PRE), bias), ah, al);
+                                    split4_pre(fma4(o[m][2 * pp + 1], bcast4(UNS * PRE), bias), bh, bl);
+                                    char* d = vb + (2 * (int)(tile & 1) + pp) * 2048;
+                                    if (colok[0]) {
+                                        *reinterpret_cast<h8v*>(d) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
+                                        *reinterpret_cast<h8v*>(d + 1024) = h8v{al.x, al.y, al.z, al.w, bl.x, bl.y, bl.z, bl.w};
+                                    }
+                                }
+                            } else {                           // the ragged unit's pair partner is another wave's: 8-byte halves
+                                h4v ah, al;
+                                split4_pre(fma4(orr, bcast4(UNS * PRE), bias), ah, al);
+                                char* d = vb + (2 * (int)(tile & 1) + (wave >> 1)) * 2048 + (wave & 1) * 8;
+                                if (colok[0]) {
+                                    *reinterpret_cast<h4v*>(d) = ah;
+                                    *reinterpret_cast<h4v*>(d + 1024) = al;
+                                }
+                            }
+                        } else if (cls == 1) {                 // token tile 8 = first half of key pair tile 4; its second half is token 144 (class T)
+#pragma unroll                                                 // and zeros: lanes g > 0 write them, lane group 0 leaves its second half to class T
+                            for (int ct = 0; ct < 4; ++ct) {
+                                if (m == 2 && ct != wave) continue;
+                                h4v ah, al;
+                                split4_pre(fma4(m < 2 ? o[m < 2 ? m : 0][ct] : orr, bcast4(UNS * PRE), bias), ah, al);
+                                char* d = g.qkv + (int64_t)pidx[ct] * QKV_BYTES + QO_V + mt * V_TILE + 4 * 2048 + lane * 16;
+                                if (colok[ct]) {
+                                    if (gq == 0) {
+                                        *reinterpret_cast<h4v*>(d) = ah;
+                                        *reinterpret_cast<h4v*>(d + 1024) = al;
+                                    } else {
+                                        *reinterpret_cast<h8v*>(d) = h8v{ah.x, ah.y, ah.z, ah.w, 0, 0, 0, 0};
+                                        *reinterpret_cast<h8v*>(d + 1024) = h8v{al.x, al.y, al.z, al.w, 0, 0, 0, 0};
+                                    }
+                                }
+                            }
+                        } else {                               // token 144 of problems 64 n + 16 ct + 4 g + r: (key 144, 0, 0, 0) of lane (0, j)
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) {
+                                if (m == 2 && ct != wave) continue;
+                                h4v ah, al;
+                                split4_pre(fma4(m < 2 ? o[m < 2 ? m : 0][ct] : orr, bcast4(UNS * PRE), bias), ah, al);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int64_t qi = 64 * (tile - nF - nE) + 16 * ct + 4 * gq + r;
+                                    const int64_t pr = qi < L ? qi : g.half + (qi - L);
+                                    char* d = g.qkv + pr * QKV_BYTES + QO_V + mt * V_TILE + 4 * 2048 + j * 16 + 8;
+                                    if (qi < NQ) {
+                                        *reinterpret_cast<h4v*>(d) = h4v{ah[r], 0, 0, 0};
+                                        *reinterpret_cast<h4v*>(d + 1024) = h4v{al[r], 0, 0, 0};
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                TT(8);
+            }
+        }
+#ifdef PATS_DIAG
+        ++nprob;
+#endif
+    }
+    if (bad) atomicOr(g.flag, 1);
+#ifdef PATS_DIAG
+    if (g.tl && t_ == 0) {
+        for (int k = 0; k < FT_N - 1; ++k) g.tl[(size_t)blockIdx.x * FT_N + k] = tsum[k];
+        g.tl[(size_t)blockIdx.x * FT_N + FT_N - 1] = nprob;
+    }
+#endif
+}
+
+// ---- the attention core per problem ------------------------------------------------------------------------------------------------
+// One persistent 512-thread workgroup per CU owns a problem at a time: K_h (double-buffered) and V_h are DMA'd into LDS per head from
+// the problem's block of projections (source problem (p + shift) % P), the queries are read from global memory as B fragments.
+// Unit = (head, 16-query tile): S^T = K^T Q with the keys as rows (softmax in-lane + two exchanges); the accumulators of key tiles
+// 2 kk, 2 kk + 1 ARE the B operand of out^T = V P^T.  The output leaves as a TF image in the folded mlp[0]'s channel order.
+// The next problem's first head is fetched under the last head of the current one.
+struct AttnArgs {
+    const char* qkv; char* tf_att;
+    int64_t P, shift;
+    const int* gate;
+    const int64_t* live; int64_t live_off, half;
+    int sets, stagger;
+#ifdef PATS_DIAG
+    long long* tl;
+#endif
+};
+constexpr int ATT_LDS = L_ATT_END + V_TILE;            // + a second extras tile of v (the next problem's lands while this one's is read)
+
+__global__ void __launch_bounds__(512, 1)
+gnn_fine_attn_kernel(AttnArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (g.gate && *g.gate == 0) return;
+    const int t = threadIdx.x, lane0 = t & 63, wave0 = __builtin_amdgcn_readfirstlane(t >> 6);
     for (int i = (int)(blockIdx.x >> 3 & 31) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);       // ~1 us a step
 #ifdef PATS_DIAG
     long long tsum[FT_N] = {0}, tlast = 0, nprob = 0;
@@ -433,151 +819,64 @@ gnn_fine_layer_kernel(FineArgs g) {
     int64_t L = g.half;                                   // live rows per descriptor set
     if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
     const int64_t NQ = L * g.sets;                         // live problems: q -> problem (q / L) * half + q % L
+    auto kv_block = [&](int64_t q_) {
+        int64_t ps = (q_ < L ? q_ : g.half + (q_ - L)) + g.shift;
+        if (ps >= g.P) ps -= g.P;
+        return g.qkv + ps * QKV_BYTES;
+    };
+    bool first = true;
+    int vxsel = 0;
     for (int64_t q_ = blockIdx.x; q_ < NQ; q_ += gridDim.x) {
         const int64_t p = q_ < L ? q_ : g.half + (q_ - L);
-        // Everything the epilogues address is invariant over the problem loop (the scratch block, the lane's offsets in a TF image):
-        // left alone the compiler hoists several hundred store addresses and fragment bases out of the loop and spills the
-        // accumulators around them (672 spilled VGPRs in the first build).  An opaque copy of the lane index per problem ...
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        // ... and of the uniform bases (weights, biases, scratch): hoisted out of the problem loop, the fragment addresses of nine
-        // products alone are several hundred SGPRs
-        const h8v* pw = g.pw;
-        const float* pb = g.pb;
-        char* scr = scr0;
-        int wave = wave0;
-        asm volatile("" : "+s"(pw), "+s"(pb), "+s"(scr), "+s"(wave));
-        // ragged-tile units of this wave: plain products - token tiles w and (waves 0, 1) w + 8; v^T - token tiles 2 w, 2 w + 1 (waves 0..4)
-        const int rt0 = wave, rt1 = wave < 2 ? wave + 8 : -1;
-        const int vt0 = wave < 5 ? 2 * wave : -1, vt1 = wave < 5 ? 2 * wave + 1 : -1;
+        // Everything the epilogues address is invariant over the problem loop: left alone the compiler hoists the store addresses and
+        // fragment bases out of it and spills the accumulators around them.  An opaque copy of the lane index per problem.
+        int lane = lane0, wave = wave0;
+        asm volatile("" : "+v"(lane), "+s"(wave));
         const int gq = lane >> 4, j = lane & 15;
         const LaneOff lo_ = lane_offsets(lane);
-        const char* img_x = g.tf_x + p * TF_BYTES;
-        int64_t ps = p + g.shift;
-        if (ps >= g.P) ps -= g.P;
-        const char* img_s = g.tf_s + ps * TF_BYTES;
-        f4v acc[2][FNT], accr[2];
+        const char* qb = g.qkv + p * QKV_BYTES;
+        const char* kvb = kv_block(q_);
+        const bool has_next = q_ + gridDim.x < NQ;
+        const char* kvn = has_next ? kv_block(q_ + gridDim.x) : kvb;
+        char* att_dst = g.tf_att + p * TF_BYTES;
 #ifdef PATS_DIAG
         tlast = __builtin_amdgcn_s_memrealtime();
 #endif
-        // ================= source -> k (TF image + packed extras), v^T (A fragments of the second attention product) =================
-        if (first) dma_fill<TF_BYTES>(lds, img_s, wave, lane);      // (later problems: started under the previous output epilogue)
+        if (first) {
+            dma_fill<4 * TFB>(lds + L_KA, kvb + QO_K, wave, lane);
+            dma_fill<FN * 16>(lds + L_KA + 4 * TFB, kvb + QO_KX, wave, lane);
+            dma_fill<4 * V_TILE>(lds + L_V, kvb + QO_V, wave, lane);
+            dma_fill<V_TILE>(lds + L_VX, kvb + QO_V + 16 * V_TILE, wave, lane);
+        }
         first = false;
-        wg_barrier_global();
-        FT(0);
-        zero_acc(acc, accr);
-        conv_pass<false, 9>(pw + FW_K, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(1);
-        {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f4v bias = load4(pb + FB_K + 16 * (2 * wave + m) + 4 * gq) * PRE;
-#pragma unroll
-                for (int tt = 0; tt < FNT; ++tt) store_tf(scr + SC_K, 2 * wave + m, tt, fma4(acc[m][tt], bcast4(UNS * PRE), bias), lane, lo_);
-            }
-            // extras: rows 256 + 4 g + r = (head 2 g + (r >> 1), channel 64 + (r & 1)); A packing (h0 h1 l0 l1 h0 h1 0 0)
-            const f4v bias = load4(pb + FB_K + 256 + 4 * (gq & 1)) * PRE;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int tt = u == 0 ? rt0 : rt1;
-                if (tt >= 0 && gq < 2 && (tt < 9 || j == 0)) {
-                    h4v hi, lo;
-                    split4_pre(fma4(accr[u], bcast4(UNS * PRE), bias), hi, lo);
-                    char* d = scr + SC_KX + ((2 * gq) * FN + 16 * tt + j) * 16;
-                    *reinterpret_cast<h8v*>(d) = h8v{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y, 0, 0};
-                    *reinterpret_cast<h8v*>(d + FN * 16) = h8v{hi.z, hi.w, lo.z, lo.w, hi.z, hi.w, 0, 0};
-                }
-            }
-        }
-        FT(2);
-        zero_acc(acc, accr);
-        conv_pass<true, 9>(pw + FW_V, 0, 0, lds, wave, lane, acc, accr, vt0, vt1);
-        FT(3);
-        wg_barrier();                                      // the source image has been read: x lands under the epilogue
-        dma_fill<TF_BYTES>(lds, img_x, wave, lane);
-        {
-            // rows = tokens 16 t + 4 g + r, column = channel 16 mt + j: key slots (g, e) of k-step kk = token tiles 2 kk (e < 4), 2 kk + 1
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                if (m == 2 && wave >= 5) break;
-                const int mt = m < 2 ? 2 * wave + m : 16;
-                const float bias = pb[FB_V + 16 * mt + j] * PRE;
-#pragma unroll
-                for (int kk = 0; kk < 5; ++kk) {
-                    if (m == 2 && kk != wave) continue;
-                    f4v a = fma4(m < 2 ? acc[m][2 * kk] : accr[0], bcast4(UNS * PRE), bcast4(bias));
-                    f4v b = fma4(m < 2 ? acc[m][2 * kk + 1] : accr[1], bcast4(UNS * PRE), bcast4(bias));
-                    if (kk == 4) {                        // token tile 9 holds token 144 alone; key slots past it must be exact zeros
-                        b.y = 0.f; b.z = 0.f; b.w = 0.f;
-                        if (gq != 0) b.x = 0.f;
-                    }
-                    h4v ah, al, bh, bl;
-                    split4_pre(a, ah, al);
-                    split4_pre(b, bh, bl);
-                    char* d = scr + SC_V + (mt * 5 + kk) * 2048 + lane * 16;
-                    *reinterpret_cast<h8v*>(d) = h8v{ah.x, ah.y, ah.z, ah.w, bh.x, bh.y, bh.z, bh.w};
-                    *reinterpret_cast<h8v*>(d + 1024) = h8v{al.x, al.y, al.z, al.w, bl.x, bl.y, bl.z, bl.w};
-                }
-            }
-        }
-        FT(4);
-        // ================= x -> q (TF image + packed extras, B packing (h0 h1 h0 h1 l0 l1 0 0)) ======================================
-        wg_barrier_global();
-        FT(5);
-        zero_acc(acc, accr);
-        conv_pass<false, 9>(pw + FW_Q, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(6);
-        wg_barrier();                                      // the x image has been read: k_0, v_0 and the extras tile land under the epilogue
-        dma_fill<4 * TFB>(lds + L_KA, scr + SC_K, wave, lane);       // (k and v have been in the scratch block since the barriers above)
-        dma_fill<FN * 16>(lds + L_KA + 4 * TFB, scr + SC_KX, wave, lane);
-        dma_fill<4 * V_TILE>(lds + L_V, scr + SC_V, wave, lane);
-        dma_fill<V_TILE>(lds + L_VX, scr + SC_V + 16 * V_TILE, wave, lane);
-        {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f4v bias = load4(pb + FB_Q + 16 * (2 * wave + m) + 4 * gq) * PRE;
-#pragma unroll
-                for (int tt = 0; tt < FNT; ++tt) store_tf(scr + SC_Q, 2 * wave + m, tt, fma4(acc[m][tt], bcast4(UNS * PRE), bias), lane, lo_);
-            }
-            const f4v bias = load4(pb + FB_Q + 256 + 4 * (gq & 1)) * PRE;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int tt = u == 0 ? rt0 : rt1;
-                if (tt >= 0 && gq < 2 && (tt < 9 || j == 0)) {
-                    h4v hi, lo;
-                    split4_pre(fma4(accr[u], bcast4(UNS * PRE), bias), hi, lo);
-                    char* d = scr + SC_QX + ((2 * gq) * FN + 16 * tt + j) * 16;
-                    *reinterpret_cast<h8v*>(d) = h8v{hi.x, hi.y, hi.x, hi.y, lo.x, lo.y, 0, 0};
-                    *reinterpret_cast<h8v*>(d + FN * 16) = h8v{hi.z, hi.w, hi.z, hi.w, lo.z, lo.w, 0, 0};
-                }
-            }
-        }
-        FT(7);
-        wg_barrier_global();                               // q, k, v are in the scratch block; the x image has been read
-        FT(8);
-        // ================= attention: unit = (head, 16-query tile); its output replaces its own q tile ===============================
+        const char* vx = lds + L_VX + vxsel * (L_ATT_END - L_VX);      // this problem's extras tile of v: slot 0 or the one behind the staging area
         // this wave's queries of a unit: B operand, two k-steps + the packed extras (every lane reads the piece of its query; lanes
-        // k / 8 > 0 then take zeros).  Loaded one unit AHEAD: the scratch block is an L2 / Infinity-Cache round trip away.
+        // k / 8 > 0 then take zeros).  Loaded one unit AHEAD: the block is an L2 / Infinity-Cache round trip away.
         struct QF { h8v h0, l0, h1, l1, x; };
         auto qload = [&](int h, int qt, QF& q) {
             const int qoff = tf_off(false, qt, lane);
             const int qtok = qt < 9 ? 16 * qt + j : 144;
-            q.h0 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h, 0) + qoff);
-            q.l0 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h, 1) + qoff);
-            q.h1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 0) + qoff);
-            q.l1 = *reinterpret_cast<const h8v*>(scr + SC_Q + tf_blk(2 * h + 1, 1) + qoff);
-            q.x = *reinterpret_cast<const h8v*>(scr + SC_QX + (h * FN + qtok) * 16);
+            q.h0 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h, 0) + qoff);
+            q.l0 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h, 1) + qoff);
+            q.h1 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h + 1, 0) + qoff);
+            q.l1 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h + 1, 1) + qoff);
+            q.x = *reinterpret_cast<const h8v*>(qb + QO_QX + (h * FN + qtok) * 16);
         };
-        char* att_dst = FULL ? scr + SC_Q : g.tf_att + p * TF_BYTES;
         QF q;
         qload(0, wave, q);
         for (int h = 0; h < 4; ++h) {
             wg_barrier_global();                           // k_h, v_h (and the extras tile) have landed
             FT(9);
-            if (h < 3) {
+            {
                 char* kn = lds + L_KA + ((h + 1) & 1) * KH_BYTES;
-                dma_fill<4 * TFB>(kn, scr + SC_K + (h + 1) * 4 * TFB, wave, lane);
-                dma_fill<FN * 16>(kn + 4 * TFB, scr + SC_KX + (h + 1) * FN * 16, wave, lane);
+                if (h < 3) {
+                    dma_fill<4 * TFB>(kn, kvb + QO_K + (h + 1) * 4 * TFB, wave, lane);
+                    dma_fill<FN * 16>(kn + 4 * TFB, kvb + QO_KX + (h + 1) * FN * 16, wave, lane);
+                } else if (has_next) {
+                    dma_fill<4 * TFB>(kn, kvn + QO_K, wave, lane);
+                    dma_fill<FN * 16>(kn + 4 * TFB, kvn + QO_KX, wave, lane);
+                    dma_fill<V_TILE>(lds + L_VX + (1 - vxsel) * (L_ATT_END - L_VX), kvn + QO_V + 16 * V_TILE, wave, lane);
+                }
             }
             const char* kb = lds + L_KA + (h & 1) * KH_BYTES;
             for (int qt = wave; qt < FNT; qt += 8) {
@@ -644,7 +943,7 @@ gnn_fine_layer_kernel(FineArgs g) {
                 const float osc = UNS * PRE * inv;
                 h8v vf[2][5][2];
                 auto vload = [&](int dt, h8v (&v)[5][2]) {
-                    const char* vb = dt < 4 ? lds + L_V + dt * V_TILE : lds + L_VX;
+                    const char* vb = dt < 4 ? lds + L_V + dt * V_TILE : vx;
 #pragma unroll
                     for (int kk = 0; kk < 5; ++kk) {
                         v[kk][0] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + lane * 16);
@@ -674,385 +973,22 @@ gnn_fine_layer_kernel(FineArgs g) {
                 }
             }
             FT(10);
-            if (h < 3) {
-                wg_barrier();                              // every wave is done with v_h
-                FT(11);
-                dma_fill<4 * V_TILE>(lds + L_V, scr + SC_V + (h + 1) * 4 * V_TILE, wave, lane);
-            }
+            wg_barrier();                                  // every wave is done with v_h
+            FT(11);
+            if (h < 3) dma_fill<4 * V_TILE>(lds + L_V, kvb + QO_V + (h + 1) * 4 * V_TILE, wave, lane);
+            else if (has_next) dma_fill<4 * V_TILE>(lds + L_V, kvn + QO_V, wave, lane);
         }
-        wg_barrier_global();                               // the attention output is in the scratch block; the staging area is free
-        FT(11);
-        if (!FULL) {                                       // the MLP is gnn_fine_mlp_kernel's: next problem (its source lands now)
-            if (q_ + gridDim.x < NQ) {
-                const int64_t qn = q_ + gridDim.x;
-                int64_t pn = (qn < L ? qn : g.half + (qn - L)) + g.shift;
-                if (pn >= g.P) pn -= g.P;
-                dma_fill<TF_BYTES>(lds, g.tf_s + pn * TF_BYTES, wave, lane);
-            }
-#ifdef PATS_DIAG
-            ++nprob;
-#endif
-            continue;
-        }
-        // ================= hidden = relu(bn(W1x x + W1a att + b1')): two halves of 264 rows =========================================
-        dma_fill<TF_BYTES>(lds, scr + SC_Q, wave, lane);   // att
-        wg_barrier_global();
-        FT(12);
-        zero_acc(acc, accr);
-        conv_pass<false, 18>(pw + FW_1, 0, 9, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(13);
-        wg_barrier();
-        dma_fill<TF_BYTES>(lds, img_x, wave, lane);
-        wg_barrier_global();
-        FT(14);
-        conv_pass<false, 18>(pw + FW_1, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(15);
-        auto hidden_out = [&](const f4v (&a)[2][FNT], const f4v (&ar)[2], int hf, char* dst) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int mt = m < 2 ? 2 * wave + m : 16, ch = hf * 272 + 16 * mt + 4 * gq;
-                const f4v bias = load4(pb + FB_1 + ch), sc = load4(pb + FB_A + ch), sh = load4(pb + FB_S + ch);
-                const f4v scl = sc * (UNS * PRE), shf = (bias * sc + sh) * PRE;
-#pragma unroll
-                for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
-                    const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
-                    if (tok_t < 0) continue;
-                    f4v v = fma4(m < 2 ? a[m][tt] : ar[tt], scl, shf);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];            // ReLU that keeps NaN
-                    store_tf(dst, mt, tok_t, v, lane, lo_);
-                }
-            }
-        };
-        hidden_out(acc, accr, 0, scr + SC_K);
-        FT(16);
-        zero_acc(acc, accr);
-        conv_pass<false, 18>(pw + FW_1, 17, 0, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(15);
-        wg_barrier();
-        dma_fill<TF_BYTES>(lds, scr + SC_Q, wave, lane);   // att again
-        wg_barrier_global();
-        FT(12);
-        conv_pass<false, 18>(pw + FW_1, 17, 9, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(13);
-        wg_barrier();                                      // att has been read: hidden[264:528] goes from the accumulators straight into the slot
-        hidden_out(acc, accr, 1, lds);
-        FT(16);
-        wg_barrier();
-        // ================= out = W2 hidden + b2 [+ residual] -> fp32 blocked + TF image ==============================================
-        zero_acc(acc, accr);
-        conv_pass<false, 18>(pw + FW_2, 0, 9, lds, wave, lane, acc, accr, rt0, rt1);      // the second half of the channels first
-        FT(18);
-        wg_barrier();
-        dma_fill<TF_BYTES>(lds, scr + SC_K, wave, lane);   // hidden[0:264] (in the scratch block since the barriers behind its epilogue)
-        wg_barrier_global();
-        FT(17);
-        conv_pass<false, 18>(pw + FW_2, 0, 0, lds, wave, lane, acc, accr, rt0, rt1);
-        FT(18);
-        wg_barrier();                                      // the slot is free: the next problem's source lands under the output epilogue
-        if (q_ + gridDim.x < NQ) {
-            const int64_t qn = q_ + gridDim.x;
-            int64_t pn = (qn < L ? qn : g.half + (qn - L)) + g.shift;
-            if (pn >= g.P) pn -= g.P;
-            dma_fill<TF_BYTES>(lds, g.tf_s + pn * TF_BYTES, wave, lane);
-        }
-        {
-            const char* R = g.tf_res ? g.tf_res + p * TF_BYTES : nullptr;
-            char* TO = g.tf_out + p * TF_BYTES;
-            // per row tile: its ten residual pieces in one batch (a load -> add -> store chain per piece would pay a memory round trip
-            // each; all 22 at once is 88 more registers beside the accumulators - the allocator then spills, and a spill reload waits
-            // for every store issued before it).  The residual comes from the descriptor's IMAGE - lines the fills of this problem
-            // just read - and is exact to the 22 bits an image holds.
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int mt = m < 2 ? 2 * wave + m : 16, ch = 16 * mt + 4 * gq;
-                const f4v bias = load4(pb + FB_2 + ch);
-                const bool rows_ok = mt < 16 || gq < 2;
-                u4v_t res[FNT];
-                if (R) {
-#pragma unroll
-                    for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
-                        const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
-                        res[tt] = u4v_t{0u, 0u, 0u, 0u};
-                        if (tok_t >= 0) res[tt] = load_tf_piece(R, mt, tok_t, lane, lo_);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tt = 0; tt < (m < 2 ? FNT : 2); ++tt) {
-                    const int tok_t = m < 2 ? tt : (tt == 0 ? rt0 : rt1);
-                    if (tok_t < 0) continue;
-                    const bool live = rows_ok && !(tok_t == 9 && j != 0);
-                    f4v v = fma4(m < 2 ? acc[m][tt] : accr[tt], bcast4(UNS), bias);
-                    if (R) v = tf_piece_value(res[tt]) + v;                  // (every lane: the pieces are paired across lanes)
-                    if (live) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
-                    }
-                    store_tf(TO, mt, tok_t, v * PRE, lane, lo_);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        FT(19);
+        vxsel = 1 - vxsel;
 #ifdef PATS_DIAG
         ++nprob;
 #endif
     }
-    if (bad) atomicOr(g.flag, 1);
 #ifdef PATS_DIAG
     if (g.tl && t == 0) {
         for (int k = 0; k < FT_N - 1; ++k) g.tl[(size_t)blockIdx.x * FT_N + k] = tsum[k];
         g.tl[(size_t)blockIdx.x * FT_N + FT_N - 1] = nprob;
     }
 #endif
-}
-
-// ---- the MLP half of the layer on FLATTENED column tiles ------------------------------------------------------------------------
-// hidden = relu(bn(W1x x + W1a att + b1')), out = W2 hidden + b2 + x are per-token: a workgroup takes 64 columns of the flattened
-// (problem, token) axis - no token padding (145 = 9 x 16 + 1 costs the per-problem kernel 10 %), and x-tile + att-tile (2 x 66 KB as
-// fragments) sit in LDS TOGETHER, so mlp[0] is one 18-k-step loop whose 528 x 64 output lives in the accumulators (17 tile units a
-// wave), is written - BatchNorm, ReLU, split - over the operands it came from, and feeds mlp[3] from there: the hidden tensor never
-// leaves the CU and x / att are read once.  The residual is rebuilt from the x fragments in LDS before they are overwritten.
-// Operands arrive by gather DMA from the per-problem TF images (a lane's source address is its column's; the 64 pieces of a
-// fragment land contiguously), the output leaves as 16-byte pieces scattered into the per-problem images of the next layer.
-constexpr int MT_HALF = 8 * 8192 + 2 * 1024;          // one operand half-tile: eight full k-steps [plane][4 column tiles][64 x 16 B] + the ragged one
-constexpr int MLP_LDS = 2 * MT_HALF;                  // 135 168
-
-struct MlpArgs {
-    const char* tf_x; const char* tf_att; char* tf_out;
-    const h8v* pw; const float* pb;
-    int64_t P, half; int sets;
-    const int64_t* live; int64_t live_off;
-    int* flag;
-    int residual;              // add x (AttentionalGNN.forward's desc + delta); 0: the delta alone
-    const int* gate;
-};
-
-// byte offset of token t's 16-byte piece (k-group kq) inside a (k-step, plane) block of a per-problem image
-__device__ __forceinline__ int img_tok_off(bool ragged, int t, int kq) {
-    if (!ragged) return t < 144 ? (t >> 4) * 1024 + kq * 256 + (t & 15) * 16 : 9216 + kq * 16;
-    return t < 144 ? (t >> 4) * 256 + (t & 15) * 16 : 2304;
-}
-
-__global__ void __launch_bounds__(512, 1)
-gnn_fine_mlp_kernel(MlpArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (g.gate && *g.gate == 0) return;
-    const int t_ = threadIdx.x, lane0 = t_ & 63, wave0 = __builtin_amdgcn_readfirstlane(t_ >> 6);
-    int64_t L = g.half;
-    if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
-    const int64_t ncol = L * g.sets * FN, ntile = (ncol + 63) >> 6;
-    bool bad = false;
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        int lane = lane0, wave = wave0;
-        const h8v* pw = g.pw;
-        const float* pb = g.pb;
-        asm volatile("" : "+v"(lane), "+s"(wave), "+s"(pw), "+s"(pb));       // (as in the layer kernel: nothing hoisted out of the tile loop)
-        const int gq = lane >> 4, j = lane & 15;
-        // this lane's four columns (one per column tile): problem image and token
-        int64_t pbase[4];
-        int tok[4];
-        bool colok[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            int64_t c = tile * 64 + ct * 16 + j;
-            colok[ct] = c < ncol;
-            if (c >= ncol) c = ncol - 1;
-            const int64_t q = c / FN;
-            tok[ct] = (int)(c - q * FN);
-            pbase[ct] = (q < L ? q : g.half + (q - L)) * (int64_t)TF_BYTES;
-        }
-        wg_barrier();                                      // the previous tile's hidden fragments have been read
-        // ---- gather: 2 x 72 fragments, 18 a wave ------------------------------------------------------------------------------------
-#pragma unroll 2
-        for (int i = 0; i < 18; ++i) {
-            const int idx = wave + 8 * i, part = idx >= 72 ? 1 : 0, r = idx - 72 * part;
-            const char* img = part ? g.tf_att : g.tf_x;
-            if (r < 64) {
-                const int ks = r >> 3, plane = (r >> 2) & 1, ct = r & 3;
-                const int64_t pbc = ct == 0 ? pbase[0] : ct == 1 ? pbase[1] : ct == 2 ? pbase[2] : pbase[3];
-                const int tk = ct == 0 ? tok[0] : ct == 1 ? tok[1] : ct == 2 ? tok[2] : tok[3];
-                const char* src = img + pbc + (2 * ks + plane) * TFB + img_tok_off(false, tk, gq);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + ks * 8192 + plane * 4096 + ct * 1024), 16, 0, 0);
-            } else {
-                const int rr = r - 64, plane = rr >> 2, ct = rr & 3;
-                const int64_t pbc = ct == 0 ? pbase[0] : ct == 1 ? pbase[1] : ct == 2 ? pbase[2] : pbase[3];
-                const int tk = ct == 0 ? tok[0] : ct == 1 ? tok[1] : ct == 2 ? tok[2] : tok[3];
-                const char* src = img + pbc + TF_MAIN + plane * TFR + img_tok_off(true, tk, 0);
-                if (lane < 16)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + 65536 + plane * 1024 + ct * 256), 16, 0, 0);
-            }
-        }
-        wg_barrier_global();
-        // B fragments of k-step kk (0..8; 8 = ragged) of operand half `part`
-        auto bload = [&](int part, int kk, h8v (&bh)[4], h8v (&bl)[4]) {
-            const char* base = lds + part * MT_HALF;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                if (kk < 8) {
-                    bh[ct] = *reinterpret_cast<const h8v*>(base + kk * 8192 + ct * 1024 + lane * 16);
-                    bl[ct] = *reinterpret_cast<const h8v*>(base + kk * 8192 + 4096 + ct * 1024 + lane * 16);
-                } else {
-                    const h8v a = *reinterpret_cast<const h8v*>(base + 65536 + ct * 256 + j * 16);
-                    const h8v b = *reinterpret_cast<const h8v*>(base + 65536 + 1024 + ct * 256 + j * 16);
-                    bh[ct] = lane < 16 ? a : zero8();
-                    bl[ct] = lane < 16 ? b : zero8();
-                }
-            }
-        };
-        // ---- mlp[0]: row tiles 2 w, 2 w + 1 of both halves (FW_1 numbering: half 1 starts at tile 17) + one unit of a ragged tile -------
-        const int rag_tile = wave < 4 ? 16 : 33, rag_ct = wave & 3;
-        f4v acc[4][4], accr = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-        {
-            h8v a[2][5][2];
-            auto aload5 = [&](int ks, h8v (&r)[5][2]) {
-#pragma unroll
-                for (int m = 0; m < 5; ++m) {
-                    const int mt = m < 2 ? 2 * wave + m : m < 4 ? 17 + 2 * wave + (m - 2) : rag_tile;
-                    gptr_h8 Wf = uniform_ptr(pw + FW_1 + ((size_t)mt * 18 + ks) * FR);
-                    r[m][0] = Wf[lane];
-                    r[m][1] = Wf[64 + lane];
-                }
-            };
-            aload5(0, a[0]);
-#pragma unroll 1
-            for (int kp = 0; kp < 9; ++kp) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int ks = 2 * kp + e;
-                    if (ks + 1 < 18) aload5(ks + 1, a[1 - e]);
-                    h8v bh[4], bl[4];
-                    bload(ks >= 9 ? 1 : 0, ks >= 9 ? ks - 9 : ks, bh, bl);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) acc[m][ct] = mfma3(a[e][m][0], a[e][m][1], bh[ct], bl[ct], acc[m][ct]);
-                        if (ct == rag_ct) accr = mfma3(a[e][4][0], a[e][4][1], bh[ct], bl[ct], accr);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // ---- the residual of this wave's mlp[3] units, from the x fragments still in LDS: rows 16 mt + 4 g.. of its four columns ---------
-        f4v res[2][4], resr = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) res[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-        if (g.residual) {
-            auto rd = [&](int mt, int ct) {
-                const char* bx = mt < 16 ? lds + (mt >> 1) * 8192 + ct * 1024 + ((2 * (mt & 1) + (gq >> 1)) * 16 + j) * 16 + (gq & 1) * 8
-                                         : lds + 65536 + ct * 256 + j * 16 + (gq & 1) * 8;
-                const int pl = mt < 16 ? 4096 : 1024;
-                const h4v hi = *reinterpret_cast<const h4v*>(bx), lo = *reinterpret_cast<const h4v*>(bx + pl);
-                return (__builtin_convertvector(hi, f4v) + __builtin_convertvector(lo, f4v)) * (1.0f / PRE);
-            };
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) res[m][ct] = rd(2 * wave + m, ct);
-            if (wave < 4 && gq < 2) resr = rd(16, wave);
-        }
-        wg_barrier();                                      // every wave is done with x | att: hidden takes their place
-        {
-            auto put = [&](int mtl, int hf, int ct, const f4v acc_, bool ragged) {
-                const int ch = hf * 272 + 16 * mtl + 4 * gq;
-                const f4v bias = load4(pb + FB_1 + ch), sc = load4(pb + FB_A + ch), sh = load4(pb + FB_S + ch);
-                f4v v = fma4(acc_, sc * (UNS * PRE), (bias * sc + sh) * PRE);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];                  // ReLU that keeps NaN
-                h4v hi, lo;
-                split4_pre(v, hi, lo);
-                const u2v H = __builtin_bit_cast(u2v, hi), Lo = __builtin_bit_cast(u2v, lo);
-                unsigned hx = H.x, hy = H.y, lx = Lo.x, ly = Lo.y;
-                lane_swap16(hx, lx);
-                lane_swap16(hy, ly);
-                char* d = ragged ? lds + hf * MT_HALF + 65536 + (gq & 1) * 1024 + ct * 256 + j * 16
-                                 : lds + hf * MT_HALF + (mtl >> 1) * 8192 + (gq & 1) * 4096 + ct * 1024 + ((2 * (mtl & 1) + (gq >> 1)) * 16 + j) * 16;
-                if (!ragged || gq < 2) *reinterpret_cast<u4v*>(d) = u4v{hx, hy, lx, ly};
-            };
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) put(2 * wave + (m & 1), m >> 1, ct, acc[m][ct], false);
-            put(16, wave >> 2, rag_ct, accr, true);
-        }
-        wg_barrier();
-        // ---- mlp[3]: row tiles 2 w, 2 w + 1 over the four column tiles + (waves 0..3) column tile w of the ragged 17th ---------------
-        f4v o[2][4], orr = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) o[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-        {
-            h8v a[2][3][2];
-            auto aload3 = [&](int ks, h8v (&r)[3][2]) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const int mt = m < 2 ? 2 * wave + m : 16;
-                    gptr_h8 Wf = uniform_ptr(pw + FW_2 + ((size_t)mt * 18 + ks) * FR);
-                    r[m][0] = Wf[lane];
-                    r[m][1] = Wf[64 + lane];
-                }
-            };
-            aload3(0, a[0]);
-#pragma unroll 1
-            for (int kp = 0; kp < 9; ++kp) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int ks = 2 * kp + e;
-                    if (ks + 1 < 18) aload3(ks + 1, a[1 - e]);
-                    h8v bh[4], bl[4];
-                    bload(ks >= 9 ? 1 : 0, ks >= 9 ? ks - 9 : ks, bh, bl);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        o[0][ct] = mfma3(a[e][0][0], a[e][0][1], bh[ct], bl[ct], o[0][ct]);
-                        o[1][ct] = mfma3(a[e][1][0], a[e][1][1], bh[ct], bl[ct], o[1][ct]);
-                        if (ct == wave) orr = mfma3(a[e][2][0], a[e][2][1], bh[ct], bl[ct], orr);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // ---- out = . + b2 + x -> the next layer's images (16-byte pieces, lane pairs exchange halves) ---------------------------------
-        {
-            auto emit = [&](int mt, int ct, const f4v acc_, const f4v res_, bool mine) {
-                const f4v bias = load4(pb + FB_2 + 16 * mt + 4 * gq);
-                const f4v v = fma4(acc_, bcast4(UNS), bias) + res_;
-                const int64_t pbc = ct == 0 ? pbase[0] : ct == 1 ? pbase[1] : ct == 2 ? pbase[2] : pbase[3];
-                const int tk = ct == 0 ? tok[0] : ct == 1 ? tok[1] : ct == 2 ? tok[2] : tok[3];
-                const bool ok = (ct == 0 ? colok[0] : ct == 1 ? colok[1] : ct == 2 ? colok[2] : colok[3]) && mine && (mt < 16 || gq < 2);
-                if (ok) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
-                }
-                h4v hi, lo;
-                split4_pre(v * PRE, hi, lo);
-                const u2v H = __builtin_bit_cast(u2v, hi), Lo = __builtin_bit_cast(u2v, lo);
-                unsigned hx = H.x, hy = H.y, lx = Lo.x, ly = Lo.y;
-                lane_swap16(hx, lx);
-                lane_swap16(hy, ly);
-                char* d = g.tf_out + pbc + (mt < 16 ? ((mt >> 1) * 2 + (gq & 1)) * TFB + img_tok_off(false, tk, 2 * (mt & 1) + (gq >> 1))
-                                                    : TF_MAIN + (gq & 1) * TFR + img_tok_off(true, tk, 0));
-                if (ok) *reinterpret_cast<u4v*>(d) = u4v{hx, hy, lx, ly};
-            };
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) emit(2 * wave + m, ct, o[m][ct], res[m][ct], true);
-            emit(16, wave & 3, orr, resr, wave < 4);
-        }
-    }
-    if (bad) atomicOr(g.flag, 1);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
@@ -1072,29 +1008,27 @@ int launch_fine_pack(const pats_propagation_weights& w, void* section, hipStream
     return check_launch("gnn_fine_pack_kernel");
 }
 
-static int fine_grid(int64_t P) {
+// CUs of the device (0: the kernels' LDS attributes were refused)
+static int fine_cus() {
     struct PerDevice { int state = 0; int n_cu = 256; };
     static PerDevice per_dev[64];
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) { (void)hipGetLastError(); dev_id = 0; }
     PerDevice& pd = per_dev[dev_id];
     if (pd.state == 0) {
-        bool ok = hipFuncSetAttribute((const void*)gnn_fine_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_LDS) == hipSuccess &&
-                  hipFuncSetAttribute((const void*)gnn_fine_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) == hipSuccess;
-#ifdef PATS_DIAG
-        ok = ok && hipFuncSetAttribute((const void*)gnn_fine_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_LDS) == hipSuccess;
-#endif
+        const bool ok = hipFuncSetAttribute((const void*)gnn_fine_tile_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_fine_tile_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_fine_tile_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)gnn_fine_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         int v = 256;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) (void)hipGetLastError();
         pd.n_cu = v > 0 ? v : 256;
         pd.state = ok ? 1 : -1;
     }
-    if (pd.state != 1) return 0;
-    return (int)std::min<int64_t>(P, pd.n_cu);
+    return pd.state == 1 ? pd.n_cu : 0;
 }
-int fine_max_grid() { return 512; }                      // scratch blocks a workspace must provide at most (CUs of the device, capped)
-size_t fine_scratch_bytes(int64_t P) { return (size_t)std::min<int64_t>(P, fine_max_grid()) * SC_BYTES; }
+size_t fine_scratch_bytes(int64_t P) { return (size_t)P * QKV_BYTES; }      // the per-problem blocks of projections
 size_t fine_image_bytes(int64_t P) { return (size_t)P * TF_BYTES; }
 
 int launch_fine_in(const float* x, int64_t P, char* tf, hipStream_t st) {
@@ -1107,58 +1041,103 @@ int launch_fine_out(const char* tf, int64_t P, float* y, hipStream_t st, const i
     hipLaunchKernelGGL(gnn_fine_out_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, tf, P, y, live, live_off, add);
     return check_launch("gnn_fine_out_kernel");
 }
-// one layer over P problems: image p of tf_x with source image (p + shift) % P of tf_s
-// One layer over P problems (sets descriptor sets of P / sets rows each; live (optional): device-side row count of a set, minus
-// live_off): image p of tf_x with source image (p + shift) % P of tf_s.  Two launches: q / k / v + attention per problem
-// (gnn_fine_layer_kernel<false> -> tf_att), then the MLP on flattened 64-column tiles (gnn_fine_mlp_kernel -> tf_out; residual != 0:
-// + x).  Diagnostic library, PATS_FINE_SPLIT=0: the whole layer per problem in the first kernel (the round's first form).
-int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, int residual, int64_t P, const void* section,
-                      char* tf_out, char* tf_att, char* scratch, int* flag, const int* gate, hipStream_t st, int sets,
-                      const int64_t* live, int64_t live_off) {
-    const int grid = fine_grid(P);
-    if (grid <= 0) return PATS_ERR_UNSUPPORTED;
-    const h8v* pw = (const h8v*)section;
-    // De-phasing: a layer's far-memory traffic comes in bursts (image fills, epilogues) that every workgroup of a lockstep grid
-    // issues at the same instants; workgroup i starts ((i >> 3) % 32) x 4 us late, which spreads them over a problem's period.
-    // Only where a workgroup has enough problems to pay for the ramp.
+
+#ifdef PATS_DIAG
+static long long* tl_begin(unsigned wgs) {
+    if (!diag_env("PATS_FINE_TL")) return nullptr;
+    long long* tl = nullptr;
+    (void)hipMalloc((void**)&tl, (size_t)wgs * FT_N * 8);
+    (void)hipMemset(tl, 0, (size_t)wgs * FT_N * 8);
+    return tl;
+}
+static void tl_end(long long* tl, unsigned wgs, hipStream_t st, const char* what, const char* unit, const char* const* names, int first, int last) {
+    if (!tl) return;
+    (void)hipStreamSynchronize(st);
+    std::vector<long long> h((size_t)wgs * FT_N);
+    (void)hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum[FT_N] = {0}, np = 0;
+    for (unsigned w = 0; w < wgs; ++w) { for (int k = 0; k < FT_N - 1; ++k) sum[k] += (double)h[(size_t)w * FT_N + k]; np += (double)h[(size_t)w * FT_N + FT_N - 1]; }
+    double tot = 0;
+    for (int k = first; k <= last; ++k) tot += sum[k];
+    fprintf(stderr, "%s (%u workgroups, %.0f %ss; mean us per %s, thread 0): total %.2f\n", what, wgs, np, unit, unit, tot / np / 100.0);
+    for (int k = first; k <= last; ++k) if (sum[k] > 0) fprintf(stderr, "  %-38s %7.2f\n", names[k - first], sum[k] / np / 100.0);
+    (void)hipFree(tl);
+}
+#endif
+
+// The per-token products over the flattened column tiles of P problems (sets descriptor sets of P / sets rows each; live (optional):
+// device-side row count of a set, minus live_off).  mlp_section: the layer whose MLP runs on (tf_x, tf_att) -> tf_out (+ x when
+// residual != 0), or null; qkv_section: the layer whose q / k / v are taken - of the MLP's output if there is one, else of tf_x - into
+// the per-problem blocks at qkv, or null.
+static int launch_fine_tile(const char* tf_x, const char* tf_att, char* tf_out, int residual, const void* mlp_section, const void* qkv_section,
+                            char* qkv, int want_q, int want_kv, int64_t P, int* flag, const int* gate, hipStream_t st, int sets,
+                            const int64_t* live, int64_t live_off) {
+    const int cus = fine_cus();
+    if (cus <= 0) return PATS_ERR_UNSUPPORTED;
+    const h8v* pw = (const h8v*)mlp_section;
+    const h8v* pwq = (const h8v*)qkv_section;
+    TileArgs a{tf_x, tf_att, tf_out, qkv, pw, pw ? (const float*)(pw + FW_END) : nullptr, pwq, pwq ? (const float*)(pwq + FW_END) : nullptr,
+               P, P / sets, sets, live, live_off, flag, residual, want_q, want_kv, gate};
+    const int64_t ntile = 2 * P + (P + 3) / 4 + (P + 63) / 64;
+    const unsigned wgs = (unsigned)std::min<int64_t>(ntile, cus);
+#ifdef PATS_DIAG
+    a.tl = tl_begin(wgs);
+#endif
+    if (pw && pwq) hipLaunchKernelGGL((gnn_fine_tile_kernel<true, true>), dim3(wgs), dim3(512), MLP_LDS, st, a);
+    else if (pw) hipLaunchKernelGGL((gnn_fine_tile_kernel<true, false>), dim3(wgs), dim3(512), MLP_LDS, st, a);
+    else hipLaunchKernelGGL((gnn_fine_tile_kernel<false, true>), dim3(wgs), dim3(512), MLP_LDS, st, a);
+#ifdef PATS_DIAG
+    static const char* names[14] = {"gather: wait", "mlp[0] product", "hidden: barrier behind the LDS writes", "mlp[3] product", "output tile", "q, k product", "q, k out",
+                                    "v^T product", "v^T out", "hidden: residual from LDS", "hidden: barrier (operands read)", "hidden: BN, ReLU, split -> LDS",
+                                    "tile start: mapping + barrier", "gather: issue + first weights"};
+    tl_end(a.tl, wgs, st, pw && pwq ? "gnn_fine_tile_kernel<MLP, QKV>" : pw ? "gnn_fine_tile_kernel<MLP>" : "gnn_fine_tile_kernel<QKV>", "tile", names, 0, 13);
+#endif
+    return check_launch("gnn_fine_tile_kernel");
+}
+int launch_fine_qkv(const char* tf, int64_t P, const void* section, char* qkv, int want_q, int want_kv, const int* gate, hipStream_t st, int sets,
+                    const int64_t* live, int64_t live_off) {
+    return launch_fine_tile(tf, nullptr, nullptr, 0, nullptr, section, qkv, want_q, want_kv, P, nullptr, gate, st, sets, live, live_off);
+}
+int launch_fine_mlp(const char* tf_x, const char* tf_att, int residual, const void* section, char* tf_out, const void* next_section, char* qkv,
+                    int64_t P, int* flag, const int* gate, hipStream_t st, int sets, const int64_t* live, int64_t live_off) {
+    return launch_fine_tile(tf_x, tf_att, tf_out, residual, section, next_section, qkv, 1, 1, P, flag, gate, st, sets, live, live_off);
+}
+// the attention core of P problems: queries of block p, keys / values of block (p + shift) % P -> tf_att
+int launch_fine_attn(const char* qkv, int64_t shift, char* tf_att, int64_t P, const int* gate, hipStream_t st, int sets, const int64_t* live,
+                     int64_t live_off) {
+    const int cus = fine_cus();
+    if (cus <= 0) return PATS_ERR_UNSUPPORTED;
+    const unsigned wgs = (unsigned)std::min<int64_t>(P, cus);
+    // De-phasing: the staging traffic comes in bursts that every workgroup of a lockstep grid issues at the same instants; workgroup i
+    // starts ((i >> 3) % 32) x 4 us late.  Only where a workgroup has enough problems to pay for the ramp.
     static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
-    const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)grid ? 4 : 0);
-    FineArgs g{tf_x, tf_s, residual ? tf_x : nullptr, tf_out, tf_att, pw, (const float*)(pw + FW_END), scratch, P, shift, flag, gate, live, live_off,
-               P / sets, sets, stagger};
-    const unsigned wgs = (unsigned)std::min(grid, fine_max_grid());
-    bool split = true;
+    const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)wgs ? 4 : 0);
+    AttnArgs a{qkv, tf_att, P, shift, gate, live, live_off, P / sets, sets, stagger};
 #ifdef PATS_DIAG
-    static const bool whole = [] { const char* e = diag_env("PATS_FINE_SPLIT"); return e && atoi(e) == 0; }();
-    split = !whole;
-    g.tl = nullptr;
-    if (diag_env("PATS_FINE_TL")) { (void)hipMalloc((void**)&g.tl, (size_t)wgs * FT_N * 8); (void)hipMemset(g.tl, 0, (size_t)wgs * FT_N * 8); }
-    if (!split) hipLaunchKernelGGL(gnn_fine_layer_kernel<true>, dim3(wgs), dim3(512), FINE_LDS, st, g);
-    else
+    a.tl = tl_begin(wgs);
 #endif
-    hipLaunchKernelGGL(gnn_fine_layer_kernel<false>, dim3(wgs), dim3(512), FINE_LDS, st, g);
+    hipLaunchKernelGGL(gnn_fine_attn_kernel, dim3(wgs), dim3(512), ATT_LDS, st, a);
 #ifdef PATS_DIAG
-    if (g.tl) {
-        (void)hipStreamSynchronize(st);
-        std::vector<long long> h((size_t)wgs * FT_N);
-        (void)hipMemcpy(h.data(), g.tl, h.size() * 8, hipMemcpyDeviceToHost);
-        double sum[FT_N] = {0}, np = 0;
-        for (unsigned w = 0; w < wgs; ++w) { for (int k = 0; k < FT_N - 1; ++k) sum[k] += (double)h[(size_t)w * FT_N + k]; np += (double)h[(size_t)w * FT_N + FT_N - 1]; }
-        static const char* names[FT_N] = {"fill s", "k product", "k epilogue", "v^T product", "v^T epilogue (x fill under it)", "barrier", "q product", "q epilogue (k, v staging under it)",
-            "barrier (q k v visible)", "attention: wait k_h v_h", "attention: units", "attention: barriers", "fill att", "hidden: att part (x2)",
-            "barrier + fill x", "hidden: x part (x2)", "hidden epilogues", "fill hidden0", "out product (x2)", "out epilogue", "", "", "", ""};
-        double tot = 0;
-        for (int k = 0; k <= 20; ++k) tot += sum[k];
-        fprintf(stderr, "gnn_fine timeline, %s (%u workgroups, %.0f problems; mean us per problem, thread 0): total %.2f\n",
-                split ? "first kernel of the split layer" : "whole layer in one kernel", wgs, np, tot / np / 100.0);
-        for (int k = 0; k <= 19; ++k) if (sum[k] > 0) fprintf(stderr, "  %-38s %7.2f\n", names[k], sum[k] / np / 100.0);
-        (void)hipFree(g.tl);
+    static const char* names[3] = {"wait k_h v_h", "units", "barrier"};
+    tl_end(a.tl, wgs, st, "gnn_fine_attn_kernel", "problem", names, 9, 11);
+#endif
+    return check_launch("gnn_fine_attn_kernel");
+}
+
+// One layer: image p of tf_x with source image (p + shift) % P of tf_s -> tf_out (the single-layer entry; a stack chains the
+// launches itself and lets a layer's MLP produce the next layer's projections)
+int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, int residual, int64_t P, const void* section,
+                      char* tf_out, char* tf_att, char* qkv, int* flag, const int* gate, hipStream_t st, int sets,
+                      const int64_t* live, int64_t live_off) {
+    int rc;
+    if (tf_s == tf_x) {
+        if ((rc = launch_fine_qkv(tf_x, P, section, qkv, 1, 1, gate, st, sets, live, live_off))) return rc;
+    } else {
+        if ((rc = launch_fine_qkv(tf_x, P, section, qkv, 1, 0, gate, st, sets, live, live_off))) return rc;
+        if ((rc = launch_fine_qkv(tf_s, P, section, qkv, 0, 1, gate, st, sets, live, live_off))) return rc;
     }
-#endif
-    int rc = check_launch("gnn_fine_layer_kernel");
-    if (rc || !split) return rc;
-    MlpArgs m{tf_x, tf_att, tf_out, pw, (const float*)(pw + FW_END), P, P / sets, sets, live, live_off, flag, residual, gate};
-    hipLaunchKernelGGL(gnn_fine_mlp_kernel, dim3(wgs), dim3(512), MLP_LDS, st, m);
-    return check_launch("gnn_fine_mlp_kernel");
+    if ((rc = launch_fine_attn(qkv, shift, tf_att, P, gate, st, sets, live, live_off))) return rc;
+    return launch_fine_mlp(tf_x, tf_att, residual, section, tf_out, nullptr, nullptr, P, flag, gate, st, sets, live, live_off);
 }
 
 }  // namespace pats

@@ -1088,7 +1088,7 @@ def attentional_propagation(x, source, params, heads=4, bn_train=False, residual
 
 
 UNSUPPORTED = 2            # include/pats_amd.h PATS_ERR_UNSUPPORTED
-GNN_STACK_ROWS = 4096     # rows of a descriptor set per pats_attentional_gnn_packed_f32 call (its workspace is ~1.2 MB a row)
+GNN_STACK_ROWS = 4096     # rows of a descriptor set per pats_attentional_gnn_packed_f32 call (its workspace is ~1.9 MB a row)
 
 
 def _gnn_packed_stack(desc0, desc1, layers, names, heads, count=None, out=None):
@@ -1150,6 +1150,8 @@ def attentional_gnn(desc0, desc1, layers, names, heads=4, bn_train=False, count=
         return desc0, desc1
     # batch statistics couple all rows of a launch: no blocking there
     step = b if (bn_train or b <= GNN_LAYER_ROWS) else GNN_LAYER_ROWS
+    if not bn_train and tuple(desc0.shape[1:]) == (264, 145):
+        step = min(step, 2 * GNN_STACK_ROWS)     # (the fine level's kernels keep 0.5 MB of projections per problem in the workspace)
     if step == b and out is None:
         res = None
     else:

@@ -62,6 +62,14 @@ def main():
               % (d.max(), int((d > 1e-4).sum()), np.array_equal(y, y2)))
         if (d > 1e-4).any():
             print("  first bad problems:", np.nonzero(d > 1e-4)[0][:20])
+    if "--stack" in sys.argv:                        # four layers on 2 x 2048 rows = 4096 problems a layer
+        names = ["self", "cross", "self", "cross"]
+        layers = [ops.PropagationParams(synth.gnn_params(seed=20 + i, C=C)) for i in range(4)]
+        d0, d1 = torch.randn((2048, C, n), device=dev), torch.randn((2048, C, n), device=dev)
+        out = (torch.empty_like(d0), torch.empty_like(d1))
+        t = timeit(lambda: ops.attentional_gnn(d0, d1, layers, names, out=out), n=3)
+        print(json.dumps({"stack_ms": round(t, 3), "layer_ms_per_4096": round(t / 4, 3)}))
+        return
     b = 4096
     x = torch.randn((b, C, n), device=dev)
     s = torch.randn((b, C, n), device=dev)
