@@ -202,6 +202,24 @@ __device__ __forceinline__ void wg_barrier_global() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Barriers of a wave that does nothing but LDS DMA (global_load_lds) for the others - csrc/gnn_fine.hip's attention kernel gives the
+// K and V staging a wave each, so that their vmcnt queues hold nothing else and the computing waves' hold no DMA.  No fences: a
+// workgroup-scope release with DMA in flight makes hipcc wait vmcnt(0) (the DMA's LDS writes are what it would publish), which is
+// exactly what wg_dma_arrive() must not do (the fill issued before it is awaited one phase later); wg_dma_landed() waits for
+// everything the wave has issued, then joins - the waves it releases read the staged bytes behind their own wg_barrier().
+__device__ __forceinline__ void wg_dma_arrive() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(WAITCNT_LGKM0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wg_dma_landed() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // wave_lds_sync(): between a wave's LDS writes and the reads of them by OTHER lanes of the SAME wave where no wg_barrier() stands in
 // between.  The hardware runs a wave's LDS operations in order, but to the compiler a lane's load does not depend on another lane's
 // store - in sinkhorn_blk145w2_kernel it hoisted such a read above the store (round 4: seven lanes in eight multiplied with the

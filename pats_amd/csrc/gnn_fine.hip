@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #ifdef PATS_DIAG
 #include <cstdio>
 #include <vector>
@@ -64,7 +65,6 @@ constexpr int V_TILE = 5 * 2 * 1024;          // one 16-channel tile of v as A f
 constexpr int V_BYTES = 17 * V_TILE;
 // LDS while the attention runs
 constexpr int KH_BYTES = 4 * TFB + FN * 16;   // one head of k: two k-steps x (hi, lo) + its extras
-constexpr int L_KA = 0, L_V = 2 * KH_BYTES, L_VX = L_V + 4 * V_TILE, L_ATT_END = L_VX + V_TILE;
 // packed weights (units of h8v): fragment (row tile, k-step) = [hi | lo][64 lanes]
 constexpr int FR = 128;
 constexpr int FW_Q = 0, FW_K = FW_Q + 17 * 9 * FR, FW_V = FW_K + 17 * 9 * FR, FW_1 = FW_V + 17 * 9 * FR, FW_2 = FW_1 + 34 * 18 * FR,
@@ -74,7 +74,7 @@ constexpr int FB_Q = 0, FB_K = 272, FB_V = 544, FB_1 = 816, FB_A = FB_1 + 544, F
 
 // Diagnostic library only (python -m pats_amd.build --diag, PATS_AMD_DIAG_LIB=1, PATS_FINE_TL=1): s_memrealtime stamps at the stage
 // boundaries of thread 0, summed over the workgroup's problems; launch_fine_layer prints the means per problem
-constexpr int FT_N = 24;          // (diagnostic library)
+[[maybe_unused]] constexpr int FT_N = 24;          // (diagnostic library)
 #ifdef PATS_DIAG
 #define FT(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_amdgcn_s_memrealtime(); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -311,6 +311,8 @@ struct TileArgs {
     int* flag;
     int residual;              // MLP: add x (AttentionalGNN.forward's desc + delta); 0: the delta alone
     int want_q, want_kv;       // QKV: which of the projections leave
+    char* dump;                // 256 bytes nobody reads: where a lane with nothing to store stores (see `sink` in the kernel)
+    int stagger;               // workgroup i starts ((i >> 3) % 32) x stagger us late (launch_fine_tile)
     const int* gate;
 #ifdef PATS_DIAG
     long long* tl;
@@ -363,16 +365,31 @@ __device__ __forceinline__ void wload(const h8v* const (&w)[N], int ks, int lane
 #endif
 // five row tiles (w[m]: fragment of k-step 0; k-step ks at + ks * FR) x four column tiles over NKS k-steps; the fifth - a ragged row
 // tile shared by four waves - for column tile rag_ct only
+// Two waves share a SIMD's matrix pipe, and when both have an MFMA ready the OLDER wave's is taken (priority, then age): waves 0..3
+// ran a product's k loop nearly unimpeded, waves 4..7 on what was left - and finished it alone, with nobody to cover their LDS and
+// weight latencies (thread 0 waited 5 of mlp[0]'s 21 us at the barrier behind it).  Half way through a k loop the younger wave takes
+// priority 1: the older one leads the first half, the younger the second, both arrive together.
+#if defined(PATS_DIAG) && defined(PATS_EXP_NOPRIO)
+#define PRIO_SWAP(kp, NKS, younger) do { } while (0)
+#define PRIO_END(younger) do { } while (0)
+#else
+#define PRIO_SWAP(kp, NKS, younger) do { if ((kp) == ((NKS) + 1) / 4 && (younger)) __builtin_amdgcn_s_setprio(1); } while (0)
+#define PRIO_END(younger) do { if (younger) __builtin_amdgcn_s_setprio(0); } while (0)
+#endif
 struct W5 { const h8v* w[5]; };
 template <int NKS>
-__device__ __forceinline__ void prod5(const W5& W, h8v (&a)[2][5][2], const char* lds, int lane, int rag_ct, f4v (&acc)[4][4], f4v& accr) {
+__device__ __forceinline__ void prod5(const W5& W, h8v (&a)[2][5][2], const char* lds, int lane, int rag_ct, f4v (&acc)[4][4], f4v& accr, bool younger) {
 #pragma unroll 1
     for (int kp = 0; kp < (NKS + 1) / 2; ++kp) {
+        PRIO_SWAP(kp, NKS, younger);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int ks = 2 * kp + e;
             if (ks < NKS) {
-                if (ks + 1 < NKS) WLOAD_IN_LOOP(5, W.w, ks + 1, lane, a[1 - e]);
+                // (UNCONDITIONAL - the last k-step fetches its own fragments again: behind `if (ks + 1 < NKS)` the compiler's one
+                //  `s_waitcnt vmcnt(n)` for the fragments of THIS k-step must also be right on the path that skipped the loads, so n
+                //  counted none of them and every k-step waited for the loads it had just issued - no prefetch distance at all)
+                WLOAD_IN_LOOP(5, W.w, ks + 1 < NKS ? ks + 1 : NKS - 1, lane, a[1 - e]);
                 const int part = ks >= 9 ? 1 : 0, kk = BKK(ks >= 9 ? ks - 9 : ks);
                 h8v bh[4], bl[4];
 #pragma unroll
@@ -387,19 +404,21 @@ __device__ __forceinline__ void prod5(const W5& W, h8v (&a)[2][5][2], const char
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    PRIO_END(younger);
 }
 // three row tiles (the third for column tile rag_ct only; rag_ct < 0: none).  TRANS: the tile's fragments are the A operand, the
 // weights B - the accumulators hold rows = tokens 4 g + r of the column tile, column = channel j of the weight tile
 struct W3 { const h8v* w[3]; };
 template <int NKS, bool TRANS>
-__device__ __forceinline__ void prod3(const W3& W, h8v (&a)[2][3][2], const char* lds, int lane, int rag_ct, f4v (&o)[2][4], f4v& orr) {
+__device__ __forceinline__ void prod3(const W3& W, h8v (&a)[2][3][2], const char* lds, int lane, int rag_ct, f4v (&o)[2][4], f4v& orr, bool younger) {
 #pragma unroll 1
     for (int kp = 0; kp < (NKS + 1) / 2; ++kp) {
+        PRIO_SWAP(kp, NKS, younger);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int ks = 2 * kp + e;
             if (ks < NKS) {
-                if (ks + 1 < NKS) WLOAD_IN_LOOP(3, W.w, ks + 1, lane, a[1 - e]);
+                WLOAD_IN_LOOP(3, W.w, ks + 1 < NKS ? ks + 1 : NKS - 1, lane, a[1 - e]);       // (unconditional: see prod5)
                 const int part = ks >= 9 ? 1 : 0, kk = BKK(ks >= 9 ? ks - 9 : ks);
                 h8v bh[4], bl[4];
 #pragma unroll
@@ -421,6 +440,7 @@ __device__ __forceinline__ void prod3(const W3& W, h8v (&a)[2][3][2], const char
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    PRIO_END(younger);
 }
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -460,6 +480,7 @@ gnn_fine_tile_kernel(TileArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (g.gate && *g.gate == 0) return;
     const int t_ = threadIdx.x, lane0 = t_ & 63, wave0 = __builtin_amdgcn_readfirstlane(t_ >> 6);
+    for (int i = (int)(blockIdx.x >> 3 & 31) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);       // ~1 us a step
     int64_t L = g.half;
     if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
     const int64_t NQ = L * g.sets;                         // live problems: index qi -> problem (qi / L) * half + qi % L
@@ -467,11 +488,59 @@ gnn_fine_tile_kernel(TileArgs g) {
     bool bad = false;
 #ifdef PATS_DIAG
     long long tsum[FT_N] = {0}, tlast = 0, nprob = 0;
+    const long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const float* pb = reinterpret_cast<const float*>(lds + L_PB);
     const float* pbq = reinterpret_cast<const float*>(lds + L_PBQ);
     if (MLP) for (int i = t_; i < FB_END; i += 512) reinterpret_cast<float*>(lds + L_PB)[i] = g.pb[i];
     if (QKV) for (int i = t_; i < FB_1; i += 512) reinterpret_cast<float*>(lds + L_PBQ)[i] = g.pbq[i];
+    // ---- gather: 72 fragments per operand half, 9 (QKV alone) or 18 a wave: column tile w & 3 of the tile whose column (p_, t_) this
+    //      lane fetches.  Issued for tile i + 1 as soon as every wave has read the last LDS operand of tile i - BEFORE that tile's last
+    //      epilogue, whose conversions and stores then run under the DMA's flight ----------------------------------------------------
+    auto gather = [&](int p_, int t_) {
+        const int wave = wave0, lane = lane0, gq = lane >> 4, myct = wave & 3;
+#pragma unroll 2
+        for (int i = 0; i < (MLP ? 18 : 9); ++i) {
+            const int idx = wave + 8 * i, part = idx >= 72 ? 1 : 0, r = idx - 72 * part;
+            const char* img = part ? g.tf_att : g.tf_x;
+            // (fragment r = (k-step, plane, column tile r & 3): wave w's are all of column tile w & 3)
+            if (r < 64) {
+                const int ks = r >> 3, plane = (r >> 2) & 1;
+                const char* src = img + (int64_t)p_ * TF_BYTES + (2 * ks + plane) * TFB + img_tok_off(false, t_, gq);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + ks * 8192 + plane * 4096 + myct * 1024), 16, 0, 0);
+            } else {
+                const int plane = (r - 64) >> 2;
+                const char* src = img + (int64_t)p_ * TF_BYTES + TF_MAIN + plane * TFR + img_tok_off(true, t_, 0);
+                if (lane < 16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + 65536 + plane * 1024 + myct * 256), 16, 0, 0);
+            }
+        }
+    };
+    // the column (problem, token) this wave's lanes gather for tile tl: column tile w & 3
+    auto gather_column = [&](int64_t tl, int& pi, int& tk) {
+        const int j = lane0 & 15, ct = wave0 & 3;
+        int64_t qi;
+        if (tl < nF) { qi = tl >> 1; tk = 64 * (int)(tl & 1) + 16 * ct + j; }
+        else if (tl < nF + nE) { qi = 4 * (tl - nF) + ct; tk = 128 + j; }
+        else { qi = 64 * (tl - nF - nE) + 16 * ct + j; tk = 144; }
+        if (qi >= NQ) qi = NQ - 1;
+        pi = (int)(qi < L ? qi : g.half + (qi - L));
+    };
+    // the next tile's operands: called by every wave behind the barrier that ends the tile's last LDS read
+    auto gather_next = [&](int64_t tile) {
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntile) {
+            int pn, tkn;
+            gather_column(tn, pn, tkn);
+            gather(pn, tkn);
+        }
+    };
+    // A lane with nothing to store stores to `sink` instead of branching around the instruction: behind a skipped-or-not branch the
+    // compiler's `s_waitcnt vmcnt(n)` for a LOAD issued before the stores must assume they were skipped - n = 0, and the first
+    // weight fragments of the next product waited for every store of the epilogue in front of it to be acknowledged.
+    char* const sink = g.dump;
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         int lane = lane0, wave = wave0;
         const h8v* pw = g.pw;
@@ -507,27 +576,11 @@ gnn_fine_tile_kernel(TileArgs g) {
 #ifdef PATS_DIAG
         tlast = __builtin_amdgcn_s_memrealtime();
 #endif
-        wg_barrier();                                      // the previous tile's fragments have been read
-        TT(12);
-        // ---- gather: 72 fragments per operand half, 9 (QKV alone) or 18 a wave ------------------------------------------------------
-#pragma unroll 2
-        for (int i = 0; i < (MLP ? 18 : 9); ++i) {
-            const int idx = wave + 8 * i, part = idx >= 72 ? 1 : 0, r = idx - 72 * part;
-            const char* img = part ? g.tf_att : g.tf_x;
-            // (fragment r = (k-step, plane, column tile r & 3): wave w's are all of column tile w & 3)
-            if (r < 64) {
-                const int ks = r >> 3, plane = (r >> 2) & 1;
-                const char* src = img + (int64_t)my_p * TF_BYTES + (2 * ks + plane) * TFB + img_tok_off(false, my_t, gq);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + ks * 8192 + plane * 4096 + myct * 1024), 16, 0, 0);
-            } else {
-                const int plane = (r - 64) >> 2;
-                const char* src = img + (int64_t)my_p * TF_BYTES + TF_MAIN + plane * TFR + img_tok_off(true, my_t, 0);
-                if (lane < 16)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(lds + part * MT_HALF + 65536 + plane * 1024 + myct * 256), 16, 0, 0);
-            }
+        if (tile == (int64_t)blockIdx.x) {                 // (every later tile's gather went out behind the last product of the tile before)
+            wg_barrier();
+            gather(my_p, my_t);
         }
+        TT(12);
         // the weight fragments of the tile's first k-step go out behind the gather (and every later product's before the epilogue
         // in front of it)
         const int rag_tile = wave < 4 ? 16 : 33;
@@ -559,7 +612,7 @@ gnn_fine_tile_kernel(TileArgs g) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) acc[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-            prod5<18>(W0, a5, lds, lane, rag_ct, acc, accr);
+            prod5<18>(W0, a5, lds, lane, rag_ct, acc, accr, wave >= 4);
             W3 W2;
             W2.w[0] = (const h8v*)uniform_ptr(pw + FW_2 + (size_t)(2 * wave) * 18 * FR);
             W2.w[1] = (const h8v*)uniform_ptr(pw + FW_2 + (size_t)(2 * wave + 1) * 18 * FR);
@@ -613,7 +666,7 @@ gnn_fine_tile_kernel(TileArgs g) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) o[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-            prod3<18, false>(W2, a3, lds, lane, wave < 4 ? wave : -1, o, orr);
+            prod3<18, false>(W2, a3, lds, lane, wave < 4 ? wave : -1, o, orr, wave >= 4);
             if (QKV) {
                 W0.w[0] = (const h8v*)uniform_ptr(pwq + FW_Q + (size_t)(2 * wave) * 9 * FR);
                 W0.w[1] = (const h8v*)uniform_ptr(pwq + FW_Q + (size_t)(2 * wave + 1) * 9 * FR);
@@ -623,7 +676,8 @@ gnn_fine_tile_kernel(TileArgs g) {
                 wload<5>(W0.w, 0, lane, a5[0]);
             }
             TT(3);
-            if (QKV) wg_barrier();                         // every wave is done with the hidden fragments: the output tile takes their place
+            wg_barrier();                                  // every wave is done with the hidden fragments: the output tile takes their place
+            if (!QKV) gather_next(tile);                   // ... or the next tile's operands, under this epilogue
             // ---- out = . + b2 + x -> the next layer's images (16-byte pieces, lane pairs exchange halves) [-> LDS: the QKV phase's operand] --
             {
                 auto emit = [&](int mt, int ct, int cp, int ctk, bool cok, const f4v acc_, const f4v res_, bool mine) {
@@ -635,8 +689,11 @@ gnn_fine_tile_kernel(TileArgs g) {
                         for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.0e38f);
                     }
                     const u4v piece = make_piece(v * PRE);
+                    // with a QKV phase behind it the tile goes to LDS only and leaves for global memory at the END of the tile (out_store):
+                    // a load issued behind a store completes behind it (one in-order queue), so stores issued here would cost the q, k
+                    // product's first weight fragments a far-memory write acknowledgement (~2 us)
                     char* d = g.tf_out + (int64_t)cp * TF_BYTES + img_piece_off(mt, ctk, gq);
-                    if (ok) *reinterpret_cast<u4v*>(d) = piece;
+                    if (!QKV) *reinterpret_cast<u4v*>(ok ? d : sink) = piece;
                     if (QKV && mine && (mt < 16 || gq < 2)) *reinterpret_cast<u4v*>(lds + lds_piece_off(mt, ct, gq, j)) = piece;
                 };
 #pragma unroll
@@ -661,49 +718,65 @@ gnn_fine_tile_kernel(TileArgs g) {
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) acc[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-                prod5<9>(W0, a5, lds, lane, rag_ct, acc, accr);
+                prod5<9>(W0, a5, lds, lane, rag_ct, acc, accr, wave >= 4);
                 wload<3>(WV.w, 0, lane, a3[0]);
                 TT(5);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int mt = 2 * wave + (m & 1);
-                    const f4v bias = load4(pbq + (m < 2 ? FB_Q : FB_K) + 16 * mt + 4 * gq) * PRE;
-                    const bool want = m < 2 ? g.want_q != 0 : g.want_kv != 0;
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
+                // q, k leave BEHIND the v^T product (unit u = row tile u >> 2 of the wave's four, column tile u & 3; unit 16 = the
+                // extras): see out_store.  (Slices of this epilogue under the k-steps of v^T - vector work while its MFMAs occupy the
+                // pipe - made that product 16 instead of 5.5 us: every k-step's weights waited behind the slice's stores.)
+                auto qk_unit = [&](int u) {
+                    if (u < 16) {
+                        const int m = u >> 2, ct = u & 3;
+                        const int mt = 2 * wave + (m & 1);
+                        const f4v bias = load4(pbq + (m < 2 ? FB_Q : FB_K) + 16 * mt + 4 * gq) * PRE;
+                        const bool want = m < 2 ? g.want_q != 0 : g.want_kv != 0;
                         const u4v piece = make_piece(fma4(acc[m][ct], bcast4(UNS * PRE), bias));
                         char* d = g.qkv + (int64_t)pidx[ct] * QKV_BYTES + (m < 2 ? QO_Q : QO_K) + img_piece_off(mt, tok[ct], gq);
-                        if (want && colok[ct]) *reinterpret_cast<u4v*>(d) = piece;
+                        *reinterpret_cast<u4v*>(want && colok[ct] ? d : sink) = piece;
+                    } else {
+                        // extras: rows 256 + 4 g + r = (head 2 g + (r >> 1), channel 64 + (r & 1)); k as the A operand (h0 h1 l0 l1 h0 h1 0 0),
+                        // q as B (h0 h1 h0 h1 l0 l1 0 0): ONE more MFMA per key tile gives hi.hi + lo.hi + hi.lo of both channels
+                        const bool isq = wave < 4;
+                        const f4v bias = load4(pbq + (isq ? FB_Q : FB_K) + 256 + 4 * (gq & 1)) * PRE;
+                        h4v hi, lo;
+                        split4_pre(fma4(accr, bcast4(UNS * PRE), bias), hi, lo);
+                        char* d = g.qkv + (int64_t)my_p * QKV_BYTES + (isq ? QO_QX : QO_KX) + ((2 * gq) * FN + my_t) * 16;
+                        const bool st_ = (isq ? g.want_q != 0 : g.want_kv != 0) && my_ok && gq < 2;
+                        const h8v p0 = isq ? h8v{hi.x, hi.y, hi.x, hi.y, lo.x, lo.y, 0, 0} : h8v{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y, 0, 0};
+                        const h8v p1 = isq ? h8v{hi.z, hi.w, hi.z, hi.w, lo.z, lo.w, 0, 0} : h8v{hi.z, hi.w, lo.z, lo.w, hi.z, hi.w, 0, 0};
+                        *reinterpret_cast<h8v*>(st_ ? d : sink) = p0;
+                        *reinterpret_cast<h8v*>(st_ ? d + FN * 16 : sink + 16) = p1;
                     }
-                }
-                // extras: rows 256 + 4 g + r = (head 2 g + (r >> 1), channel 64 + (r & 1)); k as the A operand (h0 h1 l0 l1 h0 h1 0 0),
-                // q as B (h0 h1 h0 h1 l0 l1 0 0): ONE more MFMA per key tile gives hi.hi + lo.hi + hi.lo of both channels
-                {
-                    const bool isq = wave < 4;
-                    const f4v bias = load4(pbq + (isq ? FB_Q : FB_K) + 256 + 4 * (gq & 1)) * PRE;
-                    h4v hi, lo;
-                    split4_pre(fma4(accr, bcast4(UNS * PRE), bias), hi, lo);
-                    char* d = g.qkv + (int64_t)my_p * QKV_BYTES + (isq ? QO_QX : QO_KX) + ((2 * gq) * FN + my_t) * 16;
-                    if ((isq ? g.want_q != 0 : g.want_kv != 0) && my_ok && gq < 2) {
-                        if (isq) {
-                            *reinterpret_cast<h8v*>(d) = h8v{hi.x, hi.y, hi.x, hi.y, lo.x, lo.y, 0, 0};
-                            *reinterpret_cast<h8v*>(d + FN * 16) = h8v{hi.z, hi.w, hi.z, hi.w, lo.z, lo.w, 0, 0};
-                        } else {
-                            *reinterpret_cast<h8v*>(d) = h8v{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y, 0, 0};
-                            *reinterpret_cast<h8v*>(d + FN * 16) = h8v{hi.z, hi.w, lo.z, lo.w, hi.z, hi.w, 0, 0};
-                        }
-                    }
-                }
-                TT(6);
-            }
-            // ---- v^T: channel tiles 2 w, 2 w + 1 (+ the ragged 17th for column tile w, waves 0..3); rows = the column tile's tokens ------
-            {
+                };
+                // ---- v^T: channel tiles 2 w, 2 w + 1 (+ the ragged 17th for column tile w, waves 0..3); rows = the column tile's tokens ------
                 f4v o[2][4], orr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) o[m][ct] = f4v{0.f, 0.f, 0.f, 0.f};
-                prod3<9, true>(WV, a3, lds, lane, wave < 4 ? wave : -1, o, orr);
+                prod3<9, true>(WV, a3, lds, lane, wave < 4 ? wave : -1, o, orr, wave >= 4);
+                TT(7);
+                // Every store of the tile from here on, in one burst in front of the next tile's gather wait: the output tile (read
+                // back from LDS - each lane its own pieces, no barrier needed), then - behind the barrier that frees the LDS and the
+                // next tile's gather - q, k and v^T.  Their acknowledgements and the DMA fly together.
+                if (MLP) {
+                    auto out_store = [&](int mt, int ct, int cp, int ctk, bool cok, bool mine) {
+                        const bool ok = cok && mine && (mt < 16 || gq < 2);
+                        const u4v piece = *reinterpret_cast<const u4v*>(lds + lds_piece_off(mt, ct, gq, j));
+                        char* d = g.tf_out + (int64_t)cp * TF_BYTES + img_piece_off(mt, ctk, gq);
+                        *reinterpret_cast<u4v*>(ok ? d : sink) = piece;
+                    };
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) out_store(2 * wave + m, ct, pidx[ct], tok[ct], colok[ct], true);
+                    out_store(16, myct, my_p, my_t, my_ok, wave < 4);
+                }
+                wg_barrier();                              // every wave has read the tile's last operand
+                gather_next(tile);
+#pragma unroll
+                for (int u = 0; u < 17; ++u) qk_unit(u);
+                TT(6);
                 TT(7);
                 if (g.want_kv) {
                     // A fragment (channel tile mt, key pair tile kk) of a problem: lane (g, j = channel) holds keys 32 kk + 4 g + r (first
@@ -782,6 +855,8 @@ gnn_fine_tile_kernel(TileArgs g) {
     }
     if (bad) atomicOr(g.flag, 1);
 #ifdef PATS_DIAG
+    tsum[20] = __builtin_amdgcn_s_memtime() - clk0;       // shader clocks / 100 MHz ticks: the clock the workgroup ran at
+    tsum[21] = __builtin_amdgcn_s_memrealtime() - rt0;
     if (g.tl && t_ == 0) {
         for (int k = 0; k < FT_N - 1; ++k) g.tl[(size_t)blockIdx.x * FT_N + k] = tsum[k];
         g.tl[(size_t)blockIdx.x * FT_N + FT_N - 1] = nprob;
@@ -789,12 +864,41 @@ gnn_fine_tile_kernel(TileArgs g) {
 #endif
 }
 
+// The same store through a buffer descriptor of the problem's image: a lane that has nothing to write takes an offset past the
+// descriptor's range and the hardware drops its part - no branch around the instruction, so the number of stores a wave has in
+// flight is a compile-time fact and a later `s_waitcnt vmcnt(n)` for a LOAD issued before them waits for that load alone (behind a
+// skipped-or-not branch the compiler must assume the stores were skipped and wait for the whole queue).
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(char* img) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, TF_BYTES, 0x00020000);
+}
+__device__ __forceinline__ void store_tf_buf(__amdgpu_buffer_rsrc_t rs, int mt, int t, const f4v v, int lane, const LaneOff& lo_) {
+    const int g = lane >> 4, j = lane & 15;
+    const u4v piece = make_piece(v);
+    unsigned off;
+    if (mt < 16) {
+        const unsigned d = (mt >> 1) * (2 * TFB) + (mt & 1) * (t < 9 ? 512 : 32) + (t < 9 ? t * 1024 : 9216);
+        off = t < 9 ? d + lo_.tf0 : (j == 0 ? d + lo_.tf1 : BUF_OOB);
+    } else {
+        const unsigned d = TF_MAIN + (t < 9 ? t * 256 : 2304);
+        off = (g < 2 && (t < 9 || j == 0)) ? d + lo_.tf2 : BUF_OOB;
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(piece, rs, (int)off, 0, 0);
+}
+
 // ---- the attention core per problem ------------------------------------------------------------------------------------------------
-// One persistent 512-thread workgroup per CU owns a problem at a time: K_h (double-buffered) and V_h are DMA'd into LDS per head from
-// the problem's block of projections (source problem (p + shift) % P), the queries are read from global memory as B fragments.
-// Unit = (head, 16-query tile): S^T = K^T Q with the keys as rows (softmax in-lane + two exchanges); the accumulators of key tiles
-// 2 kk, 2 kk + 1 ARE the B operand of out^T = V P^T.  The output leaves as a TF image in the folded mlp[0]'s channel order.
-// The next problem's first head is fetched under the last head of the current one.
+// One persistent 512-thread workgroup per CU owns a problem at a time, its eight waves in ROLES:
+//   waves 0..3  PAIR units: query tiles 2 w, 2 w + 1 of the head - every K and V fragment read from LDS once for 32 queries (a
+//               one-tile unit reads 100 KB of fragments for 145 MFMAs: eight of them a round made the units LDS-read-bound),
+//   waves 6, 7  SINGLE units: query tiles 8 and 9 (token 144 alone),
+//   wave 4      stages K_h (+ its extras; double-buffered, one head ahead) and, once a problem, the extras tile of v,
+//   wave 5      stages V_h (single buffer, under the scores of head h).
+// The staging waves issue nothing but LDS DMA and the computing waves none, so a staging wave's `s_waitcnt vmcnt(0)` waits for its
+// fill alone and the computing waves' queues hold only their query loads and output stores (which nobody waits for).
+// Two barriers a head: X_h (K_h has landed; every wave is done with V_(h-1)) - scores S^T = K^T Q with the keys as rows, softmax
+// in-lane + two exchanges - Y_h (V_h has landed; every wave is done with K_h) - out^T = V P^T with the accumulators of key tiles
+// 2 kk, 2 kk + 1 AS the B operand.  The output leaves as a TF image in the folded mlp[0]'s channel order.  A head is one round:
+// SIMDs 2, 3 carry 435 MFMAs of it (pair + single), SIMDs 0, 1 290 beside their staging wave.
 struct AttnArgs {
     const char* qkv; char* tf_att;
     int64_t P, shift;
@@ -805,7 +909,37 @@ struct AttnArgs {
     long long* tl;
 #endif
 };
-constexpr int ATT_LDS = L_ATT_END + V_TILE;            // + a second extras tile of v (the next problem's lands while this one's is read)
+constexpr int A_K = 0, A_V = 2 * KH_BYTES, A_VX = A_V + 4 * V_TILE, ATT_LDS = A_VX + 2 * V_TILE;
+
+// one wave's LDS DMA of BYTES (whole 16-byte pieces) - completion: the issuing wave's vmcnt
+template <int BYTES>
+__device__ __forceinline__ void dma_wave(char* lds_dst, const char* src, int lane) {
+    static_assert(BYTES % 16 == 0, "whole 16-byte pieces");
+    constexpr int PIECES = BYTES / 16, FULL = PIECES / 64, REST = PIECES - 64 * FULL;
+    const char* s = src + lane * 16;
+    char* d = lds_dst;
+#pragma unroll 1
+    for (int r = 0; r < FULL; ++r) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+        s += 1024;
+        d += 1024;
+    }
+    if (REST > 0 && lane < REST)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+}
+
+struct QF { h8v h0, l0, h1, l1, x; };      // a query tile of one head as the B operand: two k-steps (hi, lo) + the packed extras
+__device__ __forceinline__ void qload(const char* qb, int h, int qt, int lane, QF& q) {
+    const int qoff = tf_off(false, qt, lane);
+    const int qtok = qt < 9 ? 16 * qt + (lane & 15) : 144;
+    q.h0 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h, 0) + qoff);
+    q.l0 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h, 1) + qoff);
+    q.h1 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h + 1, 0) + qoff);
+    q.l1 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h + 1, 1) + qoff);
+    q.x = *reinterpret_cast<const h8v*>(qb + QO_QX + (h * FN + qtok) * 16);
+}
 
 __global__ void __launch_bounds__(512, 1)
 gnn_fine_attn_kernel(AttnArgs g) {
@@ -819,170 +953,228 @@ gnn_fine_attn_kernel(AttnArgs g) {
     int64_t L = g.half;                                   // live rows per descriptor set
     if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
     const int64_t NQ = L * g.sets;                         // live problems: q -> problem (q / L) * half + q % L
+    auto problem_of = [&](int64_t q_) { return q_ < L ? q_ : g.half + (q_ - L); };
     auto kv_block = [&](int64_t q_) {
-        int64_t ps = (q_ < L ? q_ : g.half + (q_ - L)) + g.shift;
+        int64_t ps = problem_of(q_) + g.shift;
         if (ps >= g.P) ps -= g.P;
         return g.qkv + ps * QKV_BYTES;
     };
-    bool first = true;
-    int vxsel = 0;
-    for (int64_t q_ = blockIdx.x; q_ < NQ; q_ += gridDim.x) {
-        const int64_t p = q_ < L ? q_ : g.half + (q_ - L);
-        // Everything the epilogues address is invariant over the problem loop: left alone the compiler hoists the store addresses and
-        // fragment bases out of it and spills the accumulators around them.  An opaque copy of the lane index per problem.
-        int lane = lane0, wave = wave0;
-        asm volatile("" : "+v"(lane), "+s"(wave));
-        const int gq = lane >> 4, j = lane & 15;
-        const LaneOff lo_ = lane_offsets(lane);
-        const char* qb = g.qkv + p * QKV_BYTES;
-        const char* kvb = kv_block(q_);
-        const bool has_next = q_ + gridDim.x < NQ;
-        const char* kvn = has_next ? kv_block(q_ + gridDim.x) : kvb;
-        char* att_dst = g.tf_att + p * TF_BYTES;
-#ifdef PATS_DIAG
-        tlast = __builtin_amdgcn_s_memrealtime();
-#endif
-        if (first) {
-            dma_fill<4 * TFB>(lds + L_KA, kvb + QO_K, wave, lane);
-            dma_fill<FN * 16>(lds + L_KA + 4 * TFB, kvb + QO_KX, wave, lane);
-            dma_fill<4 * V_TILE>(lds + L_V, kvb + QO_V, wave, lane);
-            dma_fill<V_TILE>(lds + L_VX, kvb + QO_V + 16 * V_TILE, wave, lane);
-        }
-        first = false;
-        const char* vx = lds + L_VX + vxsel * (L_ATT_END - L_VX);      // this problem's extras tile of v: slot 0 or the one behind the staging area
-        // this wave's queries of a unit: B operand, two k-steps + the packed extras (every lane reads the piece of its query; lanes
-        // k / 8 > 0 then take zeros).  Loaded one unit AHEAD: the block is an L2 / Infinity-Cache round trip away.
-        struct QF { h8v h0, l0, h1, l1, x; };
-        auto qload = [&](int h, int qt, QF& q) {
-            const int qoff = tf_off(false, qt, lane);
-            const int qtok = qt < 9 ? 16 * qt + j : 144;
-            q.h0 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h, 0) + qoff);
-            q.l0 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h, 1) + qoff);
-            q.h1 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h + 1, 0) + qoff);
-            q.l1 = *reinterpret_cast<const h8v*>(qb + QO_Q + tf_blk(2 * h + 1, 1) + qoff);
-            q.x = *reinterpret_cast<const h8v*>(qb + QO_QX + (h * FN + qtok) * 16);
-        };
-        QF q;
-        qload(0, wave, q);
-        for (int h = 0; h < 4; ++h) {
-            wg_barrier_global();                           // k_h, v_h (and the extras tile) have landed
-            FT(9);
-            {
-                char* kn = lds + L_KA + ((h + 1) & 1) * KH_BYTES;
+    if (wave0 == 4) {
+        // ---- K_h one head ahead (buffer h & 1), the next problem's extras tile of v under head 3 -------------------------------
+        int vxsel = 0;
+        bool first = true;
+        for (int64_t q_ = blockIdx.x; q_ < NQ; q_ += gridDim.x) {
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            const char* kvb = kv_block(q_);
+            const bool has_next = q_ + gridDim.x < NQ;
+            const char* kvn = has_next ? kv_block(q_ + gridDim.x) : kvb;
+            if (first) {
+                dma_wave<4 * TFB>(lds + A_K, kvb + QO_K, lane);
+                dma_wave<FN * 16>(lds + A_K + 4 * TFB, kvb + QO_KX, lane);
+                dma_wave<V_TILE>(lds + A_VX + vxsel * V_TILE, kvb + QO_V + 16 * V_TILE, lane);
+            }
+            first = false;
+            for (int h = 0; h < 4; ++h) {
+                wg_dma_landed();                           // X_h: K_h (and, at h = 0, the extras tile) are in LDS
+                char* kn = lds + A_K + ((h + 1) & 1) * KH_BYTES;
                 if (h < 3) {
-                    dma_fill<4 * TFB>(kn, kvb + QO_K + (h + 1) * 4 * TFB, wave, lane);
-                    dma_fill<FN * 16>(kn + 4 * TFB, kvb + QO_KX + (h + 1) * FN * 16, wave, lane);
+                    dma_wave<4 * TFB>(kn, kvb + QO_K + (h + 1) * 4 * TFB, lane);
+                    dma_wave<FN * 16>(kn + 4 * TFB, kvb + QO_KX + (h + 1) * FN * 16, lane);
                 } else if (has_next) {
-                    dma_fill<4 * TFB>(kn, kvn + QO_K, wave, lane);
-                    dma_fill<FN * 16>(kn + 4 * TFB, kvn + QO_KX, wave, lane);
-                    dma_fill<V_TILE>(lds + L_VX + (1 - vxsel) * (L_ATT_END - L_VX), kvn + QO_V + 16 * V_TILE, wave, lane);
+                    dma_wave<4 * TFB>(kn, kvn + QO_K, lane);
+                    dma_wave<FN * 16>(kn + 4 * TFB, kvn + QO_KX, lane);
+                    dma_wave<V_TILE>(lds + A_VX + (1 - vxsel) * V_TILE, kvn + QO_V + 16 * V_TILE, lane);
                 }
+                wg_dma_arrive();                           // Y_h
             }
-            const char* kb = lds + L_KA + (h & 1) * KH_BYTES;
-            for (int qt = wave; qt < FNT; qt += 8) {
-                const h8v qx = gq == 0 ? q.x : zero8();
-                f4v st[FNT];
-                const float c = UNS * 0.12309149097933272f * LOG2E;          // accumulator -> exponent of 2: 2^-12 / sqrt(66) * log2(e)
-                float mx = -INFINITY;
-                // the key fragments of tile kt + 1 are read while the MFMAs of tile kt run (two register sets)
-                struct KF { h8v h0, l0, h1, l1, x; };
-                auto kload = [&](int kt, KF& k) {
-                    const int koff = tf_off(false, kt, lane);
-                    k.h0 = *reinterpret_cast<const h8v*>(kb + koff);
-                    k.l0 = *reinterpret_cast<const h8v*>(kb + TFB + koff);
-                    k.h1 = *reinterpret_cast<const h8v*>(kb + 2 * TFB + koff);
-                    k.l1 = *reinterpret_cast<const h8v*>(kb + 3 * TFB + koff);
-                    k.x = *reinterpret_cast<const h8v*>(kb + 4 * TFB + (kt < 9 ? 16 * kt + j : 144) * 16);
-                };
-                KF kf[2];
-                kload(0, kf[0]);
-#pragma unroll
-                for (int kt = 0; kt < FNT; ++kt) {
-                    if (kt + 1 < FNT) kload(kt + 1, kf[(kt + 1) & 1]);
-                    const KF& k = kf[kt & 1];
-                    f4v s = mfma3(k.h0, k.l0, q.h0, q.l0, f4v{0.f, 0.f, 0.f, 0.f});         // rows = keys 16 kt + 4 g + r, column = query
-                    s = mfma3(k.h1, k.l1, q.h1, q.l1, s);
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(gq == 0 ? k.x : zero8(), qx, s, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = s[r] * c;
-                        if (kt == 9 && (gq != 0 || r != 0)) v = -INFINITY;                  // keys 145..: not there
-                        s[r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-                    st[kt] = s;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the next unit's queries: this wave's second tile of the head (waves 0, 1), else its tile of the next head
-                const int qt_own = qt;
-                if (qt + 8 < FNT) qload(h, qt + 8, q);
-                else if (h < 3) qload(h + 1, wave, q);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float den = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < FNT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pr = fast_exp2(st[kt][r] - mx);
-                        st[kt][r] = pr;
-                        den += pr;
-                    }
-                den += __shfl_xor(den, 16);
-                den += __shfl_xor(den, 32);
-                const float inv = 1.0f / den;
-                h8v ph[5], pl[5];
-#pragma unroll
-                for (int kk = 0; kk < 5; ++kk) {
-                    h4v h0, l0, h1, l1;
-                    split4_pre(st[2 * kk] * PRE, h0, l0);
-                    split4_pre(st[2 * kk + 1] * PRE, h1, l1);
-                    ph[kk] = h8v{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                    pl[kk] = h8v{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-                }
-                const float osc = UNS * PRE * inv;
-                h8v vf[2][5][2];
-                auto vload = [&](int dt, h8v (&v)[5][2]) {
-                    const char* vb = dt < 4 ? lds + L_V + dt * V_TILE : vx;
-#pragma unroll
-                    for (int kk = 0; kk < 5; ++kk) {
-                        v[kk][0] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + lane * 16);
-                        v[kk][1] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + 1024 + lane * 16);
-                    }
-                };
-                vload(0, vf[0]);
-#pragma unroll
-                for (int dt = 0; dt < 5; ++dt) {
-                    if (dt + 1 < 5) vload(dt + 1, vf[(dt + 1) & 1]);
-                    f4v o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 5; ++kk) o = mfma3(vf[dt & 1][kk][0], vf[dt & 1][kk][1], ph[kk], pl[kk], o);     // rows = channels, column = query
-                    __builtin_amdgcn_sched_barrier(0);
-                    o = o * osc;
-                    if (dt < 4) {
-                        store_tf(att_dst, 4 * h + dt, qt_own, o, lane, lo_);
-                    } else if (gq == (h >> 1) && (qt_own < 9 || j == 0)) {
-                        // rows 2 h', 2 h' + 1 of the extras tile are head h's channels 64, 65 -> bytes 4 h .. of the ragged block's piece
-                        const float e0 = (h & 1) ? o.z : o.x, e1 = (h & 1) ? o.w : o.y;
-                        const _Float16 a0 = (_Float16)e0, a1 = (_Float16)e1;
-                        const h2v hi = {a0, a1}, lo = {(_Float16)(e0 - (float)a0), (_Float16)(e1 - (float)a1)};
-                        const int off = tf_off(true, qt_own, j) + 4 * h;
-                        *reinterpret_cast<h2v*>(att_dst + tf_blk(8, 0) + off) = hi;
-                        *reinterpret_cast<h2v*>(att_dst + tf_blk(8, 1) + off) = lo;
-                    }
-                }
-            }
-            FT(10);
-            wg_barrier();                                  // every wave is done with v_h
-            FT(11);
-            if (h < 3) dma_fill<4 * V_TILE>(lds + L_V, kvb + QO_V + (h + 1) * 4 * V_TILE, wave, lane);
-            else if (has_next) dma_fill<4 * V_TILE>(lds + L_V, kvn + QO_V, wave, lane);
+            vxsel = 1 - vxsel;
         }
-        vxsel = 1 - vxsel;
-#ifdef PATS_DIAG
-        ++nprob;
-#endif
+        return;
     }
+    if (wave0 == 5) {
+        // ---- V_h under the scores of head h --------------------------------------------------------------------------------------
+        for (int64_t q_ = blockIdx.x; q_ < NQ; q_ += gridDim.x) {
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            const char* kvb = kv_block(q_);
+            for (int h = 0; h < 4; ++h) {
+                wg_dma_arrive();                           // X_h: every wave is done with V_(h-1)
+                dma_wave<4 * V_TILE>(lds + A_V, kvb + QO_V + h * 4 * V_TILE, lane);
+                wg_dma_landed();                           // Y_h
+            }
+        }
+        return;
+    }
+    auto compute = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        QF q[NT];
+        bool first = true;
+        int vxsel = 0;
+        for (int64_t q_ = blockIdx.x; q_ < NQ; q_ += gridDim.x) {
+            const int64_t p = problem_of(q_);
+            // Everything the epilogues address is invariant over the problem loop: left alone the compiler hoists the store addresses
+            // and fragment bases out of it and spills the accumulators around them.  An opaque copy of the lane index per problem.
+            int lane = lane0, wave = wave0;
+            asm volatile("" : "+v"(lane), "+s"(wave));
+            const int gq = lane >> 4, j = lane & 15;
+            const LaneOff lo_ = lane_offsets(lane);
+            const char* qb = g.qkv + p * QKV_BYTES;
+            const bool has_next = q_ + gridDim.x < NQ;
+            const char* qbn = g.qkv + problem_of(has_next ? q_ + gridDim.x : q_) * QKV_BYTES;
+            const __amdgpu_buffer_rsrc_t att_rs = image_rsrc(g.tf_att + p * TF_BYTES);
+            int qt[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) qt[n] = NT == 2 ? 2 * wave + n : wave + 2;
+#ifdef PATS_DIAG
+            tlast = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (first) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) qload(qb, 0, qt[n], lane, q[n]);
+            }
+            first = false;
+            const char* vx = lds + A_VX + vxsel * V_TILE;
+            for (int h = 0; h < 4; ++h) {
+                wg_barrier();                              // X_h
+                FT(9);
+                const char* kb = lds + A_K + (h & 1) * KH_BYTES;
+                h8v ph[NT][5], pl[NT][5];
+                float osc[NT];
+                {
+                    // ---- scores: rows = keys 16 kt + 4 g + r, column = query; the key fragments of tile kt + 1 are read while the
+                    //      MFMAs of tile kt run (two register sets) ---------------------------------------------------------------
+                    f4v st[NT][FNT];
+                    float mx[NT];
+                    h8v qx[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) { qx[n] = gq == 0 ? q[n].x : zero8(); mx[n] = -INFINITY; }
+                    const float c = UNS * 0.12309149097933272f * LOG2E;          // accumulator -> exponent of 2: 2^-12 / sqrt(66) * log2(e)
+                    struct KF { h8v h0, l0, h1, l1, x; };
+                    auto kload = [&](int kt, KF& k) {
+                        const int koff = tf_off(false, kt, lane);
+                        k.h0 = *reinterpret_cast<const h8v*>(kb + koff);
+                        k.l0 = *reinterpret_cast<const h8v*>(kb + TFB + koff);
+                        k.h1 = *reinterpret_cast<const h8v*>(kb + 2 * TFB + koff);
+                        k.l1 = *reinterpret_cast<const h8v*>(kb + 3 * TFB + koff);
+                        k.x = *reinterpret_cast<const h8v*>(kb + 4 * TFB + (kt < 9 ? 16 * kt + j : 144) * 16);
+                    };
+                    KF kf[2];
+                    kload(0, kf[0]);
+#pragma unroll
+                    for (int kt = 0; kt < FNT; ++kt) {
+                        if (kt + 1 < FNT) kload(kt + 1, kf[(kt + 1) & 1]);
+                        const KF& k = kf[kt & 1];
+                        const h8v kx = gq == 0 ? k.x : zero8();
+                        f4v s[NT];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) s[n] = mfma3(k.h0, k.l0, q[n].h0, q[n].l0, f4v{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) s[n] = mfma3(k.h1, k.l1, q[n].h1, q[n].l1, s[n]);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) s[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kx, qx[n], s[n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float v = s[n][r] * c;
+                                if (kt == 9 && (gq != 0 || r != 0)) v = -INFINITY;          // keys 145..: not there
+                                s[n][r] = v;
+                                mx[n] = fmaxf(mx[n], v);
+                            }
+                            st[n][kt] = s[n];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        float m_ = mx[n];
+                        m_ = fmaxf(m_, __shfl_xor(m_, 16));
+                        m_ = fmaxf(m_, __shfl_xor(m_, 32));
+                        float den = 0.f;
+#pragma unroll
+                        for (int kt = 0; kt < FNT; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float pr = fast_exp2(st[n][kt][r] - m_);
+                                st[n][kt][r] = pr;
+                                den += pr;
+                            }
+                        den += __shfl_xor(den, 16);
+                        den += __shfl_xor(den, 32);
+                        osc[n] = UNS * PRE * (1.0f / den);
+#pragma unroll
+                        for (int kk = 0; kk < 5; ++kk) {
+                            h4v h0, l0, h1, l1;
+                            split4_pre(st[n][2 * kk] * PRE, h0, l0);
+                            split4_pre(st[n][2 * kk + 1] * PRE, h1, l1);
+                            ph[n][kk] = h8v{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                            pl[n][kk] = h8v{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                        }
+                    }
+                }
+                FT(10);
+                wg_barrier();                              // Y_h
+                FT(11);
+                // the next head's queries (the next problem's first head under the last): an L2 / Infinity-Cache round trip away
+                // (unconditional, from a selected address: behind a branch the loaded registers are copied into q at the join - and
+                //  waited for right here, a far-memory round trip at the head of every out phase)
+                {
+                    const char* qsrc = h < 3 ? qb : qbn;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) qload(qsrc, (h + 1) & 3, qt[n], lane, q[n]);
+                }
+                {
+                    // ---- out^T = V P^T: rows = channels, column = query --------------------------------------------------------------
+                    h8v vf[2][5][2];
+                    auto vload = [&](int dt, h8v (&v)[5][2]) {
+                        const char* vb = dt < 4 ? lds + A_V + dt * V_TILE : vx;
+#pragma unroll
+                        for (int kk = 0; kk < 5; ++kk) {
+                            v[kk][0] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + lane * 16);
+                            v[kk][1] = *reinterpret_cast<const h8v*>(vb + kk * 2048 + 1024 + lane * 16);
+                        }
+                    };
+                    vload(0, vf[0]);
+#pragma unroll
+                    for (int dt = 0; dt < 5; ++dt) {
+                        if (dt + 1 < 5) vload(dt + 1, vf[(dt + 1) & 1]);
+                        f4v o[NT];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) o[n] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 5; ++kk)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) o[n] = mfma3(vf[dt & 1][kk][0], vf[dt & 1][kk][1], ph[n][kk], pl[n][kk], o[n]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const f4v on = o[n] * osc[n];
+                            if (dt < 4) {
+                                store_tf_buf(att_rs, 4 * h + dt, qt[n], on, lane, lo_);
+                            } else {
+                                // rows 2 h', 2 h' + 1 of the extras tile are head h's channels 64, 65 -> bytes 4 h .. of the ragged block's piece
+                                const float e0 = (h & 1) ? on.z : on.x, e1 = (h & 1) ? on.w : on.y;
+                                const _Float16 a0 = (_Float16)e0, a1 = (_Float16)e1;
+                                const h2v hi = {a0, a1}, lo = {(_Float16)(e0 - (float)a0), (_Float16)(e1 - (float)a1)};
+                                const bool mine = gq == (h >> 1) && (qt[n] < 9 || j == 0);
+                                const unsigned off = mine ? (unsigned)(tf_off(true, qt[n], j) + 4 * h) : BUF_OOB;
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hi), att_rs, (int)(off + tf_blk(8, 0)), 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lo), att_rs, (int)(off + tf_blk(8, 1)), 0, 0);
+                            }
+                        }
+                    }
+                }
+                FT(12);
+            }
+            vxsel = 1 - vxsel;
+#ifdef PATS_DIAG
+            ++nprob;
+#endif
+        }
+    };
+    if (wave0 < 4) compute(std::integral_constant<int, 2>{});
+    else compute(std::integral_constant<int, 1>{});
 #ifdef PATS_DIAG
     if (g.tl && t == 0) {
         for (int k = 0; k < FT_N - 1; ++k) g.tl[(size_t)blockIdx.x * FT_N + k] = tsum[k];
@@ -1028,7 +1220,7 @@ static int fine_cus() {
     }
     return pd.state == 1 ? pd.n_cu : 0;
 }
-size_t fine_scratch_bytes(int64_t P) { return (size_t)P * QKV_BYTES; }      // the per-problem blocks of projections
+size_t fine_scratch_bytes(int64_t P) { return (size_t)P * QKV_BYTES + 256; }      // the per-problem blocks of projections + the sink of masked stores
 size_t fine_image_bytes(int64_t P) { return (size_t)P * TF_BYTES; }
 
 int launch_fine_in(const float* x, int64_t P, char* tf, hipStream_t st) {
@@ -1061,6 +1253,7 @@ static void tl_end(long long* tl, unsigned wgs, hipStream_t st, const char* what
     for (int k = first; k <= last; ++k) tot += sum[k];
     fprintf(stderr, "%s (%u workgroups, %.0f %ss; mean us per %s, thread 0): total %.2f\n", what, wgs, np, unit, unit, tot / np / 100.0);
     for (int k = first; k <= last; ++k) if (sum[k] > 0) fprintf(stderr, "  %-38s %7.2f\n", names[k - first], sum[k] / np / 100.0);
+    if (sum[21] > 0) fprintf(stderr, "  shader clock over the kernel: %.0f MHz\n", sum[20] / sum[21] * 100.0);
     (void)hipFree(tl);
 }
 #endif
@@ -1077,9 +1270,15 @@ static int launch_fine_tile(const char* tf_x, const char* tf_att, char* tf_out, 
     const h8v* pw = (const h8v*)mlp_section;
     const h8v* pwq = (const h8v*)qkv_section;
     TileArgs a{tf_x, tf_att, tf_out, qkv, pw, pw ? (const float*)(pw + FW_END) : nullptr, pwq, pwq ? (const float*)(pwq + FW_END) : nullptr,
-               P, P / sets, sets, live, live_off, flag, residual, want_q, want_kv, gate};
+               P, P / sets, sets, live, live_off, flag, residual, want_q, want_kv, qkv + (size_t)P * QKV_BYTES, 0, gate};
+    if (!qkv) return PATS_ERR_INVALID;      // (every launch is handed the scratch area: its tail holds the sink of the masked stores)
     const int64_t ntile = 2 * P + (P + 3) / 4 + (P + 63) / 64;
     const unsigned wgs = (unsigned)std::min<int64_t>(ntile, cus);
+    // De-phasing: a tile ends in one burst of far-memory traffic (its ~270 KB of stores and the next tile's 132 KB gather), and a
+    // lockstep grid issues all 256 bursts at the same instants - each at the 1 / 256 share (~25 GB/s) of what the memory side serves.
+    // Workgroup i starts ((i >> 3) % 32) x 2 us late: the 32 CUs of an XCD spread over one tile period.
+    static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_TILE_STAGGER"); return e ? atoi(e) : -1; }();
+    a.stagger = stagger_env >= 0 ? stagger_env : (ntile >= 8 * (int64_t)wgs ? 2 : 0);
 #ifdef PATS_DIAG
     a.tl = tl_begin(wgs);
 #endif
@@ -1118,8 +1317,8 @@ int launch_fine_attn(const char* qkv, int64_t shift, char* tf_att, int64_t P, co
 #endif
     hipLaunchKernelGGL(gnn_fine_attn_kernel, dim3(wgs), dim3(512), ATT_LDS, st, a);
 #ifdef PATS_DIAG
-    static const char* names[3] = {"wait k_h v_h", "units", "barrier"};
-    tl_end(a.tl, wgs, st, "gnn_fine_attn_kernel", "problem", names, 9, 11);
+    static const char* names[4] = {"X: wait for K_h / the out phases", "scores + softmax", "Y: wait for V_h / the scores", "out = V P"};
+    tl_end(a.tl, wgs, st, "gnn_fine_attn_kernel", "problem", names, 9, 12);
 #endif
     return check_launch("gnn_fine_attn_kernel");
 }
@@ -1137,7 +1336,7 @@ int launch_fine_layer(const char* tf_x, const char* tf_s, int64_t shift, int res
         if ((rc = launch_fine_qkv(tf_s, P, section, qkv, 0, 1, gate, st, sets, live, live_off))) return rc;
     }
     if ((rc = launch_fine_attn(qkv, shift, tf_att, P, gate, st, sets, live, live_off))) return rc;
-    return launch_fine_mlp(tf_x, tf_att, residual, section, tf_out, nullptr, nullptr, P, flag, gate, st, sets, live, live_off);
+    return launch_fine_mlp(tf_x, tf_att, residual, section, tf_out, nullptr, qkv, P, flag, gate, st, sets, live, live_off);
 }
 
 }  // namespace pats

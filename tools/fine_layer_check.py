@@ -64,8 +64,15 @@ def main():
             print("  first bad problems:", np.nonzero(d > 1e-4)[0][:20])
     if "--stack" in sys.argv:                        # four layers on 2 x 2048 rows = 4096 problems a layer
         names = ["self", "cross", "self", "cross"]
-        layers = [ops.PropagationParams(synth.gnn_params(seed=20 + i, C=C)) for i in range(4)]
+        def pars(i):
+            q = synth.gnn_params(seed=20 + i, C=C)
+            if "--zeros" in sys.argv:                # the same instruction stream on all-zero operands: what the power budget costs (DVFS)
+                q = {k: (np.ones_like(v) if k.endswith("running_var") else np.zeros_like(v)) for k, v in q.items()}
+            return q
+        layers = [ops.PropagationParams(pars(i)) for i in range(4)]
         d0, d1 = torch.randn((2048, C, n), device=dev), torch.randn((2048, C, n), device=dev)
+        if "--zeros" in sys.argv:                    # same instruction stream on all-zero operands: what the power budget costs (DVFS)
+            d0.zero_(); d1.zero_()
         out = (torch.empty_like(d0), torch.empty_like(d1))
         t = timeit(lambda: ops.attentional_gnn(d0, d1, layers, names, out=out), n=3)
         print(json.dumps({"stack_ms": round(t, 3), "layer_ms_per_4096": round(t / 4, 3)}))
