@@ -1,36 +1,35 @@
 // AttentionalPropagation (models/modules.py:107-117) + the residual of AttentionalGNN.forward (:131-133) at the FINE level's shape
-// - x, source [b, 264, 145], 4 heads of 66 channels (second_layer.py:44,89 runs 18 such layers on both descriptor sets) - as ONE
-// kernel (round 5).  Round 4 ran this layer as six conv_pk_kernel launches around attention145_kernel: 24 tensor passes of 153 KB per
-// problem through HBM and 360 KB of packed weights streamed per 64-column tile (5.7 MB per problem through each CU's L1).
+// - x, source [b, 264, 145], 4 heads of 66 channels (second_layer.py:44,89 runs 18 such layers on both descriptor sets) - in THREE
+// kernels a layer (round 5).  Round 4 ran this layer as six conv_pk_kernel launches around attention145_kernel: 24 tensor passes of
+// 153 KB per problem through HBM and 360 KB of packed weights streamed per 64-column tile (5.7 MB per problem through each CU's L1).
 //
 //   q = Wq x, k = Wk s, v = Wv s;  att = softmax(q^T k / sqrt(66)) v  per head           MultiHeadedAttention.forward :100-105
 //   hidden = relu(bn(W1x x + (W1m Wm) att + b1'))                                          (merge folded into mlp[0]: gnn_fold_kernel)
 //   out = x + W2 hidden + b2                                                              AttentionalPropagation :114-117, GNN :133
 //
-// One persistent 512-thread workgroup per CU owns a PROBLEM at a time:
+// Everything but the attention core is per TOKEN, so it runs on 64-column tiles of the FLATTENED list of (problem, 16-token tile)
+// pairs (gnn_fine_tile_kernel: no token padding - 145 = 9 x 16 + 1 costs a per-problem kernel 10 %); the attention core runs per
+// problem (gnn_fine_attn_kernel).  A layer = attention of layer l, then ONE tile launch that does the MLP of layer l and, from the
+// output tile still in LDS, the q / k / v projections of layer l + 1.  (The first version of this file was one persistent kernel per
+// problem - DESIGN.md section 7a has its timeline and why it lost: its far-memory phases ran at the 1 / 256 share of the memory side.)
 //   * a [264 x 145] tensor split for the fp16 matrix pipe (x 2^6 = hi + lo) in MFMA fragment order is 153 120 bytes ("TF image":
 //     per 32-channel k-step and 16-token tile, lane (k / 8, token) holds its 8 channels as one 16-byte piece = the B operand of
-//     v_mfma_f32_16x16x32_f16; token 144 and channels 256..263 are ragged blocks without padding) - exactly ONE of them fits the
-//     CU's 160 KB of LDS.  So a stage is: DMA one TF image from global memory into LDS (global_load_lds_dwordx4: no registers, no
-//     VALU), run a convolution whose OUTPUT lives in the accumulators (wave w: row tiles 2 w, 2 w + 1 and a share of the ragged
-//     17th, all ten token tiles = 88 registers), write it - split again, in the next consumer's fragment order - to a per-workgroup
-//     scratch block in global memory (L2 / Infinity-Cache resident: written and read back by the same CU), next stage.
+//     v_mfma_f32_16x16x32_f16; token 144 and channels 256..263 are ragged blocks without padding).  Operands reach LDS by DMA
+//     (global_load_lds_dwordx4: no registers, no VALU), a product's OUTPUT lives in the accumulators and leaves split again, in the
+//     next consumer's fragment order.
 //   * the WEIGHTS are the A operand straight from L2 into a register ring (pre-split fragments, one 16-byte load per lane, packed once
-//     per layer by gnn_fine_pack_kernel): 2.7 MB per problem per CU instead of 5.7, at a quarter of the rate the L2 sustains
-//     (tools/wstream_probe.hip: 115-135 GB/s per CU with every CU streaming).
-//   * descriptors travel BETWEEN layers as TF images: the layer's epilogue writes one, the next layer DMAs it and rebuilds the
+//     per layer by gnn_fine_pack_kernel): 2.8 MB per 64-column tile.
+//   * descriptors travel BETWEEN layers as TF images: the layer's epilogue writes one, the next layer gathers it and rebuilds the
 //     residual from it ((hi + lo) / 2^6: exact to the 22 bits an image holds) - 16-byte accesses everywhere, no 4-byte strided
 //     loads (round 4's limiter).  gnn_fine_in_kernel / gnn_fine_out_kernel convert at the ends of a stack.
 //   * heads: the reference views a projection as [b, 66, 4, n] (channel = d * 4 + h).  q / k / v rows are permuted at pack time to
 //     [head][d < 64] (head h = k-steps 2 h, 2 h + 1 of a TF image) followed by the eight "extra" channels (d = 64, 65 of each head) in
 //     the ragged 17th row tile; the folded mlp[0] matrix has its attention columns in the same order.
 //   * attention per (head, 16-query tile) as in csrc/attention145.hip: S^T = K^T Q with the keys as rows (softmax in-lane + two
-//     exchanges), the accumulators of key tiles 2 kk, 2 kk + 1 ARE the B operand of out^T = V P^T; K_h (double-buffered) and V_h are
-//     DMA'd into LDS per head, v is produced TRANSPOSED by its projection (activations as A, weights as B) directly in that A-fragment
-//     order.  The two extra channels of a head cost ONE more MFMA per key tile instead of a k-step of three: A = (kh0 kh1 kl0 kl1 kh0
-//     kh1 0 0), B = (qh0 qh1 qh0 qh1 ql0 ql1 0 0) gives hi.hi + lo.hi + hi.lo of both channels.
-// Stages per problem: s -> [k, v^T]; x -> [q]; attention; att -> [hidden0 (attention part)]; x -> [hidden0 (x part) -> scratch,
-// hidden1 (x part)]; att -> [hidden1 -> LDS straight from the accumulators -> out (second half)]; hidden0 -> [out + b2 + x -> TF image].
+//     exchanges), the accumulators of key tiles 2 kk, 2 kk + 1 ARE the B operand of out^T = V P^T; v is produced TRANSPOSED by its
+//     projection (activations as A, weights as B) directly in that A-fragment order.  The two extra channels of a head cost ONE more
+//     MFMA per key tile instead of a k-step of three: A = (kh0 kh1 kl0 kl1 kh0 kh1 0 0), B = (qh0 qh1 qh0 qh1 ql0 ql1 0 0) gives
+//     hi.hi + lo.hi + hi.lo of both channels.
 // BatchNorm in eval mode only (the second layer always is: pats.py:112-114).  Range: |activation| < 1023; a non-finite output raises
 // *flag and the round-2 composition queued behind, gated on it, redoes the layer.
 #include "common.hpp"
@@ -312,7 +311,6 @@ struct TileArgs {
     int residual;              // MLP: add x (AttentionalGNN.forward's desc + delta); 0: the delta alone
     int want_q, want_kv;       // QKV: which of the projections leave
     char* dump;                // 256 bytes nobody reads: where a lane with nothing to store stores (see `sink` in the kernel)
-    int stagger;               // workgroup i starts ((i >> 3) % 32) x stagger us late (launch_fine_tile)
     const int* gate;
 #ifdef PATS_DIAG
     long long* tl;
@@ -480,7 +478,6 @@ gnn_fine_tile_kernel(TileArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (g.gate && *g.gate == 0) return;
     const int t_ = threadIdx.x, lane0 = t_ & 63, wave0 = __builtin_amdgcn_readfirstlane(t_ >> 6);
-    for (int i = (int)(blockIdx.x >> 3 & 31) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);       // ~1 us a step
     int64_t L = g.half;
     if (g.live) { const int64_t l_ = *g.live - g.live_off; L = l_ < 0 ? 0 : (l_ < g.half ? l_ : g.half); }
     const int64_t NQ = L * g.sets;                         // live problems: index qi -> problem (qi / L) * half + qi % L
@@ -1270,15 +1267,12 @@ static int launch_fine_tile(const char* tf_x, const char* tf_att, char* tf_out, 
     const h8v* pw = (const h8v*)mlp_section;
     const h8v* pwq = (const h8v*)qkv_section;
     TileArgs a{tf_x, tf_att, tf_out, qkv, pw, pw ? (const float*)(pw + FW_END) : nullptr, pwq, pwq ? (const float*)(pwq + FW_END) : nullptr,
-               P, P / sets, sets, live, live_off, flag, residual, want_q, want_kv, qkv + (size_t)P * QKV_BYTES, 0, gate};
+               P, P / sets, sets, live, live_off, flag, residual, want_q, want_kv, qkv + (size_t)P * QKV_BYTES, gate};
     if (!qkv) return PATS_ERR_INVALID;      // (every launch is handed the scratch area: its tail holds the sink of the masked stores)
     const int64_t ntile = 2 * P + (P + 3) / 4 + (P + 63) / 64;
     const unsigned wgs = (unsigned)std::min<int64_t>(ntile, cus);
-    // De-phasing: a tile ends in one burst of far-memory traffic (its ~270 KB of stores and the next tile's 132 KB gather), and a
-    // lockstep grid issues all 256 bursts at the same instants - each at the 1 / 256 share (~25 GB/s) of what the memory side serves.
-    // Workgroup i starts ((i >> 3) % 32) x 2 us late: the 32 CUs of an XCD spread over one tile period.
-    static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_TILE_STAGGER"); return e ? atoi(e) : -1; }();
-    a.stagger = stagger_env >= 0 ? stagger_env : (ntile >= 8 * (int64_t)wgs ? 2 : 0);
+    // (A start stagger of the workgroups - the attention kernel's de-phasing - was measured here and does nothing: the burst at the
+    //  end of a tile is bound by the rate a CU issues its stores, not by what the memory side serves.  DESIGN.md section 7a.)
 #ifdef PATS_DIAG
     a.tl = tl_begin(wgs);
 #endif
@@ -1307,10 +1301,12 @@ int launch_fine_attn(const char* qkv, int64_t shift, char* tf_att, int64_t P, co
     const int cus = fine_cus();
     if (cus <= 0) return PATS_ERR_UNSUPPORTED;
     const unsigned wgs = (unsigned)std::min<int64_t>(P, cus);
-    // De-phasing: the staging traffic comes in bursts that every workgroup of a lockstep grid issues at the same instants; workgroup i
-    // starts ((i >> 3) % 32) x 4 us late.  Only where a workgroup has enough problems to pay for the ramp.
+    // De-phasing (workgroup i starts ((i >> 3) % 32) x stagger us late) paid in the one-kernel layer, whose staging came in bursts that
+    // every workgroup of a lockstep grid issued at the same instants.  With a staging wave per operand the fills are spread over the
+    // heads: at 4 096 problems the kernel runs 0.556 ms without it and 0.623 with 4 us steps (profiles/r05_gnn_fine_attn_stagger.txt).
+    // Off; the diagnostic library still reads PATS_FINE_STAGGER.
     static const int stagger_env = [] { const char* e = diag_env("PATS_FINE_STAGGER"); return e ? atoi(e) : -1; }();
-    const int stagger = stagger_env >= 0 ? stagger_env : (P >= 8 * (int64_t)wgs ? 4 : 0);
+    const int stagger = stagger_env >= 0 ? stagger_env : 0;
     AttnArgs a{qkv, tf_att, P, shift, gate, live, live_off, P / sets, sets, stagger};
 #ifdef PATS_DIAG
     a.tl = tl_begin(wgs);

@@ -242,3 +242,37 @@ def test_fused_gnn_layer_25920_problems_identical_from_the_first_launch_of_a_pro
     assert len(lines) == 2
     for ln in lines:
         assert ln.endswith("[0, 0, 0]"), ln
+
+
+FINE_STACK_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(repo)r)
+from pats_amd import ops, synth
+C, n, rows = 264, 145, 2048
+layers = [ops.PropagationParams(synth.gnn_params(seed=20 + i, C=C)) for i in range(4)]
+names = ["self", "cross", "self", "cross"]
+g = torch.Generator(device="cuda"); g.manual_seed(12)
+d0 = torch.randn((rows, C, n), device="cuda", generator=g); d1 = torch.randn((rows, C, n), device="cuda", generator=g)
+runs = []
+for _ in range(4):                                   # launch 0 = the process's first
+    a, b = ops.attentional_gnn(d0, d1, layers, names)
+    runs.append(torch.cat([a, b]).clone())
+torch.cuda.synchronize()
+print("DIFF", [int((r != runs[0]).flatten(1).any(1).sum()) for r in runs[1:]], bool(torch.isfinite(runs[0]).all()))
+"""
+
+
+def test_fine_level_gnn_stack_4096_problems_identical_from_the_first_launch_of_a_process():
+    """The fine level's three-kernel layer (csrc/gnn_fine.hip: gnn_fine_tile_kernel on flattened 64-column tiles - fp16-split MFMA
+    products, LDS DMA gathers, masked stores through a sink - and gnn_fine_attn_kernel in wave roles with its two staging waves) as a
+    four-layer self / cross stack on 2 x 2 048 rows of [264, 145] in a FRESH process with no pre-heat: four runs on the same inputs are
+    bit-identical, the first included (every workgroup owns 36 tiles / 16 problems: the LDS slots, the projections' scratch blocks and
+    the staging buffers are all reused)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", FINE_STACK_CHILD % {"repo": repo}], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIFF")]
+    assert len(lines) == 1 and lines[0].endswith("[0, 0, 0] True"), lines
