@@ -811,7 +811,7 @@ def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
     cost build (first_layer.py:102, second_layer.py:89, third_layer.py:148), random weights, timed at the step's own problem
     counts - one AttentionalPropagation per level (both descriptor sides), scaled by the reference's layer counts (18 / 18 / 10).
     Third level: the fused kernel of csrc/gnn_fused.hip (BatchNorm as PATS.eval() leaves it: running statistics outdoors, batch
-    statistics indoors, pats.py:112-118); fine level: the one-kernel layer of csrc/gnn_fine.hip, run as a stack (round 5); coarse
+    statistics indoors, pats.py:112-118); fine level: the tile + attention kernels of csrc/gnn_fine.hip, run as a stack (round 5); coarse
     level: five packed-weights convolutions (csrc/conv_pk.hip) around the general attention kernel.  The MEASURED counterpart - whole
     steps with every head inside - is with_gnn_leg / `bench.py --with-gnn`."""
     gen = torch.Generator(device=dev)
@@ -856,17 +856,20 @@ def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
                     "(token padding 80 / 65 not counted); hbm_frac = x + source + residual in, out (4 x 33 KB per problem) against 8 TB/s"}
     roof["frac"] = roof["achieved"] / F16_PEAK_TFLOPS
     flops2 = 2.0 * 145 * (4 * 264 * 264 + 528 * 528 + 528 * 264) + 4 * 2 * (2.0 * 145 * 145 * 66)
-    by2 = 264 * 145 * 4.0 * 5              # source image, x image in; residual (fp32) in; out as fp32 + as image (the q / k / v / attention /
-                                           # hidden traffic stays in the per-workgroup scratch blocks: L2 / Infinity Cache, not counted here)
-    fine = {"kernel": "gnn_fine_layer_kernel (AttentionalPropagation at [264,145] as ONE kernel, both descriptor sets = %d problems per launch)" % (2 * b2),
+    by2 = 4 * 153120.0 + 2 * 475680.0      # per problem and layer, all of it past the L2: x and attention images in, attention and output images
+                                           # out (4 x 153 120 B), the block of projections (q, k, v^T as fragments: 475 680 B) written and read
+    fine = {"kernel": "gnn_fine_tile_kernel + gnn_fine_attn_kernel (AttentionalPropagation at [264,145], two launches a layer, both descriptor sets = %d problems per launch)" % (2 * b2),
             "bound": "mfma", "achieved": 3.0 * flops2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e12, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "ms_per_launch": 2.0 * t2 * b2 / rows_step, "ms_per_4096_problems": t2 * 4096.0 / rows_step,
             "algorithmic_tflops": flops2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e12,
             "hbm_frac": by2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "one persistent workgroup per CU per problem: descriptor images by LDS DMA, outputs in the accumulators, q / k / v / "
-                    "attention / hidden[0:264] through a per-workgroup scratch block (2.7 MB of L2-missing traffic per problem at the "
-                    "6.3 TB/s the chip sustains for it: the layer is bound by that, not by the matrix pipe); same 3 x pricing as the third "
-                    "level's fused layer; timed as a 4-layer stack, conversions at its ends included"}
+            "note": "per-token products (mlp of layer l + q / k / v of layer l + 1) on 64-column tiles of the flattened (problem, token tile) "
+                    "list, operands by LDS DMA, outputs in the accumulators, hidden tensor never off the CU; attention core per problem in wave "
+                    "roles; same 3 x pricing as the third level's fused layer against the NOMINAL dense fp16 peak - the tile kernel clocks to "
+                    "the power budget (1.5-2.0 GHz by box; the same instruction stream on all-zero operands runs 21 % faster: "
+                    "profiles/r05_gnn_fine_power_zeros_ab.txt), matrix pipe 49-59 % busy at the clock it gets; hbm_frac = 1.56 MB per problem "
+                    "and layer (four descriptor images + the projections written and read) against 8 TB/s; timed as a 4-layer stack, "
+                    "conversions at its ends and the first layer's own projection launch included"}
     fine["frac"] = fine["achieved"] / F16_PEAK_TFLOPS
     roof["fine_level_layer"] = fine
     return {"ms_per_step": per_step, "layers": {"coarse": 18, "fine": 18, "third": 10},
