@@ -791,18 +791,23 @@ def secondary_rooflines(ops, dev):
                 "against": "the reference's own run (tests/golden/roofline_4097.npz)"}
         assert real_r + real_c == 0, "config 5: a match index differs from the reference's beyond a 4-ulp tie"
         del Z, Zc
-    res.append({"kernel": "stream_sweep_kernel + stream_colreduce_kernel, config 5 (4097^2, %d sweeps)" % iters5, "bound": "hbm", "achieved": gbs,
+    nblk5, np5 = (M + 16) // 17, (M + 3) & ~3
+    phys = (2.0 * nblk5 * np5 * 4 + nblk5 * 8.0 * M + 8.0 * M) * iters5 / (ms * 1e-3) / 1e9
+    res.append({"kernel": "stream_resident_kernel, config 5 (4097^2, %d sweeps in one launch, K register-resident)" % iters5, "bound": "hbm", "achieved": gbs,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms, "sweeps_per_s": iters5 / (ms * 1e-3),
-                "algorithmic_GBps": gbs, "physical_GBps": 0.5 * gbs, "physical_frac_of_6300_GBps_measured_ceiling": 0.5 * gbs / 6300.0,
+                "algorithmic_GBps": gbs, "physical_GBps": phys,
                 "argmax_vs_reference": ties,
-                "note": "algorithmic = SURVEY 8d's two-pass model, 8*M*N bytes per sweep; PHYSICAL = what the kernels move: the sweep "
-                        "kernel reads K once per sweep (4*M*N = 67 MB) and keeps it in registers for the column partials - half the "
-                        "model's bytes, so `frac` flatters the memory system by 2 x: physical_GBps is the rate to judge.  The matrix "
-                        "does not fit the 32 MB of L2, and L2 misses are served at ~6.3-6.7 TB/s in aggregate whether they hit the "
-                        "Infinity Cache or HBM (tools/dma_far_probe.hip: 2.5 GB set 6.3, 98 MB set 6.7 TB/s).  In the kernel trace a "
-                        "sweep is 13.1 us of stream_sweep_kernel (5.1 TB/s physical = 0.81 of that ceiling) + 4.1 us of the dependent "
-                        "column reduce (65 workgroups, at the launch floor): 58 000 sweeps/s; the ceiling of this two-launch form "
-                        "is ~68 000"})
+                "note": "algorithmic = SURVEY 8d's two-pass model, 8*M*N bytes per sweep - the figure the roofline is quoted against, and since "
+                        "round 5 a MODEL only: stream_resident_kernel (csrc/sinkhorn_stream.hip) keeps every workgroup's 17 x 4097 piece of K "
+                        "in registers for all 200 sweeps, so a sweep moves no K at all - PHYSICAL traffic per sweep = 241 rows of column "
+                        "partials written and read (2 x 3.95 MB), the 33 KB of {b_j, sweep} granules every workgroup polls, nothing else; "
+                        "`frac` therefore says how much faster the solve runs than a two-pass streaming solve at 8 TB/s could, not how busy "
+                        "HBM is.  What bounds a sweep now is two grid-wide hand-overs through memory that is not coherent across XCDs "
+                        "(timeline of the diagnostic build, us per sweep: the barrier behind the partials 5.8 - write-through of the stores, "
+                        "arrival, poll - the wait for the granules of the new b 5.8, row dots 1.7, reduce 0.9): 14.2 us = 70 400 sweeps/s "
+                        "against 17.1 us = 58 700 for round 4's two launches a sweep (13.1 us of it the 67 MB read of K; hipGraph replay "
+                        "of those 400 launches: 59 200 - the gaps are GPU-side, tools/config5_graph_probe.py).  Spins are bounded: a grid "
+                        "that is not fully resident gives up and the problem is re-solved by the log-domain kernel"})
     return res
 
 

@@ -16,9 +16,18 @@
 //                         "two passes" model (8 M N).
 //   stream_colreduce_kernel  b_j = nu_j / sum_blocks partial[block][j]   (16 waves split the blocks)
 //
+// Since round 5 the 4097^2-class shape (one problem, N in 4097..4608, at most one 17-row block per CU) runs ALL its sweeps in ONE
+// launch instead: stream_resident_kernel keeps a workgroup's 17 x N piece of K in REGISTERS (153 a lane) for the whole solve, so a
+// sweep moves no K at all - 16 KB of column partials out, 17 columns' worth of partials and the 16 KB scaling vector in - and pays two
+// grid-wide barriers instead of two kernel boundaries and a 67 MB read.  See the kernel.
+//
 // Set-up (row max, column max of Z - r, K build) and the epilogue (duals back to log space,
 // Z_out = ((Z + u) + v) - norm, guard) are plain streaming kernels.  Deterministic: no atomics.
 #include "common.hpp"
+#include <algorithm>
+#ifdef PATS_DIAG
+#include <cstdio>
+#endif
 
 namespace pats {
 
@@ -198,10 +207,247 @@ stream_sweep_kernel(const float* __restrict__ K, int M, int N, const float* __re
     }
 }
 
+// ---- all sweeps of one problem in one launch: K register-resident ------------------------------------------------------------
+// Grid = nblk workgroups (blocks of RB = 17 rows), ALL co-resident (the host launches it only when nblk <= CUs; a workgroup's 153 +
+// registers a lane admit one per CU).  Thread t owns columns 8 t .. 8 t + 7 and, in a ninth slot, column 4096 + t (N <= 4608).
+// A sweep:   b -> registers (from the set-up's vector in sweep 0, then from GRANULES, below); row dots -> a (local);
+//            column partials of the block -> partial[blk][NP] (rows padded to 16 bytes: two 16-byte stores a thread);
+//            GRID BARRIER;
+//            workgroup g < ceil(N / 32) reduces columns 32 g .. 32 g + 31 over all blocks in a fixed order (16-byte loads: eight
+//            threads a block row, 64 slices of the blocks) -> b_j, published as an 8-byte granule {b_j, sweep + 1}.
+// There is no second barrier: a thread of the next sweep polls ITS nine granules until their tags say "this sweep" (the micro-arch
+// guide's cheapest transport: one naturally aligned 8-byte {data, tag} written by ONE store).  That is safe: a reducer publishes a
+// group only after it has read every partial of it, so a workgroup that holds all granules may overwrite its partial row; and a
+// reducer overwrites a granule only behind the next barrier, which every reader of the old one has passed.
+// What crosses workgroups is stored and loaded `sc1`: written through to memory and read past the caches that are not coherent
+// across XCDs (guide: "16 B sc1 stores AND sc1 loads") - the 16-byte ones as inline assembly (an atomic gives 8 bytes at most; the
+// loads' `s_waitcnt vmcnt(0)` is explicit, the compiler does not see them), granules and counters as agent-scope relaxed atomics.
+// So the barrier needs NO release / acquire fence (buffer_wbl2 / buffer_inv: 1.7-6.5 us each), only `s_waitcnt vmcnt(0)` before the
+// arrival.  The barrier: eight monotonic arrival counters (shard = blk & 7, 64 bytes apart: one word takes ~88 arrivals a
+// microsecond), thread 0 adds 1 to its shard's and polls all eight until each has reached generation x shard size.  EVERY spin is
+// bounded: a workgroup that never sees the others (fewer CUs available than the launch assumed) gives up after ~0.2 s, raises *err,
+// and the problem is re-solved by the log-domain kernel like any guard failure - a wrong residency assumption costs time, not a hang.
+// Deterministic: fixed reduction orders.
+constexpr int RES_RB = 17, RES_CPT = 9;
+constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
+typedef float f4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st4_sc1(float* p, const f4s v) {                  // p 16-byte aligned
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f4s ld4_sc1_issue(const float* p) {                    // pair with ld4_sc1_wait before the value is used
+    f4s v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld4_sc1_wait(f4s& a) {                            // the values pass through: nothing uses them earlier
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) :: "memory");
+}
+__device__ __forceinline__ void ld4_sc1_wait(f4s& a, f4s& b, f4s& c, f4s& d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+}
+// granule {value, tag}
+__device__ __forceinline__ void st_granule(unsigned long long* g, float v, unsigned tag) {
+    __hip_atomic_store(g, (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)tag << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ld_granule(const unsigned long long* g, unsigned tag, float& v) {
+    const unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = __builtin_bit_cast(float, (unsigned)(x & 0xffffffffu));
+    return (unsigned)(x >> 32) == tag;
+}
+
+// grid-wide barrier, generation gen = 1, 2, ...; returns false when it gave up (then every workgroup gives up: the counters stop)
+__device__ __forceinline__ bool res_grid_sync(unsigned* cnt, unsigned gen, int nblk, int* lds_ok) {
+    __builtin_amdgcn_s_waitcnt(0);                     // this thread's sc1 stores are written through
+    wg_barrier();
+    if (threadIdx.x == 0) {
+        const int blk = blockIdx.x;
+        __hip_atomic_fetch_add(&cnt[(blk & 7) * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (unsigned spin = 0; spin < RES_SPIN_LIMIT; ++spin) {
+            bool all = true;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const unsigned members = (unsigned)((nblk - x + 7) >> 3);          // workgroups with blk & 7 == x
+                const unsigned v = __hip_atomic_load(&cnt[x * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && v >= gen * members;
+            }
+            if (all) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *lds_ok = ok;
+    }
+    wg_barrier();
+    return *lds_ok != 0;
+}
+
+__global__ void __launch_bounds__(ST)
+stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, const float* __restrict__ log_mu,
+                       const float* __restrict__ log_nu, float* __restrict__ avec, float* partial, int nblk, int iters,
+                       unsigned* cnt, int* err, long long* tl) {
+    constexpr int RB = RES_RB, CPT = RES_CPT;
+#ifdef PATS_DIAG
+    long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
+#define RT(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_amdgcn_s_memrealtime(); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RT(k) do { } while (0)
+#endif
+    __shared__ float red[SW][RB];
+    __shared__ float a_s[RB];
+    __shared__ float red2[64][33];
+    __shared__ int sync_ok;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, blk = blockIdx.x;
+    const int NP = (N + 3) & ~3;                                   // row pitch of `partial`: 16-byte rows
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(partial + (size_t)nblk * NP);      // N granules behind the rows
+    // ---- this thread's piece of K: rows blk RB .., columns 8 t .. 8 t + 7 and 4096 + t --------------------------------------------
+    float kv[RB][CPT];
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+        const int i = blk * RB + k;
+        const float* Kr = K + (int64_t)i * N;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = 8 * t + q;
+            kv[k][q] = (i < M && j < N) ? Kr[j] : 0.f;
+        }
+        const int j8 = 4096 + t;
+        kv[k][8] = (i < M && j8 < N) ? Kr[j8] : 0.f;
+    }
+    float mu = 0.f;
+    if (t < RB && blk * RB + t < M) mu = expf(log_mu[blk * RB + t]);
+    // the columns this workgroup reduces: group blk of 32, four columns a thread (c4), 64 slices of the blocks (rs)
+    const int ngroups = (N + 31) >> 5;
+    const int c4 = t & 7, rs = t >> 3;
+    const int rj0 = blk * 32 + 4 * c4;
+    const bool reducer = blk < ngroups && rj0 < NP;
+    float nu = 0.f;
+    if (t < 32 && blk < ngroups && blk * 32 + t < N) nu = expf(log_nu[blk * 32 + t]);
+    bool alive = true;
+    for (int it = 0; it < iters && alive; ++it) {
+        // ---- b -> registers ---------------------------------------------------------------------------------------------------------
+        float bq[CPT];
+        if (it == 0) {                                             // the set-up's vector (a kernel boundary behind us)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bq[q] = 8 * t + q < N ? bvec[8 * t + q] : 0.f;
+            bq[8] = 4096 + t < N ? bvec[4096 + t] : 0.f;
+        } else {
+            bool ok = false;
+            const unsigned want = (unsigned)it;
+            for (unsigned spin = 0; spin < RES_SPIN_LIMIT && !ok; ++spin) {
+                ok = true;
+                // (8-byte agent-scope atomic loads, one granule each.  Four 16-byte `sc1` loads by inline assembly were tried here and
+                //  hipcc (ROCm 7.2) MISCOMPILES the component reads behind them: `g.y == want && g.w == want` on an asm-defined
+                //  float4 became ONE compare of g.x - every poll "failed" and the kernel gave up; tools/asm_vec_component_repro.hip.
+                //  Whole-vector arithmetic on such a value - the reducers' sums - is translated correctly.)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = 8 * t + q;
+                    if (j < N) ok = ld_granule(gran + j, want, bq[q]) && ok;
+                    else bq[q] = 0.f;
+                }
+                if (4096 + t < N) ok = ld_granule(gran + 4096 + t, want, bq[8]) && ok;
+                else bq[8] = 0.f;
+            }
+            if (!ok) alive = false;                                // (every thread still walks to the barrier: it fails there too)
+        }
+        RT(0);
+        // ---- row dots: per-thread partials, wave all-reduce, then across the 8 waves through LDS ---------------------------------
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) p = fmaf(kv[k][q], bq[q], p);
+            p = wave_sum(p);
+            if (lane == 0) red[wave][k] = p;
+        }
+        wg_barrier();
+        if (t < RB) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < SW; ++w) s += red[w][t];
+            const float a = blk * RB + t < M ? mu * __builtin_amdgcn_rcpf(s) : 0.f;
+            a_s[t] = a;
+            if (it + 1 == iters && blk * RB + t < M) avec[blk * RB + t] = a;
+        }
+        wg_barrier();
+        RT(1);
+        // ---- column partials of this row block ---------------------------------------------------------------------------------
+        {
+            float* pb = partial + (size_t)blk * NP;
+            float acc[CPT];
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                acc[q] = 0.f;
+#pragma unroll
+                for (int k = 0; k < RB; ++k) acc[q] = fmaf(kv[k][q], a_s[k], acc[q]);
+            }
+            if (8 * t < NP) st4_sc1(pb + 8 * t, f4s{acc[0], acc[1], acc[2], acc[3]});
+            if (8 * t + 4 < NP) st4_sc1(pb + 8 * t + 4, f4s{acc[4], acc[5], acc[6], acc[7]});
+            if (4096 + t < N) st_sc1(pb + 4096 + t, acc[8]);
+        }
+        RT(2);
+        if (!res_grid_sync(cnt, (unsigned)(it + 1), nblk, &sync_ok)) alive = false;
+        RT(3);
+        if (!alive) break;
+        // ---- b_j = nu_j / sum over the blocks, columns 32 blk .. -------------------------------------------------------------------
+        if (blk < ngroups) {                                       // (workgroup-uniform)
+            f4s v = {0.f, 0.f, 0.f, 0.f};
+            if (reducer) {
+                f4s x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, x2 = x0, x3 = x0;
+                const float* src = partial + rj0;
+                if (rs < nblk) x0 = ld4_sc1_issue(src + (size_t)rs * NP);
+                if (rs + 64 < nblk) x1 = ld4_sc1_issue(src + (size_t)(rs + 64) * NP);
+                if (rs + 128 < nblk) x2 = ld4_sc1_issue(src + (size_t)(rs + 128) * NP);
+                if (rs + 192 < nblk) x3 = ld4_sc1_issue(src + (size_t)(rs + 192) * NP);
+                ld4_sc1_wait(x0, x1, x2, x3);
+                v = ((x0 + x1) + x2) + x3;
+                for (int bk = rs + 256; bk < nblk; bk += 64) {     // (nblk <= 256 on this part: not taken)
+                    f4s x = ld4_sc1_issue(src + (size_t)bk * NP);
+                    ld4_sc1_wait(x);
+                    v = v + x;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red2[rs][4 * c4 + e] = v[e];
+            wg_barrier();
+            {                                                      // 64 slices -> 16 (four a thread) -> 1: the publishers' chain is 4 + 16 reads, not 63
+                const int col = t & 31, part = t >> 5;
+                const float s4 = ((red2[4 * part][col] + red2[4 * part + 1][col]) + red2[4 * part + 2][col]) + red2[4 * part + 3][col];
+                wg_barrier();
+                red2[part][col] = s4;
+                wg_barrier();
+            }
+            if (t < 32) {
+                const int j = blk * 32 + t;
+                float s = red2[0][t];
+#pragma unroll
+                for (int w = 1; w < 16; ++w) s += red2[w][t];
+                if (j < N) {
+                    const float bj = nu * __builtin_amdgcn_rcpf(s);
+                    st_granule(gran + j, bj, (unsigned)(it + 1));
+                    if (it + 1 == iters) st_sc1(bvec + j, bj);
+                }
+            }
+        }
+        RT(4);
+    }
+    if (!alive && t == 0) atomicOr(err, 1);
+#ifdef PATS_DIAG
+    if (tl && t == 0) for (int k = 0; k < 5; ++k) tl[blk * 6 + k] = tsum[k];
+#endif
+}
+
 // ---- epilogue: guard + Z_out = ((Z + u) + v) - norm -------------------------------------------------
 __global__ void __launch_bounds__(ST)
 stream_guard_kernel(const float* __restrict__ a, int M, const float* __restrict__ bvec, int N,
-                    int* __restrict__ fail) {
+                    int* __restrict__ fail, const int* __restrict__ err) {
     __shared__ float scratch[SW];
     const int b = blockIdx.x;
     float bad = 0.f;
@@ -214,7 +460,7 @@ stream_guard_kernel(const float* __restrict__ a, int M, const float* __restrict_
         if (!(x <= 1073741824.0f && x > 0.f)) bad = 1.f;
     }
     bad = block_allreduce(bad, OpMax(), scratch);
-    if (threadIdx.x == 0) fail[b] = bad > 0.f ? 1 : 0;
+    if (threadIdx.x == 0) fail[b] = (bad > 0.f || (err && *err != 0)) ? 1 : 0;      // err: the resident kernel gave up at a barrier
 }
 
 __global__ void __launch_bounds__(ST)
@@ -249,6 +495,7 @@ size_t stream_workspace_bytes(int64_t batch, int M, int N) {
     f += al256((size_t)batch * nblk * N * 4);       // partial
     f += 2 * al256((size_t)batch * M * 4);          // r, a
     f += 2 * al256((size_t)batch * N * 4);          // c, b
+    f += 1024;                                      // the resident kernel's arrival counters (8 x 64 B) and its give-up flag
     return f;
 }
 
@@ -285,14 +532,46 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
     float* r = (float*)p;        p += al256((size_t)batch * M * 4);
     float* a = (float*)p;        p += al256((size_t)batch * M * 4);
     float* c = (float*)p;        p += al256((size_t)batch * N * 4);
-    float* bv = (float*)p;
+    float* bv = (float*)p;       p += al256((size_t)batch * N * 4);
+    unsigned* cnt = (unsigned*)p;
+    int* err = (int*)(p + 512);
     const dim3 rows_grid(M, (unsigned)batch), blk_grid(nblk, (unsigned)batch), col_grid((N + 63) / 64, (unsigned)batch);
     hipLaunchKernelGGL(stream_rowmax_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r);
     if (rb17) hipLaunchKernelGGL((stream_colmax_partial_kernel<17>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
     else hipLaunchKernelGGL((stream_colmax_partial_kernel<16>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
     hipLaunchKernelGGL((stream_colreduce_kernel<0>), col_grid, dim3(1024), 0, st, partial, nblk, N, log_nu, c, bv);
     hipLaunchKernelGGL(stream_kbuild_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r, c, K);
-    for (int it = 0; it < iters; ++it) {
+    // one problem of the 4097^2 class, every 17-row block on its own CU: all sweeps in one launch, K in registers
+    static const bool resident_off = [] { const char* e = diag_env("PATS_STREAM_RESIDENT"); return e && atoi(e) == 0; }();
+    const int NPr = (N + 3) & ~3;
+    const bool resident = !resident_off && batch == 1 && rb17 && cpt == RES_CPT && nblk <= n_cu && nblk <= 256 && (N + 31) / 32 <= nblk &&
+                          (size_t)nblk * NPr + 2 * (size_t)N <= (size_t)((M + 15) / 16) * N && iters > 0;
+#ifdef PATS_DIAG
+    if (diag_env("PATS_STREAM_TRACE")) fprintf(stderr, "launch_stream: batch %lld M %d N %d cpt %d rb17 %d nblk %d n_cu %d iters %d -> resident %d\n", (long long)batch, M, N, cpt, (int)rb17, nblk, n_cu, iters, (int)resident);
+#endif
+    if (resident) {
+        if (int rc = fill_bytes(cnt, 0, 1024, st)) return rc;
+        long long* tl = nullptr;
+#ifdef PATS_DIAG
+        if (diag_env("PATS_STREAM_TL")) { (void)hipMalloc((void**)&tl, (size_t)nblk * 6 * 8); (void)hipMemset(tl, 0, (size_t)nblk * 6 * 8); }
+#endif
+        hipLaunchKernelGGL(stream_resident_kernel, dim3(nblk), dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, nblk, iters, cnt, err, tl);
+#ifdef PATS_DIAG
+        if (tl) {
+            (void)hipStreamSynchronize(st);
+            static long long h[256 * 6];
+            (void)hipMemcpy(h, tl, (size_t)nblk * 6 * 8, hipMemcpyDeviceToHost);
+            static const char* names[5] = {"b -> registers (granule wait)", "row dots -> a", "column partials + stores issued", "grid barrier", "reduce + publish (reducers)"};
+            for (int k = 0; k < 5; ++k) {
+                double sum = 0, mx = 0;
+                for (int w = 0; w < nblk; ++w) { sum += (double)h[w * 6 + k]; mx = std::max(mx, (double)h[w * 6 + k]); }
+                fprintf(stderr, "  resident sweep: %-34s mean %.2f us, slowest workgroup %.2f us per sweep\n", names[k], sum / nblk / iters / 100.0, mx / iters / 100.0);
+            }
+            (void)hipFree(tl);
+        }
+#endif
+    }
+    for (int it = 0; it < (resident ? 0 : iters); ++it) {
         if (rb17) {
             switch (cpt) {
                 case 7: launch_sweep<17, 7>(K, M, N, bv, log_mu, a, partial, nblk, batch, st); break;
@@ -320,7 +599,7 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
         (void)hipMemsetAsync(fail, 0xff, sizeof(int) * (size_t)batch, st);     // failure surfaces in check_launch
         return check_launch("streaming sinkhorn (iters == 0)");
     }
-    hipLaunchKernelGGL(stream_guard_kernel, dim3((unsigned)batch), dim3(ST), 0, st, a, M, bv, N, fail);
+    hipLaunchKernelGGL(stream_guard_kernel, dim3((unsigned)batch), dim3(ST), 0, st, a, M, bv, N, fail, resident ? (const int*)err : (const int*)nullptr);
     hipLaunchKernelGGL(stream_finish_kernel, rows_grid, dim3(ST), 0, st, src, M, N, a, r, bv, c, norm, fail, out);
     return check_launch("streaming sinkhorn");
 }

@@ -276,3 +276,27 @@ def test_fine_level_gnn_stack_4096_problems_identical_from_the_first_launch_of_a
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIFF")]
     assert len(lines) == 1 and lines[0].endswith("[0, 0, 0] True"), lines
+
+
+def test_resident_streaming_solve_4097_identical_and_every_workgroup_takes_part(ops):
+    """csrc/sinkhorn_stream.hip's stream_resident_kernel (BASELINE config 5's shape: all 200 sweeps of a 4097 x 4097 problem in ONE
+    launch, K in registers, partials and the scaling vector handed between the 241 workgroups through `sc1` stores, a counter barrier
+    and tagged granules - no fences): three solves on the same scores are bit-identical (a torn or stale hand-over would perturb the
+    duals), finite, and their marginals hold (a workgroup whose partials were missed would show in the column sums)."""
+    import torch
+    from pats_amd import synth
+    inp = synth.roofline_inputs()
+    d0, d1, ns = (torch.from_numpy(inp[k]).cuda() for k in ("d0", "d1", "ns"))
+    alpha = torch.tensor(float(inp["alpha"]), device="cuda")
+    S = ops.cost(d0, d1)
+    runs = [ops.log_optimal_transport(S, alpha, ns, 200) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.isfinite(runs[0]).all()
+    for k, r in enumerate(runs[1:]):
+        assert torch.equal(r, runs[0]), "solve %d differs from solve 0" % (k + 1)
+    # a sweep ends with the column update (modules.py:142): after any number of sweeps target j holds exactly its area ns_j and the
+    # dustbin column the 4096 sources' mass
+    cols = torch.exp(runs[0].double()).sum(1)
+    nsd = ns.reshape(1, -1).double()
+    assert ((cols[:, :-1] - nsd).abs() / nsd).max().item() <= 2e-5
+    assert abs(cols[0, -1].item() - 4096.0) / 4096.0 <= 2e-5

@@ -550,7 +550,9 @@ def test_roofline_config_4096(ops):
                                    (1, 4097, 3600),     # 8 columns per thread, blocks of 17 rows (one round of workgroups)
                                    (2, 4097, 3600),     # the same as a batch: 2 x 241 workgroups are two rounds, 2 x 257 three
                                    (1, 4100, 3100),     # 7 columns per thread, blocks of 17 rows
-                                   (1, 700, 4608)])     # the widest problem the streaming solver takes, blocks of 16 rows
+                                   (1, 700, 4608),      # the widest problem the streaming solver takes, blocks of 16 rows
+                                   (1, 4097, 4600)])    # one problem, 241 blocks of 17 rows, 9 columns per thread: all sweeps in ONE launch
+                                                        # (stream_resident_kernel: K in registers, grid barrier + granules), ragged last columns
 def test_streaming_solver_block_shapes(ops, oracle, B, M, N):
     """csrc/sinkhorn_stream.hip picks rows per workgroup and columns per thread from the shape: every branch of that
     choice against the oracle (modules.py:137-143), four sweeps."""
