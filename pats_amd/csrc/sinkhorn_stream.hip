@@ -241,17 +241,6 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 __device__ __forceinline__ void st4_sc1(float* p, const f4s v) {                  // p 16-byte aligned
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ f4s ld4_sc1_issue(const float* p) {                    // pair with ld4_sc1_wait before the value is used
-    f4s v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void ld4_sc1_wait(f4s& a) {                            // the values pass through: nothing uses them earlier
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) :: "memory");
-}
-__device__ __forceinline__ void ld4_sc1_wait(f4s& a, f4s& b, f4s& c, f4s& d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
-}
 // granule {value, tag}
 __device__ __forceinline__ void st_granule(unsigned long long* g, float v, unsigned tag) {
     __hip_atomic_store(g, (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)tag << 32), __ATOMIC_RELAXED,
@@ -264,14 +253,15 @@ __device__ __forceinline__ bool ld_granule(const unsigned long long* g, unsigned
 }
 
 // grid-wide barrier, generation gen = 1, 2, ...; returns false when it gave up (then every workgroup gives up: the counters stop)
-__device__ __forceinline__ bool res_grid_sync(unsigned* cnt, unsigned gen, int nblk, int* lds_ok) {
+// (wait = false: arrive only - a workgroup that reduces nothing needs nobody's partials; what it waits for is the granules)
+__device__ __forceinline__ bool res_grid_sync(unsigned* cnt, unsigned gen, int nblk, int* lds_ok, bool wait) {
     __builtin_amdgcn_s_waitcnt(0);                     // this thread's sc1 stores are written through
     wg_barrier();
     if (threadIdx.x == 0) {
         const int blk = blockIdx.x;
         __hip_atomic_fetch_add(&cnt[(blk & 7) * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 0;
-        for (unsigned spin = 0; spin < RES_SPIN_LIMIT; ++spin) {
+        int ok = wait ? 0 : 1;
+        for (unsigned spin = 0; wait && spin < RES_SPIN_LIMIT; ++spin) {
             bool all = true;
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
@@ -340,7 +330,13 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
         } else {
             bool ok = false;
             const unsigned want = (unsigned)it;
+            // One granule is polled, then all nine are read and checked: the thread's eight consecutive columns sit in ONE 32-column
+            // group, whose granules leave their reducer in one store instruction - an eighth of the polling traffic of 241 x 512
+            // threads re-reading everything (the polls share the memory side with the reducers' loads they are waiting for).
+            const int jp = 8 * t < N ? (8 * t + 7 < N ? 8 * t + 7 : N - 1) : N - 1;
             for (unsigned spin = 0; spin < RES_SPIN_LIMIT && !ok; ++spin) {
+                float probe;
+                if (!ld_granule(gran + jp, want, probe)) continue;
                 ok = true;
                 // (8-byte agent-scope atomic loads, one granule each.  Four 16-byte `sc1` loads by inline assembly were tried here and
                 //  hipcc (ROCm 7.2) MISCOMPILES the component reads behind them: `g.y == want && g.w == want` on an asm-defined
@@ -393,26 +389,29 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
             if (4096 + t < N) st_sc1(pb + 4096 + t, acc[8]);
         }
         RT(2);
-        if (!res_grid_sync(cnt, (unsigned)(it + 1), nblk, &sync_ok)) alive = false;
+        if (!res_grid_sync(cnt, (unsigned)(it + 1), nblk, &sync_ok, blk < ngroups)) alive = false;
         RT(3);
         if (!alive) break;
         // ---- b_j = nu_j / sum over the blocks, columns 32 blk .. -------------------------------------------------------------------
         if (blk < ngroups) {                                       // (workgroup-uniform)
             f4s v = {0.f, 0.f, 0.f, 0.f};
             if (reducer) {
-                f4s x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, x2 = x0, x3 = x0;
+                // four block rows a thread (nblk <= 256), in ONE assembly statement with its wait: the compiler does not know that
+                // these registers are written asynchronously - between a separate "issue" and "wait" it may copy them
                 const float* src = partial + rj0;
-                if (rs < nblk) x0 = ld4_sc1_issue(src + (size_t)rs * NP);
-                if (rs + 64 < nblk) x1 = ld4_sc1_issue(src + (size_t)(rs + 64) * NP);
-                if (rs + 128 < nblk) x2 = ld4_sc1_issue(src + (size_t)(rs + 128) * NP);
-                if (rs + 192 < nblk) x3 = ld4_sc1_issue(src + (size_t)(rs + 192) * NP);
-                ld4_sc1_wait(x0, x1, x2, x3);
-                v = ((x0 + x1) + x2) + x3;
-                for (int bk = rs + 256; bk < nblk; bk += 64) {     // (nblk <= 256 on this part: not taken)
-                    f4s x = ld4_sc1_issue(src + (size_t)bk * NP);
-                    ld4_sc1_wait(x);
-                    v = v + x;
-                }
+                const float* p0 = src + (size_t)(rs < nblk ? rs : 0) * NP;
+                const float* p1 = src + (size_t)(rs + 64 < nblk ? rs + 64 : 0) * NP;
+                const float* p2 = src + (size_t)(rs + 128 < nblk ? rs + 128 : 0) * NP;
+                const float* p3 = src + (size_t)(rs + 192 < nblk ? rs + 192 : 0) * NP;
+                f4s x0, x1, x2, x3;
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                             "global_load_dwordx4 %1, %5, off sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off sc1\n\t"
+                             "global_load_dwordx4 %3, %7, off sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+                const f4s z4 = {0.f, 0.f, 0.f, 0.f};
+                v = (((rs < nblk ? x0 : z4) + (rs + 64 < nblk ? x1 : z4)) + (rs + 128 < nblk ? x2 : z4)) + (rs + 192 < nblk ? x3 : z4);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) red2[rs][4 * c4 + e] = v[e];
