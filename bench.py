@@ -793,16 +793,17 @@ def secondary_rooflines(ops, dev):
         del Z, Zc
     nblk5, np5 = (M + 16) // 17, (M + 3) & ~3
     phys = (2.0 * nblk5 * np5 * 4 + nblk5 * 8.0 * M + 8.0 * M) * iters5 / (ms * 1e-3) / 1e9
-    res.append({"kernel": "stream_resident_kernel, config 5 (4097^2, %d sweeps in one launch, K register-resident)" % iters5, "bound": "hbm", "achieved": gbs,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": ms, "sweeps_per_s": iters5 / (ms * 1e-3),
-                "algorithmic_GBps": gbs, "physical_GBps": phys,
+    res.append({"kernel": "stream_resident_kernel, config 5 (4097^2, %d sweeps in one launch, K register-resident)" % iters5, "bound": "hbm", "achieved": phys,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": phys / HBM_PEAK_GBS, "ms": ms, "sweeps_per_s": iters5 / (ms * 1e-3),
+                "streaming_model_GBps": gbs, "resident_model_GBps": 8.0 * M * M / (ms * 1e-3) / 1e9, "physical_GBps": phys,
                 "argmax_vs_reference": ties,
-                "note": "algorithmic = SURVEY 8d's two-pass model, 8*M*N bytes per sweep - the figure the roofline is quoted against, and since "
-                        "round 5 a MODEL only: stream_resident_kernel (csrc/sinkhorn_stream.hip) keeps every workgroup's 17 x 4097 piece of K "
+                "note": "achieved / frac = the PHYSICAL traffic of the solve against 8 TB/s.  SURVEY 8d prices a sweep at 8*M*N bytes when it "
+                        "streams (streaming_model_GBps: what a two-pass streaming solve would have to move at this sweep rate - more than HBM "
+                        "can deliver) and the whole problem at 8*M*N when it is on-chip resident (resident_model_GBps); since round 5 the "
+                        "solve IS resident: stream_resident_kernel (csrc/sinkhorn_stream.hip) keeps every workgroup's 17 x 4097 piece of K "
                         "in registers for all 200 sweeps, so a sweep moves no K at all - PHYSICAL traffic per sweep = 241 rows of column "
                         "partials written and read (2 x 3.95 MB), the 33 KB of {b_j, sweep} granules every workgroup polls, nothing else; "
-                        "`frac` therefore says how much faster the solve runs than a two-pass streaming solve at 8 TB/s could, not how busy "
-                        "HBM is.  What bounds a sweep now is two grid-wide hand-overs through memory that is not coherent across XCDs "
+                        "the memory system is a seventh busy.  What bounds a sweep now is two grid-wide hand-overs through memory that is not coherent across XCDs "
                         "(timeline of the diagnostic build, us per sweep: the barrier behind the partials 5.8 - write-through of the stores, "
                         "arrival, poll - the wait for the granules of the new b 5.8, row dots 1.7, reduce 0.9): 14.2 us = 70 400 sweeps/s "
                         "against 17.1 us = 58 700 for round 4's two launches a sweep (13.1 us of it the 67 MB read of K; hipGraph replay "
