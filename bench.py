@@ -877,6 +877,9 @@ def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
                     "and layer (four descriptor images + the projections written and read) against 8 TB/s; timed as a 4-layer stack, "
                     "conversions at its ends and the first layer's own projection launch included"}
     fine["frac"] = fine["achieved"] / F16_PEAK_TFLOPS
+    # the matrix pipe's own rate on random operands (tools/mfma_rate_probe.hip, profiles/r05_mfma_rate_probe.txt): 1 720 TFLOP/s at the
+    # 1.74 GHz the part sustains on toggling data - what a split-fp16 product can at most reach here
+    fine["frac_of_measured_random_operand_ceiling_1720_TFLOPs"] = fine["achieved"] / 1720.0
     roof["fine_level_layer"] = fine
     return {"ms_per_step": per_step, "layers": {"coarse": 18, "fine": 18, "third": 10},
             "sample": {"third": "%d of %d problems" % (b3, P_step), "fine": "%d of %d rows" % (b2, rows_step), "coarse": "%d of %d pairs" % (b1, pairs)},
