@@ -1417,6 +1417,24 @@ def main():
             torch.cuda.synchronize()
             res["value_" + other_maps] = pairs * steps / (time.perf_counter() - t1)
             nets.set_layout(args.maps == "nhwc")
+            if args.overlap == 0:
+                # the same steps with the HBM-bound stages of one batch beside the VALU-bound stages of its neighbour (two streams with
+                # disjoint CU masks, `--overlap 3`): what the pairing buys - reported beside the headline, which stays on ONE stream
+                # (every kernel with the whole GPU: per-kernel rooflines unambiguous, the per-step status watch in place)
+                try:
+                    n_cu_ = torch.cuda.get_device_properties(dev).multi_processor_count
+                    st2 = (ops.masked_stream([c for c in range(n_cu_) if c // 32 < 3]), ops.masked_stream([c for c in range(n_cu_) if c // 32 >= 3]))
+                    run_steps(batch, nets, cap, wl, None, 2, st2)
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    run_steps(batch, nets, cap, wl, None, steps, st2)
+                    torch.cuda.synchronize()
+                    res["value_two_masked_streams"] = {"pairs_per_s": pairs * steps / (time.perf_counter() - t2), "overlap": 3,
+                                                       "note": "gathers + crops of batch i on 3 of every 8 CUs of each shader engine beside the solvers of "
+                                                               "batch i - 1 on the other 5 (bench.py --overlap 3); not the headline"}
+                    del st2
+                except Exception as e:                   # noqa: BLE001  (a runtime without CU-mask streams)
+                    res["value_two_masked_streams"] = {"error": repr(e)[:200]}
             gnn, gnn_roof = gnn_secondary(ops, dev, pairs, rows_step, P_step, 1e3 * dt / max(steps, 1), wl["outdoor"])
             res["gnn"] = gnn
             res["gnn"]["measured"] = with_gnn_leg(ops, batch, dev, nets, cap, wl, h, w, 2)
