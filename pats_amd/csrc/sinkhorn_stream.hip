@@ -543,7 +543,19 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
     // one problem of the 4097^2 class, every 17-row block on its own CU: all sweeps in one launch, K in registers
     static const bool resident_off = [] { const char* e = diag_env("PATS_STREAM_RESIDENT"); return e && atoi(e) == 0; }();
     const int NPr = (N + 3) & ~3;
-    const bool resident = !resident_off && batch == 1 && rb17 && cpt == RES_CPT && nblk <= n_cu && nblk <= 256 && (N + 31) / 32 <= nblk &&
+    // the CUs THIS stream may use (ops.masked_stream / hipExtStreamCreateWithCUMask): the grid must fit on them at once
+    int stream_cus = n_cu;
+    {
+        uint32_t mask[16] = {0};
+        if (hipExtStreamGetCUMask(st, 16, mask) == hipSuccess) {
+            int bits = 0;
+            for (int i = 0; i < 16; ++i) bits += __builtin_popcount(mask[i]);
+            if (bits > 0 && bits < stream_cus) stream_cus = bits;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    const bool resident = nblk <= stream_cus && !resident_off && batch == 1 && rb17 && cpt == RES_CPT && nblk <= n_cu && nblk <= 256 && (N + 31) / 32 <= nblk &&
                           (size_t)nblk * NPr + 2 * (size_t)N <= (size_t)((M + 15) / 16) * N && iters > 0;
 #ifdef PATS_DIAG
     if (diag_env("PATS_STREAM_TRACE")) fprintf(stderr, "launch_stream: batch %lld M %d N %d cpt %d rb17 %d nblk %d n_cu %d iters %d -> resident %d\n", (long long)batch, M, N, cpt, (int)rb17, nblk, n_cu, iters, (int)resident);

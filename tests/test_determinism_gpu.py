@@ -300,3 +300,30 @@ def test_resident_streaming_solve_4097_identical_and_every_workgroup_takes_part(
     nsd = ns.reshape(1, -1).double()
     assert ((cols[:, :-1] - nsd).abs() / nsd).max().item() <= 2e-5
     assert abs(cols[0, -1].item() - 4096.0) / 4096.0 <= 2e-5
+
+
+def test_resident_streaming_solve_is_not_chosen_on_a_stream_with_too_few_cus(ops):
+    """launch_stream asks the stream for its CU mask (hipExtStreamGetCUMask): on a stream masked to 160 of the CUs the 241-workgroup
+    resident kernel could never be co-resident - the two-launch form runs instead (milliseconds, not the resident kernel's bounded
+    0.2 s give-up), and agrees with the full-GPU solve to summation order."""
+    import time
+    import torch
+    from pats_amd import synth
+    inp = synth.roofline_inputs()
+    d0, d1, ns = (torch.from_numpy(inp[k]).cuda() for k in ("d0", "d1", "ns"))
+    alpha = torch.tensor(float(inp["alpha"]), device="cuda")
+    S = ops.cost(d0, d1)
+    ref = ops.log_optimal_transport(S, alpha, ns, 200)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    ms = ops.masked_stream([c for c in range(n_cu) if c // 32 < 5])
+    ms.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(ms):
+        ops.log_optimal_transport(S, alpha, ns, 200)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z = ops.log_optimal_transport(S, alpha, ns, 200)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    torch.cuda.current_stream().wait_stream(ms)
+    assert dt < 0.05, "the solve took %.3f s on the masked stream" % dt
+    assert (z - ref).abs().max().item() <= 5e-5

@@ -551,8 +551,10 @@ def test_roofline_config_4096(ops):
                                    (2, 4097, 3600),     # the same as a batch: 2 x 241 workgroups are two rounds, 2 x 257 three
                                    (1, 4100, 3100),     # 7 columns per thread, blocks of 17 rows
                                    (1, 700, 4608),      # the widest problem the streaming solver takes, blocks of 16 rows
-                                   (1, 4097, 4600)])    # one problem, 241 blocks of 17 rows, 9 columns per thread: all sweeps in ONE launch
+                                   (1, 4097, 4600),     # one problem, 241 blocks of 17 rows, 9 columns per thread: all sweeps in ONE launch
                                                         # (stream_resident_kernel: K in registers, grid barrier + granules), ragged last columns
+                                   (1, 4100, 4608),     # the same kernel: a last block of 3 rows, the widest row (every ninth slot in use)
+                                   (1, 4352, 4097)])    # 256 blocks = every CU of the part, one column in the ninth slot
 def test_streaming_solver_block_shapes(ops, oracle, B, M, N):
     """csrc/sinkhorn_stream.hip picks rows per workgroup and columns per thread from the shape: every branch of that
     choice against the oracle (modules.py:137-143), four sweeps."""
