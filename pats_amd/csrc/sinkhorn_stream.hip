@@ -229,7 +229,7 @@ stream_sweep_kernel(const float* __restrict__ K, int M, int N, const float* __re
 // and the problem is re-solved by the log-domain kernel like any guard failure - a wrong residency assumption costs time, not a hang.
 // Deterministic: fixed reduction orders.
 constexpr int RES_RB = 17, RES_CPT = 9;
-constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
+constexpr unsigned RES_SPIN_LIMIT = 1u << 15;      // ~6 us a poll under load: ~0.2 s a wait (a normal one takes one to three polls)
 typedef float f4s __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float ld_sc1(const float* p) {
@@ -555,7 +555,9 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
             (void)hipGetLastError();
         }
     }
-    const bool resident = nblk <= stream_cus && !resident_off && batch == 1 && rb17 && cpt == RES_CPT && nblk <= n_cu && nblk <= 256 && (N + 31) / 32 <= nblk &&
+    // (diagnostic library: PATS_STREAM_RESIDENT=2 launches the resident kernel whatever the stream's CUs - the give-up path on purpose)
+    static const bool resident_force = [] { const char* e = diag_env("PATS_STREAM_RESIDENT"); return e && atoi(e) == 2; }();
+    const bool resident = (nblk <= stream_cus || resident_force) && !resident_off && batch == 1 && rb17 && cpt == RES_CPT && nblk <= n_cu && nblk <= 256 && (N + 31) / 32 <= nblk &&
                           (size_t)nblk * NPr + 2 * (size_t)N <= (size_t)((M + 15) / 16) * N && iters > 0;
 #ifdef PATS_DIAG
     if (diag_env("PATS_STREAM_TRACE")) fprintf(stderr, "launch_stream: batch %lld M %d N %d cpt %d rb17 %d nblk %d n_cu %d iters %d -> resident %d\n", (long long)batch, M, N, cpt, (int)rb17, nblk, n_cu, iters, (int)resident);
