@@ -16,7 +16,8 @@
 //                         "two passes" model (8 M N).
 //   stream_colreduce_kernel  b_j = nu_j / sum_blocks partial[block][j]   (16 waves split the blocks)
 //
-// Since round 5 the 4097^2-class shape (one problem, N in 4097..4608, at most one 17-row block per CU) runs ALL its sweeps in ONE
+// Since round 5 the 4097^2-class shape (one problem, N in 4097..4608, at most one 17-row block per CU) and batches of narrow problems
+// (N <= 1024: the 769^2 coarse level of BASELINE config [3], all blocks of all problems resident at once) run ALL their sweeps in ONE
 // launch instead: stream_resident_kernel keeps a workgroup's 17 x N piece of K in REGISTERS (153 a lane) for the whole solve, so a
 // sweep moves no K at all - 16 KB of column partials out, 17 columns' worth of partials and the 16 KB scaling vector in - and pays two
 // grid-wide barriers instead of two kernel boundaries and a 67 MB read.  See the kernel.
@@ -24,6 +25,7 @@
 // Set-up (row max, column max of Z - r, K build) and the epilogue (duals back to log space,
 // Z_out = ((Z + u) + v) - norm, guard) are plain streaming kernels.  Deterministic: no atomics.
 #include "common.hpp"
+#include "lane_reduce.hpp"
 #include <algorithm>
 #ifdef PATS_DIAG
 #include <cstdio>
@@ -228,7 +230,7 @@ stream_sweep_kernel(const float* __restrict__ K, int M, int N, const float* __re
 // bounded: a workgroup that never sees the others (fewer CUs available than the launch assumed) gives up after ~0.2 s, raises *err,
 // and the problem is re-solved by the log-domain kernel like any guard failure - a wrong residency assumption costs time, not a hang.
 // Deterministic: fixed reduction orders.
-constexpr int RES_RB = 17, RES_CPT = 9;
+constexpr int RES_CPT = 9;
 constexpr unsigned RES_SPIN_LIMIT = 1u << 15;      // ~6 us a poll under load: ~0.2 s a wait (a normal one takes one to three polls)
 typedef float f4s __attribute__((ext_vector_type(4)));
 
@@ -237,6 +239,10 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 }
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st2_sc1(float* p, float x, float y) {               // p 8-byte aligned
+    const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, x) | ((unsigned long long)__builtin_bit_cast(unsigned, y) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st4_sc1(float* p, const f4s v) {                  // p 16-byte aligned
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
@@ -278,11 +284,38 @@ __device__ __forceinline__ bool res_grid_sync(unsigned* cnt, unsigned gen, int n
     return *lds_ok != 0;
 }
 
+// Eight values a lane, each summed over the 64 lanes: lane 8 I + J returns the total of index J.  The transposed butterfly of
+// lane_reduce.hpp over a lane's row-octet (4 + 2 + 1 combines) and three more levels across the octets - ten steps for eight sums
+// where eight wave_sum() take forty-eight (the row dots of a 64-row block were 4.6 us of a 10 us sweep).
+__device__ __forceinline__ float wave_sum8(const float (&p)[8], int lane) {
+    float v = reduce8_consecutive(p, OpSum(), lane);
+    v = v + dpp_f<DPP_ROW_ROR8>(v);                                   // lane ^ 8
+    {
+        unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+        lane_swap16(x, y);
+        v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    }
+    {
+        unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+        lane_swap32(x, y);
+        v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    }
+    return v;
+}
+
+// Two shapes of the kernel (template):
+//   <17, 9, 32>   the 4097^2 class: thread t owns columns 8 t .. 8 t + 7 and, in a ninth slot, column 4096 + t; 32-column reduce groups
+//   <RB, 2, 64>   N <= 1024 (the 769^2 coarse level of 1024 x 768 images, batched: BASELINE config [3]): thread t owns columns 2 t,
+//                 2 t + 1, RB = 32 or 64 rows a workgroup so that every problem of the batch has all its blocks resident at once
+//                 (blockIdx.y = problem; counters, partial rows and granules per problem), 64-column reduce groups
+template <int RB, int CPT, int GW>
 __global__ void __launch_bounds__(ST)
 stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, const float* __restrict__ log_mu,
-                       const float* __restrict__ log_nu, float* __restrict__ avec, float* partial, int nblk, int iters,
-                       unsigned* cnt, int* err, long long* tl) {
-    constexpr int RB = RES_RB, CPT = RES_CPT;
+                       const float* __restrict__ log_nu, float* __restrict__ avec, float* partial, int64_t partial_stride, int nblk,
+                       int iters, unsigned* cnt, int* err, long long* tl) {
+    static_assert((CPT == 9 && GW == 32) || (CPT == 2 && GW == 64), "the two column layouts");
+    constexpr int LG = GW / 4, NSL = ST / LG, PARTS = ST / GW;     // threads per block row of a group, slices of the blocks, second-stage parts
+    static_assert(NSL == 4 * PARTS, "four slices a part");
 #ifdef PATS_DIAG
     long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
 #define RT(k) { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_amdgcn_s_memrealtime(); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); }
@@ -291,49 +324,51 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
 #endif
     __shared__ float red[SW][RB];
     __shared__ float a_s[RB];
-    __shared__ float red2[64][33];
+    __shared__ float red2[NSL][GW + 1];
     __shared__ int sync_ok;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, blk = blockIdx.x;
+    {                                                              // this problem's slices of every array
+        const int64_t pb_ = blockIdx.y;
+        K += pb_ * M * N; bvec += pb_ * N; log_mu += pb_ * M; log_nu += pb_ * N; avec += pb_ * M;
+        partial += pb_ * partial_stride; cnt += pb_ * 128;
+    }
     const int NP = (N + 3) & ~3;                                   // row pitch of `partial`: 16-byte rows
     unsigned long long* gran = reinterpret_cast<unsigned long long*>(partial + (size_t)nblk * NP);      // N granules behind the rows
-    // ---- this thread's piece of K: rows blk RB .., columns 8 t .. 8 t + 7 and 4096 + t --------------------------------------------
+    auto col = [&](int q) { return CPT == 9 ? (q < 8 ? 8 * t + q : 4096 + t) : 2 * t + q; };
+    // ---- this thread's piece of K: rows blk RB .. -----------------------------------------------------------------------------------
     float kv[RB][CPT];
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
         const int i = blk * RB + k;
         const float* Kr = K + (int64_t)i * N;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = 8 * t + q;
-            kv[k][q] = (i < M && j < N) ? Kr[j] : 0.f;
-        }
-        const int j8 = 4096 + t;
-        kv[k][8] = (i < M && j8 < N) ? Kr[j8] : 0.f;
+        for (int q = 0; q < CPT; ++q) kv[k][q] = (i < M && col(q) < N) ? Kr[col(q)] : 0.f;
     }
     float mu = 0.f;
     if (t < RB && blk * RB + t < M) mu = expf(log_mu[blk * RB + t]);
-    // the columns this workgroup reduces: group blk of 32, four columns a thread (c4), 64 slices of the blocks (rs)
-    const int ngroups = (N + 31) >> 5;
-    const int c4 = t & 7, rs = t >> 3;
-    const int rj0 = blk * 32 + 4 * c4;
+    // the columns this workgroup reduces: group blk of GW, four columns a thread (c4), NSL slices of the blocks (rs)
+    const int ngroups = (N + GW - 1) / GW;
+    const int c4 = t % LG, rs = t / LG;
+    const int rj0 = blk * GW + 4 * c4;
     const bool reducer = blk < ngroups && rj0 < NP;
     float nu = 0.f;
-    if (t < 32 && blk < ngroups && blk * 32 + t < N) nu = expf(log_nu[blk * 32 + t]);
+    if (t < GW && blk < ngroups && blk * GW + t < N) nu = expf(log_nu[blk * GW + t]);
+    // the granule polled first: the last valid one of the thread's consecutive columns (one reduce group holds them all)
+    const int jlast = CPT == 9 ? 8 * t + 7 : 2 * t + 1;
+    const int jp = jlast < N ? jlast : N - 1;
     bool alive = true;
     for (int it = 0; it < iters && alive; ++it) {
         // ---- b -> registers ---------------------------------------------------------------------------------------------------------
         float bq[CPT];
         if (it == 0) {                                             // the set-up's vector (a kernel boundary behind us)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bq[q] = 8 * t + q < N ? bvec[8 * t + q] : 0.f;
-            bq[8] = 4096 + t < N ? bvec[4096 + t] : 0.f;
+            for (int q = 0; q < CPT; ++q) bq[q] = col(q) < N ? bvec[col(q)] : 0.f;
         } else {
             bool ok = false;
             const unsigned want = (unsigned)it;
-            // One granule is polled, then all nine are read and checked: the thread's eight consecutive columns sit in ONE 32-column
-            // group, whose granules leave their reducer in one store instruction - an eighth of the polling traffic of 241 x 512
-            // threads re-reading everything (the polls share the memory side with the reducers' loads they are waiting for).
-            const int jp = 8 * t < N ? (8 * t + 7 < N ? 8 * t + 7 : N - 1) : N - 1;
+            // One granule is polled, then all are read and checked: the thread's consecutive columns sit in ONE reduce group, whose
+            // granules leave their reducer in one store instruction - a fraction of the polling traffic of every thread re-reading
+            // everything (the polls share the memory side with the reducers' loads they are waiting for).
             for (unsigned spin = 0; spin < RES_SPIN_LIMIT && !ok; ++spin) {
                 float probe;
                 if (!ld_granule(gran + jp, want, probe)) continue;
@@ -343,20 +378,30 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
                 //  float4 became ONE compare of g.x - every poll "failed" and the kernel gave up; tools/asm_vec_component_repro.hip.
                 //  Whole-vector arithmetic on such a value - the reducers' sums - is translated correctly.)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = 8 * t + q;
-                    if (j < N) ok = ld_granule(gran + j, want, bq[q]) && ok;
+                for (int q = 0; q < CPT; ++q) {
+                    if (col(q) < N) ok = ld_granule(gran + col(q), want, bq[q]) && ok;
                     else bq[q] = 0.f;
                 }
-                if (4096 + t < N) ok = ld_granule(gran + 4096 + t, want, bq[8]) && ok;
-                else bq[8] = 0.f;
             }
             if (!ok) alive = false;                                // (every thread still walks to the barrier: it fails there too)
         }
         RT(0);
-        // ---- row dots: per-thread partials, wave all-reduce, then across the 8 waves through LDS ---------------------------------
+        // ---- row dots: per-thread partials, summed over the wave eight rows at a time, then across the 8 waves through LDS ------------
 #pragma unroll
-        for (int k = 0; k < RB; ++k) {
+        for (int g8 = 0; g8 < RB / 8; ++g8) {
+            float pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float p = 0.f;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) p = fmaf(kv[8 * g8 + e][q], bq[q], p);
+                pk[e] = p;
+            }
+            const float tot = wave_sum8(pk, lane);
+            if (lane < 8) red[wave][8 * g8 + lane] = tot;
+        }
+#pragma unroll
+        for (int k = 8 * (RB / 8); k < RB; ++k) {
             float p = 0.f;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) p = fmaf(kv[k][q], bq[q], p);
@@ -384,25 +429,29 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
 #pragma unroll
                 for (int k = 0; k < RB; ++k) acc[q] = fmaf(kv[k][q], a_s[k], acc[q]);
             }
-            if (8 * t < NP) st4_sc1(pb + 8 * t, f4s{acc[0], acc[1], acc[2], acc[3]});
-            if (8 * t + 4 < NP) st4_sc1(pb + 8 * t + 4, f4s{acc[4], acc[5], acc[6], acc[7]});
-            if (4096 + t < N) st_sc1(pb + 4096 + t, acc[8]);
+            if (CPT == 9) {
+                if (8 * t < NP) st4_sc1(pb + 8 * t, f4s{acc[0], acc[1], acc[2], acc[3]});
+                if (8 * t + 4 < NP) st4_sc1(pb + 8 * t + 4, f4s{acc[4], acc[5], acc[6], acc[7]});
+                if (4096 + t < N) st_sc1(pb + 4096 + t, acc[CPT - 1]);
+            } else {
+                if (2 * t < NP) st2_sc1(pb + 2 * t, acc[0], acc[1]);          // (NP is a multiple of 4: the pair is inside the row)
+            }
         }
         RT(2);
         if (!res_grid_sync(cnt, (unsigned)(it + 1), nblk, &sync_ok, blk < ngroups)) alive = false;
         RT(3);
         if (!alive) break;
-        // ---- b_j = nu_j / sum over the blocks, columns 32 blk .. -------------------------------------------------------------------
+        // ---- b_j = nu_j / sum over the blocks, columns GW blk .. -------------------------------------------------------------------
         if (blk < ngroups) {                                       // (workgroup-uniform)
             f4s v = {0.f, 0.f, 0.f, 0.f};
             if (reducer) {
-                // four block rows a thread (nblk <= 256), in ONE assembly statement with its wait: the compiler does not know that
+                // four block rows a thread (nblk <= 4 NSL), in ONE assembly statement with its wait: the compiler does not know that
                 // these registers are written asynchronously - between a separate "issue" and "wait" it may copy them
                 const float* src = partial + rj0;
                 const float* p0 = src + (size_t)(rs < nblk ? rs : 0) * NP;
-                const float* p1 = src + (size_t)(rs + 64 < nblk ? rs + 64 : 0) * NP;
-                const float* p2 = src + (size_t)(rs + 128 < nblk ? rs + 128 : 0) * NP;
-                const float* p3 = src + (size_t)(rs + 192 < nblk ? rs + 192 : 0) * NP;
+                const float* p1 = src + (size_t)(rs + NSL < nblk ? rs + NSL : 0) * NP;
+                const float* p2 = src + (size_t)(rs + 2 * NSL < nblk ? rs + 2 * NSL : 0) * NP;
+                const float* p3 = src + (size_t)(rs + 3 * NSL < nblk ? rs + 3 * NSL : 0) * NP;
                 f4s x0, x1, x2, x3;
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
                              "global_load_dwordx4 %1, %5, off sc1\n\t"
@@ -411,23 +460,23 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
                              "s_waitcnt vmcnt(0)"
                              : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
                 const f4s z4 = {0.f, 0.f, 0.f, 0.f};
-                v = (((rs < nblk ? x0 : z4) + (rs + 64 < nblk ? x1 : z4)) + (rs + 128 < nblk ? x2 : z4)) + (rs + 192 < nblk ? x3 : z4);
+                v = (((rs < nblk ? x0 : z4) + (rs + NSL < nblk ? x1 : z4)) + (rs + 2 * NSL < nblk ? x2 : z4)) + (rs + 3 * NSL < nblk ? x3 : z4);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) red2[rs][4 * c4 + e] = v[e];
             wg_barrier();
-            {                                                      // 64 slices -> 16 (four a thread) -> 1: the publishers' chain is 4 + 16 reads, not 63
-                const int col = t & 31, part = t >> 5;
-                const float s4 = ((red2[4 * part][col] + red2[4 * part + 1][col]) + red2[4 * part + 2][col]) + red2[4 * part + 3][col];
+            {                                                      // NSL slices -> PARTS (four a thread) -> 1: the publishers' chain is 4 + PARTS reads
+                const int cc = t % GW, part = t / GW;
+                const float s4 = ((red2[4 * part][cc] + red2[4 * part + 1][cc]) + red2[4 * part + 2][cc]) + red2[4 * part + 3][cc];
                 wg_barrier();
-                red2[part][col] = s4;
+                red2[part][cc] = s4;
                 wg_barrier();
             }
-            if (t < 32) {
-                const int j = blk * 32 + t;
+            if (t < GW) {
+                const int j = blk * GW + t;
                 float s = red2[0][t];
 #pragma unroll
-                for (int w = 1; w < 16; ++w) s += red2[w][t];
+                for (int w = 1; w < PARTS; ++w) s += red2[w][t];
                 if (j < N) {
                     const float bj = nu * __builtin_amdgcn_rcpf(s);
                     st_granule(gran + j, bj, (unsigned)(it + 1));
@@ -439,7 +488,7 @@ stream_resident_kernel(const float* __restrict__ K, int M, int N, float* bvec, c
     }
     if (!alive && t == 0) atomicOr(err, 1);
 #ifdef PATS_DIAG
-    if (tl && t == 0) for (int k = 0; k < 5; ++k) tl[blk * 6 + k] = tsum[k];
+    if (tl && t == 0 && blockIdx.y == 0) for (int k = 0; k < 5; ++k) tl[blk * 6 + k] = tsum[k];
 #endif
 }
 
@@ -494,7 +543,7 @@ size_t stream_workspace_bytes(int64_t batch, int M, int N) {
     f += al256((size_t)batch * nblk * N * 4);       // partial
     f += 2 * al256((size_t)batch * M * 4);          // r, a
     f += 2 * al256((size_t)batch * N * 4);          // c, b
-    f += 1024;                                      // the resident kernel's arrival counters (8 x 64 B) and its give-up flag
+    f += al256(512 * (size_t)batch + 512);          // the resident kernel's arrival counters (8 x 64 B a problem) and its give-up flag
     return f;
 }
 
@@ -533,7 +582,7 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
     float* c = (float*)p;        p += al256((size_t)batch * N * 4);
     float* bv = (float*)p;       p += al256((size_t)batch * N * 4);
     unsigned* cnt = (unsigned*)p;
-    int* err = (int*)(p + 512);
+    int* err = (int*)(p + 512 * (size_t)batch);
     const dim3 rows_grid(M, (unsigned)batch), blk_grid(nblk, (unsigned)batch), col_grid((N + 63) / 64, (unsigned)batch);
     hipLaunchKernelGGL(stream_rowmax_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r);
     if (rb17) hipLaunchKernelGGL((stream_colmax_partial_kernel<17>), blk_grid, dim3(ST), 0, st, src, M, N, r, partial, nblk);
@@ -557,28 +606,49 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
     }
     // (diagnostic library: PATS_STREAM_RESIDENT=2 launches the resident kernel whatever the stream's CUs - the give-up path on purpose)
     static const bool resident_force = [] { const char* e = diag_env("PATS_STREAM_RESIDENT"); return e && atoi(e) == 2; }();
-    const bool resident = (nblk <= stream_cus || resident_force) && !resident_off && batch == 1 && rb17 && cpt == RES_CPT && nblk <= n_cu && nblk <= 256 && (N + 31) / 32 <= nblk &&
-                          (size_t)nblk * NPr + 2 * (size_t)N <= (size_t)((M + 15) / 16) * N && iters > 0;
+    // which shape of stream_resident_kernel, if any: 1 = <17, 9, 32> (one problem of the 4097^2 class), 2 / 3 = <32 | 64, 2, 64>
+    // (N <= 1024, every problem of the batch with all its blocks on the stream's CUs at once)
+    int res_kind = 0, res_nblk = 0;
+    if (!resident_off && iters > 0) {
+        if (batch == 1 && rb17 && cpt == RES_CPT) { res_kind = 1; res_nblk = nblk; }
+        else if (N <= 1024 && (int64_t)M * N >= 500 * 500) {
+            const int64_t per = stream_cus / batch;                       // blocks a problem may have
+            const int64_t need = per >= 1 ? (M + per - 1) / per : 1 << 30;
+            if (need <= 32) { res_kind = 2; res_nblk = (M + 31) / 32; }
+            else if (need <= 64) { res_kind = 3; res_nblk = (M + 63) / 64; }
+        }
+        if (res_kind) {
+            const int gw = res_kind == 1 ? 32 : 64, nsl = ST / (gw / 4);
+            const bool fits = (int64_t)res_nblk * batch <= stream_cus || resident_force;
+            if (!(fits && res_nblk <= 4 * nsl && (N + gw - 1) / gw <= res_nblk &&
+                  (size_t)res_nblk * NPr + 2 * (size_t)N <= (size_t)((M + 15) / 16) * N)) res_kind = 0;
+        }
+    }
+    const bool resident = res_kind != 0;
 #ifdef PATS_DIAG
-    if (diag_env("PATS_STREAM_TRACE")) fprintf(stderr, "launch_stream: batch %lld M %d N %d cpt %d rb17 %d nblk %d n_cu %d iters %d -> resident %d\n", (long long)batch, M, N, cpt, (int)rb17, nblk, n_cu, iters, (int)resident);
+    if (diag_env("PATS_STREAM_TRACE")) fprintf(stderr, "launch_stream: batch %lld M %d N %d cpt %d rb17 %d nblk %d stream CUs %d iters %d -> resident shape %d, %d blocks a problem\n", (long long)batch, M, N, cpt, (int)rb17, nblk, stream_cus, iters, res_kind, res_nblk);
 #endif
     if (resident) {
-        if (int rc = fill_bytes(cnt, 0, 1024, st)) return rc;
+        if (int rc = fill_bytes(cnt, 0, 512 * (size_t)batch + 256, st)) return rc;
         long long* tl = nullptr;
 #ifdef PATS_DIAG
-        if (diag_env("PATS_STREAM_TL")) { (void)hipMalloc((void**)&tl, (size_t)nblk * 6 * 8); (void)hipMemset(tl, 0, (size_t)nblk * 6 * 8); }
+        if (diag_env("PATS_STREAM_TL")) { (void)hipMalloc((void**)&tl, (size_t)res_nblk * 6 * 8); (void)hipMemset(tl, 0, (size_t)res_nblk * 6 * 8); }
 #endif
-        hipLaunchKernelGGL(stream_resident_kernel, dim3(nblk), dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, nblk, iters, cnt, err, tl);
+        const dim3 rgrid((unsigned)res_nblk, (unsigned)batch);
+        const int64_t pstride = (int64_t)((M + 15) / 16) * N;            // a problem's share of the partial area (floats)
+        if (res_kind == 1) hipLaunchKernelGGL((stream_resident_kernel<17, 9, 32>), rgrid, dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, pstride, res_nblk, iters, cnt, err, tl);
+        else if (res_kind == 2) hipLaunchKernelGGL((stream_resident_kernel<32, 2, 64>), rgrid, dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, pstride, res_nblk, iters, cnt, err, tl);
+        else hipLaunchKernelGGL((stream_resident_kernel<64, 2, 64>), rgrid, dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, pstride, res_nblk, iters, cnt, err, tl);
 #ifdef PATS_DIAG
         if (tl) {
             (void)hipStreamSynchronize(st);
             static long long h[256 * 6];
-            (void)hipMemcpy(h, tl, (size_t)nblk * 6 * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h, tl, (size_t)res_nblk * 6 * 8, hipMemcpyDeviceToHost);
             static const char* names[5] = {"b -> registers (granule wait)", "row dots -> a", "column partials + stores issued", "grid barrier", "reduce + publish (reducers)"};
             for (int k = 0; k < 5; ++k) {
                 double sum = 0, mx = 0;
-                for (int w = 0; w < nblk; ++w) { sum += (double)h[w * 6 + k]; mx = std::max(mx, (double)h[w * 6 + k]); }
-                fprintf(stderr, "  resident sweep: %-34s mean %.2f us, slowest workgroup %.2f us per sweep\n", names[k], sum / nblk / iters / 100.0, mx / iters / 100.0);
+                for (int w = 0; w < res_nblk; ++w) { sum += (double)h[w * 6 + k]; mx = std::max(mx, (double)h[w * 6 + k]); }
+                fprintf(stderr, "  resident sweep: %-34s mean %.2f us, slowest workgroup %.2f us per sweep\n", names[k], sum / res_nblk / iters / 100.0, mx / iters / 100.0);
             }
             (void)hipFree(tl);
         }

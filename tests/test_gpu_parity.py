@@ -554,7 +554,11 @@ def test_roofline_config_4096(ops):
                                    (1, 4097, 4600),     # one problem, 241 blocks of 17 rows, 9 columns per thread: all sweeps in ONE launch
                                                         # (stream_resident_kernel: K in registers, grid barrier + granules), ragged last columns
                                    (1, 4100, 4608),     # the same kernel: a last block of 3 rows, the widest row (every ninth slot in use)
-                                   (1, 4352, 4097)])    # 256 blocks = every CU of the part, one column in the ninth slot
+                                   (1, 4352, 4097),     # 256 blocks = every CU of the part, one column in the ninth slot
+                                   (1, 769, 769),       # the narrow shape of the resident kernel (N <= 1024, two columns a thread): 25 blocks of 32 rows
+                                   (16, 769, 769),      # ... batched as BASELINE config [3] runs it: 16 problems x 13 blocks of 64 rows, all resident
+                                   (3, 1000, 1024),     # ... the widest narrow problem, 32-row blocks, a ragged last block
+                                   (1, 2000, 520)])     # ... tall: 63 blocks, 9 reduce groups
 def test_streaming_solver_block_shapes(ops, oracle, B, M, N):
     """csrc/sinkhorn_stream.hip picks rows per workgroup and columns per thread from the shape: every branch of that
     choice against the oracle (modules.py:137-143), four sweeps."""
