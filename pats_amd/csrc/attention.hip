@@ -35,6 +35,7 @@ struct AttnArgs {
     float sq, rsq;                        // dim**.5 and its reciprocal
     float* out; float* prob;
     const int* gate;                      // optional: the launch is a no-op unless *gate != 0 (fallback behind the fused GNN layer)
+    int64_t total;                        // attention65_kernel: batch * heads work items (a gated launch covers them with a capped grid)
 };
 }  // namespace
 
@@ -176,7 +177,11 @@ attention65_kernel(AttnArgs g) {
     __shared__ Attn65Lds lds;
     if (g.gate && *g.gate == 0) return;
     const int lane = threadIdx.x, li = lane & 31, lk = lane >> 5;
-    const int64_t bh = blockIdx.x, bi = bh / g.heads;
+    // (grid-stride: an ungated launch has one workgroup per item; a GATED one - the fp32 redo behind the fused GNN layer, which
+    //  normally leaves at the gate - comes with a capped grid: an empty launch of 131 072 one-wave workgroups cost 28 us, 180 of them
+    //  a step in the bench's with-GNN leg)
+    for (int64_t bh = blockIdx.x; bh < g.total; bh += gridDim.x) {
+    const int64_t bi = bh / g.heads;
     const int h = (int)(bh - bi * g.heads);
     const int ld = g.heads * 65;
     const int64_t base = (bi * 32 * g.heads + h) * 65;
@@ -276,6 +281,8 @@ attention65_kernel(AttnArgs g) {
         }
         O[li * ld + 64] = fmaf(vr[64], lds.p64[64], acc0 + acc1);
     }
+    wg_barrier();                                               // the LDS staging is free for the next item
+    }
 }
 
 }  // namespace pats
@@ -302,8 +309,9 @@ int pats::launch_attention(const float* query, const float* key, const float* va
     static const bool general_only = diag_env("PATS_ATTN_GENERAL") != nullptr;     // A/B switch for benchmarking
     if (n == 65 && m == 65 && dim == 32 && !prob && !general_only) {            // the third-level shape
         PATS_REQUIRE(batch * heads < (1ll << 31), "attention: grid too large (split the batch)");
-        AttnArgs g{query, key, value, dim, heads, n, m, 0, 32, sq0, 1.0f / sq0, out, nullptr, gate};
-        hipLaunchKernelGGL(attention65_kernel, dim3((unsigned)(batch * heads)), dim3(64), 0, as_stream(stream), g);
+        AttnArgs g{query, key, value, dim, heads, n, m, 0, 32, sq0, 1.0f / sq0, out, nullptr, gate, batch * heads};
+        const int64_t wgs = gate ? std::min<int64_t>(batch * heads, 4096) : batch * heads;
+        hipLaunchKernelGGL(attention65_kernel, dim3((unsigned)wgs), dim3(64), 0, as_stream(stream), g);
         return check_launch("attention65_kernel");
     }
     const int mt = (m + 31) / 32, mp = 32 * mt + 1;

@@ -20,6 +20,7 @@
 // The attention core in the middle is pats_attention_f32 (attention.hip).
 #include "mfma_tile.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace pats {
@@ -42,6 +43,7 @@ struct ConvArgs {
                                // conv1x1_kernel: if non-null, the whole launch is a no-op unless *redo != 0
     const int* gate;           // optional: every kernel of the launch is a no-op unless *gate != 0 (the composition as the
                                // fallback behind the fused layer of gnn_fused.hip)
+    int64_t tiles;             // conv1x1_kernel: workgroup tiles of the product (a gated / redo launch covers them with a capped grid)
 };
 
 // column addressing for mfma_tile.hpp's CmSrc: A = transposed weights at output rows i0.. (clamped), B = activations at
@@ -71,8 +73,12 @@ conv1x1_kernel(ConvArgs g) {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int64_t tiles_j = (g.cols + mt::CT - 1) / mt::CT;
-    const int i0 = (int)(blockIdx.x / tiles_j) * g.tile_rows;
-    const int64_t j0 = (int64_t)(blockIdx.x % tiles_j) * mt::CT;
+    // (grid-stride: a plain launch has one workgroup per tile; a launch that normally leaves at its gate - the redo behind
+    //  conv_lean_kernel, the composition behind a fused layer - comes with a capped grid: ~2 600 of them a step in the bench's
+    //  with-GNN leg cost 5 us each as full grids of workgroups that do nothing)
+    for (int64_t vb = blockIdx.x; vb < g.tiles; vb += gridDim.x) {
+    const int i0 = (int)(vb / tiles_j) * g.tile_rows;
+    const int64_t j0 = (int64_t)(vb % tiles_j) * mt::CT;
     const int n = g.n, M = g.M;
     // output-row tiles that exist: rows i0 + 32 w .. for wave w, and the fifth tile row (i0 + 128 ..) shared by all
     // (workgroup-uniform: 128-channel layers skip it)
@@ -107,6 +113,8 @@ conv1x1_kernel(ConvArgs g) {
     if (row4) {
         store_tile(acc[5], 4, wave);
         if (wave == 0) store_tile(acc[6], 4, 4);
+    }
+    wg_barrier();                                    // the staging LDS is free for the next tile
     }
 }
 
@@ -605,7 +613,8 @@ static int launch_conv(const ConvArgs& g0, int* redo, hipStream_t st, const int*
     g.tile_rows = rows128 ? 128 : mt::CT;
     const int64_t tiles = (int64_t)((g.M + g.tile_rows - 1) / g.tile_rows) * ((g.cols + mt::CT - 1) / mt::CT);
     PATS_REQUIRE(tiles < (1ll << 31), "attentional_propagation: grid too large (split the batch)");
-    const dim3 grid((unsigned)tiles), block(256);
+    g.tiles = tiles;
+    const dim3 grid((unsigned)((g.gate || g.redo) ? std::min<int64_t>(tiles, 2048) : tiles)), block(256);
     if (fp32_only) hipLaunchKernelGGL((conv1x1_kernel<false, true>), grid, block, 0, st, g);
     else if (rows128) hipLaunchKernelGGL((conv1x1_kernel<true, false>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((conv1x1_kernel<true, true>), grid, block, 0, st, g);
