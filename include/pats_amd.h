@@ -377,6 +377,15 @@ int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, int H, int 
                              double* scores_back, int zero_scores_back, uint8_t* out, void* workspace,
                              size_t workspace_bytes, pats_stream_t stream);
 
+/* The same merges for chunks [c_lo, c_hi) of the row table only, on tensors that hold table rows row_origin .. row_origin +
+ * rows_local (trust_score, if_nomatching1_L2, out [rows_local,144]): PATS.forward's chunk loop (models/pats.py:33-39) walked
+ * chunk by chunk - one launch per chunk, scores_back handed from call to call (zero_scores_back != 0 on the first,
+ * pats.py:32), pats.py:38-39 applied through row_forced.  Rows of `out` outside the walked blocks read "no match". */
+int pats_merge_patches_chunks(int merge_new, int Cmax, int c_lo, int c_hi, int64_t pairs, int H, int W, int64_t row_origin,
+                              int64_t rows_local, const int64_t* chunk_base, const int32_t* row_cell, const int32_t* row_slot,
+                              const uint8_t* row_forced, float* trust_score, uint8_t* if_nomatching1_L2, double* scores_back,
+                              int zero_scores_back, uint8_t* out, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
 /* SecondLayer.merge_patches_new (merge_new != 0, reference models/second_layer.py:193-240) and
  * merge_patches_old (merge_new == 0, :137-191): resolves every 8-px cell among the up to nine 96x96
  * windows covering it.  Like the reference it works in place on trust_score [B,144] (border weighting

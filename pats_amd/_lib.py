@@ -107,6 +107,8 @@ SIGNATURES = {
     "pats_merge_batch_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "pats_merge_patches_batch": (c_int, [c_int, c_int, c_i64, c_int, c_int, c_i64] + [c_void_p] * 7 + [c_int, c_void_p, c_void_p,
                                          c_size, c_void_p]),
+    "pats_merge_patches_chunks": (c_int, [c_int, c_int, c_int, c_int, c_i64, c_int, c_int, c_i64, c_i64] + [c_void_p] * 7 +
+                                  [c_int, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_get_result_chunks_f32": (c_int, [c_int, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
                                            ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),

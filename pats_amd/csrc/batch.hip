@@ -162,6 +162,18 @@ chunk_fill_kernel(ChunkRowsArgs g) {
     }
 }
 
+// the table's defaults in ONE launch (four fills until round 5): rows no chunk uses keep cell / crop -1 and stay "forced" (no match)
+__global__ void __launch_bounds__(256)
+chunk_init_kernel(ChunkRowsArgs g) {
+    const int64_t r0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r0 == 0) *g.status = 0;
+    for (int64_t r = r0; r < g.rows_cap; r += (int64_t)gridDim.x * 256) {
+        g.row_cell[r] = -1;
+        g.row_crop[r] = -1;
+        g.row_forced[r] = 1;
+    }
+}
+
 // an empty kernel with a name of its own: bench.py brackets its timed region with it so that a kernel trace can be cut
 // to the steps (tools/rocpd_stats.py --between-markers)
 __global__ void profile_marker_kernel(int tag) { (void)tag; }
@@ -200,9 +212,10 @@ extern "C" int pats_chunk_rows_device(const uint8_t* if_nomatching1, int64_t pai
     int32_t* counts = reinterpret_cast<int32_t*>(pair_base + n);
     ChunkRowsArgs g{if_nomatching1, pairs, height, width, max_once_used, Cmax, rows_cap, sum_cycle, cycle_num, second, third,
                     masks, chunk_base, crop_base, row_cell, row_forced, row_crop, row_slot, counts, pair_base, status};
-    if (fill_bytes(status, 0, sizeof(int32_t), st) || fill_bytes(row_cell, 0xff, sizeof(int32_t) * (size_t)rows_cap, st) ||
-        fill_bytes(row_crop, 0xff, sizeof(int32_t) * (size_t)rows_cap, st) || fill_bytes(row_forced, 1, (size_t)rows_cap, st))
-        return PATS_ERR_LAUNCH;
+    {
+        const int64_t blocks = ceil_div(rows_cap > 0 ? rows_cap : 1, 256);
+        hipLaunchKernelGGL(chunk_init_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, g);
+    }
     hipLaunchKernelGGL(chunk_plan_kernel, dim3((unsigned)pairs), dim3(256), 0, st, g);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(256), 0, st, g);
     hipLaunchKernelGGL(chunk_fill_kernel, dim3((unsigned)ceil_div(pairs * height * width, 256)), dim3(256), 0, st, g);

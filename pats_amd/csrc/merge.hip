@@ -130,14 +130,10 @@ merge_slots_kernel(const uint8_t* __restrict__ ifn_L1, Scan sc, int64_t NP, int6
 }
 
 // border weighting, flag update, score hand-over into scores_back (second_layer.py:140-149,161-163 / :192-201,210-211)
-__global__ void __launch_bounds__(256)
-merge_prepare_kernel(int merge_new, RowBlock rb, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
-                     const int32_t* __restrict__ patch_of, double* __restrict__ scores_back) {
-    int64_t base, B;
-    rb.get(base, B);
-    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (el >= B * 144) return;
-    const int64_t e = el + base * 144, b = e / 144;
+// for element e = row b, window cell `cell` of the trust / flag tensors
+__device__ __forceinline__ void merge_prepare_el(int merge_new, int64_t e, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
+                                                 const int32_t* __restrict__ patch_of, double* __restrict__ scores_back) {
+    const int64_t b = e / 144;
     const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
     float t = trust[e];
 #pragma unroll
@@ -154,6 +150,16 @@ merge_prepare_kernel(int merge_new, RowBlock rb, float* __restrict__ trust, uint
     if (q >= 0) scores_back[(q * 16 + r * 4 + s) * 9 + a * 3 + c] = (double)t;
 }
 
+__global__ void __launch_bounds__(256)
+merge_prepare_kernel(int merge_new, RowBlock rb, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
+                     const int32_t* __restrict__ patch_of, double* __restrict__ scores_back) {
+    int64_t base, B;
+    rb.get(base, B);
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= B * 144) return;
+    merge_prepare_el(merge_new, el + base * 144, trust, ifn_L2, patch_of, scores_back);
+}
+
 struct MergeGeom {
     int h, w, h4, w4;
     int64_t per;                 // 4h * 4w * 9
@@ -165,15 +171,10 @@ struct MergeGeom {
 // choice is the first minimum of ITS OWNER's nine scores (+100000 for windows leaving the grid) -
 // argsort runs on scores_back_use, not on the re-gathered copy (:232).  The value scattered is
 // if_matching2[Y, X, sb] = if_matching at the entry itself, i.e. the (updated) L2 flag.
-__global__ void __launch_bounds__(256)
-merge_select_new_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ patch_of,
-                        const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
-                        const uint8_t* __restrict__ row_forced, uint8_t* __restrict__ out) {
-    int64_t base, B;
-    rb.get(base, B);
-    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (el >= B * 144) return;
-    const int64_t e = el + base * 144, b = e / 144;
+__device__ __forceinline__ void merge_select_new_el(const MergeGeom& g, int64_t e, const int32_t* __restrict__ patch_of,
+                                                    const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
+                                                    const uint8_t* __restrict__ row_forced, uint8_t* __restrict__ out) {
+    const int64_t b = e / 144;
     const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
     const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
     const int64_t q = patch_of[b];
@@ -202,19 +203,25 @@ merge_select_new_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ pa
     out[e] = res;
 }
 
+__global__ void __launch_bounds__(256)
+merge_select_new_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ patch_of,
+                        const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
+                        const uint8_t* __restrict__ row_forced, uint8_t* __restrict__ out) {
+    int64_t base, B;
+    rb.get(base, B);
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= B * 144) return;
+    merge_select_new_el(g, el + base * 144, patch_of, ifn_L2, scores_back, row_forced, out);
+}
+
 // "old" (second_layer.py:165-189): one thread per fine cell re-gathers its nine candidates by geometry
 // (channel k from the owner 4(a-1), 4(c-1) cells away where that slice assignment reaches, its own
 // otherwise), applies -10000 to matching ones, takes the first minimum and scatters the flag to the
 // (clamped) source entry.  ATen's CPU scatter is sequential, so the last source wins:
 // atomicMax on ((source index + 1) << 1 | value).
-__global__ void __launch_bounds__(256)
-merge_scatter_old_kernel(MergeGeom g, int batch_num, const int32_t* __restrict__ slot,
-                         const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
-                         unsigned* __restrict__ winner) {
-    const int64_t cells = (int64_t)g.h4 * g.w4;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= cells * batch_num) return;
-    const int64_t bt = e / cells, n = e - bt * cells;
+__device__ __forceinline__ void merge_scatter_old_cell(const MergeGeom& g, int64_t bt, int64_t n, const int32_t* __restrict__ slot,
+                                                       const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
+                                                       unsigned* __restrict__ winner) {
     const int Y = (int)(n / g.w4), X = (int)(n % g.w4), hw = g.h * g.w;
     int sb = 0;
     double best = 0.0;
@@ -239,14 +246,21 @@ merge_scatter_old_kernel(MergeGeom g, int batch_num, const int32_t* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-merge_finish_old_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ patch_of,
-                        const unsigned* __restrict__ winner, const uint8_t* __restrict__ row_forced,
-                        uint8_t* __restrict__ out) {
-    int64_t base, B;
-    rb.get(base, B);
-    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (el >= B * 144) return;
-    const int64_t e = el + base * 144, b = e / 144;
+merge_scatter_old_kernel(MergeGeom g, int batch_num, const int32_t* __restrict__ slot,
+                         const uint8_t* __restrict__ ifn_L2, const double* __restrict__ scores_back,
+                         unsigned* __restrict__ winner) {
+    const int64_t cells = (int64_t)g.h4 * g.w4;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cells * batch_num) return;
+    const int64_t bt = e / cells;
+    merge_scatter_old_cell(g, bt, e - bt * cells, slot, ifn_L2, scores_back, winner);
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void merge_finish_old_el(const MergeGeom& g, int64_t e, const int32_t* __restrict__ patch_of,
+                                                    const unsigned* __restrict__ winner, const uint8_t* __restrict__ row_forced,
+                                                    uint8_t* __restrict__ out) {
+    const int64_t b = e / 144;
     const int cell = (int)(e - b * 144), x = cell % 12, y = cell / 12;
     const int a = y / 4, r = y % 4, c = x / 4, s = x % 4;
     const int64_t q = patch_of[b];
@@ -255,11 +269,89 @@ merge_finish_old_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ pa
         const int hw = g.h * g.w;
         const int64_t bt = q / hw;
         const int p = (int)(q - bt * hw), hh = p / g.w, ww = p % g.w;
-        const unsigned v = winner[bt * g.per + ((int64_t)(4 * hh + r) * g.w4 + 4 * ww + s) * 9 + a * 3 + c];
+        const unsigned* wp = &winner[bt * g.per + ((int64_t)(4 * hh + r) * g.w4 + 4 * ww + s) * 9 + a * 3 + c];
+        // COHERENT: the atomics of the scatter ran at L2 inside THIS launch; read past the CU's vector cache
+        const unsigned v = COHERENT ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *wp;
         if (v) res = (uint8_t)(v & 1u);
     }
     if (row_forced && row_forced[b]) res = 1;
     out[e] = res;
+}
+
+__global__ void __launch_bounds__(256)
+merge_finish_old_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ patch_of,
+                        const unsigned* __restrict__ winner, const uint8_t* __restrict__ row_forced,
+                        uint8_t* __restrict__ out) {
+    int64_t base, B;
+    rb.get(base, B);
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= B * 144) return;
+    merge_finish_old_el<false>(g, el + base * 144, patch_of, winner, row_forced, out);
+}
+
+// ---- the merges of ONE PAIR in one workgroup: chunk blocks in order (scores_back couples them, pats.py:32,37), the phases of a
+// chunk separated by workgroup barriers instead of kernel boundaries.  One launch per batch (grid = pairs) where
+// pats_merge_patches_batch queued two fills + two (new) / four (old) launches per chunk: at one pair a step - the reference's
+// execution mode - the merges were 16 of a pair's 60 launches.  Pairs never read each other's rows or scores_back slice.
+// Everything that crosses threads inside a phase boundary is global memory written and read by the SAME workgroup (stores are
+// written through the CU's vector cache, so after the barrier's vmcnt(0) the loads see them); `winner` is updated by L2 atomics
+// and therefore read back with agent-scope loads.
+__global__ void __launch_bounds__(1024)
+merge_pairs_kernel(int merge_new, MergeGeom g, int Cmax, int c_lo, int c_hi, int64_t row_origin, int64_t rows_local,
+                   const int64_t* __restrict__ chunk_base,
+                   const int32_t* __restrict__ row_cell, const int32_t* __restrict__ row_slot,
+                   const uint8_t* __restrict__ row_forced, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
+                   double* __restrict__ scores_back, int zero_scores_back, unsigned* __restrict__ winner, uint8_t* __restrict__ out) {
+    __shared__ int lohi[2];
+    const int tid = threadIdx.x, N = g.h * g.w;
+    const int64_t p = blockIdx.x, pairs = gridDim.x, NP = pairs * N;
+    // trust / ifn_L2 / out hold table rows row_origin .. row_origin + rows_local (the whole table in batch mode: origin 0; one
+    // chunk's rows when PATS.forward's chunk loop is walked chunk by chunk, pats_merge_patches_chunks): index them by table row
+    trust -= row_origin * 144; ifn_L2 -= row_origin * 144; out -= row_origin * 144;
+    // rows outside the blocks walked here (padding past the total in batch mode) are never visited: "no match"
+    {
+        const int64_t first = chunk_base[c_lo], last = chunk_base[c_hi];
+        for (int64_t e = row_origin * 144 + p * 1024 + tid; e < (row_origin + rows_local) * 144; e += pairs * 1024)
+            if (e < first * 144 || e >= last * 144) out[e] = 1;
+    }
+    double* sbp = scores_back + p * N * 144;
+    if (zero_scores_back)                                   // pats.py:32: every pair starts from a zeroed scores_back
+        for (int i = tid; i < N * 144; i += 1024) sbp[i] = 0.0;
+    auto phase = [&]() { wg_barrier_global(); };
+    phase();
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int64_t base = chunk_base[c], end = chunk_base[c + 1];
+        if (end <= base) continue;                          // (uniform)
+        // this pair's rows of the block: a contiguous run (rows are ordered (chunk, pair, cell))
+        if (tid == 0) { lohi[0] = 0x7fffffff; lohi[1] = -1; }
+        wg_barrier();
+        for (int64_t r = base + tid; r < end; r += 1024) {
+            const int32_t q = row_cell[r];
+            if (q >= 0 && q / N == p) { atomicMin(&lohi[0], (int)(r - base)); atomicMax(&lohi[1], (int)(r - base)); }
+        }
+        wg_barrier();
+        const int lo = lohi[0], hi = lohi[1];
+        wg_barrier();                                       // (lohi is rewritten at the top of the next chunk)
+        const int64_t e0 = (base + lo) * 144;
+        const int n = hi >= lo ? (hi - lo + 1) * 144 : 0;
+        for (int el = tid; el < n; el += 1024) merge_prepare_el(merge_new, e0 + el, trust, ifn_L2, row_cell, scores_back);
+        phase();
+        if (merge_new) {
+            for (int el = tid; el < n; el += 1024) merge_select_new_el(g, e0 + el, row_cell, ifn_L2, scores_back, row_forced, out);
+        } else {
+            unsigned* wp = winner + p * g.per;
+            for (int64_t i = tid; i < g.per; i += 1024) __hip_atomic_store(&wp[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            phase();
+            const int cells = g.h4 * g.w4;
+            for (int i = tid; i < cells; i += 1024)
+                merge_scatter_old_cell(g, p, i, row_slot + (int64_t)c * NP, ifn_L2, scores_back, winner);
+            phase();
+            for (int el = tid; el < n; el += 1024) merge_finish_old_el<true>(g, e0 + el, row_cell, winner, row_forced, out);
+            // merge_patches_old hands back a zeroed scores_back (second_layer.py:191): the next chunk starts from zeros
+            for (int i = tid; i < N * 144; i += 1024) sbp[i] = 0.0;
+        }
+        phase();
+    }
 }
 
 // ---- third-level inputs, pats.py:53-58 ---------------------------------------------------------------
@@ -442,6 +534,14 @@ extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, 
     const int64_t NP = pairs * g.h * g.w;
     const int64_t block_cap = NP < rows_cap ? NP : rows_cap;       // a chunk block holds at most one row per coarse cell
     unsigned* winner = reinterpret_cast<unsigned*>(workspace);
+    // one workgroup per pair walks the chunk blocks in order (merge_pairs_kernel); PATS_MERGE_PER_CHUNK=1 (diagnostic library):
+    // the launch chain per chunk of rounds 3-5
+    static const bool per_chunk = [] { const char* e = diag_env("PATS_MERGE_PER_CHUNK"); return e && atoi(e) != 0; }();
+    if (!per_chunk && pairs <= 65535) {
+        hipLaunchKernelGGL(merge_pairs_kernel, dim3((unsigned)pairs), dim3(1024), 0, st, merge_new, g, Cmax, 0, Cmax, (int64_t)0, rows_cap,
+                           chunk_base, row_cell, row_slot, row_forced, trust_score, if_nomatching1_L2, scores_back, zero_scores_back, winner, out);
+        return check_launch("merge_patches_batch");
+    }
     // rows outside every block (padding past the total) are never visited: "no match"
     if (fill_bytes(out, 1, (size_t)rows_cap * 144, st)) return PATS_ERR_LAUNCH;
     // pats.py:32: every pair starts from a zeroed scores_back
@@ -464,6 +564,29 @@ extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, 
         }
     }
     return check_launch("merge_patches_batch");
+}
+
+// Chunks [c_lo, c_hi) of the table only, on tensors that hold table rows row_origin .. row_origin + rows_local (trust_score,
+// if_nomatching1_L2, out [rows_local,144]): PATS.forward's chunk loop (pats.py:33-37) walked chunk by chunk with the device-side
+// table - one launch per chunk, scores_back handed from call to call (zero_scores_back on the first).  row_forced applies
+// pats.py:38-39.  No reference counterpart beyond merge_patches_new / _old themselves (second_layer.py:137-238).
+extern "C" int pats_merge_patches_chunks(int merge_new, int Cmax, int c_lo, int c_hi, int64_t pairs, int H, int W, int64_t row_origin,
+                                         int64_t rows_local, const int64_t* chunk_base, const int32_t* row_cell,
+                                         const int32_t* row_slot, const uint8_t* row_forced, float* trust_score,
+                                         uint8_t* if_nomatching1_L2, double* scores_back, int zero_scores_back, uint8_t* out,
+                                         void* workspace, size_t workspace_bytes, pats_stream_t stream) {
+    PATS_REQUIRE(Cmax >= 1 && 0 <= c_lo && c_lo <= c_hi && c_hi <= Cmax && pairs >= 0 && pairs <= 65535 && H >= 32 && W >= 32 &&
+                     row_origin >= 0 && rows_local >= 0, "merge_patches_chunks: bad shape");
+    if (pairs == 0 || rows_local == 0 || c_lo == c_hi) return PATS_OK;
+    PATS_REQUIRE(chunk_base && row_cell && row_slot && row_forced && trust_score && if_nomatching1_L2 && scores_back && out,
+                 "merge_patches_chunks: null pointer");
+    PATS_REQUIRE(merge_new || (workspace && workspace_bytes >= pats_merge_batch_workspace_bytes(pairs, H, W)),
+                 "merge_patches_chunks: workspace too small");
+    MergeGeom g{H / 32, W / 32, 4 * (H / 32), 4 * (W / 32), (int64_t)(H / 32) * 4 * (W / 32) * 4 * 9};
+    hipLaunchKernelGGL(merge_pairs_kernel, dim3((unsigned)pairs), dim3(1024), 0, as_stream(stream), merge_new, g, Cmax, c_lo, c_hi,
+                       row_origin, rows_local, chunk_base, row_cell, row_slot, row_forced, trust_score, if_nomatching1_L2, scores_back,
+                       zero_scores_back, reinterpret_cast<unsigned*>(workspace), out);
+    return check_launch("merge_patches_chunks");
 }
 
 // ---- matches of a batch, grouped by pair (throughput mode's hand-over: what batch.split_by_pair did with argsort + bincount) ----

@@ -535,12 +535,25 @@ stream_finish_kernel(SrcViewS src, int M, int N, const float* __restrict__ a,
 // ------------------------------------------------------------------------------------------
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// A problem's share of the `partial` area in floats: ceil(M / 16) rows of N, rounded up to a multiple of FOUR floats.  The resident
+// kernel puts every problem's rows (pitch NP = N rounded to 4) and its 8-byte {b_j, tag} granules at partial + problem * stride: an odd
+// stride (49 x 769 for the 16 x 769^2 shape) left every odd problem's granule atomics and 16-byte sc1 loads on a 4-byte boundary,
+// where a granule can straddle a cache line and tear (round-5 advice).
+static inline size_t res_partial_stride(int M, int N) { return (((size_t)((M + 15) / 16) * (size_t)N) + 3) & ~(size_t)3; }
+
+// zeroes the N granules {b_j, tag} of every problem before the resident kernel: sweep 1 accepts a granule whose tag word is 1, and
+// the area is otherwise whatever the workspace held (tags of an earlier solve, any int32 array)
+__global__ void stream_granule_clear_kernel(float* partial, int64_t stride, size_t gran_off, int N) {
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(partial + (int64_t)blockIdx.y * stride + gran_off);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < N; j += gridDim.x * blockDim.x) g[j] = 0ull;
+}
+
 size_t stream_workspace_bytes(int64_t batch, int M, int N) {
     const int RB = 16;
     const int nblk = (M + RB - 1) / RB;
     size_t f = 0;
     f += al256((size_t)batch * M * N * 4);          // K
-    f += al256((size_t)batch * nblk * N * 4);       // partial
+    f += al256((size_t)batch * res_partial_stride(M, N) * 4);   // partial (a problem's share rounded to 16 bytes: see res_partial_stride)
     f += 2 * al256((size_t)batch * M * 4);          // r, a
     f += 2 * al256((size_t)batch * N * 4);          // c, b
     f += al256(512 * (size_t)batch + 512);          // the resident kernel's arrival counters (8 x 64 B a problem) and its give-up flag
@@ -576,7 +589,7 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
     const int nblk = (M + RBr - 1) / RBr;
     char* p = (char*)ws;
     float* K = (float*)p;        p += al256((size_t)batch * M * N * 4);
-    float* partial = (float*)p;  p += al256((size_t)batch * ((M + 15) / 16) * N * 4);       // sized for blocks of 16
+    float* partial = (float*)p;  p += al256((size_t)batch * res_partial_stride(M, N) * 4);  // sized for blocks of 16, 16-byte shares
     float* r = (float*)p;        p += al256((size_t)batch * M * 4);
     float* a = (float*)p;        p += al256((size_t)batch * M * 4);
     float* c = (float*)p;        p += al256((size_t)batch * N * 4);
@@ -635,7 +648,9 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
         if (diag_env("PATS_STREAM_TL")) { (void)hipMalloc((void**)&tl, (size_t)res_nblk * 6 * 8); (void)hipMemset(tl, 0, (size_t)res_nblk * 6 * 8); }
 #endif
         const dim3 rgrid((unsigned)res_nblk, (unsigned)batch);
-        const int64_t pstride = (int64_t)((M + 15) / 16) * N;            // a problem's share of the partial area (floats)
+        const int64_t pstride = (int64_t)res_partial_stride(M, N);       // a problem's share of the partial area (floats, multiple of 4)
+        hipLaunchKernelGGL(stream_granule_clear_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)batch), dim3(256), 0, st, partial, pstride,
+                           (size_t)res_nblk * NPr, N);
         if (res_kind == 1) hipLaunchKernelGGL((stream_resident_kernel<17, 9, 32>), rgrid, dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, pstride, res_nblk, iters, cnt, err, tl);
         else if (res_kind == 2) hipLaunchKernelGGL((stream_resident_kernel<32, 2, 64>), rgrid, dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, pstride, res_nblk, iters, cnt, err, tl);
         else hipLaunchKernelGGL((stream_resident_kernel<64, 2, 64>), rgrid, dim3(ST), 0, st, K, M, N, bv, log_mu, log_nu, a, partial, pstride, res_nblk, iters, cnt, err, tl);

@@ -894,6 +894,31 @@ def merge_patches_batch(merge_new, rows, trust_score, original_image_shape, if_n
     return out
 
 
+def merge_patches_chunk(merge_new, rows, c, row_origin, trust_score, original_image_shape, if_nomatching1_L2, scores_back,
+                        first=False):
+    """merge_patches_new / _old for chunk `c` of a ChunkRows table on that chunk's own tensors (trust_score / if_nomatching1_L2
+    [B,144] = table rows row_origin .. row_origin + B, updated in place): PATS.forward's chunk loop walked chunk by chunk
+    (pats.py:33-39) with one launch per chunk and no host read.  scores_back [pairs,N,16,9] float64 is handed from call to
+    call (first=True clears it, pats.py:32).  Returns if_nomatching [B,144] bool (pats.py:38-39 applied)."""
+    B = trust_score.shape[0]
+    H, W = int(original_image_shape[0]), int(original_image_shape[1])
+    if trust_score.dtype != torch.float32 or not trust_score.is_contiguous() or if_nomatching1_L2.dtype != torch.bool or \
+            not if_nomatching1_L2.is_contiguous() or trust_score.numel() != B * 144 or if_nomatching1_L2.numel() != B * 144:
+        raise RuntimeError("merge_patches_chunk: trust_score / if_nomatching1_L2 must be contiguous [B,144] float32 / bool")
+    if scores_back.dtype != torch.float64 or not scores_back.is_contiguous() or scores_back.numel() != rows.pairs * rows.h * rows.w * 144:
+        raise RuntimeError("merge_patches_chunk: scores_back must be a contiguous float64 [pairs, N, 16, 9] tensor")
+    dev = trust_score.device
+    out = torch.empty((B, 144), dtype=torch.bool, device=dev)
+    nws = _L().pats_merge_batch_workspace_bytes(rows.pairs, H, W)
+    ws = _workspace(nws, dev)
+    _check(_L().pats_merge_patches_chunks(1 if merge_new else 0, rows.Cmax, int(c), int(c) + 1, rows.pairs, H, W, int(row_origin), B,
+                                          _ptr(rows.chunk_base), _ptr(rows.row_cell), _ptr(rows.row_slot), _ptr(rows.row_forced),
+                                          _ptr(trust_score), _ptr(if_nomatching1_L2.view(torch.uint8)), _ptr(scores_back),
+                                          int(bool(first)), _ptr(out.view(torch.uint8)), _ptr(ws), nws, _stream()),
+           "merge_patches_chunk")
+    return out
+
+
 _ONES = {}
 
 

@@ -36,10 +36,16 @@ def _round4(x, clamp96):
     return torch.round(x / 4.0).long() * 4
 
 
-def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=True, iters=100, batch_chunks=False):
+def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=True, iters=100, batch_chunks=False,
+                 device_counts=False, streams=1):
     """left / right: [1,H,W,3] float32 HWC images (what first_layer.py:128-129 permutes to).
     Returns {"matches_l": [M,2], "matches_r": [M,2]} in the reference's (row, col) pixel convention and
     order, plus "chunks": per-chunk (B, P, M) for inspection.
+
+    device_counts=True (with batch_chunks=False): the same chunk-by-chunk walk with the counts the reference reads back inside
+    the loop (P per chunk, M per chunk, the boolean-mask sizes) left on the device - see forward_chunks_device below: two host
+    reads per pair (the chunk plan up front, the match counts at the end).  `streams` > 1 walks consecutive chunks on
+    different HIP streams (the merges stay in chunk order).
 
     batch_chunks=True runs all chunks of the pair together (the reference walks them one by one to bound
     memory on a 16-40 GB card): ONE fine-level cost+OT+expansion launch over the concatenated chunk rows,
@@ -49,6 +55,8 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
         nets.fine(None, new_left_all, new_right_all, masks [C,N], sizes=[B_0, ...])
         nets.third(None, mkpts0_c, mkpts1_c, b_ids (rows of the concatenation), sizes=[B_0, ...])
     Same matches in the same order (tests/test_gpu_parity.py::test_pipeline_chain runs both modes)."""
+    if device_counts and not batch_chunks:
+        return forward_chunks_device(left, right, nets, if_local, if_outdoor, merge_new, iters, streams)
     dev = left.device
     H, W = int(left.shape[1]), int(left.shape[2])
     h, w = H // 32, W // 32
@@ -154,3 +162,113 @@ def _forward_batched(left, nets, if_outdoor, iters, merge, scores_back, ifn1, su
                             [torch.ones([C], dtype=torch.bool, device=dev), torch.ones([Bt], dtype=torch.bool, device=dev)],
                             validate=False)                       # host read: M
     return {"matches_l": ml, "matches_r": mr, "chunks": [(b, -1, -1) for b in sizes]}
+
+
+_ONE = {}
+
+
+def _one(device):
+    """The reference's `self.one` (second_layer.py:63): a device-resident 1.0, made once per device."""
+    key = str(device)
+    if key not in _ONE:
+        _ONE[key] = torch.tensor(1.0, device=device)
+    return _ONE[key]
+
+
+class _ChunkTable:
+    """What ops.get_result_chunks reads of a ChunkRows table, for ONE chunk of one pair (its mask as the level-0 flags)."""
+    __slots__ = ("Cmax", "pairs", "h", "w", "rows_cap", "masks")
+
+    def __init__(self, rows, c, B):
+        self.Cmax, self.pairs, self.h, self.w, self.rows_cap, self.masks = 1, 1, rows.h, rows.w, int(B), rows.masks[c:c + 1]
+
+
+def forward_chunks_device(left, right, nets, if_local=True, if_outdoor=True, merge_new=True, iters=100, streams=1):
+    """PATS.forward's control flow (pats.py:18-85: the first layer, then chunk by chunk the second layer, the merge, the third
+    layer and get_result) with the counts the reference reads back INSIDE the chunk loop left on the device.  Host reads per
+    pair: the chunk plan (the chunk sizes B size the backbone's batch, so the host must know them: first_layer.py:130-146) and,
+    after the last chunk, the per-chunk match counts.  Per chunk: ~24 launches, no torch kernel, no synchronisation.
+      * the chunk masks, the rows' cells and pats.py:38-39's tail rows come from the device-side table (ops.chunk_rows);
+      * the merge is ONE launch per chunk on the chunk's own tensors (ops.merge_patches_chunk), scores_back handed on;
+      * the third level runs over the chunk's capacity 144 B with the count P on the device (ops.third_inputs(sync=False),
+        ops.third_level(count=P)); get_result likewise (ops.get_result_chunks on the chunk's mask).
+    Callbacks as in forward_path, except that the third level's tensors are a CAPACITY and the count arrives with them:
+        nets.third(num, mkpts0_c [144 B,2], mkpts1_c [144 B,2], b_ids [144 B], count=P_dev [1] int64) ->
+            feat0 [144 B,128,65], feat1, scale [144 B,1,64] [, p_s, p_t [144 B,2] int64 - ops.third_descriptors' roundings]
+        nets.fine may append scale_x * scale_y as a fifth tensor.
+    streams > 1: chunk c runs on side stream c % streams (its kernels are too small to fill the GPU: ~54 rows); the merges
+    wait for each other in chunk order (scores_back, pats.py:37).  Same matches, same order."""
+    dev = left.device
+    H, W = int(left.shape[1]), int(left.shape[2])
+    h, w = H // 32, W // 32
+    empty = torch.zeros([0, 2], device=dev)
+    mdesc0, mdesc1, scale, alpha = nets.coarse(left, right)
+    scores = ops.cost_ot(mdesc0, mdesc1, 1, alpha, scale, iters)
+    scales, cflag = ops.colmass_sqrt(scores, return_flags=True)
+    trust, pts, xs, ys, ifn1, ifn2 = ops.est_position_first(scores, scales, (H, W), 32, col_nomatch=cflag)
+    rows = ops.chunk_rows(ifn1, h, w, 2 * w if if_local else 512)
+    new_left, new_right, xsn, ysn, avn, _, _, _ = ops.Compute_imgs_ex(xs, ys, pts, ifn1, left, right, width=w, height=h,
+                                                                      known_count="device")
+    # host read 1: the chunk plan (row offsets of the chunks, their first crops, the table's status)
+    plan = torch.cat([rows.chunk_base, rows.second.reshape(-1), rows.status.to(torch.int64)]).cpu().tolist()
+    Cmax = rows.Cmax
+    base, second, status = plan[:Cmax + 1], plan[Cmax + 1:-1], plan[-1]
+    if status:
+        raise RuntimeError("pats_amd.pipeline: the chunk table overflowed (status %d)" % status)
+    if base[-1] <= 0:                                           # pats.py:27-31
+        return {"matches_l": empty, "matches_r": empty, "chunks": []}
+    scores_back = torch.empty([1, h * w, 16, 9], dtype=torch.float64, device=dev)       # pats.py:32 (cleared by the first merge)
+    cur = torch.cuda.current_stream()
+    side = [torch.cuda.Stream() for _ in range(streams)] if streams > 1 else None
+    if side is not None:
+        ready = torch.cuda.Event()
+        ready.record(cur)
+    one, bias_k = _one(dev), 2.0 if if_outdoor else 3.0
+    parts, sizes, prev_merge, first = [], [], None, True
+    for c in range(Cmax):
+        B = base[c + 1] - base[c]
+        if B <= 0:
+            continue
+        lo = second[2 * c]
+        st = side[len(parts) % streams] if side is not None else cur
+        with torch.cuda.stream(st):
+            if side is not None and len(parts) < streams:
+                st.wait_event(ready)
+            # ---- second layer tail (second_layer.py:100-118) ----------------------------------------------------------
+            fine = nets.fine(c, new_left[lo:lo + B], new_right[lo:lo + B], rows.masks[c])
+            f0, f1, sx, sy = fine[:4]
+            ns2 = fine[4] if len(fine) > 4 else (sx * sy).contiguous()
+            Z2, cflag2 = ops.cost_ot(f0, f1, 2, one, ns2, iters, bias_k=bias_k, return_flags=True)
+            trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
+            # ---- merge (second_layer.py:119-122, pats.py:37-39), in chunk order ------------------------------------------
+            if side is not None and prev_merge is not None:
+                st.wait_event(prev_merge)
+            merged = ops.merge_patches_chunk(merge_new, rows, c, base[c], trust2, (H, W), ifn_L2, scores_back, first=first)
+            first = False
+            if side is not None:
+                prev_merge = torch.cuda.Event()
+                prev_merge.record(st)
+            # ---- third layer over the chunk's capacity (pats.py:53-58, third_layer.py:121-170) -----------------------------
+            mk0, mk1, b_ids, P = ops.third_inputs(merged, pts2, capacity=B * 144, sync=False)
+            third = nets.third(c, mk0, mk1, b_ids, count=P)
+            feat0, feat1, scale3 = third[:3]
+            p_s, p_t = third[3:5] if len(third) > 3 else (_round4(mk0, False), _round4(mk1, True))
+            m0f, m1f, label, ifm = ops.third_level(feat0, feat1, scale3, p_s, p_t, outdoor=if_outdoor, iters=iters, count=P)
+            # ---- results (pats.py:59-78) ---------------------------------------------------------------------------------
+            ifn16, pts16 = ops.refine_scatter(merged, pts2, m1f, label)
+            ml, mr, _, M = ops.get_result_chunks(_ChunkTable(rows, c, B), ifn16, avn, pts16, xsn)
+        parts.append((ml, mr, M, P))
+        sizes.append(B)
+    if side is not None:
+        for st in side:
+            cur.wait_stream(st)
+        for ml, mr, M, P in parts:
+            for t in (ml, mr, M, P):
+                t.record_stream(cur)
+    # host read 2: the counts of every chunk
+    counts = torch.cat([torch.cat([M, P]) for _, _, M, P in parts]).cpu().tolist()
+    Ms, Ps = counts[0::2], counts[1::2]
+    out_l = [ml[:m] for (ml, _, _, _), m in zip(parts, Ms) if m > 0]
+    out_r = [mr[:m] for (_, mr, _, _), m in zip(parts, Ms) if m > 0]
+    return {"matches_l": torch.cat(out_l) if out_l else empty, "matches_r": torch.cat(out_r) if out_r else empty,
+            "chunks": [(b, p_, m) for b, p_, m in zip(sizes, Ps, Ms)]}

@@ -764,7 +764,14 @@ class _CudaNets:
         f = self.n.fine(num, new_left.shape[0])
         return cu(f["d0"]), cu(f["d1"]), cu(f["scale_x"]), cu(f["scale_y"])
 
-    def third(self, num, mk0, mk1, b_ids, sizes=None):
+    def third(self, num, mk0, mk1, b_ids, sizes=None, count=None):
+        if count is not None:           # device-count walk: the tensors are a capacity, the first `count` rows exist
+            P, cap = int(count.item()), mk0.shape[0]        # (a host read inside the TEST's network stand-in, not in the path)
+            t = self.n.third(num, P) if P > 0 else None
+            pad = lambda a, shape: cu(np.concatenate([a, np.ones((cap - P,) + shape, np.float32)]) if a is not None
+                                      else np.ones((cap,) + shape, np.float32))
+            return (pad(t["d0"] if t else None, (128, 65)), pad(t["d1"] if t else None, (128, 65)),
+                    pad(t["scale"] if t else None, (1, 64)))
         if num is None:
             edges = np.cumsum([0] + list(sizes))
             per = np.histogram(b_ids.cpu().numpy(), bins=edges)[0]          # third-level problems per chunk
@@ -774,7 +781,7 @@ class _CudaNets:
         return cu(t["d0"]), cu(t["d1"]), cu(t["scale"])
 
 
-@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("batched", [False, True, "device_counts", "device_counts_3_streams"])
 @pytest.mark.parametrize("name", ["pipeline_outdoor.npz", "pipeline_indoor.npz", "pipeline_640x480_outdoor.npz",
                                   "pipeline_640x480_indoor.npz"])
 def test_pipeline_chain(name, batched):
@@ -787,8 +794,11 @@ def test_pipeline_chain(name, batched):
     g = golden(name)
     nets = synth.SynthNets(seed=int(g["seed"]), h=int(g["h"]), w=int(g["w"]))
     left, right = [cu(x) for x in nets.images()]
+    mode = {}
+    if isinstance(batched, str):        # the chunk walk with the counts on the device (pipeline.forward_chunks_device)
+        mode, batched = dict(device_counts=True, streams=3 if batched.endswith("streams") else 1), False
     out = pipeline.forward_path(left, right, _CudaNets(nets), if_local=bool(g["if_local"]),
-                                if_outdoor=bool(g["if_outdoor"]), merge_new=bool(g["merge_new"]), batch_chunks=batched)
+                                if_outdoor=bool(g["if_outdoor"]), merge_new=bool(g["merge_new"]), batch_chunks=batched, **mode)
     if batched:
         assert [c[0] for c in out["chunks"]] == g["chunks"][:, 0].tolist()
     else:
