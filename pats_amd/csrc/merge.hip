@@ -75,6 +75,36 @@ scan_tiles_kernel(int32_t* __restrict__ tile_base, int tiles, int64_t* __restric
     if (t == 0 && total) *total = carry;
 }
 
+// n <= 16 384 flags (a chunk's 144 B cells, a pair's coarse cells): the whole scan in ONE workgroup and one launch - 16 flags a
+// thread; offs holds the global exclusive offsets, the tile bases are zero.  (Walking PATS.forward chunk by chunk runs four scans
+// per chunk: two launches each were 64 of a pair's 210.)
+constexpr int SCAN_SMALL = 16384;
+__global__ void __launch_bounds__(1024)
+scan_small_kernel(const uint8_t* __restrict__ flags, int n, int32_t* __restrict__ offs, int32_t* __restrict__ tile_base, int tiles,
+                  int64_t* __restrict__ total) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i0 = t * 16;
+    int keep[16], c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        keep[k] = (i0 + k < n) ? (flags[i0 + k] == 0) : 0;
+        c += keep[k];
+    }
+    const int incl = wave_incl_scan(c, lane);
+    if (lane == 63) wsum[wave] = incl;
+    wg_barrier();
+    int base = 0, all = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum[w]; all += wsum[w]; }
+    int run = base + incl - c;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (i0 + k < n) offs[i0 + k] = run;
+        run += keep[k];
+    }
+    if (t < tiles) tile_base[t] = 0;
+    if (t == 0 && total) *total = all;
+}
+
 struct Scan {
     int32_t* offs;
     int32_t* tile_base;
@@ -95,6 +125,10 @@ static int run_scan(const uint8_t* flags, int64_t n, int64_t* total_dev, char** 
     if (n == 0) {
         if (total_dev && hipMemsetAsync(total_dev, 0, sizeof(int64_t), st) != hipSuccess) return check_launch("scan memset");
         return PATS_OK;
+    }
+    if (n <= SCAN_SMALL) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, flags, (int)n, sc->offs, sc->tile_base, (int)tiles, total_dev);
+        return check_launch("scan_small");
     }
     hipLaunchKernelGGL(scan_flags_kernel, dim3((unsigned)tiles), dim3(256), 0, st, flags, n, sc->offs, sc->tile_base);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, sc->tile_base, (int)tiles, total_dev);
@@ -256,7 +290,6 @@ merge_scatter_old_kernel(MergeGeom g, int batch_num, const int32_t* __restrict__
     merge_scatter_old_cell(g, bt, e - bt * cells, slot, ifn_L2, scores_back, winner);
 }
 
-template <bool COHERENT>
 __device__ __forceinline__ void merge_finish_old_el(const MergeGeom& g, int64_t e, const int32_t* __restrict__ patch_of,
                                                     const unsigned* __restrict__ winner, const uint8_t* __restrict__ row_forced,
                                                     uint8_t* __restrict__ out) {
@@ -269,9 +302,7 @@ __device__ __forceinline__ void merge_finish_old_el(const MergeGeom& g, int64_t 
         const int hw = g.h * g.w;
         const int64_t bt = q / hw;
         const int p = (int)(q - bt * hw), hh = p / g.w, ww = p % g.w;
-        const unsigned* wp = &winner[bt * g.per + ((int64_t)(4 * hh + r) * g.w4 + 4 * ww + s) * 9 + a * 3 + c];
-        // COHERENT: the atomics of the scatter ran at L2 inside THIS launch; read past the CU's vector cache
-        const unsigned v = COHERENT ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *wp;
+        const unsigned v = winner[bt * g.per + ((int64_t)(4 * hh + r) * g.w4 + 4 * ww + s) * 9 + a * 3 + c];
         if (v) res = (uint8_t)(v & 1u);
     }
     if (row_forced && row_forced[b]) res = 1;
@@ -286,72 +317,120 @@ merge_finish_old_kernel(MergeGeom g, RowBlock rb, const int32_t* __restrict__ pa
     rb.get(base, B);
     const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (el >= B * 144) return;
-    merge_finish_old_el<false>(g, el + base * 144, patch_of, winner, row_forced, out);
+    merge_finish_old_el(g, el + base * 144, patch_of, winner, row_forced, out);
 }
 
-// ---- the merges of ONE PAIR in one workgroup: chunk blocks in order (scores_back couples them, pats.py:32,37), the phases of a
-// chunk separated by workgroup barriers instead of kernel boundaries.  One launch per batch (grid = pairs) where
-// pats_merge_patches_batch queued two fills + two (new) / four (old) launches per chunk: at one pair a step - the reference's
-// execution mode - the merges were 16 of a pair's 60 launches.  Pairs never read each other's rows or scores_back slice.
-// Everything that crosses threads inside a phase boundary is global memory written and read by the SAME workgroup (stores are
-// written through the CU's vector cache, so after the barrier's vmcnt(0) the loads see them); `winner` is updated by L2 atomics
-// and therefore read back with agent-scope loads.
-__global__ void __launch_bounds__(1024)
-merge_pairs_kernel(int merge_new, MergeGeom g, int Cmax, int c_lo, int c_hi, int64_t row_origin, int64_t rows_local,
-                   const int64_t* __restrict__ chunk_base,
-                   const int32_t* __restrict__ row_cell, const int32_t* __restrict__ row_slot,
-                   const uint8_t* __restrict__ row_forced, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
-                   double* __restrict__ scores_back, int zero_scores_back, unsigned* __restrict__ winner, uint8_t* __restrict__ out) {
-    __shared__ int lohi[2];
-    const int tid = threadIdx.x, N = g.h * g.w;
-    const int64_t p = blockIdx.x, pairs = gridDim.x, NP = pairs * N;
-    // trust / ifn_L2 / out hold table rows row_origin .. row_origin + rows_local (the whole table in batch mode: origin 0; one
-    // chunk's rows when PATS.forward's chunk loop is walked chunk by chunk, pats_merge_patches_chunks): index them by table row
-    trust -= row_origin * 144; ifn_L2 -= row_origin * 144; out -= row_origin * 144;
-    // rows outside the blocks walked here (padding past the total in batch mode) are never visited: "no match"
-    {
-        const int64_t first = chunk_base[c_lo], last = chunk_base[c_hi];
-        for (int64_t e = row_origin * 144 + p * 1024 + tid; e < (row_origin + rows_local) * 144; e += pairs * 1024)
-            if (e < first * 144 || e >= last * 144) out[e] = 1;
-    }
-    double* sbp = scores_back + p * N * 144;
-    if (zero_scores_back)                                   // pats.py:32: every pair starts from a zeroed scores_back
-        for (int i = tid; i < N * 144; i += 1024) sbp[i] = 0.0;
-    auto phase = [&]() { wg_barrier_global(); };
-    phase();
-    for (int c = c_lo; c < c_hi; ++c) {
-        const int64_t base = chunk_base[c], end = chunk_base[c + 1];
-        if (end <= base) continue;                          // (uniform)
-        // this pair's rows of the block: a contiguous run (rows are ordered (chunk, pair, cell))
-        if (tid == 0) { lohi[0] = 0x7fffffff; lohi[1] = -1; }
-        wg_barrier();
-        for (int64_t r = base + tid; r < end; r += 1024) {
-            const int32_t q = row_cell[r];
-            if (q >= 0 && q / N == p) { atomicMin(&lohi[0], (int)(r - base)); atomicMax(&lohi[1], (int)(r - base)); }
+// ---- merge_patches_new for SEVERAL chunks of a row table in two fully parallel launches ---------------------------------------
+// The reference walks the chunks in order because they couple through scores_back (pats.py:32,37): the select of chunk c reads,
+// for every candidate window, the score its owner patch left there - written by the prepare of the LATEST chunk <= c that holds the
+// owner (a patch of the grid row two chunks share is in both), or what scores_back held before.  That value is a function of the
+// owner row's RAW trust score and flag alone (merge_prepared below), so nothing has to be written before it is read:
+//   select   one thread per (row, window cell): finds each candidate owner's row through the table (row_slot of chunk c, c - 1, ...),
+//            recomputes the nine prepared scores from the raw tensors, falls back to the scores_back it was handed (zeros when the
+//            call starts a pair) and writes `out`.  Reads trust / flags, writes only `out`.
+//   prepare  afterwards, in place: border weighting + flag update of every row (second_layer.py:192-201), the scores of a patch's
+//            LAST row in the range into scores_back (what the sequential walk leaves there), zeros for patches without a row when
+//            the call starts a pair, "no match" for rows outside the walked blocks.
+// Two launches for all chunks of all pairs (rounds 3-5: two per chunk, 16 of a pair's 60 launches at one pair a step); the same
+// two per chunk when PATS.forward's loop is walked chunk by chunk (pats_merge_patches_chunks).  A one-workgroup-per-pair kernel
+// with barriers between the phases was tried first: 18 us a chunk, VALU-bound on its single CU.
+struct MergeTable {
+    int Cmax, c_lo, c_hi;
+    int64_t pairs, row_origin, rows_local;
+    const int64_t* chunk_base; const int32_t* row_cell; const int32_t* row_slot; const uint8_t* row_forced;
+};
+
+// second_layer.py:194-201 for one cell: weighted trust score and updated flag from the raw ones
+__device__ __forceinline__ float merge_prepared(float t, uint8_t f_in, int x, int y, uint8_t& f_out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (x < 3 - i || x > 7 + i || y < 3 - i || y > 7 + i) t *= 2.0f;
+    uint8_t f = f_in;
+    if (t > 2.0f) f = 1;
+    if (x < 1 || x > 10 || y < 1 || y > 10) f = 1;
+    if (!f) t -= 10000.0f;
+    f_out = f;
+    return t;
+}
+
+__global__ void __launch_bounds__(256)
+merge_select_new_par_kernel(MergeGeom g, MergeTable tb, const float* __restrict__ trust, const uint8_t* __restrict__ ifn_L2,
+                            const double* __restrict__ scores_back, int fresh, uint8_t* __restrict__ out) {
+    const int64_t first = tb.chunk_base[tb.c_lo], last = tb.chunk_base[tb.c_hi];
+    const int64_t el = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (el >= (last - first) * 144) return;
+    const int64_t row = first + el / 144;
+    const int cell = (int)(el % 144), x = cell % 12, y = cell / 12;
+    int c = tb.c_lo;
+    while (c + 1 < tb.c_hi && row >= tb.chunk_base[c + 1]) ++c;       // the row's chunk
+    const int N = g.h * g.w;
+    const int64_t NP = tb.pairs * N;
+    const int32_t q = tb.row_cell[row];
+    trust -= tb.row_origin * 144; ifn_L2 -= tb.row_origin * 144; out -= tb.row_origin * 144;
+    const int64_t e = row * 144 + cell;
+    uint8_t res = 1;
+    if (q >= 0) {
+        uint8_t f_own;
+        (void)merge_prepared(trust[e], ifn_L2[e], x, y, f_own);
+        const int bt = q / N, pl = q - bt * N, hh = pl / g.w, ww = pl - hh * g.w;
+        const int a = y >> 2, r = y & 3, cc = x >> 2, s_ = x & 3;
+        const int Y = 4 * hh + r + 4 * (a - 1), X = 4 * ww + s_ + 4 * (cc - 1);
+        if (Y >= 0 && Y < g.h4 && X >= 0 && X < g.w4) {
+            const int64_t qs = (int64_t)bt * N + (Y >> 2) * g.w + (X >> 2);      // the owner of fine cell (Y, X)
+            int64_t rs = -1;                                                  // its row in the latest chunk <= c of the walk
+            for (int c2 = c; c2 >= tb.c_lo && rs < 0; --c2) rs = tb.row_slot[(int64_t)c2 * NP + qs];
+            const double* u = scores_back + (qs * 16 + (Y & 3) * 4 + (X & 3)) * 9;
+            int sb = 0;
+            double best = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                double v;
+                if (rs >= 0) {
+                    const int yy = (k / 3) * 4 + (Y & 3), xx = (k % 3) * 4 + (X & 3);
+                    uint8_t fk;
+                    v = (double)merge_prepared(trust[rs * 144 + yy * 12 + xx], ifn_L2[rs * 144 + yy * 12 + xx], xx, yy, fk);
+                } else {
+                    v = fresh ? 0.0 : u[k];
+                }
+                const int by = Y + 4 * (k / 3 - 1), bx = X + 4 * (k % 3 - 1);
+                if (by < 0 || by >= g.h4 || bx < 0 || bx >= g.w4) v += 100000.0;
+                if (k == 0 || v < best) { best = v; sb = k; }
+            }
+            if (sb == 8 - (a * 3 + cc)) res = f_own;
         }
-        wg_barrier();
-        const int lo = lohi[0], hi = lohi[1];
-        wg_barrier();                                       // (lohi is rewritten at the top of the next chunk)
-        const int64_t e0 = (base + lo) * 144;
-        const int n = hi >= lo ? (hi - lo + 1) * 144 : 0;
-        for (int el = tid; el < n; el += 1024) merge_prepare_el(merge_new, e0 + el, trust, ifn_L2, row_cell, scores_back);
-        phase();
-        if (merge_new) {
-            for (int el = tid; el < n; el += 1024) merge_select_new_el(g, e0 + el, row_cell, ifn_L2, scores_back, row_forced, out);
-        } else {
-            unsigned* wp = winner + p * g.per;
-            for (int64_t i = tid; i < g.per; i += 1024) __hip_atomic_store(&wp[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            phase();
-            const int cells = g.h4 * g.w4;
-            for (int i = tid; i < cells; i += 1024)
-                merge_scatter_old_cell(g, p, i, row_slot + (int64_t)c * NP, ifn_L2, scores_back, winner);
-            phase();
-            for (int el = tid; el < n; el += 1024) merge_finish_old_el<true>(g, e0 + el, row_cell, winner, row_forced, out);
-            // merge_patches_old hands back a zeroed scores_back (second_layer.py:191): the next chunk starts from zeros
-            for (int i = tid; i < N * 144; i += 1024) sbp[i] = 0.0;
-        }
-        phase();
     }
+    if (tb.row_forced[row]) res = 1;                    // pats.py:38-39 on the returned flags
+    out[e] = res;
+}
+
+__global__ void __launch_bounds__(256)
+merge_prepare_new_par_kernel(MergeGeom g, MergeTable tb, float* __restrict__ trust, uint8_t* __restrict__ ifn_L2,
+                             double* __restrict__ scores_back, int fresh, uint8_t* __restrict__ out) {
+    const int64_t first = tb.chunk_base[tb.c_lo], last = tb.chunk_base[tb.c_hi];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int N = g.h * g.w;
+    const int64_t NP = tb.pairs * N;
+    if (fresh && i < NP * 144) {                        // pats.py:32: a pair starts from zeros - patches without a row keep them
+        const int64_t qz = i / 144;
+        bool has = false;
+        for (int c2 = tb.c_lo; c2 < tb.c_hi && !has; ++c2) has = tb.row_slot[(int64_t)c2 * NP + qz] >= 0;
+        if (!has) scores_back[i] = 0.0;
+    }
+    if (i >= tb.rows_local * 144) return;
+    const int64_t row = tb.row_origin + i / 144;
+    if (row < first || row >= last) { out[i] = 1; return; }            // rows outside the walked blocks: "no match"
+    const int cell = (int)(i % 144), x = cell % 12, y = cell / 12;
+    uint8_t f;
+    const float t = merge_prepared(trust[i], ifn_L2[i], x, y, f);
+    trust[i] = t;
+    ifn_L2[i] = f;
+    const int32_t q = tb.row_cell[row];
+    if (q < 0) return;
+    int c = tb.c_lo;
+    while (c + 1 < tb.c_hi && row >= tb.chunk_base[c + 1]) ++c;
+    for (int c2 = c + 1; c2 < tb.c_hi; ++c2)
+        if (tb.row_slot[(int64_t)c2 * NP + q] >= 0) return;           // a later chunk of the walk holds the patch again: its row writes
+    scores_back[((int64_t)q * 16 + (y & 3) * 4 + (x & 3)) * 9 + (y >> 2) * 3 + (x >> 2)] = (double)t;
 }
 
 // ---- third-level inputs, pats.py:53-58 ---------------------------------------------------------------
@@ -534,12 +613,16 @@ extern "C" int pats_merge_patches_batch(int merge_new, int Cmax, int64_t pairs, 
     const int64_t NP = pairs * g.h * g.w;
     const int64_t block_cap = NP < rows_cap ? NP : rows_cap;       // a chunk block holds at most one row per coarse cell
     unsigned* winner = reinterpret_cast<unsigned*>(workspace);
-    // one workgroup per pair walks the chunk blocks in order (merge_pairs_kernel); PATS_MERGE_PER_CHUNK=1 (diagnostic library):
-    // the launch chain per chunk of rounds 3-5
+    // merge_new: two parallel launches for all chunks (merge_select_new_par_kernel); PATS_MERGE_PER_CHUNK=1 (diagnostic library): the
+    // launch chain per chunk of rounds 3-5.  merge_old (indoor: one chunk, cap 512) keeps its chain.
     static const bool per_chunk = [] { const char* e = diag_env("PATS_MERGE_PER_CHUNK"); return e && atoi(e) != 0; }();
-    if (!per_chunk && pairs <= 65535) {
-        hipLaunchKernelGGL(merge_pairs_kernel, dim3((unsigned)pairs), dim3(1024), 0, st, merge_new, g, Cmax, 0, Cmax, (int64_t)0, rows_cap,
-                           chunk_base, row_cell, row_slot, row_forced, trust_score, if_nomatching1_L2, scores_back, zero_scores_back, winner, out);
+    if (merge_new && !per_chunk) {
+        const MergeTable tb{Cmax, 0, Cmax, pairs, 0, rows_cap, chunk_base, row_cell, row_slot, row_forced};
+        hipLaunchKernelGGL(merge_select_new_par_kernel, dim3(blocks256(rows_cap * 144)), dim3(256), 0, st, g, tb, trust_score, if_nomatching1_L2,
+                           scores_back, zero_scores_back, out);
+        const int64_t n2 = rows_cap > NP ? rows_cap : NP;
+        hipLaunchKernelGGL(merge_prepare_new_par_kernel, dim3(blocks256(n2 * 144)), dim3(256), 0, st, g, tb, trust_score, if_nomatching1_L2,
+                           scores_back, zero_scores_back, out);
         return check_launch("merge_patches_batch");
     }
     // rows outside every block (padding past the total) are never visited: "no match"
@@ -583,9 +666,34 @@ extern "C" int pats_merge_patches_chunks(int merge_new, int Cmax, int c_lo, int 
     PATS_REQUIRE(merge_new || (workspace && workspace_bytes >= pats_merge_batch_workspace_bytes(pairs, H, W)),
                  "merge_patches_chunks: workspace too small");
     MergeGeom g{H / 32, W / 32, 4 * (H / 32), 4 * (W / 32), (int64_t)(H / 32) * 4 * (W / 32) * 4 * 9};
-    hipLaunchKernelGGL(merge_pairs_kernel, dim3((unsigned)pairs), dim3(1024), 0, as_stream(stream), merge_new, g, Cmax, c_lo, c_hi,
-                       row_origin, rows_local, chunk_base, row_cell, row_slot, row_forced, trust_score, if_nomatching1_L2, scores_back,
-                       zero_scores_back, reinterpret_cast<unsigned*>(workspace), out);
+    hipStream_t st = as_stream(stream);
+    const int64_t NP = pairs * g.h * g.w;
+    if (merge_new) {
+        const MergeTable tb{Cmax, c_lo, c_hi, pairs, row_origin, rows_local, chunk_base, row_cell, row_slot, row_forced};
+        hipLaunchKernelGGL(merge_select_new_par_kernel, dim3(blocks256(rows_local * 144)), dim3(256), 0, st, g, tb, trust_score,
+                           if_nomatching1_L2, scores_back, zero_scores_back, out);
+        const int64_t n2 = zero_scores_back && NP > rows_local ? NP : rows_local;
+        hipLaunchKernelGGL(merge_prepare_new_par_kernel, dim3(blocks256(n2 * 144)), dim3(256), 0, st, g, tb, trust_score, if_nomatching1_L2,
+                           scores_back, zero_scores_back, out);
+        return check_launch("merge_patches_chunks");
+    }
+    // merge_old: the per-chunk chain on pointers shifted to table rows
+    unsigned* winner = reinterpret_cast<unsigned*>(workspace);
+    float* tr = trust_score - row_origin * 144;
+    uint8_t* fl = if_nomatching1_L2 - row_origin * 144;
+    uint8_t* ou = out - row_origin * 144;
+    if (fill_bytes(out, 1, (size_t)rows_local * 144, st)) return PATS_ERR_LAUNCH;
+    if (zero_scores_back && fill_bytes(scores_back, 0, sizeof(double) * (size_t)(NP * 144), st)) return PATS_ERR_LAUNCH;
+    const int64_t block_cap = NP < rows_local ? NP : rows_local;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const RowBlock rb{chunk_base + c, 0};
+        hipLaunchKernelGGL(merge_prepare_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, 0, rb, tr, fl, row_cell, scores_back);
+        if (fill_bytes(winner, 0, sizeof(unsigned) * (size_t)(pairs * g.per), st)) return PATS_ERR_LAUNCH;
+        hipLaunchKernelGGL(merge_scatter_old_kernel, dim3(blocks256((int64_t)g.h4 * g.w4 * pairs)), dim3(256), 0, st, g, (int)pairs,
+                           row_slot + (int64_t)c * NP, fl, scores_back, winner);
+        hipLaunchKernelGGL(merge_finish_old_kernel, dim3(blocks256(block_cap * 144)), dim3(256), 0, st, g, rb, row_cell, winner, row_forced, ou);
+        if (fill_bytes(scores_back, 0, sizeof(double) * (size_t)(NP * 144), st)) return PATS_ERR_LAUNCH;
+    }
     return check_launch("merge_patches_chunks");
 }
 

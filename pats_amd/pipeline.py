@@ -89,7 +89,7 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
             continue
         mask = torch.logical_or(ifn1, torch.logical_or(sum_cycle <= lo, sum_cycle > hi))    # first_layer.py:137-138
         # ---- second layer tail (second_layer.py:100-124) --------------------------------------------
-        f0, f1, sx, sy = nets.fine(num, new_left[lo:hi_c], new_right[lo:hi_c], mask)
+        f0, f1, sx, sy = nets.fine(num, new_left[lo:hi_c], new_right[lo:hi_c], mask)[:4]
         Z2, cflag2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0,
                                  return_flags=True)
         trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
@@ -132,7 +132,7 @@ def _forward_batched(left, nets, if_outdoor, iters, merge, scores_back, ifn1, su
     masks = torch.cat([torch.logical_or(ifn1, torch.logical_or(sum_cycle <= lo, sum_cycle > hi))
                        for lo, hi in second_set if min(hi, K) - lo > 0])                  # [C,N]  (first_layer.py:137-138)
     rows = torch.cat([torch.arange(lo, hi, device=dev) for lo, hi, _ in spans])          # overlap rows appear twice
-    f0, f1, sx, sy = nets.fine(None, new_left[rows], new_right[rows], masks, sizes=sizes)
+    f0, f1, sx, sy = nets.fine(None, new_left[rows], new_right[rows], masks, sizes=sizes)[:4]
     Z2, cflag2 = ops.cost_ot(f0, f1, 2, 1.0, (sx * sy).contiguous(), iters, bias_k=2.0 if if_outdoor else 3.0,
                              return_flags=True)
     trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
@@ -173,6 +173,17 @@ def _one(device):
     if key not in _ONE:
         _ONE[key] = torch.tensor(1.0, device=device)
     return _ONE[key]
+
+
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    """The chunk walk's side streams, made once per device (a new HIP stream per pair cost up to 90 ms now and then)."""
+    pool = _SIDE.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
 
 
 class _ChunkTable:
@@ -219,7 +230,7 @@ def forward_chunks_device(left, right, nets, if_local=True, if_outdoor=True, mer
         return {"matches_l": empty, "matches_r": empty, "chunks": []}
     scores_back = torch.empty([1, h * w, 16, 9], dtype=torch.float64, device=dev)       # pats.py:32 (cleared by the first merge)
     cur = torch.cuda.current_stream()
-    side = [torch.cuda.Stream() for _ in range(streams)] if streams > 1 else None
+    side = _side_streams(dev, streams) if streams > 1 else None
     if side is not None:
         ready = torch.cuda.Event()
         ready.record(cur)

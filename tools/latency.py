@@ -197,8 +197,10 @@ def latency_leg(ops, batch, pipeline, bench, dev, workload="megadepth", n=20, wi
             return o
 
         def run_b():
+            t0 = time.perf_counter()
             o = batch.forward_pairs(left, right, nets_b, cap, **kw)
             batch.group_by_pair(o, cap)
+            info.setdefault("enq", []).append(time.perf_counter() - t0)      # host time to queue the pair's launches
             info["Mb"] = hand(o)
             return o
         leg(tag + "a_reference_control_flow", lambda: run_a(False), n)
@@ -213,6 +215,7 @@ def latency_leg(ops, batch, pipeline, bench, dev, workload="megadepth", n=20, wi
         leg(tag + "b_forward_pairs_1", run_b, n)
         if tag + "b_forward_pairs_1" in res:
             res[tag + "b_forward_pairs_1"]["matches"] = info.get("Mb")
+            res[tag + "b_forward_pairs_1"]["host_enqueue_ms"] = 1e3 * float(np.median(info["enq"]))
         name = tag + "b_graph"
         if legs is None or name in legs:
             try:
