@@ -71,6 +71,7 @@ def _ptr(t):
 
 _WS = {}
 _WS_MAX = 64 << 20
+_WS_OFF = __import__("os").environ.get("PATS_WS_CACHE", "1") == "0"      # A/B switch of the scratch cache (python side only)
 
 
 def _workspace(nbytes, device):
@@ -79,7 +80,7 @@ def _workspace(nbytes, device):
     walked chunk by chunk made 300 allocator calls, a third of them these).  Larger requests (the GNN stacks) and calls made
     while a HIP graph is being captured get a block of their own."""
     n = max(int(nbytes), 1)
-    if n > _WS_MAX or _raw_stream is None or torch.cuda.is_current_stream_capturing():
+    if n > _WS_MAX or _raw_stream is None or _WS_OFF or torch.cuda.is_current_stream_capturing():
         return torch.empty(n, dtype=torch.uint8, device=device)
     key = (device.index, _raw_stream(torch.cuda.current_device()))
     t = _WS.get(key)
