@@ -90,6 +90,7 @@ def parse():
                     help="do not re-run three steps under rocprofv3 --pmc for roofline.traffic (default: done when rocprofv3 is on PATH, one "
                          "rank, not --no-secondary; the committed profiles/r*_pmc_step_<layout>.json is the fallback, with its age in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-pair-at-a-time latency legs (tools/latency.py)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline / guard-trip measurements")
     ap.add_argument("--overlap", type=int, default=0, metavar="K",
                     help="K > 0: two HIP streams with disjoint compute-unit masks - the HBM-bound stages (crops, descriptor gathers) of "
@@ -562,7 +563,7 @@ def expansion_parity(ops, oracle, dev, sx, sy, gZ2, Z2):
     }
 
 
-def cpu_baseline(ops, batch, dev, nets, cap, wl, out):
+def cpu_baseline(ops, batch, dev, nets, cap, wl, out, torch_leg=True):
     """The CPU oracle ("port") on the host cores over ONE WHOLE PAIR (pair 0 of a step: L1 in full, every fine problem,
     every third-level problem the merge left, the merges, the scatter and get_result) - measured, not extrapolated.
     Each stage is fed what the GPU handed its own next stage, so the same run is a stage-by-stage parity check on the
@@ -691,6 +692,10 @@ def cpu_baseline(ops, batch, dev, nets, cap, wl, out):
     assert parity["l3_mkpts1_max_abs_diff_px"] <= 3e-4 * 8 and parity["l2_mass_max_abs_diff"] <= 1e-4, parity
     assert same_count and parity["matches_l_mismatch"] == 0 and parity["matches_r_mismatch"] == 0, parity
     per_pair = sum(times.values())
+    if not torch_leg:                                    # the secondary workloads: the oracle's pair + its parity only
+        return {"value": 1.0 / per_pair, "unit": "pairs/s", "cores": cores, "kind": "port", "seconds_per_pair": per_pair,
+                "sample": "oracle/pats_oracle.c on ONE WHOLE PAIR (pair 0 of a step): L1 %dx%d, %d fine, %d third-level problems"
+                          % (N + 1, N + 1, B0, P0), "parity_sample": parity}
 
     # ---- torch-CPU transcription of what the reference executes (einsum cost + logsumexp sweeps), on samples ----------
     torch.set_num_threads(cores)
@@ -996,6 +1001,68 @@ def guard_trip_sweep(ops, batch, nets, cap, wl, fracs=(0.01, 0.10)):
     return res
 
 
+# algorithmic HBM bytes per unit of the four data-moving kernels of a step (kernel table); the same figures main() prices
+# the headline's kernels with
+THIRD_BYTES_PER_PROBLEM = 2 * 128 * 65 * 4 + 64 * 4 + 2 * 2 * 8 + 2 * 16 * 2 * 4 + 16 * 2 * 4 + 16
+FINE_BYTES_PER_ROW = 2.0 * 264 * 145 * 4 + 145 * 145 * 4
+FD_BYTES_PER_IMAGE = (2 * 64 * 144 * 4 + 128 * 144 + 8 + 264) * 4 + 264 * 145 * 4
+TD_BYTES_PER_POINT = 2 * 128 * 64 * 4 + 128 * 4 + 2 * 128 * 65 * 4 + 2 * 2 * 4 + 8 + 2 * 2 * 8
+
+
+def secondary_workloads(ops, batch, dev, rank, names=("scannet", "yfcc"), steps=5, warm=2, maps="nchw"):
+    """BASELINE.json configs[2] and configs[3] in the SAME run as the headline (round-5 verdict item 4): the same step on the
+    ScanNet shapes (indoor: one fine chunk of up to 300 rows, +ln3, fixed-cell label, merge_old) and on the YFCC shapes (24x32 grid,
+    769x769 coarse problem, 16 pairs a step - the 8-GPU sharding of configs[3] is rank-local work of exactly this kind).  Per
+    workload: pairs/s over `steps` steps, the step's kernels timed inside the steps by HIP events with the dominant one's
+    fraction of the HBM roofline (algorithmic bytes / time / 8 TB/s), and pair 0 of a step checked against the CPU oracle
+    stage by stage (index outputs asserted)."""
+    out = []
+    for name in names:
+        h, w, if_local, outdoor, pairs, label = WORKLOADS[name]
+        wl = {"outdoor": outdoor, "merge_new": outdoor, "bias_k": 2.0 if outdoor else 3.0}
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(synth.SEED + rank)
+        cap = batch.Capacities(pairs, h, w, if_local=if_local)
+        t0 = time.perf_counter()
+        nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch, channels_last=maps == "nhwc")
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
+        run_steps(batch, nets, cap, wl, None, warm, None)
+        ev = {}
+        nets.ev = ev
+        watch = StepWatch(cap)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = run_steps(batch, nets, cap, wl, ev, steps, None, watch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nets.ev = None
+        P_step, rows_step = int(o["P"].item()), int(o["rows"].chunk_base[-1].item())
+        ms = lambda tag: float(np.mean([a.elapsed_time(b_) for a, b_ in ev[tag]]))       # noqa: E731
+        kernels = [("third_fused3_kernel (third-level cost + OT + Compute_result, %d problems)" % P_step, ms("third"), THIRD_BYTES_PER_PROBLEM * P_step),
+                   ("cost_mfma_kernel + sinkhorn_blk145w2_kernel (fine-level launch pair, %d rows)" % rows_step, ms("fine"), FINE_BYTES_PER_ROW * rows_step),
+                   ("fine_desc_kernel (a15, %d stacked crops)" % (2 * rows_step), ms("fine_desc"), FD_BYTES_PER_IMAGE * 2.0 * rows_step),
+                   ("third_desc_kernel (a16, %d points)" % P_step, ms("third_desc"), TD_BYTES_PER_POINT * float(P_step))]
+        roofs = sorted(({"kernel": k, "avg_launch_ms": t, "algorithmic_bytes_per_launch": float(by), "bound": "hbm",
+                         "achieved": by / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        for k, t, by in kernels), key=lambda r: -r["avg_launch_ms"])
+        rep = {"workload": label, "value": pairs * steps / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm,
+               "pairs_per_step": pairs, "rows_in_use_per_step": rows_step, "third_problems_per_step": P_step, "setup_s": setup_s,
+               "roofline": roofs[0], "other_kernels": roofs[1:], "map_layout": maps}
+        try:
+            o2 = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
+            cb = cpu_baseline(ops, batch, dev, nets, cap, wl, o2, torch_leg=False)
+            rep["parity_sample"] = cb["parity_sample"]
+            rep["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            del o2
+        except AssertionError as e:
+            rep["parity_sample"] = {"FAILED": repr(e)[:400]}
+        out.append(rep)
+        del nets, o, ev, watch
+        torch.cuda.empty_cache()
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -1018,7 +1085,7 @@ def live_pmc(args):
     import pmc_step
     tmp = tempfile.mkdtemp(prefix="pats_pmc_", dir="/tmp")
     cmd = [sys.executable, os.path.abspath(__file__), "--maps", args.maps, "--steps", "3", "--warmup", "1", "--no-secondary",
-           "--no-cpu-baseline", "--no-pmc"] + (["--pairs", str(args.pairs)] if args.pairs else [])
+           "--no-cpu-baseline", "--no-pmc", "--no-latency"] + (["--pairs", str(args.pairs)] if args.pairs else [])
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         line = os.path.join(tmp, "bench.json")
@@ -1115,12 +1182,13 @@ def main():
         assert dist.get_world_size() == args.gpus
     from pats_amd import batch, ops, shard
 
-    # roofline.traffic of THIS run: two rocprofv3 --pmc passes over three steps of this same script, in child processes, BEFORE this
-    # process makes its resident set (two of them do not fit 288 GB side by side); None -> the committed file, with its age
+    # roofline.traffic of THIS run: two rocprofv3 --pmc passes over three steps of this same script, in child processes, at the END
+    # of this run, once its resident set is freed (two of them do not fit 288 GB side by side; until round 5 the passes ran first -
+    # and the CU-masked two-stream leg of the parent then ran at a third of its rate, every time: 548 against 1 930 pairs/s
+    # without the passes); until then the committed file stands in, and it stays if a pass fails - with its age
     pj_live = None
-    if (world == 1 and not args.no_pmc and not args.no_secondary and not args.with_gnn and args.soak == 0 and args.workload == "megadepth"
-            and args.total_pairs == 0 and args.wild == 0.0):
-        pj_live = live_pmc(args)
+    want_live_pmc = (world == 1 and not args.no_pmc and not args.no_secondary and not args.with_gnn and args.soak == 0
+                     and args.workload == "megadepth" and args.total_pairs == 0 and args.wild == 0.0)
 
     h, w, if_local, outdoor, default_pairs, label = WORKLOADS[args.workload]
     pairs = args.pairs if args.pairs else default_pairs
@@ -1256,10 +1324,12 @@ def main():
             import re
             hit = [v for k, v in pmc.items() if k.startswith(prefix) or re.sub(r"<[^<>]*>", "", k).startswith(prefix)]
             return (float(max(hit, key=lambda v: v["hbm_bytes"])["hbm_bytes"]), pmc_src) if hit else (None, None)
+        # ("_pmc": the kernel-name prefixes a roofline's traffic is summed over - the live passes at the end of the run re-fill it)
+        P_COST, P_OT145 = "pats::cost_mfma_kernel grid=%d" % (cap.rows_cap * 256), "pats::sinkhorn_blk145"
         traffic, traffic_src = traffic_of("pats::third_fused3_kernel")
         third_roof = {"bound": "hbm", "kernel": "third_fused3_kernel (fused third level, %d problems per launch over a capacity of %d)"
                       % (P_step, cap.P_cap), "achieved": t_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS,
-                      "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_age": pmc_age,
+                      "traffic": traffic, "_pmc": ["pats::third_fused3_kernel"], "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_age": pmc_age,
                       "algorithmic_bytes_per_launch": float(BYTES_PER_PROBLEM * P_step), "avg_launch_ms": float(third_ms.mean()),
                       "launches": int(len(third_ms)), "algorithmic_bytes_per_problem": BYTES_PER_PROBLEM,
                       "valu_frac": t_valu / F32_PEAK_TFLOPS, "valu_tflops": t_valu,
@@ -1274,7 +1344,7 @@ def main():
         f_traffic = float(sum(f_parts)) if all(v is not None for v in f_parts) else None
         fine_roof = {"bound": "hbm", "kernel": "fine-level launch pair as timed inside the steps: cost_mfma_kernel + sinkhorn_blk145[w2]_kernel (%d x 145x145 = the row capacity, %d rows in use)"
                      % (cap.rows_cap, rows_step), "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_ach / HBM_PEAK_GBS,
-                     "traffic": f_traffic, "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145[w2]_kernel: includes the "
+                     "traffic": f_traffic, "_pmc": [P_COST, P_OT145], "traffic_unit": "bytes per launch pair (cost_mfma_kernel + sinkhorn_blk145[w2]_kernel: includes the "
                      "score matrix written by the first and read by the second)", "traffic_source": pmc_src if f_traffic is not None else None,
                      "algorithmic_bytes_per_launch": f_by, "avg_launch_ms": fine_ms, "launches": int(len(ev["fine"])),
                      "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * rows_step / (fine_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
@@ -1300,7 +1370,7 @@ def main():
             split_roofs = [
                 {"bound": "hbm", "kernel": "%s (fine-level OT: %%d x 145x145 in use of a capacity of %%d, 100 sweeps)" % fine_kernel % (rows_step, cap.rows_cap),
                  "achieved": s_by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "traffic": s_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if s_tr is not None else None,
+                 "traffic": s_tr, "_pmc": [P_OT145], "traffic_unit": "bytes per launch", "traffic_source": pmc_src if s_tr is not None else None,
                  "algorithmic_bytes_per_launch": s_by, "avg_launch_ms": s_ms, "launches": int(len(ev["fine"])),
                  "valu_frac": 2.0 * 2.0 * ITERS * 145 * 145 * rows_step / (s_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
                  "timed": "inside the timed steps (event recorded between the two launches of the one C call); in-step pair %.3f ms" % fine_ms,
@@ -1312,7 +1382,7 @@ def main():
                             "packed, three barriers; VALU 95 % busy")},
                 {"bound": "hbm", "kernel": "cost_mfma_kernel<true> (fine-level cost build: %d x [264,145]^2 in use of a capacity of %d)" % (rows_step, cap.rows_cap),
                  "achieved": c_by / (c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_by / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "traffic": c_tr, "traffic_unit": "bytes per launch", "traffic_source": pmc_src if c_tr is not None else None,
+                 "traffic": c_tr, "_pmc": [P_COST], "traffic_unit": "bytes per launch", "traffic_source": pmc_src if c_tr is not None else None,
                  "algorithmic_bytes_per_launch": c_by, "avg_launch_ms": c_ms, "launches": int(len(ev["fine"])),
                  "timed": "inside the timed steps; in-step pair %.3f ms" % fine_ms,
                  "note": "both descriptor blocks in, the score matrix out: a streaming kernel (the fp16-split MFMA passes hide under the "
@@ -1329,7 +1399,7 @@ def main():
         fd_roof = {"bound": "hbm", "kernel": "%s (a15: fine descriptor sampling, %d stacked crops, %s maps)"
                                              % (fd_name, 2 * rows_step, "channels-last" if cl else "NCHW"),
                    "achieved": fd_by / (fd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": fd_by / (fd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + fd_name + " ")[0],
+                   "frac": fd_by / (fd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + fd_name + " ")[0], "_pmc": ["pats::" + fd_name + " "],
                    "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": fd_by,
                    "algorithmic_bytes_per_image": FD_BYTES, "avg_launch_ms": fd_ms, "launches": int(len(ev["fine_desc"])),
                    "note": ("reads every sampled pixel of the three backbone maps once - a pixel's 64 / 128 channels are one run of "
@@ -1344,7 +1414,7 @@ def main():
         td_roof = {"bound": "hbm", "kernel": "%s (a16: third-level window gather, %d points, %s maps)"
                                              % (td_name, P_step, "channels-last" if cl else "NCHW"),
                    "achieved": td_by / (td_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": td_by / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + td_name + " ")[0],
+                   "frac": td_by / (td_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("pats::" + td_name + " ")[0], "_pmc": ["pats::" + td_name + " "],
                    "traffic_unit": "bytes per launch", "traffic_source": pmc_src, "algorithmic_bytes_per_launch": td_by,
                    "algorithmic_bytes_per_point": TD_BYTES, "avg_launch_ms": td_ms, "launches": int(len(ev["third_desc"])),
                    "note": ("a window cell is one 512-byte run (128 channels) of the channels-last 52x52 map: 64 such runs in per "
@@ -1443,12 +1513,54 @@ def main():
             res["step_determinism"] = step_determinism(batch, nets, cap, wl)
             res["gather_layouts"] = gather_layout_ab(ops, dev, cap, P_step)
             torch.cuda.empty_cache()
+        if not args.no_latency and n_gpus == 1:
+            # the reference's execution mode: ONE pair at a time (evaluate.py:20-35), chunk by chunk and as a whole pair, with and
+            # without the layers' heads; ms per pair, launches and host reads per pair (tools/latency.py)
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import latency as latency_mod
+            from pats_amd import pipeline
+            try:
+                res["latency"] = latency_mod.latency_leg(ops, batch, pipeline, sys.modules[__name__], dev, args.workload, n=20, with_gnn=True)
+            except Exception as e:                       # noqa: BLE001
+                res["latency"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and n_gpus == 1:
             # one more step outside the clock, keeping the coarse tensors the parity leg needs
             o2 = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
             res["cpu_baseline"] = cpu_baseline(ops, batch, dev, nets, cap, wl, o2)
         else:
             res["cpu_baseline"] = None
+        if not args.no_secondary and n_gpus == 1 and args.workload == "megadepth" and args.total_pairs == 0 and args.wild == 0.0:
+            # BASELINE.json configs[2] / configs[3] in the same line: the headline's resident set goes first (two do not fit side by side)
+            import gc
+            out = o2 = watch = ev = gathered = local = per_pair = None
+            nets.__dict__.clear()
+            del nets
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                res["workloads_secondary"] = secondary_workloads(ops, batch, dev, rank, maps=args.maps)
+            except Exception as e:                       # noqa: BLE001
+                res["workloads_secondary"] = {"error": repr(e)[:300]}
+            if want_live_pmc:
+                pj_live = live_pmc(args)                 # nothing of this process is resident any more: the child fits
+                roofs = [res["roofline"]] + [r for r in res.get("roofline_secondary", []) if isinstance(r, dict)]
+                if pj_live is not None and int(pj_live.get("rows_cap", -1)) == cap.rows_cap:
+                    import re
+                    src = "live: bench.py ran itself under rocprofv3 at the end of this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes " \
+                          "over bench.py --steps 3), factors from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the " \
+                          "third-level kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
+                          % (pj_live["calibration"]["fetch_factor"], pj_live["calibration"]["write_factor"])
+                    for r in roofs:
+                        parts = []
+                        for prefix in r.get("_pmc", []):
+                            hit = [v for k, v in pj_live["kernels"].items() if k.startswith(prefix) or re.sub(r"<[^<>]*>", "", k).startswith(prefix)]
+                            parts.append(float(max(hit, key=lambda v: v["hbm_bytes"])["hbm_bytes"]) if hit else None)
+                        if parts and all(v is not None for v in parts):
+                            r["traffic"], r["traffic_source"] = float(sum(parts)), src
+                            if "traffic_age" in r:
+                                r["traffic_age"] = {"source": "live (this run)", "kernel_sources_changed_since": []}
+        for r in [res.get("roofline", {})] + [r for r in res.get("roofline_secondary", []) if isinstance(r, dict)]:
+            r.pop("_pmc", None)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
