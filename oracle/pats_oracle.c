@@ -257,6 +257,12 @@ void oracle_positions(int h, int w, float* positions /*[h*w,2]*/) {
 
 static inline float range_val(int d, int k) { return k <= d ? (float)k : 1e7f; }
 
+/* the `ranges` tensor itself, [n,n] with n = max(h, w): row i = [0 .. i] padded with 1e7 (utils.py:1532-1536) */
+void oracle_ranges(int n, float* ranges /*[n,n]*/) {
+    for (int d = 0; d < n; ++d)
+        for (int k = 0; k < n; ++k) ranges[d * n + k] = range_val(d, k);
+}
+
 /* ------------------------------------------------------------------------------------------
  * a10 + a11  Iterative_expand_matrix (utils/utils.py:1179-1297) + Compute_scaling (:1321-1340)
  *

@@ -124,6 +124,15 @@ def argmax(Z):
     return r, c
 
 
+def compute_positions_and_ranges(h, w):
+    """utils/utils.py:1527-1537: (positions [h*w,2], ranges [max(h,w), max(h,w)]) float32."""
+    n = max(h, w)
+    pos, rng = np.empty((h * w, 2), np.float32), np.empty((n, n), np.float32)
+    lib().oracle_positions(int(h), int(w), _p(pos, c_f))
+    lib().oracle_ranges(int(n), _p(rng, c_f))
+    return pos, rng
+
+
 def iterative_expand(P, scalex, scaley, lim3, h, w, lower_bound, iter_num, with_margin=False):
     """with_margin: a seventh output [b,m,2], the smallest relative distance by which (0) a rectangle decision and
     (1) a per-element `> lower_bound` test (whole_cost only) could have gone the other way - see pats_oracle.c."""

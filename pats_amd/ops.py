@@ -308,12 +308,31 @@ def Compute_positions_and_ranges(height, width, device):
 
 
 def _grid_of(positions, ranges):
+    """(h, w) of the index tables handed to Iterative_expand_matrix.  The expansion kernel does not READ the two tensors: it forms
+    positions[k] = (k // w, k % w) and ranges[i] = [0 .. i, 1e7 ...] itself (utils.py:1527-1537 - what every call site of the
+    reference passes, first_layer.py:173-175 / second_layer.py:254-256).  The reference does honour other contents (a shifted
+    `ranges` changes 311 of 1 152 rectangle bounds of the golden case, tests/golden/positions_ranges.npz), so tensors that do
+    not come from Compute_positions_and_ranges above are CHECKED against those tables once (one device comparison) and
+    anything else is refused instead of being silently replaced."""
     g = getattr(positions, "_pats_grid", None) or getattr(ranges, "_pats_grid", None)
     if g is not None:
         return g
-    # foreign tensors: recover (h, w) from the values (one device read)
+    # foreign tensors: recover (h, w) from the values (one device read), then hold both to the canonical tables
+    if positions.dim() != 2 or positions.shape[1] != 2 or ranges.dim() != 2 or ranges.shape[0] != ranges.shape[1]:
+        raise RuntimeError("Iterative_expand_matrix: positions must be [h*w,2] and ranges [max(h,w),max(h,w)]")
     w = int((positions[:, 0] == 0).sum().item())
-    return positions.shape[0] // w, w
+    if w <= 0 or positions.shape[0] % w != 0:
+        raise RuntimeError("Iterative_expand_matrix: positions is not the table of Compute_positions_and_ranges")
+    h = positions.shape[0] // w
+    cp, cr = Compute_positions_and_ranges(h, w, positions.device)
+    if tuple(ranges.shape) != tuple(cr.shape) or not torch.equal(positions.float(), cp) or not torch.equal(ranges.float().to(cr.device), cr):
+        raise RuntimeError("Iterative_expand_matrix: only the index tables Compute_positions_and_ranges builds are supported "
+                           "(positions[k] = (k // w, k % w), ranges[i] = [0 .. i, 1e7 ...]); the tensors handed in differ")
+    try:
+        positions._pats_grid = ranges._pats_grid = (h, w)      # checked once
+    except Exception:                                          # noqa: BLE001
+        pass
+    return h, w
 
 
 def Iterative_expand_matrix(scores_in, scalex, scaley, limitation, ranges, positions,

@@ -292,6 +292,32 @@ def test_fine_level(ops, name, k):
     np.testing.assert_allclose(out[1].cpu().numpy(), g["core_cost"], atol=3e-6, rtol=5e-4)
 
 
+def test_expansion_index_tables_are_checked_not_ignored(ops):
+    """a9 / a10: the expansion kernel forms positions / ranges itself.  Tables that arrive WITHOUT the annotation of
+    ops.Compute_positions_and_ranges - the reference's own tensors, uploaded - are compared with the canonical ones: equal ->
+    same bits as the annotated call and the reference's rectangles; a shifted `ranges` (which the reference honours: 311 bounds
+    of this case change, positions_ranges.npz) -> refused, never silently replaced."""
+    g = golden("positions_ranges.npz")
+    f = synth.fine_inputs(seed=synth.SEED + 1, B=2)
+    Z = ops.cost_ot(cu(f["d0"]), cu(f["d1"]), 2, 1.0, cu(f["scale_x"] * f["scale_y"]), 100)
+    P = ops.exp(Z)
+    sx, sy = cu(f["scale_x"]).reshape(2, -1, 1), cu(f["scale_y"]).reshape(2, -1, 1)
+    kw = dict(iter_num=8, lower_bound=1e-3, width=12, height=12)
+    pos, rng_ = ops.Compute_positions_and_ranges(12, 12, "cuda")
+    want = ops.Iterative_expand_matrix(P, sx, sy, [0, 12, 0, 12], rng_, pos, **kw)
+    assert np.array_equal(want[5].cpu().numpy(), g["bound_canonical"])
+    fpos, frng = cu(g["positions_12x12"]), cu(g["ranges_12x12"])             # foreign: no annotation
+    assert not hasattr(fpos, "_pats_grid")
+    got = ops.Iterative_expand_matrix(P, sx, sy, [0, 12, 0, 12], frng, fpos, **kw)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="only the index tables"):
+        ops.Iterative_expand_matrix(P, sx, sy, [0, 12, 0, 12], cu(g["wrong_ranges_12x12"]), cu(g["positions_12x12"]), **kw)
+    for h, w in ((15, 20), (20, 15), (12, 12), (24, 32)):                    # the device tables themselves
+        p2, r2 = ops.Compute_positions_and_ranges(h, w, "cuda")
+        assert np.array_equal(p2.cpu().numpy(), g["positions_%dx%d" % (h, w)]) and np.array_equal(r2.cpu().numpy(), g["ranges_%dx%d" % (h, w)])
+
+
 # ---- third level -------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["third_65.npz", "third_65_indoor.npz"])
 def test_third_level(ops, oracle, name):

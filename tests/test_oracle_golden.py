@@ -3,6 +3,7 @@ code (tools/make_golden.py).  CPU only.  Gates: indices e
 mass |d exp(Z)| <= 1e-4 element-wise and on marginals, crops <= 1e-4 abs on 0-255 data."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import golden
 from pats_amd import synth
@@ -434,3 +435,25 @@ def test_scale_head_against_torch_conv2d(oracle, tag, C, b, h, w, heads, dust, s
     assert y.shape == want.shape == (b, 1, h * w)
     assert want.min() >= (1 / 16) ** heads * (1 - 1e-5) and want.max() <= 16.0 ** heads * (1 + 1e-5) and want.std() > 0.05    # a non-trivial fixture
     np.testing.assert_allclose(y, want, rtol=2e-5)
+
+
+@pytest.mark.parametrize("h,w", [(15, 20), (20, 15), (12, 12), (24, 32)])
+def test_positions_and_ranges_tables(oracle, h, w):
+    """a9 pinned directly (utils/utils.py:1527-1537): the oracle's tables AND the product's host function against the values the
+    reference's Compute_positions_and_ranges returned (tools/make_golden.py::gen_positions_ranges)."""
+    g = golden("positions_ranges.npz")
+    pos, rng = oracle.compute_positions_and_ranges(h, w)
+    np.testing.assert_array_equal(pos, g["positions_%dx%d" % (h, w)])
+    np.testing.assert_array_equal(rng, g["ranges_%dx%d" % (h, w)])
+    from pats_amd import ops
+    p2, r2 = ops.Compute_positions_and_ranges(h, w, "cpu")
+    assert p2.dtype == torch.float32 and r2.dtype == torch.float32
+    np.testing.assert_array_equal(p2.numpy(), g["positions_%dx%d" % (h, w)])
+    np.testing.assert_array_equal(r2.numpy(), g["ranges_%dx%d" % (h, w)])
+
+
+def test_reference_honours_a_different_ranges_table():
+    """The fixture's control: handed a shifted `ranges`, the reference's own expansion returns different rectangles - so a
+    replacement must either read the tensor or refuse anything but the canonical table (ops._grid_of refuses; GPU test)."""
+    g = golden("positions_ranges.npz")
+    assert bool(g["wrong_changes_bound"]) and (g["bound_canonical"] != g["bound_wrong_ranges"]).sum() > 100

@@ -32,6 +32,8 @@ What each fixture pins (reference file:line):
                    in the flattened NHWC view, the dustbin index that reads the next patch (third_layer.py:127,141-144)
   dropin_gnn.npz   AttentionalGNN (3 layers) / AttentionalPropagation / KeypointEncoder instances of the reference in eval and
                    train mode and after two parameter changes (models/modules.py:70-134): the drop-in test's expected values
+  positions_ranges.npz  Compute_positions_and_ranges' two tables for 15x20, 20x15, 12x12, 24x32 (utils/utils.py:1527-1537) and the
+                   reference's expansion on a shifted `ranges` (the tensor is an input it honours)
   result.npz / result_mixed.npz   third-level inputs, result scatter and get_result
                    (pats.py:53-78, utils/utils.py:189-213); _mixed flips left_choice per row
 """
@@ -664,6 +666,27 @@ def gen_dropin(R):
     save("dropin_gnn.npz", **arrs)
 
 
+def gen_positions_ranges(R):
+    """a9, utils/utils.py:1527-1537: the two index tables themselves for the four grids of the path (15x20 and its portrait twin,
+    the fine level's 12x12, YFCC's 24x32), and what the reference's expansion returns when it is handed a DIFFERENT `ranges`
+    (every row shifted by one: [1 .. i + 1, 1e7 ...]) - the proof that the tensor is an input the reference honours."""
+    out = {}
+    for h, w in ((15, 20), (20, 15), (12, 12), (24, 32)):
+        pos, rng = R.U.Compute_positions_and_ranges(h, w, 'cpu')
+        out["positions_%dx%d" % (h, w)], out["ranges_%dx%d" % (h, w)] = pos, rng
+    f = synth.fine_inputs(seed=synth.SEED + 1, B=2)
+    Z = R.M.log_optimal_transport2(cost(T(f["d0"]), T(f["d1"]), 264), torch.tensor(1.0), T(f["scale_x"] * f["scale_y"]), 100)
+    pos, rng = R.U.Compute_positions_and_ranges(12, 12, 'cpu')
+    wrong = torch.where(rng < 1e6, rng + 1.0, rng)
+    lim = torch.tensor([0, 12, 0, 12])
+    sx, sy = T(f["scale_x"]).reshape(2, -1, 1), T(f["scale_y"]).reshape(2, -1, 1)
+    good = R.U.Iterative_expand_matrix(Z.exp(), sx, sy, lim, rng, pos, height=12, width=12, iter_num=8, lower_bound=1e-3)
+    bad = R.U.Iterative_expand_matrix(Z.exp(), sx, sy, lim, wrong, pos, height=12, width=12, iter_num=8, lower_bound=1e-3)
+    out.update(wrong_ranges_12x12=wrong, bound_canonical=good[5], bound_wrong_ranges=bad[5],
+               wrong_changes_bound=np.bool_(not torch.equal(good[5], bad[5])))
+    save("positions_ranges.npz", **out)
+
+
 def gen_roofline(R):
     """BASELINE.json configs[4] through the reference itself: cost einsum at [1,448,4096]^2, then
     log_optimal_transport on 4097x4097 with 200 iterations (modules.py:145-162; ~10 s on 8 cores).  Stored:
@@ -691,6 +714,9 @@ def main():
         gen_pipeline(R, "pipeline_640x480_outdoor.npz", synth.SEED + 50, 15, 20, True, True, True)
         gen_pipeline(R, "pipeline_640x480_indoor.npz", synth.SEED + 51, 15, 20, False, False, False)
         gen_roofline(R)
+        return
+    if only == ["a9"]:                                            # round 6: the index tables of Compute_positions_and_ranges
+        gen_positions_ranges(R)
         return
     if only == ["gnn"]:
         gen_gnn(R)
@@ -725,6 +751,7 @@ def main():
     gen_merge(R, "merge_new_portrait.npz", True, synth.SEED + 10, h=20, w=15)
     gen_result(R, "result.npz", synth.SEED + 8, False)
     gen_result(R, "result_mixed.npz", synth.SEED + 11, True)
+    gen_positions_ranges(R)
     gen_attention(R)
     gen_gnn(R)
     gen_heads(R)
