@@ -71,16 +71,29 @@ def _ptr(t):
 
 _WS = {}
 _WS_MAX = 64 << 20
-_WS_OFF = __import__("os").environ.get("PATS_WS_CACHE", "1") == "0"      # A/B switch of the scratch cache (python side only)
+_WS_ON = [False]
+
+
+class workspace_cache:
+    """Context: inside it the scratch block of a C call (up to 64 MB) is kept per (device, stream) and shared by consecutive
+    calls instead of being allocated per call - the calls of a stream run in order and none reads its scratch after it returns.
+    pipeline.forward_chunks_device uses it (a pair walked chunk by chunk made 300 allocator calls, a third of them these).
+    Off by default: with it on for every call, bench.py's CU-masked two-stream leg - run in-process after the headline at 20
+    steps in flight - fell from 2 010 to 530 pairs/s, reproducibly and for a reason not found (stand-alone the same leg is
+    unaffected; profiles/r06_ws_cache_ab.txt), so the throughput path keeps the allocator."""
+
+    def __enter__(self):
+        self.prev = _WS_ON[0]
+        _WS_ON[0] = True
+
+    def __exit__(self, *exc):
+        _WS_ON[0] = self.prev
 
 
 def _workspace(nbytes, device):
-    """Scratch for ONE C call on the current stream.  Blocks up to 64 MB are kept per (device, stream) and grown on demand: the
-    calls of a stream run in order and none reads its scratch after it returns, so consecutive calls share the block (a pair
-    walked chunk by chunk made 300 allocator calls, a third of them these).  Larger requests (the GNN stacks) and calls made
-    while a HIP graph is being captured get a block of their own."""
+    """Scratch for ONE C call on the current stream (see workspace_cache)."""
     n = max(int(nbytes), 1)
-    if n > _WS_MAX or _raw_stream is None or _WS_OFF or torch.cuda.is_current_stream_capturing():
+    if not _WS_ON[0] or n > _WS_MAX or _raw_stream is None or torch.cuda.is_current_stream_capturing():
         return torch.empty(n, dtype=torch.uint8, device=device)
     key = (device.index, _raw_stream(torch.cuda.current_device()))
     t = _WS.get(key)

@@ -56,7 +56,8 @@ def forward_path(left, right, nets, if_local=True, if_outdoor=True, merge_new=Tr
         nets.third(None, mkpts0_c, mkpts1_c, b_ids (rows of the concatenation), sizes=[B_0, ...])
     Same matches in the same order (tests/test_gpu_parity.py::test_pipeline_chain runs both modes)."""
     if device_counts and not batch_chunks:
-        return forward_chunks_device(left, right, nets, if_local, if_outdoor, merge_new, iters, streams)
+        with ops.workspace_cache():
+            return forward_chunks_device(left, right, nets, if_local, if_outdoor, merge_new, iters, streams)
     dev = left.device
     H, W = int(left.shape[1]), int(left.shape[2])
     h, w = H // 32, W // 32
