@@ -138,9 +138,11 @@ def test_coarse_level(ops, oracle, name, seed, h, w):
     assert torch.equal(b2, bound)
 
 
-def test_coarse_769(ops):
-    g = golden("coarse_769.npz")
-    inp = synth.coarse_inputs(seed=synth.SEED + 21, h=24, w=32)
+@pytest.mark.parametrize("name,seed,h,w", [("coarse_769.npz", synth.SEED + 21, 24, 32),          # YFCC, BASELINE configs[3]
+                                           ("coarse_1901.npz", synth.SEED + 22, 38, 50)])        # the demo's size (demo.py:36): the
+def test_coarse_769(ops, name, seed, h, w):                                                       # streaming solver between 769^2 and 4097^2
+    g = golden(name)
+    inp = synth.coarse_inputs(seed=seed, h=h, w=w)
     Z = ops.cost_ot(cu(inp["d0"]), cu(inp["d1"]), 1, float(inp["alpha"]), cu(inp["ns"]), 100)
     zs = Z.cpu().numpy().reshape(-1)[g["Z_idx"]]
     assert np.abs(np.exp(zs.astype(np.float64)) - np.exp(g["Z_val"].astype(np.float64))).max() <= MASS_TOL
@@ -150,8 +152,9 @@ def test_coarse_769(ops):
     np.testing.assert_allclose(e.sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-5)
     np.testing.assert_allclose(e.sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-5)
     scales = ops.colmass_sqrt(Z)
-    out = ops.est_position_first(Z, scales, (768, 1024), 32)
+    out = ops.est_position_first(Z, scales, (32 * h, 32 * w), 32)
     np.testing.assert_allclose(out[1].cpu().numpy(), g["average_point"], atol=1e-4)
+    assert np.array_equal(out[4].cpu().numpy(), g["ifn1"]) and np.array_equal(out[5].cpu().numpy(), g["ifn2"])
 
 
 def test_split_and_compute_imgs(ops, oracle):

@@ -90,8 +90,10 @@ def test_coarse_ot_and_expand(oracle, name, seed, h, w):
     assert np.array_equal(bound2, g["bound"])
 
 
-def test_coarse_769_sampled(oracle):
-    g, inp, S, Z = _coarse(oracle, "coarse_769.npz", synth.SEED + 21, 24, 32)
+@pytest.mark.parametrize("name,seed,h,w", [("coarse_769.npz", synth.SEED + 21, 24, 32),          # YFCC, BASELINE configs[3]
+                                           ("coarse_1901.npz", synth.SEED + 22, 38, 50)])        # the demo's size (demo.py:36)
+def test_coarse_769_sampled(oracle, name, seed, h, w):
+    g, inp, S, Z = _coarse(oracle, name, seed, h, w)
     zs = Z.reshape(-1)[g["Z_idx"]]
     e0, e1 = np.exp(zs.astype(np.float64)), np.exp(g["Z_val"].astype(np.float64))
     assert np.abs(e0 - e1).max() <= MASS_TOL
@@ -100,7 +102,7 @@ def test_coarse_769_sampled(oracle):
     np.testing.assert_allclose(np.exp(Z).sum(2), g["row_mass"], atol=MASS_TOL, rtol=1e-5)
     np.testing.assert_allclose(np.exp(Z).sum(1), g["col_mass"], atol=MASS_TOL, rtol=1e-5)
     whole, core, avg, xs, ys, bound = oracle.iterative_expand(np.exp(Z), oracle.colmass_sqrt(Z),
-                                                              oracle.colmass_sqrt(Z), 32, 24, 32, 1e-5, 15)
+                                                              oracle.colmass_sqrt(Z), w, h, w, 1e-5, 15)
     assert np.array_equal(bound, g["bound"])
     np.testing.assert_allclose(avg, g["average_point"], atol=1e-4)
 

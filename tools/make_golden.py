@@ -16,6 +16,7 @@ What each fixture pins (reference file:line):
                    utils/utils.py:152-181,1179-1393; setup/library.cpp:47-66)
   coarse_portrait.npz  same expansion on a 20x15 grid (the height/width swap quirk, utils.py:1181)
   coarse_769.npz   YFCC-sized L1 (24x32 grid): argmax, marginals, sampled Z
+  coarse_1901.npz  the demo's L1 (demo.py:36: long side 1 600 -> 38x50 grid, 1901x1901 OT): the same, between 769^2 and 4097^2
   fine_145.npz     L2: cost, log_optimal_transport2, dustbin bias ln2, est_position(8 iters)
                    (second_layer.py:100-116,240-259)
   fine_145_indoor.npz  L2 with ln3 bias
@@ -715,6 +716,9 @@ def main():
         gen_pipeline(R, "pipeline_640x480_indoor.npz", synth.SEED + 51, 15, 20, False, False, False)
         gen_roofline(R)
         return
+    if only == ["demo"]:                                          # round 6: the demo's coarse problem (demo.py:36: long side 1 600 -> 38x50 grid)
+        run_coarse(R, synth.coarse_inputs(seed=synth.SEED + 22, h=38, w=50), 1216, 1600, "coarse_1901.npz", full=False, with_imgs=False)
+        return
     if only == ["a9"]:                                            # round 6: the index tables of Compute_positions_and_ranges
         gen_positions_ranges(R)
         return
@@ -738,6 +742,7 @@ def main():
                "coarse_portrait.npz", full=True, with_imgs=False)
     run_coarse(R, synth.coarse_inputs(seed=synth.SEED + 21, h=24, w=32), 768, 1024,
                "coarse_769.npz", full=False, with_imgs=False)
+    run_coarse(R, synth.coarse_inputs(seed=synth.SEED + 22, h=38, w=50), 1216, 1600, "coarse_1901.npz", full=False, with_imgs=False)
     gen_fine(R, "fine_145.npz", 6, True, synth.SEED + 1)
     gen_fine(R, "fine_145_indoor.npz", 2, False, synth.SEED + 31)
     gen_third(R, "third_65.npz", 32, True, synth.SEED + 2)
