@@ -38,6 +38,7 @@ struct Fused65Args {
     int fingerprint;                 // libpats_amd_diag.so only: leave a fingerprint of the score matrix in label[p*16][1]
     int lds_poison_on;               // libpats_amd_diag.so only: fill the workgroup's LDS with lds_poison first
     unsigned lds_poison;
+    int reverse_blocks;              // libpats_amd_diag.so only: workgroup b solves problem P - 1 - b (round-6 first-launch experiment)
 };
 // number of problems that exist: min(capacity, device-side count)
 __device__ __forceinline__ int64_t live_problems(const Fused65Args& g) {

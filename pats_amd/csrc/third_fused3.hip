@@ -612,7 +612,11 @@ __global__ void __launch_bounds__(64, WAVES)
 third_fused3_kernel(Fused65Args g) {
     __shared__ Blk3Lds lds;
     const int lane = threadIdx.x;
+#ifdef PATS_DIAG
+    const int64_t p = g.reverse_blocks ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
+#else
     const int64_t p = blockIdx.x;
+#endif
     if (p >= live_problems(g)) return;
     // de-phase the first wave-front (see sinkhorn65_kernel)
     if (g.stagger > 0 && blockIdx.x < 8192u) {
@@ -658,6 +662,7 @@ int launch_third_fused3(const Fused65Args& g0, hipStream_t st) {
     if (g.P >= 8192) g.stagger = (int)((30.0f + 0.6f * (float)g.iters) / 16.0f / 3.4f);
     if (const char* e = diag_env("PATS_STAGGER")) g.stagger = atoi(e);
 #ifdef PATS_DIAG
+    if (const char* e = diag_env("PATS_REVERSE_BLOCKS")) g.reverse_blocks = atoi(e);
     g.fingerprint = diag_env("PATS_THIRD_FINGERPRINT") != nullptr;
     if (const char* e = diag_env("PATS_THIRD_LDS_POISON")) { g.lds_poison_on = 1; g.lds_poison = (unsigned)strtoul(e, nullptr, 0); }
 #endif

@@ -11,7 +11,10 @@ call; the scenario comes from the environment:
   PREHEAT=<kind>:<s>  before launch 0, <s> seconds of: matmul (8192^3 fp32) | vec (elementwise fp32 fma chain, no matrix pipe) |
                     copy (HBM copies) | same (the third-level kernel itself on the same inputs) | same1 (one such launch) |
                     other (the kernel on COPIES of the inputs) | touch (<s> passes of a.sum() over every input) |
-                    outbufs (tensors of the output shapes written and freed <s> times: the allocator hands launch 0 used blocks)
+                    outbufs (tensors of the output shapes written and freed <s> times: the allocator hands launch 0 used blocks) |
+                    iters1 (round 6: one full-size launch with ONE sweep: all code on all CUs) | small (the full solve on 256 problems)
+  PATS_REVERSE_BLOCKS=1  (round 6, diagnostic library) workgroup b solves problem P - 1 - b: do the affected problems follow the
+                    dispatch order or the data?
   MATMUL_CHECK=1    additionally: is hipBLASLt's own first heavy launch reproducible?  (x @ x) repeated, first result against later
   SMI=1             print sclk / power from sysfs right before and after launch 0
   POISON=<hex>[:k]  (round 5, diagnostic library) before launch 0 - and again before launch k (default 2) - overwrite every vector
@@ -111,6 +114,12 @@ def preheat(kind, seconds, args):
                  torch.zeros((P, 16), dtype=torch.uint8, device="cuda")]
             torch.cuda.synchronize()
             del o
+    elif kind == "iters1":         # round 6: ONE full-size launch of the same code object with a single sweep - every workgroup
+        ops.third_level(*args, outdoor=True, iters=1)     # fetches and executes every code path on every CU, 1 % of the work / heat
+        torch.cuda.synchronize()
+    elif kind == "small":          # round 6: the full solve on 256 problems only - the code is in L2, one or two CUs have executed it
+        ops.third_level(*[a[:256].contiguous() for a in args], outdoor=True)
+        torch.cuda.synchronize()
     elif kind == "touch":          # every byte of the inputs read once by another kernel (address translations, no compute)
         for _ in range(max(1, int(seconds))):
             for a in args:
@@ -183,7 +192,7 @@ def main():
                   (i, n, d, ["%.3f" % (k / P) for k in idx[:8]]), flush=True)
     print("RESULT variant=%s scenario=%s differing-from-launch-1 per launch = %s" %
           (os.environ.get("PATS_THIRD_VARIANT", "default"),
-           ",".join("%s=%s" % (k, os.environ[k]) for k in ("SYNC_FIRST", "HOST_QUIET", "IDLE", "PREHEAT", "POISON", "P") if k in os.environ) or "plain",
+           ",".join("%s=%s" % (k, os.environ[k]) for k in ("SYNC_FIRST", "HOST_QUIET", "IDLE", "PREHEAT", "POISON", "P", "PATS_REVERSE_BLOCKS") if k in os.environ) or "plain",
            counts), flush=True)
 
 
