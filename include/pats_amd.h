@@ -514,6 +514,14 @@ int pats_attentional_propagation_f32(const float* x, const float* source, int64_
  * The weights must not change between the packing and the calls that use it.
  * PATS_GNN_FUSED=0 / PATS_CONV_PK=0 / PATS_ATTN145=0 and launches in which an activation left the fp16 range of the split
  * operands take the composition above (same workspace; device-side flags, no host read). */
+/* The layers' overflow protocol, no reference counterpart.  Mode 0 (default, "inline"): every packed call queues its fp32
+ * composition behind the fast kernels, gated on a device-side flag - right without a host read, ~16 launches per layer that
+ * normally do nothing.  Mode 1 ("deferred"): none is queued; a fast kernel that meets an activation beyond the fp16 range raises
+ * ONE sticky flag per device, and the outputs of that call are then NOT valid.  The caller reads the flag where it synchronises
+ * anyway - pats_gnn_overflows(&raised, reset): drains the device, raised = 0 / 1 - and repeats the work in mode 0 if it is up.
+ * pats_set_gnn_redo_mode returns the previous mode (and leaves it unchanged for any other argument).  Process-wide. */
+int pats_set_gnn_redo_mode(int mode);
+int pats_gnn_overflows(int64_t* raised, int reset);
 size_t pats_propagation_packed_bytes(int C, int heads);
 int pats_propagation_pack_f32(const pats_propagation_weights* w, int C, int heads, void* packed, size_t packed_bytes,
                               pats_stream_t stream);

@@ -28,6 +28,8 @@ SIGNATURES = {
     "pats_set_sinkhorn_mode": (c_int, [c_int]),
     "pats_set_fine_fused": (c_int, [c_int]),
     "pats_sinkhorn_fallbacks": (c_int, [ctypes.POINTER(ctypes.c_int64), c_int]),
+    "pats_set_gnn_redo_mode": (c_int, [c_int]),
+    "pats_gnn_overflows": (c_int, [ctypes.POINTER(ctypes.c_int64), c_int]),
     "pats_cost_f32": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pats_sinkhorn_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "pats_sinkhorn_f32": (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,

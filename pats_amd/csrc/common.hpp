@@ -36,6 +36,9 @@ int sinkhorn_mode();   // PATS_SINKHORN_* (host.cpp)
 // device-resident count of problems whose linear-domain solve left the guard and was redone in the
 // log domain (host.cpp; one counter per device, allocated on first use; null if that failed)
 unsigned long long* fallback_counter();
+// the GNN layers' overflow protocol (host.cpp): deferred mode = no gated redo chain, one sticky device flag the caller reads
+bool gnn_redo_deferred();
+int* gnn_overflow_flag();
 
 #define PATS_REQUIRE(cond, ...)               \
     do {                                      \

@@ -742,7 +742,12 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     double* bpart = (double*)p; p += al256((size_t)2 * C * 512 * 2 * sizeof(double));
     int* redo = (int*)p; p += 256;
     char* fine_scratch = p;
-    if (fill_bytes(redo, 0, 8 * sizeof(int), st)) return PATS_ERR_LAUNCH;      // (a pats:: kernel: the steps hold no runtime fill)
+    // deferred overflow protocol (pats_set_gnn_redo_mode(1), host.cpp): the one-kernel / packed-weights branches raise the device's
+    // sticky flag instead of a per-call one and NO gated composition is queued behind them; the caller reads the flag at its own
+    // synchronisation point (pats_gnn_overflows) and repeats the work in the default mode if it is up
+    const bool deferred = gnn_redo_deferred() && !ext_gate && packed;
+    int* const fast_flag = deferred ? gnn_overflow_flag() : redo + 7;
+    if (!deferred && fill_bytes(redo, 0, 8 * sizeof(int), st)) return PATS_ERR_LAUNCH;      // (a pats:: kernel: the steps hold no runtime fill)
     int rc;
     const int* gate = ext_gate;
     if (ext_gate) packed = nullptr;
@@ -750,7 +755,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
         // The fine level (round 5, gnn_fine.hip): the whole layer in one kernel on (fp32 blocked, TF image) descriptors.  This
         // single-layer entry converts on the way in and out (pats_attentional_gnn_packed_f32 keeps a stack in that form); the
         // images and blocked copies overlay the composition's q / att / msg / k buffers, which only the gated redo would use.
-        int* flag = redo + 7;
+        int* flag = fast_flag;
         char* tf_x = (char*)q;
         char* tf_s = source == x ? tf_x : (char*)att;
         char* tf_att = (char*)msg;
@@ -762,6 +767,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
                                flag, nullptr, st, 1, live, live_off);
         if (rc == PATS_OK) {
             if ((rc = launch_fine_out(tf_out, batch, out, st, live, live_off, residual && residual != x ? residual : nullptr))) return rc;
+            if (deferred) return PATS_OK;
             gate = flag;         // the composition below runs only if the kernel raised it
         } else if (rc != PATS_ERR_UNSUPPORTED) {
             return rc;
@@ -770,7 +776,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     if (packed && !gate && fused_layer_supported(C, heads, n, m) && !(residual && residual == out)) {
         // residual == out is excluded (round-4 advice): the kernel itself reads and writes each element once, but the gated redo
         // behind it would read the residual the first attempt has already overwritten - such a call takes the composition alone
-        int* flag = redo + 7;
+        int* flag = fast_flag;
         int splits = 0;
         rc = launch_fused_layer(x, source, batch, packed, w->bn_a, w->bn_b, bn_train, residual, out, hid, flag, bpart, &splits, st, live, live_off);
         if (rc == PATS_OK) {
@@ -781,6 +787,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
                 if ((rc = check_launch("bn_finish_kernel"))) return rc;
                 if ((rc = launch_gnn_tail(hid, batch, packed, bsc, bsh, residual, out, flag, st))) return rc;
             }
+            if (deferred) return PATS_OK;
             gate = flag;         // the composition below runs only if the fused kernel raised it
         } else if (rc != PATS_ERR_UNSUPPORTED) {
             return rc;
@@ -793,7 +800,7 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
     static const bool no_pk = [] { const char* e = diag_env("PATS_CONV_PK"); return e && atoi(e) == 0; }();         // A/B switch
     const bool fp32_only = cost_f32_only();
     if (packed && !gate && !no_pk && !fp32_only && !(residual && residual == out) && conv_pk_ready() && batch * (int64_t)std::max(n, m) < (1ll << 31)) {
-        int* flag = redo + 7;
+        int* flag = fast_flag;
         const char* q0 = (const char*)packed + packed_fused_bytes(C, heads);
         const size_t cc = conv_packed_bytes(C, C);
         const char* pk4 = q0 + 4 * cc;
@@ -822,8 +829,10 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
             sc = bsc; sh = bsh;
         }
         if ((rc = launch_conv_pk(pk5, hid, nullptr, 2 * C, 0, C, n, batch * n, sc, sh, w->b2, residual, out, flag, nullptr, st, 1))) return rc;
+        if (deferred) return PATS_OK;
         gate = flag;             // the composition below runs only if one of the kernels above raised it
     }
+    if (deferred && fill_bytes(redo, 0, 8 * sizeof(int), st)) return PATS_ERR_LAUNCH;     // no fast branch took the call: the composition's flags
     // (as the gated fallback behind the fused layer / the packed-weights kernels: conv1x1_kernel alone - it has the fp32 redo inside -
     //  i.e. nine empty launches per layer instead of fifteen)
     // projections (modules.py:101-102)
@@ -891,8 +900,9 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     char* tf[2] = {p, p + al256(fine_image_bytes(P))};
     char* tf_att = p + 2 * al256(fine_image_bytes(P));
     char* scratch = p + std::max(fused, redo_b);
-    int* flag = (int*)(scratch + al256(fine_scratch_bytes(P)));
-    if (fill_bytes(flag, 0, sizeof(int), st)) return PATS_ERR_LAUNCH;
+    const bool deferred = gnn_redo_deferred();          // no redo chain: the device's sticky flag, read by the caller (host.cpp)
+    int* flag = deferred ? gnn_overflow_flag() : (int*)(scratch + al256(fine_scratch_bytes(P)));
+    if (!deferred && fill_bytes(flag, 0, sizeof(int), st)) return PATS_ERR_LAUNCH;
     int rc;
     // in: the two descriptor sets into one array of problems
     if ((rc = launch_fine_in(desc0, batch, tf[0], st))) return rc;
@@ -910,6 +920,7 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     }
     if ((rc = launch_fine_out(tf[cur], batch, out0, st, live, live_off))) return rc;
     if ((rc = launch_fine_out(tf[cur] + fine_image_bytes(batch), batch, out1, st, live, live_off))) return rc;
+    if (deferred) return check_launch("attentional_gnn_packed");
     // the redo chain (no-ops unless the flag is up): the layers one by one on the round-2 composition, from the inputs
     float* d[2][2] = {{(float*)p, (float*)(p + al256(elems * sizeof(float)))},
                       {(float*)(p + 2 * al256(elems * sizeof(float))), (float*)(p + 3 * al256(elems * sizeof(float)))}};

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "chunk_plan.hpp"
 
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -67,9 +68,51 @@ unsigned long long* fallback_counter() {
     return g_fallbacks[dev];
 }
 
+// ---- the GNN layers' overflow protocol (gnn.hip) -----------------------------------------------------------------------------
+// The fp16-split kernels of a layer raise a device-side flag when an activation leaves the fp16 range; by default (mode 0,
+// "inline") every call queues its fp32 composition behind them, each kernel gated on that flag - correct without a host read,
+// at the price of ~16 launches per layer that do nothing (340 per image pair, 21 ms of a 48-pair step).  Mode 1 ("deferred")
+// queues none of them: the flag is ONE sticky word per device, the caller reads it where it synchronises anyway
+// (pats_gnn_overflows) and, if it is raised, repeats the work in mode 0 - outputs of a call that raised it are not valid.
+static std::atomic<int> g_gnn_redo_mode{0};
+bool gnn_redo_deferred() { return g_gnn_redo_mode.load(std::memory_order_relaxed) == 1; }
+static int* g_gnn_overflow[64];
+int* gnn_overflow_flag() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_fallbacks_mu);
+    if (!g_gnn_overflow[dev]) {
+        int* p = nullptr;
+        if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g_gnn_overflow[dev] = p;
+    }
+    return g_gnn_overflow[dev];
+}
+
 }  // namespace pats
 
 using namespace pats;
+
+extern "C" int pats_set_gnn_redo_mode(int mode) {
+    if (mode != 0 && mode != 1) return g_gnn_redo_mode.load();
+    if (mode == 1 && !gnn_overflow_flag()) return g_gnn_redo_mode.load();       // no flag on this device: stay inline
+    return g_gnn_redo_mode.exchange(mode);
+}
+
+extern "C" int pats_gnn_overflows(int64_t* raised, int reset) {
+    PATS_REQUIRE(raised, "gnn_overflows: null pointer");
+    int* p = gnn_overflow_flag();
+    PATS_REQUIRE(p, "gnn_overflows: no flag on this device");
+    int v = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return check_launch("gnn_overflows");
+    if (hipMemcpy(&v, p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return check_launch("gnn_overflows");
+    if (reset && (hipMemset(p, 0, sizeof(v)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) return check_launch("gnn_overflows");
+    *raised = v != 0;
+    return PATS_OK;
+}
 
 extern "C" const char* pats_version(void) { return "pats_amd 0.3.0 (gfx950)"; }
 

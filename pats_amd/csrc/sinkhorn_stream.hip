@@ -549,8 +549,6 @@ __global__ void stream_granule_clear_kernel(float* partial, int64_t stride, size
 }
 
 size_t stream_workspace_bytes(int64_t batch, int M, int N) {
-    const int RB = 16;
-    const int nblk = (M + RB - 1) / RB;
     size_t f = 0;
     f += al256((size_t)batch * M * N * 4);          // K
     f += al256((size_t)batch * res_partial_stride(M, N) * 4);   // partial (a problem's share rounded to 16 bytes: see res_partial_stride)

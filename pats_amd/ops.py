@@ -133,6 +133,24 @@ def sinkhorn_fallbacks(reset=True):
     return int(n.value)
 
 
+def set_gnn_redo(mode):
+    """'inline' (default) | 'deferred' (include/pats_amd.h pats_set_gnn_redo_mode): in deferred mode the GNN layers queue no gated
+    fp32 redo chain; an activation beyond the fp16 range raises a sticky device flag instead and the outputs of that call are not
+    valid - read gnn_overflows() where you synchronise anyway and repeat the work under 'inline' if it says True.  Returns the
+    previous mode."""
+    names = {"inline": 0, "deferred": 1}
+    prev = _L().pats_set_gnn_redo_mode(names[mode])
+    return {v: k for k, v in names.items()}[prev]
+
+
+def gnn_overflows(reset=True):
+    """True if a GNN layer launched under set_gnn_redo('deferred') on the current device left the fp16 range since the last reset
+    (pats_gnn_overflows; synchronises)."""
+    n = ctypes.c_int64(0)
+    _check(_L().pats_gnn_overflows(ctypes.byref(n), 1 if reset else 0), "gnn_overflows")
+    return bool(n.value)
+
+
 # ------------------------------------------------------------------------------------------------
 # cost build
 # ------------------------------------------------------------------------------------------------

@@ -728,6 +728,35 @@ def test_fuzz_slice(ops, oracle, op):
         fuzz_parity.OPS[op](np.random.default_rng(777000 + 31 * case + len(op)))
 
 
+def test_gnn_deferred_overflow_protocol(ops):
+    """ops.set_gnn_redo('deferred'): the fine level's packed stack and the third level's fused layer queue no gated redo chain; in-range
+    inputs give the inline mode's bits and leave the device flag down, a spike beyond the fp16 range raises it (outputs void) and
+    the inline mode's answer for the same inputs is finite."""
+    for C, n, rows in ((264, 145, 64), (128, 65, 256)):
+        layers = [ops.PropagationParams(synth.gnn_params(seed=900 + i, C=C)) for i in range(2)]
+        names = ["self", "cross"]
+        g = torch.Generator(device="cuda")
+        g.manual_seed(33)
+        d0, d1 = torch.randn((rows, C, n), device="cuda", generator=g), torch.randn((rows, C, n), device="cuda", generator=g)
+        want = [t.clone() for t in ops.attentional_gnn(d0, d1, layers, names)]
+        prev = ops.set_gnn_redo("deferred")
+        try:
+            assert prev == "inline"
+            ops.gnn_overflows(reset=True)
+            got = ops.attentional_gnn(d0, d1, layers, names)
+            assert not ops.gnn_overflows(reset=True)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            wild = d0.clone()
+            wild[3, :, 7] *= 1e6                                   # far beyond the fp16 range of the split operands
+            ops.attentional_gnn(wild, d1, layers, names)
+            assert ops.gnn_overflows(reset=True)
+            assert not ops.gnn_overflows(reset=False)              # the read above reset it
+        finally:
+            assert ops.set_gnn_redo(prev) == "deferred"
+        ok = ops.attentional_gnn(wild, d1, layers, names)          # inline: the gated composition redoes the stack
+        assert torch.isfinite(ok[0]).all() and torch.isfinite(ok[1]).all()
+
+
 # ---- SURVEY.md section 8(f) rank 4: attention(query, key, value), modules.py:84-88 ----------------------
 def test_attention_golden(ops):
     g = golden("attention.npz")

@@ -246,7 +246,14 @@ def latency_leg(ops, batch, pipeline, bench, dev, workload="megadepth", n=20, wi
     make(base, PipelineNets(base, ops), "")
     if with_gnn:
         gn = bench.GnnNets(base, ops, dev, h, w)
-        make(gn, PipelineNets(base, ops, gnn=gn), "c_")
+        # the layers' overflow flag is read once, behind all legs (ops.set_gnn_redo("deferred")): no gated fp32 redo chains
+        prev = ops.set_gnn_redo("deferred")
+        ops.gnn_overflows(reset=True)
+        try:
+            make(gn, PipelineNets(base, ops, gnn=gn), "c_")
+            res["c_gnn_redo"] = "deferred; overflow flag behind the legs: %s" % ("RAISED - c_ legs void" if ops.gnn_overflows(reset=True) else "not raised")
+        finally:
+            ops.set_gnn_redo(prev)
         del gn
     del base
     torch.cuda.empty_cache()
