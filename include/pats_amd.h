@@ -538,7 +538,8 @@ int pats_attentional_propagation_packed_f32(const float* x, const float* source,
  * pats_attentional_gnn_packed_f32 is AttentionalGNN.forward (models/modules.py:127-134: `layers` propagations on both descriptor
  * sets, cross[l] != 0 = 'cross', the residual of :133 included) with the descriptors kept in the kernel's own form between the
  * layers.  weights[l] / packed[l]: the layer's weights and its pats_propagation_pack_f32 buffer.  Returns PATS_ERR_UNSUPPORTED
- * (nothing launched) at any other shape - run the layers one by one then.  A launch that meets a non-finite value raises a
+ * at any other shape (nothing launched) or when the kernel's LDS attribute is refused at run time (then a workspace fill and the
+ * two input conversions have already been queued: harmless, the outputs are untouched) - run the layers one by one then.  A launch that meets a non-finite value raises a
  * device-side flag; the per-layer compositions queued behind, gated on it, redo the stack (no host read).  PATS_GNN_FINE=0
  * switches the kernel off (both entry points take the round-4 kernels).
  * live (may be NULL): a device-side row count - throughput mode's row total; rows >= clamp(*live - live_off, 0, batch) of both

@@ -601,7 +601,11 @@ int launch_stream(const float* base, int64_t stride, int ld, int rows, int cols,
     hipLaunchKernelGGL((stream_colreduce_kernel<0>), col_grid, dim3(1024), 0, st, partial, nblk, N, log_nu, c, bv);
     hipLaunchKernelGGL(stream_kbuild_kernel, rows_grid, dim3(ST), 0, st, src, M, N, r, c, K);
     // one problem of the 4097^2 class, every 17-row block on its own CU: all sweeps in one launch, K in registers
-    static const bool resident_off = [] { const char* e = diag_env("PATS_STREAM_RESIDENT"); return e && atoi(e) == 0; }();
+    // PATS_STREAM_RESIDENT=0 (production switch): never the resident kernel.  Its co-residency check knows the
+    // stream's CU mask but not what OTHER streams or processes keep on the CUs: workgroups that cannot be placed make every
+    // spin run into its bound (~0.2 s a solve), then the guard flag re-solves the batch in the log domain - bounded, but a latency
+    // cliff for a process that shares the GPU (round-5 advice).
+    static const bool resident_off = [] { const char* e = env_switch("PATS_STREAM_RESIDENT"); return e && atoi(e) == 0; }();
     const int NPr = (N + 3) & ~3;
     // the CUs THIS stream may use (ops.masked_stream / hipExtStreamCreateWithCUMask): the grid must fit on them at once
     int stream_cus = n_cu;

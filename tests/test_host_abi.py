@@ -122,7 +122,7 @@ def test_production_library_reads_only_the_documented_environment_switches():
     """Round 5: the shipped library reads an environment variable only through env_switch() (csrc/common.hpp) and every such
     switch - each selects a TESTED alternative - has a row in INTEGRATION.md's table; the A/B partners of superseded kernel
     generations, timelines, ablations and occupancy pads go through diag_env(), a constant outside -DPATS_DIAG builds.  Checked
-    on the SOURCE (no getenv outside common.hpp, at most ten switches) and on the BINARY (its PATS_* strings)."""
+    on the SOURCE (no getenv outside common.hpp, at most eleven switches) and on the BINARY (its PATS_* strings)."""
     from pats_amd import _lib
     csrc = os.path.join(REPO, "pats_amd", "csrc")
     switches = set()
@@ -134,7 +134,7 @@ def test_production_library_reads_only_the_documented_environment_switches():
             if fn != "common.hpp":
                 assert not re.search(r"(?<![_a-z])getenv\s*\(", text), "%s calls getenv directly" % fn
             switches |= set(re.findall(r'env_switch\("(PATS_[A-Z0-9_]+)"\)', text))
-    assert 0 < len(switches) <= 10, sorted(switches)
+    assert 0 < len(switches) <= 11, sorted(switches)
     doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
     table = doc[doc.index("## 6. Environment switches"):]
     documented = set(re.findall(r"^\| `(PATS_[A-Z0-9_]+)", table, flags=re.M))
