@@ -12,28 +12,47 @@ namespace pats {
 
 // out (optional): sqrt(column mass + 1e-8); col_nomatch (optional): scores.max(1).indices == M - 1, i.e. the
 // dustbin row strictly above every real row (first index wins ties)   first_layer.py:117-118,163,167
+// 64 columns x 4 row slices per workgroup (round 6): one thread per column walked all M rows alone - 27 us for ONE 301 x 301 plan,
+// a fixed cost of every pair's coarse level and again of its fine level's flags.  Slice q sums rows q, q + 4, ... (two running sums
+// as before), the four partials meet in LDS and are added in a fixed order; the exponentials are skipped when only the flags are
+// asked for (the fine level's call).
 __global__ void __launch_bounds__(256)
 colmass_kernel(const float* __restrict__ Z, int M, int N, float* __restrict__ out, uint8_t* __restrict__ col_nomatch,
                const int* __restrict__ only_if) {
+    __shared__ float ps[4][64], pm[4][64];
     const int64_t b = blockIdx.y;
-    if (only_if && !only_if[b]) return;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N - 1) return;
-    const float* z = Z + b * (int64_t)M * N + j;
+    if (only_if && !only_if[b]) return;                 // (workgroup-uniform)
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cl;
+    const bool live = j < N - 1;
+    const float* z = Z + b * (int64_t)M * N + (live ? j : 0);
     float s0 = 0.f, s1 = 0.f, mx = -INFINITY;
-    int i = 0;
-    for (; i + 1 < M - 1; i += 2) {
-        const float x0 = z[(int64_t)i * N], x1 = z[(int64_t)(i + 1) * N];
-        s0 += expf(x0);
-        s1 += expf(x1);
-        mx = fmaxf(mx, fmaxf(x0, x1));
+    if (live) {
+        int i = q;
+        if (out) {
+            for (; i + 4 < M - 1; i += 8) {
+                const float x0 = z[(int64_t)i * N], x1 = z[(int64_t)(i + 4) * N];
+                s0 += expf(x0);
+                s1 += expf(x1);
+                mx = fmaxf(mx, fmaxf(x0, x1));
+            }
+            if (i < M - 1) {
+                const float x0 = z[(int64_t)i * N];
+                s0 += expf(x0);
+                mx = fmaxf(mx, x0);
+            }
+        } else {
+            for (; i + 4 < M - 1; i += 8) mx = fmaxf(mx, fmaxf(z[(int64_t)i * N], z[(int64_t)(i + 4) * N]));
+            if (i < M - 1) mx = fmaxf(mx, z[(int64_t)i * N]);
+        }
     }
-    if (i < M - 1) {
-        const float x0 = z[(int64_t)i * N];
-        s0 += expf(x0);
-        mx = fmaxf(mx, x0);
-    }
-    if (out) out[b * (N - 1) + j] = sqrtf((s0 + s1) + 1e-8f);
+    ps[q][cl] = s0 + s1;
+    pm[q][cl] = mx;
+    wg_barrier();
+    if (q != 0 || !live) return;
+    const float tot = (ps[0][cl] + ps[1][cl]) + (ps[2][cl] + ps[3][cl]);
+    mx = fmaxf(fmaxf(pm[0][cl], pm[1][cl]), fmaxf(pm[2][cl], pm[3][cl]));
+    if (out) out[b * (N - 1) + j] = sqrtf(tot + 1e-8f);
     if (col_nomatch) col_nomatch[b * (N - 1) + j] = z[(int64_t)(M - 1) * N] > mx;
 }
 
@@ -103,7 +122,7 @@ extern "C" int pats_colmass_sqrt_f32(const float* Z, int64_t batch, int M, int N
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(Z && out, "colmass: null pointer");
     PATS_REQUIRE(batch <= 65535, "colmass: batch too large");
-    hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)batch),
+    hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 64), (unsigned)batch),
                        dim3(256), 0, as_stream(stream), Z, M, N, out, (uint8_t*)nullptr, (const int*)nullptr);
     return check_launch("colmass_kernel");
 }
@@ -114,7 +133,7 @@ extern "C" int pats_colmass_flags_f32(const float* Z, int64_t batch, int M, int 
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(Z && (out || col_nomatch), "colmass_flags: null pointer");
     PATS_REQUIRE(batch <= 65535, "colmass_flags: batch too large");
-    hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)batch),
+    hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 64), (unsigned)batch),
                        dim3(256), 0, as_stream(stream), Z, M, N, out, col_nomatch, (const int*)nullptr);
     return check_launch("colmass_kernel");
 }
@@ -125,7 +144,7 @@ namespace pats {
 int launch_col_flags(const float* Z, int64_t batch, int M, int N, uint8_t* col_nomatch, const int* only_if, hipStream_t st) {
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const int64_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
-        hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 256), (unsigned)nb), dim3(256), 0, st,
+        hipLaunchKernelGGL(colmass_kernel, dim3((unsigned)ceil_div(N - 1, 64), (unsigned)nb), dim3(256), 0, st,
                            Z + b0 * (int64_t)M * N, M, N, (float*)nullptr, col_nomatch + b0 * (N - 1),
                            only_if ? only_if + b0 : nullptr);
     }
