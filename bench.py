@@ -391,18 +391,12 @@ class StepWatch:
 
     def __init__(self, cap, depth=2):
         self.cap, self.q, self.depth = cap, [], depth
-        self.pool = [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(2, dtype=torch.int64).pin_memory(),
-                      torch.empty(cap.pairs + 1, dtype=torch.int64).pin_memory())
-                     for _ in range(depth + 1)]             # plain D2H copies: no kernel outside pats:: enters the steps
-        self.steps = 0
+        self.pool = [torch.empty(cap.pairs + 4, dtype=torch.int64).pin_memory() for _ in range(depth + 1)]
+        self.steps = 0                                      # (one plain D2H copy a step: no kernel outside pats:: enters the steps)
 
     def push(self, out):
         buf = self.pool[self.steps % len(self.pool)]
-        buf[0].copy_(out["status"], non_blocking=True)
-        buf[1][0:1].copy_(out["P"], non_blocking=True)
-        buf[1][1:2].copy_(out["M"], non_blocking=True)
-        if "by_pair" in out:
-            buf[2].copy_(out["by_pair"][2], non_blocking=True)        # where every pair's matches start
+        buf.copy_(out["summary"], non_blocking=True)        # batch.group_by_pair: the pairs + 1 offsets, then M, P, table status
         e = torch.cuda.Event()
         e.record()
         self.q.append((e, buf))
@@ -412,10 +406,10 @@ class StepWatch:
 
     def _check(self, e, buf):
         e.synchronize()
-        status, (P, M) = int(buf[0][0]), (int(v) for v in buf[1].tolist())
+        v = buf.tolist()
+        off, (M, P, status) = v[:self.cap.pairs + 1], v[self.cap.pairs + 1:]
         if status or P > self.cap.P_cap:
             raise RuntimeError("bench: a step overflowed a capacity (status %d, P %d of %d)" % (status, P, self.cap.P_cap))
-        off = buf[2].tolist()
         if off[-1] not in (0, M) or any(b_ < a_ for a_, b_ in zip(off, off[1:])):
             raise RuntimeError("bench: the per-pair offsets of a step do not add up to its match count")
         self.last = (status, P, M)

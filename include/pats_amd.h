@@ -458,6 +458,12 @@ int pats_matches_by_pair_f32(const float* matches_l, const float* matches_r, con
                              const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
                              float* out_l, float* out_r, int64_t* pair_off, void* workspace, size_t workspace_bytes,
                              pats_stream_t stream);
+/* The same with the step's counters appended: pair_off has pairs + 4 entries - the pairs + 1 offsets, then M, P (*P_dev: the
+ * third-level problem count of the step, may be null) and the row table's status - a batch's hand-over is ONE device-to-host copy. */
+int pats_matches_by_pair_summary_f32(const float* matches_l, const float* matches_r, const int32_t* match_row, const int64_t* M_dev,
+                                     const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
+                                     float* out_l, float* out_r, int64_t* pair_off, const int64_t* P_dev, const int32_t* status,
+                                     void* workspace, size_t workspace_bytes, pats_stream_t stream);
 
 /* attention(query, key, value) of the GNN layers (reference models/modules.py:84-88; the core of
  * MultiHeadedAttention.forward :100-105): scores = q^T k / dim**.5 per (batch, head), softmax over the

@@ -140,6 +140,8 @@ SIGNATURES = {
     "pats_matches_by_pair_workspace_bytes": (c_size, [c_int, c_i64]),
     "pats_matches_by_pair_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_matches_by_pair_summary_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "pats_conv1x1_workspace_bytes": (c_size, []),
     "pats_conv1x1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size, c_void_p]),

@@ -185,21 +185,27 @@ def forward_pairs(lefts, rights, nets, cap, if_outdoor=True, merge_new=True, ite
 
 def group_by_pair(out, cap, buffers=None):
     """Device side of the hand-over: the batch's matches regrouped by pair (ops.matches_by_pair), no host read.  Adds
-    `by_pair` = (matches_l, matches_r, pair_off) to the result; a caller in a loop passes `buffers` to reuse the outputs."""
-    out["by_pair"] = ops.matches_by_pair(out["rows"], out["matches_l"], out["matches_r"], out["match_row"], out["M"], out=buffers)
+    `by_pair` = (matches_l, matches_r, pair_off) and `summary` (int64 [pairs + 4]: the pairs + 1 offsets, then M, P, table status -
+    everything the host reads of a step, in ONE buffer) to the result; a caller in a loop passes `buffers` (out_l, out_r,
+    summary-sized pair_off) to reuse the outputs."""
+    ml, mr, off, summary = ops.matches_by_pair(out["rows"], out["matches_l"], out["matches_r"], out["match_row"], out["M"], out=buffers,
+                                               P=out["P"])
+    out["by_pair"], out["summary"] = (ml, mr, off), summary
     return out["by_pair"]
 
 
 def split_by_pair(out, cap):
     """Host side, AFTER the step: per-pair (matches_l, matches_r) lists from a forward_pairs result, in the reference's
     order.  Reads the counts back (the one synchronisation of a batch) and raises on a capacity overflow."""
-    status, M, P = int(out["status"].item()), int(out["M"].item()), int(out["P"].item())
+    if "summary" not in out:
+        group_by_pair(out, cap)
+    o = out["summary"].cpu().tolist()                 # the one synchronisation of a batch: offsets, M, P, status in one copy
+    M, P, status = o[cap.pairs + 1:]
     if status & 1:
         raise RuntimeError("pats_amd.batch: a pair needed more than Cmax = %d chunks" % cap.Cmax)
     if status & 2:
         raise RuntimeError("pats_amd.batch: the row table overflowed rows_cap = %d" % cap.rows_cap)
     if P > cap.P_cap:
         raise RuntimeError("pats_amd.batch: %d third-level problems exceed P_cap = %d" % (P, cap.P_cap))
-    ml, mr, off = out["by_pair"] if "by_pair" in out else group_by_pair(out, cap)
-    o = off.cpu().tolist()
+    ml, mr, _ = out["by_pair"]
     return [(ml[o[p]:o[p + 1]], mr[o[p]:o[p + 1]]) for p in range(cap.pairs)]

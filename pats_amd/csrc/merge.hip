@@ -706,6 +706,7 @@ struct ByPairArgs {
     const float* ml; const float* mr; const int32_t* match_row; const int64_t* M; const int32_t* row_cell; const int64_t* chunk_base;
     int Cmax; int64_t pairs; int N;
     float* out_l; float* out_r; int64_t* pair_off; int64_t* seg_lo; int64_t* seg_hi; int64_t* seg_dst;
+    const int64_t* P_dev; const int32_t* status;      // optional: the step's summary behind the offsets (pats_matches_by_pair_summary_f32)
 };
 __device__ __forceinline__ int64_t bypair_key(const ByPairArgs& g, int64_t i) {
     const int64_t row = g.match_row[i];
@@ -738,6 +739,11 @@ __global__ void __launch_bounds__(256) bypair_offsets_kernel(ByPairArgs g) {    
             for (int64_t p = p0; p < P && p < p0 + 1024; ++p) { const int64_t t = total[p - p0]; total[p - p0] = run; g.pair_off[p] = run; run += t; }
             g.pair_off[P < p0 + 1024 ? P : p0 + 1024] = run;
             carry = run;
+            if (g.status && p0 + 1024 >= P) {             // the hand-over's counters in the same buffer: ONE device-to-host copy per step
+                g.pair_off[P + 1] = *g.M;
+                g.pair_off[P + 2] = g.P_dev ? *g.P_dev : 0;
+                g.pair_off[P + 3] = (int64_t)*g.status;
+            }
         }
         wg_barrier();
         for (int64_t p = p0 + threadIdx.x; p < P && p < p0 + 1024; p += 256) {
@@ -761,10 +767,32 @@ extern "C" size_t pats_matches_by_pair_workspace_bytes(int Cmax, int64_t pairs) 
     return Cmax > 0 && pairs > 0 ? (size_t)3 * Cmax * pairs * sizeof(int64_t) : 0;
 }
 
+static int matches_by_pair_impl(const float* matches_l, const float* matches_r, const int32_t* match_row, const int64_t* M_dev,
+                                const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
+                                float* out_l, float* out_r, int64_t* pair_off, const int64_t* P_dev, const int32_t* status,
+                                void* workspace, size_t workspace_bytes, pats_stream_t stream);
 extern "C" int pats_matches_by_pair_f32(const float* matches_l, const float* matches_r, const int32_t* match_row, const int64_t* M_dev,
                                         const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
                                         float* out_l, float* out_r, int64_t* pair_off, void* workspace, size_t workspace_bytes,
                                         pats_stream_t stream) {
+    return matches_by_pair_impl(matches_l, matches_r, match_row, M_dev, row_cell, chunk_base, Cmax, pairs, N, out_l, out_r, pair_off, nullptr,
+                                nullptr, workspace, workspace_bytes, stream);
+}
+// The same with the step's counters appended: pair_off has pairs + 4 entries - the pairs + 1 offsets, then M, P (*P_dev, the
+// third-level problem count; may be null -> 0) and the row table's status - so that a batch's hand-over is ONE device-to-host copy.
+extern "C" int pats_matches_by_pair_summary_f32(const float* matches_l, const float* matches_r, const int32_t* match_row,
+                                                const int64_t* M_dev, const int32_t* row_cell, const int64_t* chunk_base, int Cmax,
+                                                int64_t pairs, int N, float* out_l, float* out_r, int64_t* pair_off,
+                                                const int64_t* P_dev, const int32_t* status, void* workspace, size_t workspace_bytes,
+                                                pats_stream_t stream) {
+    PATS_REQUIRE(status, "matches_by_pair_summary: null status");
+    return matches_by_pair_impl(matches_l, matches_r, match_row, M_dev, row_cell, chunk_base, Cmax, pairs, N, out_l, out_r, pair_off, P_dev,
+                                status, workspace, workspace_bytes, stream);
+}
+static int matches_by_pair_impl(const float* matches_l, const float* matches_r, const int32_t* match_row, const int64_t* M_dev,
+                                const int32_t* row_cell, const int64_t* chunk_base, int Cmax, int64_t pairs, int N,
+                                float* out_l, float* out_r, int64_t* pair_off, const int64_t* P_dev, const int32_t* status,
+                                void* workspace, size_t workspace_bytes, pats_stream_t stream) {
     PATS_REQUIRE(Cmax >= 1 && pairs >= 1 && N >= 1, "matches_by_pair: bad shape");
     PATS_REQUIRE(matches_l && matches_r && match_row && M_dev && row_cell && chunk_base && out_l && out_r && pair_off,
                  "matches_by_pair: null pointer");
@@ -774,7 +802,7 @@ extern "C" int pats_matches_by_pair_f32(const float* matches_l, const float* mat
     const int64_t nseg = (int64_t)Cmax * pairs;
     if (fill_bytes(ws, 0, sizeof(int64_t) * (size_t)(2 * nseg), st)) return PATS_ERR_LAUNCH;        // runs without matches: lo = hi = 0
     ByPairArgs g{matches_l, matches_r, match_row, M_dev, row_cell, chunk_base, Cmax, pairs, N, out_l, out_r, pair_off, ws, ws + nseg,
-                 ws + 2 * nseg};
+                 ws + 2 * nseg, P_dev, status};
     hipLaunchKernelGGL(bypair_runs_kernel, dim3(2048), dim3(256), 0, st, g);
     hipLaunchKernelGGL(bypair_offsets_kernel, dim3(1), dim3(256), 0, st, g);
     hipLaunchKernelGGL(bypair_copy_kernel, dim3(2048), dim3(256), 0, st, g);

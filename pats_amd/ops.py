@@ -1034,20 +1034,31 @@ def get_result_chunks(rows, if_nomatching16, pts_new, pts16, scales, patch_size=
     return ml, mr, mrow, cnt
 
 
-def matches_by_pair(rows, matches_l, matches_r, match_row, M, out=None):
+def matches_by_pair(rows, matches_l, matches_r, match_row, M, out=None, P=None):
     """The matches of a batch (get_result_chunks) grouped by pair ON THE DEVICE: (matches_l, matches_r) with every pair's
     list contiguous in the reference's order, and pair_off [pairs + 1] int64 (pair p = rows pair_off[p] .. pair_off[p + 1]).
-    What batch.split_by_pair reads back is then only pair_off.  out: optional (out_l, out_r, pair_off) to write into."""
+    What batch.split_by_pair reads back is then only pair_off.  out: optional (out_l, out_r, pair_off) to write into.
+    P (device int64 [1], the step's third-level problem count): pair_off is then the first pairs + 1 entries of a pairs + 4
+    buffer whose tail is (M, P, table status) - returned as a fourth element: the whole hand-over in ONE device-to-host copy."""
     dev = matches_l.device
+    n_off = rows.pairs + 1 + (3 if P is not None else 0)
     if out is None:
-        out = (torch.empty_like(matches_l), torch.empty_like(matches_r), torch.empty((rows.pairs + 1,), dtype=torch.int64, device=dev))
-    ol, orr, off = out
+        out = (torch.empty_like(matches_l), torch.empty_like(matches_r), torch.empty((n_off,), dtype=torch.int64, device=dev))
+    ol, orr, off = out[:3]
+    if off.numel() != n_off or not off.is_contiguous():
+        raise RuntimeError("matches_by_pair: pair_off must be a contiguous int64 tensor of %d entries" % n_off)
     nws = _L().pats_matches_by_pair_workspace_bytes(rows.Cmax, rows.pairs)
     ws = _workspace(nws, dev)
-    _check(_L().pats_matches_by_pair_f32(_ptr(matches_l), _ptr(matches_r), _ptr(match_row), _ptr(M), _ptr(rows.row_cell),
-                                         _ptr(rows.chunk_base), rows.Cmax, rows.pairs, rows.h * rows.w, _ptr(ol), _ptr(orr), _ptr(off),
-                                         _ptr(ws), nws, _stream()), "matches_by_pair")
-    return ol, orr, off
+    if P is None:
+        _check(_L().pats_matches_by_pair_f32(_ptr(matches_l), _ptr(matches_r), _ptr(match_row), _ptr(M), _ptr(rows.row_cell),
+                                             _ptr(rows.chunk_base), rows.Cmax, rows.pairs, rows.h * rows.w, _ptr(ol), _ptr(orr), _ptr(off),
+                                             _ptr(ws), nws, _stream()), "matches_by_pair")
+        return ol, orr, off
+    _check(_L().pats_matches_by_pair_summary_f32(_ptr(matches_l), _ptr(matches_r), _ptr(match_row), _ptr(M), _ptr(rows.row_cell),
+                                                 _ptr(rows.chunk_base), rows.Cmax, rows.pairs, rows.h * rows.w, _ptr(ol), _ptr(orr),
+                                                 _ptr(off), _ptr(_dev(P, "P", torch.int64)), _ptr(rows.status), _ptr(ws), nws, _stream()),
+           "matches_by_pair")
+    return ol, orr, off[:rows.pairs + 1], off
 
 
 def masked_stream(cus):

@@ -318,5 +318,9 @@ def test_matches_grouped_by_pair_on_the_device_equal_the_stable_argsort():
     torch.cuda.synchronize()
     assert off.cpu().tolist() == [0] + torch.cumsum(counts, 0).cpu().tolist()
     assert M > 0 and torch.equal(ml[:M], want_l) and torch.equal(mr[:M], want_r)
+    # the step's summary behind the offsets (pats_matches_by_pair_summary_f32): M, P, table status - one copy hands a step over
+    assert out["summary"].cpu().tolist() == off.cpu().tolist() + [M, int(out["P"].item()), int(out["status"].item())]
+    ml2, mr2, off2 = ops.matches_by_pair(rows, out["matches_l"], out["matches_r"], out["match_row"], out["M"])    # without the summary
+    assert torch.equal(off2, off) and torch.equal(ml2[:M], ml[:M]) and torch.equal(mr2[:M], mr[:M])
     per_pair = batch.split_by_pair(out, cap)
     assert [int(a.shape[0]) for a, _ in per_pair] == counts.cpu().tolist()

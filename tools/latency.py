@@ -93,21 +93,17 @@ class PipelineNets:
 
 
 class Handover:
-    """The per-pair hand-over of the batched path: status / P / M / per-pair offsets into pinned memory, one synchronisation."""
+    """The per-pair hand-over of the batched path: offsets / M / P / status - batch.group_by_pair's `summary` - into pinned memory,
+    ONE copy, one synchronisation."""
 
     def __init__(self, cap):
         self.cap = cap
-        self.status = torch.empty(1, dtype=torch.int32).pin_memory()
-        self.pm = torch.empty(2, dtype=torch.int64).pin_memory()
-        self.off = torch.empty(cap.pairs + 1, dtype=torch.int64).pin_memory()
+        self.buf = torch.empty(cap.pairs + 4, dtype=torch.int64).pin_memory()
 
     def __call__(self, out):
-        self.status.copy_(out["status"], non_blocking=True)
-        self.pm[0:1].copy_(out["P"], non_blocking=True)
-        self.pm[1:2].copy_(out["M"], non_blocking=True)
-        self.off.copy_(out["by_pair"][2], non_blocking=True)
+        self.buf.copy_(out["summary"], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        status, P, M = int(self.status[0]), int(self.pm[0]), int(self.pm[1])
+        M, P, status = self.buf[self.cap.pairs + 1:].tolist()
         if status or P > self.cap.P_cap:
             raise RuntimeError("latency: capacity overflow (status %d, P %d of %d)" % (status, P, self.cap.P_cap))
         return M
