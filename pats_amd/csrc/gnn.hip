@@ -889,6 +889,8 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     if (!fine_layer_supported(C, heads, n, n) || !gnn_fold_enabled()) return PATS_ERR_UNSUPPORTED;
     if (batch == 0) return PATS_OK;
     PATS_REQUIRE(desc0 && desc1 && out0 && out1 && (layers == 0 || (weights && packed && cross)), "attentional_gnn_packed: null pointer");
+    // (round-5 advice) the inline redo chain re-reads the inputs AFTER the fast path has written the outputs
+    PATS_REQUIRE(out0 != desc0 && out0 != desc1 && out1 != desc0 && out1 != desc1, "attentional_gnn_packed: the outputs must not alias the inputs");
     PATS_REQUIRE(workspace && workspace_bytes >= pats_attentional_gnn_packed_workspace_bytes(batch, C, heads, n), "attentional_gnn_packed: workspace too small");
     for (int l = 0; l < layers; ++l) PATS_REQUIRE(weights[l] && packed[l], "attentional_gnn_packed: null layer");
     hipStream_t st = as_stream(stream);
