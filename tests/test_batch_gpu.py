@@ -213,6 +213,7 @@ def test_batched_merge_and_result_against_the_single_chunk_ops(new):
     masks = rows.masks.cpu().numpy()
     third = rows.third.cpu().numpy()
     want = np.ones((R, 144), bool)
+    want_t, want_f = trust.copy(), ifn2.copy()           # the in-place updates of the reference (second_layer.py:194-201)
     merge = ops.merge_patches_new if new else ops.merge_patches_old
     for p in range(pairs):
         sb = torch.zeros((1, N, 16, 9), dtype=torch.float64, device="cuda")
@@ -220,7 +221,9 @@ def test_batched_merge_and_result_against_the_single_chunk_ops(new):
             idx = np.nonzero(cell[base[c]:base[c + 1]] // N == p)[0] + int(base[c])
             if len(idx) == 0:
                 continue
-            out, sb = merge(len(idx), cu(trust[idx].copy()), (H, W), cu(masks[c, p:p + 1]), cu(ifn2[idx].copy()), sb)
+            t_in, f_in = cu(trust[idx].copy()), cu(ifn2[idx].copy())
+            out, sb = merge(len(idx), t_in, (H, W), cu(masks[c, p:p + 1]), f_in, sb)
+            want_t[idx], want_f[idx] = t_in.cpu().numpy(), f_in.cpu().numpy()
             out = out.cpu().numpy()
             tail = int(third[p, c, 1])
             if tail != 0:
@@ -228,6 +231,20 @@ def test_batched_merge_and_result_against_the_single_chunk_ops(new):
             want[idx] = out
     assert np.array_equal(merged.cpu().numpy(), want)
     assert merged[total:].all()
+    assert np.array_equal(t_b.cpu().numpy()[:total], want_t[:total]) and np.array_equal(f_b.cpu().numpy()[:total], want_f[:total])
+    # the same table walked chunk by chunk on each chunk's own tensors (pats_merge_patches_chunks: pipeline.forward_chunks_device),
+    # scores_back handed from call to call
+    sbw = torch.empty((pairs, N, 16, 9), dtype=torch.float64, device="cuda")
+    first = True
+    for c in range(rows.Cmax):
+        lo, hi = int(base[c]), int(base[c + 1])
+        if hi <= lo:
+            continue
+        t_c, f_c = cu(trust[lo:hi].copy()), cu(ifn2[lo:hi].copy())
+        out_c = ops.merge_patches_chunk(new, rows, c, lo, t_c, (H, W), f_c, sbw, first=first)
+        first = False
+        assert np.array_equal(out_c.cpu().numpy(), want[lo:hi]), "chunk %d" % c
+        assert np.array_equal(t_c.cpu().numpy(), want_t[lo:hi]) and np.array_equal(f_c.cpu().numpy(), want_f[lo:hi])
     # get_result for all chunks in one call against the expanded batch
     f16 = rng.random((R, 2304)) < 0.7
     f16[total:] = True
