@@ -78,9 +78,9 @@ class workspace_cache:
     """Context: inside it the scratch block of a C call (up to 64 MB) is kept per (device, stream) and shared by consecutive
     calls instead of being allocated per call - the calls of a stream run in order and none reads its scratch after it returns.
     pipeline.forward_chunks_device uses it (a pair walked chunk by chunk made 300 allocator calls, a third of them these).
-    Off by default: with it on for every call, bench.py's CU-masked two-stream leg - run in-process after the headline at 20
-    steps in flight - fell from 2 010 to 530 pairs/s, reproducibly and for a reason not found (stand-alone the same leg is
-    unaffected; profiles/r06_ws_cache_ab.txt), so the throughput path keeps the allocator."""
+    Off by default: it is a host-side saving for many small calls on few streams; the throughput path (big tensors, their own
+    allocations) keeps the allocator.  (profiles/r06_ws_cache_ab.txt: an apparent 4x cost to bench.py's masked-stream leg turned
+    out to be a first-process-on-the-box effect, not the cache.)"""
 
     def __enter__(self):
         self.prev = _WS_ON[0]
