@@ -386,6 +386,36 @@ int pats_merge_patches_chunks(int merge_new, int Cmax, int c_lo, int c_hi, int64
                               const uint8_t* row_forced, float* trust_score, uint8_t* if_nomatching1_L2, double* scores_back,
                               int zero_scores_back, uint8_t* out, void* workspace, size_t workspace_bytes, pats_stream_t stream);
 
+/* PATS.forward's chunk loop (models/pats.py:33-78) walked chunk by chunk: everything between the network callbacks of ONE chunk in
+ * two calls (csrc/chunk_walk.cpp - each runs the entry points above in the reference's order on `stream`; what they save is host
+ * time).  B = the chunk's rows; the row table is pats_chunk_rows_device's, c the chunk, row_origin = chunk_base[c] (host copy).
+ *   fine tail: second_layer.py:100-122 + pats.py:37-39,53-58.  In: the chunk's descriptors d0, d1 [B,264,145], one (device 1.0f),
+ *   ns = scale_x * scale_y [B,144], the two scale heads.  Out: Z [B,145,145] (+ ln bias_k), col_nomatch / row_nomatch [B,144], the
+ *   expansion's six outputs, merged [B,144] (the returned if_nomatching, tail rows forced), mkpts0 / mkpts1 [144 B,2], b_ids [144 B],
+ *   *P_dev.  trust and row_nomatch are updated in place by the merge as in the reference.  wait_before_merge / record_after_merge:
+ *   optional hipEvent_t handles - the stream waits for the first right before the merge and records the second right behind it (the
+ *   merges of a pair are ordered, pats.py:37; with consecutive chunks on different streams only they need to wait for each other).
+ *   third tail: third_layer.py:153-170 + pats.py:59-78.  In: the third level's descriptors over the capacity P_cap = 144 B with the
+ *   count *P_dev, scale [P_cap,64], the rounded points, merged / points2 of the fine tail, the chunk's mask [h w] (level-0 flags),
+ *   Compute_imgs' pts_new / scales [1,h w,2], `ones` = B bytes of 1.  Out: the third level's four outputs, if_nomatching16 [B,2304],
+ *   pts16 [B,2304,2], matches_l / matches_r [2304 B,2], match_row, *M_dev. */
+size_t pats_chunk_fine_tail_workspace_bytes(int64_t B, int64_t pairs, int H, int W);
+int pats_chunk_fine_tail_f32(const float* d0, const float* d1, int64_t B, const float* one, const float* ns, int iters, float bias_k,
+                             const float* scale_x, const float* scale_y, int merge_new, int Cmax, int c, int64_t pairs, int H, int W,
+                             int64_t row_origin, const int64_t* chunk_base, const int32_t* row_cell, const int32_t* row_slot,
+                             const uint8_t* row_forced, double* scores_back, int first_chunk, float* Z, uint8_t* col_nomatch,
+                             float* trust, float* core, float* points, float* x_scale, float* y_scale, int64_t* bound,
+                             uint8_t* row_nomatch, uint8_t* merged, float* mkpts0, float* mkpts1, int64_t* b_ids, int64_t* P_dev,
+                             void* wait_before_merge, void* record_after_merge, void* workspace, size_t workspace_bytes,
+                             pats_stream_t stream);
+size_t pats_chunk_third_tail_workspace_bytes(int64_t B, int h, int w);
+int pats_chunk_third_tail_f32(const float* feat0, const float* feat1, int64_t P_cap, const int64_t* P_dev, const float* scale,
+                              const int64_t* p_s, const int64_t* p_t, int iters, int outdoor, const uint8_t* merged,
+                              const float* points2, int64_t B, const uint8_t* chunk_mask, int h, int w, const float* pts_new,
+                              const float* scales, const uint8_t* ones, float* mkpts0_f, float* mkpts1_f, float* label,
+                              uint8_t* if_matching1, uint8_t* if_nomatching16, float* pts16, float* matches_l, float* matches_r,
+                              int32_t* match_row, int64_t* M_dev, void* workspace, size_t workspace_bytes, pats_stream_t stream);
+
 /* SecondLayer.merge_patches_new (merge_new != 0, reference models/second_layer.py:193-240) and
  * merge_patches_old (merge_new == 0, :137-191): resolves every 8-px cell among the up to nine 96x96
  * windows covering it.  Like the reference it works in place on trust_score [B,144] (border weighting

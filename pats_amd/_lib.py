@@ -111,6 +111,13 @@ SIGNATURES = {
                                          c_size, c_void_p]),
     "pats_merge_patches_chunks": (c_int, [c_int, c_int, c_int, c_int, c_i64, c_int, c_int, c_i64, c_i64] + [c_void_p] * 7 +
                                   [c_int, c_void_p, c_void_p, c_size, c_void_p]),
+    "pats_chunk_fine_tail_workspace_bytes": (c_size, [c_i64, c_i64, c_int, c_int]),
+    "pats_chunk_fine_tail_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_f, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_i64, c_int, c_int, c_i64] + [c_void_p] * 5 + [c_int] + [c_void_p] * 16 + [c_void_p, c_size, c_void_p]),
+    "pats_chunk_third_tail_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "pats_chunk_third_tail_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                          c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p] + [c_void_p] * 10 +
+                                  [c_void_p, c_size, c_void_p]),
     "pats_get_result_chunks_f32": (c_int, [c_int, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
                                            ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),

@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libpats_amd.so")
 LIB_DIAG = os.path.join(HERE, "libpats_amd_diag.so")
 DIAG_SOURCES = None      # every source, each with -DPATS_DIAG=1 (set below SOURCES): diag_env() (csrc/common.hpp) is live in that library only
 SOURCES = ["host.cpp", "sinkhorn.hip", "sinkhorn_stream.hip", "sinkhorn_blk.hip", "sinkhorn_blk2w.hip", "cost.hip", "post.hip", "expand.hip", "resize.hip", "third.hip", "third_fused.hip", "third_fused3.hip", "gather.hip", "merge.hip", "attention.hip", "attention145.hip", "gnn.hip", "gnn_fused.hip", "gnn_fine.hip", "conv_pk.hip",
-           "fused.hip", "scale_head.hip", "batch.hip"]
+           "fused.hip", "scale_head.hip", "batch.hip", "chunk_walk.cpp"]
 DIAG_SOURCES = {src: ["-DPATS_DIAG=1"] for src in SOURCES}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-x", "hip"]

@@ -992,6 +992,82 @@ def merge_patches_chunk(merge_new, rows, c, row_origin, trust_score, original_im
     return out
 
 
+def _carve(device, *sizes):
+    """One allocation for several internal tensors of a fused call: returns (arena, [device addresses])."""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (int(n) + 255) & ~255
+    arena = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+    base = arena.data_ptr()
+    return arena, [ctypes.c_void_p(base + o) for o in offs]
+
+
+def chunk_fine_tail(f0, f1, one, ns, scale_x, scale_y, iters, bias_k, merge_new, rows, c, row_origin, image_shape, scores_back, first,
+                    wait_before_merge=None, record_after_merge=None):
+    """Everything between the fine network callback and the third one for ONE chunk of a pair walked chunk by chunk, in one C
+    call (pats_chunk_fine_tail_f32, csrc/chunk_walk.cpp): second_layer.py:100-122 (cost build, log_optimal_transport2 + ln k,
+    est_position, the chunk's merge through the row table `rows`) and pats.py:37-39,53-58 (tail rows, the third level's inputs over
+    the capacity 144 B).  Returns (merged [B,144] bool, points [B,144,2], mkpts0_c [144 B,2], mkpts1_c, b_ids [144 B], P [1] int64
+    on the device); the log plan, flags and the other expansion outputs stay internal.
+    wait_before_merge / record_after_merge: torch.cuda.Event objects (already recorded once, so that their handles exist) - the
+    stream waits for the first right before the merge and re-records the second right behind it."""
+    d0, d1 = _dev(f0, "f0"), _dev(f1, "f1")
+    B = d0.shape[0]
+    if tuple(d0.shape) != (B, 264, 145) or d1.shape != d0.shape:
+        raise RuntimeError("chunk_fine_tail: descriptors must be [B,264,145]")
+    nsv, sx, sy = _dev(ns, "ns").reshape(B, 144), _dev(scale_x, "scale_x").reshape(B, 144), _dev(scale_y, "scale_y").reshape(B, 144)
+    H, W = int(image_shape[0]), int(image_shape[1])
+    dev = d0.device
+    merged = torch.empty((B, 144), dtype=torch.bool, device=dev)
+    pts = torch.empty((B, 144, 2), dtype=torch.float32, device=dev)
+    mk = torch.empty((2, B * 144, 2), dtype=torch.float32, device=dev)
+    bi = torch.empty((B * 144,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int64, device=dev)
+    nws = _L().pats_chunk_fine_tail_workspace_bytes(B, rows.pairs, H, W)
+    n1 = B * 144
+    arena, (Z, cflag, trust, core, xs, ys, bound, rflag, ws) = _carve(dev, B * 145 * 145 * 4, n1, n1 * 4, n1 * 4, n1 * 4, n1 * 4, n1 * 4 * 8,
+                                                                      n1, nws)
+    _check(_L().pats_chunk_fine_tail_f32(_ptr(d0), _ptr(d1), B, _ptr(_scalar_dev(one, dev)), _ptr(nsv), int(iters), float(bias_k), _ptr(sx),
+                                         _ptr(sy), 1 if merge_new else 0, rows.Cmax, int(c), rows.pairs, H, W, int(row_origin),
+                                         _ptr(rows.chunk_base), _ptr(rows.row_cell), _ptr(rows.row_slot), _ptr(rows.row_forced),
+                                         _ptr(scores_back), int(bool(first)), Z, cflag, trust, core, _ptr(pts), xs, ys, bound, rflag,
+                                         _ptr(merged.view(torch.uint8)), _ptr(mk[0]), _ptr(mk[1]), _ptr(bi), _ptr(cnt),
+                                         ctypes.c_void_p(wait_before_merge.cuda_event if wait_before_merge is not None else 0),
+                                         ctypes.c_void_p(record_after_merge.cuda_event if record_after_merge is not None else 0),
+                                         ws, nws, _stream()),
+           "chunk_fine_tail")
+    return merged, pts, mk[0], mk[1], bi, cnt
+
+
+def chunk_third_tail(feat0, feat1, P, scale, p_s, p_t, iters, outdoor, merged, points, chunk_mask, h, w, pts_new, scales):
+    """Everything behind the third network callback for ONE chunk, in one C call (pats_chunk_third_tail_f32): third_layer.py:153-170
+    over the capacity 144 B with the count P on the device, pats.py:59-67 (scatter onto the sub-cell grid) and :68-78 (get_result with
+    the chunk's mask [h w] as the level-0 flags; pts_new / scales = Compute_imgs' [1, h w, 2] tensors).  Returns (matches_l, matches_r
+    [2304 B, 2], M [1] int64 on the device): the first M rows are the chunk's matches in the reference's order."""
+    a, b = _dev(feat0, "feat0"), _dev(feat1, "feat1")
+    Pc = a.shape[0]
+    B = merged.shape[0]
+    if tuple(a.shape) != (Pc, 128, 65) or b.shape != a.shape or Pc != B * 144:
+        raise RuntimeError("chunk_third_tail: descriptors must be [144 B,128,65]")
+    sc = _dev(scale, "scale").reshape(Pc, 64)
+    ps = _dev(p_s.to(torch.int64), "p_s", torch.int64).reshape(Pc, 2)
+    pt = _dev(p_t.to(torch.int64), "p_t", torch.int64).reshape(Pc, 2)
+    dev = a.device
+    ml = torch.empty((B * 2304, 2), dtype=torch.float32, device=dev)
+    mr = torch.empty((B * 2304, 2), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int64, device=dev)
+    nws = _L().pats_chunk_third_tail_workspace_bytes(B, int(h), int(w))
+    arena, (m0, m1, label, ifm, f16, p16, mrow, ws) = _carve(dev, Pc * 32 * 4, Pc * 32 * 4, Pc * 32 * 4, Pc * 16, B * 2304, B * 2304 * 8,
+                                                             B * 2304 * 4, nws)
+    _check(_L().pats_chunk_third_tail_f32(_ptr(a), _ptr(b), Pc, _ptr(_dev(P, "P", torch.int64)), _ptr(sc), _ptr(ps), _ptr(pt), int(iters),
+                                          int(bool(outdoor)), _ptr(_as_flags(merged, "merged")), _ptr(_dev(points, "points")), B,
+                                          _ptr(_as_flags(chunk_mask, "chunk_mask")), int(h), int(w), _ptr(_dev(pts_new, "pts_new")),
+                                          _ptr(_dev(scales, "scales")), _ptr(_ones(B, dev)), m0, m1, label, ifm, f16, p16, _ptr(ml), _ptr(mr),
+                                          mrow, _ptr(cnt), ws, nws, _stream()), "chunk_third_tail")
+    return ml, mr, cnt
+
+
 _ONES = {}
 
 

@@ -250,25 +250,21 @@ def forward_chunks_device(left, right, nets, if_local=True, if_outdoor=True, mer
             fine = nets.fine(c, new_left[lo:lo + B], new_right[lo:lo + B], rows.masks[c])
             f0, f1, sx, sy = fine[:4]
             ns2 = fine[4] if len(fine) > 4 else (sx * sy).contiguous()
-            Z2, cflag2 = ops.cost_ot(f0, f1, 2, one, ns2, iters, bias_k=bias_k, return_flags=True)
-            trust2, pts2, _, _, ifn_L2, _ = ops.est_position_second(Z2, sx, sy, [96, 96], 8, col_nomatch=cflag2)
-            # ---- merge (second_layer.py:119-122, pats.py:37-39), in chunk order ------------------------------------------
-            if side is not None and prev_merge is not None:
-                st.wait_event(prev_merge)
-            merged = ops.merge_patches_chunk(merge_new, rows, c, base[c], trust2, (H, W), ifn_L2, scores_back, first=first)
+            # ---- cost + OT + expansion + merge + third-level inputs: ONE C call (ops.chunk_fine_tail); the merges in chunk order ------
+            done = None
+            if side is not None:                              # (the call waits for the previous chunk's merge right before its own and
+                done = torch.cuda.Event()                     #  re-records `done` right behind it; recorded here once so its handle exists)
+                done.record(st)
+            merged, pts2, mk0, mk1, b_ids, P = ops.chunk_fine_tail(f0, f1, one, ns2, sx, sy, iters, bias_k, merge_new, rows, c, base[c],
+                                                                   (H, W), scores_back, first, wait_before_merge=prev_merge,
+                                                                   record_after_merge=done)
             first = False
-            if side is not None:
-                prev_merge = torch.cuda.Event()
-                prev_merge.record(st)
-            # ---- third layer over the chunk's capacity (pats.py:53-58, third_layer.py:121-170) -----------------------------
-            mk0, mk1, b_ids, P = ops.third_inputs(merged, pts2, capacity=B * 144, sync=False)
+            prev_merge = done
+            # ---- third layer over the chunk's capacity + scatter + get_result: the callback, then ONE C call (ops.chunk_third_tail) ----
             third = nets.third(c, mk0, mk1, b_ids, count=P)
             feat0, feat1, scale3 = third[:3]
             p_s, p_t = third[3:5] if len(third) > 3 else (_round4(mk0, False), _round4(mk1, True))
-            m0f, m1f, label, ifm = ops.third_level(feat0, feat1, scale3, p_s, p_t, outdoor=if_outdoor, iters=iters, count=P)
-            # ---- results (pats.py:59-78) ---------------------------------------------------------------------------------
-            ifn16, pts16 = ops.refine_scatter(merged, pts2, m1f, label)
-            ml, mr, _, M = ops.get_result_chunks(_ChunkTable(rows, c, B), ifn16, avn, pts16, xsn)
+            ml, mr, M = ops.chunk_third_tail(feat0, feat1, P, scale3, p_s, p_t, iters, if_outdoor, merged, pts2, rows.masks[c], h, w, avn, xsn)
         parts.append((ml, mr, M, P))
         sizes.append(B)
     if side is not None:
