@@ -37,18 +37,12 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from pats_amd import synth  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
-F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA
-ITERS = 100
-DTYPE = "f32 (contractions: fp32 operands split into fp16 hi + lo, three exact-product MFMA passes, fp32 accumulate)"
-
-# name -> (grid h, grid w, if_local, outdoor, default pairs per step, label); BASELINE.json configs[1..3], SURVEY.md 8d
-WORKLOADS = {"megadepth": (15, 20, True, True, 48, "configs[1]: MegaDepth 640x480 shapes, outdoor (if_local chunks of 2w, +ln2, label from the dustbin, merge_new)"),
-             "scannet": (15, 20, False, False, 48, "configs[2]: ScanNet 640x480 shapes, indoor (one L2 chunk, cap 512; +ln3; fixed-cell label; merge_old)"),
-             "yfcc": (24, 32, True, True, 16, "configs[3]: YFCC 768x1024 shapes (24x32 grid, 769x769 coarse problem), outdoor, merge_new")}
+from pats_amd import synth  # noqa: E402,F401
+from benchlib.common import *  # noqa: E402,F401,F403  (peaks, ITERS, DTYPE, WORKLOADS, algorithmic bytes per unit)
+from benchlib.nets import BenchNets, GnnNets, StepWatch, run_steps, with_gnn_leg  # noqa: E402,F401
+from benchlib.baseline import cpu_baseline  # noqa: E402
+from benchlib.secondary import (gather_layout_ab, gnn_secondary, guard_trip_sweep, secondary_rooflines, secondary_workloads,  # noqa: E402
+                                step_determinism)
 
 
 def parse():
@@ -100,975 +94,6 @@ def parse():
                          "so they only time-slice)")
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
     return ap.parse_args()
-
-
-def correlated_pair(shape, dev, gen, noise=0.3, amp=3.0, chunk=2048, channels_last=False):
-    """[2, rows, ...]: two views of the same random base with independent noise - what a backbone makes of the left and
-    the right crop of a matching patch.  Built in row chunks so that the temporaries stay small.
-    channels_last: [2, rows, C, H, W] whose [rows, C, H, W] halves lie in torch.channels_last memory order."""
-    if channels_last:
-        r, c, hh, ww = shape
-        out = torch.empty((2, r, hh, ww, c), dtype=torch.float32, device=dev).permute(0, 1, 4, 2, 3)
-    else:
-        out = torch.empty((2,) + tuple(shape), dtype=torch.float32, device=dev)
-    for r0 in range(0, shape[0], chunk):
-        sub = (min(chunk, shape[0] - r0),) + tuple(shape[1:])
-        base = torch.randn(sub, device=dev, generator=gen)
-        out[0, r0:r0 + sub[0]] = amp * (base + noise * torch.randn(sub, device=dev, generator=gen))
-        out[1, r0:r0 + sub[0]] = amp * (base + noise * torch.randn(sub, device=dev, generator=gen))
-    return out
-
-
-def scale_head(shape, dev, gen):
-    x = 0.3 * torch.randn(shape, device=dev, generator=gen)
-    return torch.exp(torch.sigmoid(x) * synth.LN256 - synth.LN256 / 2)
-
-
-class BenchNets:
-    """The network outputs the path consumes, synthetic and RESIDENT in HBM before the timed region (the callbacks of
-    pats_amd.batch): coarse descriptors per pair; per row of the fine level's table the three ResNet2.forward2 maps of its
-    left / right crop, title / dustbin features and the two scale heads; per row the two half-resolution maps of the third
-    level, its dustbin features, and one scale-head row per third-level problem slot.  Inside the step the callbacks only
-    run the path's own gathers (a15: ops.fine_descriptors, a16: ops.third_descriptors); GNN + final_proj = identity."""
-
-    def __init__(self, ops, dev, gen, cap, h, w, batch=None, channels_last=True, rows_cap_policy="worst"):
-        self.ops = ops
-        self.channels_last = cl = bool(channels_last)
-        pairs, N = cap.pairs, h * w
-        c = correlated_pair((pairs, 448, N), dev, gen)
-        self.d0, self.d1 = c[0].contiguous(), c[1].contiguous()
-        gone = torch.rand((pairs, 1, N), device=dev, generator=gen) < 0.03         # a few coarse cells without a partner
-        self.d0 = torch.where(gone, 3.12 * torch.randn((pairs, 448, N), device=dev, generator=gen), self.d0).contiguous()
-        self.ns = scale_head((pairs, 1, N), dev, gen)
-        self.alpha = torch.tensor(0.0, device=dev)
-        img = torch.randint(0, 256, (2, pairs, 32 * h, 32 * w, 3), device=dev, generator=gen).float()
-        self.lefts, self.rights = img[0].contiguous(), (0.5 * img[1] + 0.5 * torch.roll(img[1], 1, dims=2)).contiguous()
-        # row capacity: the worst case N + (Cmax - 1) w per pair by default (the fine level's launches cover the capacity; rows
-        # past the device-side total are skipped by every kernel).  --rows-cap dry-run (round 3): a dry run of the coarse stage
-        # tells how many rows the table holds for THESE pairs and the capacity becomes that + 1 % - the benchmark peeking at its
-        # data, kept as an option only
-        if batch is not None and rows_cap_policy == "dry-run":
-            total = int(batch.coarse_stage(self.lefts, self.rights, self, cap, ITERS, fine_inputs="rows_only")["rows"].chunk_base[-1].item())
-            cap.rows_cap = min(cap.rows_cap, (int(total * 1.01) + 63) // 64 * 64)
-        self.cap = cap
-        R, Pc = cap.rows_cap, cap.P_cap
-        # fine level: ResNet2.forward2 maps of the stacked (left | right) crops, second_layer.py:69-70
-        # memory order of the backbone maps: torch.channels_last (the default: what a backbone run under MIOpen emits, and
-        # the order in which the gathers' per-pixel reads are contiguous) or NCHW (--maps nchw: a torch conv's default)
-        self.m0 = correlated_pair((R, 64, 48, 48), dev, gen, channels_last=cl).reshape(2 * R, 64, 48, 48)
-        self.m1 = correlated_pair((R, 64, 24, 24), dev, gen, channels_last=cl).reshape(2 * R, 64, 24, 24)
-        self.m2 = correlated_pair((R, 128, 12, 12), dev, gen, channels_last=cl).reshape(2 * R, 128, 12, 12)
-        assert all(m.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format) for m in (self.m0, self.m1, self.m2))
-        self.title = 0.5 * torch.randn((R, 8), device=dev, generator=gen)
-        self.rubbish = 1.5 * torch.randn((R, 264), device=dev, generator=gen)
-        self.sx, self.sy = scale_head((R, 1, 144), dev, gen), scale_head((R, 1, 144), dev, gen)
-        self.ns2 = (self.sx * self.sy).contiguous()
-        # outputs of the two gathers, double-buffered: with the stages of consecutive batches on different streams the
-        # gather of batch i + 1 writes while a solver of batch i still reads
-        self.desc = [torch.empty((2, R, 264, 145), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.fine_calls = self.third_calls = 0
-        self.ev = None                       # dict of lists of (start, end) HIP events while the timed steps run
-        # third level: the 1/2-resolution maps (padded to 52x52) of both crops, third_layer.py:112-120
-        f = correlated_pair((R, 128, 52, 52), dev, gen, chunk=1024, channels_last=cl)
-        self.ff0, self.ff1 = f[0], f[1]
-        assert self.ff0.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
-        self.kenc = 0.1 * torch.randn((128, 64), device=dev, generator=gen)
-        self.rubbish3 = 1.5 * torch.randn((R, 128, 144), device=dev, generator=gen)
-        self.scale3 = scale_head((Pc, 1, 64), dev, gen)
-        self.t0 = [torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.t1 = [torch.empty((Pc, 128, 65), dtype=torch.float32, device=dev) for _ in range(2)]
-
-    def set_layout(self, channels_last):
-        """Re-lay the five backbone maps (same logical tensors) in the other memory order, one tensor at a time."""
-        fmt = torch.channels_last if channels_last else torch.contiguous_format
-        for name in ("m0", "m1", "m2", "ff0", "ff1"):
-            t = getattr(self, name)
-            setattr(self, name, None)
-            t2 = t.contiguous(memory_format=fmt)
-            del t
-            setattr(self, name, t2)
-            assert t2.is_contiguous(memory_format=fmt)
-        self.channels_last = bool(channels_last)
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-
-    def resident_bytes(self):
-        flat = []
-        for v in vars(self).values():
-            flat += v if isinstance(v, list) else [v]
-        return sum(t.numel() * t.element_size() for t in flat if isinstance(t, torch.Tensor))
-
-    def coarse(self, lefts, rights):
-        return self.d0, self.d1, self.ns, self.alpha
-
-    def _timed(self, tag):
-        if self.ev is None:
-            return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.ev.setdefault(tag, []).append((e0, e1))
-        e0.record()
-        return e1
-
-    def fine(self, rows, new_left, new_right):
-        desc = self.desc[self.fine_calls & 1]
-        self.fine_calls += 1
-        e = self._timed("fine_desc")
-        self.ops.fine_descriptors([self.m0, self.m1, self.m2], self.title, self.rubbish, out=desc,
-                                  count=rows.chunk_base[-1:])                                                 # a15
-        if e is not None:
-            e.record()
-        return desc[0], desc[1], self.sx, self.sy, self.ns2
-
-    def third(self, rows, mk0, mk1, b_ids, P_dev):
-        k = self.third_calls & 1
-        self.third_calls += 1
-        e = self._timed("third_desc")
-        t0, t1, ps, pt = self.ops.third_descriptors(self.ff0, self.ff1, mk0, mk1, b_ids, self.kenc, self.rubbish3,
-                                                    count=P_dev, out=(self.t0[k], self.t1[k]))               # a16
-        if e is not None:
-            e.record()
-        return t0, t1, self.scale3, ps, pt
-
-
-class GnnNets:
-    """BenchNets with the HEADS inside the step (round-4 verdict item 3): what the three layers run between their backbone and their
-    optimal-transport problem - KeypointEncoder, the 18 / 18 / 10-layer AttentionalGNN stacks (first_layer.py:100-102,
-    second_layer.py:89, third_layer.py:146-148), final_proj, the scale heads - on random weights, as callbacks of
-    pats_amd.batch.forward_pairs.  The backbones stay what BenchNets holds (synthetic maps, resident).  Weights: the reference's
-    initialisation (synth.gnn_params / kenc_params) with the LAST Conv1d of every MLP scaled by 0.02, final_proj orthogonal and
-    the scale heads' stencils small: the residual stacks then perturb the synthetic descriptors instead of scrambling them, so the
-    optimal-transport problems behind them keep the headline's match structure and the step's counts (rows, P, M) stay comparable -
-    the arithmetic per layer does not depend on the values.  Every launch that runs over a capacity takes its count from the device
-    (rows: chunk_base[-1]; third-level problems: P)."""
-
-    def __init__(self, base, ops, dev, h, w):
-        from pats_amd import heads
-        self.base, self.ops, self.h, self.w = base, ops, h, w
-        self.lefts, self.rights = base.lefts, base.rights
-        g = torch.Generator(device=dev)
-        g.manual_seed(99)
-
-        def gnn(C, layers, seed):
-            out = []
-            for i in range(layers):
-                p = synth.gnn_params(seed=seed + i, C=C)
-                p["mlp.3.weight"] = (0.02 * p["mlp.3.weight"]).astype(np.float32)
-                out.append(ops.PropagationParams(p, device=dev))
-            return out
-
-        def kenc(dim, seed):
-            p = synth.kenc_params(seed=seed, feature_dim=dim)
-            last = max(int(k.split(".")[1]) for k in p if k.endswith(".weight") and p[k].ndim == 3)
-            p["encoder.%d.weight" % last] = (0.02 * p["encoder.%d.weight" % last]).astype(np.float32)
-            return ops.MLPParams(p, device=dev, prefix="encoder.")
-
-        def ortho(C):
-            q, _ = torch.linalg.qr(torch.randn((C, C), device=dev, generator=g))
-            return q.contiguous().reshape(C, C, 1), torch.zeros((C,), device=dev)
-
-        def stencil(C):
-            return (0.002 * torch.randn((1, C, 3, 3), device=dev, generator=g)).contiguous(), torch.zeros((1,), device=dev)
-        self.names18, self.names10 = ["self", "cross"] * 9, ["self", "cross"] * 5
-        self.coarse_heads = heads.CoarseHeads(kenc(448, 501), gnn(448, 18, 510), self.names18, ortho(448), stencil(448), bin_score=0.0)
-        self.gnn2, self.proj2 = gnn(264, 18, 540), ortho(264)
-        self.sx2, self.sy2 = stencil(264), stencil(264)
-        self.kenc3, self.gnn3, self.scale3 = kenc(128, 502), gnn(128, 10, 570), stencil(128)
-        R, Pc = base.cap.rows_cap, base.cap.P_cap
-        # outputs of the stacks over the capacities, resident (rows past the device-side counts are never written: zeros)
-        self.g2 = (torch.zeros((R, 264, 145), device=dev), torch.zeros((R, 264, 145), device=dev))
-        self.g3 = (torch.zeros((Pc, 128, 65), device=dev), torch.zeros((Pc, 128, 65), device=dev))
-        for t in base.desc + base.t0 + base.t1:
-            t.zero_()                                       # the gathers' padding rows: zeros, not whatever torch.empty left
-        self.ev = None
-
-    def _timed(self, tag):
-        if self.ev is None:
-            return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.ev.setdefault(tag, []).append((e0, e1))
-        e0.record()
-        return e1
-
-    def coarse(self, lefts, rights):
-        b = self.base
-        e = self._timed("coarse_heads")
-        pairs = b.d0.shape[0]
-        out = self.coarse_heads(b.d0.reshape(pairs, 448, self.h, self.w), b.d1.reshape(pairs, 448, self.h, self.w))
-        if e is not None:
-            e.record()
-        return out
-
-    def fine(self, rows, new_left, new_right):
-        b, ops = self.base, self.ops
-        live = rows.chunk_base[-1:]
-        desc = b.fine(rows, new_left, new_right)                                                     # a15 (counted)
-        e = self._timed("fine_gnn")
-        d0, d1 = ops.attentional_gnn(desc[0], desc[1], self.gnn2, self.names18, count=live, out=self.g2)     # second_layer.py:89
-        if e is not None:
-            e.record()
-        e = self._timed("fine_proj_scale")
-        m0, m1 = ops.conv1d(d0, *self.proj2), ops.conv1d(d1, *self.proj2)                             # :91
-        _, (sx, sy) = ops.scale_head(m1, 12, 12, [self.sx2[0], self.sy2[0]], [self.sx2[1], self.sy2[1]], return_heads=True)   # :92-97
-        if e is not None:
-            e.record()
-        return m0, m1, sx.contiguous(), sy.contiguous()
-
-    def third(self, rows, mk0, mk1, b_ids, P_dev):
-        b, ops = self.base, self.ops
-        from pats_amd import heads
-        k3 = ops.keypoint_encoder(heads.grid_kpts(8, 8, mk0.device), self.kenc3)                    # third_layer.py:132-140
-        kk = b.third_calls & 1
-        b.third_calls += 1
-        t0, t1, ps, pt = ops.third_descriptors(b.ff0, b.ff1, mk0, mk1, b_ids, k3.reshape(128, 64), b.rubbish3, count=P_dev,
-                                               out=(b.t0[kk], b.t1[kk]))                             # a16
-        e = self._timed("third_gnn")
-        f0, f1 = ops.attentional_gnn(t0, t1, self.gnn3, self.names10, count=P_dev, out=self.g3)      # :146-148
-        if e is not None:
-            e.record()
-        scale = ops.scale_head(f1, 8, 8, [self.scale3[0]], [self.scale3[1]])                         # :151-152
-        return f0, f1, scale, ps, pt
-
-
-def with_gnn_leg(ops, batch, dev, base, cap, wl, h, w, steps, warm=1):
-    """`steps` whole steps with the heads inside (GnnNets), timed like the headline's: barrier, wall clock, markers for a kernel trace."""
-    nets = GnnNets(base, ops, dev, h, w)
-    # the layers' overflow protocol in its deferred form (ops.set_gnn_redo): no gated fp32 redo chain behind the fast kernels (~340
-    # empty launches per pair, 21 ms of a 48-pair step in round 5) - the device's sticky flag is read HERE, after the steps, and a
-    # raised flag repeats the leg under the inline protocol
-    prev_mode = ops.set_gnn_redo(os.environ.get("PATS_BENCH_GNN_REDO", "deferred"))
-    ops.gnn_overflows(reset=True)
-    try:
-        for attempt in range(2):
-            run_steps(batch, nets, cap, wl, None, warm, None)
-            torch.cuda.synchronize()
-            ev = {}
-            nets.ev = ev
-            watch = StepWatch(cap)
-            torch.cuda.synchronize()
-            ops.profile_marker(1)
-            t0 = time.perf_counter()
-            out = run_steps(batch, nets, cap, wl, None, steps, None, watch)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            ops.profile_marker(2)
-            nets.ev = None
-            overflow = ops.gnn_overflows(reset=True)
-            if not overflow:
-                break
-            ops.set_gnn_redo("inline")                   # an activation left the fp16 range: the results above are void
-    finally:
-        redo_mode = ops.set_gnn_redo(prev_mode)
-    mean = lambda tag: float(np.mean([a.elapsed_time(b_) for a, b_ in ev[tag]])) if tag in ev else None
-    rep = {"pairs_per_s_with_gnn_measured": cap.pairs * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-           "ms_in_step": {"coarse_heads (KeypointEncoder + 18 layers + final_proj + scale head)": mean("coarse_heads"),
-                          "fine_gnn (18 layers, both descriptor sets, every row in use)": mean("fine_gnn"),
-                          "fine_proj_scale (final_proj x 2 + two scale heads)": mean("fine_proj_scale"),
-                          "third_gnn (10 layers, both sets, every problem in use)": mean("third_gnn")},
-           "rows_in_use": int(out["rows"].chunk_base[-1].item()), "third_problems": int(out["P"].item()), "matches": int(out["M"].item()),
-           "gnn_redo": "%s (overflow flag read after the timed steps: %s)" % (redo_mode, "raised - repeated inline" if attempt else "not raised"),
-           "note": "the headline step with the layers' heads as callbacks of batch.forward_pairs (bench.py::GnnNets): random weights, "
-                   "backbones synthetic and resident; launches over capacities take their counts from the device"}
-    del nets
-    torch.cuda.empty_cache()
-    return rep
-
-
-def _tensors(obj):
-    if isinstance(obj, torch.Tensor):
-        yield obj
-    elif isinstance(obj, dict):
-        for v in obj.values():
-            yield from _tensors(v)
-    elif hasattr(obj, "__slots__"):
-        for k in obj.__slots__:
-            yield from _tensors(getattr(obj, k, None))
-
-
-class StepWatch:
-    """Every step's counters (table status, third-level problem count P, match count M) come back to the host INSIDE the timed
-    region - asynchronously into pinned memory, checked one step behind, so the steps still queue ahead of the GPU - and a
-    capacity overflow in ANY step raises (batch.split_by_pair checks only the step it is handed)."""
-
-    def __init__(self, cap, depth=2):
-        self.cap, self.q, self.depth = cap, [], depth
-        self.pool = [torch.empty(cap.pairs + 4, dtype=torch.int64).pin_memory() for _ in range(depth + 1)]
-        self.steps = 0                                      # (one plain D2H copy a step: no kernel outside pats:: enters the steps)
-
-    def push(self, out):
-        buf = self.pool[self.steps % len(self.pool)]
-        buf.copy_(out["summary"], non_blocking=True)        # batch.group_by_pair: the pairs + 1 offsets, then M, P, table status
-        e = torch.cuda.Event()
-        e.record()
-        self.q.append((e, buf))
-        self.steps += 1
-        while len(self.q) > self.depth:
-            self._check(*self.q.pop(0))
-
-    def _check(self, e, buf):
-        e.synchronize()
-        v = buf.tolist()
-        off, (M, P, status) = v[:self.cap.pairs + 1], v[self.cap.pairs + 1:]
-        if status or P > self.cap.P_cap:
-            raise RuntimeError("bench: a step overflowed a capacity (status %d, P %d of %d)" % (status, P, self.cap.P_cap))
-        if off[-1] not in (0, M) or any(b_ < a_ for a_, b_ in zip(off, off[1:])):
-            raise RuntimeError("bench: the per-pair offsets of a step do not add up to its match count")
-        self.last = (status, P, M)
-
-    def drain(self):
-        while self.q:
-            self._check(*self.q.pop(0))
-
-
-def run_steps(batch, nets, cap, wl, ev, n, streams, watch=None):
-    """n complete steps (batches).  streams = None: the stages of a batch one after the other on the current stream.
-    streams = (sG, sS): two HIP streams with DISJOINT compute-unit masks (ops.masked_stream) -
-        sG  the HBM-bound stages: coarse level + chunk rows + crops + fine descriptor gather of batch i, third-level window
-            gather of batch i - 1
-        sS  the VALU-bound stages: fine cost + OT + expansion + merges of batch i, third-level OT + results of batch i - 1
-    Consecutive batches are independent (pairs are), so the memory-bound gathers of one batch run beside the solvers of its
-    neighbour on different CUs (plain streams only time-slice: every kernel of the path fills all CUs' registers on its own).
-    Every batch still goes through every kernel inside the timed region; nothing leaves the function unfinished (the
-    caller's stream waits for both).  The gather outputs are double-buffered (BenchNets)."""
-    kw = dict(if_outdoor=wl["outdoor"], iters=ITERS)
-    if n <= 0:
-        return None
-    if streams is None:
-        out = None
-        for _ in range(n):
-            co = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)
-            fs = batch.fine_stage(co, nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
-            out = batch.third_stage(fs, nets, cap, events=ev, **kw)
-            batch.group_by_pair(out, cap)                 # the hand-over: every pair's match list contiguous, offsets on the device
-            if watch is not None:
-                watch.push(out)
-        if watch is not None:
-            watch.drain()
-        return out
-    sG, sS = streams
-    cur = torch.cuda.current_stream()
-    sG.wait_stream(cur)
-    sS.wait_stream(cur)
-
-    def hand_over(obj, to):
-        for t in _tensors(obj):                          # allocated on one stream, read on the other
-            t.record_stream(to)
-
-    def mark(stream):
-        e = torch.cuda.Event()
-        e.record(stream)
-        return e
-    co, fs, eC, eFS, eG, eT, out = {}, {}, {}, {}, {}, {}, None
-    for i in range(n + 1):
-        j = i - 1
-        with torch.cuda.stream(sG):
-            if i < n:                                    # (the fine-descriptor buffer of batch i - 2 is free: sG already waited
-                co[i] = batch.coarse_stage(nets.lefts, nets.rights, nets, cap, ITERS)    # for eFS[i - 2] one tick ago)
-                eC[i] = mark(sG)
-            if 0 <= j < n:
-                sG.wait_event(eFS[j])                    # the points of batch j exist
-                if j - 2 in eT:
-                    sG.wait_event(eT[j - 2])             # the third-level descriptor buffer of batch j - 2 has been read
-                hand_over(fs[j], sG)
-                batch.third_gather_stage(fs[j], nets, cap)
-                eG[j] = mark(sG)
-        with torch.cuda.stream(sS):
-            if i < n:
-                sS.wait_event(eC[i])
-                hand_over(co[i], sS)
-                fs[i] = batch.fine_solve_stage(co[i], nets, cap, merge_new=wl["merge_new"], events=ev, **kw)
-                eFS[i] = mark(sS)
-            if 0 <= j < n:
-                sS.wait_event(eG[j])
-                hand_over(fs[j], sS)
-                out = batch.third_stage(fs[j], nets, cap, events=ev, **kw)
-                eT[j] = mark(sS)
-                co.pop(j, None)
-                if j - 1 in fs:
-                    fs.pop(j - 1)
-    cur.wait_stream(sG)
-    cur.wait_stream(sS)
-    hand_over(out, cur)
-    return out
-
-
-def torch_cpu_sinkhorn(Z, log_mu, log_nu, iters):
-    """What the reference executes on CPU (modules.py:137-143), transcribed: logsumexp row / column sweeps."""
-    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
-    for _ in range(iters):
-        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
-        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
-    return Z + u.unsqueeze(2) + v.unsqueeze(1)
-
-
-def torch_cpu_cost_ot2(d0, d1, ns, iters):
-    """second_layer.py:100-104 / third_layer.py:156-158 on CPU tensors: einsum cost build + log_optimal_transport2."""
-    scores = 0.1 * (torch.einsum("bdn,bdm->bnm", d0, d1) / d0.shape[1] ** .5)
-    b, m, n = scores.shape
-    ms = torch.tensor(float(m - 1))
-    nssum = ns.sum(dim=2)                                             # [b,1]
-    norm = -(ms + nssum).log()
-    log_nu = torch.cat([ns.log()[:, 0] + norm, ms.log().expand(b, 1) + norm], dim=1)
-    log_mu = torch.cat([norm.expand(b, m - 1), nssum.log() + norm], dim=1)
-    return torch_cpu_sinkhorn(scores, log_mu, log_nu, iters) - norm[:, :, None]
-
-
-ULP4 = 4.0 * 2.0 ** -23     # "a threshold tie": the deciding quantities agree to 4 ulp
-
-
-def expansion_parity(ops, oracle, dev, sx, sy, gZ2, Z2):
-    """Area expansion of pair 0's fine problems (utils.py:1213-1243), HIP against the oracle, every differing row classified.
-
-    (1) SAME INPUT: the oracle expands the plan the GPU produced (exp on the GPU, the identical fp32 array on both
-        sides), so the only freedom left is the summation order of a strip.  A row whose rectangle differs is a
-        threshold tie if the oracle's own decision margin - the relative distance between the strip sum that decided
-        and `lower_bound` / the competing strip (oracle_iterative_expand_margin) - is within 4 ulp; anything else is a
-        REAL mismatch, and the bench asserts there is none.
-    (2) END TO END: each side expands its OWN plan.  The plans agree to the 1e-4 transport-mass gate, not bit for bit,
-        and `lower_bound` = 1e-3 is only 10x that gate, so a strip sum - or a single strip cell, for the per-element test
-        of :1225 that charges the opposite dustbin mass to whole_cost - that lands within the measured plan difference of
-        the threshold is counted on one side only; such a row carries a different trust score (this is where round 2's
-        unexplained max |d trust| = 0.04 came from: one row, one cell) and possibly a different rectangle.  A differing
-        row is "explained" if its margin is below what the measured plan difference of its problem can move a strip sum
-        by (12 cells x max |dP|, relative to lower_bound); anything else is REAL and asserted zero."""
-    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    nb = gZ2.shape[0]
-    pos, rng_ = ops.Compute_positions_and_ranges(12, 12, dev)
-    gP = ops.exp(gZ2)
-    gsame = ops.Iterative_expand_matrix(gP, td(sx).reshape(nb, -1, 1), td(sy).reshape(nb, -1, 1), [0, 12, 0, 12], rng_, pos,
-                                        lower_bound=1e-3, iter_num=8, width=12, height=12)
-    gbound, gtrust = gsame[5].cpu().numpy(), gsame[0].cpu().numpy()
-    osame = oracle.iterative_expand(gP.cpu().numpy(), sx, sy, 12, 12, 12, 1e-3, 8, with_margin=True)
-    diff_rows = (gbound != osame[5]).any(axis=2)
-    tie = diff_rows & (osame[6][..., 0] <= ULP4)
-    real_same = diff_rows & ~tie
-    elem_tie = osame[6][..., 1] <= ULP4
-    dtrust = np.abs(gtrust - osame[0])
-    ok_rows = ~diff_rows & ~elem_tie
-    trust_same = float(dtrust[ok_rows].max()) if ok_rows.any() else 0.0
-    # end to end (each side its own plan)
-    own = oracle.iterative_expand(np.exp(Z2), sx, sy, 12, 12, 12, 1e-3, 8, with_margin=True)
-    ebound_diff = (gbound != own[5]).any(axis=2)
-    dP = np.abs(np.exp(gZ2.cpu().numpy().astype(np.float64)) - np.exp(Z2.astype(np.float64)))[:, :-1, :].max(axis=(1, 2))
-    reach = (12.0 * dP / 1e-3 + ULP4)[:, None]
-    explained = ebound_diff & (own[6][..., 0] <= reach)
-    real_e2e = ebound_diff & ~explained
-    dtrust_e2e = np.abs(gtrust - own[0])
-    tol_t = 1e-4 + 1e-4 * np.abs(own[0])
-    tdiff = (dtrust_e2e > tol_t) & ~ebound_diff
-    t_explained = tdiff & (own[6][..., 1] <= reach)
-    return {
-        "l2_rows": int(diff_rows.size),
-        "l2_bound_mismatch_same_input": int(diff_rows.sum()), "l2_bound_threshold_ties": int(tie.sum()),
-        "l2_bound_real_mismatch": int(real_same.sum() + real_e2e.sum()),
-        "l2_trust_max_abs_diff_same_input_same_rectangle": trust_same,
-        "l2_bound_mismatch_end_to_end": int(ebound_diff.sum()),
-        "l2_bound_mismatch_end_to_end_explained_by_plan_difference": int(explained.sum()),
-        "l2_plan_max_abs_diff": float(dP.max()),
-        "l2_trust_max_abs_diff": float(dtrust_e2e.max()), "l2_trust_max_abs": float(np.abs(own[0]).max()),
-        "l2_trust_rows_differing_with_equal_rectangles": int(tdiff.sum()),
-        "l2_trust_rows_explained_by_element_threshold": int(t_explained.sum()),
-        "l2_trust_real_mismatch": int((tdiff & ~t_explained).sum()),
-    }
-
-
-def cpu_baseline(ops, batch, dev, nets, cap, wl, out, torch_leg=True):
-    """The CPU oracle ("port") on the host cores over ONE WHOLE PAIR (pair 0 of a step: L1 in full, every fine problem,
-    every third-level problem the merge left, the merges, the scatter and get_result) - measured, not extrapolated.
-    Each stage is fed what the GPU handed its own next stage, so the same run is a stage-by-stage parity check on the
-    bench's own data (`parity_sample`; index outputs are ASSERTED).  Beside it the torch-CPU transcription of
-    modules.py:137-182 + the einsum cost builds, on samples.  Checker code, timed as a baseline only."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import pats_oracle as oracle
-    cores = oracle.num_threads()
-    h, w, N = cap.h, cap.w, cap.N
-    H, W = 32 * h, 32 * w
-    st, rows, co = out["stages"], out["rows"], out["coarse"]
-    cell = rows.row_cell.cpu().numpy()
-    total = int(rows.chunk_base[-1].item())
-    rows0 = np.nonzero((cell[:total] >= 0) & (cell[:total] // N == 0))[0]
-    B0 = len(rows0)
-    base = rows.chunk_base.cpu().numpy()
-    r0t = torch.from_numpy(rows0).to(dev)
-    cpu = lambda t: t.detach().cpu().numpy()   # noqa: E731
-    times = {}
-
-    # ---- L1 (first_layer.py:110-127) -------------------------------------------------------------------------------
-    d0, d1, ns = cpu(nets.d0[0:1]), cpu(nets.d1[0:1]), cpu(nets.ns[0:1])
-    t0 = time.perf_counter()
-    S = oracle.cost(d0, d1)
-    Z = oracle.log_optimal_transport(S, float(nets.alpha.item()), ns, ITERS)
-    sc = oracle.colmass_sqrt(Z)
-    r1, c1 = oracle.argmax(Z)
-    oracle.iterative_expand(np.exp(Z), sc, sc, w, h, w, 1e-5, 15)
-    times["L1"] = time.perf_counter() - t0
-    ifn1_o = (r1[:, :-1] == N)
-    parity = {"pair": 0, "l1_if_nomatching_mismatch": int((ifn1_o[0] != cpu(co["ifn1"][0])).sum()),
-              "l1_matched_patches": int((~ifn1_o).sum())}
-
-    # ---- L2 (second_layer.py:100-118) on the descriptors the GPU's gather produced ---------------------------------
-    f0, f1 = cpu(st["f0"][r0t]), cpu(st["f1"][r0t])
-    sx, sy = cpu(st["sx"][r0t]), cpu(st["sy"][r0t])
-    t0 = time.perf_counter()
-    S2 = oracle.cost(f0, f1)
-    Z2 = oracle.dustbin_bias(oracle.log_optimal_transport2(S2, 1.0, sx * sy, ITERS), wl["bias_k"])
-    r2, c2 = oracle.argmax(Z2)
-    oracle.iterative_expand(np.exp(Z2), sx, sy, 12, 12, 12, 1e-3, 8)
-    times["L2"] = time.perf_counter() - t0
-    gZ2 = st["Z2"][r0t].contiguous()
-    gr2, gc2 = ops.argmax(gZ2)
-    e2, e2r = np.exp(cpu(gZ2).astype(np.float64)), np.exp(Z2.astype(np.float64))
-    pre = ops.est_position_second(gZ2, st["sx"][r0t].contiguous(), st["sy"][r0t].contiguous(), [96, 96], 8)   # before the merge
-    parity.update({"l2_problems": B0, "l2_row_argmax_mismatch": int((cpu(gr2) != r2).sum()),
-                   "l2_col_argmax_mismatch": int((cpu(gc2) != c2).sum()),
-                   "l2_mass_max_abs_diff": float(np.abs(e2[:, :-1, :-1] - e2r[:, :-1, :-1]).max()),
-                   "l2_flag_mismatch": int((cpu(pre[4]) != (r2[:, :-1] == 144)).sum() + (cpu(pre[5]) != (c2[:, :-1] == 144)).sum())})
-    parity.update(expansion_parity(ops, oracle, dev, sx, sy, gZ2, Z2))
-
-    # ---- merge (second_layer.py:119-122, pats.py:38-39): the oracle on the GPU's trust scores, chunk after chunk -----
-    trust_g, ifn_g = cpu(pre[0]), cpu(pre[4])
-    masks0 = cpu(rows.masks[:, 0, :])
-    third_set = cpu(rows.third[0])
-    nchunks = int(rows.cycle_num[0].item())
-    merged_o = np.ones((B0, 144), bool)
-    scores_back = np.zeros((1, N, 16, 9), np.float64)
-    t0 = time.perf_counter()
-    o = 0
-    for c in range(min(nchunks, cap.Cmax)):
-        n = int(((cell[int(base[c]):int(base[c + 1])] // N) == 0).sum())
-        if n == 0:
-            continue
-        res, _, _, sb = oracle.merge_patches(wl["merge_new"], trust_g[o:o + n], (H, W), masks0[c:c + 1], ifn_g[o:o + n], scores_back)
-        scores_back = sb if wl["merge_new"] else np.zeros_like(sb)
-        tail = int(third_set[c, 1])
-        if tail != 0:
-            res[-tail:, :] = True
-        merged_o[o:o + n] = res
-        o += n
-    times["merge"] = time.perf_counter() - t0
-    merged_g = cpu(out["merged"][r0t])
-    parity["merge_if_nomatching_mismatch"] = int((merged_g != merged_o).sum())
-
-    # ---- L3 (pats.py:53-58, third_layer.py:153-170) on the descriptors the GPU's window gather produced --------------
-    P = int(out["P"].item())
-    b_ids = cpu(st["b_ids"][:P])
-    idx3 = np.nonzero(np.isin(b_ids, rows0))[0]
-    i3t = torch.from_numpy(idx3).to(dev)
-    P0 = len(idx3)
-    t3a, t3b, sc3 = cpu(st["feat0"][i3t]), cpu(st["feat1"][i3t]), cpu(st["scale3"][i3t])
-    ps3, pt3 = cpu(st["p_s"][i3t]), cpu(st["p_t"][i3t])
-    sq = np.sqrt(sc3 + np.float32(1e-8)).astype(np.float32)
-    pts2_0 = cpu(st["pts2"][r0t])
-    t0 = time.perf_counter()
-    mk0_o, mk1_o, bid_o = oracle.third_inputs(merged_o, pts2_0)
-    S3 = oracle.cost(t3a, t3b)
-    Z3 = oracle.log_optimal_transport2(S3, 1.0, sc3, ITERS)
-    q0, q1, _, qlabel, qifm = oracle.compute_result(np.exp(Z3), sq, sq, ps3, pt3, wl["outdoor"])
-    times["L3"] = time.perf_counter() - t0
-    g1 = cpu(st["m1f"][i3t])
-    glabel = cpu(st["label"].reshape(-1, 16, 2)[i3t])
-    parity.update({"l3_problems": P0,
-                   "l3_points_mismatch": int((mk0_o != cpu(st["mk0"][i3t])).sum() + (mk1_o != cpu(st["mk1"][i3t])).sum()) if len(mk0_o) == P0 else -1,
-                   "l3_label_mismatch": int((glabel.reshape(-1, 2) != qlabel).sum()),
-                   "l3_if_matching_mismatch": int((cpu(st["ifm"][i3t]).astype(bool) != qifm.astype(bool)).sum()),
-                   "l3_mkpts0_mismatch": int((cpu(st["m0f"][i3t]) != q0).sum()),
-                   "l3_mkpts1_max_abs_diff_px": float(np.abs(g1 - q1).max()) if P0 else 0.0})
-
-    # ---- results (pats.py:59-78): the oracle's scatter + get_result on the GPU's third-level output -----------------
-    t0 = time.perf_counter()
-    ifn16_o, pts16_o = oracle.refine_scatter(merged_o, pts2_0, g1, glabel[:, :, 0].reshape(-1))
-    C = masks0.shape[0]
-    xs0, av0 = cpu(co["xsn"][0:1]), cpu(co["avn"][0:1])
-    xs_c, av_c = np.repeat(xs0, C, axis=0), np.repeat(av0, C, axis=0)
-    sc_rows = xs_c[~masks0]
-    ml_o, mr_o = oracle.get_result(C, [masks0, ifn16_o], [np.ascontiguousarray(av_c[:, :, ::-1]) / np.float32(32.0),
-                                                          np.ascontiguousarray(pts16_o[:, :, ::-1]) / np.float32(2.0)],
-                                   [xs_c, np.repeat(sc_rows.reshape(-1, 1, 2), 2304, 1)], [[32, h, w], [2, 48, 48]],
-                                   [np.ones(C, bool), np.ones(B0, bool)])
-    times["result"] = time.perf_counter() - t0
-    ml_g, mr_g = [cpu(t) for t in batch.split_by_pair(out, cap)[0]]
-    same_count = ml_g.shape == ml_o.shape
-    parity.update({"matches_pair0": int(ml_g.shape[0]), "matches_count_equal": bool(same_count),
-                   "matches_l_mismatch": int((ml_g != ml_o).sum()) if same_count else -1,
-                   "matches_r_mismatch": int((mr_g != mr_o).sum()) if same_count else -1})
-    if same_count and parity["matches_l_mismatch"]:
-        sys.stderr.write("matches_l gpu %s\noracle %s\nmatches_r gpu %s\noracle %s\n" % (ml_g[:4], ml_o[:4], mr_g[:4], mr_o[:4]))
-    assert parity["l1_if_nomatching_mismatch"] == 0 and parity["l2_flag_mismatch"] == 0, parity
-    assert parity["l2_row_argmax_mismatch"] == 0 and parity["l2_col_argmax_mismatch"] == 0, parity
-    assert parity["l2_bound_real_mismatch"] == 0 and parity["l2_trust_real_mismatch"] == 0, parity
-    assert parity["merge_if_nomatching_mismatch"] == 0 and parity["l3_points_mismatch"] == 0, parity
-    assert parity["l3_label_mismatch"] == 0 and parity["l3_if_matching_mismatch"] == 0 and parity["l3_mkpts0_mismatch"] == 0, parity
-    assert parity["l3_mkpts1_max_abs_diff_px"] <= 3e-4 * 8 and parity["l2_mass_max_abs_diff"] <= 1e-4, parity
-    assert same_count and parity["matches_l_mismatch"] == 0 and parity["matches_r_mismatch"] == 0, parity
-    per_pair = sum(times.values())
-    if not torch_leg:                                    # the secondary workloads: the oracle's pair + its parity only
-        return {"value": 1.0 / per_pair, "unit": "pairs/s", "cores": cores, "kind": "port", "seconds_per_pair": per_pair,
-                "sample": "oracle/pats_oracle.c on ONE WHOLE PAIR (pair 0 of a step): L1 %dx%d, %d fine, %d third-level problems"
-                          % (N + 1, N + 1, B0, P0), "parity_sample": parity}
-
-    # ---- torch-CPU transcription of what the reference executes (einsum cost + logsumexp sweeps), on samples ----------
-    torch.set_num_threads(cores)
-    tns = torch.from_numpy(ns)
-    t0 = time.perf_counter()
-    sco = 0.1 * (torch.einsum("bdn,bdm->bnm", torch.from_numpy(d0), torch.from_numpy(d1)) / 448 ** .5)
-    b, m, n = sco.shape
-    alpha = torch.tensor(float(nets.alpha.item()))
-    coup = torch.cat([torch.cat([sco, alpha.expand(b, m, 1)], -1), alpha.expand(b, 1, n + 1)], 1)
-    msn = torch.tensor(float(m))
-    norm = -(msn + tns.sum(dim=2)).log()
-    log_nu = torch.cat([tns.log()[:, 0] + norm, msn.log().expand(b, 1) + norm], dim=1)
-    log_mu = torch.cat([norm.expand(b, m), tns.sum(dim=2).log() + norm], dim=1)
-    torch_cpu_sinkhorn(coup, log_mu, log_nu, ITERS)
-    tt1 = time.perf_counter() - t0
-    # the WHOLE pair, measured (no sampling): every fine problem, every third-level problem the merge left, in the batch
-    # sizes the reference issues them in (one chunk of <= 2w rows at a time; the third level chunk by chunk: ~300 problems)
-    t0 = time.perf_counter()
-    for o in range(0, B0, 40):
-        torch_cpu_cost_ot2(torch.from_numpy(f0[o:o + 40]), torch.from_numpy(f1[o:o + 40]), torch.from_numpy((sx * sy)[o:o + 40]), ITERS)
-    tt2 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    step3 = max(1, -(-P0 // max(nchunks, 1)))
-    for o in range(0, P0, step3):
-        torch_cpu_cost_ot2(torch.from_numpy(t3a[o:o + step3]), torch.from_numpy(t3b[o:o + step3]), torch.from_numpy(sc3[o:o + step3]), ITERS)
-    tt3 = time.perf_counter() - t0
-    torch_pair = tt1 + tt2 + tt3
-    return {"value": 1.0 / per_pair, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "oracle/pats_oracle.c (OpenMP over problems) on ONE WHOLE PAIR, measured: pair 0 of a step - L1 %dx%d "
-                      "(%.3fs), its %d fine problems (%.3fs), the merges of its %d chunks (%.3fs), its %d third-level problems "
-                      "(%.3fs), scatter + get_result (%.3fs)" % (N + 1, N + 1, times["L1"], B0, times["L2"], nchunks, times["merge"],
-                                                                  P0, times["L3"], times["result"]),
-            "seconds_per_pair": per_pair,
-            "torch_cpu": {"value": 1.0 / torch_pair, "unit": "pairs/s", "cores": cores,
-                          "sample": "measured on ONE WHOLE PAIR (no sampling): torch transcription of the reference's CPU arithmetic (einsum "
-                                    "cost builds + modules.py:137-182 logsumexp sweeps; no expansion / merge), %d torch threads: L1 "
-                                    "(%.3fs), all %d fine problems in chunks of 40 (%.3fs), all %d third-level problems in %d chunks (%.3fs)"
-                                    % (cores, tt1, B0, tt2, P0, max(nchunks, 1), tt3),
-                          "seconds_per_pair": torch_pair},
-            "parity_sample": parity}
-
-
-def timed(fn, reps=5, warm=2):
-    """Mean duration of one call: one HIP event pair around `reps` back-to-back calls on the stream the kernels run on.
-    For a kernel of tens of microseconds the calls must not allocate (pass out=) and reps must be large enough for
-    the queue to stay ahead of the GPU - an event pair per call adds ~35 us of marker latency to each."""
-    for _ in range(warm):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
-
-
-def secondary_rooflines(ops, dev):
-    """Kernels of BASELINE.json configs[4] (config 5 of SURVEY 8d) against their nearer roofline (live HIP-event timings;
-    rocprof counterparts under profiles/)."""
-    res = []
-    r = synth.roofline_inputs()
-    d0, d1, ns = [torch.from_numpy(r[k]).to(dev) for k in ("d0", "d1", "ns")]
-    N, D = d0.shape[2], d0.shape[1]
-    S = ops.cost(d0, d1)
-    ms = timed(lambda: ops.cost(d0, d1, out=S), reps=200, warm=20)
-    tf = 2.0 * D * N * N / (ms * 1e-3) / 1e12
-    res.append({"kernel": "cost_mfma_kernel, config 5 (4096^2 x %d)" % D, "bound": "mfma", "achieved": 3.0 * tf,
-                "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3.0 * tf / F16_PEAK_TFLOPS, "ms": ms,
-                "algorithmic_tflops": tf, "fp32_equivalent_frac": tf / F32_PEAK_TFLOPS,
-                "note": "priced on the pipe the kernel uses: fp32 operands as fp16 hi + lo pairs, THREE exact-product passes of "
-                        "v_mfma_f32_32x32x16_f16 per tile (fp32 accumulation) = 3 x the 2*D*M*N algorithmic flops against the dense fp16 "
-                        "matrix peak; the limiter is the descriptor stream, the LDS staging and the VALU split, not the matrix pipe.  "
-                        "fp32_equivalent_frac = algorithmic flops against the 157.3 TF/s fp32 matrix peak the reference arithmetic "
-                        "would be priced at (a note, not the claim)"})
-    alpha = torch.tensor(float(r["alpha"]), device=dev)
-    iters5 = 200
-    ms = timed(lambda: ops.log_optimal_transport(S, alpha, ns, iters5), reps=3, warm=1)
-    M = N + 1
-    gbs = 8.0 * M * M * iters5 / (ms * 1e-3) / 1e9
-    # match indices against the REFERENCE's own 4097 x 4097, 200-sweep run (tests/golden/roofline_4097.npz holds both argmax vectors):
-    # an index may differ only where the two candidates' log-plan values agree to 4 ulp (flat N(0, 0.01) scores: exact-noise ties)
-    ties = None
-    gpath = os.path.join(REPO, "tests", "golden", "roofline_4097.npz")
-    if os.path.exists(gpath):
-        g = np.load(gpath)
-        Z = ops.log_optimal_transport(S, alpha, ns, int(g["iters"]))
-        rr, cc = ops.argmax(Z)
-        Zc = Z[0].cpu().numpy()
-
-        def flips(Zn, got, want):
-            bad = np.nonzero(got != want)[0]
-            real = sum(1 for i in bad if abs(float(Zn[i, got[i]]) - float(Zn[i, want[i]])) >
-                       4 * np.spacing(np.float32(max(abs(Zn[i, got[i]]), abs(Zn[i, want[i]])))))
-            return int(len(bad)), int(real)
-        (nr, real_r), (nc, real_c) = flips(Zc, rr[0].cpu().numpy(), g["max0"]), flips(Zc.T, cc[0].cpu().numpy(), g["max1"])
-        ties = {"rows_differing": nr, "cols_differing": nc, "not_a_4ulp_tie": real_r + real_c, "of": 2 * (M - 1),
-                "against": "the reference's own run (tests/golden/roofline_4097.npz)"}
-        assert real_r + real_c == 0, "config 5: a match index differs from the reference's beyond a 4-ulp tie"
-        del Z, Zc
-    nblk5, np5 = (M + 16) // 17, (M + 3) & ~3
-    phys = (2.0 * nblk5 * np5 * 4 + nblk5 * 8.0 * M + 8.0 * M) * iters5 / (ms * 1e-3) / 1e9
-    res.append({"kernel": "stream_resident_kernel, config 5 (4097^2, %d sweeps in one launch, K register-resident)" % iters5, "bound": "hbm", "achieved": phys,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": phys / HBM_PEAK_GBS, "ms": ms, "sweeps_per_s": iters5 / (ms * 1e-3),
-                "streaming_model_GBps": gbs, "resident_model_GBps": 8.0 * M * M / (ms * 1e-3) / 1e9, "physical_GBps": phys,
-                "argmax_vs_reference": ties,
-                "note": "achieved / frac = the PHYSICAL traffic of the solve against 8 TB/s.  SURVEY 8d prices a sweep at 8*M*N bytes when it "
-                        "streams (streaming_model_GBps: what a two-pass streaming solve would have to move at this sweep rate - more than HBM "
-                        "can deliver) and the whole problem at 8*M*N when it is on-chip resident (resident_model_GBps); since round 5 the "
-                        "solve IS resident: stream_resident_kernel (csrc/sinkhorn_stream.hip) keeps every workgroup's 17 x 4097 piece of K "
-                        "in registers for all 200 sweeps, so a sweep moves no K at all - PHYSICAL traffic per sweep = 241 rows of column "
-                        "partials written and read (2 x 3.95 MB), the 33 KB of {b_j, sweep} granules every workgroup polls, nothing else; "
-                        "the memory system is a seventh busy.  What bounds a sweep now is two grid-wide hand-overs through memory that is not coherent across XCDs "
-                        "(timeline of the diagnostic build, us per sweep: the barrier behind the partials 5.8 - write-through of the stores, "
-                        "arrival, poll - the wait for the granules of the new b 5.8, row dots 1.7, reduce 0.9): 14.2 us = 70 400 sweeps/s "
-                        "against 17.1 us = 58 700 for round 4's two launches a sweep (13.1 us of it the 67 MB read of K; hipGraph replay "
-                        "of those 400 launches: 59 200 - the gaps are GPU-side, tools/config5_graph_probe.py).  Spins are bounded: a grid "
-                        "that is not fully resident gives up and the problem is re-solved by the log-domain kernel"})
-    return res
-
-
-def gnn_secondary(ops, dev, pairs, rows_step, P_step, ms_per_step, outdoor):
-    """SURVEY 8f rank 4 beside the headline, NOT in it: the AttentionalGNN stacks that sit between each level's gather and its
-    cost build (first_layer.py:102, second_layer.py:89, third_layer.py:148), random weights, timed at the step's own problem
-    counts - one AttentionalPropagation per level (both descriptor sides), scaled by the reference's layer counts (18 / 18 / 10).
-    Third level: the fused kernel of csrc/gnn_fused.hip (BatchNorm as PATS.eval() leaves it: running statistics outdoors, batch
-    statistics indoors, pats.py:112-118); fine level: the tile + attention kernels of csrc/gnn_fine.hip, run as a stack (round 5); coarse
-    level: five packed-weights convolutions (csrc/conv_pk.hip) around the general attention kernel.  The MEASURED counterpart - whole
-    steps with every head inside - is with_gnn_leg / `bench.py --with-gnn`."""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(4242)
-
-    def layer_ms(C, b, n, train, chunk):
-        P = ops.PropagationParams(synth.gnn_params(seed=9, C=C))
-        bb = min(b, chunk)
-        x = torch.randn((bb, C, n), device=dev, generator=gen)
-        s_ = torch.randn((bb, C, n), device=dev, generator=gen)
-        ms = timed(lambda: ops.attentional_propagation(x, s_, P, bn_train=train, residual=x), reps=3, warm=1)
-        del x, s_
-        torch.cuda.empty_cache()
-        return ms * b / float(bb), bb
-    def fine_stack_ms(b, chunk, layers=4):
-        """one layer of the fine level's stack as the stack runs it (round 5, csrc/gnn_fine.hip): both descriptor sets in one launch,
-        descriptors kept in the kernel's own form between the layers - timed as a `layers`-deep stack, conversions included"""
-        Ps = [ops.PropagationParams(synth.gnn_params(seed=9 + i, C=264)) for i in range(layers)]
-        names = (["self", "cross"] * layers)[:layers]
-        bb = min(b, chunk)
-        x = torch.randn((bb, 264, 145), device=dev, generator=gen)
-        s_ = torch.randn((bb, 264, 145), device=dev, generator=gen)
-        o = (torch.empty_like(x), torch.empty_like(s_))
-        ms = timed(lambda: ops.attentional_gnn(x, s_, Ps, names, out=o), reps=3, warm=1)
-        del x, s_, o
-        torch.cuda.empty_cache()
-        return ms / layers / 2.0 * b / float(bb), bb          # per layer and descriptor set, like layer_ms
-    t3, b3 = layer_ms(128, P_step, 65, not outdoor, 131072)
-    t2, b2 = fine_stack_ms(rows_step, 4096)
-    t1, b1 = layer_ms(448, pairs, 300, False, 64)
-    per_step = {"coarse": 2 * 18 * t1, "fine": 2 * 18 * t2, "third": 2 * 10 * t3}
-    total = sum(per_step.values())
-    flops3 = 2.0 * 65 * (4 * 128 * 128 + 256 * 256 + 256 * 128) + 4 * 2 * (2.0 * 65 * 65 * 32)
-    by3 = 3.0 * 128 * 65 * 4 + 128 * 65 * 4
-    roof = {"kernel": "gnn_layer_fused_kernel (AttentionalPropagation at [128,65], %d problems per launch%s)"
-                      % (b3, "" if outdoor else "; batch statistics: up to the hidden tensor, + statistics passes + last convolution"),
-            "bound": "mfma", "achieved": 3.0 * flops3 * b3 / (t3 * b3 / P_step * 1e-3) / 1e12, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "ms_per_launch": t3 * b3 / P_step, "algorithmic_tflops": flops3 * b3 / (t3 * b3 / P_step * 1e-3) / 1e12,
-            "hbm_frac": by3 * b3 / (t3 * b3 / P_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "the whole layer in one kernel, activations LDS-resident in MFMA fragment order; priced like the cost build: fp32 "
-                    "operands as fp16 hi + lo, three exact-product passes = 3 x the algorithmic flops against the dense fp16 matrix peak "
-                    "(token padding 80 / 65 not counted); hbm_frac = x + source + residual in, out (4 x 33 KB per problem) against 8 TB/s"}
-    roof["frac"] = roof["achieved"] / F16_PEAK_TFLOPS
-    flops2 = 2.0 * 145 * (4 * 264 * 264 + 528 * 528 + 528 * 264) + 4 * 2 * (2.0 * 145 * 145 * 66)
-    by2 = 4 * 153120.0 + 2 * 475680.0      # per problem and layer, all of it past the L2: x and attention images in, attention and output images
-                                           # out (4 x 153 120 B), the block of projections (q, k, v^T as fragments: 475 680 B) written and read
-    fine = {"kernel": "gnn_fine_tile_kernel + gnn_fine_attn_kernel (AttentionalPropagation at [264,145], two launches a layer, both descriptor sets = %d problems per launch)" % (2 * b2),
-            "bound": "mfma", "achieved": 3.0 * flops2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e12, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "ms_per_launch": 2.0 * t2 * b2 / rows_step, "ms_per_4096_problems": t2 * 4096.0 / rows_step,
-            "algorithmic_tflops": flops2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e12,
-            "hbm_frac": by2 * b2 / (t2 * b2 / rows_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "per-token products (mlp of layer l + q / k / v of layer l + 1) on 64-column tiles of the flattened (problem, token tile) "
-                    "list, operands by LDS DMA, outputs in the accumulators, hidden tensor never off the CU; attention core per problem in wave "
-                    "roles; same 3 x pricing as the third level's fused layer against the NOMINAL dense fp16 peak - the tile kernel clocks to "
-                    "the power budget (1.5-2.0 GHz by box; the same instruction stream on all-zero operands runs 21 % faster: "
-                    "profiles/r05_gnn_fine_power_zeros_ab.txt), matrix pipe 49-59 % busy at the clock it gets; hbm_frac = 1.56 MB per problem "
-                    "and layer (four descriptor images + the projections written and read) against 8 TB/s; timed as a 4-layer stack, "
-                    "conversions at its ends and the first layer's own projection launch included"}
-    fine["frac"] = fine["achieved"] / F16_PEAK_TFLOPS
-    # the matrix pipe's own rate on random operands (tools/mfma_rate_probe.hip, profiles/r05_mfma_rate_probe.txt): 1 720 TFLOP/s at the
-    # 1.74 GHz the part sustains on toggling data - what a split-fp16 product can at most reach here
-    fine["frac_of_measured_random_operand_ceiling_1720_TFLOPs"] = fine["achieved"] / 1720.0
-    roof["fine_level_layer"] = fine
-    return {"ms_per_step": per_step, "layers": {"coarse": 18, "fine": 18, "third": 10},
-            "sample": {"third": "%d of %d problems" % (b3, P_step), "fine": "%d of %d rows" % (b2, rows_step), "coarse": "%d of %d pairs" % (b1, pairs)},
-            "pairs_per_s_with_gnn": pairs / ((ms_per_step + total) * 1e-3),
-            "note": "headline step + the three GNN stacks on random weights, added as sequential stream time (every kernel fills the "
-                    "GPU on its own); backbones, KeypointEncoder, final_proj and scale heads not included"}, roof
-
-
-def gather_layout_ab(ops, dev, cap, P_step, rows=2048):
-    """The two descriptor gathers on the SAME logical maps in both memory orders (a sample of `rows` fine rows and the
-    matching share of third-level points, times scaled to the step's launch sizes): outputs compared bit for bit."""
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(77)
-    R = min(rows, cap.rows_cap)
-    P = max(64, int(P_step * R / float(cap.rows_cap)))
-
-    def timed(fn, n=5):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
-
-    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
-    maps = [torch.randn(sh, device=dev, generator=gen) for sh in ((2 * R, 64, 48, 48), (2 * R, 64, 24, 24), (2 * R, 128, 12, 12))]
-    title, rub = torch.randn((R, 8), device=dev, generator=gen), torch.randn((R, 264), device=dev, generator=gen)
-    out = torch.empty((2, R, 264, 145), dtype=torch.float32, device=dev)
-    f_nchw = timed(lambda: ops.fine_descriptors(maps, title, rub, out=out))
-    ref = out.clone()
-    maps = [cl(m) for m in maps]
-    f_nhwc = timed(lambda: ops.fine_descriptors(maps, title, rub, out=out))
-    same = torch.equal(ref, out)
-    del maps, out, ref
-    ff0, ff1 = (torch.randn((R, 128, 52, 52), device=dev, generator=gen) for _ in range(2))
-    mk0 = (torch.randint(1, 11, (P, 2), device=dev, generator=gen) * 8 + 4).float()
-    mk1 = torch.rand((P, 2), device=dev, generator=gen) * 96
-    b_ids = torch.sort(torch.randint(0, R, (P,), device=dev, generator=gen))[0]
-    kenc, rub3 = torch.randn((128, 64), device=dev, generator=gen), torch.randn((R, 128, 144), device=dev, generator=gen)
-    o = (torch.empty((P, 128, 65), device=dev), torch.empty((P, 128, 65), device=dev))
-    t_nchw = timed(lambda: ops.third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rub3, out=o))
-    r0, r1 = o[0].clone(), o[1].clone()
-    ff0, ff1 = cl(ff0), cl(ff1)
-    t_nhwc = timed(lambda: ops.third_descriptors(ff0, ff1, mk0, mk1, b_ids, kenc, rub3, out=o))
-    same = same and torch.equal(r0, o[0]) and torch.equal(r1, o[1])
-    assert same, "the channels-last gathers differ from the NCHW gathers"
-    kf, kt = cap.rows_cap / float(R), P_step / float(P)
-    return {"sample": "%d fine rows, %d third-level points; ms scaled to %d rows / %d points" % (R, P, cap.rows_cap, P_step),
-            "fine_desc_ms": {"nchw": f_nchw * kf, "channels_last": f_nhwc * kf},
-            "third_desc_ms": {"nchw": t_nchw * kt, "channels_last": t_nhwc * kt}, "outputs_bit_identical": bool(same)}
-
-
-def step_determinism(batch, nets, cap, wl, n=4):
-    """The bench's steps all run on the same resident inputs: n more of them, every stage's output compared bit for bit with
-    the first one's (the fine-level log-plans of the rows in use, the third-level points, the matches).  Before the round-3
-    barrier fix (now wg_barrier() in csrc/common.hpp) the fine level differed in ~10 of 20 224 problems in every step."""
-    kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
-    ref, rep = None, {"steps": n, "fine_log_plan_problems_differing": [], "third_level_points_differing": [],
-                      "matches_differing": [], "match_count_equal": True}
-    for k in range(n):
-        out = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, **kw)
-        M = int(out["M"].item())
-        live = int(out["rows"].chunk_base[-1].item())         # rows in use: padding rows past it are skipped by the launches
-        cur = {"Z2": out["stages"]["Z2"][:live].clone(), "m1f": out["stages"]["m1f"].clone(), "ml": out["matches_l"][:M].clone(),
-               "mr": out["matches_r"][:M].clone(), "M": M, "P": int(out["P"].item())}
-        if ref is None:
-            ref = cur
-            continue
-        rep["fine_log_plan_problems_differing"].append(int((cur["Z2"] != ref["Z2"]).flatten(1).any(1).sum().item()))
-        P = min(cur["P"], ref["P"])
-        rep["third_level_points_differing"].append(int((cur["m1f"][:P] != ref["m1f"][:P]).flatten(1).any(1).sum().item()))
-        same = cur["M"] == ref["M"]
-        rep["match_count_equal"] = rep["match_count_equal"] and same
-        rep["matches_differing"].append(int(((cur["ml"] != ref["ml"]) | (cur["mr"] != ref["mr"])).any(1).sum().item()) if same else -1)
-        del cur
-    rep["identical"] = rep["match_count_equal"] and not any(rep["fine_log_plan_problems_differing"] + rep["third_level_points_differing"]
-                                                              + rep["matches_differing"])
-    return rep
-
-
-def guard_trip_sweep(ops, batch, nets, cap, wl, fracs=(0.01, 0.10)):
-    """pairs/s when a fraction of the fine / third-level problems leaves the linear-domain solver's guard band and is
-    re-solved in the log domain: the rows' backbone maps are scaled by 32 (both sides: scores x 1024, far outside the band),
-    three steps are timed, the maps restored (a power of two: exactly)."""
-    res = []
-    R = cap.rows_cap
-    g = torch.Generator(device=nets.m0.device)
-    g.manual_seed(12345)
-    kw = dict(if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
-    for frac in fracs:
-        pick = torch.nonzero(torch.rand((R,), device=nets.m0.device, generator=g) < frac).flatten()
-        both = torch.cat([pick, pick + R])
-        for t in (nets.m0, nets.m1, nets.m2):
-            t[both] *= 32.0
-        nets.ff0[pick] *= 32.0
-        nets.ff1[pick] *= 32.0
-        torch.cuda.synchronize()
-        ops.sinkhorn_fallbacks(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            batch.forward_pairs(nets.lefts, nets.rights, nets, cap, **kw)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        trips = ops.sinkhorn_fallbacks(reset=True)
-        for t in (nets.m0, nets.m1, nets.m2):
-            t[both] /= 32.0
-        nets.ff0[pick] /= 32.0
-        nets.ff1[pick] /= 32.0
-        res.append({"wild_row_fraction": frac, "pairs_per_s": 3 * cap.pairs / dt, "guard_fallbacks_per_step": trips / 3.0,
-                    "note": "no stream overlap in this leg"})
-    return res
-
-
-# algorithmic HBM bytes per unit of the four data-moving kernels of a step (DESIGN.md, kernel table); the same figures main() prices
-# the headline's kernels with
-THIRD_BYTES_PER_PROBLEM = 2 * 128 * 65 * 4 + 64 * 4 + 2 * 2 * 8 + 2 * 16 * 2 * 4 + 16 * 2 * 4 + 16
-FINE_BYTES_PER_ROW = 2.0 * 264 * 145 * 4 + 145 * 145 * 4
-FD_BYTES_PER_IMAGE = (2 * 64 * 144 * 4 + 128 * 144 + 8 + 264) * 4 + 264 * 145 * 4
-TD_BYTES_PER_POINT = 2 * 128 * 64 * 4 + 128 * 4 + 2 * 128 * 65 * 4 + 2 * 2 * 4 + 8 + 2 * 2 * 8
-
-
-def secondary_workloads(ops, batch, dev, rank, names=("scannet", "yfcc"), steps=5, warm=2, maps="nchw"):
-    """BASELINE.json configs[2] and configs[3] in the SAME run as the headline (round-5 verdict item 4): the same step on the
-    ScanNet shapes (indoor: one fine chunk of up to 300 rows, +ln3, fixed-cell label, merge_old) and on the YFCC shapes (24x32 grid,
-    769x769 coarse problem, 16 pairs a step - the 8-GPU sharding of configs[3] is rank-local work of exactly this kind).  Per
-    workload: pairs/s over `steps` steps, the step's kernels timed inside the steps by HIP events with the dominant one's
-    fraction of the HBM roofline (algorithmic bytes / time / 8 TB/s), and pair 0 of a step checked against the CPU oracle
-    stage by stage (index outputs asserted)."""
-    out = []
-    for name in names:
-        h, w, if_local, outdoor, pairs, label = WORKLOADS[name]
-        wl = {"outdoor": outdoor, "merge_new": outdoor, "bias_k": 2.0 if outdoor else 3.0}
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(synth.SEED + rank)
-        cap = batch.Capacities(pairs, h, w, if_local=if_local)
-        t0 = time.perf_counter()
-        nets = BenchNets(ops, dev, gen, cap, h, w, batch=batch, channels_last=maps == "nhwc")
-        torch.cuda.synchronize()
-        setup_s = time.perf_counter() - t0
-        run_steps(batch, nets, cap, wl, None, warm, None)
-        ev = {}
-        nets.ev = ev
-        watch = StepWatch(cap)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        o = run_steps(batch, nets, cap, wl, ev, steps, None, watch)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        nets.ev = None
-        P_step, rows_step = int(o["P"].item()), int(o["rows"].chunk_base[-1].item())
-        ms = lambda tag: float(np.mean([a.elapsed_time(b_) for a, b_ in ev[tag]]))       # noqa: E731
-        kernels = [("third_fused3_kernel (third-level cost + OT + Compute_result, %d problems)" % P_step, ms("third"), THIRD_BYTES_PER_PROBLEM * P_step),
-                   ("cost_mfma_kernel + sinkhorn_blk145w2_kernel (fine-level launch pair, %d rows)" % rows_step, ms("fine"), FINE_BYTES_PER_ROW * rows_step),
-                   ("fine_desc_kernel (a15, %d stacked crops)" % (2 * rows_step), ms("fine_desc"), FD_BYTES_PER_IMAGE * 2.0 * rows_step),
-                   ("third_desc_kernel (a16, %d points)" % P_step, ms("third_desc"), TD_BYTES_PER_POINT * float(P_step))]
-        roofs = sorted(({"kernel": k, "avg_launch_ms": t, "algorithmic_bytes_per_launch": float(by), "bound": "hbm",
-                         "achieved": by / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                        for k, t, by in kernels), key=lambda r: -r["avg_launch_ms"])
-        rep = {"workload": label, "value": pairs * steps / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warm,
-               "pairs_per_step": pairs, "rows_in_use_per_step": rows_step, "third_problems_per_step": P_step, "setup_s": setup_s,
-               "roofline": roofs[0], "other_kernels": roofs[1:], "map_layout": maps}
-        try:
-            o2 = batch.forward_pairs(nets.lefts, nets.rights, nets, cap, if_outdoor=wl["outdoor"], merge_new=wl["merge_new"], iters=ITERS)
-            cb = cpu_baseline(ops, batch, dev, nets, cap, wl, o2, torch_leg=False)
-            rep["parity_sample"] = cb["parity_sample"]
-            rep["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
-            del o2
-        except AssertionError as e:
-            rep["parity_sample"] = {"FAILED": repr(e)[:400]}
-        out.append(rep)
-        del nets, o, ev, watch
-        torch.cuda.empty_cache()
-    return out
 
 
 def free_port():
