@@ -37,6 +37,16 @@ __device__ __forceinline__ void stm(T* p, T v) {
     else *p = v;
 }
 
+// two neighbouring floats as ONE 8-byte access at 4-byte alignment (gfx950 global memory takes unaligned dwordx2; the pooled taps of
+// map 0 start at an odd element): half the load instructions of the pooling loops
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int POL>
+__device__ __forceinline__ f2u ldm2(const float* p) {
+    const f2u* q = reinterpret_cast<const f2u*>(p);
+    if (POL & 1) return __builtin_nontemporal_load(q);
+    return *q;
+}
+
 // ---- fine level ------------------------------------------------------------------------------
 // One 256-thread workgroup per stacked image n = s * B + b (left crops first).  Wave w takes channels w, w + 4, ...;
 // a lane owns the points l, l + 64, l + 128 (< 145) of every channel it visits, so the source offsets of the three maps are
@@ -82,7 +92,8 @@ fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const float* q = m + off0[g];
-            v[g] = (((ldm<POL>(q) + ldm<POL>(q + 1)) + ldm<POL>(q + 48)) + ldm<POL>(q + 49)) / 4.0f;
+            const f2u a = ldm2<POL>(q), c2 = ldm2<POL>(q + 48);
+            v[g] = (((a.x + a.y) + c2.x) + c2.y) / 4.0f;
         }
         put(ch, v[0], v[1], v[2]);
     }
@@ -93,7 +104,8 @@ fine_desc_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const float* q = m + off1[g];
-            v[g] = (((ldm<POL>(q) + ldm<POL>(q + 1)) + ldm<POL>(q + 24)) + ldm<POL>(q + 25)) / 4.0f;
+            const f2u a = ldm2<POL>(q), c2 = ldm2<POL>(q + 24);
+            v[g] = (((a.x + a.y) + c2.x) + c2.y) / 4.0f;
         }
         put(ch, v[0], v[1], v[2]);
     }
