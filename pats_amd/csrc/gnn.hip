@@ -868,9 +868,18 @@ static int propagation_impl(const float* x, const float* source, int64_t batch, 
 // operands) a device flag is raised and the chain of per-layer compositions queued behind - every kernel gated on that flag -
 // recomputes the whole stack from the inputs.
 namespace pats {
-__global__ void __launch_bounds__(256) gated_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4, const int* __restrict__ gate) {
+// (rows past the device-side count are NOT copied: the redo chain recomputes them from padding inputs, and the fast path's contract -
+//  gnn_fine_out_kernel leaves zeros there - must survive a redo; round-5 advice)
+__global__ void __launch_bounds__(256) gated_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4, const int* __restrict__ gate,
+                                                         int64_t row4, const int64_t* __restrict__ live, int64_t live_off) {
     if (*gate == 0) return;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    int64_t lim = n4;
+    if (live) {
+        int64_t rows = *live - live_off;
+        rows = rows < 0 ? 0 : rows;
+        lim = rows * row4 < n4 ? rows * row4 : n4;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < lim; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 }
 extern "C" size_t pats_attentional_gnn_packed_workspace_bytes(int64_t batch, int C, int heads, int n) {
@@ -938,8 +947,9 @@ extern "C" int pats_attentional_gnn_packed_f32(const float* desc0, const float* 
     }
     const int64_t n4 = (int64_t)(elems / 4);
     const unsigned cg = (unsigned)std::min<int64_t>((n4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(gated_copy_kernel, dim3(cg), dim3(256), 0, st, (const float4*)c0, (float4*)out0, n4, (const int*)flag);
-    hipLaunchKernelGGL(gated_copy_kernel, dim3(cg), dim3(256), 0, st, (const float4*)c1, (float4*)out1, n4, (const int*)flag);
+    const int64_t row4 = (int64_t)C * n / 4;            // (C n is a multiple of four at the one supported shape: 264 x 145)
+    hipLaunchKernelGGL(gated_copy_kernel, dim3(cg), dim3(256), 0, st, (const float4*)c0, (float4*)out0, n4, (const int*)flag, row4, live, live_off);
+    hipLaunchKernelGGL(gated_copy_kernel, dim3(cg), dim3(256), 0, st, (const float4*)c1, (float4*)out1, n4, (const int*)flag, row4, live, live_off);
     return check_launch("gated_copy_kernel");
 }
 
