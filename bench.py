@@ -343,7 +343,7 @@ def main():
         if pj is not None and int(pj.get("rows_cap", -1)) == cap.rows_cap and args.workload == "megadepth":
             pmc = pj["kernels"]
             pmc_src = "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over bench.py --steps 3), factors " \
-                      "from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the third-level " \
+                      "from the cost build's known read count in the same run (x%.2f reads; writes x%.2f: tools/write_patterns.hip; the third-level " \
                       "kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
                       % (pmc_name, pj["calibration"]["fetch_factor"], pj["calibration"]["write_factor"])
             # how old is the figure?  kernel sources whose content differs from what the PMC run measured
@@ -584,7 +584,7 @@ def main():
                 if pj_live is not None and int(pj_live.get("rows_cap", -1)) == cap.rows_cap:
                     import re
                     src = "live: bench.py ran itself under rocprofv3 at the end of this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes " \
-                          "over bench.py --steps 3), factors from the cost build's known byte count in the same run (x%.2f reads, x%.2f writes; the " \
+                          "over bench.py --steps 3), factors from the cost build's known read count in the same run (x%.2f reads; writes x%.2f: tools/write_patterns.hip; the " \
                           "third-level kernel's 8-byte lane loads x1.38 as calibrated in round 2)" \
                           % (pj_live["calibration"]["fetch_factor"], pj_live["calibration"]["write_factor"])
                     for r in roofs:

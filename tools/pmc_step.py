@@ -56,6 +56,11 @@ def summarise(fetch_dir, write_dir, bench_line_path):
     out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python bench.py --steps 3 --warmup 1 "
                       "--no-secondary --no-cpu-baseline (one run per counter, no trace domains)",
            "unit": "bytes per launch (mean over the launches of the run)"}
+    # WRITE_SIZE needs no factor: tools/write_patterns.hip (profiles/r06_write_patterns.txt) writes 1.68 GB once with 16- / 8- / 4-byte
+    # linear stores and the counter x 1024 equals the byte count to 5 digits.  Until round 5 the cost build's "known" write count
+    # calibrated it to x0.93 - but that kernel's MFMA-layout stores really move 1.05-1.08x their algorithmic bytes (partial lines:
+    # pattern d of the same probe), so every other kernel's writes were under-reported by 7 %.
+    WRITE_FACTOR = 1.0
     f_fac = w_fac = None
     if cal_key:
         k = cal_key[0]
@@ -63,10 +68,14 @@ def summarise(fetch_dir, write_dir, bench_line_path):
         f_fac, w_fac = known_r / (fetch[k] * KB), known_w / (write[k] * KB)
         out["calibration"] = {"kernel": k[0], "grid": k[1], "known_read_bytes": known_r, "FETCH_SIZE_raw_bytes": fetch[k] * KB,
                               "fetch_factor": f_fac, "known_write_bytes": known_w, "WRITE_SIZE_raw_bytes": write[k] * KB,
-                              "write_factor": w_fac,
+                              "write_factor": WRITE_FACTOR, "cost_build_write_overhead": 1.0 / w_fac,
+                              "how_writes": "WRITE_SIZE x 1024 = bytes for linear 16- / 8- / 4-byte stores (tools/write_patterns.hip, "
+                                            "profiles/r06_write_patterns.txt): no factor; cost_build_write_overhead = what this kernel's "
+                                            "MFMA-layout stores move over their algorithmic bytes",
                               "how": "pats::cost_mfma_kernel at the fine level reads 2 x 264 x 145 x 4 B and writes 145 x 145 x 4 B per "
-                                     "problem, nothing else; FETCH_SIZE / WRITE_SIZE of that launch in the same run give the factors "
-                                     "applied to every kernel below (the guide: x2 for 16-byte lane loads, other widths uncalibrated)"}
+                                     "problem, nothing else; FETCH_SIZE of that launch in the same run gives the read factor "
+                                     "applied to every kernel below (the guide: x2 for 16-byte lane loads; backed independently by "
+                                     "tools/fetch_patterns.hip)"}
     # FETCH_SIZE counts fabric requests at 64 B each whatever their size, so the factor depends on the access width of
     # the kernel: the cost build's loads come out at x2.00 (the guide's figure for 16-byte lane loads); the third-level
     # kernel streams its descriptors with 8-byte lane loads, calibrated in round 2 on cost65_kernel (the same loads,
@@ -81,8 +90,8 @@ def summarise(fetch_dir, write_dir, bench_line_path):
         r, w = fetch[k] * KB, write.get(k, 0.0) * KB
         ff = next((v for n, v in override.items() if k[0].startswith(n)), f_fac or 1.0)
         ks["%s grid=%d" % k] = {"launches_seen": nf[k], "FETCH_SIZE_raw_bytes": r, "WRITE_SIZE_raw_bytes": w, "fetch_factor": ff,
-                                "hbm_read_bytes": r * ff, "hbm_write_bytes": w * (w_fac or 1.0),
-                                "hbm_bytes": r * ff + w * (w_fac or 1.0)}
+                                "hbm_read_bytes": r * ff, "hbm_write_bytes": w * WRITE_FACTOR,
+                                "hbm_bytes": r * ff + w * WRITE_FACTOR}
     out["kernels"] = ks
     out["csrc_sha16"] = csrc_sha16()
     return out
