@@ -203,6 +203,7 @@ def latency_leg(ops, batch, pipeline, bench, dev, workload="megadepth", n=20, wi
         if tag + "a_reference_control_flow" in res:
             res[tag + "a_reference_control_flow"]["matches"] = info.get("M")
         for nm, more in (("a_device_counts", dict(device_counts=True)), ("a_device_counts_2_streams", dict(device_counts=True, streams=2)),
+                         ("a_device_counts_3_streams", dict(device_counts=True, streams=3)),
                          ("a_device_counts_4_streams", dict(device_counts=True, streams=4))):
             leg(tag + nm, lambda: run_a(False, **more), n)
             if tag + nm in res:
