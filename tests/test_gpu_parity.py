@@ -873,6 +873,38 @@ def test_pipeline_chain(name, batched):
     np.testing.assert_allclose(mr, g["matches_r"], atol=6e-3, rtol=1e-6)
 
 
+def test_chunk_walk_edge_cases_no_match_and_many_chunks(ops):
+    """pipeline.forward_chunks_device at its edges: (1) a pair whose coarse level matches nothing returns empty tensors without
+    touching the chunk loop (pats.py:27-31), in every mode; (2) a 24 x 32 grid (YFCC shapes: up to 12 chunks) gives the same
+    matches in the same order on one, two and three streams as the host-read walk."""
+    from pats_amd import pipeline
+
+    class Nets(_CudaNets):
+        def __init__(self, nets, kill):
+            super().__init__(nets)
+            self.kill = kill
+
+        def coarse(self, left, right):
+            d0, d1, ns, alpha = super().coarse(left, right)
+            if self.kill:                                     # unrelated descriptors: every patch goes to the dustbin
+                d1 = torch.randn(d1.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+                d0 = torch.randn(d0.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+            return d0, d1, ns, alpha
+    nets = synth.SynthNets(seed=synth.SEED + 77, h=5, w=6)
+    left, right = [cu(x) for x in nets.images()]
+    for mode in (dict(), dict(batch_chunks=True), dict(device_counts=True), dict(device_counts=True, streams=3)):
+        out = pipeline.forward_path(left, right, Nets(nets, True), **mode)
+        assert out["matches_l"].shape == (0, 2) and out["matches_r"].shape == (0, 2) and out["chunks"] == [], mode
+    big = synth.SynthNets(seed=synth.SEED + 78, h=24, w=32)
+    left, right = [cu(x) for x in big.images()]
+    want = pipeline.forward_path(left, right, _CudaNets(big))
+    assert len(want["chunks"]) >= 8 and want["matches_l"].shape[0] > 5000
+    for streams in (1, 2, 3):
+        got = pipeline.forward_path(left, right, _CudaNets(big), device_counts=True, streams=streams)
+        assert [tuple(c) for c in got["chunks"]] == [tuple(c) for c in want["chunks"]]
+        assert torch.equal(got["matches_l"], want["matches_l"]) and torch.equal(got["matches_r"], want["matches_r"]), streams
+
+
 # ---- index parity at bench-like volumes: thousands of problems, HIP vs the oracle -----------------------
 def test_index_parity_4096_third_level_problems(ops, oracle):
     """4 096 third-level problems (the bench solves 25 920 per pair): label, if_matching1, source points
